@@ -1,0 +1,450 @@
+/* TEST INFRASTRUCTURE ONLY — CPU oracle for the node-embedding hot path.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and only as the checker.  The product (graphvite_amd/) never links, imports
+ * or falls back to anything in oracle/.
+ *
+ * Every function restates, in plain sequential C, one piece of the reference
+ * (DeepGraphLearning/graphvite v0.2.2, paths relative to /root/reference):
+ *
+ *   gvo_sigmoid            include/util/math.h:30-33
+ *   gvo_lr                 include/core/optimizer.h:77-79,132-134
+ *   gvo_train              include/instance/gpu/graph.cuh:54-94 (SGD), :122-166 (1 moment),
+ *                          :196-241 (Adam) + instance/model/graph.h:40-85 + core/optimizer.h:161-210
+ *   gvo_predict            include/instance/gpu/graph.cuh:265-278
+ *   gvo_alias_build        include/base/alias_table.cuh:84-128
+ *   gvo_alias_sample       include/base/alias_table.cuh:148-152
+ *   gvo_alias_sample_gpu   include/base/alias_table.cuh:174-182 (gpu::Sample narrows to Float first)
+ *   gvo_partition          include/core/solver.h:873-887 (+ locations :399-410)
+ *   gvo_schedule           include/core/solver.h:519-575 (non-tied branch; GraphSolver never ties)
+ *   gvo_negative_weights   include/core/solver.h:1264-1278
+ *   gvo_sample_edges       include/core/solver.h:1012-1055
+ *   gvo_sample_walks       include/instance/graph.cuh:376-450 (biased = 0), :298-373 (biased = 1)
+ *   gvo_edge_edge_weights  include/instance/graph.cuh:656-677
+ *
+ * Two functions restate THIS repo's documented ABI rather than the reference (the
+ * reference takes its uniforms from cuRAND XORWOW, which is unavailable here and pinned
+ * by nothing — SURVEY.md §8c): gvo_philox4x32 (Philox4x32-10, Salmon et al. SC'11,
+ * checked against the Random123 known-answer vectors in tests) and gvo_negative_draw /
+ * gvo_host_uniforms (include/gvk.h "RNG contract").
+ *
+ * Parity status: the reference ships no tests or golden vectors, so this
+ * oracle is pinned against the reference's own arithmetic compiled for the host
+ * (oracle/ref_harness.cpp -> oracle/_ref/libgvref.so) and against fixtures generated
+ * from that build (tests/golden/, script committed).  Pieces the reference cannot
+ * compile here (alias table, partition, schedule, samplers: they need CUDA/glog headers)
+ * are "parity unpinned" restatements, checked by known-answer and property tests.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define GVO_EPS 1e-15f /* util/common.h:28 */
+
+enum { GVO_SGD = 0, GVO_MOMENTUM, GVO_ADAGRAD, GVO_RMSPROP, GVO_ADAM }; /* optimizer.h:27-34 */
+
+float gvo_sigmoid(float x) { return x > 0 ? 1 / (1 + expf(-x)) : expf(x) / (expf(x) + 1); }
+
+float gvo_lr(float init_lr, int linear, int batch_id, int num_batch) {
+    float s = 1;
+    if (linear) {
+        s = 1 - (float)batch_id / num_batch;
+        if (s < 1e-4f) s = 1e-4f;
+    }
+    return init_lr * s;
+}
+
+/* hp = {momentum | alpha | beta1, beta2, epsilon} (optimizer.h:110-122) */
+static float gvo_update(int type, float lr, float wd, const float *hp, float param, float grad, float weight,
+                        float *m1, float *m2) {
+    float reg = weight * (grad + wd * param);
+    switch (type) {
+        case GVO_SGD: return lr * weight * (grad + wd * param); /* optimizer.h:161-164 */
+        case GVO_MOMENTUM:                                      /* :170-175 */
+            *m1 = hp[0] * *m1 + (1 - hp[0]) * reg;
+            return lr * *m1;
+        case GVO_ADAGRAD: /* :181-186 */
+            *m1 += reg * reg;
+            return lr * reg / (sqrtf(*m1) + hp[2]);
+        case GVO_RMSPROP: /* :192-197 */
+            *m1 = hp[0] * *m1 + (1 - hp[0]) * reg * reg;
+            return lr * reg / sqrtf(*m1 + hp[2]);
+        default: /* Adam :203-210 */
+            *m1 = hp[0] * *m1 + (1 - hp[0]) * reg;
+            *m2 = hp[1] * *m2 + (1 - hp[1]) * reg * reg;
+            return lr * *m1 / (sqrtf(*m2) + hp[2]);
+    }
+}
+
+/* One batch, samples processed strictly in order. batch = {tail, head} u32 records. */
+int gvo_train(int dim, int type, float *vertex, float *context, float *vm1, float *cm1, float *vm2, float *cm2,
+              const uint32_t *batch, const uint32_t *negatives, float *loss, int batch_size, int k, float lr,
+              float wd, float negative_weight, const float *hp) {
+    float *buf = (float *)malloc(sizeof(float) * dim);
+    float dummy1 = 0, dummy2 = 0;
+    if (!buf) return -1;
+    for (int s = 0; s < batch_size; s++) {
+        size_t head = batch[2 * s + 1];
+        float *v = vertex + head * dim;
+        memcpy(buf, v, sizeof(float) * dim);
+        float sample_loss = 0;
+        for (int j = 0; j <= k; j++) {
+            size_t tail = j < k ? negatives[(size_t)s * k + j] : batch[2 * s];
+            int label = j == k;
+            float *c = context + tail * dim;
+            float logit = 0;
+            for (int i = 0; i < dim; i++) logit += buf[i] * c[i];
+            float prob = gvo_sigmoid(logit);
+            float gradient, weight;
+            if (label) {
+                gradient = prob - 1;
+                weight = 1;
+                sample_loss += weight * -logf(prob + GVO_EPS);
+            } else {
+                gradient = prob;
+                weight = negative_weight;
+                sample_loss += weight * -logf(1 - prob + GVO_EPS);
+            }
+            for (int i = 0; i < dim; i++) {
+                float vi = buf[i], ci = c[i];
+                float *pvm1 = vm1 ? vm1 + head * dim + i : &dummy1, *pcm1 = cm1 ? cm1 + tail * dim + i : &dummy1;
+                float *pvm2 = vm2 ? vm2 + head * dim + i : &dummy2, *pcm2 = cm2 ? cm2 + tail * dim + i : &dummy2;
+                buf[i] -= gvo_update(type, lr, wd, hp, vi, gradient * ci, weight, pvm1, pvm2);
+                c[i] -= gvo_update(type, lr, wd, hp, ci, gradient * vi, weight, pcm1, pcm2);
+            }
+        }
+        loss[s] = sample_loss / (1 + k * negative_weight);
+        memcpy(v, buf, sizeof(float) * dim);
+    }
+    free(buf);
+    return 0;
+}
+
+void gvo_predict(int dim, const float *vertex, const float *context, const uint32_t *batch, float *logits,
+                 int batch_size) {
+    for (int s = 0; s < batch_size; s++) {
+        const float *v = vertex + (size_t)batch[2 * s + 1] * dim, *c = context + (size_t)batch[2 * s] * dim;
+        float logit = 0;
+        for (int i = 0; i < dim; i++) logit += v[i] * c[i];
+        logits[s] = logit;
+    }
+}
+
+/* ---- alias table ------------------------------------------------------------------ */
+
+/* index_bytes = 4 (uint32 alias) or 8 (uint64 alias; the edge table uses size_t, solver.h:123) */
+int gvo_alias_build(const float *w, size_t n, float *prob, void *alias, int index_bytes) {
+    if (n == 0) return -1;
+    uint32_t *a32 = (uint32_t *)alias;
+    uint64_t *a64 = (uint64_t *)alias;
+    size_t *large = (size_t *)malloc(sizeof(size_t) * n), *little = (size_t *)malloc(sizeof(size_t) * n);
+    if (!large || !little) return -1;
+    /* FIFO queues (std::queue in the reference). An index enters `little` at most once (at the start,
+     * or when it drops out of `large`), so a linear array of n slots suffices; an index can re-enter
+     * `large` many times but never more than n are live, so `large` is a ring of capacity n. */
+    size_t lh = 0, lt = 0, gh = 0, gt = 0, gcount = 0;
+    double norm = 0;
+    memcpy(prob, w, sizeof(float) * n);
+    for (size_t i = 0; i < n; i++) norm += prob[i];
+    norm = norm / n;
+    for (size_t i = 0; i < n; i++) prob[i] /= norm; /* float /= double -> rounded to float */
+    for (size_t i = 0; i < n; i++) {
+        if (prob[i] < 1)
+            little[lt++] = i;
+        else {
+            large[gt] = i;
+            gt = (gt + 1) % n;
+            gcount++;
+        }
+    }
+#define SET_ALIAS(i, j)            \
+    do {                           \
+        if (index_bytes == 8)      \
+            a64[i] = (uint64_t)(j); \
+        else                       \
+            a32[i] = (uint32_t)(j); \
+    } while (0)
+    while (lh < lt && gcount > 0) {
+        size_t i = little[lh++], j = large[gh];
+        gh = (gh + 1) % n;
+        gcount--;
+        SET_ALIAS(i, j);
+        prob[j] = prob[i] + prob[j] - 1;
+        if (prob[j] < 1)
+            little[lt++] = j;
+        else {
+            large[gt] = j;
+            gt = (gt + 1) % n;
+            gcount++;
+        }
+    }
+    while (lh < lt) {
+        size_t i = little[lh++];
+        SET_ALIAS(i, i);
+    }
+    while (gcount > 0) {
+        size_t i = large[gh];
+        gh = (gh + 1) % n;
+        gcount--;
+        SET_ALIAS(i, i);
+    }
+#undef SET_ALIAS
+    free(large);
+    free(little);
+    return 0;
+}
+
+uint64_t gvo_alias_sample(const float *prob, const void *alias, int index_bytes, uint64_t count, double rand1,
+                          double rand2) {
+    uint64_t index = (uint64_t)(rand1 * count);
+    float p = (float)rand2;
+    if (p < prob[index]) return index;
+    return index_bytes == 8 ? ((const uint64_t *)alias)[index] : ((const uint32_t *)alias)[index];
+}
+
+/* gpu::Sample: both uniforms are narrowed to Float before sample() widens them again */
+uint32_t gvo_alias_sample_gpu(const float *prob, const uint32_t *alias, uint32_t count, double rand1, double rand2) {
+    float r1 = (float)rand1, r2 = (float)rand2;
+    return (uint32_t)gvo_alias_sample(prob, alias, 4, count, (double)r1, (double)r2);
+}
+
+/* ---- Philox4x32-10 and the repo's RNG contract (include/gvk.h) -------------------- */
+
+void gvo_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+#define GVO_TAG_NEG 0x6e656721u  /* "neg!" */
+#define GVO_TAG_HOST 0x686f7374u /* "host" */
+
+/* Negative j of sample `sample_id` in batch `batch_id`:
+ *   words = philox(ctr = {sample_id, batch_id, j / 2, TAG_NEG}, key = seed);  (w_a, w_b) = words[2*(j&1) ..]
+ *   index = (w_a * count) >> 32;  u = (w_b >> 8) * 2^-24;  result = u < prob[index] ? index : alias[index] */
+uint32_t gvo_negative_draw(const float *prob, const uint32_t *alias, uint32_t count, uint64_t seed,
+                           uint32_t batch_id, uint32_t sample_id, uint32_t j) {
+    uint32_t ctr[4] = {sample_id, batch_id, j / 2, GVO_TAG_NEG}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t w[4];
+    gvo_philox4x32(ctr, key, w);
+    uint32_t wa = w[2 * (j & 1)], wb = w[2 * (j & 1) + 1];
+    uint32_t index = (uint32_t)(((uint64_t)wa * count) >> 32);
+    float u = (float)(wb >> 8) * (1.0f / 16777216.0f);
+    return u < prob[index] ? index : alias[index];
+}
+
+/* Host uniform stream `stream`: doubles number 2i and 2i+1 come from
+ *   philox(ctr = {i_lo, i_hi, stream, TAG_HOST}, key = seed); d = (((u64)w_hi << 32 | w_lo) >> 11) * 2^-53 */
+void gvo_host_uniforms(uint64_t seed, uint32_t stream, uint64_t first, size_t n, double *out) {
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    for (size_t t = 0; t < n; t++) {
+        uint64_t idx = first + t, i = idx / 2;
+        uint32_t ctr[4] = {(uint32_t)i, (uint32_t)(i >> 32), stream, GVO_TAG_HOST}, w[4];
+        gvo_philox4x32(ctr, key, w);
+        uint64_t bits = idx & 1 ? ((uint64_t)w[3] << 32 | w[2]) : ((uint64_t)w[1] << 32 | w[0]);
+        out[t] = (double)(bits >> 11) * (1.0 / 9007199254740992.0);
+    }
+}
+
+/* ---- partition / schedule ---------------------------------------------------------- */
+
+typedef struct {
+    float w;
+    uint32_t id;
+} gvo_wid;
+
+static int gvo_cmp_desc(const void *a, const void *b) {
+    const gvo_wid *x = (const gvo_wid *)a, *y = (const gvo_wid *)b;
+    if (x->w > y->w) return -1;
+    if (x->w < y->w) return 1;
+    /* std::sort leaves ties unspecified in the reference; this repo fixes them by ascending id */
+    return x->id < y->id ? -1 : x->id > y->id;
+}
+
+/* part[v], local[v] for every vertex; part_sizes[P]. */
+int gvo_partition(const float *weights, uint32_t n, int P, int32_t *part, uint32_t *local, uint32_t *part_sizes) {
+    gvo_wid *order = (gvo_wid *)malloc(sizeof(gvo_wid) * (n ? n : 1));
+    if (!order) return -1;
+    for (uint32_t i = 0; i < n; i++) {
+        order[i].w = weights[i];
+        order[i].id = i;
+    }
+    qsort(order, n, sizeof(gvo_wid), gvo_cmp_desc);
+    for (int p = 0; p < P; p++) part_sizes[p] = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        int pid = (int)(i % (uint32_t)(P * 2));
+        if (pid > P * 2 - 1 - pid) pid = P * 2 - 1 - pid;
+        part[order[i].id] = pid;
+        local[order[i].id] = part_sizes[pid]++;
+    }
+    free(order);
+    return 0;
+}
+
+/* out[step][worker] = {head_part, tail_part}; returns number of steps. out needs (P/W)^2*W*W*2 ints. */
+int gvo_schedule(int P, int W, int32_t *out) {
+    int steps = 0;
+    if (P == 1) {
+        out[0] = 0;
+        out[1] = 0;
+        return 1;
+    }
+    for (int x = 0; x < P; x += W)
+        for (int y = 0; y < P; y += W)
+            for (int offset = 0; offset < W; offset++) {
+                for (int i = 0; i < W; i++) {
+                    out[(steps * W + i) * 2] = x + (i + offset) % W;
+                    out[(steps * W + i) * 2 + 1] = y + i;
+                }
+                steps++;
+            }
+    return steps;
+}
+
+void gvo_negative_weights(const float *vertex_weights, const uint32_t *global_ids, uint32_t n, float exponent,
+                          float *out) {
+    for (uint32_t i = 0; i < n; i++) out[i] = powf(vertex_weights[global_ids[i]], exponent);
+}
+
+/* ---- samplers ---------------------------------------------------------------------- */
+
+typedef struct {
+    const double *r;
+    size_t n, pos;
+} gvo_rand;
+
+static double gvo_next(gvo_rand *g) { return g->pos < g->n ? g->r[g->pos++] : (g->pos++, 0.0); }
+
+/* Base edge sampler.  edges_uv = flattened directed edges {u, v}; pools[hp * P + tp] -> {tail, head}
+ * records of capacity pool_size.  Fills [start, end) of every block pool.  Returns randoms consumed,
+ * or (size_t)-1 if the supplied stream was too short. */
+size_t gvo_sample_edges(const uint32_t *edges_uv, const float *edge_prob, const uint64_t *edge_alias,
+                        uint64_t num_edge_entries, const int32_t *part, const uint32_t *local, int P,
+                        uint32_t **pools, int start, int end, int sample_batch_size, const double *rnd,
+                        size_t n_rnd) {
+    gvo_rand g = {rnd, n_rnd, 0};
+    if (start >= end) return 0;
+    int *offsets = (int *)malloc(sizeof(int) * P * P);
+    uint32_t *hu = (uint32_t *)malloc(sizeof(uint32_t) * sample_batch_size * 2);
+    for (int i = 0; i < P * P; i++) offsets[i] = start;
+    int num_complete = 0;
+    while (num_complete < P * P) {
+        for (int i = 0; i < sample_batch_size; i++) {
+            double r1 = gvo_next(&g), r2 = gvo_next(&g);
+            uint64_t e = gvo_alias_sample(edge_prob, edge_alias, 8, num_edge_entries, r1, r2);
+            hu[2 * i] = edges_uv[2 * e];
+            hu[2 * i + 1] = edges_uv[2 * e + 1];
+        }
+        for (int i = 0; i < sample_batch_size; i++) {
+            uint32_t h = hu[2 * i], t = hu[2 * i + 1];
+            int hp = part[h], tp = part[t];
+            int *offset = &offsets[hp * P + tp];
+            if (*offset < end) {
+                uint32_t *pool = pools[hp * P + tp];
+                pool[2 * (size_t)*offset] = local[t];
+                pool[2 * (size_t)*offset + 1] = local[h];
+                if (++*offset == end) num_complete++;
+            }
+        }
+    }
+    free(offsets);
+    free(hu);
+    return g.pos > g.n ? (size_t)-1 : g.pos;
+}
+
+/* Random-walk sampler (biased = 0: per-vertex tables indexed by CSR slot; biased = 1: node2vec
+ * per-edge tables, table of directed edge e starts at ee_offsets[e] and has deg(v) entries). */
+size_t gvo_sample_walks(int biased, const uint32_t *edges_uv, const float *edge_prob, const uint64_t *edge_alias,
+                        uint64_t num_edge_entries, const uint64_t *flat_offsets /* [N+1] */, const float *nb_prob,
+                        const uint32_t *nb_alias, const uint64_t *ee_offsets, const int32_t *part,
+                        const uint32_t *local, int P, uint32_t **pools, int pool_size, int start, int end,
+                        int walk_length, int walk_batch, int augmentation_step, int shuffle_base,
+                        const double *rnd, size_t n_rnd) {
+    gvo_rand g = {rnd, n_rnd, 0};
+    if (start >= end) return 0;
+    if (pool_size % shuffle_base) return (size_t)-2;
+    int L = walk_length;
+    int *offsets = (int *)malloc(sizeof(int) * P * P);
+    uint32_t *chains = (uint32_t *)malloc(sizeof(uint32_t) * walk_batch * (L + 1));
+    int *lengths = (int *)malloc(sizeof(int) * walk_batch);
+    for (int i = 0; i < P * P; i++) offsets[i] = start;
+    int num_complete = 0;
+    while (num_complete < P * P) {
+        for (int i = 0; i < walk_batch; i++) {
+            uint32_t *chain = chains + (size_t)i * (L + 1);
+            double r1 = gvo_next(&g), r2 = gvo_next(&g);
+            uint64_t edge_id = gvo_alias_sample(edge_prob, edge_alias, 8, num_edge_entries, r1, r2);
+            uint32_t current = edges_uv[2 * edge_id];
+            chain[0] = current;
+            current = edges_uv[2 * edge_id + 1];
+            chain[1] = current;
+            lengths[i] = L;
+            for (int j = 2; j <= L; j++) {
+                uint64_t deg = flat_offsets[current + 1] - flat_offsets[current];
+                if (deg > 0) {
+                    r1 = gvo_next(&g);
+                    r2 = gvo_next(&g);
+                    uint64_t base = biased ? ee_offsets[edge_id] : flat_offsets[current];
+                    uint32_t nb = (uint32_t)gvo_alias_sample(nb_prob + base, nb_alias + base, 4, deg, r1, r2);
+                    edge_id = flat_offsets[current] + nb;
+                    current = edges_uv[2 * edge_id + 1];
+                    chain[j] = current;
+                } else {
+                    lengths[i] = j - 1;
+                    break;
+                }
+            }
+        }
+        for (int i = 0; i < walk_batch; i++) {
+            const uint32_t *chain = chains + (size_t)i * (L + 1);
+            for (int j = 0; j < lengths[i]; j++)
+                for (int k = 1; k <= augmentation_step; k++) {
+                    if (j + k > lengths[i]) break;
+                    uint32_t h = chain[j], t = chain[j + k];
+                    int hp = part[h], tp = part[t];
+                    int *offset = &offsets[hp * P + tp];
+                    if (*offset < end) {
+                        uint32_t *pool = pools[hp * P + tp];
+                        int shuffled = *offset % shuffle_base * (pool_size / shuffle_base) + *offset / shuffle_base;
+                        pool[2 * (size_t)shuffled] = local[t];
+                        pool[2 * (size_t)shuffled + 1] = local[h];
+                        if (++*offset == end) num_complete++;
+                    }
+                }
+        }
+    }
+    free(offsets);
+    free(chains);
+    free(lengths);
+    return g.pos > g.n ? (size_t)-1 : g.pos;
+}
+
+static int gvo_has_neighbor(const uint32_t *edges_uv, const uint64_t *flat_offsets, uint32_t x, uint32_t u) {
+    for (uint64_t e = flat_offsets[x]; e < flat_offsets[x + 1]; e++)
+        if (edges_uv[2 * e + 1] == u) return 1;
+    return 0;
+}
+
+/* node2vec transition weights of directed edge e = (u -> v): one entry per out-edge (v -> x, w). */
+void gvo_edge_edge_weights(const uint32_t *edges_uv, const float *edge_weights, const uint64_t *flat_offsets,
+                           uint64_t e, float p, float q, float *out) {
+    uint32_t u = edges_uv[2 * e], v = edges_uv[2 * e + 1];
+    for (uint64_t f = flat_offsets[v]; f < flat_offsets[v + 1]; f++) {
+        uint32_t x = edges_uv[2 * f + 1];
+        float w = edge_weights[f];
+        if (x == u)
+            *out++ = w / p;
+        else if (!gvo_has_neighbor(edges_uv, flat_offsets, x, u))
+            *out++ = w / q;
+        else
+            *out++ = w;
+    }
+}

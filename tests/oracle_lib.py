@@ -1,0 +1,260 @@
+"""ctypes bindings of the CPU oracle (oracle/liboracle.so) and of the host build of the
+reference's own arithmetic (oracle/_ref/libgvref.so).  TEST INFRASTRUCTURE ONLY: imported by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg — never by graphvite_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+SGD, MOMENTUM, ADAGRAD, RMSPROP, ADAM = range(5)
+
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+def build_oracle():
+    """Compile oracle/ (and oracle/_ref when /root/reference is present)."""
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def _opt(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle(object):
+    def __init__(self):
+        path = os.path.join(ORACLE_DIR, "liboracle.so")
+        if not os.path.exists(path):
+            build_oracle()
+        self.lib = lib = C.CDLL(path)
+        lib.gvo_sigmoid.restype = C.c_float
+        lib.gvo_sigmoid.argtypes = [C.c_float]
+        lib.gvo_lr.restype = C.c_float
+        lib.gvo_lr.argtypes = [C.c_float, C.c_int, C.c_int, C.c_int]
+        lib.gvo_train.restype = C.c_int
+        lib.gvo_train.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 6 + [_u32p, _u32p, _f32p, C.c_int, C.c_int,
+                                                                         C.c_float, C.c_float, C.c_float, _f32p]
+        lib.gvo_predict.restype = None
+        lib.gvo_predict.argtypes = [C.c_int, _f32p, _f32p, _u32p, _f32p, C.c_int]
+        lib.gvo_alias_build.restype = C.c_int
+        lib.gvo_alias_build.argtypes = [_f32p, C.c_size_t, _f32p, C.c_void_p, C.c_int]
+        lib.gvo_alias_sample.restype = C.c_uint64
+        lib.gvo_alias_sample.argtypes = [_f32p, C.c_void_p, C.c_int, C.c_uint64, C.c_double, C.c_double]
+        lib.gvo_alias_sample_gpu.restype = C.c_uint32
+        lib.gvo_alias_sample_gpu.argtypes = [_f32p, _u32p, C.c_uint32, C.c_double, C.c_double]
+        lib.gvo_philox4x32.restype = None
+        lib.gvo_philox4x32.argtypes = [_u32p, _u32p, _u32p]
+        lib.gvo_negative_draw.restype = C.c_uint32
+        lib.gvo_negative_draw.argtypes = [_f32p, _u32p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        lib.gvo_host_uniforms.restype = None
+        lib.gvo_host_uniforms.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_size_t, _f64p]
+        lib.gvo_partition.restype = C.c_int
+        lib.gvo_partition.argtypes = [_f32p, C.c_uint32, C.c_int, _i32p, _u32p, _u32p]
+        lib.gvo_schedule.restype = C.c_int
+        lib.gvo_schedule.argtypes = [C.c_int, C.c_int, _i32p]
+        lib.gvo_negative_weights.restype = None
+        lib.gvo_negative_weights.argtypes = [_f32p, _u32p, C.c_uint32, C.c_float, _f32p]
+        lib.gvo_sample_edges.restype = C.c_size_t
+        lib.gvo_sample_edges.argtypes = [_u32p, _f32p, _u64p, C.c_uint64, _i32p, _u32p, C.c_int,
+                                         C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, _f64p, C.c_size_t]
+        lib.gvo_sample_walks.restype = C.c_size_t
+        lib.gvo_sample_walks.argtypes = [C.c_int, _u32p, _f32p, _u64p, C.c_uint64, _u64p, _f32p, _u32p,
+                                         C.c_void_p, _i32p, _u32p, C.c_int, C.POINTER(C.c_void_p), C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f64p, C.c_size_t]
+        lib.gvo_edge_edge_weights.restype = None
+        lib.gvo_edge_edge_weights.argtypes = [_u32p, _f32p, _u64p, C.c_uint64, C.c_float, C.c_float, _f32p]
+
+    # -- arithmetic ---------------------------------------------------------------------
+    def sigmoid(self, x):
+        return self.lib.gvo_sigmoid(x)
+
+    def lr(self, init_lr, linear, batch_id, num_batch):
+        return self.lib.gvo_lr(init_lr, int(linear), batch_id, num_batch)
+
+    def train(self, vertex, context, batch, negatives, lr, wd, negative_weight, optimizer=SGD, moments=None,
+              hp=(0, 0, 0)):
+        """In place on vertex/context (and moments = [vm1, cm1, vm2, cm2]). Returns loss[B]."""
+        B = batch.shape[0]
+        k = negatives.size // B if B else 0
+        loss = np.zeros(B, np.float32)
+        m = list(moments or []) + [None] * 4
+        hp = np.asarray(hp, np.float32)
+        rc = self.lib.gvo_train(vertex.shape[1], optimizer, _opt(vertex), _opt(context), _opt(m[0]), _opt(m[1]),
+                                _opt(m[2]), _opt(m[3]), batch.reshape(-1), negatives.reshape(-1), loss, B, k, lr,
+                                wd, negative_weight, hp)
+        assert rc == 0
+        return loss
+
+    def predict(self, vertex, context, batch):
+        out = np.zeros(batch.shape[0], np.float32)
+        self.lib.gvo_predict(vertex.shape[1], vertex, context, batch.reshape(-1), out, batch.shape[0])
+        return out
+
+    # -- alias ---------------------------------------------------------------------------
+    def alias_build(self, w, index_bytes=4):
+        w = np.ascontiguousarray(w, np.float32)
+        prob = np.zeros(w.size, np.float32)
+        alias = np.zeros(w.size, np.uint64 if index_bytes == 8 else np.uint32)
+        rc = self.lib.gvo_alias_build(w, w.size, prob, alias.ctypes.data_as(C.c_void_p), index_bytes)
+        assert rc == 0
+        return prob, alias
+
+    def alias_sample(self, prob, alias, r1, r2):
+        return self.lib.gvo_alias_sample(prob, alias.ctypes.data_as(C.c_void_p), alias.itemsize, prob.size, r1, r2)
+
+    def alias_sample_gpu(self, prob, alias, r1, r2):
+        return self.lib.gvo_alias_sample_gpu(prob, alias, prob.size, r1, r2)
+
+    # -- rng contract ----------------------------------------------------------------------
+    def philox(self, ctr, key):
+        out = np.zeros(4, np.uint32)
+        self.lib.gvo_philox4x32(np.asarray(ctr, np.uint32), np.asarray(key, np.uint32), out)
+        return out
+
+    def negative_draw(self, prob, alias, seed, batch_id, sample_id, j):
+        return self.lib.gvo_negative_draw(prob, alias, prob.size, seed, batch_id, sample_id, j)
+
+    def negatives(self, prob, alias, seed, batch_id, batch_size, k):
+        out = np.zeros((batch_size, k), np.uint32)
+        for s in range(batch_size):
+            for j in range(k):
+                out[s, j] = self.negative_draw(prob, alias, seed, batch_id, s, j)
+        return out
+
+    def host_uniforms(self, seed, stream, first, n):
+        out = np.zeros(n, np.float64)
+        self.lib.gvo_host_uniforms(seed, stream, first, n, out)
+        return out
+
+    # -- partition / schedule ----------------------------------------------------------------
+    def partition(self, weights, P):
+        weights = np.ascontiguousarray(weights, np.float32)
+        part = np.zeros(weights.size, np.int32)
+        local = np.zeros(weights.size, np.uint32)
+        sizes = np.zeros(P, np.uint32)
+        assert self.lib.gvo_partition(weights, weights.size, P, part, local, sizes) == 0
+        return part, local, sizes
+
+    def schedule(self, P, W):
+        out = np.zeros(max(1, (P // max(W, 1)) ** 2 * W * W) * 2 + 2, np.int32)
+        steps = self.lib.gvo_schedule(P, W, out)
+        nw = 1 if P == 1 else W
+        return out[:steps * nw * 2].reshape(steps, nw, 2)
+
+    def negative_weights(self, vertex_weights, global_ids, exponent):
+        out = np.zeros(global_ids.size, np.float32)
+        self.lib.gvo_negative_weights(np.ascontiguousarray(vertex_weights, np.float32),
+                                      np.ascontiguousarray(global_ids, np.uint32), global_ids.size, exponent, out)
+        return out
+
+    # -- samplers --------------------------------------------------------------------------
+    @staticmethod
+    def _pool_ptrs(pools):
+        arr = (C.c_void_p * len(pools))()
+        for i, p in enumerate(pools):
+            arr[i] = p.ctypes.data
+        return arr
+
+    def sample_edges(self, edges_uv, edge_prob, edge_alias, part, local, P, pools, start, end, sample_batch_size,
+                     rnd):
+        n = self.lib.gvo_sample_edges(edges_uv.reshape(-1), edge_prob, edge_alias, edge_prob.size, part, local, P,
+                                      self._pool_ptrs(pools), start, end, sample_batch_size, rnd, rnd.size)
+        assert n != C.c_size_t(-1).value, "uniform stream too short"
+        return n
+
+    def sample_walks(self, biased, edges_uv, edge_prob, edge_alias, flat_offsets, nb_prob, nb_alias, ee_offsets,
+                     part, local, P, pools, pool_size, start, end, walk_length, walk_batch, augmentation_step,
+                     shuffle_base, rnd):
+        eo = None if ee_offsets is None else ee_offsets.ctypes.data_as(C.c_void_p)
+        n = self.lib.gvo_sample_walks(int(biased), edges_uv.reshape(-1), edge_prob, edge_alias, edge_prob.size,
+                                      flat_offsets, nb_prob, nb_alias, eo, part, local, P,
+                                      self._pool_ptrs(pools), pool_size, start, end, walk_length, walk_batch,
+                                      augmentation_step, shuffle_base, rnd, rnd.size)
+        assert n < C.c_size_t(-2).value, "uniform stream too short / bad shuffle base"
+        return n
+
+    def edge_edge_weights(self, edges_uv, edge_weights, flat_offsets, e, p, q):
+        v = int(edges_uv[e, 1])
+        out = np.zeros(int(flat_offsets[v + 1] - flat_offsets[v]), np.float32)
+        self.lib.gvo_edge_edge_weights(edges_uv.reshape(-1), edge_weights, flat_offsets, e, p, q, out)
+        return out
+
+
+class Reference(object):
+    """Host build of the reference's own model / optimizer headers (oracle/ref_harness.cpp)."""
+
+    def __init__(self, fast=False):
+        name = "libgvref_fast.so" if fast else "libgvref.so"
+        path = os.path.join(ORACLE_DIR, "_ref", name)
+        if not os.path.exists(path):
+            build_oracle()
+        if not os.path.exists(path):
+            raise FileNotFoundError("%s is not built and /root/reference is not present" % path)
+        self.lib = lib = C.CDLL(path)
+        lib.gvref_train.restype = C.c_int
+        lib.gvref_train.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 6 + [_u32p, _u32p, _f32p, C.c_int, C.c_int,
+                                                                           C.c_float, C.c_float, C.c_float, _f32p]
+        lib.gvref_train_mt.restype = C.c_int
+        lib.gvref_train_mt.argtypes = [C.c_int, _f32p, _f32p, _u32p, _u32p, _f32p, C.c_int, C.c_int, C.c_float,
+                                       C.c_float, C.c_float, C.c_int]
+        lib.gvref_predict.restype = C.c_int
+        lib.gvref_predict.argtypes = [C.c_int, _f32p, _f32p, _u32p, _f32p, C.c_int]
+        lib.gvref_sigmoid.restype = C.c_float
+        lib.gvref_sigmoid.argtypes = [C.c_float]
+        lib.gvref_lr.restype = C.c_float
+        lib.gvref_lr.argtypes = [C.c_float, C.c_int, C.c_int, C.c_int]
+
+    @staticmethod
+    def available():
+        return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libgvref.so")) or os.path.exists(
+            "/root/reference/include/instance/model/graph.h")
+
+    def train(self, vertex, context, batch, negatives, lr, wd, negative_weight, optimizer=SGD, moments=None,
+              hp=(0, 0, 0)):
+        B = batch.shape[0]
+        k = negatives.size // B if B else 0
+        loss = np.zeros(B, np.float32)
+        m = list(moments or []) + [None] * 4
+        hp = np.asarray(hp, np.float32)
+        rc = self.lib.gvref_train(vertex.shape[1], optimizer, _opt(vertex), _opt(context), _opt(m[0]), _opt(m[1]),
+                                  _opt(m[2]), _opt(m[3]), batch.reshape(-1), negatives.reshape(-1), loss, B, k,
+                                  lr, wd, negative_weight, hp)
+        assert rc == 0
+        return loss
+
+    def train_mt(self, vertex, context, batch, negatives, lr, wd, negative_weight, num_thread):
+        B = batch.shape[0]
+        loss = np.zeros(B, np.float32)
+        rc = self.lib.gvref_train_mt(vertex.shape[1], vertex, context, batch.reshape(-1), negatives.reshape(-1),
+                                     loss, B, negatives.size // B, lr, wd, negative_weight, num_thread)
+        assert rc == 0
+        return loss
+
+    def predict(self, vertex, context, batch):
+        out = np.zeros(batch.shape[0], np.float32)
+        assert self.lib.gvref_predict(vertex.shape[1], vertex, context, batch.reshape(-1), out, batch.shape[0]) == 0
+        return out
+
+    def sigmoid(self, x):
+        return self.lib.gvref_sigmoid(x)
+
+    def lr(self, init_lr, linear, batch_id, num_batch):
+        return self.lib.gvref_lr(init_lr, int(linear), batch_id, num_batch)
+
+
+def link_prediction_auc(vertex, context, H, T, Y):
+    """Rank AUC exactly as python/graphvite/application/application.py:433-449 (numpy restatement)."""
+    score = np.einsum("ij,ij->i", vertex[H].astype(np.float32), context[T].astype(np.float32))
+    order = np.argsort(-score, kind="stable")
+    y = np.asarray(Y)[order]
+    hit = np.cumsum(y)
+    total = int((y == 0).sum()) * int((y == 1).sum())
+    return float(hit[y == 0].sum()) / total
