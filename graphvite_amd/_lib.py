@@ -1,0 +1,88 @@
+"""Loader of the native library (libgvk.so = HIP kernels + C++ host runtime, C ABI in include/gvk.h, gvs.h).
+
+The product path has no CPU fallback: if the library is missing this module raises, loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgvk.so")
+
+GVK_OK, GVK_EINVAL, GVK_EDIM, GVK_EHIP, GVK_ENOMEM = 0, -1, -2, -3, -4
+SGD, MOMENTUM, ADAGRAD, RMSPROP, ADAM = range(5)
+TUNE_LANES_PER_PAIR = 1
+
+
+class AliasEntry(C.Structure):
+    _fields_ = [("prob", C.c_float), ("alias", C.c_uint32)]
+
+
+class Optimizer(C.Structure):
+    _fields_ = [("type", C.c_int32), ("lr", C.c_float), ("weight_decay", C.c_float), ("hp0", C.c_float),
+                ("hp1", C.c_float), ("epsilon", C.c_float)]
+
+
+class Tables(C.Structure):
+    _fields_ = [("vertex", C.c_void_p), ("context", C.c_void_p), ("vertex_moment1", C.c_void_p),
+                ("context_moment1", C.c_void_p), ("vertex_moment2", C.c_void_p), ("context_moment2", C.c_void_p),
+                ("n_vertex", C.c_uint32), ("n_context", C.c_uint32)]
+
+
+class NegativeSource(C.Structure):
+    _fields_ = [("negatives", C.c_void_p), ("table", C.c_void_p), ("count", C.c_uint32), ("seed", C.c_uint64)]
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library. torch is imported first so that libgvk.so binds to the HIP runtime torch uses
+    (streams and device pointers cross the boundary, so there must be exactly one runtime in the process)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C graphvite_amd/csrc`. graphvite_amd has no CPU fallback for the training path." % LIB_PATH)
+    import torch  # noqa: F401  (loads libamdhip64 first)
+    try:
+        l = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise NativeLibraryError("cannot load %s: %s" % (LIB_PATH, e))
+    vp, i32, u32, u64, f32 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_float
+    P = C.POINTER
+    l.gvk_train.restype = i32
+    l.gvk_train.argtypes = [vp, i32, P(Optimizer), P(Tables), vp, P(NegativeSource), u32, vp, i32, i32, f32]
+    l.gvk_train_episode.restype = i32
+    l.gvk_train_episode.argtypes = [vp, i32, P(Optimizer), i32, P(Tables), vp, P(NegativeSource), u32, u32, i32,
+                                    vp, i32, i32, f32]
+    l.gvk_predict.restype = i32
+    l.gvk_predict.argtypes = [vp, i32, vp, vp, vp, vp, i32]
+    l.gvk_alias_sample.restype = i32
+    l.gvk_alias_sample.argtypes = [vp, vp, u32, vp, vp, i32]
+    l.gvk_negative_draw.restype = i32
+    l.gvk_negative_draw.argtypes = [vp, vp, u32, u64, u32, vp, i32, i32]
+    l.gvk_alias_build.restype = i32
+    l.gvk_alias_build.argtypes = [vp, C.c_size_t, vp, vp, i32, vp]
+    l.gvk_set_tuning.restype = i32
+    l.gvk_set_tuning.argtypes = [i32, i32]
+    l.gvk_last_error.restype = C.c_char_p
+    l.gvk_version.restype = C.c_char_p
+    _lib = l
+    return l
+
+
+def check(rc, what="gvk"):
+    if rc == GVK_OK:
+        return
+    msg = lib().gvk_last_error().decode("utf-8", "replace")
+    if rc in (GVK_EINVAL, GVK_EDIM):
+        raise ValueError("%s failed (%d): %s" % (what, rc, msg))
+    if rc == GVK_ENOMEM:
+        raise MemoryError("%s failed (%d): %s" % (what, rc, msg))
+    raise RuntimeError("%s failed (%d): %s" % (what, rc, msg))

@@ -1,0 +1,6 @@
+// Internal glue shared by the translation units of libgvk.so (not part of the ABI).
+#pragma once
+#include <stdarg.h>
+
+// Records a printf-style message for gvk_last_error() (thread-local) and returns `code`.
+int gvk_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));

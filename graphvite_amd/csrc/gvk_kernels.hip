@@ -1,0 +1,548 @@
+// gvk_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the node-embedding hot path and
+// their C-ABI launchers (include/gvk.h).  Written for MI355X only: no CUDA dual path.
+//
+// Kernel shape.  The path is a skinny gather-dot-scatter at ~1 flop/byte, so the only
+// roofline is HBM and the design goal is "as many independent 512-byte row requests in flight as
+// possible, every request a full-line coalesced burst, nothing read twice":
+//   * a group of G lanes (G = 16 at dim 128) owns one {tail, head} pair; a wavefront carries 64/G
+//     pairs.  Each lane holds dim/G consecutive-by-chunk floats of every row in VGPRs (float4 chunks:
+//     16 B per lane per request, G*16 B contiguous per row request).  Rows never touch LDS — there is
+//     no cross-lane reuse to stage for; the "vertex buffer" of the reference's kernel
+//     (include/instance/gpu/graph.cuh:51,59,93) is simply the lane's registers.
+//   * the negative draw is fused: Philox4x32-10 keyed by (seed; sample, batch, j) + one 8-byte alias
+//     entry load (include/gvk.h "RNG contract"), issued concurrently with the pair load.
+//   * all rows of a pair (vertex, negatives, positive) are requested before the first is used
+//     (one-ahead prefetch of the next target row), so a pair costs two dependent HBM round trips.
+//   * the dot product is reduced with DPP butterflies inside a 16-lane row (quad_perm, row_half_mirror,
+//     row_mirror): 4 VALU adds, no LDS, every lane ends with the same sum (no broadcast step).
+//   * updates are Hogwild exactly like the reference: plain stores, no atomics.
+//
+// Arithmetic follows include/instance/model/graph.h:40-85 and include/core/optimizer.h:161-210 term by
+// term; only the summation order of the dot product differs (lane partials + butterfly).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "gvk.h"
+#include "gvk_internal.h"
+
+namespace {
+
+constexpr float kEpsilon = 1e-15f;  // include/util/common.h:28
+constexpr int kBlock = 256;         // 4 wavefronts; no LDS, no barrier -> block size only sets dispatch granularity
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+int g_lanes_per_pair = 0;  // GVK_TUNE_LANES_PER_PAIR
+
+struct TrainArgs {
+    float *vertex, *context, *vm1, *cm1, *vm2, *cm2;
+    const uint32_t *pairs;
+    const uint32_t *negatives;
+    const gvk_alias_entry *table;
+    float *loss;
+    uint64_t seed;
+    uint32_t count, batch_id;
+    int batch_size, k;
+    float lr, wd, neg_weight, hp0, hp1, eps;
+};
+
+// ---- cross-lane ------------------------------------------------------------------------------
+
+template <int CTRL>
+__device__ __forceinline__ float dpp(float x) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+
+// Sum over the G lanes of a group; every lane of the group returns the same value.
+template <int G>
+__device__ __forceinline__ float group_sum(float x) {
+    if (G >= 2) x += dpp<0xB1>(x);   // quad_perm [1,0,3,2]
+    if (G >= 4) x += dpp<0x4E>(x);   // quad_perm [2,3,0,1]
+    if (G >= 8) x += dpp<0x141>(x);  // row_half_mirror: quad <-> other quad of the 8
+    if (G >= 16) x += dpp<0x140>(x); // row_mirror: 8 <-> other 8 of the 16-lane DPP row
+    if (G >= 32) x += __shfl_xor(x, 16);
+    if (G >= 64) x += __shfl_xor(x, 32);
+    return x;
+}
+
+// ---- Philox4x32-10 ----------------------------------------------------------------------------
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+constexpr uint32_t kTagNegative = 0x6e656721u;
+
+struct Draw {
+    uint32_t index;
+    float u;
+};
+
+__device__ __forceinline__ Draw negative_slot(uint64_t seed, uint32_t batch_id, uint32_t sample, uint32_t j,
+                                              uint32_t count) {
+    uint32_t w[4];
+    philox4x32_10(sample, batch_id, j >> 1, kTagNegative, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    uint32_t wa = (j & 1) ? w[2] : w[0], wb = (j & 1) ? w[3] : w[1];
+    Draw d;
+    d.index = __umulhi(wa, count);
+    d.u = (float)(wb >> 8) * (1.0f / 16777216.0f);
+    return d;
+}
+
+__device__ __forceinline__ uint32_t resolve(const Draw &d, const gvk_alias_entry &e) {
+    return d.u < e.prob ? d.index : e.alias;
+}
+
+// ---- rows in registers ---------------------------------------------------------------------------
+
+template <int DIM, int G>
+struct Layout {
+    static constexpr int V = DIM / G;                       // floats per lane
+    static constexpr int CW = (V % 4 == 0) ? 4 : (V % 2 == 0 ? 2 : 1);  // floats per request
+    static constexpr int NC = V / CW;                       // requests per row per lane
+    static_assert(DIM % G == 0, "dim must split over the lane group");
+};
+
+template <int DIM, int G>
+__device__ __forceinline__ void load_row(const float *table, uint32_t id, int lane, float (&r)[DIM / G]) {
+    typedef Layout<DIM, G> L;
+    const float *row = table + (size_t)id * DIM + lane * L::CW;
+#pragma unroll
+    for (int c = 0; c < L::NC; c++) {
+        const float *p = row + c * G * L::CW;
+        if (L::CW == 4) {
+            f32x4 x = *reinterpret_cast<const f32x4 *>(p);
+            r[c * 4 + 0] = x.x; r[c * 4 + 1] = x.y; r[c * 4 + 2] = x.z; r[c * 4 + 3] = x.w;
+        } else if (L::CW == 2) {
+            f32x2 x = *reinterpret_cast<const f32x2 *>(p);
+            r[c * 2 + 0] = x.x; r[c * 2 + 1] = x.y;
+        } else {
+            r[c] = *p;
+        }
+    }
+}
+
+template <int DIM, int G>
+__device__ __forceinline__ void store_row(float *table, uint32_t id, int lane, const float (&r)[DIM / G]) {
+    typedef Layout<DIM, G> L;
+    float *row = table + (size_t)id * DIM + lane * L::CW;
+#pragma unroll
+    for (int c = 0; c < L::NC; c++) {
+        float *p = row + c * G * L::CW;
+        if (L::CW == 4) {
+            f32x4 x = {r[c * 4 + 0], r[c * 4 + 1], r[c * 4 + 2], r[c * 4 + 3]};
+            *reinterpret_cast<f32x4 *>(p) = x;
+        } else if (L::CW == 2) {
+            f32x2 x = {r[c * 2 + 0], r[c * 2 + 1]};
+            *reinterpret_cast<f32x2 *>(p) = x;
+        } else {
+            *p = r[c];
+        }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void copy_row(float (&dst)[N], const float (&src)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i++) dst[i] = src[i];
+}
+
+// ---- arithmetic (include/util/math.h:30-33, include/core/optimizer.h:161-210) -------------------
+
+__device__ __forceinline__ float sigmoidf(float x) {
+    return x > 0 ? 1 / (1 + expf(-x)) : expf(x) / (expf(x) + 1);
+}
+
+template <int OPT>
+__device__ __forceinline__ float update(const TrainArgs &a, float parameter, float gradient, float weight,
+                                        float &m1, float &m2) {
+    if (OPT == GVK_SGD) return a.lr * weight * (gradient + a.wd * parameter);
+    float regularized = weight * (gradient + a.wd * parameter);
+    if (OPT == GVK_MOMENTUM) {
+        m1 = a.hp0 * m1 + (1 - a.hp0) * regularized;
+        return a.lr * m1;
+    }
+    if (OPT == GVK_ADAGRAD) {
+        m1 += regularized * regularized;
+        return a.lr * regularized / (sqrtf(m1) + a.eps);
+    }
+    if (OPT == GVK_RMSPROP) {
+        m1 = a.hp0 * m1 + (1 - a.hp0) * regularized * regularized;
+        return a.lr * regularized / sqrtf(m1 + a.eps);
+    }
+    m1 = a.hp0 * m1 + (1 - a.hp0) * regularized;
+    m2 = a.hp1 * m2 + (1 - a.hp1) * regularized * regularized;
+    return a.lr * m1 / (sqrtf(m2) + a.eps);
+}
+
+// ---- training kernel -------------------------------------------------------------------------------
+
+template <int DIM, int G, int OPT>
+__global__ void __launch_bounds__(kBlock) train_kernel(const TrainArgs a) {
+    constexpr int V = DIM / G;
+    constexpr int NM = OPT == GVK_SGD ? 0 : (OPT == GVK_ADAM ? 2 : 1);  // moments per row
+    constexpr int M1 = NM >= 1 ? V : 1, M2 = NM >= 2 ? V : 1;
+
+    const int tid = blockIdx.x * kBlock + threadIdx.x;
+    const int s = tid / G, lane = tid % G;
+    if (s >= a.batch_size) return;  // whole groups leave together: G divides 64
+
+    const int k = a.k;
+    const bool draw = a.negatives == nullptr;
+
+    // round trip 1: the pair and the first negative's alias slot (independent of each other)
+    Draw d0 = {0, 0};
+    gvk_alias_entry e0 = {0, 0};
+    uint32_t neg0 = 0;
+    if (k > 0) {
+        if (draw) {
+            d0 = negative_slot(a.seed, a.batch_id, (uint32_t)s, 0, a.count);
+            e0 = a.table[d0.index];
+        } else {
+            neg0 = __builtin_nontemporal_load(a.negatives + (size_t)s * k);
+        }
+    }
+    const u32x2 pr = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(a.pairs) + s);
+    const uint32_t tail = pr.x, head = pr.y;  // records are {tail, head}
+
+    // round trip 2: vertex row (+ moments) and the first target row
+    float v[V], vm1[M1], vm2[M2];
+    load_row<DIM, G>(a.vertex, head, lane, v);
+    if constexpr (NM >= 1) load_row<DIM, G>(a.vm1, head, lane, reinterpret_cast<float(&)[V]>(vm1));
+    if constexpr (NM >= 2) load_row<DIM, G>(a.vm2, head, lane, reinterpret_cast<float(&)[V]>(vm2));
+
+    uint32_t id_cur = k > 0 ? (draw ? resolve(d0, e0) : neg0) : tail;
+    float cur[V], cur1[M1], cur2[M2];
+    load_row<DIM, G>(a.context, id_cur, lane, cur);
+    if constexpr (NM >= 1) load_row<DIM, G>(a.cm1, id_cur, lane, reinterpret_cast<float(&)[V]>(cur1));
+    if constexpr (NM >= 2) load_row<DIM, G>(a.cm2, id_cur, lane, reinterpret_cast<float(&)[V]>(cur2));
+
+    float sample_loss = 0;
+    for (int j = 0; j <= k; j++) {
+        // request the next target row before touching the current one
+        uint32_t id_nxt = 0;
+        float nxt[V], nxt1[M1], nxt2[M2];
+        if (j < k) {
+            if (j + 1 < k) {
+                if (draw) {
+                    Draw d = negative_slot(a.seed, a.batch_id, (uint32_t)s, (uint32_t)(j + 1), a.count);
+                    id_nxt = resolve(d, a.table[d.index]);
+                } else {
+                    id_nxt = __builtin_nontemporal_load(a.negatives + (size_t)s * k + j + 1);
+                }
+            } else {
+                id_nxt = tail;
+            }
+            load_row<DIM, G>(a.context, id_nxt, lane, nxt);
+            if constexpr (NM >= 1) load_row<DIM, G>(a.cm1, id_nxt, lane, reinterpret_cast<float(&)[V]>(nxt1));
+            if constexpr (NM >= 2) load_row<DIM, G>(a.cm2, id_nxt, lane, reinterpret_cast<float(&)[V]>(nxt2));
+        }
+
+        // forward: model/graph.h:40-45
+        float partial = 0;
+#pragma unroll
+        for (int i = 0; i < V; i++) partial += v[i] * cur[i];
+        const float logit = group_sum<G>(partial);
+        const float prob = sigmoidf(logit);
+        // gpu/graph.cuh:77-87
+        float gradient, weight;
+        if (j == k) {
+            gradient = prob - 1;
+            weight = 1;
+            sample_loss += weight * -logf(prob + kEpsilon);
+        } else {
+            gradient = prob;
+            weight = a.neg_weight;
+            sample_loss += weight * -logf(1 - prob + kEpsilon);
+        }
+        // backward: model/graph.h:47-58 — both updates use the pre-update v and c
+#pragma unroll
+        for (int i = 0; i < V; i++) {
+            const float vi = v[i], ci = cur[i];
+            v[i] -= update<OPT>(a, vi, gradient * ci, weight, vm1[NM >= 1 ? i : 0], vm2[NM >= 2 ? i : 0]);
+            cur[i] -= update<OPT>(a, ci, gradient * vi, weight, cur1[NM >= 1 ? i : 0], cur2[NM >= 2 ? i : 0]);
+        }
+        store_row<DIM, G>(a.context, id_cur, lane, cur);
+        if constexpr (NM >= 1) store_row<DIM, G>(a.cm1, id_cur, lane, reinterpret_cast<float(&)[V]>(cur1));
+        if constexpr (NM >= 2) store_row<DIM, G>(a.cm2, id_cur, lane, reinterpret_cast<float(&)[V]>(cur2));
+
+        if (j < k) {
+            // The next row was requested before this one was updated. If it is the same row (a negative
+            // equal to the next negative / to the positive tail), carry the updated registers forward so
+            // the pair sees its own update, as the reference's sequential warp does.
+            const bool same = id_nxt == id_cur;
+#pragma unroll
+            for (int i = 0; i < V; i++) cur[i] = same ? cur[i] : nxt[i];
+            if constexpr (NM >= 1) {
+#pragma unroll
+                for (int i = 0; i < V; i++) cur1[i] = same ? cur1[i] : nxt1[i];
+            }
+            if constexpr (NM >= 2) {
+#pragma unroll
+                for (int i = 0; i < V; i++) cur2[i] = same ? cur2[i] : nxt2[i];
+            }
+            id_cur = id_nxt;
+        }
+    }
+
+    if (lane == 0) __builtin_nontemporal_store(sample_loss / (1 + k * a.neg_weight), a.loss + s);
+    store_row<DIM, G>(a.vertex, head, lane, v);
+    if constexpr (NM >= 1) store_row<DIM, G>(a.vm1, head, lane, reinterpret_cast<float(&)[V]>(vm1));
+    if constexpr (NM >= 2) store_row<DIM, G>(a.vm2, head, lane, reinterpret_cast<float(&)[V]>(vm2));
+}
+
+// ---- predict / alias kernels ------------------------------------------------------------------------------
+
+template <int DIM, int G>
+__global__ void __launch_bounds__(kBlock) predict_kernel(const float *vertex, const float *context,
+                                                         const uint32_t *pairs, float *logits, int batch_size) {
+    constexpr int V = DIM / G;
+    const int tid = blockIdx.x * kBlock + threadIdx.x;
+    const int s = tid / G, lane = tid % G;
+    if (s >= batch_size) return;
+    const u32x2 pr = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pairs) + s);
+    float v[V], c[V];
+    load_row<DIM, G>(vertex, pr.y, lane, v);
+    load_row<DIM, G>(context, pr.x, lane, c);
+    float partial = 0;
+#pragma unroll
+    for (int i = 0; i < V; i++) partial += v[i] * c[i];
+    const float logit = group_sum<G>(partial);
+    if (lane == 0) logits[s] = logit;
+}
+
+__global__ void __launch_bounds__(kBlock) alias_sample_kernel(const gvk_alias_entry *table, uint32_t count,
+                                                              const double *rand, uint32_t *result, int n) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    // gpu::Sample narrows both uniforms to Float, then sample() takes them as double
+    const float r1 = (float)rand[2 * (size_t)i], r2 = (float)rand[2 * (size_t)i + 1];
+    uint32_t index = (uint32_t)((double)r1 * count);
+    if (index >= count) index = count - 1;  // cuRAND's (0, 1] can yield index == count in the reference (latent OOB)
+    const gvk_alias_entry e = table[index];
+    result[i] = r2 < e.prob ? index : e.alias;
+}
+
+__global__ void __launch_bounds__(kBlock) negative_draw_kernel(const gvk_alias_entry *table, uint32_t count,
+                                                               uint64_t seed, uint32_t batch_id, uint32_t *out,
+                                                               int batch_size, int k) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= batch_size * k) return;
+    const uint32_t s = i / k, j = i % k;
+    const Draw d = negative_slot(seed, batch_id, s, j, count);
+    out[i] = resolve(d, table[d.index]);
+}
+
+// ---- dispatch ----------------------------------------------------------------------------------------------
+
+int fail(int code, const char *what) { return gvk_fail(code, "%s", what); }
+
+int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return gvk_fail(GVK_EHIP, "%s: %s", what, hipGetErrorString(e));
+    return GVK_OK;
+}
+
+int default_lanes(int dim) {
+    switch (dim) {
+        case 32: return 8;
+        case 64: return 16;
+        case 96: return 8;
+        case 128: return 16;
+        case 256: return 16;
+        case 512: return 32;
+    }
+    return 0;
+}
+
+bool lanes_ok(int dim, int g) {
+    switch (dim) {
+        case 32: return g == 8 || g == 16;
+        case 64: return g == 8 || g == 16;
+        case 96: return g == 8 || g == 16;
+        case 128: return g == 8 || g == 16 || g == 32 || g == 64;
+        case 256: return g == 16 || g == 32 || g == 64;
+        case 512: return g == 32 || g == 64;
+    }
+    return false;
+}
+
+typedef void (*TrainKernel)(const TrainArgs);
+
+// non-default lane groups exist for A/B measurement of the SGD kernel only
+template <int DIM, int G>
+TrainKernel pick_sgd(int opt) {
+    return opt == GVK_SGD ? train_kernel<DIM, G, GVK_SGD> : nullptr;
+}
+
+template <int DIM, int G>
+TrainKernel pick_any(int opt) {
+    switch (opt) {
+        case GVK_SGD: return train_kernel<DIM, G, GVK_SGD>;
+        case GVK_MOMENTUM: return train_kernel<DIM, G, GVK_MOMENTUM>;
+        case GVK_ADAGRAD: return train_kernel<DIM, G, GVK_ADAGRAD>;
+        case GVK_RMSPROP: return train_kernel<DIM, G, GVK_RMSPROP>;
+        case GVK_ADAM: return train_kernel<DIM, G, GVK_ADAM>;
+    }
+    return nullptr;
+}
+
+TrainKernel pick_train(int dim, int g, int opt) {
+    const bool def = g == default_lanes(dim);
+#define GVK_CASE(D, GG)                                                      \
+    if (dim == D && g == GG) return def ? pick_any<D, GG>(opt) : pick_sgd<D, GG>(opt);
+    GVK_CASE(32, 8) GVK_CASE(32, 16)
+    GVK_CASE(64, 8) GVK_CASE(64, 16)
+    GVK_CASE(96, 8) GVK_CASE(96, 16)
+    GVK_CASE(128, 8) GVK_CASE(128, 16) GVK_CASE(128, 32) GVK_CASE(128, 64)
+    GVK_CASE(256, 16) GVK_CASE(256, 32) GVK_CASE(256, 64)
+    GVK_CASE(512, 32) GVK_CASE(512, 64)
+#undef GVK_CASE
+    return nullptr;
+}
+
+int validate_train(int dim, const gvk_optimizer *o, const gvk_tables *t, const uint32_t *pairs,
+                   const gvk_negative_source *neg, float *loss, int batch_size, int k) {
+    if (!default_lanes(dim)) return fail(GVK_EDIM, "gvk_train: dim must be one of 32, 64, 96, 128, 256, 512");
+    if (!o || !t || !neg) return fail(GVK_EINVAL, "gvk_train: null optimizer / tables / negative source");
+    if (batch_size < 0 || k < 0) return fail(GVK_EINVAL, "gvk_train: negative batch_size or num_negative");
+    if (batch_size == 0) return GVK_OK;
+    if (!t->vertex || !t->context || !pairs || !loss) return fail(GVK_EINVAL, "gvk_train: null table / pairs / loss");
+    if (o->type < GVK_SGD || o->type > GVK_ADAM) return fail(GVK_EINVAL, "gvk_train: unknown optimizer type");
+    if (o->type != GVK_SGD && (!t->vertex_moment1 || !t->context_moment1))
+        return fail(GVK_EINVAL, "gvk_train: optimizer needs first-moment tables");
+    if (o->type == GVK_ADAM && (!t->vertex_moment2 || !t->context_moment2))
+        return fail(GVK_EINVAL, "gvk_train: Adam needs second-moment tables");
+    if (k > 0 && !neg->negatives && (!neg->table || neg->count == 0))
+        return fail(GVK_EINVAL, "gvk_train: num_negative > 0 but neither negatives nor an alias table given");
+    if ((int64_t)batch_size * 64 > INT32_MAX) return fail(GVK_EINVAL, "gvk_train: batch_size too large");
+    return 1;
+}
+
+int launch_train(hipStream_t stream, int dim, const gvk_optimizer *o, float lr, const gvk_tables *t,
+                 const uint32_t *pairs, const gvk_negative_source *neg, uint32_t batch_id, float *loss,
+                 int batch_size, int k, float negative_weight) {
+    int g = g_lanes_per_pair && lanes_ok(dim, g_lanes_per_pair) && o->type == GVK_SGD ? g_lanes_per_pair
+                                                                                      : default_lanes(dim);
+    TrainKernel kernel = pick_train(dim, g, o->type);
+    if (!kernel) return fail(GVK_EINVAL, "gvk_train: no kernel for this (dim, lanes, optimizer)");
+    TrainArgs a;
+    a.vertex = t->vertex; a.context = t->context;
+    a.vm1 = t->vertex_moment1; a.cm1 = t->context_moment1;
+    a.vm2 = t->vertex_moment2; a.cm2 = t->context_moment2;
+    a.pairs = pairs; a.negatives = neg->negatives; a.table = neg->table; a.loss = loss;
+    a.seed = neg->seed; a.count = neg->count; a.batch_id = batch_id;
+    a.batch_size = batch_size; a.k = k;
+    a.lr = lr; a.wd = o->weight_decay; a.neg_weight = negative_weight;
+    a.hp0 = o->hp0; a.hp1 = o->hp1; a.eps = o->epsilon;
+    const unsigned grid = (unsigned)(((int64_t)batch_size * g + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, a);
+    return check_launch("gvk_train");
+}
+
+}  // namespace
+
+extern "C" {
+
+int gvk_train(void *stream, int dim, const gvk_optimizer *optimizer, const gvk_tables *tables,
+              const uint32_t *pairs, const gvk_negative_source *negative, uint32_t batch_id, float *loss,
+              int batch_size, int num_negative, float negative_weight) {
+    int rc = validate_train(dim, optimizer, tables, pairs, negative, loss, batch_size, num_negative);
+    if (rc <= 0) return rc;
+    return launch_train((hipStream_t)stream, dim, optimizer, optimizer->lr, tables, pairs, negative, batch_id, loss,
+                        batch_size, num_negative, negative_weight);
+}
+
+int gvk_train_episode(void *stream, int dim, const gvk_optimizer *optimizer, int linear_schedule,
+                      const gvk_tables *tables, const uint32_t *pairs, const gvk_negative_source *negative,
+                      uint32_t first_batch_id, uint32_t total_batches, int num_batches, float *loss,
+                      int batch_size, int num_negative, float negative_weight) {
+    if (num_batches < 0) return fail(GVK_EINVAL, "gvk_train_episode: negative num_batches");
+    int rc = validate_train(dim, optimizer, tables, pairs, negative, loss, batch_size, num_negative);
+    if (rc <= 0) return rc;
+    if (negative->negatives)
+        return fail(GVK_EINVAL, "gvk_train_episode draws negatives on device; explicit negatives are per batch");
+    for (int i = 0; i < num_batches; i++) {
+        const uint32_t id = first_batch_id + (uint32_t)i;
+        float scale = 1;
+        if (linear_schedule) {  // optimizer.h:77-79
+            scale = 1 - float(int(id)) / int(total_batches);
+            if (scale < 1e-4f) scale = 1e-4f;
+        }
+        rc = launch_train((hipStream_t)stream, dim, optimizer, optimizer->lr * scale, tables,
+                          pairs + (size_t)i * batch_size * 2, negative, id, loss, batch_size, num_negative,
+                          negative_weight);
+        if (rc != GVK_OK) return rc;
+    }
+    return GVK_OK;
+}
+
+int gvk_predict(void *stream, int dim, const float *vertex, const float *context, const uint32_t *pairs,
+                float *logits, int batch_size) {
+    if (!default_lanes(dim)) return fail(GVK_EDIM, "gvk_predict: dim must be one of 32, 64, 96, 128, 256, 512");
+    if (batch_size < 0) return fail(GVK_EINVAL, "gvk_predict: negative batch_size");
+    if (batch_size == 0) return GVK_OK;
+    if (!vertex || !context || !pairs || !logits) return fail(GVK_EINVAL, "gvk_predict: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+#define GVK_PREDICT(D, GG)                                                                                    \
+    case D:                                                                                                   \
+        hipLaunchKernelGGL((predict_kernel<D, GG>), dim3((unsigned)(((int64_t)batch_size * GG + kBlock - 1) / kBlock)), \
+                           dim3(kBlock), 0, st, vertex, context, pairs, logits, batch_size);                 \
+        break;
+    switch (dim) {
+        GVK_PREDICT(32, 8) GVK_PREDICT(64, 16) GVK_PREDICT(96, 8) GVK_PREDICT(128, 16) GVK_PREDICT(256, 16)
+        GVK_PREDICT(512, 32)
+    }
+#undef GVK_PREDICT
+    return check_launch("gvk_predict");
+}
+
+int gvk_alias_sample(void *stream, const gvk_alias_entry *table, uint32_t count, const double *rand,
+                     uint32_t *result, int n) {
+    if (n < 0) return fail(GVK_EINVAL, "gvk_alias_sample: negative n");
+    if (n == 0) return GVK_OK;
+    if (!table || !count || !rand || !result) return fail(GVK_EINVAL, "gvk_alias_sample: null pointer / empty table");
+    hipLaunchKernelGGL(alias_sample_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream,
+                       table, count, rand, result, n);
+    return check_launch("gvk_alias_sample");
+}
+
+int gvk_negative_draw(void *stream, const gvk_alias_entry *table, uint32_t count, uint64_t seed,
+                      uint32_t batch_id, uint32_t *negatives, int batch_size, int num_negative) {
+    if (batch_size < 0 || num_negative < 0) return fail(GVK_EINVAL, "gvk_negative_draw: negative size");
+    const int64_t n = (int64_t)batch_size * num_negative;
+    if (n == 0) return GVK_OK;
+    if (n > INT32_MAX) return fail(GVK_EINVAL, "gvk_negative_draw: too many draws for one call");
+    if (!table || !count || !negatives) return fail(GVK_EINVAL, "gvk_negative_draw: null pointer / empty table");
+    hipLaunchKernelGGL(negative_draw_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, table, count, seed, batch_id, negatives, batch_size, num_negative);
+    return check_launch("gvk_negative_draw");
+}
+
+int gvk_set_tuning(int key, int value) {
+    if (key == GVK_TUNE_LANES_PER_PAIR) {
+        if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64)
+            return fail(GVK_EINVAL, "gvk_set_tuning: lanes per pair must be 0, 8, 16, 32 or 64");
+        g_lanes_per_pair = value;
+        return GVK_OK;
+    }
+    return fail(GVK_EINVAL, "gvk_set_tuning: unknown key");
+}
+
+}  // extern "C"

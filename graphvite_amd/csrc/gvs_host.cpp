@@ -1,0 +1,819 @@
+// gvs_host.cpp — host runtime behind include/gvs.h: graph store, partition / schedule, and the multi-threaded
+// CPU samplers (edge, random walk, node2vec) that fill the episode sample pools the HIP kernels consume.
+//
+// Design notes (what differs from the reference's host code, and why):
+//   * the graph is kept as an insertion-ordered directed edge list while loading and turned into CSR by one
+//     stable counting sort — the same neighbour order as the reference's vector<vector<>> adjacency lists
+//     (include/instance/graph.cuh:124-153, include/core/graph.h:87-101) without 1M small heap blocks;
+//   * (partition, local id) of a vertex is one packed 8-byte word, and an edge-table slot is one 16-byte
+//     {prob, alias} record, so a positive sample costs 4 random DRAM lines instead of 7;
+//   * uniforms come from a counter-based Philox stream per sampler thread (include/gvk.h "RNG contract")
+//     instead of 40 MB cuRAND buffers copied back from the GPU (include/core/solver.h:943-967,1015-1016);
+//   * per-vertex / per-edge alias tables live in two flat CSR-aligned arrays, not in one AliasTable object
+//     (two heap blocks) per vertex or per edge (include/instance/graph.cuh:645-677).
+// The order in which uniforms are consumed and pool slots are written follows the reference loop for loop.
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <new>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "gvk.h"
+#include "gvk_internal.h"
+#include "gvs.h"
+
+// ---- graph ---------------------------------------------------------------------------------------------
+
+struct gvs_graph {
+    uint32_t num_vertex = 0;
+    uint64_t num_edge = 0;
+    bool as_undirected = true, normalization = false;
+    bool label_mode = false;
+    std::unordered_map<std::string, uint32_t> name2id;
+    std::vector<std::string> id2name;
+    std::unordered_map<uint32_t, uint32_t> label2id;
+    std::vector<uint32_t> labels;
+    // insertion-ordered directed edges (only while loading)
+    std::vector<uint32_t> src, dst;
+    std::vector<float> w;
+    // flattened
+    std::vector<float> vertex_weights;
+    std::vector<uint32_t> edges_uv;
+    std::vector<float> edge_weights;
+    std::vector<uint64_t> flat_offsets;
+
+    void clear() {
+        num_vertex = 0;
+        num_edge = 0;
+        label_mode = false;
+        decltype(name2id)().swap(name2id);
+        decltype(id2name)().swap(id2name);
+        decltype(label2id)().swap(label2id);
+        decltype(labels)().swap(labels);
+        decltype(src)().swap(src);
+        decltype(dst)().swap(dst);
+        decltype(w)().swap(w);
+        decltype(vertex_weights)().swap(vertex_weights);
+        decltype(edges_uv)().swap(edges_uv);
+        decltype(edge_weights)().swap(edge_weights);
+        decltype(flat_offsets)().swap(flat_offsets);
+    }
+
+    uint32_t id_of_name(const char *name) {
+        auto it = name2id.find(name);
+        if (it != name2id.end()) return it->second;
+        uint32_t id = num_vertex++;
+        name2id.emplace(name, id);
+        id2name.emplace_back(name);
+        vertex_weights.push_back(0);
+        return id;
+    }
+
+    uint32_t id_of_label(uint32_t label) {
+        auto it = label2id.find(label);
+        if (it != label2id.end()) return it->second;
+        uint32_t id = num_vertex++;
+        label2id.emplace(label, id);
+        labels.push_back(label);
+        vertex_weights.push_back(0);
+        return id;
+    }
+
+    // Graph::add_edge, graph.cuh:124-153 (ids already resolved, u before v)
+    void add_edge(uint32_t u, uint32_t v, float weight) {
+        src.push_back(u);
+        dst.push_back(v);
+        w.push_back(weight);
+        vertex_weights[u] += weight;
+        if (as_undirected && u != v) {
+            src.push_back(v);
+            dst.push_back(u);
+            w.push_back(weight);
+            vertex_weights[v] += weight;
+        }
+        num_edge++;
+    }
+
+    // GraphMixin::flatten (core/graph.h:87-101) + Graph::normalize (graph.cuh:103-121)
+    void finalize() {
+        const size_t D = src.size();
+        flat_offsets.assign((size_t)num_vertex + 1, 0);
+        for (size_t e = 0; e < D; e++) flat_offsets[src[e] + 1]++;
+        for (uint32_t u = 0; u < num_vertex; u++) flat_offsets[u + 1] += flat_offsets[u];
+        edges_uv.resize(2 * D);
+        edge_weights.resize(D);
+        std::vector<uint64_t> cursor(flat_offsets.begin(), flat_offsets.end() - 1);
+        for (size_t e = 0; e < D; e++) {
+            const uint64_t slot = cursor[src[e]]++;
+            edges_uv[2 * slot] = src[e];
+            edges_uv[2 * slot + 1] = dst[e];
+            edge_weights[slot] = w[e];
+        }
+        decltype(src)().swap(src);
+        decltype(dst)().swap(dst);
+        decltype(w)().swap(w);
+        if (normalization) {
+            std::vector<float> context_weights(num_vertex, 0.f);
+            for (size_t e = 0; e < D; e++) context_weights[edges_uv[2 * e + 1]] += edge_weights[e];
+            for (uint32_t u = 0; u < num_vertex; u++) {
+                float weight = 0;
+                for (uint64_t e = flat_offsets[u]; e < flat_offsets[u + 1]; e++) {
+                    edge_weights[e] /= sqrtf(vertex_weights[u] * context_weights[edges_uv[2 * e + 1]]);
+                    weight += edge_weights[e];
+                }
+                vertex_weights[u] = weight;
+            }
+        }
+    }
+};
+
+namespace {
+
+template <class F>
+int guarded(const char *what, F &&f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return gvk_fail(GVK_ENOMEM, "%s: out of host memory", what);
+    } catch (const std::exception &e) {
+        return gvk_fail(GVK_EINVAL, "%s: %s", what, e.what());
+    }
+}
+
+// strtok-compatible tokenizer over a mutable line
+char *next_token(char **cursor, const char *delimiters) {
+    char *p = *cursor;
+    p += strspn(p, delimiters);
+    if (!*p) {
+        *cursor = p;
+        return nullptr;
+    }
+    char *end = p + strcspn(p, delimiters);
+    if (*end) *end++ = 0;
+    *cursor = end;
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+gvs_graph *gvs_graph_create(void) { return new (std::nothrow) gvs_graph(); }
+
+void gvs_graph_destroy(gvs_graph *g) { delete g; }
+
+int gvs_graph_load_file(gvs_graph *g, const char *file_name, int as_undirected, int normalization,
+                        const char *delimiters, const char *comment) {
+    if (!g || !file_name) return gvk_fail(GVK_EINVAL, "gvs_graph_load_file: null argument");
+    if (!delimiters) delimiters = " \t\r\n";
+    if (!comment) comment = "#";
+    return guarded("gvs_graph_load_file", [&]() {
+        FILE *fin = fopen(file_name, "r");
+        if (!fin) return gvk_fail(GVK_EINVAL, "File `%s` doesn't exist", file_name);
+        g->clear();
+        g->as_undirected = as_undirected != 0;
+        g->normalization = normalization != 0;
+        char *line = nullptr;
+        size_t cap = 0;
+        int rc = GVK_OK;
+        for (size_t i = 1; getline(&line, &cap, fin) >= 0; i++) {
+            if (*comment) {
+                char *c = strstr(line, comment);
+                if (c) *c = 0;
+            }
+            char *cursor = line;
+            char *u_name = next_token(&cursor, delimiters);
+            if (!u_name) continue;
+            char *v_name = next_token(&cursor, delimiters);
+            char *w_str = next_token(&cursor, delimiters);
+            char *more = next_token(&cursor, delimiters);
+            if (!v_name || more) {
+                rc = gvk_fail(GVK_EINVAL, "Invalid format at line %zu of `%s`", i, file_name);
+                break;
+            }
+            const float weight = w_str ? (float)atof(w_str) : 1.f;
+            const uint32_t u = g->id_of_name(u_name);
+            const uint32_t v = g->id_of_name(v_name);
+            g->add_edge(u, v, weight);
+        }
+        free(line);
+        fclose(fin);
+        if (rc != GVK_OK) {
+            g->clear();
+            return rc;
+        }
+        g->finalize();
+        return GVK_OK;
+    });
+}
+
+int gvs_graph_load_names(gvs_graph *g, const char *const *u_names, const char *const *v_names, const float *weights,
+                         size_t n, int as_undirected, int normalization) {
+    if (!g || (n && (!u_names || !v_names))) return gvk_fail(GVK_EINVAL, "gvs_graph_load_names: null argument");
+    return guarded("gvs_graph_load_names", [&]() {
+        g->clear();
+        g->as_undirected = as_undirected != 0;
+        g->normalization = normalization != 0;
+        for (size_t i = 0; i < n; i++) {
+            if (!u_names[i] || !v_names[i]) {
+                g->clear();
+                return gvk_fail(GVK_EINVAL, "gvs_graph_load_names: null name at edge %zu", i);
+            }
+            const uint32_t u = g->id_of_name(u_names[i]);
+            const uint32_t v = g->id_of_name(v_names[i]);
+            g->add_edge(u, v, weights ? weights[i] : 1.f);
+        }
+        g->finalize();
+        return GVK_OK;
+    });
+}
+
+int gvs_graph_load_labels(gvs_graph *g, const uint32_t *u_labels, const uint32_t *v_labels, const float *weights,
+                          size_t n, int as_undirected, int normalization) {
+    if (!g || (n && (!u_labels || !v_labels))) return gvk_fail(GVK_EINVAL, "gvs_graph_load_labels: null argument");
+    return guarded("gvs_graph_load_labels", [&]() {
+        g->clear();
+        g->label_mode = true;
+        g->as_undirected = as_undirected != 0;
+        g->normalization = normalization != 0;
+        g->src.reserve(as_undirected ? 2 * n : n);
+        g->dst.reserve(as_undirected ? 2 * n : n);
+        g->w.reserve(as_undirected ? 2 * n : n);
+        for (size_t i = 0; i < n; i++) {
+            const uint32_t u = g->id_of_label(u_labels[i]);
+            const uint32_t v = g->id_of_label(v_labels[i]);
+            g->add_edge(u, v, weights ? weights[i] : 1.f);
+        }
+        g->finalize();
+        return GVK_OK;
+    });
+}
+
+int gvs_graph_save(const gvs_graph *g, const char *file_name, int weighted, int anonymous) {
+    if (!g || !file_name) return gvk_fail(GVK_EINVAL, "gvs_graph_save: null argument");
+    FILE *fout = fopen(file_name, "w");
+    if (!fout) return gvk_fail(GVK_EINVAL, "gvs_graph_save: cannot open `%s`", file_name);
+    const size_t D = g->edge_weights.size();
+    for (size_t e = 0; e < D; e++) {
+        const uint32_t i = g->edges_uv[2 * e], j = g->edges_uv[2 * e + 1];
+        if (anonymous)
+            fprintf(fout, "%llu\t%llu", (unsigned long long)i, (unsigned long long)j);
+        else if (g->label_mode)
+            fprintf(fout, "%u\t%u", g->labels[i], g->labels[j]);
+        else
+            fprintf(fout, "%s\t%s", g->id2name[i].c_str(), g->id2name[j].c_str());
+        if (weighted) fprintf(fout, "\t%f", g->edge_weights[e]);
+        fputc('\n', fout);
+    }
+    fclose(fout);
+    return GVK_OK;
+}
+
+uint32_t gvs_graph_num_vertex(const gvs_graph *g) { return g ? g->num_vertex : 0; }
+uint64_t gvs_graph_num_edge(const gvs_graph *g) { return g ? g->num_edge : 0; }
+uint64_t gvs_graph_num_directed_edge(const gvs_graph *g) { return g ? g->edge_weights.size() : 0; }
+int gvs_graph_as_undirected(const gvs_graph *g) { return g && g->as_undirected; }
+int gvs_graph_normalization(const gvs_graph *g) { return g && g->normalization; }
+
+int64_t gvs_graph_name2id(const gvs_graph *g, const char *name) {
+    if (!g || !name) return -1;
+    if (g->label_mode) {
+        char *end = nullptr;
+        unsigned long long label = strtoull(name, &end, 10);
+        if (end == name || *end || label > UINT32_MAX) return -1;
+        auto it = g->label2id.find((uint32_t)label);
+        return it == g->label2id.end() ? -1 : (int64_t)it->second;
+    }
+    auto it = g->name2id.find(name);
+    return it == g->name2id.end() ? -1 : (int64_t)it->second;
+}
+
+int64_t gvs_graph_id2name(const gvs_graph *g, uint32_t id, char *buf, size_t buflen) {
+    if (!g || id >= g->num_vertex) return -1;
+    char tmp[16];
+    const char *name;
+    if (g->label_mode) {
+        snprintf(tmp, sizeof(tmp), "%u", g->labels[id]);
+        name = tmp;
+    } else {
+        name = g->id2name[id].c_str();
+    }
+    const size_t len = strlen(name);
+    if (buf && buflen) {
+        const size_t n = std::min(len, buflen - 1);
+        memcpy(buf, name, n);
+        buf[n] = 0;
+    }
+    return (int64_t)len;
+}
+
+const uint32_t *gvs_graph_edges(const gvs_graph *g) { return g ? g->edges_uv.data() : nullptr; }
+const float *gvs_graph_edge_weights(const gvs_graph *g) { return g ? g->edge_weights.data() : nullptr; }
+const uint64_t *gvs_graph_flat_offsets(const gvs_graph *g) { return g ? g->flat_offsets.data() : nullptr; }
+const float *gvs_graph_vertex_weights(const gvs_graph *g) { return g ? g->vertex_weights.data() : nullptr; }
+
+// ---- partition / schedule -----------------------------------------------------------------------------------
+
+int gvs_partition(const float *weights, uint32_t n, int P, int32_t *part, uint32_t *local, uint32_t *part_sizes) {
+    if (P < 1) return gvk_fail(GVK_EINVAL, "gvs_partition: num_partition must be >= 1");
+    if (n && (!weights || !part || !local)) return gvk_fail(GVK_EINVAL, "gvs_partition: null argument");
+    if (!part_sizes) return gvk_fail(GVK_EINVAL, "gvs_partition: null part_sizes");
+    return guarded("gvs_partition", [&]() {
+        std::vector<uint32_t> order(n);
+        for (uint32_t i = 0; i < n; i++) order[i] = i;
+        // the reference's std::sort leaves ties in unspecified order; stable_sort on ascending ids pins them
+        std::stable_sort(order.begin(), order.end(),
+                         [weights](uint32_t x, uint32_t y) { return weights[x] > weights[y]; });
+        for (int p = 0; p < P; p++) part_sizes[p] = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            int pid = (int)(i % (uint32_t)(P * 2));
+            pid = std::min(pid, P * 2 - 1 - pid);
+            part[order[i]] = pid;
+            local[order[i]] = part_sizes[pid]++;
+        }
+        return GVK_OK;
+    });
+}
+
+int gvs_schedule(int P, int W, int32_t *out, size_t out_len) {
+    if (P < 1 || W < 1 || !out) return gvk_fail(GVK_EINVAL, "gvs_schedule: bad argument");
+    if (P == 1) {
+        if (out_len < 2) return gvk_fail(GVK_EINVAL, "gvs_schedule: output too small");
+        out[0] = out[1] = 0;
+        return 1;
+    }
+    if (P % W) return gvk_fail(GVK_EINVAL, "gvs_schedule: #partition (%d) must be a multiple of #worker (%d)", P, W);
+    const size_t need = (size_t)(P / W) * (P / W) * W * W * 2;
+    if (out_len < need) return gvk_fail(GVK_EINVAL, "gvs_schedule: output too small");
+    int steps = 0;
+    for (int x = 0; x < P; x += W)
+        for (int y = 0; y < P; y += W)
+            for (int offset = 0; offset < W; offset++) {
+                for (int i = 0; i < W; i++) {
+                    out[((size_t)steps * W + i) * 2] = x + (i + offset) % W;
+                    out[((size_t)steps * W + i) * 2 + 1] = y + i;
+                }
+                steps++;
+            }
+    return steps;
+}
+
+}  // extern "C"
+
+// ---- samplers ---------------------------------------------------------------------------------------------
+
+namespace {
+
+inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                          uint32_t out[4]) {
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0;
+        c1 = (uint32_t)p1;
+        c2 = n2;
+        c3 = (uint32_t)p0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0;
+    out[1] = c1;
+    out[2] = c2;
+    out[3] = c3;
+}
+
+constexpr uint32_t kTagHost = 0x686f7374u;
+
+struct HostRng {
+    uint32_t k0, k1, stream;
+    uint64_t pos;  // doubles consumed
+    double cached;
+    bool has_cached;
+
+    HostRng(uint64_t seed, uint32_t stream_, uint64_t pos_)
+        : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)), stream(stream_), pos(pos_), cached(0), has_cached(false) {}
+
+    static double to_double(uint32_t hi, uint32_t lo) {
+        return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+    }
+
+    inline double next() {
+        if (has_cached) {
+            has_cached = false;
+            pos++;
+            return cached;
+        }
+        const uint64_t i = pos >> 1;
+        uint32_t w[4];
+        philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), stream, kTagHost, k0, k1, w);
+        const double d0 = to_double(w[1], w[0]), d1 = to_double(w[3], w[2]);
+        if (pos & 1) {
+            pos++;
+            return d1;
+        }
+        cached = d1;
+        has_cached = true;
+        pos++;
+        return d0;
+    }
+};
+
+struct EdgeSlot {
+    float prob;
+    uint32_t pad;
+    uint64_t alias;
+};
+
+inline uint64_t pack_location(int32_t part, uint32_t local) { return ((uint64_t)(uint32_t)part << 32) | local; }
+
+}  // namespace
+
+struct gvs_sampler {
+    const gvs_graph *g = nullptr;
+    int P = 1;
+    uint64_t seed = 0;
+    std::vector<uint64_t> location;  // (part << 32) | local, per vertex
+    std::vector<float> edge_prob;
+    std::vector<uint64_t> edge_alias;
+    std::vector<EdgeSlot> edge_slots;  // the same table, one cache line touch per draw
+    int prepared = GVS_MODE_EDGE;
+    float p = 1, q = 1;
+    std::vector<float> nb_prob;
+    std::vector<uint32_t> nb_alias;
+    std::vector<uint64_t> ee_offsets;
+    std::vector<uint64_t> positions;
+
+    inline uint64_t sample_edge(HostRng &rng) const {
+        const double r1 = rng.next(), r2 = rng.next();
+        const uint64_t index = (uint64_t)(r1 * (double)edge_slots.size());
+        const EdgeSlot &s = edge_slots[index];
+        return (float)r2 < s.prob ? index : s.alias;
+    }
+
+    inline uint32_t sample_neighbor(HostRng &rng, uint64_t base, uint64_t count) const {
+        const double r1 = rng.next(), r2 = rng.next();
+        const uint64_t index = (uint64_t)(r1 * (double)count);
+        return (float)r2 < nb_prob[base + index] ? (uint32_t)index : nb_alias[base + index];
+    }
+};
+
+namespace {
+
+struct FillShared {
+    const gvs_sampler *s;
+    uint32_t *const *pools;
+    uint64_t pool_size;
+    gvs_fill_config c;
+    std::atomic<int> error{0};
+};
+
+// a block that no positive sample can reach would spin forever (the reference would, too): give up after this
+// many consecutive inner rounds in which this thread wrote nothing
+constexpr int kMaxIdleRounds = 1 << 16;
+
+struct BlockCursor {
+    std::vector<int64_t> offsets;
+    int num_complete = 0, target = 0;
+    int P, tail_filter;
+    int64_t end;
+    BlockCursor(int P_, int tail_filter_, int64_t start, int64_t end_)
+        : offsets((size_t)P_ * P_, start), P(P_), tail_filter(tail_filter_), end(end_) {
+        target = tail_filter < 0 ? P * P : P;
+    }
+    // returns the slot to write, or -1 when the block is full / not ours
+    inline int64_t claim(int hp, int tp) {
+        if (tail_filter >= 0 && tp != tail_filter) return -1;
+        int64_t &offset = offsets[(size_t)hp * P + tp];
+        if (offset >= end) return -1;
+        const int64_t slot = offset;
+        if (++offset == end) num_complete++;
+        return slot;
+    }
+    inline bool done() const { return num_complete >= target; }
+};
+
+void fill_edges(FillShared *sh, int thread, int64_t start, int64_t end, uint64_t *position) {
+    const gvs_sampler &s = *sh->s;
+    HostRng rng(s.seed, (uint32_t)thread, *position);
+    if (start >= end) return;
+    BlockCursor cur(s.P, sh->c.tail_partition, start, end);
+    const int n = sh->c.sample_batch_size;
+    std::vector<uint64_t> heads(n), tails(n);
+    const uint32_t *edges = s.g->edges_uv.data();
+    int idle = 0;
+    while (!cur.done() && !sh->error.load(std::memory_order_relaxed)) {
+        for (int i = 0; i < n; i++) {
+            const uint64_t e = s.sample_edge(rng);
+            heads[i] = s.location[edges[2 * e]];
+            tails[i] = s.location[edges[2 * e + 1]];
+        }
+        bool wrote = false;
+        for (int i = 0; i < n; i++) {
+            const int hp = (int)(heads[i] >> 32), tp = (int)(tails[i] >> 32);
+            const int64_t slot = cur.claim(hp, tp);
+            if (slot >= 0) {
+                uint32_t *pool = sh->pools[(size_t)hp * s.P + tp];
+                pool[2 * slot] = (uint32_t)tails[i];
+                pool[2 * slot + 1] = (uint32_t)heads[i];
+                wrote = true;
+            }
+        }
+        idle = wrote ? 0 : idle + 1;
+        if (idle > kMaxIdleRounds) sh->error.store(1);
+    }
+    *position = rng.pos;
+}
+
+void fill_walks(FillShared *sh, int thread, int64_t start, int64_t end, uint64_t *position) {
+    const gvs_sampler &s = *sh->s;
+    HostRng rng(s.seed, (uint32_t)thread, *position);
+    if (start >= end) return;
+    const bool biased = sh->c.mode == GVS_MODE_BIASED_WALK;
+    BlockCursor cur(s.P, sh->c.tail_partition, start, end);
+    const int L = sh->c.walk_length, nb = sh->c.walk_batch, aug = sh->c.augmentation_step;
+    const int64_t sb = sh->c.shuffle_base, stride = (int64_t)(sh->pool_size / (uint64_t)sb);
+    std::vector<uint64_t> chains((size_t)nb * (L + 1));
+    std::vector<int> lengths(nb);
+    const uint32_t *edges = s.g->edges_uv.data();
+    const uint64_t *flat = s.g->flat_offsets.data();
+    int idle = 0;
+    while (!cur.done() && !sh->error.load(std::memory_order_relaxed)) {
+        for (int i = 0; i < nb; i++) {
+            uint64_t *chain = chains.data() + (size_t)i * (L + 1);
+            uint64_t edge_id = s.sample_edge(rng);
+            uint32_t current = edges[2 * edge_id];
+            chain[0] = s.location[current];
+            current = edges[2 * edge_id + 1];
+            chain[1] = s.location[current];
+            lengths[i] = L;
+            for (int j = 2; j <= L; j++) {
+                const uint64_t deg = flat[current + 1] - flat[current];
+                if (deg == 0) {
+                    lengths[i] = j - 1;
+                    break;
+                }
+                const uint64_t base = biased ? s.ee_offsets[edge_id] : flat[current];
+                const uint32_t neighbor = s.sample_neighbor(rng, base, deg);
+                edge_id = flat[current] + neighbor;
+                current = edges[2 * edge_id + 1];
+                chain[j] = s.location[current];
+            }
+        }
+        bool wrote = false;
+        for (int i = 0; i < nb; i++) {
+            const uint64_t *chain = chains.data() + (size_t)i * (L + 1);
+            const int len = lengths[i];
+            for (int j = 0; j < len; j++)
+                for (int k = 1; k <= aug; k++) {
+                    if (j + k > len) break;
+                    const uint64_t h = chain[j], t = chain[j + k];
+                    const int hp = (int)(h >> 32), tp = (int)(t >> 32);
+                    const int64_t offset = cur.claim(hp, tp);
+                    if (offset >= 0) {
+                        const int64_t slot = offset % sb * stride + offset / sb;  // pseudo shuffle, graph.cuh:440-442
+                        uint32_t *pool = sh->pools[(size_t)hp * s.P + tp];
+                        pool[2 * slot] = (uint32_t)t;
+                        pool[2 * slot + 1] = (uint32_t)h;
+                        wrote = true;
+                    }
+                }
+        }
+        idle = wrote ? 0 : idle + 1;
+        if (idle > kMaxIdleRounds) sh->error.store(1);
+    }
+    *position = rng.pos;
+}
+
+// CSR-aligned alias tables: one table per vertex over its out-edge weights (graph.cuh:645-653)
+void build_vertex_tables(gvs_sampler *s, uint32_t begin, uint32_t end, std::atomic<int> *error) {
+    const uint64_t *flat = s->g->flat_offsets.data();
+    for (uint32_t u = begin; u < end; u++) {
+        const uint64_t off = flat[u], deg = flat[u + 1] - off;
+        if (!deg) continue;
+        if (gvk_alias_build(s->g->edge_weights.data() + off, deg, s->nb_prob.data() + off, s->nb_alias.data() + off,
+                            4, nullptr) != GVK_OK)
+            error->store(1);
+    }
+}
+
+// node2vec: one table per directed edge (u -> v) over v's out-edges (graph.cuh:656-677)
+void build_edge_tables(gvs_sampler *s, const std::vector<uint32_t> *sorted_nb, uint64_t begin, uint64_t end,
+                       std::atomic<int> *error) {
+    const uint32_t *edges = s->g->edges_uv.data();
+    const uint64_t *flat = s->g->flat_offsets.data();
+    const float *ew = s->g->edge_weights.data();
+    std::vector<float> weights;
+    for (uint64_t e = begin; e < end; e++) {
+        const uint32_t u = edges[2 * e], v = edges[2 * e + 1];
+        const uint64_t off = flat[v], deg = flat[v + 1] - off;
+        if (!deg) continue;
+        weights.resize(deg);
+        for (uint64_t f = 0; f < deg; f++) {
+            const uint32_t x = edges[2 * (off + f) + 1];
+            const float w = ew[off + f];
+            if (x == u) {
+                weights[f] = w / s->p;
+            } else {
+                const uint32_t *b = sorted_nb->data() + flat[x], *en = sorted_nb->data() + flat[x + 1];
+                weights[f] = std::binary_search(b, en, u) ? w : w / s->q;
+            }
+        }
+        const uint64_t base = s->ee_offsets[e];
+        if (gvk_alias_build(weights.data(), deg, s->nb_prob.data() + base, s->nb_alias.data() + base, 4, nullptr) !=
+            GVK_OK)
+            error->store(1);
+    }
+}
+
+template <class F>
+void parallel_ranges(uint64_t n, int num_thread, F &&f) {
+    num_thread = std::max(1, num_thread);
+    const uint64_t work = (n + num_thread - 1) / num_thread;
+    std::vector<std::thread> threads;
+    for (int t = 0; t < num_thread; t++) {
+        const uint64_t b = work * t, e = std::min(work * (t + 1), n);
+        if (b >= e) break;
+        threads.emplace_back(f, b, e);
+    }
+    for (auto &t : threads) t.join();
+}
+
+}  // namespace
+
+extern "C" {
+
+gvs_sampler *gvs_sampler_create(const gvs_graph *g, const int32_t *part, const uint32_t *local, int P, uint64_t seed) {
+    if (!g || !part || !local || P < 1) {
+        gvk_fail(GVK_EINVAL, "gvs_sampler_create: bad argument");
+        return nullptr;
+    }
+    const size_t D = g->edge_weights.size();
+    if (!D) {
+        gvk_fail(GVK_EINVAL, "gvs_sampler_create: the graph has no edges");
+        return nullptr;
+    }
+    gvs_sampler *s = nullptr;
+    try {
+        s = new gvs_sampler();
+        s->g = g;
+        s->P = P;
+        s->seed = seed;
+        s->location.resize(g->num_vertex);
+        for (uint32_t v = 0; v < g->num_vertex; v++) {
+            if (part[v] < 0 || part[v] >= P) {
+                delete s;
+                gvk_fail(GVK_EINVAL, "gvs_sampler_create: part[%u] = %d is outside [0, %d)", v, part[v], P);
+                return nullptr;
+            }
+            s->location[v] = pack_location(part[v], local[v]);
+        }
+        s->edge_prob.resize(D);
+        s->edge_alias.resize(D);
+        if (gvk_alias_build(g->edge_weights.data(), D, s->edge_prob.data(), s->edge_alias.data(), 8, nullptr) !=
+            GVK_OK) {
+            delete s;
+            return nullptr;
+        }
+        s->edge_slots.resize(D);
+        for (size_t e = 0; e < D; e++) s->edge_slots[e] = EdgeSlot{s->edge_prob[e], 0, s->edge_alias[e]};
+    } catch (const std::bad_alloc &) {
+        delete s;
+        gvk_fail(GVK_ENOMEM, "gvs_sampler_create: out of host memory");
+        return nullptr;
+    }
+    return s;
+}
+
+void gvs_sampler_destroy(gvs_sampler *s) { delete s; }
+
+int gvs_sampler_prepare(gvs_sampler *s, int mode, float p, float q, int num_thread) {
+    if (!s) return gvk_fail(GVK_EINVAL, "gvs_sampler_prepare: null sampler");
+    if (mode != GVS_MODE_EDGE && mode != GVS_MODE_WALK && mode != GVS_MODE_BIASED_WALK)
+        return gvk_fail(GVK_EINVAL, "gvs_sampler_prepare: unknown mode %d", mode);
+    return guarded("gvs_sampler_prepare", [&]() {
+        const gvs_graph *g = s->g;
+        const uint64_t D = g->edge_weights.size();
+        const uint64_t *flat = g->flat_offsets.data();
+        std::atomic<int> error{0};
+        decltype(s->nb_prob)().swap(s->nb_prob);
+        decltype(s->nb_alias)().swap(s->nb_alias);
+        decltype(s->ee_offsets)().swap(s->ee_offsets);
+        s->prepared = GVS_MODE_EDGE;
+        if (mode == GVS_MODE_WALK) {
+            s->nb_prob.resize(D);
+            s->nb_alias.resize(D);
+            parallel_ranges(g->num_vertex, num_thread, [&](uint64_t b, uint64_t e) {
+                build_vertex_tables(s, (uint32_t)b, (uint32_t)e, &error);
+            });
+        } else if (mode == GVS_MODE_BIASED_WALK) {
+            if (!(p > 0) || !(q > 0)) return gvk_fail(GVK_EINVAL, "gvs_sampler_prepare: p and q must be positive");
+            s->p = p;
+            s->q = q;
+            s->ee_offsets.resize(D + 1);
+            s->ee_offsets[0] = 0;
+            for (uint64_t e = 0; e < D; e++) {
+                const uint32_t v = g->edges_uv[2 * e + 1];
+                s->ee_offsets[e + 1] = s->ee_offsets[e] + (flat[v + 1] - flat[v]);
+            }
+            const uint64_t total = s->ee_offsets[D];
+            s->nb_prob.resize(total);  // sum over edges of deg(head): the reference's node2vec memory hog
+            s->nb_alias.resize(total);
+            std::vector<uint32_t> sorted_nb(D);
+            for (uint64_t e = 0; e < D; e++) sorted_nb[e] = g->edges_uv[2 * e + 1];
+            parallel_ranges(g->num_vertex, num_thread, [&](uint64_t b, uint64_t e) {
+                for (uint64_t u = b; u < e; u++) std::sort(sorted_nb.begin() + flat[u], sorted_nb.begin() + flat[u + 1]);
+            });
+            parallel_ranges(D, num_thread,
+                            [&](uint64_t b, uint64_t e) { build_edge_tables(s, &sorted_nb, b, e, &error); });
+        }
+        if (error.load()) return gvk_fail(GVK_EINVAL, "gvs_sampler_prepare: alias table construction failed");
+        s->prepared = mode;
+        return GVK_OK;
+    });
+}
+
+int gvs_sampler_fill(gvs_sampler *s, uint32_t *const *pools, uint64_t pool_size, const gvs_fill_config *c) {
+    if (!s || !pools || !c) return gvk_fail(GVK_EINVAL, "gvs_sampler_fill: null argument");
+    if (c->num_thread < 1) return gvk_fail(GVK_EINVAL, "gvs_sampler_fill: num_thread must be >= 1");
+    if (pool_size > (uint64_t)INT32_MAX) return gvk_fail(GVK_EINVAL, "gvs_sampler_fill: pool too large");
+    if (c->tail_partition >= s->P) return gvk_fail(GVK_EINVAL, "gvs_sampler_fill: tail_partition out of range");
+    if (c->mode == GVS_MODE_EDGE) {
+        if (c->sample_batch_size < 1) return gvk_fail(GVK_EINVAL, "gvs_sampler_fill: sample_batch_size must be >= 1");
+    } else if (c->mode == GVS_MODE_WALK || c->mode == GVS_MODE_BIASED_WALK) {
+        if (s->prepared != c->mode)
+            return gvk_fail(GVK_EINVAL, "gvs_sampler_fill: call gvs_sampler_prepare for this mode first");
+        if (c->augmentation_step < 1)
+            return gvk_fail(GVK_EINVAL, "`augmentation_step` should be a positive integer");
+        if (c->augmentation_step > c->walk_length)
+            return gvk_fail(GVK_EINVAL, "`random_walk_length` should be no less than `augmentation_step`");
+        if (c->walk_batch < 1) return gvk_fail(GVK_EINVAL, "gvs_sampler_fill: walk_batch must be >= 1");
+        if (c->shuffle_base < 1 || pool_size % (uint64_t)c->shuffle_base)
+            return gvk_fail(GVK_EINVAL,
+                            "Can't perform pseudo shuffle on %llu elements by a shuffle base of %d. Try setting the "
+                            "episode size to a multiple of the shuffle base",
+                            (unsigned long long)pool_size, c->shuffle_base);
+    } else {
+        return gvk_fail(GVK_EINVAL, "gvs_sampler_fill: unknown mode %d", c->mode);
+    }
+    for (int hp = 0; hp < s->P; hp++)
+        for (int tp = 0; tp < s->P; tp++)
+            if ((c->tail_partition < 0 || tp == c->tail_partition) && !pools[(size_t)hp * s->P + tp])
+                return gvk_fail(GVK_EINVAL, "gvs_sampler_fill: pool (%d, %d) is null", hp, tp);
+    return guarded("gvs_sampler_fill", [&]() {
+        if ((int)s->positions.size() < c->num_thread) s->positions.resize(c->num_thread, 0);
+        FillShared sh;
+        sh.s = s;
+        sh.pools = pools;
+        sh.pool_size = pool_size;
+        sh.c = *c;
+        const int64_t work = ((int64_t)pool_size + c->num_thread - 1) / c->num_thread;  // solver.h:616-617
+        std::vector<std::thread> threads;
+        for (int t = 0; t < c->num_thread; t++) {
+            const int64_t b = work * t, e = std::min(work * (t + 1), (int64_t)pool_size);
+            uint64_t *position = &s->positions[t];
+            if (c->mode == GVS_MODE_EDGE)
+                threads.emplace_back(fill_edges, &sh, t, b, e, position);
+            else
+                threads.emplace_back(fill_walks, &sh, t, b, e, position);
+        }
+        for (auto &t : threads) t.join();
+        if (sh.error.load())
+            return gvk_fail(GVK_EINVAL,
+                            "gvs_sampler_fill: a block pool cannot be filled (no positive sample falls into it); "
+                            "use fewer partitions for this graph");
+        return GVK_OK;
+    });
+}
+
+uint64_t gvs_sampler_stream_position(const gvs_sampler *s, int thread) {
+    return s && thread >= 0 && thread < (int)s->positions.size() ? s->positions[thread] : 0;
+}
+
+int gvs_sampler_set_stream_position(gvs_sampler *s, int thread, uint64_t position) {
+    if (!s || thread < 0) return gvk_fail(GVK_EINVAL, "gvs_sampler_set_stream_position: bad argument");
+    if ((int)s->positions.size() <= thread) s->positions.resize(thread + 1, 0);
+    s->positions[thread] = position;
+    return GVK_OK;
+}
+
+const float *gvs_sampler_edge_prob(const gvs_sampler *s) { return s ? s->edge_prob.data() : nullptr; }
+const uint64_t *gvs_sampler_edge_alias(const gvs_sampler *s) { return s ? s->edge_alias.data() : nullptr; }
+const float *gvs_sampler_neighbor_prob(const gvs_sampler *s) { return s ? s->nb_prob.data() : nullptr; }
+const uint32_t *gvs_sampler_neighbor_alias(const gvs_sampler *s) { return s ? s->nb_alias.data() : nullptr; }
+const uint64_t *gvs_sampler_edge_edge_offsets(const gvs_sampler *s) { return s ? s->ee_offsets.data() : nullptr; }
+
+void gvs_host_uniforms(uint64_t seed, uint32_t stream, uint64_t first, size_t n, double *out) {
+    HostRng rng(seed, stream, first);
+    for (size_t i = 0; i < n; i++) out[i] = rng.next();
+}
+
+}  // extern "C"

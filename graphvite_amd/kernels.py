@@ -1,0 +1,169 @@
+"""Thin, typed Python face of the kernel ABI (include/gvk.h) over torch tensors.
+
+torch supplies device memory and streams only; every computation is a libgvk.so kernel.
+A `HipKernels` object is what `solver.GraphSolver` calls; tests for the host logic may inject an object
+with the same methods (tests/fake_kernels.py) to run the solver without a GPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+OPTIMIZER_TYPES = {"SGD": _lib.SGD, "Momentum": _lib.MOMENTUM, "AdaGrad": _lib.ADAGRAD, "RMSprop": _lib.RMSPROP,
+                   "Adam": _lib.ADAM}
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _need(t, dtype, name, device=None):
+    if not isinstance(t, torch.Tensor) or t.dtype != dtype or not t.is_contiguous():
+        raise ValueError("%s must be a contiguous torch tensor of dtype %s" % (name, dtype))
+    if device is not None and t.device != device:
+        raise ValueError("%s lives on %s, expected %s" % (name, t.device, device))
+    if not t.is_cuda:
+        raise ValueError("%s must live in GPU memory; graphvite_amd has no CPU training path" % name)
+    return t
+
+
+def alias_build(weights, index_bytes=4):
+    """Host alias table (reference AliasTable::build). Returns (prob f32[n], alias u32|u64[n], packed)."""
+    w = np.ascontiguousarray(weights, dtype=np.float32)
+    if w.ndim != 1:
+        raise ValueError("weights must be one-dimensional")
+    prob = np.empty(w.size, np.float32)
+    alias = np.empty(w.size, np.uint64 if index_bytes == 8 else np.uint32)
+    packed = np.empty(w.size, dtype=np.dtype([("prob", np.float32), ("alias", np.uint32)])) if index_bytes == 4 \
+        else None
+    rc = _lib.lib().gvk_alias_build(w.ctypes.data, w.size, prob.ctypes.data, alias.ctypes.data, index_bytes,
+                                    None if packed is None else packed.ctypes.data)
+    _lib.check(rc, "gvk_alias_build")
+    return prob, alias, packed
+
+
+def packed_to_device(packed, device):
+    """gvk_alias_entry[n] -> int64 tensor [n] on `device` (8-byte entries, bit pattern preserved)."""
+    return torch.from_numpy(packed.view(np.int64).copy()).to(device)
+
+
+class OptimizerSpec(object):
+    """Plain description of an optimizer for the kernels (type name + hyper-parameters)."""
+
+    def __init__(self, type="SGD", lr=0.025, weight_decay=0.005, hp0=0.0, hp1=0.0, epsilon=0.0, schedule="linear"):
+        if type not in OPTIMIZER_TYPES:
+            raise ValueError("Unknown optimizer `%s`" % type)
+        self.type, self.lr, self.weight_decay = type, float(lr), float(weight_decay)
+        self.hp0, self.hp1, self.epsilon, self.schedule = float(hp0), float(hp1), float(epsilon), schedule
+
+    @property
+    def num_moment(self):
+        return {"SGD": 0, "Adam": 2}.get(self.type, 1)
+
+    def c_struct(self, lr=None):
+        return _lib.Optimizer(OPTIMIZER_TYPES[self.type], self.lr if lr is None else lr, self.weight_decay, self.hp0,
+                              self.hp1, self.epsilon)
+
+
+class HipKernels(object):
+    """Launches on torch's current stream of the tensors' device."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.lib()
+
+    @staticmethod
+    def _stream(t):
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+    @staticmethod
+    def _tables(vertex, context, moments):
+        dev = vertex.device
+        _need(vertex, torch.float32, "vertex")
+        _need(context, torch.float32, "context", dev)
+        if vertex.dim() != 2 or context.dim() != 2 or vertex.shape[1] != context.shape[1]:
+            raise ValueError("vertex / context must be [rows, dim] with equal dim")
+        m = list(moments or []) + [None] * 4
+        for i, t in enumerate(m[:4]):
+            if t is not None:
+                _need(t, torch.float32, "moment", dev)
+                if t.shape != (vertex if i % 2 == 0 else context).shape:
+                    raise ValueError("moment table %d has the wrong shape" % i)
+        return _lib.Tables(_ptr(vertex), _ptr(context), _ptr(m[0]), _ptr(m[1]), _ptr(m[2]), _ptr(m[3]),
+                           vertex.shape[0], context.shape[0])
+
+    @staticmethod
+    def _negative(negatives, table, seed, dev):
+        if negatives is not None:
+            _need(negatives, torch.int32, "negatives", dev)
+        if table is not None:
+            _need(table, torch.int64, "alias table", dev)
+        return _lib.NegativeSource(_ptr(negatives), _ptr(table), 0 if table is None else table.numel(), seed)
+
+    def train(self, vertex, context, pairs, loss, optimizer, num_negative, negative_weight, negatives=None,
+              table=None, seed=0, batch_id=0, moments=None, lr=None):
+        """One batch. pairs int32 [B, 2] = {tail, head}; negatives int32 [B, k] or None (draw from `table`)."""
+        dev = vertex.device
+        tables = self._tables(vertex, context, moments)
+        _need(pairs, torch.int32, "pairs", dev)
+        _need(loss, torch.float32, "loss", dev)
+        B = pairs.shape[0]
+        if pairs.dim() != 2 or pairs.shape[1] != 2 or loss.numel() < B:
+            raise ValueError("pairs must be [B, 2] and loss must hold B floats")
+        if negatives is not None and negatives.numel() != B * num_negative:
+            raise ValueError("negatives must hold batch_size * num_negative ids")
+        neg = self._negative(negatives, table, seed, dev)
+        opt = optimizer.c_struct(lr)
+        rc = self.lib.gvk_train(self._stream(vertex), vertex.shape[1], C.byref(opt), C.byref(tables), _ptr(pairs),
+                                C.byref(neg), batch_id, _ptr(loss), B, num_negative, negative_weight)
+        _lib.check(rc, "gvk_train")
+
+    def train_episode(self, vertex, context, pool, loss, optimizer, num_negative, negative_weight, table, seed,
+                      first_batch_id, total_batches, num_batches, batch_size, moments=None):
+        """num_batches consecutive batches of a device-resident pool (int32 [>= num_batches*batch_size, 2])."""
+        dev = vertex.device
+        tables = self._tables(vertex, context, moments)
+        _need(pool, torch.int32, "pool", dev)
+        _need(loss, torch.float32, "loss", dev)
+        if pool.numel() < num_batches * batch_size * 2 or loss.numel() < batch_size:
+            raise ValueError("pool / loss too small for %d batches of %d" % (num_batches, batch_size))
+        neg = self._negative(None, table, seed, dev)
+        opt = optimizer.c_struct()
+        rc = self.lib.gvk_train_episode(self._stream(vertex), vertex.shape[1], C.byref(opt),
+                                        int(optimizer.schedule == "linear"), C.byref(tables), _ptr(pool),
+                                        C.byref(neg), first_batch_id, total_batches, num_batches, _ptr(loss),
+                                        batch_size, num_negative, negative_weight)
+        _lib.check(rc, "gvk_train_episode")
+
+    def predict(self, vertex, context, pairs, logits):
+        dev = vertex.device
+        _need(vertex, torch.float32, "vertex")
+        _need(context, torch.float32, "context", dev)
+        _need(pairs, torch.int32, "pairs", dev)
+        _need(logits, torch.float32, "logits", dev)
+        if logits.numel() < pairs.shape[0]:
+            raise ValueError("logits too small")
+        rc = self.lib.gvk_predict(self._stream(vertex), vertex.shape[1], _ptr(vertex), _ptr(context), _ptr(pairs),
+                                  _ptr(logits), pairs.shape[0])
+        _lib.check(rc, "gvk_predict")
+
+    def alias_sample(self, table, rand, result):
+        _need(table, torch.int64, "alias table")
+        _need(rand, torch.float64, "rand", table.device)
+        _need(result, torch.int32, "result", table.device)
+        rc = self.lib.gvk_alias_sample(self._stream(table), _ptr(table), table.numel(), _ptr(rand), _ptr(result),
+                                       result.numel())
+        _lib.check(rc, "gvk_alias_sample")
+
+    def negative_draw(self, table, seed, batch_id, out, batch_size, num_negative):
+        _need(table, torch.int64, "alias table")
+        _need(out, torch.int32, "negatives", table.device)
+        rc = self.lib.gvk_negative_draw(self._stream(table), _ptr(table), table.numel(), seed, batch_id, _ptr(out),
+                                        batch_size, num_negative)
+        _lib.check(rc, "gvk_negative_draw")
+
+    def set_lanes_per_pair(self, lanes):
+        _lib.check(self.lib.gvk_set_tuning(_lib.TUNE_LANES_PER_PAIR, lanes), "gvk_set_tuning")

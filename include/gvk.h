@@ -1,0 +1,142 @@
+/* gvk.h — C ABI of the MI355X (gfx950) node-embedding training kernels ("gvk" = GraphVite kernels).
+ *
+ * This is the drop-in boundary of the hot path: plain pointers and sizes, no
+ * torch / pybind / C++ types, caller owns every buffer, every call is stream-ordered and
+ * re-entrant per device, and every call returns a status instead of aborting (the reference
+ * aborts through glog CHECK, include/util/debug.h:27-38).
+ *
+ * Reference interfaces replaced (paths relative to the reference tree, graphvite v0.2.2):
+ *   gvk_train            gpu::graph::train / train_1_moment / train_2_moment
+ *                        (include/instance/gpu/graph.cuh:36-95, 104-167, 176-242) as launched by
+ *                        GraphWorker::train_dispatch (include/instance/graph.cuh:467-554), together
+ *                        with the negative draw that WorkerMixin::train_batch performs first
+ *                        (curandGenerateUniformDouble + gpu::Sample, include/core/solver.h:1536-1539)
+ *   gvk_train_episode    WorkerMixin::train's batch loop + train_batch's lr schedule
+ *                        (include/core/solver.h:1511-1557, include/core/optimizer.h:77-79,132-134)
+ *   gvk_predict          gpu::graph::predict (include/instance/gpu/graph.cuh:250-279) as launched by
+ *                        GraphWorker::predict_dispatch (include/instance/graph.cuh:560-577)
+ *   gvk_alias_build      AliasTable::build (include/base/alias_table.cuh:84-128)
+ *   gvk_alias_sample     AliasTable::device_sample / gpu::Sample (include/base/alias_table.cuh:155-158,174-182)
+ *   gvk_negative_draw    the same draw as gvk_train's fused on-device draw, as a standalone kernel
+ *
+ * Data layout in HBM
+ *   embedding tables  row-major float32 [rows][dim] (Vector<dim,float>, include/base/vector.h:31-69);
+ *                     512 B/row at dim 128.  Moment tables have the same shape.
+ *   pairs             uint32 records {tail, head} (std::tuple<Index,Index> is laid out reversed,
+ *                     include/instance/gpu/graph.cuh:55-57), ids local to the resident partitions.
+ *   negatives         uint32 [batch_size][num_negative] (include/instance/gpu/graph.cuh:66)
+ *   alias table       gvk_alias_entry[count]: prob and alias interleaved so that one 8-byte load
+ *                     serves a draw (the reference keeps two arrays, alias_table.cuh:60-61)
+ *
+ * RNG contract (replaces cuRAND XORWOW, which nothing in the reference pins): Philox4x32-10.
+ *   negative j of sample s in batch b:
+ *       w = philox4x32_10(ctr = {s, b, j / 2, 0x6e656721}, key = {seed_lo, seed_hi})
+ *       (w_a, w_b) = (w[0], w[1]) if j even else (w[2], w[3])
+ *       index = (uint64(w_a) * count) >> 32            -- uniform slot, all of [0, count) reachable
+ *       u     = float(w_b >> 8) * 2^-24                -- the 24-bit resolution gpu::Sample has
+ *       negative = u < table[index].prob ? index : table[index].alias
+ *   host uniform stream t (used by the CPU samplers, gvs.h): doubles 2i and 2i+1 come from
+ *       w = philox4x32_10(ctr = {i_lo, i_hi, t, 0x686f7374}, key = seed);  d = (w_hi:w_lo >> 11) * 2^-53
+ */
+#ifndef GVK_H_
+#define GVK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GVK_OK 0
+#define GVK_EINVAL (-1) /* bad argument (null pointer, negative size, no negative source, ...) */
+#define GVK_EDIM (-2)   /* dim is not one of 32, 64, 96, 128, 256, 512 (the reference's instantiations,
+                           src/graphvite.cu:52-59) */
+#define GVK_EHIP (-3)   /* the HIP runtime reported an error; gvk_last_error() has the text */
+#define GVK_ENOMEM (-4)
+
+/* OptimizerType, include/core/optimizer.h:27-34 */
+enum { GVK_SGD = 0, GVK_MOMENTUM = 1, GVK_ADAGRAD = 2, GVK_RMSPROP = 3, GVK_ADAM = 4 };
+
+typedef struct {
+    float prob;
+    uint32_t alias;
+} gvk_alias_entry;
+
+/* POD stand-in for the by-value `Optimizer` kernel argument (include/instance/gpu/graph.cuh:40). */
+typedef struct {
+    int32_t type;       /* GVK_SGD ... GVK_ADAM */
+    float lr;           /* learning rate of THIS batch (schedule already applied) */
+    float weight_decay;
+    float hp0;          /* Momentum: momentum; RMSprop: alpha; Adam: beta1 (the union at optimizer.h:110-121) */
+    float hp1;          /* Adam: beta2 */
+    float epsilon;      /* AdaGrad / RMSprop / Adam */
+} gvk_optimizer;
+
+/* The embedding (and moment) tables a launch works on.  Moment pointers may be NULL for SGD. */
+typedef struct {
+    float *vertex;          /* [n_vertex][dim]   head partition */
+    float *context;         /* [n_context][dim]  tail partition */
+    float *vertex_moment1;  /* Momentum / AdaGrad / RMSprop / Adam */
+    float *context_moment1;
+    float *vertex_moment2;  /* Adam */
+    float *context_moment2;
+    uint32_t n_vertex, n_context;
+} gvk_tables;
+
+/* Where the negatives of a batch come from: an explicit array (the reference's negative_batch), or —
+ * when `negatives` is NULL — the alias table, drawn inside the training kernel per the RNG contract. */
+typedef struct {
+    const uint32_t *negatives;     /* device, [batch_size * num_negative], or NULL */
+    const gvk_alias_entry *table;  /* device, [count] */
+    uint32_t count;
+    uint64_t seed;
+} gvk_negative_source;
+
+/* One batch of negative-sampling SGD: for every {tail, head} pair, num_negative negative steps then the
+ * positive step on a progressively updated copy of vertex[head]; context rows are updated in place,
+ * Hogwild (no atomics), loss[s] = sample loss / (1 + num_negative * negative_weight).
+ * `stream` is a hipStream_t (NULL = default stream).  `batch_id` only feeds the negative draw. */
+int gvk_train(void *stream, int dim, const gvk_optimizer *optimizer, const gvk_tables *tables,
+              const uint32_t *pairs, const gvk_negative_source *negative, uint32_t batch_id, float *loss,
+              int batch_size, int num_negative, float negative_weight);
+
+/* `num_batches` consecutive batches from a device-resident pool: batch i uses pairs + i * batch_size * 2,
+ * batch id first_batch_id + i, and lr = init_lr * schedule(first_batch_id + i, total_batches) where
+ * schedule is max(1 - id / total, 1e-4) if linear_schedule else 1 (`optimizer->lr` is init_lr here).
+ * loss [batch_size] is overwritten by every batch, as in the reference. One kernel launch per batch. */
+int gvk_train_episode(void *stream, int dim, const gvk_optimizer *optimizer, int linear_schedule,
+                      const gvk_tables *tables, const uint32_t *pairs, const gvk_negative_source *negative,
+                      uint32_t first_batch_id, uint32_t total_batches, int num_batches, float *loss,
+                      int batch_size, int num_negative, float negative_weight);
+
+/* logits[s] = dot(vertex[head_s], context[tail_s]) */
+int gvk_predict(void *stream, int dim, const float *vertex, const float *context, const uint32_t *pairs,
+                float *logits, int batch_size);
+
+/* result[i] = table.sample((float)rand[2i], (float)rand[2i+1]) — the reference's double-driven draw. */
+int gvk_alias_sample(void *stream, const gvk_alias_entry *table, uint32_t count, const double *rand,
+                     uint32_t *result, int n);
+
+/* negatives[s * num_negative + j] per the RNG contract (what gvk_train draws when negatives == NULL). */
+int gvk_negative_draw(void *stream, const gvk_alias_entry *table, uint32_t count, uint64_t seed,
+                      uint32_t batch_id, uint32_t *negatives, int batch_size, int num_negative);
+
+/* Host: Vose alias construction exactly as the reference orders it (FIFO queues, double mean).
+ * index_bytes 4 -> uint32 alias[], 8 -> uint64 alias[].  n must be > 0 and < 2^31 (the reference's
+ * loop counters are int).  packed (optional, index_bytes 4 only) receives the interleaved device form. */
+int gvk_alias_build(const float *weights, size_t n, float *prob, void *alias, int index_bytes,
+                    gvk_alias_entry *packed);
+
+/* Tuning knobs for A/B measurement (bench.py --variant); they never change results beyond
+ * floating-point summation order.  Returns GVK_EINVAL for an unknown key or unsupported value. */
+#define GVK_TUNE_LANES_PER_PAIR 1 /* 0 = per-dim default; else 8, 16, 32 or 64 */
+int gvk_set_tuning(int key, int value);
+
+const char *gvk_last_error(void);
+const char *gvk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GVK_H_ */

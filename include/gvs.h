@@ -1,0 +1,127 @@
+/* gvs.h — C ABI of the host-side runtime that feeds the gvk kernels ("gvs" = GraphVite sampler/solver core).
+ *
+ * Everything the reference does on CPU threads around the training kernel, restated as a C-ABI library so
+ * that any host (the Python package in this repo, or the reference's own C++ solver) can drive it:
+ *
+ *   gvs_graph_*        Graph<Index> / GraphMixin: edge-list loading, name<->id maps, undirected doubling,
+ *                      normalisation, flatten() to CSR, save
+ *                      (include/instance/graph.cuh:61-277, include/core/graph.h:45-125)
+ *   gvs_partition      SolverMixin::partition + head/tail_locations (include/core/solver.h:873-887, 399-410)
+ *   gvs_schedule       SolverMixin::get_schedule, non-tied branch (include/core/solver.h:519-575)
+ *   gvs_sampler_*      SamplerMixin::sample (include/core/solver.h:1012-1055),
+ *                      GraphSampler::sample_random_walk / sample_biased_random_walk
+ *                      (include/instance/graph.cuh:298-450), GraphSolver::build_vertex_edge / build_edge_edge /
+ *                      get_sample_function (include/instance/graph.cuh:645-721)
+ *
+ * Index type is uint32 (the reference's only bound instantiation for this path, src/graphvite.cu:52-59).
+ * All functions return GVK_OK or a negative GVK_E* code (include/gvk.h) and set gvk_last_error(); none aborts.
+ * Pool records are {tail, head} uint32 pairs with partition-local ids (the kernel's `pairs` layout).
+ *
+ * RNG: sampler thread t consumes the host uniform stream t of the RNG contract in include/gvk.h, two doubles
+ * per alias draw, in exactly the order the reference's loops consume theirs — so a fill is a pure function of
+ * (seed, number of threads, stream positions), and the CPU oracle reproduces it bit for bit.
+ */
+#ifndef GVS_H_
+#define GVS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gvs_graph gvs_graph;
+typedef struct gvs_sampler gvs_sampler;
+
+/* ---- graph ---------------------------------------------------------------------------------------- */
+
+gvs_graph *gvs_graph_create(void);
+void gvs_graph_destroy(gvs_graph *g);
+
+/* Text edge list: "u v [w]" per line, `comment` starts a comment, `delimiters` as strtok takes them.
+ * Ids are assigned in first-seen order; duplicate lines are kept; num_edge counts lines. */
+int gvs_graph_load_file(gvs_graph *g, const char *file_name, int as_undirected, int normalization,
+                        const char *delimiters, const char *comment);
+/* Edge list of names (weights may be NULL = 1). */
+int gvs_graph_load_names(gvs_graph *g, const char *const *u_names, const char *const *v_names, const float *weights,
+                         size_t n, int as_undirected, int normalization);
+/* Edge list of integer labels (the name of a vertex is the decimal form of its label). Same id assignment. */
+int gvs_graph_load_labels(gvs_graph *g, const uint32_t *u_labels, const uint32_t *v_labels, const float *weights,
+                          size_t n, int as_undirected, int normalization);
+int gvs_graph_save(const gvs_graph *g, const char *file_name, int weighted, int anonymous);
+
+uint32_t gvs_graph_num_vertex(const gvs_graph *g);
+uint64_t gvs_graph_num_edge(const gvs_graph *g);          /* input lines, as the reference counts */
+uint64_t gvs_graph_num_directed_edge(const gvs_graph *g); /* flattened entries (about 2x when undirected) */
+int gvs_graph_as_undirected(const gvs_graph *g);
+int gvs_graph_normalization(const gvs_graph *g);
+int64_t gvs_graph_name2id(const gvs_graph *g, const char *name); /* -1 when absent */
+/* Writes the NUL-terminated name into buf (truncated to buflen - 1); returns its full length, or -1. */
+int64_t gvs_graph_id2name(const gvs_graph *g, uint32_t id, char *buf, size_t buflen);
+
+/* Flattened (CSR) views, valid until the graph is reloaded or destroyed:
+ *   edges_uv [2 * D] = {u, v} in vertex order then insertion order; edge_weights [D]; flat_offsets [N + 1];
+ *   vertex_weights [N] (weighted out-degree; after normalisation the normalised sums). */
+const uint32_t *gvs_graph_edges(const gvs_graph *g);
+const float *gvs_graph_edge_weights(const gvs_graph *g);
+const uint64_t *gvs_graph_flat_offsets(const gvs_graph *g);
+const float *gvs_graph_vertex_weights(const gvs_graph *g);
+
+/* ---- partition / schedule ------------------------------------------------------------------------------ */
+
+/* Sort vertices by weight descending (ties: ascending id — the reference leaves ties to std::sort), deal them
+ * zig-zag over P parts.  part[v], local[v] = position inside its part, part_sizes[P]. */
+int gvs_partition(const float *weights, uint32_t n, int num_partition, int32_t *part, uint32_t *local,
+                  uint32_t *part_sizes);
+/* out[(step * W + worker) * 2 + {0, 1}] = {head partition, tail partition}; returns the number of steps
+ * ((P / W)^2 * W, or 1 when P == 1), or a negative error.  P must be a multiple of W. */
+int gvs_schedule(int num_partition, int num_worker, int32_t *out, size_t out_len);
+
+/* ---- samplers ---------------------------------------------------------------------------------------------- */
+
+#define GVS_MODE_EDGE 0        /* SamplerMixin::sample: every model when augmentation_step == 1 */
+#define GVS_MODE_WALK 1        /* sample_random_walk: DeepWalk, and LINE when augmentation_step > 1 */
+#define GVS_MODE_BIASED_WALK 2 /* sample_biased_random_walk: node2vec */
+
+/* The graph must outlive the sampler (the reference borrows it the same way, solver.h:289).  part / local are
+ * copied.  Builds the edge alias table over the flattened edge weights. */
+gvs_sampler *gvs_sampler_create(const gvs_graph *g, const int32_t *part, const uint32_t *local, int num_partition,
+                                uint64_t seed);
+void gvs_sampler_destroy(gvs_sampler *s);
+
+/* Builds what `mode` needs with num_thread threads: per-vertex alias tables (WALK) or node2vec per-edge tables
+ * with return parameter p and in-out parameter q (BIASED_WALK; sum of deg^2 entries). */
+int gvs_sampler_prepare(gvs_sampler *s, int mode, float p, float q, int num_thread);
+
+typedef struct {
+    int mode;
+    int num_thread;         /* sampler threads; thread t fills slice [t*L, min((t+1)*L, pool_size)), L = ceil(pool_size / T) */
+    int sample_batch_size;  /* EDGE: edges drawn per inner round (reference: walk_length * walk_batch) */
+    int walk_length;        /* WALK modes */
+    int walk_batch;         /* walks per inner round */
+    int augmentation_step;
+    int shuffle_base;       /* pseudo shuffle; pool_size % shuffle_base must be 0 */
+    int tail_partition;     /* -1: fill all P*P block pools; r >= 0: only the blocks (*, r) — one GPU's column */
+} gvs_fill_config;
+
+/* pools[hp * P + tp] -> pool_size {tail, head} records (entries of unfilled blocks may be NULL).
+ * Blocks until every requested block pool is full.  Stream positions advance across calls. */
+int gvs_sampler_fill(gvs_sampler *s, uint32_t *const *pools, uint64_t pool_size, const gvs_fill_config *config);
+
+/* Introspection for tests: position (doubles consumed) of stream t; the built tables. */
+uint64_t gvs_sampler_stream_position(const gvs_sampler *s, int thread);
+int gvs_sampler_set_stream_position(gvs_sampler *s, int thread, uint64_t position);
+const float *gvs_sampler_edge_prob(const gvs_sampler *s);
+const uint64_t *gvs_sampler_edge_alias(const gvs_sampler *s);
+const float *gvs_sampler_neighbor_prob(const gvs_sampler *s);      /* WALK: [D]; BIASED: [sum deg^2] */
+const uint32_t *gvs_sampler_neighbor_alias(const gvs_sampler *s);
+const uint64_t *gvs_sampler_edge_edge_offsets(const gvs_sampler *s); /* BIASED: [D + 1] */
+
+/* The host uniform stream itself (RNG contract), for hosts that want to reproduce a fill. */
+void gvs_host_uniforms(uint64_t seed, uint32_t stream, uint64_t first, size_t n, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GVS_H_ */

@@ -1,0 +1,242 @@
+"""-m gpu: the HIP kernels (through the C ABI, graphvite_amd/libgvk.so) against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from graphvite_amd import kernels as K
+from oracle_lib import ADAGRAD, ADAM, MOMENTUM, RMSPROP, SGD
+from util import conflict_free_batch, init_tables, power_law_weights, random_batch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+# fp32 tolerance of the parity protocol: only the dot-product summation order and
+# FMA contraction differ between the wave64 kernel and the sequential oracle.
+RTOL, ATOL = 1e-5, 1e-7
+
+OPTS = {
+    "SGD": (SGD, K.OptimizerSpec("SGD", 0.025, 0.005), (0, 0, 0)),
+    "Momentum": (MOMENTUM, K.OptimizerSpec("Momentum", 0.025, 0.005, hp0=0.9), (0.9, 0, 0)),
+    "AdaGrad": (ADAGRAD, K.OptimizerSpec("AdaGrad", 0.025, 0.005, epsilon=1e-10), (0, 0, 1e-10)),
+    "RMSprop": (RMSPROP, K.OptimizerSpec("RMSprop", 0.025, 0.005, hp0=0.99, epsilon=1e-8), (0.99, 0, 1e-8)),
+    "Adam": (ADAM, K.OptimizerSpec("Adam", 0.025, 0.005, hp0=0.9, hp1=0.99, epsilon=1e-8), (0.9, 0.99, 1e-8)),
+}
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.view(dtype)
+    return t.to(DEV)
+
+
+def run_hip(hip, v, c, pairs, negs, spec, neg_weight, moments=None, **kw):
+    tv, tc = dev(v), dev(c)
+    tm = None if moments is None else [None if m is None else dev(m) for m in moments]
+    tp = dev(pairs.view(np.int32))
+    tn = None if negs is None else dev(negs.view(np.int32))
+    loss = torch.zeros(pairs.shape[0], dtype=torch.float32, device=DEV)
+    k = kw.pop("k", 0 if negs is None else negs.shape[1])
+    hip.train(tv, tc, tp, loss, spec, k, neg_weight, negatives=tn, moments=tm, **kw)
+    torch.cuda.synchronize()
+    out_m = None if tm is None else [None if m is None else m.cpu().numpy() for m in tm]
+    return tv.cpu().numpy(), tc.cpu().numpy(), loss.cpu().numpy(), out_m
+
+
+@pytest.mark.parametrize("dim", [32, 64, 96, 128, 256, 512])
+@pytest.mark.parametrize("k", [0, 1, 3])
+def test_sgd_conflict_free_matches_oracle(hip, oracle, dim, k):
+    rng = np.random.default_rng(dim * 10 + k)
+    N, B = 4096, 777
+    v, c = init_tables(rng, N, N, dim)
+    v *= 20  # logits away from 0 so that sigmoid / log are exercised off the linear regime
+    c *= 20
+    pairs, negs = conflict_free_batch(rng, N, N, B, k)
+    ov, oc = v.copy(), c.copy()
+    oloss = oracle.train(ov, oc, pairs, negs, 0.025, 0.005, 5.0)
+    hv, hc, hloss, _ = run_hip(hip, v, c, pairs, negs if k else None, OPTS["SGD"][1], 5.0, k=k)
+    np.testing.assert_allclose(hv, ov, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(hc, oc, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(hloss, oloss, rtol=RTOL, atol=1e-6)
+    # rows no pair touched are bit-identical
+    touched_v = np.zeros(N, bool)
+    touched_v[pairs[:, 1]] = True
+    assert (hv[~touched_v] == v[~touched_v]).all()
+
+
+@pytest.mark.parametrize("name", ["Momentum", "AdaGrad", "RMSprop", "Adam"])
+@pytest.mark.parametrize("dim", [96, 128])
+def test_moment_optimizers_match_oracle(hip, oracle, name, dim):
+    opt_id, spec, hp = OPTS[name]
+    rng = np.random.default_rng(7)
+    N, B, k = 2048, 500, 2
+    v, c = init_tables(rng, N, N, dim)
+    v *= 20
+    c *= 20
+    nm = spec.num_moment
+    moments = [rng.uniform(0, 1e-3, (N, dim)).astype(np.float32) if i < 2 * nm else None for i in range(4)]
+    pairs, negs = conflict_free_batch(rng, N, N, B, k)
+    ov, oc, om = v.copy(), c.copy(), [None if m is None else m.copy() for m in moments]
+    oloss = oracle.train(ov, oc, pairs, negs, spec.lr, spec.weight_decay, 5.0, opt_id, om, hp)
+    hv, hc, hloss, hm = run_hip(hip, v, c, pairs, negs, spec, 5.0, moments=moments)
+    # sqrt / divide chains amplify the last-bit differences of the dot product a little more than SGD
+    np.testing.assert_allclose(hv, ov, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(hc, oc, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(hloss, oloss, rtol=1e-5, atol=1e-6)
+    for a, b in zip(hm, om):
+        if a is not None:
+            np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-8)  # moments pass through zero
+
+
+@pytest.mark.parametrize("lanes", [8, 16, 32, 64])
+def test_lane_group_variants_agree(hip, oracle, lanes):
+    rng = np.random.default_rng(lanes)
+    N, B, k, dim = 4096, 1000, 1, 128
+    v, c = init_tables(rng, N, N, dim)
+    v *= 20
+    c *= 20
+    pairs, negs = conflict_free_batch(rng, N, N, B, k)
+    ov, oc = v.copy(), c.copy()
+    oloss = oracle.train(ov, oc, pairs, negs, 0.025, 0.005, 5.0)
+    hip.set_lanes_per_pair(lanes)
+    try:
+        hv, hc, hloss, _ = run_hip(hip, v, c, pairs, negs, OPTS["SGD"][1], 5.0)
+    finally:
+        hip.set_lanes_per_pair(0)
+    np.testing.assert_allclose(hv, ov, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(hc, oc, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(hloss, oloss, rtol=RTOL, atol=1e-6)
+
+
+def test_pair_sees_its_own_negative_update(hip, oracle):
+    """negative == positive tail (and repeated negatives): the pair must read its own updated row, as the
+    reference's sequential warp does (include/instance/gpu/graph.cuh:62-88)."""
+    rng = np.random.default_rng(3)
+    N, B, k, dim = 1024, 100, 3, 128
+    v, c = init_tables(rng, N, N, dim)
+    v *= 30
+    c *= 30
+    pairs, negs = conflict_free_batch(rng, N, N, B, k)
+    negs[:, 2] = pairs[:, 0]      # last negative is the tail itself
+    negs[::2, 1] = negs[::2, 0]   # adjacent duplicate negatives
+    ov, oc = v.copy(), c.copy()
+    oloss = oracle.train(ov, oc, pairs, negs, 0.025, 0.005, 5.0)
+    hv, hc, hloss, _ = run_hip(hip, v, c, pairs, negs, OPTS["SGD"][1], 5.0)
+    np.testing.assert_allclose(hv, ov, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(hc, oc, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(hloss, oloss, rtol=RTOL, atol=1e-6)
+
+
+def test_negative_draw_bit_exact(hip, oracle):
+    """The on-device draw is integer work: bit-exact against the oracle's restatement of the RNG contract."""
+    rng = np.random.default_rng(11)
+    w = power_law_weights(rng, 5000)
+    prob, alias, packed = K.alias_build(w)
+    table = K.packed_to_device(packed, DEV)
+    B, k, seed, batch_id = 300, 5, 0x1234567890ABCDEF, 77
+    out = torch.zeros(B * k, dtype=torch.int32, device=DEV)
+    hip.negative_draw(table, seed, batch_id, out, B, k)
+    got = out.cpu().numpy().view(np.uint32).reshape(B, k)
+    want = oracle.negatives(prob, alias, seed, batch_id, B, k)
+    assert (got == want).all()
+
+
+def test_fused_draw_equals_explicit_negatives(hip, oracle):
+    """gvk_train with negatives == NULL trains on exactly the negatives gvk_negative_draw reports."""
+    rng = np.random.default_rng(12)
+    N, B, k, dim = 3000, 512, 2, 128
+    v, c = init_tables(rng, N, N, dim)
+    pairs, _ = random_batch(rng, N, N, B, k)
+    pairs[:, 1] = rng.permutation(N)[:B]  # distinct heads; context conflicts remain (Hogwild)
+    prob, alias, packed = K.alias_build(power_law_weights(rng, N))
+    table = K.packed_to_device(packed, DEV)
+    seed, batch_id = 99, 5
+    negs = oracle.negatives(prob, alias, seed, batch_id, B, k)
+    # conflict-free subset check: compare against explicit-negative launch on the same data
+    tv1, tc1, tv2, tc2 = dev(v), dev(c), dev(v), dev(c)
+    tp = dev(pairs.view(np.int32))
+    l1 = torch.zeros(B, device=DEV)
+    l2 = torch.zeros(B, device=DEV)
+    spec = OPTS["SGD"][1]
+    hip.train(tv1, tc1, tp, l1, spec, k, 5.0, table=table, seed=seed, batch_id=batch_id)
+    hip.train(tv2, tc2, tp, l2, spec, k, 5.0, negatives=dev(negs.view(np.int32)))
+    torch.cuda.synchronize()
+    # vertex rows have distinct heads -> deterministic up to context races; losses are per-sample forward values
+    np.testing.assert_allclose(l1.cpu().numpy(), l2.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(tv1.cpu().numpy(), tv2.cpu().numpy(), rtol=1e-3, atol=1e-6)
+
+
+def test_alias_sample_matches_reference_semantics(hip, oracle):
+    rng = np.random.default_rng(13)
+    prob, alias, packed = K.alias_build(power_law_weights(rng, 1000))
+    table = K.packed_to_device(packed, DEV)
+    n = 4096
+    rand = rng.random(2 * n)
+    out = torch.zeros(n, dtype=torch.int32, device=DEV)
+    hip.alias_sample(table, dev(rand), out)
+    got = out.cpu().numpy().view(np.uint32)
+    want = np.array([oracle.alias_sample_gpu(prob, alias, rand[2 * i], rand[2 * i + 1]) for i in range(n)])
+    assert (got == want).all()
+
+
+@pytest.mark.parametrize("dim", [32, 64, 96, 128, 256, 512])
+def test_predict_matches_oracle(hip, oracle, dim):
+    rng = np.random.default_rng(dim)
+    N, B = 2000, 3333
+    v, c = init_tables(rng, N, N, dim)
+    pairs, _ = random_batch(rng, N, N, B, 0)
+    logits = torch.zeros(B, device=DEV)
+    hip.predict(dev(v), dev(c), dev(pairs.view(np.int32)), logits)
+    np.testing.assert_allclose(logits.cpu().numpy(), oracle.predict(v, c, pairs), rtol=1e-5, atol=1e-8)
+
+
+def test_hogwild_batch_statistics(hip, oracle):
+    """Arbitrary batch with conflicts (T2): batch-mean loss and row norms track the sequential oracle."""
+    rng = np.random.default_rng(21)
+    N, B, k, dim = 2000, 20000, 1, 128
+    v, c = init_tables(rng, N, N, dim)
+    v *= 10
+    c *= 10
+    pairs, negs = random_batch(rng, N, N, B, k)
+    ov, oc = v.copy(), c.copy()
+    oloss = oracle.train(ov, oc, pairs, negs, 0.025, 0.005, 5.0)
+    hv, hc, hloss, _ = run_hip(hip, v, c, pairs, negs, OPTS["SGD"][1], 5.0)
+    assert abs(hloss.mean() - oloss.mean()) <= 1e-3 * abs(oloss.mean())
+    assert abs(np.linalg.norm(hv) - np.linalg.norm(ov)) <= 1e-2 * np.linalg.norm(ov)
+    assert abs(np.linalg.norm(hc) - np.linalg.norm(oc)) <= 1e-2 * np.linalg.norm(oc)
+
+
+def test_empty_and_ragged_batches(hip, oracle):
+    rng = np.random.default_rng(5)
+    N, dim = 512, 128
+    v, c = init_tables(rng, N, N, dim)
+    spec = OPTS["SGD"][1]
+    # empty batch: nothing happens, no error
+    tv, tc = dev(v), dev(c)
+    hip.train(tv, tc, torch.zeros((0, 2), dtype=torch.int32, device=DEV), torch.zeros(1, device=DEV), spec, 1, 5.0,
+              negatives=torch.zeros(0, dtype=torch.int32, device=DEV))
+    torch.cuda.synchronize()
+    assert (tv.cpu().numpy() == v).all() and (tc.cpu().numpy() == c).all()
+    # batch sizes that do not fill a wavefront / a block
+    for B in (1, 3, 63, 65, 257):
+        pairs, negs = conflict_free_batch(rng, N, N, B, 1)
+        ov, oc = v.copy(), c.copy()
+        oloss = oracle.train(ov, oc, pairs, negs, 0.025, 0.005, 5.0)
+        hv, hc, hloss, _ = run_hip(hip, v, c, pairs, negs, spec, 5.0)
+        np.testing.assert_allclose(hv, ov, rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(hc, oc, rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(hloss, oloss, rtol=RTOL, atol=1e-6)
+
+
+def test_errors_are_returned_not_aborted(hip):
+    v = torch.zeros((8, 100), device=DEV)  # dim 100 is not instantiated
+    with pytest.raises(ValueError):
+        hip.train(v, v.clone(), torch.zeros((1, 2), dtype=torch.int32, device=DEV), torch.zeros(1, device=DEV),
+                  OPTS["SGD"][1], 0, 5.0)
+    v = torch.zeros((8, 128), device=DEV)
+    with pytest.raises(ValueError):  # negatives requested but no source
+        hip.train(v, v.clone(), torch.zeros((1, 2), dtype=torch.int32, device=DEV), torch.zeros(1, device=DEV),
+                  OPTS["SGD"][1], 1, 5.0)
+    with pytest.raises(ValueError):  # Adam without moment tables
+        hip.train(v, v.clone(), torch.zeros((1, 2), dtype=torch.int32, device=DEV), torch.zeros(1, device=DEV),
+                  OPTS["Adam"][1], 0, 5.0)
