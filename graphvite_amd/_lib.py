@@ -32,6 +32,15 @@ class NegativeSource(C.Structure):
     _fields_ = [("negatives", C.c_void_p), ("table", C.c_void_p), ("count", C.c_uint32), ("seed", C.c_uint64)]
 
 
+class FillConfig(C.Structure):
+    _fields_ = [("mode", C.c_int), ("num_thread", C.c_int), ("sample_batch_size", C.c_int), ("walk_length", C.c_int),
+                ("walk_batch", C.c_int), ("augmentation_step", C.c_int), ("shuffle_base", C.c_int),
+                ("tail_partition", C.c_int)]
+
+
+MODE_EDGE, MODE_WALK, MODE_BIASED_WALK = 0, 1, 2
+
+
 class NativeLibraryError(RuntimeError):
     pass
 
@@ -73,6 +82,60 @@ def lib():
     l.gvk_set_tuning.argtypes = [i32, i32]
     l.gvk_last_error.restype = C.c_char_p
     l.gvk_version.restype = C.c_char_p
+    # ---- host runtime (include/gvs.h) ----
+    sz, i64, f = C.c_size_t, C.c_int64, C.c_float
+    cp = C.c_char_p
+    l.gvs_graph_create.restype = vp
+    l.gvs_graph_destroy.argtypes = [vp]
+    l.gvs_graph_destroy.restype = None
+    l.gvs_graph_load_file.restype = i32
+    l.gvs_graph_load_file.argtypes = [vp, cp, i32, i32, cp, cp]
+    l.gvs_graph_load_names.restype = i32
+    l.gvs_graph_load_names.argtypes = [vp, P(cp), P(cp), vp, sz, i32, i32]
+    l.gvs_graph_load_labels.restype = i32
+    l.gvs_graph_load_labels.argtypes = [vp, vp, vp, vp, sz, i32, i32]
+    l.gvs_graph_save.restype = i32
+    l.gvs_graph_save.argtypes = [vp, cp, i32, i32]
+    l.gvs_graph_num_vertex.restype = u32
+    l.gvs_graph_num_vertex.argtypes = [vp]
+    l.gvs_graph_num_edge.restype = u64
+    l.gvs_graph_num_edge.argtypes = [vp]
+    l.gvs_graph_num_directed_edge.restype = u64
+    l.gvs_graph_num_directed_edge.argtypes = [vp]
+    l.gvs_graph_as_undirected.restype = i32
+    l.gvs_graph_as_undirected.argtypes = [vp]
+    l.gvs_graph_normalization.restype = i32
+    l.gvs_graph_normalization.argtypes = [vp]
+    l.gvs_graph_name2id.restype = i64
+    l.gvs_graph_name2id.argtypes = [vp, cp]
+    l.gvs_graph_id2name.restype = i64
+    l.gvs_graph_id2name.argtypes = [vp, u32, vp, sz]
+    for name in ("edges", "edge_weights", "flat_offsets", "vertex_weights"):
+        fn = getattr(l, "gvs_graph_" + name)
+        fn.restype = vp
+        fn.argtypes = [vp]
+    l.gvs_partition.restype = i32
+    l.gvs_partition.argtypes = [vp, u32, i32, vp, vp, vp]
+    l.gvs_schedule.restype = i32
+    l.gvs_schedule.argtypes = [i32, i32, vp, sz]
+    l.gvs_sampler_create.restype = vp
+    l.gvs_sampler_create.argtypes = [vp, vp, vp, i32, u64]
+    l.gvs_sampler_destroy.restype = None
+    l.gvs_sampler_destroy.argtypes = [vp]
+    l.gvs_sampler_prepare.restype = i32
+    l.gvs_sampler_prepare.argtypes = [vp, i32, f, f, i32]
+    l.gvs_sampler_fill.restype = i32
+    l.gvs_sampler_fill.argtypes = [vp, P(vp), u64, P(FillConfig)]
+    l.gvs_sampler_stream_position.restype = u64
+    l.gvs_sampler_stream_position.argtypes = [vp, i32]
+    l.gvs_sampler_set_stream_position.restype = i32
+    l.gvs_sampler_set_stream_position.argtypes = [vp, i32, u64]
+    for name in ("edge_prob", "edge_alias", "neighbor_prob", "neighbor_alias", "edge_edge_offsets"):
+        fn = getattr(l, "gvs_sampler_" + name)
+        fn.restype = vp
+        fn.argtypes = [vp]
+    l.gvs_host_uniforms.restype = None
+    l.gvs_host_uniforms.argtypes = [u64, u32, u64, sz, vp]
     _lib = l
     return l
 

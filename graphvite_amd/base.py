@@ -1,0 +1,82 @@
+"""Constants and small helpers shared by the package (the reference's libgraphvite module level:
+src/graphvite.cu:62-105, include/bind.h:53-76, include/util/io.h)."""
+import enum
+import logging
+
+auto = 0  # kAuto, include/util/common.h:29
+
+logger = logging.getLogger("graphvite_amd")
+
+
+class dtype(enum.IntEnum):
+    uint32 = 0
+    uint64 = 1
+    float32 = 2
+    float64 = 3
+
+
+# typeid(T).name() under the Itanium ABI, which is what the reference's template names are built from
+dtype2name = {dtype.uint32: "j", dtype.uint64: "m", dtype.float32: "f", dtype.float64: "d"}
+
+uint32, uint64, float32, float64 = dtype.uint32, dtype.uint64, dtype.float32, dtype.float64
+
+
+def KiB(x):
+    return x << 10
+
+
+def MiB(x):
+    return x << 20
+
+
+def GiB(x):
+    return x << 30
+
+
+class io(object):
+    """pretty-printing helpers bound as libgraphvite.io (include/util/io.h:41-103)."""
+
+    kBlockWidth = 40
+
+    @staticmethod
+    def size_string(size):
+        size = float(size)
+        if size >= 1 << 40:
+            return "%.3g TiB" % (size / (1 << 40))
+        if size >= 1 << 30:
+            return "%.3g GiB" % (size / (1 << 30))
+        if size >= 1 << 20:
+            return "%.3g MiB" % (size / (1 << 20))
+        if size >= 1 << 10:
+            return "%.3g KiB" % (size / (1 << 10))
+        return "%d B" % int(size)
+
+    @staticmethod
+    def yes_no(x):
+        return "yes" if x else "no"
+
+    @staticmethod
+    def block(content):
+        line = "<" * io.kBlockWidth
+        return "\n%s\n%s\n%s" % (line, content, ">" * io.kBlockWidth)
+
+    @staticmethod
+    def header(content):
+        pad = max(io.kBlockWidth - len(content) - 2, 0)
+        return "%s %s %s" % ("-" * (pad // 2), content, "-" * (pad - pad // 2))
+
+
+def init_logging(level=logging.INFO, dir="", verbose=False):
+    """Counterpart of graphvite.init_logging (python/graphvite/base.py:61-83)."""
+    logger.setLevel(level)
+    if not logger.handlers:
+        handler = logging.StreamHandler()
+        logger.addHandler(handler)
+    fmt = "%(levelname).1s %(asctime)s %(filename)s:%(lineno)d] %(message)s" if verbose else "%(message)s"
+    for handler in logger.handlers:
+        handler.setFormatter(logging.Formatter(fmt))
+    if dir:
+        import os
+        fh = logging.FileHandler(os.path.join(dir, "graphvite_amd.log"))
+        fh.setFormatter(logging.Formatter(fmt))
+        logger.addHandler(fh)
