@@ -68,8 +68,8 @@ def lib():
     l.gvk_train.restype = i32
     l.gvk_train.argtypes = [vp, i32, P(Optimizer), P(Tables), vp, P(NegativeSource), u32, vp, i32, i32, f32]
     l.gvk_train_episode.restype = i32
-    l.gvk_train_episode.argtypes = [vp, i32, P(Optimizer), i32, P(Tables), vp, P(NegativeSource), u32, u32, i32,
-                                    vp, i32, i32, f32]
+    l.gvk_train_episode.argtypes = [vp, i32, P(Optimizer), i32, P(Tables), vp, P(NegativeSource), u32, u32, u32,
+                                    i32, vp, i32, i32, f32]
     l.gvk_predict.restype = i32
     l.gvk_predict.argtypes = [vp, i32, vp, vp, vp, vp, i32]
     l.gvk_alias_sample.restype = i32

@@ -1,0 +1,216 @@
+"""GraphApplication: load -> build -> train -> evaluate -> save, the user-facing pipeline of the node-embedding
+path (python/graphvite/application/application.py:38-241, 244-453 in the reference).  Keyword arguments are
+forwarded verbatim to Graph.load / GraphSolver.build / GraphSolver.train, as the reference does."""
+import logging
+import pickle
+import re
+import time
+
+import numpy as np
+
+from .. import graph as graph_module
+from .. import solver as solver_module
+from ..base import auto, dtype, io
+
+logger = logging.getLogger("graphvite_amd")
+
+
+def _timed(func):
+    """@monitor.time of the reference (python/graphvite/util.py:148-167): logs the wall time of each stage."""
+    def wrapper(self, *args, **kwargs):
+        start = time.time()
+        result = func(self, *args, **kwargs)
+        logger.info("[time] %s.%s: %g s", type(self).__name__, func.__name__, time.time() - start)
+        return result
+    wrapper.__name__, wrapper.__doc__ = func.__name__, func.__doc__
+    return wrapper
+
+
+class ApplicationMixin(object):
+    """
+    General interface of graph applications.
+
+    Parameters:
+        dim (int): dimension of embeddings
+        gpus (list of int, optional): GPU ids, default is all GPUs (one process per GPU, see GraphSolver)
+        cpu_per_gpu (int, optional): number of CPU threads per GPU, default is all CPUs
+        gpu_memory_limit (int, optional): memory limit per GPU in bytes, default is all memory
+        float_type (dtype, optional): type of parameters
+        index_type (dtype, optional): type of graph indexes
+    """
+
+    def __init__(self, dim, gpus=[], cpu_per_gpu=auto, gpu_memory_limit=auto, float_type=dtype.float32,
+                 index_type=dtype.uint32):
+        self.dim, self.gpus, self.cpu_per_gpu = dim, list(gpus), cpu_per_gpu
+        self.gpu_memory_limit, self.float_type, self.index_type = gpu_memory_limit, float_type, index_type
+        self.set_format()
+
+    def get_graph(self, **kwargs):
+        raise NotImplementedError
+
+    def get_solver(self, **kwargs):
+        raise NotImplementedError
+
+    def set_format(self, delimiters=" \t\r\n", comment="#"):
+        """Set the format for parsing input data."""
+        self.delimiters, self.comment = delimiters, comment
+        self.pattern = re.compile("[%s]" % self.delimiters)
+
+    @_timed
+    def load(self, **kwargs):
+        """load(**kwargs): load a graph from file or Python object (arguments of Graph.load)."""
+        self.graph = self.get_graph(**kwargs)
+        if "file_name" in kwargs:
+            self.graph.load(delimiters=self.delimiters, comment=self.comment, **kwargs)
+        else:
+            self.graph.load(**kwargs)
+
+    @_timed
+    def build(self, **kwargs):
+        """build(**kwargs): build the solver from the graph (arguments of GraphSolver.build)."""
+        self.solver = self.get_solver(**kwargs)
+        self.solver.build(self.graph, **kwargs)
+
+    @_timed
+    def train(self, **kwargs):
+        """train(**kwargs): train embeddings with the solver (arguments of GraphSolver.train)."""
+        self.solver.train(**kwargs)
+
+    @_timed
+    def evaluate(self, task, **kwargs):
+        """evaluate(task, **kwargs): evaluate the learned embeddings on a downstream task; returns a dict."""
+        func_name = task.replace(" ", "_")
+        if not hasattr(self, func_name):
+            raise ValueError("Unknown task `%s`" % task)
+        logger.info(io.header(task))
+        result = getattr(self, func_name)(**kwargs)
+        if isinstance(result, dict):
+            for metric, value in sorted(result.items()):
+                logger.warning("%s: %g", metric, value)
+        return result
+
+    @_timed
+    def save_model(self, file_name, save_hyperparameter=False):
+        """Save the graph's name maps and the solver's embeddings with pickle (application.py:145-187)."""
+        logger.warning("save model to `%s`", file_name)
+        objects = {"graph": {"name2id": dict(self.graph.name2id), "id2name": list(self.graph.id2name)},
+                   "solver": {"vertex_embeddings": np.array(self.solver.vertex_embeddings),
+                              "context_embeddings": np.array(self.solver.context_embeddings)}}
+        if save_hyperparameter:
+            for name in ("model", "num_epoch", "num_partition", "num_negative", "batch_size", "episode_size",
+                         "augmentation_step", "random_walk_length", "shuffle_base", "p", "q", "positive_reuse",
+                         "negative_sample_exponent", "negative_weight"):
+                objects["solver"][name] = getattr(self.solver, name)
+        with open(file_name, "wb") as fout:
+            pickle.dump(objects, fout, protocol=pickle.HIGHEST_PROTOCOL)
+
+    @_timed
+    def load_model(self, file_name):
+        """Load embeddings saved by save_model into the (already built) solver, matching nodes by name."""
+        logger.warning("load model from `%s`", file_name)
+        with open(file_name, "rb") as fin:
+            objects = pickle.load(fin)
+        mapping = self.get_mapping(self.graph.id2name, objects["graph"]["name2id"])
+        self.solver.vertex_embeddings[:] = objects["solver"]["vertex_embeddings"][mapping]
+        self.solver.context_embeddings[:] = objects["solver"]["context_embeddings"][mapping]
+
+    def get_mapping(self, id2name, name2id):
+        mapping = []
+        for name in id2name:
+            if name not in name2id:
+                raise ValueError("Can't find the embedding for node `%s`" % name)
+            mapping.append(name2id[name])
+        return np.asarray(mapping, np.int64)
+
+    def tokenize(self, line):
+        comment_start = line.find(self.comment)
+        if comment_start != -1:
+            line = line[:comment_start]
+        return [t for t in self.pattern.split(line) if t]
+
+    def name_map(self, dicts, names):
+        """Map columns of names to ids, dropping the rows with an unknown name (application.py:216-236)."""
+        keep = [all(name in d for d, name in zip(dicts, row)) for row in zip(*names)]
+        return tuple([d[name] for name, k in zip(column, keep) if k] for d, column in zip(dicts, names))
+
+
+Application = ApplicationMixin
+
+
+class GraphApplication(ApplicationMixin):
+    """
+    Node embedding application (DeepWalk, LINE, node2vec).
+
+    Parameters:
+        dim (int): dimension of embeddings
+        gpus (list of int, optional): GPU ids, default is all GPUs
+        cpu_per_gpu (int, optional): number of CPU threads per GPU, default is all CPUs
+        float_type (dtype, optional): type of parameters
+        index_type (dtype, optional): type of graph indexes
+    """
+
+    def get_graph(self, **kwargs):
+        return graph_module.Graph(self.index_type)
+
+    def get_solver(self, **kwargs):
+        num_sampler_per_worker = auto if self.cpu_per_gpu == auto else self.cpu_per_gpu - 1
+        return solver_module.GraphSolver(self.dim, self.float_type, self.index_type, self.gpus,
+                                         num_sampler_per_worker, self.gpu_memory_limit)
+
+    def link_prediction(self, H=None, T=None, Y=None, file_name=None, filter_H=None, filter_T=None, filter_file=None):
+        """
+        Evaluate node embeddings on link prediction task: AUC of score = <vertex[h], context[t]>
+        (application.py:353-453; scores are computed with the solver's predict kernel).
+        """
+        if file_name:
+            if not (H is None and T is None and Y is None):
+                raise ValueError("Evaluation data and file should not be provided at the same time")
+            H, T, Y = [], [], []
+            with open(file_name, "r") as fin:
+                for line in fin:
+                    tokens = self.tokenize(line)
+                    if len(tokens) == 0:
+                        continue
+                    h, t, y = tokens
+                    H.append(h)
+                    T.append(t)
+                    Y.append(y)
+        if H is None or T is None or Y is None:
+            raise ValueError("Either evaluation data or file should be provided")
+        if filter_file:
+            if not (filter_H is None and filter_T is None):
+                raise ValueError("Filter data and file should not be provided at the same time")
+            filter_H, filter_T = [], []
+            with open(filter_file, "r") as fin:
+                for line in fin:
+                    tokens = self.tokenize(line)
+                    if len(tokens) == 0:
+                        continue
+                    h, t = tokens
+                    filter_H.append(h)
+                    filter_T.append(t)
+        elif filter_H is None:
+            filter_H, filter_T = [], []
+
+        name2id = self.graph.name2id
+        Y = [int(y) for y in Y]
+        new_H, new_T, new_Y = self.name_map((name2id, name2id, {0: 0, 1: 1}), ([str(h) for h in H],
+                                                                                [str(t) for t in T], Y))
+        logger.info("effective edges: %d / %d", len(new_H), len(H))
+        H, T, Y = new_H, new_T, new_Y
+        fH, fT = self.name_map((name2id, name2id), ([str(h) for h in filter_H], [str(t) for t in filter_T]))
+        logger.info("effective filter edges: %d / %d", len(fH), len(filter_H))
+        filters = set(zip(fH, fT))
+        keep = [(h, t, y) for h, t, y in zip(H, T, Y) if (h, t) not in filters]
+        logger.info("remaining edges: %d / %d", len(keep), len(H))
+        H = np.asarray([k[0] for k in keep], np.int64)
+        T = np.asarray([k[1] for k in keep], np.int64)
+        Y = np.asarray([k[2] for k in keep], np.int64)
+
+        score = self.solver.predict(np.stack([H, T], 1)) if len(H) else np.zeros(0, np.float32)
+        order = np.argsort(-score, kind="stable")
+        Y = Y[order]
+        hit = np.cumsum(Y)
+        total = int((Y == 0).sum()) * int((Y == 1).sum())
+        auc = float(hit[Y == 0].sum()) / total if total else float("nan")
+        return {"AUC": auc}

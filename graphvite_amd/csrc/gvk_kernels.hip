@@ -471,15 +471,15 @@ int gvk_train(void *stream, int dim, const gvk_optimizer *optimizer, const gvk_t
 
 int gvk_train_episode(void *stream, int dim, const gvk_optimizer *optimizer, int linear_schedule,
                       const gvk_tables *tables, const uint32_t *pairs, const gvk_negative_source *negative,
-                      uint32_t first_batch_id, uint32_t total_batches, int num_batches, float *loss,
-                      int batch_size, int num_negative, float negative_weight) {
+                      uint32_t first_batch_id, uint32_t batch_id_stride, uint32_t total_batches, int num_batches,
+                      float *loss, int batch_size, int num_negative, float negative_weight) {
     if (num_batches < 0) return fail(GVK_EINVAL, "gvk_train_episode: negative num_batches");
     int rc = validate_train(dim, optimizer, tables, pairs, negative, loss, batch_size, num_negative);
     if (rc <= 0) return rc;
     if (negative->negatives)
         return fail(GVK_EINVAL, "gvk_train_episode draws negatives on device; explicit negatives are per batch");
     for (int i = 0; i < num_batches; i++) {
-        const uint32_t id = first_batch_id + (uint32_t)i;
+        const uint32_t id = first_batch_id + (uint32_t)i * batch_id_stride;
         float scale = 1;
         if (linear_schedule) {  // optimizer.h:77-79
             scale = 1 - float(int(id)) / int(total_batches);

@@ -122,7 +122,7 @@ class HipKernels(object):
         _lib.check(rc, "gvk_train")
 
     def train_episode(self, vertex, context, pool, loss, optimizer, num_negative, negative_weight, table, seed,
-                      first_batch_id, total_batches, num_batches, batch_size, moments=None):
+                      first_batch_id, total_batches, num_batches, batch_size, moments=None, batch_id_stride=1):
         """num_batches consecutive batches of a device-resident pool (int32 [>= num_batches*batch_size, 2])."""
         dev = vertex.device
         tables = self._tables(vertex, context, moments)
@@ -134,7 +134,7 @@ class HipKernels(object):
         opt = optimizer.c_struct()
         rc = self.lib.gvk_train_episode(self._stream(vertex), vertex.shape[1], C.byref(opt),
                                         int(optimizer.schedule == "linear"), C.byref(tables), _ptr(pool),
-                                        C.byref(neg), first_batch_id, total_batches, num_batches, _ptr(loss),
+                                        C.byref(neg), first_batch_id, batch_id_stride, total_batches, num_batches, _ptr(loss),
                                         batch_size, num_negative, negative_weight)
         _lib.check(rc, "gvk_train_episode")
 

@@ -1,0 +1,552 @@
+"""graphvite_amd.solver — `GraphSolver`, the drop-in for graphvite.solver.GraphSolver
+(pyGraphSolver, include/bind.h:383-513; GraphSolver / SolverMixin / WorkerMixin, include/instance/graph.cuh:586-813,
+include/core/solver.h:87-888,1170-1623), redesigned for MI355X:
+
+  * one process per GPU.  A process IS one of the reference's workers; `torch.distributed` (RCCL over xGMI)
+    replaces the host-memory hub the reference moves partitions through (solver.h:1349-1428).
+  * 288 GB of HBM per GPU: every GPU keeps the WHOLE vertex table ([P][S][dim], partition-major) and the
+    context shard(s) of the tail partition(s) it owns for good, together with their negative alias tables.
+    Nothing is evicted, reloaded or rebuilt between schedule steps.
+  * a schedule step = every GPU trains its (head partition, tail partition) block from a sample pool that was
+    uploaded in one piece (no per-batch H2D), negatives drawn inside the kernel, lr applied per batch; then ONE
+    collective: all-gather of the head shards just trained.  The reference's per-step D2H + CPU scatter +
+    CPU gather + H2D is gone.
+  * CPU samplers (native threads, include/gvs.h) fill the next episode's pools while the GPU trains this one.
+
+Only torch tensors (device memory, streams) and torch.distributed are used from torch; all arithmetic is in
+libgvk.so.  There is no CPU training path: without a GPU, GraphSolver raises.
+"""
+import logging
+import math
+import os
+import threading
+
+import numpy as np
+import torch
+
+from . import hostlib
+from .base import auto, dtype, io, logger
+from .graph import Graph
+from .optimizer import SGD, Optimizer
+
+kMaxPartition = 16          # solver.h:51-57
+kMinBatchSize = int(1e4)
+kMaxNegativeWeight = 10
+kSamplePerVertex = 175
+kMinEpisodeSample = int(2e7)
+kExpectedDegree = 1600      # graph.cuh:55
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+class GraphSolver(object):
+    """
+    GraphSolver(dim, float_type=dtype.float32, index_type=dtype.uint32, device_ids=[], num_sampler_per_worker=auto,
+                gpu_memory_limit=auto)
+    Graph embedding solver.
+
+    Parameters:
+        dim (int): dimension of embeddings (32, 64, 96, 128, 256 or 512)
+        float_type (dtype): type of parameters (float32)
+        index_type (dtype): type of node indexes (uint32)
+        device_ids (list of int, optional): GPU ids, [] for auto.  One process drives ONE GPU; for several GPUs
+            launch one process per GPU (`python -m torch.distributed.run --nproc-per-node N ...`) — every
+            process constructs the same solver and `device_ids` then lists the GPUs of the whole job.
+        num_sampler_per_worker (int, optional): number of sampler threads per GPU
+        gpu_memory_limit (int, optional): memory limit for each GPU in bytes
+    """
+
+    available_dims = (32, 64, 96, 128, 256, 512)  # src/graphvite.cu:52-59
+    available_models = ("DeepWalk", "LINE", "node2vec")
+
+    def __init__(self, dim, float_type=dtype.float32, index_type=dtype.uint32, device_ids=(),
+                 num_sampler_per_worker=auto, gpu_memory_limit=auto, kernels=None, seed=0):
+        if dim not in self.available_dims or float_type != dtype.float32 or index_type != dtype.uint32:
+            raise AttributeError("Can't find an instantiation of GraphSolver with dim=%s, float_type=%s, "
+                                 "index_type=%s" % (dim, float_type, index_type))
+        self.dim = dim
+        dist = _dist()
+        self.num_worker = dist.get_world_size() if dist else 1
+        self.rank = dist.get_rank() if dist else 0
+        device_ids = list(device_ids)
+        if kernels is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("No GPU devices found (graphvite_amd has no CPU training path)")
+            from .kernels import HipKernels
+            kernels = HipKernels()
+            if device_ids and len(device_ids) != self.num_worker:
+                raise ValueError("%d GPUs requested but this job has %d process(es): graphvite_amd runs one process "
+                                 "per GPU — launch with `python -m torch.distributed.run --nproc-per-node %d`"
+                                 % (len(device_ids), self.num_worker, len(device_ids)))
+            local = int(os.environ.get("LOCAL_RANK", self.rank if dist else 0))
+            index = device_ids[self.rank] if device_ids else (local if dist else torch.cuda.current_device())
+            self.device = torch.device("cuda", index)
+        else:
+            self.device = torch.device(getattr(kernels, "device", "cpu"))
+        self.kernels = kernels
+        if num_sampler_per_worker == auto:
+            num_sampler_per_worker = max((os.cpu_count() or 1) // max(self._local_world(), 1) - 1, 1)
+        self.num_sampler_per_worker = int(num_sampler_per_worker)
+        self.num_sampler = self.num_sampler_per_worker * self.num_worker
+        self.gpu_memory_limit = gpu_memory_limit
+        self.gpu_memory_cost = 0
+        self.seed = seed
+        self.graph = None
+        self.batch_id = 0
+        self._sampler = None
+        self._device_state = None
+        self._predict_cache = None
+        self.vertex_embeddings = None
+        self.context_embeddings = None
+        # attributes the reference exposes read-only (bind.h:415-436)
+        self.num_partition = self.num_negative = self.episode_size = self.batch_size = 0
+        self.optimizer = None
+        self.negative_sample_exponent = self.negative_weight = 0.0
+        self.model = ""
+        self.num_epoch = 0
+        self.resume = False
+        self.augmentation_step = self.random_walk_length = self.random_walk_batch_size = self.shuffle_base = 0
+        self.p = self.q = 1.0
+        self.positive_reuse = 1
+        self.log_frequency = 1000
+
+    @staticmethod
+    def _local_world():
+        return int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+
+    # ------------------------------------------------------------------------------------------------ build
+    def build(self, graph, optimizer=auto, num_partition=auto, num_negative=1, batch_size=100000, episode_size=auto):
+        """
+        build(graph, optimizer=auto, num_partition=auto, num_negative=1, batch_size=100000, episode_size=auto)
+        Determine and allocate all resources for the solver.
+        """
+        if not isinstance(graph, Graph):
+            raise TypeError("graph must be a graphvite_amd.graph.Graph")
+        if graph.num_vertex == 0 or graph.num_directed_edge == 0:
+            raise ValueError("The graph is empty")
+        self.clear()
+        self.graph = graph
+        optimizer = Optimizer(optimizer)
+        if optimizer.type == "Default":  # solver.h:290-296
+            default = SGD(0.025, 5e-3)   # GraphSolver::get_default_optimizer, graph.cuh:634-636
+            if optimizer.init_lr > 0:
+                default.init_lr = default.lr = optimizer.init_lr
+            optimizer = default
+        self.optimizer = optimizer
+        self.num_vertex, self.num_edge = graph.num_vertex, graph.num_edge
+        self.num_moment = optimizer.num_moment
+        self.num_negative, self.batch_size = int(num_negative), int(batch_size)
+        if self.batch_size < 1 or self.num_negative < 0:
+            raise ValueError("batch_size must be positive and num_negative non-negative")
+        if self.batch_size < kMinBatchSize:
+            logger.warning("It is recommended to a minimum batch size of %d, but %d is specified",
+                           kMinBatchSize, self.batch_size)
+        self.batch_id = 0
+        W = self.num_worker
+        min_partition = W  # get_min_partition, non-tied (solver.h:269-276)
+        limit = self.gpu_memory_limit
+        if limit == auto:
+            limit = torch.cuda.mem_get_info(self.device)[0] if self.device.type == "cuda" else 1 << 62
+        if num_partition == auto:
+            num_partition = min_partition
+            while num_partition < kMaxPartition and self._memory_demand(num_partition) >= limit:
+                num_partition += min_partition
+        else:
+            if num_partition < min_partition:
+                raise ValueError("#partition should be no less than %d" % min_partition)
+            if num_partition % W:
+                raise ValueError("#partition (%d) must be a multiple of #worker (%d)" % (num_partition, W))
+            if num_partition > kMaxPartition:
+                logger.warning("It is recommended to use a maximum #partition of %d, but %d partitions are specified",
+                               kMaxPartition, num_partition)
+        self.num_partition = P = int(num_partition)
+        self.gpu_memory_limit = limit
+        self.gpu_memory_cost = self._memory_demand(P)
+        if self.gpu_memory_cost >= limit:
+            raise MemoryError("Can't satisfy the specified GPU memory limit")
+
+        # partitions (heads and tails are the same partition, solver.h:389-390)
+        self._part, self._local, self._part_sizes = hostlib.partition(graph.vertex_weights, P)
+        self._part_size = int(self._part_sizes.max())
+        order = np.argsort(self._part.astype(np.int64) * (1 << 32) + self._local, kind="stable")
+        starts = np.concatenate([[0], np.cumsum(self._part_sizes.astype(np.int64))]).astype(np.int64)
+        self._part_ids = [order[starts[p]:starts[p + 1]] for p in range(P)]  # global ids in local order
+        self._schedule = hostlib.schedule(P, W)
+        self._my_tails = sorted({int(step[self.rank][1]) for step in self._schedule})
+
+        if episode_size == auto:  # solver.h:426-436
+            expected = int(float(self.num_vertex) * kSamplePerVertex / P / self.batch_size)
+            expected = max(expected, 1)
+            if P == 1:
+                expected = max(expected, kMinEpisodeSample // self.batch_size)
+            episode_size = expected
+        self.episode_size = int(episode_size)
+        if self.episode_size < 1:
+            raise ValueError("episode_size must be positive")
+
+        # host embeddings: stable buffers, exposed as writable numpy views (bind.h:90-106)
+        self.vertex_embeddings = np.zeros((self.num_vertex, self.dim), np.float32)
+        self.context_embeddings = np.zeros((self.num_vertex, self.dim), np.float32)
+        self._moments_host = None
+        self._sampler = hostlib.Sampler(graph, self._part, self._local, P,
+                                        (self.seed + 0x9E3779B97F4A7C15 * (self.rank + 1)) & (2 ** 64 - 1))
+        self._sampler_mode = None
+
+    def _memory_demand(self, P):
+        """Bytes of HBM this design keeps resident per GPU with P partitions."""
+        S = (self.num_vertex + P - 1) // P
+        tails = max(P // self.num_worker, 1)
+        rows = P * S + tails * S
+        demand = rows * self.dim * 4 * (1 + self.num_moment)
+        demand += tails * S * 8                                   # negative alias tables
+        demand += self.batch_size * 4                             # loss
+        episode = self.episode_size if getattr(self, "episode_size", 0) else max(
+            int(float(self.num_vertex) * kSamplePerVertex / P / self.batch_size), 1)
+        demand += 2 * episode * self.batch_size * 8               # two device pool buffers
+        return demand
+
+    # ------------------------------------------------------------------------------------------------ info
+    def info(self):
+        lines = ["GraphSolver<%d, float32, uint32>" % self.dim, io.header("Resource"),
+                 "#worker: %d, #sampler: %d, #partition: %d" % (self.num_worker, self.num_sampler, self.num_partition),
+                 "tied weights: no, episode size: %d" % self.episode_size,
+                 "gpu memory limit: %s" % io.size_string(self.gpu_memory_limit if self.gpu_memory_limit else 0),
+                 "gpu memory cost: %s" % io.size_string(self.gpu_memory_cost), io.header("Sampling")]
+        if self.model == "LINE":
+            lines.append("augmentation step: %d, shuffle base: %d" % (self.augmentation_step, self.shuffle_base))
+        if self.model == "DeepWalk":
+            lines.append("augmentation step: %d" % self.augmentation_step)
+        if self.model == "node2vec":
+            lines.append("augmentation step: %d, p: %g, q: %g" % (self.augmentation_step, self.p, self.q))
+        lines += ["random walk length: %d" % self.random_walk_length,
+                  "random walk batch size: %d" % self.random_walk_batch_size,
+                  "#negative: %d, negative sample exponent: %g" % (self.num_negative, self.negative_sample_exponent),
+                  io.header("Training"), "model: %s" % self.model,
+                  self.optimizer.info() if self.optimizer else "optimizer: -",
+                  "#epoch: %d, batch size: %d" % (self.num_epoch, self.batch_size),
+                  "resume: %s" % io.yes_no(self.resume),
+                  "positive reuse: %d, negative weight: %g" % (self.positive_reuse, self.negative_weight)]
+        return "\n".join(lines)
+
+    __repr__ = info
+
+    # ------------------------------------------------------------------------------------------------ train
+    def train(self, model="LINE", num_epoch=2000, resume=False, augmentation_step=auto, random_walk_length=40,
+              random_walk_batch_size=100, shuffle_base=auto, p=1, q=1, positive_reuse=1,
+              negative_sample_exponent=0.75, negative_weight=5, log_frequency=1000):
+        """
+        train(model='LINE', num_epoch=2000, resume=False, augmentation_step=auto, random_walk_length=40,
+              random_walk_batch_size=100, shuffle_base=auto, p=1, q=1, positive_reuse=1,
+              negative_sample_exponent=0.75, negative_weight=5, log_frequency=1000)
+        Train node embeddings.
+        """
+        if self.graph is None:
+            raise RuntimeError("The model must be built on a graph first")
+        if model not in self.available_models:
+            raise ValueError("Invalid model `%s`" % model)
+        if augmentation_step == auto:  # graph.cuh:781-784
+            augmentation_step = int(math.log(kExpectedDegree) / math.log(float(self.num_edge) / self.num_vertex))
+        if shuffle_base == auto:
+            shuffle_base = augmentation_step
+        if model in ("DeepWalk", "node2vec"):
+            shuffle_base = 1
+        if augmentation_step < 1:
+            raise ValueError("`augmentation_step` should be a positive integer")
+        if augmentation_step > random_walk_length:
+            raise ValueError("`random_walk_length` should be no less than `augmentation_step`")
+        if positive_reuse < 1 or log_frequency < 1 or num_epoch < 0:
+            raise ValueError("positive_reuse / log_frequency must be positive and num_epoch non-negative")
+        if negative_weight > kMaxNegativeWeight:
+            logger.warning("It is recommended to a maximum negative weight of %d, but %g is specified",
+                           kMaxNegativeWeight, negative_weight)
+        self.model, self.num_epoch, self.resume = model, int(num_epoch), bool(resume)
+        self.augmentation_step, self.shuffle_base = int(augmentation_step), int(shuffle_base)
+        self.random_walk_length, self.random_walk_batch_size = int(random_walk_length), int(random_walk_batch_size)
+        self.p, self.q = float(p), float(q)
+        self.positive_reuse = int(positive_reuse)
+        self.negative_sample_exponent, self.negative_weight = float(negative_sample_exponent), float(negative_weight)
+        self.log_frequency = int(log_frequency)
+        self.sample_batch_size = self.random_walk_length * self.random_walk_batch_size  # graph.cuh:791
+        pool_size = self.episode_size * self.batch_size
+        if self.augmentation_step > 1 and pool_size % self.shuffle_base:
+            raise ValueError("Can't perform pseudo shuffle on %d elements by a shuffle base of %d. Try setting the "
+                             "episode size to a multiple of the shuffle base" % (pool_size, self.shuffle_base))
+
+        logger.warning(io.block(self.info()))
+        if not self.resume:
+            self._init_embeddings()
+            self.batch_id = 0
+        self.num_batch = self.batch_id + self.num_epoch * self.num_edge // self.batch_size  # solver.h:611
+        self._predict_cache = None
+
+        mode = "edge" if self.augmentation_step == 1 else ("biased_walk" if model == "node2vec" else "walk")
+        key = (mode, self.p, self.q)
+        if self._sampler_mode != key:  # get_sample_function, graph.cuh:680-721
+            self._sampler.prepare(mode, self.p, self.q, self.num_sampler_per_worker + 1)
+            self._sampler_mode = key
+        self._mode = mode
+
+        state = self._upload_state()
+        pools = self._host_pools()
+        try:
+            self._fill(pools[0])
+            current = 0
+            while self.batch_id < self.num_batch:  # solver.h:629-649 — one iteration = one episode
+                filler = threading.Thread(target=self._fill_guarded, args=(pools[current ^ 1],))
+                filler.start()
+                try:
+                    self._train_episode(state, pools[current])
+                finally:
+                    filler.join()
+                if self._fill_error is not None:
+                    raise self._fill_error
+                current ^= 1
+        finally:
+            self._write_back(state)
+
+    # ---- embeddings -------------------------------------------------------------------------------------
+    def _init_embeddings(self):
+        """vertex ~ U(-0.5/dim, 0.5/dim), context = 0 (GraphSolver::init_embeddings, graph.cuh:724-731).
+        The generator is seeded identically on every process so all ranks start from the same table."""
+        rng = np.random.default_rng(self.seed + 5489)
+        self.vertex_embeddings[:] = rng.uniform(-0.5 / self.dim, 0.5 / self.dim,
+                                                self.vertex_embeddings.shape).astype(np.float32)
+        self.context_embeddings[:] = 0
+        self._moments_host = None
+
+    def _to_device(self, array):
+        t = torch.from_numpy(np.ascontiguousarray(array))
+        return t.to(self.device, non_blocking=False)
+
+    def _upload_state(self):
+        """Partition-major device tables: vertex [P][S][dim] (all partitions), context [S][dim] per owned tail."""
+        P, S, dim = self.num_partition, self._part_size, self.dim
+        nm = self.num_moment
+
+        def gather(host, parts):
+            out = np.zeros((len(parts), S, dim), np.float32)
+            for i, p in enumerate(parts):
+                out[i, :len(self._part_ids[p])] = host[self._part_ids[p]]
+            return out
+
+        state = {"vertex": self._to_device(gather(self.vertex_embeddings, range(P))),
+                 "context": self._to_device(gather(self.context_embeddings, self._my_tails))}
+        if nm:
+            mh = self._moments_host if self.resume and self._moments_host is not None else None
+            for j in range(nm):
+                vm = gather(mh["vertex"][j], range(P)) if mh else np.zeros((P, S, dim), np.float32)
+                cm = gather(mh["context"][j], self._my_tails) if mh else np.zeros((len(self._my_tails), S, dim),
+                                                                                   np.float32)
+                state["vertex_m%d" % j] = self._to_device(vm)
+                state["context_m%d" % j] = self._to_device(cm)
+        # negative sampler per owned tail partition: deg^exponent in local order (solver.h:1264-1278)
+        from .kernels import alias_build, packed_to_device
+        weights = self.graph.vertex_weights
+        state["negative_tables"] = {}
+        for tp in self._my_tails:
+            w = np.power(weights[self._part_ids[tp]], np.float32(self.negative_sample_exponent)).astype(np.float32)
+            _, _, packed = alias_build(w)
+            state["negative_tables"][tp] = packed_to_device(packed, self.device)
+        state["loss"] = torch.zeros(self.batch_size, dtype=torch.float32, device=self.device)
+        pool_elems = self.episode_size * self.batch_size * 2
+        state["pool_dev"] = [torch.empty(pool_elems, dtype=torch.int32, device=self.device) for _ in range(2)]
+        if self.device.type == "cuda":
+            state["copy_stream"] = torch.cuda.Stream(self.device)
+        self._device_state = state
+        return state
+
+    def _host_pools(self):
+        """Two sets (double buffer) of pinned host pools, one per block this worker trains in an episode."""
+        pool_elems = self.episode_size * self.batch_size * 2
+        blocks = sorted({(int(step[self.rank][0]), int(step[self.rank][1])) for step in self._schedule})
+        pin = self.device.type == "cuda"
+        return [{b: torch.empty(pool_elems, dtype=torch.int32, pin_memory=pin) for b in blocks} for _ in range(2)]
+
+    # ---- sampling -----------------------------------------------------------------------------------------
+    def _fill(self, pools):
+        P = self.num_partition
+        tails = {tp for (_, tp) in pools}
+        pool_size = self.episode_size * self.batch_size
+        # this worker's blocks form whole columns (hp ranges over all partitions for each owned tail)
+        for tp in sorted(tails):
+            column = {(hp, tp): pools[(hp, tp)] for hp in range(P)}
+            self._sampler.fill(column, pool_size, self._mode, self.num_sampler_per_worker,
+                               sample_batch_size=self.sample_batch_size, walk_length=self.random_walk_length,
+                               walk_batch=self.random_walk_batch_size, augmentation_step=self.augmentation_step,
+                               shuffle_base=self.shuffle_base, tail_partition=tp if P > 1 else -1)
+
+    _fill_error = None
+
+    def _fill_guarded(self, pools):
+        self._fill_error = None
+        try:
+            self._fill(pools)
+        except BaseException as e:  # surfaced on the training thread
+            self._fill_error = e
+
+    # ---- one episode ----------------------------------------------------------------------------------------
+    def _train_episode(self, state, pools):
+        W, r = self.num_worker, self.rank
+        cuda = self.device.type == "cuda"
+        steps = [(int(s[r][0]), int(s[r][1])) for s in self._schedule]
+        # prefetch step 0's pool; afterwards step i + 1 is uploaded while step i trains
+        events = [None, None]
+
+        def upload(i):
+            buf = state["pool_dev"][i & 1]
+            if cuda:
+                with torch.cuda.stream(state["copy_stream"]):
+                    buf.copy_(pools[steps[i]], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                events[i & 1] = ev
+            else:
+                buf.copy_(pools[steps[i]])
+
+        if cuda:  # the previous episode's kernels may still be reading the buffers
+            state["copy_stream"].wait_stream(torch.cuda.current_stream(self.device))
+        upload(0)
+        for i, (hp, tp) in enumerate(steps):
+            if cuda:
+                torch.cuda.current_stream(self.device).wait_event(events[i & 1])
+            if i + 1 < len(steps):
+                if cuda:
+                    state["copy_stream"].wait_stream(torch.cuda.current_stream(self.device))
+                upload(i + 1)
+            self._train_block(state, hp, tp, state["pool_dev"][i & 1])
+            if W > 1:
+                self._exchange(state, i)
+
+    def _tables(self, state, hp, tp):
+        ti = self._my_tails.index(tp)
+        moments = None
+        if self.num_moment:
+            moments = [None] * 4
+            for j in range(self.num_moment):
+                moments[2 * j] = state["vertex_m%d" % j][hp]
+                moments[2 * j + 1] = state["context_m%d" % j][ti]
+        return state["vertex"][hp], state["context"][ti], moments
+
+    def _train_block(self, state, hp, tp, pool):
+        """WorkerMixin::train (solver.h:1511-1522): positive_reuse x episode_size batches of one block."""
+        vertex, context, moments = self._tables(state, hp, tp)
+        table = state["negative_tables"][tp]
+        spec = self.optimizer.spec()
+        W, r, B = self.num_worker, self.rank, self.batch_size
+        native_schedule = self.optimizer.schedule.type in ("linear", "constant")
+        seed = (self.seed * 0x100000001B3 + r) & (2 ** 64 - 1)
+        for reuse in range(self.positive_reuse):
+            done = 0
+            while done < self.episode_size:
+                # this worker's batches carry ids first, first + W, ... (one shared counter, solver.h:1520)
+                first = self.batch_id + (reuse * self.episode_size + done) * W + r
+                if first % self.log_frequency == 0:  # solver.h:1527-1549 (the loss is the previous batch's)
+                    logger.info("Batch id: %d / %d", first, self.num_batch)
+                    logger.info("loss = %g", float(state["loss"].mean().item()))
+                # run up to, not including, this worker's next logging batch
+                n = 1
+                while n < self.episode_size - done and (first + n * W) % self.log_frequency:
+                    n += 1
+                if native_schedule:
+                    self.kernels.train_episode(vertex, context, pool[done * B * 2:], state["loss"], spec,
+                                               self.num_negative, self.negative_weight, table, seed, first,
+                                               self.num_batch, n, B, moments=moments, batch_id_stride=W)
+                else:  # custom Python schedule: lr computed on the host per batch (optimizer.h:132-134)
+                    for b in range(n):
+                        bid = first + b * W
+                        lr = self.optimizer.init_lr * self.optimizer.schedule(bid, self.num_batch)
+                        self.kernels.train(vertex, context, pool[(done + b) * B * 2:(done + b + 1) * B * 2].view(B, 2),
+                                           state["loss"], spec, self.num_negative, self.negative_weight, table=table,
+                                           seed=seed, batch_id=bid, moments=moments, lr=lr)
+                done += n
+        self.batch_id += self.episode_size * self.positive_reuse * W
+
+    def _exchange(self, state, step_index):
+        """After a schedule step every worker has trained a different head partition: all-gather those shards so
+        that each GPU again holds the whole, current vertex table (RCCL over xGMI; gloo in the CPU tests)."""
+        import torch.distributed as dist
+        heads = [int(a[0]) for a in self._schedule[step_index]]
+        names = ["vertex"] + ["vertex_m%d" % j for j in range(self.num_moment)]
+        for name in names:
+            table = state[name]
+            outputs = [table[hp] for hp in heads]
+            dist.all_gather(outputs, table[heads[self.rank]].clone())
+
+    def _write_back(self, state):
+        """Device -> the stable host arrays behind the numpy views (WorkerMixin::write_back, solver.h:1498-1504).
+        Context shards (and context moments) of the other workers arrive by all-gather."""
+        if state is None:
+            return
+        import torch.distributed as dist
+        W, P = self.num_worker, self.num_partition
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
+        def scatter(host, dev, parts):
+            arr = dev.cpu().numpy()
+            for i, p in enumerate(parts):
+                host[self._part_ids[p]] = arr[i, :len(self._part_ids[p])]
+
+        def full_context(name):
+            mine = state[name]
+            if W == 1:
+                return mine, self._my_tails
+            gathered = [torch.empty_like(mine) for _ in range(W)]
+            dist.all_gather(gathered, mine)
+            tails = []
+            for rank in range(W):
+                tails += sorted({int(step[rank][1]) for step in self._schedule})
+            return torch.cat(gathered, 0), tails
+
+        scatter(self.vertex_embeddings, state["vertex"], range(P))
+        ctx, tails = full_context("context")
+        scatter(self.context_embeddings, ctx, tails)
+        if self.num_moment:
+            shape = (self.num_vertex, self.dim)
+            self._moments_host = {"vertex": [np.zeros(shape, np.float32) for _ in range(self.num_moment)],
+                                  "context": [np.zeros(shape, np.float32) for _ in range(self.num_moment)]}
+            for j in range(self.num_moment):
+                scatter(self._moments_host["vertex"][j], state["vertex_m%d" % j], range(P))
+                cm, tails = full_context("context_m%d" % j)
+                scatter(self._moments_host["context"][j], cm, tails)
+        self._device_state = None
+
+    # ------------------------------------------------------------------------------------------------ predict
+    def predict(self, samples):
+        """
+        predict(samples)
+        Predict logits for samples.
+
+        Parameters:
+            samples (ndarray): pairs with shape (?, 2), each pair is ordered as (v, c)
+        """
+        samples = np.asarray(samples)
+        if samples.ndim != 2 or samples.shape[1] != 2:
+            raise ValueError("Expect an array with shape (?, 2), but shape %s is found" % (samples.shape,))
+        if self.vertex_embeddings is None:
+            raise RuntimeError("The model must be built on a graph first")
+        if samples.size and (samples.min() < 0 or samples.max() >= self.num_vertex):
+            raise ValueError("node index out of range")
+        if self._predict_cache is None:
+            self._predict_cache = (self._to_device(self.vertex_embeddings), self._to_device(self.context_embeddings))
+        vertex, context = self._predict_cache
+        n, B = samples.shape[0], max(self.batch_size, 1)
+        # records are {tail, head}: numpy columns (v, c) are reversed on the way in (solver.h:1127-1132)
+        pairs = self._to_device(np.ascontiguousarray(samples[:, ::-1].astype(np.uint32)).view(np.int32))
+        logits = torch.empty(n, dtype=torch.float32, device=self.device)
+        for start in range(0, n, B):
+            self.kernels.predict(vertex, context, pairs[start:start + B], logits[start:start + B])
+        return logits.cpu().numpy()
+
+    def clear(self):
+        """Free CPU and GPU memory, except the embeddings on CPU."""
+        self._device_state = None
+        self._predict_cache = None
+        self._sampler = None
+        self._sampler_mode = None
+        self._moments_host = None
+        if self.device.type == "cuda":
+            torch.cuda.empty_cache()

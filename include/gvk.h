@@ -102,13 +102,15 @@ int gvk_train(void *stream, int dim, const gvk_optimizer *optimizer, const gvk_t
               int batch_size, int num_negative, float negative_weight);
 
 /* `num_batches` consecutive batches from a device-resident pool: batch i uses pairs + i * batch_size * 2,
- * batch id first_batch_id + i, and lr = init_lr * schedule(first_batch_id + i, total_batches) where
- * schedule is max(1 - id / total, 1e-4) if linear_schedule else 1 (`optimizer->lr` is init_lr here).
- * loss [batch_size] is overwritten by every batch, as in the reference. One kernel launch per batch. */
+ * batch id = first_batch_id + i * batch_id_stride (the reference's workers draw ids from one shared atomic
+ * counter, solver.h:142,1520, so W concurrent workers see ids W apart), and
+ * lr = init_lr * schedule(id, total_batches) where schedule is max(1 - id / total, 1e-4) if linear_schedule
+ * else 1 (`optimizer->lr` is init_lr here).  loss [batch_size] is overwritten by every batch, as in the
+ * reference. One kernel launch per batch. */
 int gvk_train_episode(void *stream, int dim, const gvk_optimizer *optimizer, int linear_schedule,
                       const gvk_tables *tables, const uint32_t *pairs, const gvk_negative_source *negative,
-                      uint32_t first_batch_id, uint32_t total_batches, int num_batches, float *loss,
-                      int batch_size, int num_negative, float negative_weight);
+                      uint32_t first_batch_id, uint32_t batch_id_stride, uint32_t total_batches, int num_batches,
+                      float *loss, int batch_size, int num_negative, float negative_weight);
 
 /* logits[s] = dot(vertex[head_s], context[tail_s]) */
 int gvk_predict(void *stream, int dim, const float *vertex, const float *context, const uint32_t *pairs,

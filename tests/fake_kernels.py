@@ -1,0 +1,56 @@
+"""A stand-in for graphvite_amd.kernels.HipKernels that runs on CPU tensors by calling the ORACLE.
+
+TEST INFRASTRUCTURE ONLY: it lets the `-m "not gpu"` suite exercise the solver's host logic (partitioning,
+schedule, sampling, pool handling, batch-id / lr accounting, the all-gather exchange over gloo, write-back)
+without a GPU.  It is injected explicitly (`GraphSolver(..., kernels=OracleKernels())`); the product never
+imports it and has no CPU fallback of its own."""
+import numpy as np
+
+from oracle_lib import Oracle
+
+_OPT = {"SGD": 0, "Momentum": 1, "AdaGrad": 2, "RMSprop": 3, "Adam": 4}
+
+
+class OracleKernels(object):
+    name = "oracle"
+    device = "cpu"
+
+    def __init__(self):
+        self.oracle = Oracle()
+        self.launches = []  # (batch_id, lr) per batch, for accounting tests
+
+    @staticmethod
+    def _np(t):
+        return None if t is None else t.numpy()
+
+    def _negatives(self, table, seed, batch_id, B, k):
+        packed = table.numpy().view(np.dtype([("prob", np.float32), ("alias", np.uint32)]))
+        prob, alias = np.ascontiguousarray(packed["prob"]), np.ascontiguousarray(packed["alias"])
+        return self.oracle.negatives(prob, alias, seed, batch_id, B, k)
+
+    def train(self, vertex, context, pairs, loss, optimizer, num_negative, negative_weight, negatives=None,
+              table=None, seed=0, batch_id=0, moments=None, lr=None):
+        B = pairs.shape[0]
+        lr = optimizer.lr if lr is None else lr
+        negs = negatives.numpy().view(np.uint32).reshape(B, num_negative) if negatives is not None else \
+            self._negatives(table, seed, batch_id, B, num_negative)
+        m = None if moments is None else [self._np(x) for x in moments]
+        hp = (optimizer.hp0, optimizer.hp1, optimizer.epsilon)
+        out = self.oracle.train(vertex.numpy(), context.numpy(), np.ascontiguousarray(pairs.numpy().view(np.uint32)),
+                                np.ascontiguousarray(negs), lr, optimizer.weight_decay, negative_weight,
+                                _OPT[optimizer.type], m, hp)
+        loss.numpy()[:B] = out
+        self.launches.append((batch_id, lr))
+
+    def train_episode(self, vertex, context, pool, loss, optimizer, num_negative, negative_weight, table, seed,
+                      first_batch_id, total_batches, num_batches, batch_size, moments=None, batch_id_stride=1):
+        for i in range(num_batches):
+            bid = first_batch_id + i * batch_id_stride
+            scale = self.oracle.lr(1.0, optimizer.schedule == "linear", bid, total_batches)
+            pairs = pool[i * batch_size * 2:(i + 1) * batch_size * 2].view(batch_size, 2)
+            self.train(vertex, context, pairs, loss, optimizer, num_negative, negative_weight, table=table, seed=seed,
+                       batch_id=bid, moments=moments, lr=np.float32(optimizer.lr) * np.float32(scale))
+
+    def predict(self, vertex, context, pairs, logits):
+        out = self.oracle.predict(vertex.numpy(), context.numpy(), np.ascontiguousarray(pairs.numpy().view(np.uint32)))
+        logits.numpy()[:len(out)] = out
