@@ -1,21 +1,29 @@
 #!/usr/bin/env python
 """bench.py — million edge-samples/sec of the LINE dim-128 SGD hot path on N MI355X GPUs.
 
-A "step" is one batch (100 000 edge-samples, num_negative 1) of negative-sampling SGD per GPU on the synthetic
-power-law graph BASELINE.json's metric is quoted on (configs[1]: 1M nodes / 10M edges, dim 128, fp32, LINE),
-with the episode's sample pool, the alias table and both embedding tables resident in HBM when the timed
-region starts.  Negatives are drawn inside the kernel; the learning-rate schedule is applied per batch.
+A "step" is one batch (100 000 edge-samples, num_negative 1) of negative-sampling SGD PER GPU on the synthetic
+power-law graph BASELINE.json's metric is quoted on (configs[1]: 1M nodes / 10M edges, dim 128, fp32, LINE,
+augmentation_step 1), driven through the product path: Graph -> GraphSolver.build (degree partition, one
+partition per GPU) -> the native CPU edge sampler fills the block pools -> pools uploaded to HBM ->
+gvk_train_episode (negatives drawn in-kernel, lr schedule per batch).  With N > 1 each GPU owns context shard
+`rank`, trains block (head (rank + step) mod N, tail rank) for `--block-batches` batches, then all GPUs
+all-gather the head shards they just trained (RCCL over xGMI) — the exchange is inside the timed region.
 
     python bench.py [--steps K] [--warmup W]                                                     (N = 1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...      (N > 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W                                                    (N > 1)
 
-Rank 0 prints ONE JSON line.  `roofline` is for the training kernel (HBM-bound): achieved = algorithmic
-bytes per launch (3088 B per edge-sample at dim 128, k = 1) / average launch duration measured
-with HIP events on the launch stream over the timed region.  `cpu_baseline` times the reference's own host-
-compiled arithmetic (oracle/_ref, Hogwild over all host cores) on a bounded sample of the same batches.
+Rank 0 prints ONE JSON line.  The sample pools, alias tables and embedding tables are resident in HBM when
+the timed region starts (sampling is a CPU producer that runs concurrently in real training; its rate is
+reported separately as `sampler`).  `roofline` is for the training kernel (HBM-bound): achieved =
+algorithmic bytes per launch (3088 B per edge-sample at dim 128, k = 1) / the average launch
+duration measured with HIP events on the launch stream over the timed region.  `cpu_baseline` (N = 1, rank 0)
+times the reference's own host-compiled arithmetic (oracle/_ref, Hogwild over all host cores) on a bounded
+sample of the same batches.
 """
 import argparse
 import json
+import logging
 import os
 import sys
 import time
@@ -43,39 +51,50 @@ def parse():
     p.add_argument("--dim", type=int, default=128)
     p.add_argument("--batch", type=int, default=100000)
     p.add_argument("--negatives", type=int, default=1)
-    p.add_argument("--pool-batches", type=int, default=200, help="batches in the HBM-resident sample pool")
+    p.add_argument("--block-batches", type=int, default=50,
+                   help="batches per (head, tail) block pool = batches between two exchanges")
     p.add_argument("--lanes", type=int, default=0, help="A/B knob: lanes per pair (0 = per-dim default)")
+    p.add_argument("--sampler-threads", type=int, default=0, help="0 = host cores / GPUs")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=3.0, help="wall seconds given to the CPU baseline")
     p.add_argument("--seed", type=int, default=1024)
     return p.parse_args()
 
 
-def cpu_baseline(args, vertex, context, pool, negs):
-    """Reference arithmetic (oracle/_ref/libgvref_fast.so), Hogwild over all host cores, on the first batches
-    of the same pool.  Test/bench infrastructure: the product never loads it."""
+def cpu_baseline(args, solver, pool, table_packed):
+    """Reference arithmetic (oracle/_ref/libgvref_fast.so), Hogwild over all host cores, on the first batches of
+    rank 0's first block pool, starting from the same initial tables.  Bench infrastructure only."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import Reference
     try:
         ref = Reference(fast=True)
-        kind = "reference"
     except (FileNotFoundError, OSError):
         return None
     cores = os.cpu_count() or 1
-    v, c = vertex.copy(), context.copy()
+    B, k = args.batch, args.negatives
+    rng = np.random.default_rng(args.seed + 7)
+    prob, alias = np.ascontiguousarray(table_packed["prob"]), np.ascontiguousarray(table_packed["alias"])
+    n = len(solver._part_ids[0])
+    v = solver.vertex_embeddings[solver._part_ids[0]].copy()   # partition-local tables, like the GPU's
+    c = np.zeros_like(v)
+    nb = pool.shape[0] // B
+    negs = []
+    for _ in range(4):  # negatives from the same alias table (numpy, vectorised)
+        idx = rng.integers(0, n, (B, k))
+        u = rng.random((B, k)).astype(np.float32)
+        negs.append(np.where(u < prob[idx], idx, alias[idx]).astype(np.uint32))
     done, t0 = 0, time.perf_counter()
-    nb = pool.shape[0] // args.batch
     while True:
         b = done % nb
-        ref.train_mt(v, c, pool[b * args.batch:(b + 1) * args.batch], negs[b % len(negs)], 0.025, 0.005, 5.0, cores)
+        ref.train_mt(v, c, pool[b * B:(b + 1) * B], negs[done % len(negs)], 0.025, 0.005, 5.0, cores)
         done += 1
         el = time.perf_counter() - t0
         if el >= args.cpu_seconds and done >= 2:
             break
-    return {"value": done * args.batch / el / 1e6, "unit": "million edge-samples/sec", "cores": cores, "kind": kind,
-            "sample": "%d batches of %d edge-samples of the same pool (%.1f s wall, %d threads, Hogwild, "
-                      "-Ofast x86-64-v3 host build of the reference's LINE::forward/backward + sgd_update)"
-                      % (done, args.batch, el, cores)}
+    return {"value": done * B / el / 1e6, "unit": "million edge-samples/sec", "cores": cores, "kind": "reference",
+            "sample": "%d batches of %d edge-samples of rank 0's first block pool (%.1f s wall, %d threads, Hogwild; "
+                      "-Ofast x86-64-v3 host build of the reference's own LINE::forward/backward + sgd_update)"
+                      % (done, B, el, cores)}
 
 
 def main():
@@ -83,103 +102,122 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from graphvite_amd import kernels as K
-    from graphvite_amd import synthetic
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
-    if world > 1:
-        raise SystemExit("multi-GPU bench path lands with the episode-partitioned solver")
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with `python -m torch.distributed.run "
+                         "--nproc-per-node %d ... bench.py --gpus %d`" % (args.gpus, world, args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    hip = K.HipKernels()
-    if args.lanes:
-        hip.set_lanes_per_pair(args.lanes)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
 
-    # ---- synthetic workload (host) ----
+    import graphvite_amd as gv
+    from graphvite_amd import synthetic
+    gv.init_logging(logging.ERROR)
+
     N, E, B, k, dim = args.vertices, args.edges, args.batch, args.negatives, args.dim
-    edges = synthetic.power_law_edges(N, E, seed=args.seed)
-    deg = synthetic.degrees(edges, N)
-    # single partition: local id = rank in (degree desc, id asc) (SolverMixin::partition, solver.h:873-887)
-    order = np.lexsort((np.arange(N), -deg))
-    local = np.empty(N, np.uint32)
-    local[order] = np.arange(N, dtype=np.uint32)
-    rng = np.random.default_rng(args.seed + 1)
-    # LINE, augmentation_step 1: edges drawn with probability ∝ weight (unit weights -> uniform over the 2E
-    # directed edges); records are {tail, head}
-    n_pool = args.pool_batches * B
-    pick = rng.integers(0, E, n_pool)
-    flip = rng.integers(0, 2, n_pool).astype(bool)
-    head = np.where(flip, edges[pick, 1], edges[pick, 0])
-    tail = np.where(flip, edges[pick, 0], edges[pick, 1])
-    pool = np.stack([local[tail], local[head]], 1).astype(np.uint32)
-    neg_w = (deg[order] ** 0.75).astype(np.float32)  # solver.h:1264-1278, in partition (local id) order
-    prob, alias, packed = K.alias_build(neg_w)
-    vertex = rng.uniform(-0.5 / dim, 0.5 / dim, (N, dim)).astype(np.float32)  # graph.cuh:724-731
-    context = np.zeros((N, dim), np.float32)
+    threads = args.sampler_threads or max((os.cpu_count() or 1) // world, 1)
 
-    # ---- HBM-resident state ----
-    t_vertex, t_context = torch.from_numpy(vertex).to(dev), torch.from_numpy(context).to(dev)
-    t_pool = torch.from_numpy(pool.view(np.int32)).to(dev)
-    t_table = K.packed_to_device(packed, dev)
-    t_loss = torch.zeros(B, device=dev)
-    spec = K.OptimizerSpec("SGD", 0.025, 0.005, schedule="linear")
-    total_batches = args.warmup + args.steps
-
-    def run(first, count):
-        done = 0
-        while done < count:
-            start = (first + done) % args.pool_batches
-            n = min(count - done, args.pool_batches - start)
-            hip.train_episode(t_vertex, t_context, t_pool[start * B:], t_loss, spec, k, 5.0, t_table, args.seed,
-                              first + done, total_batches, n, B)
-            done += n
-
-    run(0, args.warmup)
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # ---- product path up to the resident state ----
+    graph = gv.graph.Graph()
+    graph.load(synthetic.power_law_edges(N, E, seed=args.seed))
+    solver = gv.solver.GraphSolver(dim, num_sampler_per_worker=threads, seed=args.seed)
+    if args.lanes:
+        solver.kernels.set_lanes_per_pair(args.lanes)
+    solver.build(graph, optimizer=gv.optimizer.SGD(0.025, 0.005, "linear"), num_partition=world, num_negative=k,
+                 batch_size=B, episode_size=args.block_batches)
+    total_batches = (args.warmup + args.steps) * world
+    epochs = total_batches * B // graph.num_edge + 1
+    solver._configure_training("LINE", epochs, False, 1, 40, 100, gv.auto, 1, 1, 1, 0.75, 5.0, 1 << 30)
+    solver.num_batch = total_batches  # the lr schedule spans exactly the batches this run trains
+    state = solver._upload_state()
+    pools = solver._host_pools()[0]
     t0 = time.perf_counter()
-    ev0.record()
-    run(args.warmup, args.steps)
-    ev1.record()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # launches are back to back on this stream
-    final_loss = float(t_loss.mean().item())
+    solver._fill(pools)
+    fill_s = time.perf_counter() - t0
+    blocks = [(int(s[rank][0]), int(s[rank][1])) for s in solver._schedule]
+    dev_pools = {b: pools[b].to(dev) for b in blocks}  # every block pool of this GPU's column, resident in HBM
+    sampled = len(blocks) * args.block_batches * B
 
-    samples = args.steps * B
+    kernel_events = []
+
+    def run(num_batches, timed):
+        """num_batches per GPU, walking the schedule block by block with the exchange after every block."""
+        done, step = 0, 0
+        while done < num_batches:
+            hp, tp = blocks[step % len(blocks)]
+            n = min(args.block_batches, num_batches - done)
+            solver.episode_size = n
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            solver._train_block(state, hp, tp, dev_pools[(hp, tp)])
+            if timed:
+                e1.record()
+                kernel_events.append((e0, e1, n))
+            if world > 1:
+                solver._exchange(state, step % len(blocks))
+            done += n
+            step += 1
+        solver.episode_size = args.block_batches
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup, False)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps, True)
+    fence()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    kernel_ms = sum(a.elapsed_time(b) for a, b, _ in kernel_events) / sum(n for _, _, n in kernel_events)
+    final_loss = float(state["loss"].mean().item())
+
     bytes_per_launch = algorithmic_bytes(dim, k) * B
     achieved = bytes_per_launch / (kernel_ms * 1e-3)
+    lanes = args.lanes or 16
     result = {
         "metric": "million edge-samples/sec at dim=%d" % dim,
-        "value": samples / wall / 1e6,
+        "value": world * args.steps * B / wall / 1e6,
         "unit": "million edge-samples/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "LINE on synthetic power-law %d nodes / %d edges, dim %d, batch %d, num_negative %d, "
-                               "SGD lr 0.025 wd 0.005 linear, on-device negatives, pool resident in HBM"
-                               % (N, E, dim, B, k),
-                   "parallelism": "1 GPU, 1 partition", "lanes_per_pair": args.lanes or "default"},
+        "config": {"workload": "LINE (augmentation_step 1) on synthetic power-law %d nodes / %d edges, dim %d, "
+                               "batch %d edge-samples per GPU per step, num_negative %d, SGD lr 0.025 wd 0.005 linear, "
+                               "negatives drawn in-kernel, block pools resident in HBM" % (N, E, dim, B, k),
+                   "parallelism": "%d GPU(s), %d vertex partition(s), context shard pinned per GPU, all-gather of "
+                                  "head shards every %d batches" % (world, world, args.block_batches),
+                   "lanes_per_pair": lanes},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK, "traffic": None, "kernel": "train_kernel<128,16,SGD>",
-                     "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
+                     "frac": achieved / HBM_PEAK, "traffic": None,
+                     "kernel": "train_kernel<%d,%d,SGD>" % (dim, lanes), "kernel_ms": kernel_ms,
+                     "algorithmic_bytes_per_launch": bytes_per_launch},
+        "sampler": {"value": sampled / fill_s / 1e6, "unit": "million edge-samples/sec per GPU", "threads": threads,
+                    "note": "CPU edge sampler filling this GPU's block pools before the timed region"},
         "final_batch_mean_loss": final_loss,
     }
-    if not args.no_cpu_baseline:
-        # negatives for the CPU run: drawn from the same alias table (numpy, vectorised)
-        negs = []
-        for _ in range(4):
-            idx = rng.integers(0, N, (B, k))
-            u = rng.random((B, k)).astype(np.float32)
-            negs.append(np.where(u < prob[idx], idx, alias[idx]).astype(np.uint32))
-        result["cpu_baseline"] = cpu_baseline(args, vertex, context, pool, negs)
-    print(json.dumps(result))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        tp = blocks[0][1]
+        packed = state["negative_tables"][tp].cpu().numpy().view(np.dtype([("prob", np.float32),
+                                                                           ("alias", np.uint32)]))
+        pool0 = pools[blocks[0]].numpy().view(np.uint32).reshape(-1, 2)
+        result["cpu_baseline"] = cpu_baseline(args, solver, pool0, packed)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

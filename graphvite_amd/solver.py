@@ -243,6 +243,32 @@ class GraphSolver(object):
               negative_sample_exponent=0.75, negative_weight=5, log_frequency=1000)
         Train node embeddings.
         """
+        self._configure_training(model, num_epoch, resume, augmentation_step, random_walk_length,
+                                 random_walk_batch_size, shuffle_base, p, q, positive_reuse,
+                                 negative_sample_exponent, negative_weight, log_frequency)
+        state = self._upload_state()
+        pools = self._host_pools()
+        try:
+            self._fill(pools[0])
+            current = 0
+            while self.batch_id < self.num_batch:  # solver.h:629-649 — one iteration = one episode
+                filler = threading.Thread(target=self._fill_guarded, args=(pools[current ^ 1],))
+                filler.start()
+                try:
+                    self._train_episode(state, pools[current])
+                finally:
+                    filler.join()
+                if self._fill_error is not None:
+                    raise self._fill_error
+                current ^= 1
+        finally:
+            self._write_back(state)
+
+    def _configure_training(self, model, num_epoch, resume, augmentation_step, random_walk_length,
+                            random_walk_batch_size, shuffle_base, p, q, positive_reuse, negative_sample_exponent,
+                            negative_weight, log_frequency):
+        """Argument checks, auto hyper-parameters, embedding init and sampler tables: everything GraphSolver::train
+        and SolverMixin::train do before the episode loop (graph.cuh:770-793, solver.h:588-628)."""
         if self.graph is None:
             raise RuntimeError("The model must be built on a graph first")
         if model not in self.available_models:
@@ -289,23 +315,6 @@ class GraphSolver(object):
             self._sampler_mode = key
         self._mode = mode
 
-        state = self._upload_state()
-        pools = self._host_pools()
-        try:
-            self._fill(pools[0])
-            current = 0
-            while self.batch_id < self.num_batch:  # solver.h:629-649 — one iteration = one episode
-                filler = threading.Thread(target=self._fill_guarded, args=(pools[current ^ 1],))
-                filler.start()
-                try:
-                    self._train_episode(state, pools[current])
-                finally:
-                    filler.join()
-                if self._fill_error is not None:
-                    raise self._fill_error
-                current ^= 1
-        finally:
-            self._write_back(state)
 
     # ---- embeddings -------------------------------------------------------------------------------------
     def _init_embeddings(self):

@@ -32,3 +32,30 @@ def degrees(edges, num_vertex):
     """Weighted degree of the as-undirected graph with unit weights (Graph::add_edge, graph.cuh:146-151)."""
     return (np.bincount(edges[:, 0], minlength=num_vertex) + np.bincount(edges[:, 1], minlength=num_vertex)).astype(
         np.float32)
+
+
+def link_prediction_split(edges, portions=(100, 1, 1), seed=1024):
+    """The reference's Dataset.link_prediction_split (python/graphvite/dataset.py:318-361) on an in-memory edge
+    array: every edge line goes to split searchsorted(cumsum(portions) / sum, rand()); every non-train split gets
+    as many random false edges (u != v, neither (u, v) nor (v, u) an edge) as it has true ones.
+    Returns (train_edges [n, 2], [(H, T, Y) for each further split]).  Node order for the false edges is the
+    sorted label order (the reference iterates a Python set of strings, whose order is not reproducible)."""
+    rs = np.random.RandomState(seed)
+    cum = np.cumsum(portions, dtype=np.float32) / np.sum(portions)
+    which = np.searchsorted(cum, rs.rand(len(edges)))
+    nodes = np.unique(edges)
+    keys = set((edges[:, 0].astype(np.int64) << 32 | edges[:, 1].astype(np.int64)).tolist())
+    splits = []
+    for i in range(1, len(portions)):
+        true = edges[which == i]
+        H, T = [], []
+        while len(H) < len(true):
+            u = int(nodes[int(rs.rand() * len(nodes))])
+            v = int(nodes[int(rs.rand() * len(nodes))])
+            if u != v and (u << 32 | v) not in keys and (v << 32 | u) not in keys:
+                H.append(u)
+                T.append(v)
+        splits.append((np.concatenate([true[:, 0], np.asarray(H, edges.dtype)]),
+                       np.concatenate([true[:, 1], np.asarray(T, edges.dtype)]),
+                       np.concatenate([np.ones(len(true), np.int64), np.zeros(len(H), np.int64)])))
+    return edges[which == 0], splits

@@ -1,0 +1,141 @@
+"""The CPU oracle pinned against (a) the committed golden vectors that the REFERENCE's own host-compiled
+arithmetic produced (tests/golden/make_golden.py), (b) that reference build itself when it is present
+(oracle/_ref), and (c) published known-answer vectors (Philox)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle_lib import ADAGRAD, ADAM, MOMENTUM, RMSPROP, SGD, Reference
+from util import conflict_free_batch, init_tables, random_batch
+
+GOLDEN = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_arithmetic.npz"))
+HP = {SGD: (0, 0, 0), MOMENTUM: (0.9, 0, 0), ADAGRAD: (0, 0, 1e-10), RMSPROP: (0.99, 0, 1e-8), ADAM: (0.9, 0.99, 1e-8)}
+CASES = [(dim, SGD) for dim in (32, 64, 96, 128, 256, 512)] + \
+        [(dim, opt) for dim in (32, 128) for opt in (MOMENTUM, ADAGRAD, RMSPROP, ADAM)]
+
+
+@pytest.mark.parametrize("dim,opt", CASES)
+def test_train_matches_reference_golden_bit_exact(oracle, dim, opt):
+    key = "d%d_o%d" % (dim, opt)
+    v, c = GOLDEN[key + "_v_in"].copy(), GOLDEN[key + "_c_in"].copy()
+    moments = [GOLDEN[key + "_m%d_in" % i].copy() if key + "_m%d_in" % i in GOLDEN else None for i in range(4)]
+    loss = oracle.train(v, c, GOLDEN[key + "_pairs"], GOLDEN[key + "_negs"], 0.025, 0.005, 5.0, opt, moments, HP[opt])
+    # same operations in the same order in IEEE fp32 -> identical bits
+    assert (v == GOLDEN[key + "_v_out"]).all()
+    assert (c == GOLDEN[key + "_c_out"]).all()
+    assert (loss == GOLDEN[key + "_loss"]).all()
+    for i, m in enumerate(moments):
+        if m is not None:
+            assert (m == GOLDEN[key + "_m%d_out" % i]).all()
+    assert (oracle.predict(v, c, GOLDEN[key + "_pairs"]) == GOLDEN[key + "_logits"]).all()
+
+
+def test_sigmoid_and_schedule_match_reference_golden(oracle):
+    ys = np.array([oracle.sigmoid(float(x)) for x in GOLDEN["sigmoid_x"]], np.float32)
+    assert (ys == GOLDEN["sigmoid_y"]).all()
+    ids = GOLDEN["lr_batch_id"]
+    assert ([oracle.lr(0.025, True, int(i), 1000) for i in ids] == GOLDEN["lr_linear"]).all()
+    assert ([oracle.lr(0.025, False, int(i), 1000) for i in ids] == GOLDEN["lr_constant"]).all()
+    assert oracle.lr(0.025, True, 99999, 1000) == np.float32(0.025) * np.float32(1e-4)  # floor, optimizer.h:78
+
+
+@pytest.mark.parametrize("opt", [SGD, MOMENTUM, ADAGRAD, RMSPROP, ADAM])
+def test_oracle_equals_live_reference_build(oracle, reference, opt):
+    """Fresh random inputs against oracle/_ref/libgvref.so (skipped where neither it nor /root/reference exists)."""
+    rng = np.random.default_rng(opt)
+    N, B, k, dim = 100, 300, 3, 96
+    v, c = init_tables(rng, N, N, dim)
+    v *= 50
+    c *= 50
+    pairs, negs = random_batch(rng, N, N, B, k)
+    nm = 0 if opt == SGD else (2 if opt == ADAM else 1)
+    m1 = [np.full((N, dim), 1e-3, np.float32) if i < 2 * nm else None for i in range(4)]
+    m2 = [None if m is None else m.copy() for m in m1]
+    v1, c1, v2, c2 = v.copy(), c.copy(), v.copy(), c.copy()
+    l1 = oracle.train(v1, c1, pairs, negs, 0.01, 0.001, 3.0, opt, m1, HP[opt])
+    l2 = reference.train(v2, c2, pairs, negs, 0.01, 0.001, 3.0, opt, m2, HP[opt])
+    assert (v1 == v2).all() and (c1 == c2).all() and (l1 == l2).all()
+
+
+def test_philox_known_answers(oracle):
+    """Random123 kat_vectors for philox4x32-10."""
+    assert [hex(x) for x in oracle.philox([0, 0, 0, 0], [0, 0])] == \
+        ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    assert [hex(x) for x in oracle.philox([0xffffffff] * 4, [0xffffffff] * 2)] == \
+        ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    assert [hex(x) for x in oracle.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344],
+                                          [0xa4093822, 0x299f31d0])] == \
+        ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+
+
+def test_host_uniforms_are_uniform_and_reproducible(oracle):
+    a = oracle.host_uniforms(5, 3, 0, 20001)
+    assert (oracle.host_uniforms(5, 3, 7, 100) == a[7:107]).all()       # random access into the stream
+    assert (oracle.host_uniforms(5, 4, 0, 100) != a[:100]).any()        # other stream
+    assert a.min() >= 0 and a.max() < 1
+    assert abs(a.mean() - 0.5) < 0.01 and abs(a.var() - 1 / 12) < 0.005
+
+
+def test_alias_table_known_answers(oracle):
+    # uniform weights: every slot keeps itself with probability 1
+    prob, alias = oracle.alias_build(np.ones(5, np.float32))
+    assert (prob == 1).all() and (alias == np.arange(5)).all()
+    # hand-worked Vose with FIFO queues: w = [1, 2, 3, 2] -> mean 2 -> p = [.5, 1, 1.5, 1]
+    #   little = [0], large = [1, 2, 3]; pop 0 & 1: alias[0] = 1, p[1] = .5 -> little = [1], large = [2, 3]
+    #   pop 1 & 2: alias[1] = 2, p[2] = 1.0 -> large = [3, 2]; leftovers alias themselves
+    prob, alias = oracle.alias_build(np.array([1, 2, 3, 2], np.float32))
+    assert prob.tolist() == [0.5, 0.5, 1.0, 1.0] and alias.tolist() == [1, 2, 2, 3]
+    assert oracle.alias_sample(prob, alias, 0.1, 0.4) == 0 and oracle.alias_sample(prob, alias, 0.1, 0.6) == 1
+    assert oracle.alias_sample(prob, alias, 0.99, 0.999) == 3
+
+
+def test_alias_table_distribution(oracle):
+    rng = np.random.default_rng(0)
+    w = rng.pareto(1.2, 200).astype(np.float32) + 0.01
+    prob, alias = oracle.alias_build(w)
+    # exact marginal implied by the table
+    p = prob.astype(np.float64).clip(max=1) / len(w)
+    implied = p.copy()
+    np.add.at(implied, alias, 1 / len(w) - p)
+    np.testing.assert_allclose(implied, w / w.sum(), rtol=2e-5, atol=1e-8)
+    # 8-byte index variant builds the same table
+    prob8, alias8 = oracle.alias_build(w, 8)
+    assert (prob8 == prob).all() and (alias8 == alias).all()
+
+
+def test_partition_and_schedule_properties(oracle):
+    rng = np.random.default_rng(1)
+    w = np.floor(rng.pareto(1.5, 1001)).astype(np.float32)
+    for P in (1, 2, 4, 8):
+        part, local, sizes = oracle.partition(w, P)
+        assert sizes.sum() == len(w) and sizes.max() - sizes.min() <= 1
+        order = np.lexsort((np.arange(len(w)), -w))
+        zig = np.minimum(np.arange(len(w)) % (2 * P), 2 * P - 1 - np.arange(len(w)) % (2 * P))
+        assert (part[order] == zig).all()
+        for p in range(P):  # local ids are 0..size-1 in sorted order
+            assert (local[order][zig == p] == np.arange(sizes[p])).all()
+        sums = np.array([w[part == p].sum() for p in range(P)])
+        assert sums.max() - sums.min() <= max(w.max(), 1) * 2  # degree-balanced
+    for P, W in ((1, 1), (2, 2), (4, 4), (8, 8), (4, 2), (8, 4), (16, 8)):
+        sch = oracle.schedule(P, W)
+        seen = set()
+        for step in sch:
+            heads, tails = step[:, 0], step[:, 1]
+            assert len(set(heads)) == len(heads) and len(set(tails)) == len(tails)  # orthogonal blocks
+            seen.update(map(tuple, step.tolist()))
+        assert len(seen) == P * P and len(sch) * sch.shape[1] == P * P  # every block exactly once per episode
+        if P == W and W > 1:
+            assert (sch[1][:, 0] == (np.arange(W) + 1) % W).all() and (sch[1][:, 1] == np.arange(W)).all()
+
+
+def test_conflict_free_batch_is_order_independent(oracle):
+    """The premise of the GPU parity protocol: on a conflict-free batch any processing order gives the same bits."""
+    rng = np.random.default_rng(2)
+    v, c = init_tables(rng, 500, 500, 64)
+    pairs, negs = conflict_free_batch(rng, 500, 500, 100, 2)
+    v1, c1, v2, c2 = v.copy(), c.copy(), v.copy(), c.copy()
+    l1 = oracle.train(v1, c1, pairs, negs, 0.025, 0.005, 5.0)
+    perm = rng.permutation(100)
+    l2 = oracle.train(v2, c2, pairs[perm], negs[perm], 0.025, 0.005, 5.0)
+    assert (v1 == v2).all() and (c1 == c2).all() and (l1[perm] == l2).all()

@@ -1,0 +1,199 @@
+"""GraphSolver / GraphApplication host logic without a GPU: the kernels are replaced — explicitly, in the test —
+by the oracle (tests/fake_kernels.py), so that partitioning, sampling, pool handling, batch-id / learning-rate
+accounting, the multi-process exchange (gloo, world_size 2) and write-back can be checked here.  The product
+itself has no CPU path: constructing a GraphSolver without a GPU raises."""
+import os
+import pickle
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import graphvite_amd as gv
+from fake_kernels import OracleKernels
+from graphvite_amd import synthetic
+from oracle_lib import link_prediction_auc
+
+
+def make_graph(n=300, e=3000, seed=1):
+    g = gv.graph.Graph()
+    g.load(synthetic.power_law_edges(n, e, seed=seed))
+    return g
+
+
+def test_no_cpu_training_path():
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="No GPU"):
+        gv.solver.GraphSolver(128)
+    with pytest.raises(AttributeError):
+        gv.solver.GraphSolver(100, kernels=OracleKernels())
+    with pytest.raises(AttributeError):
+        gv.solver.GraphSolver(128, float_type=gv.float64, kernels=OracleKernels())
+
+
+def test_build_defaults_follow_the_reference():
+    g = make_graph()
+    s = gv.solver.GraphSolver(128, kernels=OracleKernels(), num_sampler_per_worker=2)
+    s.build(g)
+    assert s.optimizer.type == "SGD" and s.optimizer.init_lr == 0.025 and s.optimizer.weight_decay == 0.005
+    assert s.optimizer.schedule.type == "linear"
+    assert s.num_partition == 1 and s.num_negative == 1 and s.batch_size == 100000
+    assert s.episode_size == 200  # max(300 * 175 / 1 / 1e5, 1) -> 1, single partition -> 2e7 / 1e5 (solver.h:426-436)
+    assert s.vertex_embeddings.shape == (300 if g.num_vertex == 300 else g.num_vertex, 128)
+    s.build(g, optimizer=0.1, batch_size=500, episode_size=3)  # bare learning rate keeps the default optimizer
+    assert s.optimizer.type == "SGD" and s.optimizer.init_lr == pytest.approx(0.1)
+    s.build(g, optimizer=gv.optimizer.Adam(1e-3), batch_size=500, episode_size=3)
+    assert s.optimizer.type == "Adam" and s.num_moment == 2
+    with pytest.raises(ValueError):
+        s.build(g, num_partition=0 - 1)
+    with pytest.raises(ValueError):
+        s.train(model="TransE")
+
+
+def test_train_accounting_and_determinism():
+    g = make_graph()
+    runs = []
+    for _ in range(2):
+        k = OracleKernels()
+        s = gv.solver.GraphSolver(64, kernels=k, num_sampler_per_worker=2, seed=3)
+        s.build(g, batch_size=500, episode_size=6)
+        views = (s.vertex_embeddings, s.context_embeddings)
+        s.train("LINE", num_epoch=5, log_frequency=7)
+        assert s.vertex_embeddings is views[0] and s.context_embeddings is views[1]  # stable host buffers
+        runs.append((s.vertex_embeddings.copy(), s.context_embeddings.copy(), list(k.launches), s))
+    v0, c0, launches, s = runs[0]
+    assert (v0 == runs[1][0]).all() and (c0 == runs[1][1]).all()  # same seed -> same pools, negatives, result
+    # num_batch = num_epoch * |E| / batch (solver.h:611), overshoot to whole episodes (solver.h:629)
+    assert s.num_batch == 5 * 3000 // 500 and s.augmentation_step == 3 and s.shuffle_base == 3
+    ids = [b for b, _ in launches]
+    assert ids == list(range(len(ids))) and len(ids) == 30 and s.batch_id == 30
+    for b, lr in launches:  # lr = init_lr * max(1 - b / num_batch, 1e-4) (optimizer.h:77-79)
+        assert lr == pytest.approx(0.025 * max(1 - b / 30.0, 1e-4), rel=1e-6)
+    assert np.abs(c0).max() > 0 and np.isfinite(v0).all()
+    # resume continues the batch counter and does not re-initialise
+    before = s.vertex_embeddings.copy()
+    s.train("LINE", num_epoch=1, resume=True, log_frequency=1000)
+    assert s.num_batch == 30 + 6 and s.batch_id == 36 and not (s.vertex_embeddings == before).all()
+
+
+@pytest.mark.parametrize("model,aug", [("LINE", 1), ("DeepWalk", 3), ("node2vec", 2)])
+def test_models_and_samplers_run(model, aug):
+    g = make_graph(200, 1500, seed=2)
+    k = OracleKernels()
+    s = gv.solver.GraphSolver(32, kernels=k, num_sampler_per_worker=2)
+    s.build(g, batch_size=300, episode_size=4, num_negative=2)
+    s.train(model, num_epoch=2, augmentation_step=aug, random_walk_length=8, random_walk_batch_size=5, p=0.5, q=2.0,
+            positive_reuse=2)
+    assert s.batch_id == 2 * 1500 // 300 - (2 * 1500 // 300) % 8 + 8 or s.batch_id % 8 == 0  # episodes of 4 x reuse 2
+    assert np.abs(s.context_embeddings).max() > 0
+    if model != "LINE":
+        assert s.shuffle_base == 1
+
+
+def test_custom_schedule_and_optimizers():
+    g = make_graph(150, 900, seed=4)
+    k = OracleKernels()
+    s = gv.solver.GraphSolver(32, kernels=k, num_sampler_per_worker=1)
+    s.build(g, optimizer=gv.optimizer.SGD(0.1, 0, lambda b, n: 0.5), batch_size=300, episode_size=2)
+    s.train("LINE", num_epoch=1, augmentation_step=1)
+    assert all(lr == pytest.approx(0.05) for _, lr in k.launches)
+    for opt in (gv.optimizer.Momentum(0.01), gv.optimizer.AdaGrad(0.01), gv.optimizer.RMSprop(0.01),
+                gv.optimizer.Adam(0.01)):
+        s.build(g, optimizer=opt, batch_size=300, episode_size=2)
+        s.train("LINE", num_epoch=1, augmentation_step=1)
+        assert np.isfinite(s.vertex_embeddings).all() and np.abs(s.context_embeddings).max() > 0
+
+
+def test_predict_and_link_prediction_pipeline(tmp_path):
+    edges = synthetic.power_law_edges(400, 6000, seed=5)
+    train, (valid, test) = synthetic.link_prediction_split(edges, (100, 5, 5), seed=1024)
+    assert len(train) + (valid[2] == 1).sum() + (test[2] == 1).sum() == len(edges)
+    assert (test[2] == 1).sum() == (test[2] == 0).sum()
+    app = gv.application.GraphApplication(dim=32)
+    app.get_solver = lambda **kw: gv.solver.GraphSolver(32, kernels=OracleKernels(), num_sampler_per_worker=2)
+    app.load(edge_list=train)
+    app.build(batch_size=1000, episode_size=10)
+    app.train(model="LINE", num_epoch=60, augmentation_step=1, log_frequency=100000)
+    H, T, Y = test
+    result = app.evaluate("link prediction", H=[str(h) for h in H], T=[str(t) for t in T], Y=Y.tolist(),
+                          filter_H=[str(h) for h in train[:, 0]], filter_T=[str(t) for t in train[:, 1]])
+    # the same number from the numpy restatement of the reference's AUC (application.py:433-449)
+    n2i = app.graph.name2id
+    in_train = {(n2i[str(h)], n2i[str(t)]) for h, t in train}
+    keep = [(n2i[str(h)], n2i[str(t)], y) for h, t, y in zip(H, T, Y) if str(h) in n2i and str(t) in n2i]
+    keep = [k for k in keep if (k[0], k[1]) not in in_train]  # filter_H / filter_T drop pairs seen in training
+    want = link_prediction_auc(app.solver.vertex_embeddings, app.solver.context_embeddings, [k[0] for k in keep],
+                               [k[1] for k in keep], [k[2] for k in keep])
+    assert result["AUC"] == pytest.approx(want, abs=1e-9) and result["AUC"] > 0.6
+    # predict takes (v, c) pairs in global ids and returns dot products
+    pairs = np.array([[1, 2], [3, 4], [5, 5]])
+    got = app.solver.predict(pairs)
+    want = np.einsum("ij,ij->i", app.solver.vertex_embeddings[pairs[:, 0]], app.solver.context_embeddings[pairs[:, 1]])
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-9)
+    with pytest.raises(ValueError):
+        app.solver.predict(np.zeros((3, 3), np.int64))
+    # save / load round trip maps nodes by name
+    path = str(tmp_path / "model.pkl")
+    app.save_model(path)
+    saved = pickle.load(open(path, "rb"))
+    assert saved["solver"]["vertex_embeddings"].shape == app.solver.vertex_embeddings.shape
+    old = app.solver.vertex_embeddings.copy()
+    app.solver.vertex_embeddings[:] = 0
+    app.load_model(path)
+    assert (app.solver.vertex_embeddings == old).all()
+    with pytest.raises(ValueError):
+        app.evaluate("node clustering")
+
+
+# ---- world_size 2 over gloo -----------------------------------------------------------------------------------
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir, model, aug):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import logging
+        gv.init_logging(logging.ERROR)
+        g = make_graph(240, 2400, seed=6)
+        k = OracleKernels()
+        s = gv.solver.GraphSolver(32, kernels=k, num_sampler_per_worker=2, seed=9)
+        s.build(g, batch_size=400, episode_size=3)
+        assert s.num_worker == world and s.num_partition == world
+        s.train(model, num_epoch=4, augmentation_step=aug, random_walk_length=6, random_walk_batch_size=4,
+                log_frequency=100000)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), v=s.vertex_embeddings, c=s.context_embeddings,
+                 ids=np.array([b for b, _ in k.launches]), lrs=np.array([lr for _, lr in k.launches]),
+                 batch_id=s.batch_id, num_batch=s.num_batch, tails=np.array(s._my_tails))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model,aug", [("LINE", 1), ("DeepWalk", 2)])
+def test_two_process_training_over_gloo(tmp_path, model, aug):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), model, aug), nprocs=world, join=True)
+    r = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % i)) for i in range(world)]
+    # after write-back every process holds the same, complete tables
+    assert (r[0]["v"] == r[1]["v"]).all() and (r[0]["c"] == r[1]["c"]).all()
+    assert np.abs(r[0]["c"]).max() > 0 and np.isfinite(r[0]["v"]).all()
+    assert r[0]["tails"].tolist() == [0] and r[1]["tails"].tolist() == [1]  # context shard pinned per worker
+    # the two workers share one batch counter: ids interleave, every id exactly once, whole episodes
+    ids = np.sort(np.concatenate([r[0]["ids"], r[1]["ids"]]))
+    assert (ids == np.arange(len(ids))).all()
+    assert (r[0]["ids"] % 2 == 0).all() and (r[1]["ids"] % 2 == 1).all()
+    assert len(ids) % (2 * 2 * 3) == 0 and int(r[0]["batch_id"]) == len(ids) >= int(r[0]["num_batch"])
+    for i in range(world):
+        want = 0.025 * np.maximum(1 - r[i]["ids"] / float(r[i]["num_batch"]), 1e-4)
+        np.testing.assert_allclose(r[i]["lrs"], want, rtol=1e-6)
