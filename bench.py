@@ -51,9 +51,11 @@ def parse():
     p.add_argument("--dim", type=int, default=128)
     p.add_argument("--batch", type=int, default=100000)
     p.add_argument("--negatives", type=int, default=1)
-    p.add_argument("--block-batches", type=int, default=50,
-                   help="batches per (head, tail) block pool = batches between two exchanges")
+    p.add_argument("--block-batches", type=int, default=0,
+                   help="batches per (head, tail) block pool = batches between two exchanges; 0 = the solver's "
+                        "auto episode size for this graph (solver.h:426-436), capped at 250")
     p.add_argument("--lanes", type=int, default=0, help="A/B knob: lanes per pair (0 = per-dim default)")
+    p.add_argument("--variant", type=int, default=0, help="A/B knob: kernel build variant (gvk.h GVK_TUNE_VARIANT)")
     p.add_argument("--sampler-threads", type=int, default=0, help="0 = host cores / GPUs")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=3.0, help="wall seconds given to the CPU baseline")
@@ -118,6 +120,11 @@ def main():
     gv.init_logging(logging.ERROR)
 
     N, E, B, k, dim = args.vertices, args.edges, args.batch, args.negatives, args.dim
+    if not args.block_batches:
+        auto = max(int(float(N) * 175 / world / B), 1)
+        if world == 1:
+            auto = max(auto, int(2e7) // B)
+        args.block_batches = min(auto, 250)
     threads = args.sampler_threads or max((os.cpu_count() or 1) // world, 1)
 
     # ---- product path up to the resident state ----
@@ -126,6 +133,8 @@ def main():
     solver = gv.solver.GraphSolver(dim, num_sampler_per_worker=threads, seed=args.seed)
     if args.lanes:
         solver.kernels.set_lanes_per_pair(args.lanes)
+    if args.variant:
+        solver.kernels.set_variant(args.variant)
     solver.build(graph, optimizer=gv.optimizer.SGD(0.025, 0.005, "linear"), num_partition=world, num_negative=k,
                  batch_size=B, episode_size=args.block_batches)
     total_batches = (args.warmup + args.steps) * world
@@ -184,6 +193,12 @@ def main():
 
     bytes_per_launch = algorithmic_bytes(dim, k) * B
     achieved = bytes_per_launch / (kernel_ms * 1e-3)
+    # HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM); bench.py cannot read PMCs itself
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r1", "pmc_summary_bench_n1.json")
+    if world == 1 and dim == 128 and k == 1 and B == 100000 and N == 1000000 and os.path.exists(pmc):
+        traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
     lanes = args.lanes or 16
     result = {
         "metric": "million edge-samples/sec at dim=%d" % dim,
@@ -200,7 +215,8 @@ def main():
                                   "head shards every %d batches" % (world, world, args.block_batches),
                    "lanes_per_pair": lanes},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK, "traffic": None,
+                     "frac": achieved / HBM_PEAK, "traffic": traffic,
+                     "traffic_source": "profiles/r1/pmc_summary_bench_n1.json" if traffic else None,
                      "kernel": "train_kernel<%d,%d,SGD>" % (dim, lanes), "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": bytes_per_launch},
         "sampler": {"value": sampled / fill_s / 1e6, "unit": "million edge-samples/sec per GPU", "threads": threads,

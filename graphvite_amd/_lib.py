@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libgvk.so")
 GVK_OK, GVK_EINVAL, GVK_EDIM, GVK_EHIP, GVK_ENOMEM = 0, -1, -2, -3, -4
 SGD, MOMENTUM, ADAGRAD, RMSPROP, ADAM = range(5)
 TUNE_LANES_PER_PAIR = 1
+TUNE_VARIANT = 2
 
 
 class AliasEntry(C.Structure):
@@ -134,6 +135,8 @@ def lib():
         fn = getattr(l, "gvs_sampler_" + name)
         fn.restype = vp
         fn.argtypes = [vp]
+    l.gvs_sampler_column.restype = i32
+    l.gvs_sampler_column.argtypes = [vp, i32, P(u64), P(vp), P(vp), P(vp)]
     l.gvs_host_uniforms.restype = None
     l.gvs_host_uniforms.argtypes = [u64, u32, u64, sz, vp]
     _lib = l

@@ -38,6 +38,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 int g_lanes_per_pair = 0;  // GVK_TUNE_LANES_PER_PAIR
+int g_variant = 0;         // GVK_TUNE_VARIANT
 
 struct TrainArgs {
     float *vertex, *context, *vm1, *cm1, *vm2, *cm2;
@@ -193,8 +194,11 @@ __device__ __forceinline__ float update(const TrainArgs &a, float parameter, flo
 
 // ---- training kernel -------------------------------------------------------------------------------
 
-template <int DIM, int G, int OPT>
-__global__ void __launch_bounds__(kBlock) train_kernel(const TrainArgs a) {
+// KT > 0 fixes num_negative at compile time (the loop unrolls and every row request of the pair is issued
+// up front); DRAW fixes the negative source (-1: decided at run time).  WAVES is the occupancy the register
+// allocator is asked for (waves per SIMD).
+template <int DIM, int G, int OPT, int KT = 0, int DRAW = -1, int WAVES = 4>
+__global__ void __launch_bounds__(kBlock, WAVES) train_kernel(const TrainArgs a) {
     constexpr int V = DIM / G;
     constexpr int NM = OPT == GVK_SGD ? 0 : (OPT == GVK_ADAM ? 2 : 1);  // moments per row
     constexpr int M1 = NM >= 1 ? V : 1, M2 = NM >= 2 ? V : 1;
@@ -203,8 +207,8 @@ __global__ void __launch_bounds__(kBlock) train_kernel(const TrainArgs a) {
     const int s = tid / G, lane = tid % G;
     if (s >= a.batch_size) return;  // whole groups leave together: G divides 64
 
-    const int k = a.k;
-    const bool draw = a.negatives == nullptr;
+    const int k = KT > 0 ? KT : a.k;
+    const bool draw = DRAW < 0 ? a.negatives == nullptr : DRAW != 0;
 
     // round trip 1: the pair and the first negative's alias slot (independent of each other)
     Draw d0 = {0, 0};
@@ -234,7 +238,7 @@ __global__ void __launch_bounds__(kBlock) train_kernel(const TrainArgs a) {
     if constexpr (NM >= 2) load_row<DIM, G>(a.cm2, id_cur, lane, reinterpret_cast<float(&)[V]>(cur2));
 
     float sample_loss = 0;
-    for (int j = 0; j <= k; j++) {
+    auto target_step = [&](const int j) __attribute__((always_inline)) {
         // request the next target row before touching the current one
         uint32_t id_nxt = 0;
         float nxt[V], nxt1[M1], nxt2[M2];
@@ -299,6 +303,12 @@ __global__ void __launch_bounds__(kBlock) train_kernel(const TrainArgs a) {
             }
             id_cur = id_nxt;
         }
+    };
+    if constexpr (KT > 0) {
+#pragma unroll
+        for (int j = 0; j <= KT; j++) target_step(j);
+    } else {
+        for (int j = 0; j <= k; j++) target_step(j);
     }
 
     if (lane == 0) __builtin_nontemporal_store(sample_loss / (1 + k * a.neg_weight), a.loss + s);
@@ -441,6 +451,17 @@ int launch_train(hipStream_t stream, int dim, const gvk_optimizer *o, float lr, 
     int g = g_lanes_per_pair && lanes_ok(dim, g_lanes_per_pair) && o->type == GVK_SGD ? g_lanes_per_pair
                                                                                       : default_lanes(dim);
     TrainKernel kernel = pick_train(dim, g, o->type);
+    // SGD with one negative (every shipped configuration of the reference): compile-time k, fixed negative
+    // source -> straight-line code, 62 VGPRs, 8 waves/SIMD.  GVK_TUNE_VARIANT 1 forces the generic build (A/B).
+    if (o->type == GVK_SGD && k == 1 && g == default_lanes(dim) && g_variant == 0) {
+        const bool draw = neg->negatives == nullptr;
+#define GVK_K1(D, GG) \
+    case D: kernel = draw ? train_kernel<D, GG, GVK_SGD, 1, 1> : train_kernel<D, GG, GVK_SGD, 1, 0>; break;
+        switch (dim) {
+            GVK_K1(32, 8) GVK_K1(64, 16) GVK_K1(96, 8) GVK_K1(128, 16) GVK_K1(256, 16) GVK_K1(512, 32)
+        }
+#undef GVK_K1
+    }
     if (!kernel) return fail(GVK_EINVAL, "gvk_train: no kernel for this (dim, lanes, optimizer)");
     TrainArgs a;
     a.vertex = t->vertex; a.context = t->context;
@@ -540,6 +561,11 @@ int gvk_set_tuning(int key, int value) {
         if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64)
             return fail(GVK_EINVAL, "gvk_set_tuning: lanes per pair must be 0, 8, 16, 32 or 64");
         g_lanes_per_pair = value;
+        return GVK_OK;
+    }
+    if (key == GVK_TUNE_VARIANT) {
+        if (value < 0 || value > 1) return fail(GVK_EINVAL, "gvk_set_tuning: variant must be 0 or 1");
+        g_variant = value;
         return GVK_OK;
     }
     return fail(GVK_EINVAL, "gvk_set_tuning: unknown key");

@@ -451,6 +451,15 @@ struct gvs_sampler {
     std::vector<uint32_t> nb_alias;
     std::vector<uint64_t> ee_offsets;
     std::vector<uint64_t> positions;
+    // EDGE mode with a tail-partition filter: a table over just the edges whose tail lives in that partition
+    // (the exact conditional distribution) instead of drawing from all edges and dropping (P - 1) / P of them
+    struct Column {
+        std::vector<uint64_t> edge_ids;
+        std::vector<float> prob;
+        std::vector<uint64_t> alias;
+        std::vector<EdgeSlot> slots;
+    };
+    std::vector<Column> columns;
 
     inline uint64_t sample_edge(HostRng &rng) const {
         const double r1 = rng.next(), r2 = rng.next();
@@ -509,10 +518,20 @@ void fill_edges(FillShared *sh, int thread, int64_t start, int64_t end, uint64_t
     const int n = sh->c.sample_batch_size;
     std::vector<uint64_t> heads(n), tails(n);
     const uint32_t *edges = s.g->edges_uv.data();
+    const gvs_sampler::Column *column =
+        sh->c.tail_partition >= 0 && s.P > 1 ? &s.columns[sh->c.tail_partition] : nullptr;
     int idle = 0;
     while (!cur.done() && !sh->error.load(std::memory_order_relaxed)) {
         for (int i = 0; i < n; i++) {
-            const uint64_t e = s.sample_edge(rng);
+            uint64_t e;
+            if (column) {  // same draw, over the column's own table
+                const double r1 = rng.next(), r2 = rng.next();
+                const uint64_t index = (uint64_t)(r1 * (double)column->slots.size());
+                const EdgeSlot &slot = column->slots[index];
+                e = column->edge_ids[(float)r2 < slot.prob ? index : slot.alias];
+            } else {
+                e = s.sample_edge(rng);
+            }
             heads[i] = s.location[edges[2 * e]];
             tails[i] = s.location[edges[2 * e + 1]];
         }
@@ -770,6 +789,27 @@ int gvs_sampler_fill(gvs_sampler *s, uint32_t *const *pools, uint64_t pool_size,
                 return gvk_fail(GVK_EINVAL, "gvs_sampler_fill: pool (%d, %d) is null", hp, tp);
     return guarded("gvs_sampler_fill", [&]() {
         if ((int)s->positions.size() < c->num_thread) s->positions.resize(c->num_thread, 0);
+        if (c->mode == GVS_MODE_EDGE && c->tail_partition >= 0 && s->P > 1) {
+            if (s->columns.empty()) s->columns.resize(s->P);
+            gvs_sampler::Column &col = s->columns[c->tail_partition];
+            if (col.slots.empty()) {
+                const size_t D = s->g->edge_weights.size();
+                std::vector<float> weights;
+                for (size_t e = 0; e < D; e++)
+                    if ((int)(s->location[s->g->edges_uv[2 * e + 1]] >> 32) == c->tail_partition) {
+                        col.edge_ids.push_back(e);
+                        weights.push_back(s->g->edge_weights[e]);
+                    }
+                if (weights.empty())
+                    return gvk_fail(GVK_EINVAL, "gvs_sampler_fill: no edge ends in partition %d", c->tail_partition);
+                col.prob.resize(weights.size());
+                col.alias.resize(weights.size());
+                int rc = gvk_alias_build(weights.data(), weights.size(), col.prob.data(), col.alias.data(), 8, nullptr);
+                if (rc != GVK_OK) return rc;
+                col.slots.resize(weights.size());
+                for (size_t i = 0; i < weights.size(); i++) col.slots[i] = EdgeSlot{col.prob[i], 0, col.alias[i]};
+            }
+        }
         FillShared sh;
         sh.s = s;
         sh.pools = pools;
@@ -810,6 +850,19 @@ const uint64_t *gvs_sampler_edge_alias(const gvs_sampler *s) { return s ? s->edg
 const float *gvs_sampler_neighbor_prob(const gvs_sampler *s) { return s ? s->nb_prob.data() : nullptr; }
 const uint32_t *gvs_sampler_neighbor_alias(const gvs_sampler *s) { return s ? s->nb_alias.data() : nullptr; }
 const uint64_t *gvs_sampler_edge_edge_offsets(const gvs_sampler *s) { return s ? s->ee_offsets.data() : nullptr; }
+
+int gvs_sampler_column(const gvs_sampler *s, int tail_partition, uint64_t *count, const uint64_t **edge_ids,
+                       const float **prob, const uint64_t **alias) {
+    if (!s || tail_partition < 0 || tail_partition >= (int)s->columns.size() ||
+        s->columns[tail_partition].slots.empty())
+        return gvk_fail(GVK_EINVAL, "gvs_sampler_column: column %d has not been built", tail_partition);
+    const gvs_sampler::Column &col = s->columns[tail_partition];
+    if (count) *count = col.edge_ids.size();
+    if (edge_ids) *edge_ids = col.edge_ids.data();
+    if (prob) *prob = col.prob.data();
+    if (alias) *alias = col.alias.data();
+    return GVK_OK;
+}
 
 void gvs_host_uniforms(uint64_t seed, uint32_t stream, uint64_t first, size_t n, double *out) {
     HostRng rng(seed, stream, first);

@@ -105,6 +105,16 @@ class Sampler(object):
     def edge_edge_offsets(self):
         return self._array("edge_edge_offsets", self.graph.num_directed_edge + 1, C.c_uint64, np.uint64)
 
+    def column(self, tail_partition):
+        """(edge_ids u64[n], prob f32[n], alias u64[n]) of the EDGE-mode column table of a tail partition."""
+        count, ids, prob, alias = C.c_uint64(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.check(self._lib.gvs_sampler_column(self._handle, tail_partition, C.byref(count), C.byref(ids),
+                                                C.byref(prob), C.byref(alias)), "gvs_sampler_column")
+        n = count.value
+        return (np.ctypeslib.as_array(C.cast(ids, C.POINTER(C.c_uint64)), shape=(n,)),
+                np.ctypeslib.as_array(C.cast(prob, C.POINTER(C.c_float)), shape=(n,)),
+                np.ctypeslib.as_array(C.cast(alias, C.POINTER(C.c_uint64)), shape=(n,)))
+
     def neighbor_tables(self, count):
         return (self._array("neighbor_prob", count, C.c_float, np.float32),
                 self._array("neighbor_alias", count, C.c_uint32, np.uint32))

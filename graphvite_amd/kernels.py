@@ -167,3 +167,6 @@ class HipKernels(object):
 
     def set_lanes_per_pair(self, lanes):
         _lib.check(self.lib.gvk_set_tuning(_lib.TUNE_LANES_PER_PAIR, lanes), "gvk_set_tuning")
+
+    def set_variant(self, variant):
+        _lib.check(self.lib.gvk_set_tuning(_lib.TUNE_VARIANT, variant), "gvk_set_tuning")

@@ -248,14 +248,20 @@ class GraphSolver(object):
                                  negative_sample_exponent, negative_weight, log_frequency)
         state = self._upload_state()
         pools = self._host_pools()
+        uploads = [[], []]  # per pool set: events of the async H2D copies still reading its pinned buffers
         try:
             self._fill(pools[0])
             current = 0
             while self.batch_id < self.num_batch:  # solver.h:629-649 — one iteration = one episode
+                # the samplers may only overwrite a pool set once the GPU has finished copying it out; this also
+                # keeps the host at most one episode ahead of the device (producer / consumer, double buffer)
+                for event in uploads[current ^ 1]:
+                    event.synchronize()
+                uploads[current ^ 1] = []
                 filler = threading.Thread(target=self._fill_guarded, args=(pools[current ^ 1],))
                 filler.start()
                 try:
-                    self._train_episode(state, pools[current])
+                    uploads[current] = self._train_episode(state, pools[current])
                 finally:
                     filler.join()
                 if self._fill_error is not None:
@@ -403,6 +409,7 @@ class GraphSolver(object):
         steps = [(int(s[r][0]), int(s[r][1])) for s in self._schedule]
         # prefetch step 0's pool; afterwards step i + 1 is uploaded while step i trains
         events = [None, None]
+        issued = []
 
         def upload(i):
             buf = state["pool_dev"][i & 1]
@@ -412,6 +419,7 @@ class GraphSolver(object):
                     ev = torch.cuda.Event()
                     ev.record()
                 events[i & 1] = ev
+                issued.append(ev)
             else:
                 buf.copy_(pools[steps[i]])
 
@@ -428,6 +436,7 @@ class GraphSolver(object):
             self._train_block(state, hp, tp, state["pool_dev"][i & 1])
             if W > 1:
                 self._exchange(state, i)
+        return issued
 
     def _tables(self, state, hp, tp):
         ti = self._my_tails.index(tp)

@@ -59,3 +59,26 @@ def link_prediction_split(edges, portions=(100, 1, 1), seed=1024):
                        np.concatenate([true[:, 1], np.asarray(T, edges.dtype)]),
                        np.concatenate([np.ones(len(true), np.int64), np.zeros(len(H), np.int64)])))
     return edges[which == 0], splits
+
+
+def community_edges(num_vertex, num_edge, num_community=50, p_in=0.9, seed=7):
+    """Planted-partition graph with near-uniform degrees: u uniform, v in u's community with probability p_in.
+    Unlike the power-law graphs it has no hubs, so concurrent (Hogwild) and sequential training see almost no
+    same-row conflicts — the regime in which the two must agree closely."""
+    rng = np.random.default_rng(seed)
+    size = (num_vertex + num_community - 1) // num_community
+    out = np.empty((num_edge, 2), np.uint32)
+    filled = 0
+    while filled < num_edge:
+        n = num_edge - filled
+        u = rng.integers(0, num_vertex, n)
+        inside = rng.random(n) < p_in
+        base = (u // size) * size
+        width = np.minimum(size, num_vertex - base)
+        v = np.where(inside, base + (rng.random(n) * width).astype(np.int64), rng.integers(0, num_vertex, n))
+        keep = u != v
+        m = int(keep.sum())
+        out[filled:filled + m, 0] = u[keep]
+        out[filled:filled + m, 1] = v[keep]
+        filled += m
+    return out

@@ -102,7 +102,10 @@ typedef struct {
     int walk_batch;         /* walks per inner round */
     int augmentation_step;
     int shuffle_base;       /* pseudo shuffle; pool_size % shuffle_base must be 0 */
-    int tail_partition;     /* -1: fill all P*P block pools; r >= 0: only the blocks (*, r) — one GPU's column */
+    int tail_partition;     /* -1: fill all P*P block pools; r >= 0: only the blocks (*, r) — one GPU's column.
+                               EDGE mode then draws from an alias table over just the edges whose tail lives in
+                               partition r (the exact conditional distribution, nothing dropped); the walk modes
+                               draw as usual and drop pairs that end elsewhere. */
 } gvs_fill_config;
 
 /* pools[hp * P + tp] -> pool_size {tail, head} records (entries of unfilled blocks may be NULL).
@@ -117,6 +120,11 @@ const uint64_t *gvs_sampler_edge_alias(const gvs_sampler *s);
 const float *gvs_sampler_neighbor_prob(const gvs_sampler *s);      /* WALK: [D]; BIASED: [sum deg^2] */
 const uint32_t *gvs_sampler_neighbor_alias(const gvs_sampler *s);
 const uint64_t *gvs_sampler_edge_edge_offsets(const gvs_sampler *s); /* BIASED: [D + 1] */
+
+/* EDGE-mode column table of tail partition r (built by the first filtered fill): the flattened edge ids it
+ * covers and its alias table. */
+int gvs_sampler_column(const gvs_sampler *s, int tail_partition, uint64_t *count, const uint64_t **edge_ids,
+                       const float **prob, const uint64_t **alias);
 
 /* The host uniform stream itself (RNG contract), for hosts that want to reproduce a fill. */
 void gvs_host_uniforms(uint64_t seed, uint32_t stream, uint64_t first, size_t n, double *out);

@@ -328,15 +328,18 @@ static double gvo_next(gvo_rand *g) { return g->pos < g->n ? g->r[g->pos++] : (g
  * or (size_t)-1 if the supplied stream was too short. */
 size_t gvo_sample_edges(const uint32_t *edges_uv, const float *edge_prob, const uint64_t *edge_alias,
                         uint64_t num_edge_entries, const int32_t *part, const uint32_t *local, int P,
-                        uint32_t **pools, int start, int end, int sample_batch_size, const double *rnd,
-                        size_t n_rnd) {
+                        uint32_t **pools, int start, int end, int sample_batch_size, int tail_filter,
+                        const double *rnd, size_t n_rnd) {
     gvo_rand g = {rnd, n_rnd, 0};
     if (start >= end) return 0;
     int *offsets = (int *)malloc(sizeof(int) * P * P);
     uint32_t *hu = (uint32_t *)malloc(sizeof(uint32_t) * sample_batch_size * 2);
     for (int i = 0; i < P * P; i++) offsets[i] = start;
     int num_complete = 0;
-    while (num_complete < P * P) {
+    /* tail_filter >= 0 (this repo's one-column-per-GPU mode): only blocks (*, tail_filter) are filled and
+     * waited for; the caller passes the edge list / table restricted to edges that end in that partition */
+    const int target = tail_filter < 0 ? P * P : P;
+    while (num_complete < target) {
         for (int i = 0; i < sample_batch_size; i++) {
             double r1 = gvo_next(&g), r2 = gvo_next(&g);
             uint64_t e = gvo_alias_sample(edge_prob, edge_alias, 8, num_edge_entries, r1, r2);
@@ -347,6 +350,7 @@ size_t gvo_sample_edges(const uint32_t *edges_uv, const float *edge_prob, const 
             uint32_t h = hu[2 * i], t = hu[2 * i + 1];
             int hp = part[h], tp = part[t];
             int *offset = &offsets[hp * P + tp];
+            if (tail_filter >= 0 && tp != tail_filter) continue;
             if (*offset < end) {
                 uint32_t *pool = pools[hp * P + tp];
                 pool[2 * (size_t)*offset] = local[t];
@@ -366,7 +370,7 @@ size_t gvo_sample_walks(int biased, const uint32_t *edges_uv, const float *edge_
                         uint64_t num_edge_entries, const uint64_t *flat_offsets /* [N+1] */, const float *nb_prob,
                         const uint32_t *nb_alias, const uint64_t *ee_offsets, const int32_t *part,
                         const uint32_t *local, int P, uint32_t **pools, int pool_size, int start, int end,
-                        int walk_length, int walk_batch, int augmentation_step, int shuffle_base,
+                        int walk_length, int walk_batch, int augmentation_step, int shuffle_base, int tail_filter,
                         const double *rnd, size_t n_rnd) {
     gvo_rand g = {rnd, n_rnd, 0};
     if (start >= end) return 0;
@@ -377,7 +381,8 @@ size_t gvo_sample_walks(int biased, const uint32_t *edges_uv, const float *edge_
     int *lengths = (int *)malloc(sizeof(int) * walk_batch);
     for (int i = 0; i < P * P; i++) offsets[i] = start;
     int num_complete = 0;
-    while (num_complete < P * P) {
+    const int target = tail_filter < 0 ? P * P : P; /* walks: pairs ending elsewhere are drawn, then dropped */
+    while (num_complete < target) {
         for (int i = 0; i < walk_batch; i++) {
             uint32_t *chain = chains + (size_t)i * (L + 1);
             double r1 = gvo_next(&g), r2 = gvo_next(&g);
@@ -411,6 +416,7 @@ size_t gvo_sample_walks(int biased, const uint32_t *edges_uv, const float *edge_
                     uint32_t h = chain[j], t = chain[j + k];
                     int hp = part[h], tp = part[t];
                     int *offset = &offsets[hp * P + tp];
+                    if (tail_filter >= 0 && tp != tail_filter) continue;
                     if (*offset < end) {
                         uint32_t *pool = pools[hp * P + tp];
                         int shuffled = *offset % shuffle_base * (pool_size / shuffle_base) + *offset / shuffle_base;

@@ -266,6 +266,32 @@ def test_walk_samplers_bit_exact(oracle, mode):
         assert (column[(h, 1)] == want[h * P + 1]).all()
 
 
+def test_edge_sampler_column_mode_bit_exact(oracle):
+    """One GPU's column: EDGE mode draws from an alias table over exactly the edges that end in that partition."""
+    g = small_graph(seed=9)
+    P, T, pool_size, r = 3, 2, 1500, 1
+    part, local, _ = hostlib.partition(g.vertex_weights, P)
+    s = hostlib.Sampler(g, part, local, P, seed=21)
+    column = {(h, r): np.zeros(pool_size * 2, np.uint32) for h in range(P)}
+    s.fill(column, pool_size, "edge", T, sample_batch_size=200, tail_partition=r)
+    ids, prob, alias = s.column(r)
+    want_ids = np.nonzero(part[g.edges[:, 1]] == r)[0]
+    assert (ids == want_ids).all()
+    oprob, oalias = oracle.alias_build(g.edge_weights[want_ids], 8)
+    assert (prob == oprob).all() and (alias == oalias).all()
+    want = [np.zeros(pool_size * 2, np.uint32) for _ in range(P * P)]
+    work = (pool_size + T - 1) // T
+    for t in range(T):
+        rnd = oracle.host_uniforms(21, t, 0, 200000)
+        used = oracle.sample_edges(g.edges[want_ids], oprob, oalias, part, local, P, want, work * t,
+                                   min(work * (t + 1), pool_size), 200, rnd, tail_filter=r)
+        assert used == s.stream_position(t)
+    for h in range(P):
+        assert (column[(h, r)] == want[h * P + r]).all()
+    # nothing is dropped: every draw lands in the column, so exactly 2 uniforms per pool slot (+ round slack)
+    assert sum(s.stream_position(t) for t in range(T)) < 2 * (P * pool_size) * 3
+
+
 def test_edge_sampler_distribution():
     """Positive pairs follow the edge weights; ids land in the right block with the right local ids."""
     g = small_graph(seed=7, n=60, e=400)

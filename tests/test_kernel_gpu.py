@@ -142,28 +142,35 @@ def test_negative_draw_bit_exact(hip, oracle):
 
 
 def test_fused_draw_equals_explicit_negatives(hip, oracle):
-    """gvk_train with negatives == NULL trains on exactly the negatives gvk_negative_draw reports."""
+    """gvk_train with negatives == NULL trains on exactly the negatives gvk_negative_draw reports: on the pairs
+    whose rows nobody else in the batch touches, the result equals the sequential oracle fed those negatives."""
     rng = np.random.default_rng(12)
-    N, B, k, dim = 3000, 512, 2, 128
+    N, B, k, dim = 60000, 512, 2, 128
     v, c = init_tables(rng, N, N, dim)
-    pairs, _ = random_batch(rng, N, N, B, k)
-    pairs[:, 1] = rng.permutation(N)[:B]  # distinct heads; context conflicts remain (Hogwild)
+    v *= 20
+    c *= 20
+    pairs, _ = conflict_free_batch(rng, N, N, B, 0)
     prob, alias, packed = K.alias_build(power_law_weights(rng, N))
     table = K.packed_to_device(packed, DEV)
     seed, batch_id = 99, 5
     negs = oracle.negatives(prob, alias, seed, batch_id, B, k)
-    # conflict-free subset check: compare against explicit-negative launch on the same data
-    tv1, tc1, tv2, tc2 = dev(v), dev(c), dev(v), dev(c)
-    tp = dev(pairs.view(np.int32))
-    l1 = torch.zeros(B, device=DEV)
-    l2 = torch.zeros(B, device=DEV)
-    spec = OPTS["SGD"][1]
-    hip.train(tv1, tc1, tp, l1, spec, k, 5.0, table=table, seed=seed, batch_id=batch_id)
-    hip.train(tv2, tc2, tp, l2, spec, k, 5.0, negatives=dev(negs.view(np.int32)))
+    ov, oc = v.copy(), c.copy()
+    oloss = oracle.train(ov, oc, pairs, negs, 0.025, 0.005, 5.0)
+    tv, tc = dev(v), dev(c)
+    loss = torch.zeros(B, device=DEV)
+    hip.train(tv, tc, dev(pairs.view(np.int32)), loss, OPTS["SGD"][1], k, 5.0, table=table, seed=seed,
+              batch_id=batch_id)
     torch.cuda.synchronize()
-    # vertex rows have distinct heads -> deterministic up to context races; losses are per-sample forward values
-    np.testing.assert_allclose(l1.cpu().numpy(), l2.cpu().numpy(), rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(tv1.cpu().numpy(), tv2.cpu().numpy(), rtol=1e-3, atol=1e-6)
+    # pairs whose context rows (tail + negatives) are touched by no other pair: deterministic under Hogwild
+    rows = np.concatenate([pairs[:, :1], negs], 1)
+    ids, counts = np.unique(rows, return_counts=True)
+    shared = set(ids[counts > 1].tolist())
+    clean = np.array([not (set(r.tolist()) & shared) for r in rows])
+    assert clean.sum() > B // 2
+    hv, hc, hl = tv.cpu().numpy(), tc.cpu().numpy(), loss.cpu().numpy()
+    np.testing.assert_allclose(hl[clean], oloss[clean], rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(hv[pairs[clean, 1]], ov[pairs[clean, 1]], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(hc[rows[clean].ravel()], oc[rows[clean].ravel()], rtol=RTOL, atol=ATOL)
 
 
 def test_alias_sample_matches_reference_semantics(hip, oracle):
@@ -201,14 +208,16 @@ def test_hogwild_batch_statistics(hip, oracle):
     ov, oc = v.copy(), c.copy()
     oloss = oracle.train(ov, oc, pairs, negs, 0.025, 0.005, 5.0)
     hv, hc, hloss, _ = run_hip(hip, v, c, pairs, negs, OPTS["SGD"][1], 5.0)
+    # every row is hit ~10 times inside this one batch: the parallel kernel loses most same-row updates that
+    # the sequential oracle applies one after another, so only aggregate agreement is expected
     assert abs(hloss.mean() - oloss.mean()) <= 1e-3 * abs(oloss.mean())
-    assert abs(np.linalg.norm(hv) - np.linalg.norm(ov)) <= 1e-2 * np.linalg.norm(ov)
-    assert abs(np.linalg.norm(hc) - np.linalg.norm(oc)) <= 1e-2 * np.linalg.norm(oc)
+    assert abs(np.linalg.norm(hv) - np.linalg.norm(ov)) <= 3e-2 * np.linalg.norm(ov)
+    assert abs(np.linalg.norm(hc) - np.linalg.norm(oc)) <= 3e-2 * np.linalg.norm(oc)
 
 
 def test_empty_and_ragged_batches(hip, oracle):
     rng = np.random.default_rng(5)
-    N, dim = 512, 128
+    N, dim = 1024, 128
     v, c = init_tables(rng, N, N, dim)
     spec = OPTS["SGD"][1]
     # empty batch: nothing happens, no error
