@@ -77,6 +77,8 @@ def lib():
     l.gvk_alias_sample.argtypes = [vp, vp, u32, vp, vp, i32]
     l.gvk_negative_draw.restype = i32
     l.gvk_negative_draw.argtypes = [vp, vp, u32, u64, u32, vp, i32, i32]
+    l.gvk_sample_pairs.restype = i32
+    l.gvk_sample_pairs.argtypes = [vp, vp, vp, u32, u64, u64, vp, C.c_size_t]
     l.gvk_alias_build.restype = i32
     l.gvk_alias_build.argtypes = [vp, C.c_size_t, vp, vp, i32, vp]
     l.gvk_set_tuning.restype = i32

@@ -157,6 +157,50 @@ class GraphApplication(ApplicationMixin):
         return solver_module.GraphSolver(self.dim, self.float_type, self.index_type, self.gpus,
                                          num_sampler_per_worker, self.gpu_memory_limit)
 
+    def set_parameters(self, model):
+        """Copy embeddings from another application, matching nodes by name (application.py:288-291)."""
+        mapping = self.get_mapping(self.graph.id2name, model.graph.name2id)
+        self.solver.vertex_embeddings[:] = model.solver.vertex_embeddings[mapping]
+        self.solver.context_embeddings[:] = model.solver.context_embeddings[mapping]
+
+    def node_classification(self, X=None, Y=None, file_name=None, portions=(0.02,), normalization=False, times=1,
+                            patience=100):
+        """
+        Evaluate node embeddings on node classification task: one-vs-rest logistic regression on the vertex
+        embeddings for each training portion, macro / micro F1 with the top-k-labels rule
+        (application.py:293-351, 456-533).  Downstream evaluation, so plain torch like the reference's.
+
+        Returns:
+            dict: macro-F1 & micro-F1 averaged over all trials
+        """
+        if file_name:
+            if not (X is None and Y is None):
+                raise ValueError("Evaluation data and file should not be provided at the same time")
+            X, Y = [], []
+            with open(file_name, "r") as fin:
+                for line in fin:
+                    tokens = self.tokenize(line)
+                    if len(tokens) == 0:
+                        continue
+                    x, y = tokens
+                    X.append(x)
+                    Y.append(y)
+        if X is None or Y is None:
+            raise ValueError("Either evaluataion data (X, Y) or a file name should be provided")
+        name2id = self.graph.name2id
+        class2id = {c: i for i, c in enumerate(np.unique(Y))}
+        new_X, new_Y = self.name_map((name2id, class2id), ([str(x) for x in X], list(Y)))
+        logger.info("effective labels: %d / %d", len(new_X), len(X))
+        labels = np.zeros((self.graph.num_vertex, len(class2id)), np.int64)
+        labels[np.asarray(new_X, np.int64), np.asarray(new_Y, np.int64)] = 1
+        indexes = np.nonzero(labels.sum(1) > 0)[0]  # discard non-labeled nodes
+        labels = labels[indexes]
+        embeddings = np.array(self.solver.vertex_embeddings[indexes])
+        metrics = {}
+        for portion in portions:
+            metrics.update(linear_classification(embeddings, labels, portion, normalization, times, patience))
+        return metrics
+
     def link_prediction(self, H=None, T=None, Y=None, file_name=None, filter_H=None, filter_T=None, filter_file=None):
         """
         Evaluate node embeddings on link prediction task: AUC of score = <vertex[h], context[t]>
@@ -214,3 +258,56 @@ class GraphApplication(ApplicationMixin):
         total = int((Y == 0).sum()) * int((Y == 1).sum())
         auc = float(hit[Y == 0].sum()) / total if total else float("nan")
         return {"AUC": auc}
+
+
+def linear_classification(embeddings, labels, portion, normalization=False, times=1, patience=100):
+    """One-vs-rest logistic regression on frozen embeddings, as the reference's linear_classification
+    (application.py:456-533): SGD(lr 1, weight decay 2e-5, momentum 0.9) on the full training set until the loss
+    has not improved for `patience` epochs; a test node with n true labels is assigned its n top-scoring classes."""
+    import torch
+    from torch.nn import functional as F
+
+    device = "cuda" if torch.cuda.is_available() else "cpu"
+    num_sample, num_class = labels.shape
+    num_train = int(num_sample * portion)
+    if normalization:
+        embeddings = embeddings / np.linalg.norm(embeddings, axis=1, keepdims=True)
+    features = torch.as_tensor(embeddings, dtype=torch.float32, device=device)
+    all_labels = torch.as_tensor(labels, device=device)
+    macro_f1s, micro_f1s = [], []
+    for _ in range(times):
+        samples = np.random.permutation(num_sample)
+        train = labels[samples[:num_train]]
+        rows, classes = np.nonzero(train)  # one training example per (node, label) pair
+        train_x = features[torch.as_tensor(samples[:num_train][rows], device=device)]
+        train_y = torch.zeros((len(rows), num_class), device=device)
+        train_y[torch.arange(len(rows), device=device), torch.as_tensor(classes, device=device)] = 1
+        test_index = torch.as_tensor(samples[num_train:], device=device)
+        test_x, test_y = features[test_index], all_labels[test_index]
+
+        linear = torch.nn.Linear(features.shape[1], num_class, bias=True).to(device)
+        optimizer = torch.optim.SGD(linear.parameters(), lr=1, weight_decay=2e-5, momentum=0.9)
+        best_loss, best_epoch = float("inf"), -1
+        for epoch in range(100000):
+            optimizer.zero_grad()
+            loss = F.binary_cross_entropy_with_logits(linear(train_x), train_y)
+            loss.backward()
+            optimizer.step()
+            loss = loss.item()
+            if loss < best_loss:
+                best_epoch, best_loss = epoch, loss
+            if epoch == best_epoch + patience:
+                break
+
+        with torch.no_grad():
+            logits = linear(test_x)
+            num_labels = test_y.sum(dim=1, keepdim=True)
+            ordered, _ = logits.sort(dim=1, descending=True)
+            thresholds = ordered.gather(dim=1, index=num_labels - 1)
+            predictions = (logits >= thresholds).long()
+            tp = (predictions & test_y).sum(dim=0).float()
+            t, p = test_y.sum(dim=0).float(), predictions.sum(dim=0).float()
+            macro_f1s.append((2 * tp / (t + p)).mean().item())
+            micro_f1s.append((2 * tp.sum() / (t.sum() + p.sum())).item())
+    return {"macro-F1@%g%%" % (portion * 100): float(np.mean(macro_f1s)),
+            "micro-F1@%g%%" % (portion * 100): float(np.mean(micro_f1s))}

@@ -359,6 +359,23 @@ __global__ void __launch_bounds__(kBlock) negative_draw_kernel(const gvk_alias_e
     out[i] = resolve(d, table[d.index]);
 }
 
+constexpr uint32_t kTagPositive = 0x706f7321u;
+
+__global__ void __launch_bounds__(kBlock) sample_pairs_kernel(const gvk_alias_entry *table, const u32x2 *block_pairs,
+                                                              uint32_t count, uint64_t seed, uint64_t first_index,
+                                                              u32x2 *pool, size_t n) {
+    const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n) return;
+    const uint64_t i = first_index + t;
+    uint32_t w[4];
+    philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), 0, kTagPositive, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    Draw d;
+    d.index = __umulhi(w[0], count);
+    d.u = (float)(w[1] >> 8) * (1.0f / 16777216.0f);
+    const uint32_t edge = resolve(d, table[d.index]);
+    __builtin_nontemporal_store(block_pairs[edge], pool + t);
+}
+
 // ---- dispatch ----------------------------------------------------------------------------------------------
 
 int fail(int code, const char *what) { return gvk_fail(code, "%s", what); }
@@ -554,6 +571,18 @@ int gvk_negative_draw(void *stream, const gvk_alias_entry *table, uint32_t count
     hipLaunchKernelGGL(negative_draw_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                        (hipStream_t)stream, table, count, seed, batch_id, negatives, batch_size, num_negative);
     return check_launch("gvk_negative_draw");
+}
+
+int gvk_sample_pairs(void *stream, const gvk_alias_entry *table, const uint32_t *block_pairs, uint32_t count,
+                     uint64_t seed, uint64_t first_index, uint32_t *pool, size_t n) {
+    if (n == 0) return GVK_OK;
+    if (!table || !block_pairs || !count || !pool) return fail(GVK_EINVAL, "gvk_sample_pairs: null pointer / empty block");
+    const size_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffu) return fail(GVK_EINVAL, "gvk_sample_pairs: pool too large for one call");
+    hipLaunchKernelGGL(sample_pairs_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, table,
+                       reinterpret_cast<const u32x2 *>(block_pairs), count, seed, first_index,
+                       reinterpret_cast<u32x2 *>(pool), n);
+    return check_launch("gvk_sample_pairs");
 }
 
 int gvk_set_tuning(int key, int value) {

@@ -165,6 +165,17 @@ class HipKernels(object):
                                         batch_size, num_negative)
         _lib.check(rc, "gvk_negative_draw")
 
+    def sample_pairs(self, table, block_pairs, seed, first_index, pool, n):
+        """pool[:n] = positive pairs of one block drawn on the device (gvk_sample_pairs)."""
+        _need(table, torch.int64, "block alias table")
+        _need(block_pairs, torch.int32, "block pairs", table.device)
+        _need(pool, torch.int32, "pool", table.device)
+        if block_pairs.numel() != 2 * table.numel() or pool.numel() < 2 * n:
+            raise ValueError("block_pairs must hold one {tail, head} record per table entry and pool 2 * n values")
+        rc = self.lib.gvk_sample_pairs(self._stream(table), _ptr(table), _ptr(block_pairs), table.numel(), seed,
+                                       first_index, _ptr(pool), n)
+        _lib.check(rc, "gvk_sample_pairs")
+
     def set_lanes_per_pair(self, lanes):
         _lib.check(self.lib.gvk_set_tuning(_lib.TUNE_LANES_PER_PAIR, lanes), "gvk_set_tuning")
 

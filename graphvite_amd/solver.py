@@ -63,7 +63,7 @@ class GraphSolver(object):
     available_models = ("DeepWalk", "LINE", "node2vec")
 
     def __init__(self, dim, float_type=dtype.float32, index_type=dtype.uint32, device_ids=(),
-                 num_sampler_per_worker=auto, gpu_memory_limit=auto, kernels=None, seed=0):
+                 num_sampler_per_worker=auto, gpu_memory_limit=auto, kernels=None, seed=0, device_sampling=False):
         if dim not in self.available_dims or float_type != dtype.float32 or index_type != dtype.uint32:
             raise AttributeError("Can't find an instantiation of GraphSolver with dim=%s, float_type=%s, "
                                  "index_type=%s" % (dim, float_type, index_type))
@@ -94,6 +94,8 @@ class GraphSolver(object):
         self.gpu_memory_limit = gpu_memory_limit
         self.gpu_memory_cost = 0
         self.seed = seed
+        # extension: draw LINE's positive edge samples on the GPU instead of CPU threads
+        self.device_sampling = bool(device_sampling)
         self.graph = None
         self.batch_id = 0
         self._sampler = None
@@ -247,6 +249,17 @@ class GraphSolver(object):
                                  random_walk_batch_size, shuffle_base, p, q, positive_reuse,
                                  negative_sample_exponent, negative_weight, log_frequency)
         state = self._upload_state()
+        if self.device_sampling:
+            if self._mode != "edge":
+                raise ValueError("device_sampling covers edge sampling (augmentation_step 1); random-walk models "
+                                 "use the CPU samplers")
+            try:
+                self._upload_block_tables(state)
+                while self.batch_id < self.num_batch:
+                    self._train_episode_device_sampling(state)
+            finally:
+                self._write_back(state)
+            return
         pools = self._host_pools()
         uploads = [[], []]  # per pool set: events of the async H2D copies still reading its pinned buffers
         try:
@@ -401,6 +414,37 @@ class GraphSolver(object):
             self._fill(pools)
         except BaseException as e:  # surfaced on the training thread
             self._fill_error = e
+
+    # ---- device-side positive sampling (edge mode) ---------------------------------------------------------
+    def _upload_block_tables(self, state):
+        """Per block this worker trains: the block's directed edges as {tail, head} local-id records and an alias
+        table over their weights — what gvk_sample_pairs draws from."""
+        from .kernels import alias_build, packed_to_device
+        edges, weights = self.graph.edges, self.graph.edge_weights
+        hp_of, tp_of = self._part[edges[:, 0]], self._part[edges[:, 1]]
+        state["block_tables"] = {}
+        for hp, tp in sorted({(int(s[self.rank][0]), int(s[self.rank][1])) for s in self._schedule}):
+            ids = np.nonzero((hp_of == hp) & (tp_of == tp))[0]
+            if ids.size == 0:
+                raise ValueError("block (%d, %d) has no edges; use fewer partitions for this graph" % (hp, tp))
+            pairs = np.stack([self._local[edges[ids, 1]], self._local[edges[ids, 0]]], 1).astype(np.uint32)
+            _, _, packed = alias_build(weights[ids])
+            state["block_tables"][(hp, tp)] = (packed_to_device(packed, self.device),
+                                                self._to_device(pairs.view(np.int32).reshape(-1)))
+        state["positive_index"] = 0
+
+    def _train_episode_device_sampling(self, state):
+        n = self.episode_size * self.batch_size
+        seed = (self.seed * 0x9E3779B1 + 0x706f73 + self.rank) & (2 ** 64 - 1)
+        for i, step in enumerate(self._schedule):
+            hp, tp = int(step[self.rank][0]), int(step[self.rank][1])
+            table, pairs = state["block_tables"][(hp, tp)]
+            pool = state["pool_dev"][i & 1]
+            self.kernels.sample_pairs(table, pairs, seed, state["positive_index"], pool, n)
+            state["positive_index"] += n
+            self._train_block(state, hp, tp, pool)
+            if self.num_worker > 1:
+                self._exchange(state, i)
 
     # ---- one episode ----------------------------------------------------------------------------------------
     def _train_episode(self, state, pools):
@@ -558,6 +602,19 @@ class GraphSolver(object):
         for start in range(0, n, B):
             self.kernels.predict(vertex, context, pairs[start:start + B], logits[start:start + B])
         return logits.cpu().numpy()
+
+    def save_embeddings(self, file_name):
+        """Save vertex embeddings in word2vec binary format: "N dim\n", then per node its name, a space, dim raw
+        float32 values and a newline (GraphSolver::save_embeddings, graph.cuh:796-805; unbound in the reference)."""
+        if self.vertex_embeddings is None:
+            raise RuntimeError("The model must be built on a graph first")
+        names = self.graph.id2name
+        with open(file_name, "wb") as fout:
+            fout.write(b"%d %d\n" % (self.num_vertex, self.dim))
+            for i in range(self.num_vertex):
+                fout.write(names[i].encode() + b" ")
+                fout.write(self.vertex_embeddings[i].tobytes())
+                fout.write(b"\n")
 
     def clear(self):
         """Free CPU and GPU memory, except the embeddings on CPU."""

@@ -124,6 +124,17 @@ int gvk_alias_sample(void *stream, const gvk_alias_entry *table, uint32_t count,
 int gvk_negative_draw(void *stream, const gvk_alias_entry *table, uint32_t count, uint64_t seed,
                       uint32_t batch_id, uint32_t *negatives, int batch_size, int num_negative);
 
+/* Positive sampling on the device (SURVEY.md §8f rank 4 — the reference, and this repo's default, draw positives
+ * on CPU threads, include/core/solver.h:1012-1055).  For LINE with augmentation_step 1 a positive sample of block
+ * (head partition, tail partition) is an edge of that block drawn with probability proportional to its weight, so
+ * with an alias table over the block's edges the whole block pool is one kernel:
+ *     w = philox4x32_10(ctr = {i_lo, i_hi, 0, 0x706f7321}, key = seed),  i = first_index + t
+ *     index = (uint64(w[0]) * count) >> 32;  u = float(w[1] >> 8) * 2^-24
+ *     pool[t] = block_pairs[u < table[index].prob ? index : table[index].alias]          ({tail, head} records)
+ * Same distribution as the CPU edge sampler restricted to the block (exact conditional, nothing dropped). */
+int gvk_sample_pairs(void *stream, const gvk_alias_entry *table, const uint32_t *block_pairs, uint32_t count,
+                     uint64_t seed, uint64_t first_index, uint32_t *pool, size_t n);
+
 /* Host: Vose alias construction exactly as the reference orders it (FIFO queues, double mean).
  * index_bytes 4 -> uint32 alias[], 8 -> uint64 alias[].  n must be > 0 and < 2^31 (the reference's
  * loop counters are int).  packed (optional, index_bytes 4 only) receives the interleaved device form. */

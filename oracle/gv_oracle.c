@@ -241,6 +241,31 @@ uint32_t gvo_negative_draw(const float *prob, const uint32_t *alias, uint32_t co
     return u < prob[index] ? index : alias[index];
 }
 
+void gvo_negative_draw_batch(const float *prob, const uint32_t *alias, uint32_t count, uint64_t seed,
+                              uint32_t batch_id, int batch_size, int k, uint32_t *out) {
+    for (int s = 0; s < batch_size; s++)
+        for (int j = 0; j < k; j++)
+            out[(size_t)s * k + j] = gvo_negative_draw(prob, alias, count, seed, batch_id, (uint32_t)s, (uint32_t)j);
+}
+
+#define GVO_TAG_POS 0x706f7321u /* "pos!" */
+
+/* Device-side positive sampling of include/gvk.h (gvk_sample_pairs): out[t] = block_pairs[draw(first + t)] */
+void gvo_sample_pairs(const float *prob, const uint32_t *alias, const uint32_t *block_pairs, uint32_t count,
+                      uint64_t seed, uint64_t first, size_t n, uint32_t *out) {
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    for (size_t t = 0; t < n; t++) {
+        uint64_t i = first + t;
+        uint32_t ctr[4] = {(uint32_t)i, (uint32_t)(i >> 32), 0, GVO_TAG_POS}, w[4];
+        gvo_philox4x32(ctr, key, w);
+        uint32_t index = (uint32_t)(((uint64_t)w[0] * count) >> 32);
+        float u = (float)(w[1] >> 8) * (1.0f / 16777216.0f);
+        uint32_t edge = u < prob[index] ? index : alias[index];
+        out[2 * t] = block_pairs[2 * (size_t)edge];
+        out[2 * t + 1] = block_pairs[2 * (size_t)edge + 1];
+    }
+}
+
 /* Host uniform stream `stream`: doubles number 2i and 2i+1 come from
  *   philox(ctr = {i_lo, i_hi, stream, TAG_HOST}, key = seed); d = (((u64)w_hi << 32 | w_lo) >> 11) * 2^-53 */
 void gvo_host_uniforms(uint64_t seed, uint32_t stream, uint64_t first, size_t n, double *out) {

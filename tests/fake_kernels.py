@@ -51,6 +51,12 @@ class OracleKernels(object):
             self.train(vertex, context, pairs, loss, optimizer, num_negative, negative_weight, table=table, seed=seed,
                        batch_id=bid, moments=moments, lr=np.float32(optimizer.lr) * np.float32(scale))
 
+    def sample_pairs(self, table, block_pairs, seed, first_index, pool, n):
+        packed = table.numpy().view(np.dtype([("prob", np.float32), ("alias", np.uint32)]))
+        out = self.oracle.sample_pairs(np.ascontiguousarray(packed["prob"]), np.ascontiguousarray(packed["alias"]),
+                                       block_pairs.numpy().view(np.uint32), seed, first_index, n)
+        pool.numpy().view(np.uint32)[:2 * n] = out.reshape(-1)
+
     def predict(self, vertex, context, pairs, logits):
         out = self.oracle.predict(vertex.numpy(), context.numpy(), np.ascontiguousarray(pairs.numpy().view(np.uint32)))
         logits.numpy()[:len(out)] = out

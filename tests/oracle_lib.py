@@ -54,6 +54,10 @@ class Oracle(object):
         lib.gvo_philox4x32.argtypes = [_u32p, _u32p, _u32p]
         lib.gvo_negative_draw.restype = C.c_uint32
         lib.gvo_negative_draw.argtypes = [_f32p, _u32p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        lib.gvo_negative_draw_batch.restype = None
+        lib.gvo_negative_draw_batch.argtypes = [_f32p, _u32p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.c_int, _u32p]
+        lib.gvo_sample_pairs.restype = None
+        lib.gvo_sample_pairs.argtypes = [_f32p, _u32p, _u32p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_size_t, _u32p]
         lib.gvo_host_uniforms.restype = None
         lib.gvo_host_uniforms.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_size_t, _f64p]
         lib.gvo_partition.restype = C.c_int
@@ -125,9 +129,13 @@ class Oracle(object):
 
     def negatives(self, prob, alias, seed, batch_id, batch_size, k):
         out = np.zeros((batch_size, k), np.uint32)
-        for s in range(batch_size):
-            for j in range(k):
-                out[s, j] = self.negative_draw(prob, alias, seed, batch_id, s, j)
+        self.lib.gvo_negative_draw_batch(prob, alias, prob.size, seed, batch_id, batch_size, k, out.reshape(-1))
+        return out
+
+    def sample_pairs(self, prob, alias, block_pairs, seed, first, n):
+        out = np.zeros((n, 2), np.uint32)
+        self.lib.gvo_sample_pairs(prob, alias, np.ascontiguousarray(block_pairs, np.uint32).reshape(-1), prob.size,
+                                  seed, first, n, out.reshape(-1))
         return out
 
     def host_uniforms(self, seed, stream, first, n):

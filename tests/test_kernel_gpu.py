@@ -173,6 +173,19 @@ def test_fused_draw_equals_explicit_negatives(hip, oracle):
     np.testing.assert_allclose(hc[rows[clean].ravel()], oc[rows[clean].ravel()], rtol=RTOL, atol=ATOL)
 
 
+def test_sample_pairs_bit_exact(hip, oracle):
+    """Device-side positive sampling: integer work, bit-exact against the oracle's restatement."""
+    rng = np.random.default_rng(31)
+    n_edges, n = 7000, 20000
+    prob, alias, packed = K.alias_build(power_law_weights(rng, n_edges))
+    block_pairs = rng.integers(0, 1 << 20, (n_edges, 2)).astype(np.uint32)
+    pool = torch.zeros(2 * n, dtype=torch.int32, device=DEV)
+    seed, first = 0xABCDEF0123456789, (1 << 33) + 5
+    hip.sample_pairs(K.packed_to_device(packed, DEV), dev(block_pairs.view(np.int32).reshape(-1)), seed, first, pool, n)
+    got = pool.cpu().numpy().view(np.uint32).reshape(n, 2)
+    assert (got == oracle.sample_pairs(prob, alias, block_pairs, seed, first, n)).all()
+
+
 def test_alias_sample_matches_reference_semantics(hip, oracle):
     rng = np.random.default_rng(13)
     prob, alias, packed = K.alias_build(power_law_weights(rng, 1000))

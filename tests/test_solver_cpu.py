@@ -93,6 +93,36 @@ def test_models_and_samplers_run(model, aug):
         assert s.shuffle_base == 1
 
 
+def test_device_sampling_mode_host_logic(oracle):
+    """Edge positives drawn by gvk_sample_pairs (oracle-backed here): block tables cover exactly the block's edges,
+    every pair trained on is a real edge of the right block, training learns, walk models are refused."""
+    g = make_graph(200, 2000, seed=8)
+    k = OracleKernels()
+    s = gv.solver.GraphSolver(32, kernels=k, num_sampler_per_worker=1, device_sampling=True, seed=4)
+    s.build(g, batch_size=400, episode_size=3)
+    s.train("LINE", num_epoch=3, augmentation_step=1)
+    assert s.batch_id == 15 and np.abs(s.context_embeddings).max() > 0
+    with pytest.raises(ValueError, match="device_sampling"):
+        s.train("DeepWalk", num_epoch=1, augmentation_step=2)
+    # the pairs the kernel produced for an episode are edges of the graph (local ids of the single partition)
+    s._configure_training("LINE", 1, False, 1, 40, 100, 0, 1, 1, 1, 0.75, 5.0, 1000)
+    state = s._upload_state()
+    s._upload_block_tables(state)
+    table, pairs = state["block_tables"][(0, 0)]
+    assert table.numel() == g.num_directed_edge
+    pool = torch.zeros(2 * 5000, dtype=torch.int32)
+    k.sample_pairs(table, pairs, 123, 0, pool, 5000)
+    inv = np.argsort(s._local)  # local id -> global id (one partition)
+    rec = pool.numpy().view(np.uint32).reshape(-1, 2)
+    real = set(map(tuple, g.edges.tolist()))
+    assert all((int(inv[h]), int(inv[t])) in real for t, h in rec[:500])
+    # uniform weights -> every directed edge equally likely: heads follow the degree distribution
+    deg = np.bincount(g.edges[:, 0], minlength=g.num_vertex)
+    got = np.bincount(inv[rec[:, 1]], minlength=g.num_vertex)
+    top = np.argsort(-deg)[:5]
+    assert np.allclose(got[top] / 5000.0, deg[top] / deg.sum(), atol=0.02)
+
+
 def test_custom_schedule_and_optimizers():
     g = make_graph(150, 900, seed=4)
     k = OracleKernels()
@@ -146,6 +176,55 @@ def test_predict_and_link_prediction_pipeline(tmp_path):
     assert (app.solver.vertex_embeddings == old).all()
     with pytest.raises(ValueError):
         app.evaluate("node clustering")
+
+
+def test_node_classification_cli_and_embedding_file(tmp_path):
+    """The "next" rows around the path: node classification, `run config.yaml`, word2vec-format embeddings."""
+    import yaml
+    from graphvite_amd import cmd
+    edges = synthetic.community_edges(300, 6000, num_community=3, seed=2)
+    graph_file = tmp_path / "graph.txt"
+    np.savetxt(graph_file, edges, fmt="%d")
+    label_file = tmp_path / "label.txt"
+    with open(label_file, "w") as f:
+        for i in range(300):
+            f.write("%d\tc%d\n" % (i, i // 100))
+    config = {"application": "graph", "resource": {"dim": 32}, "format": {"delimiters": " \t\r\n", "comment": "#"},
+              "graph": {"file_name": str(graph_file), "as_undirected": True},
+              "build": {"optimizer": {"type": "SGD", "lr": 0.025, "weight_decay": 0.005}, "num_partition": "auto",
+                        "num_negative": 1, "batch_size": 1000, "episode_size": 10},
+              "train": {"model": "LINE", "num_epoch": 150, "augmentation_step": 1, "log_frequency": 100000},
+              "evaluate": [{"task": "node classification", "file_name": str(label_file), "portions": [0.2],
+                            "times": 1}],
+              "save": {"file_name": str(tmp_path / "model.pkl")}}
+    config_file = tmp_path / "config.yaml"
+    config_file.write_text(yaml.safe_dump(config))
+    real = gv.application.GraphApplication.get_solver
+    gv.application.GraphApplication.get_solver = lambda self, **kw: gv.solver.GraphSolver(
+        self.dim, kernels=OracleKernels(), num_sampler_per_worker=2)
+    try:
+        app = cmd.run_main(cmd.main.__globals__["argparse"].Namespace(config=str(config_file), gpu=None, cpu=None,
+                                                                      eval=True))
+    finally:
+        gv.application.GraphApplication.get_solver = real
+    assert app.solver.num_partition == 1 and app.solver.optimizer.type == "SGD" and (tmp_path / "model.pkl").exists()
+    result = app.node_classification(file_name=str(label_file), portions=(0.2,), times=2)
+    assert result["micro-F1@20%"] > 0.9 and result["macro-F1@20%"] > 0.9  # three planted communities
+    # word2vec-style embedding file
+    out = tmp_path / "emb.bin"
+    app.solver.save_embeddings(str(out))
+    data = open(out, "rb").read()
+    header, rest = data.split(b"\n", 1)
+    assert header == b"300 32"
+    name0 = app.graph.id2name[0].encode()
+    assert rest.startswith(name0 + b" ")
+    first = np.frombuffer(rest[len(name0) + 1:len(name0) + 1 + 32 * 4], np.float32)
+    assert (first == app.solver.vertex_embeddings[0]).all()
+    with pytest.raises(ValueError):
+        cmd.load_config.__call__  # placeholder datasets are rejected
+        bad = tmp_path / "bad.yaml"
+        bad.write_text("graph:\n  file_name: <blogcatalog.train>\n")
+        cmd.load_config(str(bad))
 
 
 # ---- world_size 2 over gloo -----------------------------------------------------------------------------------
