@@ -176,6 +176,11 @@ class GraphSolver(object):
         order = np.argsort(self._part.astype(np.int64) * (1 << 32) + self._local, kind="stable")
         starts = np.concatenate([[0], np.cumsum(self._part_sizes.astype(np.int64))]).astype(np.int64)
         self._part_ids = [order[starts[p]:starts[p + 1]] for p in range(P)]  # global ids in local order
+        # device tables are partition-major [P][S][dim]: slot p * S + local(v) holds vertex v
+        S = self._part_size
+        self._row_of_vertex = self._part.astype(np.int64) * S + self._local.astype(np.int64)
+        self._vertex_of_row = np.zeros(P * S, np.int64)  # padding slots point at vertex 0 and are never trained
+        self._vertex_of_row[self._row_of_vertex] = np.arange(self.num_vertex, dtype=np.int64)
         self._schedule = hostlib.schedule(P, W)
         self._my_tails = sorted({int(step[self.rank][1]) for step in self._schedule})
 
@@ -193,8 +198,7 @@ class GraphSolver(object):
         self.vertex_embeddings = np.zeros((self.num_vertex, self.dim), np.float32)
         self.context_embeddings = np.zeros((self.num_vertex, self.dim), np.float32)
         self._moments_host = None
-        self._sampler = hostlib.Sampler(graph, self._part, self._local, P,
-                                        (self.seed + 0x9E3779B97F4A7C15 * (self.rank + 1)) & (2 ** 64 - 1))
+        self._sampler = None  # the CPU sampler (edge alias table over all edges) is built at the first train()
         self._sampler_mode = None
 
     def _memory_demand(self, P):
@@ -245,10 +249,28 @@ class GraphSolver(object):
               negative_sample_exponent=0.75, negative_weight=5, log_frequency=1000)
         Train node embeddings.
         """
+        import time
+        t0 = time.time()
         self._configure_training(model, num_epoch, resume, augmentation_step, random_walk_length,
                                  random_walk_batch_size, shuffle_base, p, q, positive_reuse,
                                  negative_sample_exponent, negative_weight, log_frequency)
+        t1 = time.time()
         state = self._upload_state()
+        t2 = time.time()
+        first_batch = self.batch_id
+
+        def report():
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            t3 = time.time()
+            self._write_back(state)
+            t4 = time.time()
+            self.timing = {"configure": t1 - t0, "upload": t2 - t1, "episodes": t3 - t2, "write_back": t4 - t3,
+                           "batches": self.batch_id - first_batch}
+            logger.info("[time] configure %.2f s, upload %.2f s, %d batches in %.2f s (%.1f M edge-samples/s), "
+                        "write back %.2f s", t1 - t0, t2 - t1, self.batch_id - first_batch, t3 - t2,
+                        (self.batch_id - first_batch) * self.batch_size / max(t3 - t2, 1e-9) / 1e6, t4 - t3)
+
         if self.device_sampling:
             if self._mode != "edge":
                 raise ValueError("device_sampling covers edge sampling (augmentation_step 1); random-walk models "
@@ -258,7 +280,7 @@ class GraphSolver(object):
                 while self.batch_id < self.num_batch:
                     self._train_episode_device_sampling(state)
             finally:
-                self._write_back(state)
+                report()
             return
         pools = self._host_pools()
         uploads = [[], []]  # per pool set: events of the async H2D copies still reading its pinned buffers
@@ -281,7 +303,7 @@ class GraphSolver(object):
                     raise self._fill_error
                 current ^= 1
         finally:
-            self._write_back(state)
+            report()
 
     def _configure_training(self, model, num_epoch, resume, augmentation_step, random_walk_length,
                             random_walk_batch_size, shuffle_base, p, q, positive_reuse, negative_sample_exponent,
@@ -328,6 +350,12 @@ class GraphSolver(object):
         self._predict_cache = None
 
         mode = "edge" if self.augmentation_step == 1 else ("biased_walk" if model == "node2vec" else "walk")
+        self._mode = mode
+        if self.device_sampling and mode == "edge":
+            return  # positives are drawn on the device: no CPU tables needed
+        if self._sampler is None:
+            self._sampler = hostlib.Sampler(self.graph, self._part, self._local, self.num_partition,
+                                            (self.seed + 0x9E3779B97F4A7C15 * (self.rank + 1)) & (2 ** 64 - 1))
         key = (mode, self.p, self.q)
         if self._sampler_mode != key:  # get_sample_function, graph.cuh:680-721
             self._sampler.prepare(mode, self.p, self.q, self.num_sampler_per_worker + 1)
@@ -340,8 +368,9 @@ class GraphSolver(object):
         """vertex ~ U(-0.5/dim, 0.5/dim), context = 0 (GraphSolver::init_embeddings, graph.cuh:724-731).
         The generator is seeded identically on every process so all ranks start from the same table."""
         rng = np.random.default_rng(self.seed + 5489)
-        self.vertex_embeddings[:] = rng.uniform(-0.5 / self.dim, 0.5 / self.dim,
-                                                self.vertex_embeddings.shape).astype(np.float32)
+        rng.random(out=self.vertex_embeddings, dtype=np.float32)     # U[0, 1) straight into the stable buffer
+        self.vertex_embeddings -= np.float32(0.5)
+        self.vertex_embeddings *= np.float32(1.0 / self.dim)
         self.context_embeddings[:] = 0
         self._moments_host = None
 
@@ -355,21 +384,26 @@ class GraphSolver(object):
         nm = self.num_moment
 
         def gather(host, parts):
-            out = np.zeros((len(parts), S, dim), np.float32)
-            for i, p in enumerate(parts):
-                out[i, :len(self._part_ids[p])] = host[self._part_ids[p]]
+            """host [N][dim] (global ids) -> device [len(parts)][S][dim] (local ids); the permutation runs on the
+            device, the host only streams the table once."""
+            full = self._to_device(host)
+            rows = np.concatenate([self._vertex_of_row[p * S:(p + 1) * S] for p in parts])
+            out = full[self._to_device(rows)].view(len(parts), S, dim)
+            del full
             return out
 
-        state = {"vertex": self._to_device(gather(self.vertex_embeddings, range(P))),
-                 "context": self._to_device(gather(self.context_embeddings, self._my_tails))}
+        state = {"vertex": gather(self.vertex_embeddings, list(range(P))),
+                 "context": gather(self.context_embeddings, self._my_tails)}
         if nm:
             mh = self._moments_host if self.resume and self._moments_host is not None else None
             for j in range(nm):
-                vm = gather(mh["vertex"][j], range(P)) if mh else np.zeros((P, S, dim), np.float32)
-                cm = gather(mh["context"][j], self._my_tails) if mh else np.zeros((len(self._my_tails), S, dim),
-                                                                                   np.float32)
-                state["vertex_m%d" % j] = self._to_device(vm)
-                state["context_m%d" % j] = self._to_device(cm)
+                if mh:
+                    state["vertex_m%d" % j] = gather(mh["vertex"][j], list(range(P)))
+                    state["context_m%d" % j] = gather(mh["context"][j], self._my_tails)
+                else:
+                    state["vertex_m%d" % j] = torch.zeros((P, S, dim), dtype=torch.float32, device=self.device)
+                    state["context_m%d" % j] = torch.zeros((len(self._my_tails), S, dim), dtype=torch.float32,
+                                                           device=self.device)
         # negative sampler per owned tail partition: deg^exponent in local order (solver.h:1264-1278)
         from .kernels import alias_build, packed_to_device
         weights = self.graph.vertex_weights
@@ -543,14 +577,21 @@ class GraphSolver(object):
         if state is None:
             return
         import torch.distributed as dist
-        W, P = self.num_worker, self.num_partition
+        W, P, S = self.num_worker, self.num_partition, self._part_size
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
 
         def scatter(host, dev, parts):
-            arr = dev.cpu().numpy()
-            for i, p in enumerate(parts):
-                host[self._part_ids[p]] = arr[i, :len(self._part_ids[p])]
+            """device [len(parts)][S][dim] -> host [N][dim]: un-permute on the device, one D2H per table."""
+            slot = np.full(P, -1, np.int64)
+            slot[list(parts)] = np.arange(len(parts))
+            owned = slot[self._part] >= 0
+            rows = slot[self._part[owned]] * S + self._local[owned].astype(np.int64)
+            values = dev.reshape(-1, self.dim)[self._to_device(rows)].cpu().numpy()
+            if owned.all():
+                np.copyto(host, values)
+            else:
+                host[owned] = values
 
         def full_context(name):
             mine = state[name]
@@ -563,7 +604,7 @@ class GraphSolver(object):
                 tails += sorted({int(step[rank][1]) for step in self._schedule})
             return torch.cat(gathered, 0), tails
 
-        scatter(self.vertex_embeddings, state["vertex"], range(P))
+        scatter(self.vertex_embeddings, state["vertex"], list(range(P)))
         ctx, tails = full_context("context")
         scatter(self.context_embeddings, ctx, tails)
         if self.num_moment:
@@ -571,7 +612,7 @@ class GraphSolver(object):
             self._moments_host = {"vertex": [np.zeros(shape, np.float32) for _ in range(self.num_moment)],
                                   "context": [np.zeros(shape, np.float32) for _ in range(self.num_moment)]}
             for j in range(self.num_moment):
-                scatter(self._moments_host["vertex"][j], state["vertex_m%d" % j], range(P))
+                scatter(self._moments_host["vertex"][j], state["vertex_m%d" % j], list(range(P)))
                 cm, tails = full_context("context_m%d" % j)
                 scatter(self._moments_host["context"][j], cm, tails)
         self._device_state = None

@@ -21,10 +21,13 @@ for label, kw, train_kw in (("cpu-samplers", {}, {}), ("cpu-samplers reuse=4", {
                             ("DeepWalk aug=5", {}, {"model": "DeepWalk", "augmentation_step": 5})):
     solver = gv.solver.GraphSolver(128, **kw)
     solver.build(graph, batch_size=100000, episode_size=250)
-    cfg = dict(model="LINE", num_epoch=30, augmentation_step=1, log_frequency=1 << 30)
+    cfg = dict(model="LINE", num_epoch=100, augmentation_step=1, log_frequency=1 << 30)
     cfg.update(train_kw)
     t = time.time()
     solver.train(**cfg)
     el = time.time() - t
-    print("%-28s %8.1f M edge-samples/s end to end (%d batches in %.2f s, %d sampler threads)" % (
-        label, solver.batch_id * 100000 / el / 1e6, solver.batch_id, el, solver.num_sampler_per_worker), flush=True)
+    tm = solver.timing
+    print("%-28s %8.1f M edge-samples/s in the episode loop | train() %.2f s = configure %.2f + upload %.2f + "
+          "%d batches %.2f + write-back %.2f (%d sampler threads)" % (
+              label, tm["batches"] * 100000 / tm["episodes"] / 1e6, el, tm["configure"], tm["upload"], tm["batches"],
+              tm["episodes"], tm["write_back"], solver.num_sampler_per_worker), flush=True)
