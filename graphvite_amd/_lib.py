@@ -42,6 +42,13 @@ class FillConfig(C.Structure):
 MODE_EDGE, MODE_WALK, MODE_BIASED_WALK = 0, 1, 2
 
 
+class WalkGraph(C.Structure):
+    _fields_ = [("flat_offsets", C.c_void_p), ("edges_uv", C.c_void_p), ("edge_table", C.c_void_p),
+                ("neighbor_table", C.c_void_p), ("sorted_neighbors", C.c_void_p), ("local", C.c_void_p),
+                ("num_vertex", C.c_uint32), ("num_edge_entries", C.c_uint32), ("biased", C.c_int32),
+                ("p", C.c_float), ("q", C.c_float)]
+
+
 class NativeLibraryError(RuntimeError):
     pass
 
@@ -79,6 +86,8 @@ def lib():
     l.gvk_negative_draw.argtypes = [vp, vp, u32, u64, u32, vp, i32, i32]
     l.gvk_sample_pairs.restype = i32
     l.gvk_sample_pairs.argtypes = [vp, vp, vp, u32, u64, u64, vp, C.c_size_t]
+    l.gvk_sample_walks.restype = i32
+    l.gvk_sample_walks.argtypes = [vp, P(WalkGraph), u64, u64, vp, C.c_size_t, i32, i32, i32]
     l.gvk_alias_build.restype = i32
     l.gvk_alias_build.argtypes = [vp, C.c_size_t, vp, vp, i32, vp]
     l.gvk_set_tuning.restype = i32

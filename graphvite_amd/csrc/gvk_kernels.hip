@@ -376,6 +376,81 @@ __global__ void __launch_bounds__(kBlock) sample_pairs_kernel(const gvk_alias_en
     __builtin_nontemporal_store(block_pairs[edge], pool + t);
 }
 
+constexpr uint32_t kTagWalk = 0x77616c6bu;
+
+__device__ __forceinline__ bool has_neighbor(const gvk_walk_graph &g, uint32_t x, uint32_t u) {
+    uint64_t lo = g.flat_offsets[x], hi = g.flat_offsets[x + 1];
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        const uint32_t v = g.sorted_neighbors[mid];
+        if (v == u) return true;
+        if (v < u)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return false;
+}
+
+constexpr int kMaxAugmentation = 16;
+
+__global__ void __launch_bounds__(kBlock) sample_walks_kernel(const gvk_walk_graph g, uint64_t seed, uint64_t first_walk,
+                                                              u32x2 *pool, size_t pool_pairs, int L, int aug,
+                                                              uint64_t pairs_per_walk, uint64_t sb, uint64_t num_walks) {
+    const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= num_walks) return;
+    const uint64_t walk = first_walk + t;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const uint64_t begin = t * pairs_per_walk;
+    const uint64_t end = begin + pairs_per_walk < pool_pairs ? begin + pairs_per_walk : pool_pairs;
+    const uint64_t stride = pool_pairs / sb;
+    const float fmax = fmaxf(1.0f, fmaxf(1.0f / g.p, 1.0f / g.q));
+    uint64_t offset = begin;
+    uint32_t draw = 0;
+    uint32_t window[kMaxAugmentation];  // rows of the last `aug` chain nodes, window[j % aug]
+    while (offset < end) {
+        // start (or restart) a chain from a weighted random edge
+        uint32_t w[4];
+        philox4x32_10((uint32_t)walk, (uint32_t)(walk >> 32), draw++, kTagWalk, k0, k1, w);
+        Draw d;
+        d.index = __umulhi(w[0], g.num_edge_entries);
+        d.u = (float)(w[1] >> 8) * (1.0f / 16777216.0f);
+        uint64_t edge = resolve(d, g.edge_table[d.index]);
+        uint32_t previous = g.edges_uv[2 * edge], current = g.edges_uv[2 * edge + 1];
+        window[0] = g.local[previous];
+        int j = 1;  // index of `current` in the chain
+        while (true) {
+            // node j joined the chain: emit its pairs with the previous min(aug, j) nodes
+            const uint32_t row = g.local[current];
+            const int back = j < aug ? j : aug;
+            for (int k = 1; k <= back && offset < end; k++) {
+                const uint64_t slot = offset % sb * stride + offset / sb;
+                u32x2 record = {row, window[(j - k) % aug]};
+                __builtin_nontemporal_store(record, pool + slot);
+                offset++;
+            }
+            window[j % aug] = row;
+            if (j == L || offset >= end) break;
+            const uint64_t base = g.flat_offsets[current], degree = g.flat_offsets[current + 1] - base;
+            if (degree == 0) break;  // dead end: the chain stops here (graph.cuh:346-349,421-424)
+            uint32_t next;
+            while (true) {
+                philox4x32_10((uint32_t)walk, (uint32_t)(walk >> 32), draw++, kTagWalk, k0, k1, w);
+                d.index = __umulhi(w[0], (uint32_t)degree);
+                d.u = (float)(w[1] >> 8) * (1.0f / 16777216.0f);
+                const uint32_t neighbor = resolve(d, g.neighbor_table[base + d.index]);
+                next = g.edges_uv[2 * (base + neighbor) + 1];
+                if (!g.biased) break;
+                const float f = next == previous ? 1.0f / g.p : (has_neighbor(g, next, previous) ? 1.0f : 1.0f / g.q);
+                if ((float)(w[2] >> 8) * (1.0f / 16777216.0f) * fmax < f) break;
+            }
+            previous = current;
+            current = next;
+            j++;
+        }
+    }
+}
+
 // ---- dispatch ----------------------------------------------------------------------------------------------
 
 int fail(int code, const char *what) { return gvk_fail(code, "%s", what); }
@@ -583,6 +658,32 @@ int gvk_sample_pairs(void *stream, const gvk_alias_entry *table, const uint32_t 
                        reinterpret_cast<const u32x2 *>(block_pairs), count, seed, first_index,
                        reinterpret_cast<u32x2 *>(pool), n);
     return check_launch("gvk_sample_pairs");
+}
+
+int gvk_sample_walks(void *stream, const gvk_walk_graph *graph, uint64_t seed, uint64_t first_walk, uint32_t *pool,
+                     size_t pool_pairs, int walk_length, int augmentation_step, int shuffle_base) {
+    if (pool_pairs == 0) return GVK_OK;
+    if (!graph || !pool) return fail(GVK_EINVAL, "gvk_sample_walks: null pointer");
+    if (!graph->flat_offsets || !graph->edges_uv || !graph->edge_table || !graph->neighbor_table || !graph->local ||
+        !graph->num_edge_entries)
+        return fail(GVK_EINVAL, "gvk_sample_walks: incomplete graph description");
+    if (graph->biased && (!graph->sorted_neighbors || !(graph->p > 0) || !(graph->q > 0)))
+        return fail(GVK_EINVAL, "gvk_sample_walks: node2vec needs sorted_neighbors and positive p, q");
+    if (augmentation_step < 1 || augmentation_step > kMaxAugmentation)
+        return fail(GVK_EINVAL, "gvk_sample_walks: augmentation_step must be in [1, 16]");
+    if (augmentation_step > walk_length)
+        return fail(GVK_EINVAL, "`random_walk_length` should be no less than `augmentation_step`");
+    if (shuffle_base < 1 || pool_pairs % (size_t)shuffle_base)
+        return fail(GVK_EINVAL, "gvk_sample_walks: pool size must be a multiple of the shuffle base");
+    const uint64_t per_walk = (uint64_t)augmentation_step * walk_length -
+                              (uint64_t)augmentation_step * (augmentation_step - 1) / 2;
+    const uint64_t walks = (pool_pairs + per_walk - 1) / per_walk;
+    const uint64_t blocks = (walks + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffu) return fail(GVK_EINVAL, "gvk_sample_walks: pool too large for one call");
+    hipLaunchKernelGGL(sample_walks_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, *graph, seed,
+                       first_walk, reinterpret_cast<u32x2 *>(pool), pool_pairs, walk_length, augmentation_step, per_walk,
+                       (uint64_t)shuffle_base, walks);
+    return check_launch("gvk_sample_walks");
 }
 
 int gvk_set_tuning(int key, int value) {

@@ -11,7 +11,11 @@
 //     instead of 40 MB cuRAND buffers copied back from the GPU (include/core/solver.h:943-967,1015-1016);
 //   * per-vertex / per-edge alias tables live in two flat CSR-aligned arrays, not in one AliasTable object
 //     (two heap blocks) per vertex or per edge (include/instance/graph.cuh:645-677).
-// The order in which uniforms are consumed and pool slots are written follows the reference loop for loop.
+//   * every sampler stage (alias slot -> edge -> locations; per walk step: table slot -> edge -> location) runs over
+//     a whole inner round with the next stage's cache lines prefetched: tens of DRAM misses in flight per thread
+//     instead of one dependent chain at a time (5x on the edge sampler end to end).
+// Pool slots are written in the reference's order; uniforms are consumed in the reference's order by the edge sampler
+// and in lockstep order (see fill_walks) by the walk samplers.
 
 #include <math.h>
 #include <stdint.h>
@@ -516,24 +520,40 @@ void fill_edges(FillShared *sh, int thread, int64_t start, int64_t end, uint64_t
     if (start >= end) return;
     BlockCursor cur(s.P, sh->c.tail_partition, start, end);
     const int n = sh->c.sample_batch_size;
-    std::vector<uint64_t> heads(n), tails(n);
     const uint32_t *edges = s.g->edges_uv.data();
     const gvs_sampler::Column *column =
         sh->c.tail_partition >= 0 && s.P > 1 ? &s.columns[sh->c.tail_partition] : nullptr;
+    const EdgeSlot *slots = column ? column->slots.data() : s.edge_slots.data();
+    const double count = (double)(column ? column->slots.size() : s.edge_slots.size());
+    // A draw is a chain of dependent cache misses (slot -> edge -> two locations) into tables far larger than the
+    // caches.  The reference walks that chain one sample at a time (solver.h:1022-1035); here every stage runs over
+    // the whole inner round with the next stage's lines prefetched, so a thread keeps tens of misses in flight.
+    // Uniforms are still consumed two per sample, in sample order.
+    std::vector<uint64_t> index(n), edge(n), heads(n), tails(n);
+    std::vector<float> u(n);
     int idle = 0;
     while (!cur.done() && !sh->error.load(std::memory_order_relaxed)) {
         for (int i = 0; i < n; i++) {
-            uint64_t e;
-            if (column) {  // same draw, over the column's own table
-                const double r1 = rng.next(), r2 = rng.next();
-                const uint64_t index = (uint64_t)(r1 * (double)column->slots.size());
-                const EdgeSlot &slot = column->slots[index];
-                e = column->edge_ids[(float)r2 < slot.prob ? index : slot.alias];
-            } else {
-                e = s.sample_edge(rng);
-            }
-            heads[i] = s.location[edges[2 * e]];
-            tails[i] = s.location[edges[2 * e + 1]];
+            const double r1 = rng.next(), r2 = rng.next();
+            index[i] = (uint64_t)(r1 * count);
+            u[i] = (float)r2;
+            __builtin_prefetch(&slots[index[i]]);
+        }
+        for (int i = 0; i < n; i++) {
+            const EdgeSlot &slot = slots[index[i]];
+            const uint64_t pick = u[i] < slot.prob ? index[i] : slot.alias;
+            edge[i] = column ? column->edge_ids[pick] : pick;
+            __builtin_prefetch(&edges[2 * edge[i]]);
+        }
+        for (int i = 0; i < n; i++) {
+            heads[i] = edges[2 * edge[i]];
+            tails[i] = edges[2 * edge[i] + 1];
+            __builtin_prefetch(&s.location[heads[i]]);
+            __builtin_prefetch(&s.location[tails[i]]);
+        }
+        for (int i = 0; i < n; i++) {
+            heads[i] = s.location[heads[i]];
+            tails[i] = s.location[tails[i]];
         }
         bool wrote = false;
         for (int i = 0; i < n; i++) {
@@ -564,27 +584,79 @@ void fill_walks(FillShared *sh, int thread, int64_t start, int64_t end, uint64_t
     std::vector<int> lengths(nb);
     const uint32_t *edges = s.g->edges_uv.data();
     const uint64_t *flat = s.g->flat_offsets.data();
+    const EdgeSlot *slots = s.edge_slots.data();
+    const double edge_count = (double)s.edge_slots.size();
+    // The walks of one inner round advance in LOCKSTEP: all start edges, then step 2 of every live walk, step 3, ...
+    // (the reference finishes one walk before it starts the next, graph.cuh:322-350,400-425).  Each stage runs over
+    // the whole round with the next stage's cache lines prefetched, so a thread overlaps ~walk_batch misses instead
+    // of paying every one of them serially.  Uniforms are consumed in that lockstep order, two per draw.
+    std::vector<uint64_t> index(nb), edge_id(nb), base(nb);
+    std::vector<uint32_t> current(nb);
+    std::vector<float> u(nb);
+    std::vector<int> live(nb);
     int idle = 0;
     while (!cur.done() && !sh->error.load(std::memory_order_relaxed)) {
         for (int i = 0; i < nb; i++) {
+            const double r1 = rng.next(), r2 = rng.next();
+            index[i] = (uint64_t)(r1 * edge_count);
+            u[i] = (float)r2;
+            __builtin_prefetch(&slots[index[i]]);
+        }
+        for (int i = 0; i < nb; i++) {
+            const EdgeSlot &slot = slots[index[i]];
+            edge_id[i] = u[i] < slot.prob ? index[i] : slot.alias;
+            __builtin_prefetch(&edges[2 * edge_id[i]]);
+        }
+        for (int i = 0; i < nb; i++) {
+            const uint32_t c0 = edges[2 * edge_id[i]];
+            current[i] = edges[2 * edge_id[i] + 1];
+            index[i] = c0;
+            __builtin_prefetch(&s.location[c0]);
+            __builtin_prefetch(&s.location[current[i]]);
+            __builtin_prefetch(&flat[current[i]]);
+        }
+        int num_live = 0;
+        for (int i = 0; i < nb; i++) {
             uint64_t *chain = chains.data() + (size_t)i * (L + 1);
-            uint64_t edge_id = s.sample_edge(rng);
-            uint32_t current = edges[2 * edge_id];
-            chain[0] = s.location[current];
-            current = edges[2 * edge_id + 1];
-            chain[1] = s.location[current];
+            chain[0] = s.location[index[i]];
+            chain[1] = s.location[current[i]];
             lengths[i] = L;
-            for (int j = 2; j <= L; j++) {
-                const uint64_t deg = flat[current + 1] - flat[current];
-                if (deg == 0) {
+            live[num_live++] = i;
+        }
+        for (int j = 2; j <= L && num_live; j++) {
+            int kept = 0;
+            for (int n = 0; n < num_live; n++) {  // draw a neighbour slot for every live walk
+                const int i = live[n];
+                const uint64_t first = flat[current[i]], degree = flat[current[i] + 1] - first;
+                if (degree == 0) {  // dead end: the chain stops (graph.cuh:346-349,421-424)
                     lengths[i] = j - 1;
-                    break;
+                    continue;
                 }
-                const uint64_t base = biased ? s.ee_offsets[edge_id] : flat[current];
-                const uint32_t neighbor = s.sample_neighbor(rng, base, deg);
-                edge_id = flat[current] + neighbor;
-                current = edges[2 * edge_id + 1];
-                chain[j] = s.location[current];
+                const double r1 = rng.next(), r2 = rng.next();
+                base[i] = biased ? s.ee_offsets[edge_id[i]] : first;
+                index[i] = (uint64_t)(r1 * (double)degree);
+                u[i] = (float)r2;
+                __builtin_prefetch(&s.nb_prob[base[i] + index[i]]);
+                __builtin_prefetch(&s.nb_alias[base[i] + index[i]]);
+                live[kept++] = i;
+            }
+            num_live = kept;
+            for (int n = 0; n < num_live; n++) {
+                const int i = live[n];
+                const uint64_t slot = base[i] + index[i];
+                const uint32_t neighbor = u[i] < s.nb_prob[slot] ? (uint32_t)index[i] : s.nb_alias[slot];
+                edge_id[i] = flat[current[i]] + neighbor;
+                __builtin_prefetch(&edges[2 * edge_id[i] + 1]);
+            }
+            for (int n = 0; n < num_live; n++) {
+                const int i = live[n];
+                current[i] = edges[2 * edge_id[i] + 1];
+                __builtin_prefetch(&s.location[current[i]]);
+                __builtin_prefetch(&flat[current[i]]);
+            }
+            for (int n = 0; n < num_live; n++) {
+                const int i = live[n];
+                chains[(size_t)i * (L + 1) + j] = s.location[current[i]];
             }
         }
         bool wrote = false;

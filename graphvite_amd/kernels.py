@@ -176,6 +176,35 @@ class HipKernels(object):
                                        first_index, _ptr(pool), n)
         _lib.check(rc, "gvk_sample_pairs")
 
+    def sample_walks(self, walk_graph, seed, first_walk, pool, pool_pairs, walk_length, augmentation_step,
+                     shuffle_base):
+        """pool[:pool_pairs] = random-walk positive pairs drawn on the device (gvk_sample_walks).
+        walk_graph: dict of device tensors flat_offsets (int64), edges_uv (int32), edge_table / neighbor_table (int64
+        packed alias entries), local (int32), optional sorted_neighbors (int32), plus biased / p / q."""
+        g = walk_graph
+        dev = g["edges_uv"].device
+        _need(g["flat_offsets"], torch.int64, "flat_offsets", dev)
+        _need(g["edges_uv"], torch.int32, "edges_uv", dev)
+        _need(g["edge_table"], torch.int64, "edge_table", dev)
+        _need(g["neighbor_table"], torch.int64, "neighbor_table", dev)
+        _need(g["local"], torch.int32, "local", dev)
+        _need(pool, torch.int32, "pool", dev)
+        biased = bool(g.get("biased", False))
+        snb = g.get("sorted_neighbors")
+        if biased:
+            _need(snb, torch.int32, "sorted_neighbors", dev)
+        if pool.numel() < 2 * pool_pairs:
+            raise ValueError("pool too small")
+        D = g["edge_table"].numel()
+        if g["edges_uv"].numel() != 2 * D or g["neighbor_table"].numel() != D:
+            raise ValueError("edge arrays / tables disagree in size")
+        desc = _lib.WalkGraph(_ptr(g["flat_offsets"]), _ptr(g["edges_uv"]), _ptr(g["edge_table"]),
+                              _ptr(g["neighbor_table"]), _ptr(snb), _ptr(g["local"]), g["local"].numel(), D, int(biased),
+                              float(g.get("p", 1.0)), float(g.get("q", 1.0)))
+        rc = self.lib.gvk_sample_walks(self._stream(pool), C.byref(desc), seed, first_walk, _ptr(pool), pool_pairs,
+                                       walk_length, augmentation_step, shuffle_base)
+        _lib.check(rc, "gvk_sample_walks")
+
     def set_lanes_per_pair(self, lanes):
         _lib.check(self.lib.gvk_set_tuning(_lib.TUNE_LANES_PER_PAIR, lanes), "gvk_set_tuning")
 

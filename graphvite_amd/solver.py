@@ -272,11 +272,14 @@ class GraphSolver(object):
                         (self.batch_id - first_batch) * self.batch_size / max(t3 - t2, 1e-9) / 1e6, t4 - t3)
 
         if self.device_sampling:
-            if self._mode != "edge":
-                raise ValueError("device_sampling covers edge sampling (augmentation_step 1); random-walk models "
-                                 "use the CPU samplers")
+            if self._mode != "edge" and self.num_partition != 1:
+                raise ValueError("device_sampling of random walks needs a single partition (one GPU); with several "
+                                 "GPUs the random-walk models use the CPU samplers")
             try:
-                self._upload_block_tables(state)
+                if self._mode == "edge":
+                    self._upload_block_tables(state)
+                else:
+                    self._upload_walk_graph(state)
                 while self.batch_id < self.num_batch:
                     self._train_episode_device_sampling(state)
             finally:
@@ -351,8 +354,8 @@ class GraphSolver(object):
 
         mode = "edge" if self.augmentation_step == 1 else ("biased_walk" if model == "node2vec" else "walk")
         self._mode = mode
-        if self.device_sampling and mode == "edge":
-            return  # positives are drawn on the device: no CPU tables needed
+        if self.device_sampling and (mode == "edge" or self.num_partition == 1):
+            return  # positives are drawn on the device: no CPU sampler needed
         if self._sampler is None:
             self._sampler = hostlib.Sampler(self.graph, self._part, self._local, self.num_partition,
                                             (self.seed + 0x9E3779B97F4A7C15 * (self.rank + 1)) & (2 ** 64 - 1))
@@ -467,9 +470,50 @@ class GraphSolver(object):
                                                 self._to_device(pairs.view(np.int32).reshape(-1)))
         state["positive_index"] = 0
 
+    def _upload_walk_graph(self, state):
+        """CSR, per-vertex alias tables and the global edge table in HBM — what gvk_sample_walks walks on."""
+        from .kernels import alias_build, packed_to_device
+        g = self.graph
+        edges, weights, flat = g.edges, g.edge_weights, g.flat_offsets
+        D = g.num_directed_edge
+        if D >= 2 ** 32:
+            raise ValueError("device_sampling supports graphs with fewer than 2^32 directed edges")
+        _, _, edge_packed = alias_build(weights)
+        entry = np.dtype([("prob", np.float32), ("alias", np.uint32)])
+        nb = np.zeros(D, entry)
+        degree = np.diff(flat.astype(np.int64))
+        if (weights == weights[0]).all():  # unweighted: every neighbour table is uniform (prob 1, alias self)
+            nb["prob"] = 1
+            nb["alias"] = (np.arange(D, dtype=np.int64) - np.repeat(flat[:-1].astype(np.int64), degree)).astype(np.uint32)
+        else:
+            for u in np.nonzero(degree)[0]:
+                b, e = int(flat[u]), int(flat[u + 1])
+                _, _, packed = alias_build(weights[b:e])
+                nb[b:e] = packed
+        walk = {"flat_offsets": self._to_device(flat.astype(np.int64)),
+                "edges_uv": self._to_device(edges.astype(np.uint32).view(np.int32).reshape(-1)),
+                "edge_table": packed_to_device(edge_packed, self.device),
+                "neighbor_table": packed_to_device(nb, self.device),
+                "local": self._to_device(self._local.view(np.int32)),
+                "biased": self._mode == "biased_walk", "p": self.p, "q": self.q}
+        if self._mode == "biased_walk":
+            order = np.lexsort((edges[:, 1], edges[:, 0]))  # ascending neighbour ids inside each vertex's segment
+            walk["sorted_neighbors"] = self._to_device(np.ascontiguousarray(edges[order, 1]).view(np.int32))
+        state["walk_graph"] = walk
+        state["positive_index"] = 0
+
     def _train_episode_device_sampling(self, state):
         n = self.episode_size * self.batch_size
         seed = (self.seed * 0x9E3779B1 + 0x706f73 + self.rank) & (2 ** 64 - 1)
+        if self._mode != "edge":  # single partition: one block, walks drawn on the device
+            pool = state["pool_dev"][0]
+            L, aug = self.random_walk_length, self.augmentation_step
+            self.kernels.sample_walks(state["walk_graph"], seed, state["positive_index"], pool, n, L, aug,
+                                      self.shuffle_base)
+            per_walk = aug * L - aug * (aug - 1) // 2
+            state["positive_index"] += (n + per_walk - 1) // per_walk
+            self._train_block(state, 0, 0, pool)
+            return
         for i, step in enumerate(self._schedule):
             hp, tp = int(step[self.rank][0]), int(step[self.rank][1])
             table, pairs = state["block_tables"][(hp, tp)]

@@ -135,6 +135,34 @@ int gvk_negative_draw(void *stream, const gvk_alias_entry *table, uint32_t count
 int gvk_sample_pairs(void *stream, const gvk_alias_entry *table, const uint32_t *block_pairs, uint32_t count,
                      uint64_t seed, uint64_t first_index, uint32_t *pool, size_t n);
 
+/* Random-walk positive sampling on the device (same extension): what GraphSampler::sample_random_walk /
+ * sample_biased_random_walk do on CPU threads (include/instance/graph.cuh:298-450), one walk per GPU thread.
+ *   walk w: draw 0 picks a directed edge (c0 -> c1) from edge_table; every further draw picks the next node from the
+ *   current node's out-edge alias table (neighbor_table, CSR-aligned with flat_offsets).  With `biased` (node2vec)
+ *   a proposal x from node v reached from u is accepted with probability f(x) / max(1/p, 1, 1/q), f = 1/p if x == u,
+ *   1 if u is an out-neighbour of x, 1/q otherwise — rejection sampling over the SAME per-vertex tables, which yields
+ *   exactly the transition distribution of the reference's per-edge tables (graph.cuh:656-677) without their
+ *   sum-of-deg^2 memory.  A node with no out-edge ends the chain; the thread restarts from a fresh edge.
+ *   When node j >= 1 joins the chain the pairs (chain[j-k], chain[j]), k = 1..min(augmentation_step, j) are emitted
+ *   as {tail, head} = {local[chain[j]], local[chain[j-k]]}; thread w owns pool offsets [w*M, (w+1)*M),
+ *   M = aug*L - aug*(aug-1)/2, written through the pseudo shuffle slot = offset % sb * (pool_pairs / sb) + offset / sb.
+ *   Draw d of walk w uses philox4x32_10(ctr = {w_lo, w_hi, d, 0x77616c6b}, key = seed): w[0] -> slot (multiply-shift),
+ *   w[1] -> alias probability, w[2] -> acceptance (biased).  Single partition (local[] maps vertex -> row). */
+typedef struct {
+    const uint64_t *flat_offsets;           /* [num_vertex + 1] */
+    const uint32_t *edges_uv;               /* [2 * num_edge_entries] {u, v}, CSR order */
+    const gvk_alias_entry *edge_table;      /* [num_edge_entries] over the edge weights */
+    const gvk_alias_entry *neighbor_table;  /* [num_edge_entries] per-vertex tables, CSR-aligned */
+    const uint32_t *sorted_neighbors;       /* [num_edge_entries] out-neighbours of each vertex, ascending (biased only) */
+    const uint32_t *local;                  /* [num_vertex] vertex -> row of the (single) partition */
+    uint32_t num_vertex, num_edge_entries;
+    int32_t biased;
+    float p, q;
+} gvk_walk_graph;
+
+int gvk_sample_walks(void *stream, const gvk_walk_graph *graph, uint64_t seed, uint64_t first_walk, uint32_t *pool,
+                     size_t pool_pairs, int walk_length, int augmentation_step, int shuffle_base);
+
 /* Host: Vose alias construction exactly as the reference orders it (FIFO queues, double mean).
  * index_bytes 4 -> uint32 alias[], 8 -> uint64 alias[].  n must be > 0 and < 2^31 (the reference's
  * loop counters are int).  packed (optional, index_bytes 4 only) receives the interleaved device form. */

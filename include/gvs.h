@@ -18,8 +18,10 @@
  * Pool records are {tail, head} uint32 pairs with partition-local ids (the kernel's `pairs` layout).
  *
  * RNG: sampler thread t consumes the host uniform stream t of the RNG contract in include/gvk.h, two doubles
- * per alias draw, in exactly the order the reference's loops consume theirs — so a fill is a pure function of
- * (seed, number of threads, stream positions), and the CPU oracle reproduces it bit for bit.
+ * per alias draw.  The edge sampler consumes them in the reference's order (sample by sample); the walk samplers
+ * advance the walks of one inner round in lockstep (all start edges, then step 2 of every live walk, ...) so that
+ * each stage can be software-pipelined over the round.  Either way a fill is a pure function of (seed, number of
+ * threads, stream positions), and the CPU oracle reproduces it bit for bit.
  */
 #ifndef GVS_H_
 #define GVS_H_

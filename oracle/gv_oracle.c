@@ -266,6 +266,81 @@ void gvo_sample_pairs(const float *prob, const uint32_t *alias, const uint32_t *
     }
 }
 
+#define GVO_TAG_WALK 0x77616c6bu /* "walk" */
+
+static int gvo_sorted_has(const uint32_t *sorted_nb, const uint64_t *flat, uint32_t x, uint32_t u) {
+    uint64_t lo = flat[x], hi = flat[x + 1];
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (sorted_nb[mid] == u) return 1;
+        if (sorted_nb[mid] < u)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return 0;
+}
+
+/* Device-side random-walk sampling of include/gvk.h (gvk_sample_walks), thread by thread. */
+int gvo_sample_walks_device(const uint64_t *flat, const uint32_t *edges_uv, const float *edge_prob,
+                            const uint32_t *edge_alias, uint32_t D, const float *nb_prob, const uint32_t *nb_alias,
+                            const uint32_t *sorted_nb, const uint32_t *local, int biased, float p, float q,
+                            uint64_t seed, uint64_t first_walk, uint32_t *pool, size_t pool_pairs, int L, int aug,
+                            int shuffle_base) {
+    if (aug < 1 || aug > 16 || aug > L || shuffle_base < 1 || pool_pairs % (size_t)shuffle_base) return -1;
+    uint64_t per_walk = (uint64_t)aug * L - (uint64_t)aug * (aug - 1) / 2, sb = (uint64_t)shuffle_base;
+    uint64_t walks = (pool_pairs + per_walk - 1) / per_walk, stride = pool_pairs / sb;
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    float fmax = 1.0f;
+    if (1.0f / p > fmax) fmax = 1.0f / p;
+    if (1.0f / q > fmax) fmax = 1.0f / q;
+    for (uint64_t t = 0; t < walks; t++) {
+        uint64_t walk = first_walk + t, begin = t * per_walk;
+        uint64_t end = begin + per_walk < pool_pairs ? begin + per_walk : pool_pairs, offset = begin;
+        uint32_t draw = 0, window[16];
+        while (offset < end) {
+            uint32_t ctr[4] = {(uint32_t)walk, (uint32_t)(walk >> 32), draw++, GVO_TAG_WALK}, w[4];
+            gvo_philox4x32(ctr, key, w);
+            uint32_t index = (uint32_t)(((uint64_t)w[0] * D) >> 32);
+            float u = (float)(w[1] >> 8) * (1.0f / 16777216.0f);
+            uint64_t edge = u < edge_prob[index] ? index : edge_alias[index];
+            uint32_t previous = edges_uv[2 * edge], current = edges_uv[2 * edge + 1];
+            window[0] = local[previous];
+            int j = 1;
+            for (;;) {
+                uint32_t row = local[current];
+                int back = j < aug ? j : aug;
+                for (int k = 1; k <= back && offset < end; k++) {
+                    uint64_t slot = offset % sb * stride + offset / sb;
+                    pool[2 * slot] = row;
+                    pool[2 * slot + 1] = window[(j - k) % aug];
+                    offset++;
+                }
+                window[j % aug] = row;
+                if (j == L || offset >= end) break;
+                uint64_t base = flat[current], degree = flat[current + 1] - base;
+                if (degree == 0) break;
+                uint32_t next;
+                for (;;) {
+                    uint32_t c2[4] = {(uint32_t)walk, (uint32_t)(walk >> 32), draw++, GVO_TAG_WALK};
+                    gvo_philox4x32(c2, key, w);
+                    index = (uint32_t)(((uint64_t)w[0] * (uint32_t)degree) >> 32);
+                    u = (float)(w[1] >> 8) * (1.0f / 16777216.0f);
+                    uint32_t neighbor = u < nb_prob[base + index] ? index : nb_alias[base + index];
+                    next = edges_uv[2 * (base + neighbor) + 1];
+                    if (!biased) break;
+                    float f = next == previous ? 1.0f / p : (gvo_sorted_has(sorted_nb, flat, next, previous) ? 1.0f : 1.0f / q);
+                    if ((float)(w[2] >> 8) * (1.0f / 16777216.0f) * fmax < f) break;
+                }
+                previous = current;
+                current = next;
+                j++;
+            }
+        }
+    }
+    return 0;
+}
+
 /* Host uniform stream `stream`: doubles number 2i and 2i+1 come from
  *   philox(ctr = {i_lo, i_hi, stream, TAG_HOST}, key = seed); d = (((u64)w_hi << 32 | w_lo) >> 11) * 2^-53 */
 void gvo_host_uniforms(uint64_t seed, uint32_t stream, uint64_t first, size_t n, double *out) {
@@ -407,32 +482,38 @@ size_t gvo_sample_walks(int biased, const uint32_t *edges_uv, const float *edge_
     for (int i = 0; i < P * P; i++) offsets[i] = start;
     int num_complete = 0;
     const int target = tail_filter < 0 ? P * P : P; /* walks: pairs ending elsewhere are drawn, then dropped */
+    uint64_t *edge_ids = (uint64_t *)malloc(sizeof(uint64_t) * walk_batch);
+    uint32_t *currents = (uint32_t *)malloc(sizeof(uint32_t) * walk_batch);
     while (num_complete < target) {
+        /* This repo's samplers advance the walks of a round in lockstep (all start edges, then step 2 of every
+         * live walk, ...), where the reference finishes walk i before starting walk i + 1; the walk itself —
+         * start edge by weight, next node from the vertex / edge alias table, stop at a node without out-edges —
+         * is the reference's.  Only the order in which the i.i.d. uniforms are consumed differs. */
         for (int i = 0; i < walk_batch; i++) {
             uint32_t *chain = chains + (size_t)i * (L + 1);
             double r1 = gvo_next(&g), r2 = gvo_next(&g);
-            uint64_t edge_id = gvo_alias_sample(edge_prob, edge_alias, 8, num_edge_entries, r1, r2);
-            uint32_t current = edges_uv[2 * edge_id];
-            chain[0] = current;
-            current = edges_uv[2 * edge_id + 1];
-            chain[1] = current;
+            edge_ids[i] = gvo_alias_sample(edge_prob, edge_alias, 8, num_edge_entries, r1, r2);
+            chain[0] = edges_uv[2 * edge_ids[i]];
+            currents[i] = edges_uv[2 * edge_ids[i] + 1];
+            chain[1] = currents[i];
             lengths[i] = L;
-            for (int j = 2; j <= L; j++) {
-                uint64_t deg = flat_offsets[current + 1] - flat_offsets[current];
-                if (deg > 0) {
-                    r1 = gvo_next(&g);
-                    r2 = gvo_next(&g);
-                    uint64_t base = biased ? ee_offsets[edge_id] : flat_offsets[current];
-                    uint32_t nb = (uint32_t)gvo_alias_sample(nb_prob + base, nb_alias + base, 4, deg, r1, r2);
-                    edge_id = flat_offsets[current] + nb;
-                    current = edges_uv[2 * edge_id + 1];
-                    chain[j] = current;
-                } else {
-                    lengths[i] = j - 1;
-                    break;
-                }
-            }
         }
+        for (int j = 2; j <= L; j++)
+            for (int i = 0; i < walk_batch; i++) {
+                if (lengths[i] < L) continue; /* stopped earlier */
+                uint32_t current = currents[i];
+                uint64_t deg = flat_offsets[current + 1] - flat_offsets[current];
+                if (deg == 0) {
+                    lengths[i] = j - 1;
+                    continue;
+                }
+                double r1 = gvo_next(&g), r2 = gvo_next(&g);
+                uint64_t base = biased ? ee_offsets[edge_ids[i]] : flat_offsets[current];
+                uint32_t nb = (uint32_t)gvo_alias_sample(nb_prob + base, nb_alias + base, 4, deg, r1, r2);
+                edge_ids[i] = flat_offsets[current] + nb;
+                currents[i] = edges_uv[2 * edge_ids[i] + 1];
+                chains[(size_t)i * (L + 1) + j] = currents[i];
+            }
         for (int i = 0; i < walk_batch; i++) {
             const uint32_t *chain = chains + (size_t)i * (L + 1);
             for (int j = 0; j < lengths[i]; j++)
@@ -455,6 +536,8 @@ size_t gvo_sample_walks(int biased, const uint32_t *edges_uv, const float *edge_
     free(offsets);
     free(chains);
     free(lengths);
+    free(edge_ids);
+    free(currents);
     return g.pos > g.n ? (size_t)-1 : g.pos;
 }
 

@@ -18,7 +18,11 @@ print("graph build+load %.1f s" % (time.time() - t), flush=True)
 for label, kw, train_kw in (("cpu-samplers", {}, {}), ("cpu-samplers reuse=4", {}, {"positive_reuse": 4}),
                             ("device-sampling", {"device_sampling": True}, {}),
                             ("cpu-samplers aug=2 (walks)", {}, {"augmentation_step": 2}),
-                            ("DeepWalk aug=5", {}, {"model": "DeepWalk", "augmentation_step": 5})):
+                            ("DeepWalk aug=5", {}, {"model": "DeepWalk", "augmentation_step": 5}),
+                            ("device-sampling DeepWalk aug=5", {"device_sampling": True},
+                             {"model": "DeepWalk", "augmentation_step": 5}),
+                            ("device-sampling node2vec aug=5", {"device_sampling": True},
+                             {"model": "node2vec", "augmentation_step": 5, "p": 0.25, "q": 0.25})):
     solver = gv.solver.GraphSolver(128, **kw)
     solver.build(graph, batch_size=100000, episode_size=250)
     cfg = dict(model="LINE", num_epoch=100, augmentation_step=1, log_frequency=1 << 30)

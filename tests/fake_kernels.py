@@ -57,6 +57,20 @@ class OracleKernels(object):
                                        block_pairs.numpy().view(np.uint32), seed, first_index, n)
         pool.numpy().view(np.uint32)[:2 * n] = out.reshape(-1)
 
+    def sample_walks(self, walk_graph, seed, first_walk, pool, pool_pairs, walk_length, augmentation_step,
+                     shuffle_base):
+        g = walk_graph
+        entry = np.dtype([("prob", np.float32), ("alias", np.uint32)])
+        et, nt = g["edge_table"].numpy().view(entry), g["neighbor_table"].numpy().view(entry)
+        snb = g.get("sorted_neighbors")
+        out = self.oracle.sample_walks_device(
+            g["flat_offsets"].numpy().view(np.uint64), g["edges_uv"].numpy().view(np.uint32).reshape(-1, 2),
+            np.ascontiguousarray(et["prob"]), np.ascontiguousarray(et["alias"]), np.ascontiguousarray(nt["prob"]),
+            np.ascontiguousarray(nt["alias"]), None if snb is None else snb.numpy().view(np.uint32),
+            g["local"].numpy().view(np.uint32), bool(g.get("biased", False)), float(g.get("p", 1.0)),
+            float(g.get("q", 1.0)), seed, first_walk, pool_pairs, walk_length, augmentation_step, shuffle_base)
+        pool.numpy().view(np.uint32)[:2 * pool_pairs] = out.reshape(-1)
+
     def predict(self, vertex, context, pairs, logits):
         out = self.oracle.predict(vertex.numpy(), context.numpy(), np.ascontiguousarray(pairs.numpy().view(np.uint32)))
         logits.numpy()[:len(out)] = out

@@ -58,6 +58,10 @@ class Oracle(object):
         lib.gvo_negative_draw_batch.argtypes = [_f32p, _u32p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.c_int, _u32p]
         lib.gvo_sample_pairs.restype = None
         lib.gvo_sample_pairs.argtypes = [_f32p, _u32p, _u32p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_size_t, _u32p]
+        lib.gvo_sample_walks_device.restype = C.c_int
+        lib.gvo_sample_walks_device.argtypes = [_u64p, _u32p, _f32p, _u32p, C.c_uint32, _f32p, _u32p, C.c_void_p, _u32p,
+                                                C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_uint64, _u32p,
+                                                C.c_size_t, C.c_int, C.c_int, C.c_int]
         lib.gvo_host_uniforms.restype = None
         lib.gvo_host_uniforms.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_size_t, _f64p]
         lib.gvo_partition.restype = C.c_int
@@ -137,6 +141,16 @@ class Oracle(object):
         self.lib.gvo_sample_pairs(prob, alias, np.ascontiguousarray(block_pairs, np.uint32).reshape(-1), prob.size,
                                   seed, first, n, out.reshape(-1))
         return out
+
+    def sample_walks_device(self, flat, edges_uv, edge_prob, edge_alias, nb_prob, nb_alias, sorted_nb, local, biased,
+                            p, q, seed, first_walk, pool_pairs, L, aug, shuffle_base):
+        pool = np.zeros((pool_pairs, 2), np.uint32)
+        snb = None if sorted_nb is None else sorted_nb.ctypes.data_as(C.c_void_p)
+        rc = self.lib.gvo_sample_walks_device(flat, np.ascontiguousarray(edges_uv).reshape(-1), edge_prob, edge_alias,
+                                              edge_prob.size, nb_prob, nb_alias, snb, local, int(biased), p, q, seed,
+                                              first_walk, pool.reshape(-1), pool_pairs, L, aug, shuffle_base)
+        assert rc == 0
+        return pool
 
     def host_uniforms(self, seed, stream, first, n):
         out = np.zeros(n, np.float64)

@@ -186,6 +186,41 @@ def test_sample_pairs_bit_exact(hip, oracle):
     assert (got == oracle.sample_pairs(prob, alias, block_pairs, seed, first, n)).all()
 
 
+@pytest.mark.parametrize("biased", [False, True])
+def test_sample_walks_bit_exact(hip, oracle, biased):
+    """Device-side random walks (DeepWalk / node2vec by rejection): bit-exact against the oracle's restatement."""
+    import graphvite_amd as gv
+    from graphvite_amd import hostlib, synthetic
+    g = gv.graph.Graph()
+    edges = synthetic.power_law_edges(3000, 30000, seed=4)
+    w = np.random.default_rng(1).uniform(0.5, 2.0, len(edges)).astype(np.float32)
+    # the directed variant has dead ends, which exercises the chain restart
+    g.load([(str(a), str(b), float(c)) for (a, b), c in zip(edges, w)], as_undirected=not biased)
+    part, local, _ = hostlib.partition(g.vertex_weights, 1)
+    s = hostlib.Sampler(g, part, local, 1, seed=0)
+    s.prepare("walk", num_thread=4)
+    D = g.num_directed_edge
+    nb_prob, nb_alias = [np.ascontiguousarray(a) for a in s.neighbor_tables(D)]
+    edge_prob, edge_alias, edge_packed = K.alias_build(g.edge_weights)
+    E, flat = g.edges, g.flat_offsets
+    order = np.lexsort((E[:, 1], E[:, 0]))
+    sorted_nb = np.ascontiguousarray(E[order, 1])
+    entry = np.dtype([("prob", np.float32), ("alias", np.uint32)])
+    nb = np.zeros(D, entry)
+    nb["prob"], nb["alias"] = nb_prob, nb_alias
+    walk = {"flat_offsets": dev(flat.astype(np.int64)), "edges_uv": dev(E.view(np.int32).reshape(-1)),
+            "edge_table": K.packed_to_device(edge_packed, DEV), "neighbor_table": K.packed_to_device(nb, DEV),
+            "local": dev(local.view(np.int32)), "sorted_neighbors": dev(sorted_nb.view(np.int32)), "biased": biased,
+            "p": 0.5, "q": 2.0}
+    L, aug, sb, pool_pairs, seed, first = 12, 3, 3, 3 * 33333, 77, (1 << 32) + 9
+    pool = torch.zeros(2 * pool_pairs, dtype=torch.int32, device=DEV)
+    hip.sample_walks(walk, seed, first, pool, pool_pairs, L, aug, sb)
+    got = pool.cpu().numpy().view(np.uint32).reshape(-1, 2)
+    want = oracle.sample_walks_device(flat, E, edge_prob, edge_alias, nb_prob, nb_alias, sorted_nb, local, biased, 0.5, 2.0,
+                                      seed, first, pool_pairs, L, aug, sb)
+    assert (got == want).all()
+
+
 def test_alias_sample_matches_reference_semantics(hip, oracle):
     rng = np.random.default_rng(13)
     prob, alias, packed = K.alias_build(power_law_weights(rng, 1000))

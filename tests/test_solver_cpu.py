@@ -102,8 +102,12 @@ def test_device_sampling_mode_host_logic(oracle):
     s.build(g, batch_size=400, episode_size=3)
     s.train("LINE", num_epoch=3, augmentation_step=1)
     assert s.batch_id == 15 and np.abs(s.context_embeddings).max() > 0
-    with pytest.raises(ValueError, match="device_sampling"):
-        s.train("DeepWalk", num_epoch=1, augmentation_step=2)
+    # random-walk models sample on the device too when there is a single partition
+    for model, aug in (("DeepWalk", 3), ("node2vec", 2), ("LINE", 2)):
+        s.build(g, batch_size=300, episode_size=4)
+        s.train(model, num_epoch=2, augmentation_step=aug, random_walk_length=8, p=0.5, q=2.0)
+        assert np.abs(s.context_embeddings).max() > 0 and s._sampler is None  # no CPU sampler was ever built
+    s.build(g, batch_size=400, episode_size=3)
     # the pairs the kernel produced for an episode are edges of the graph (local ids of the single partition)
     s._configure_training("LINE", 1, False, 1, 40, 100, 0, 1, 1, 1, 0.75, 5.0, 1000)
     state = s._upload_state()
@@ -121,6 +125,68 @@ def test_device_sampling_mode_host_logic(oracle):
     got = np.bincount(inv[rec[:, 1]], minlength=g.num_vertex)
     top = np.argsort(-deg)[:5]
     assert np.allclose(got[top] / 5000.0, deg[top] / deg.sum(), atol=0.02)
+
+
+def test_device_walk_sampler_semantics(oracle):
+    """gvk_sample_walks as restated by the oracle: every emitted pair is a walk pair (distance <= augmentation_step
+    along real edges), each thread fills exactly its quota, node2vec transition frequencies follow the p / q weights
+    of the reference's per-edge tables (graph.cuh:656-677)."""
+    from graphvite_amd import hostlib
+    g = gv.graph.Graph()
+    edges = synthetic.community_edges(60, 500, num_community=3, seed=1)
+    w = np.random.default_rng(0).uniform(0.5, 2.0, len(edges)).astype(np.float32)
+    g.load([(str(a), str(b), float(c)) for (a, b), c in zip(edges, w)])
+    part, local, _ = hostlib.partition(g.vertex_weights, 1)
+    s = hostlib.Sampler(g, part, local, 1, seed=0)
+    s.prepare("walk", num_thread=2)
+    D = g.num_directed_edge
+    nb_prob, nb_alias = s.neighbor_tables(D)
+    edge_prob, edge_alias = oracle.alias_build(g.edge_weights)
+    flat, E = g.flat_offsets, g.edges
+    order = np.lexsort((E[:, 1], E[:, 0]))
+    sorted_nb = np.ascontiguousarray(E[order, 1])
+    adj = {}
+    for (u, v), x in zip(E.tolist(), g.edge_weights.tolist()):
+        adj.setdefault(u, {})
+        adj[u][v] = adj[u].get(v, 0) + x
+    inv = np.argsort(local)
+    L, aug, sb = 6, 2, 2
+    per_walk = aug * L - aug * (aug - 1) // 2
+    pool_pairs = per_walk * 4000
+    pool = oracle.sample_walks_device(flat, E, edge_prob, edge_alias, np.ascontiguousarray(nb_prob),
+                                      np.ascontiguousarray(nb_alias), sorted_nb, local, False, 1.0, 1.0, 5, 0,
+                                      pool_pairs, L, aug, sb)
+    # undo the pseudo shuffle, then thread w's pairs are offsets [w * per_walk, (w + 1) * per_walk)
+    offsets = np.arange(pool_pairs)
+    slots = offsets % sb * (pool_pairs // sb) + offsets // sb
+    rec = pool[slots]
+    heads, tails = inv[rec[:, 1]], inv[rec[:, 0]]
+    first = rec.reshape(4000, per_walk, 2)
+    for wlk in range(0, 4000, 97):  # pair order: (c0,c1) (c1,c2) (c0,c2) (c2,c3) (c1,c3) ...
+        h, t = inv[first[wlk, :, 1]], inv[first[wlk, :, 0]]
+        chain = [h[0], t[0]]
+        i = 1
+        while i < per_walk:
+            chain.append(t[i])
+            assert h[i] == chain[-2] and h[i + 1] == chain[-3] and t[i + 1] == chain[-1]
+            i += 2
+        assert all(chain[j + 1] in adj[chain[j]] for j in range(L))
+    # first step of unbiased walks follows the out-edge weights of the start edge's head
+    # node2vec: from a fixed (u -> v), next-node frequencies ~ w(v, x) * f(x)
+    p, q = 0.25, 4.0
+    pool = oracle.sample_walks_device(flat, E, edge_prob, edge_alias, np.ascontiguousarray(nb_prob),
+                                      np.ascontiguousarray(nb_alias), sorted_nb, local, True, p, q, 9, 0,
+                                      3 * 60000, 2, 2, 1)
+    rec = pool.reshape(60000, 3, 2)  # (c0,c1) (c1,c2) (c0,c2)
+    c0, c1, c2 = inv[rec[:, 0, 1]], inv[rec[:, 0, 0]], inv[rec[:, 1, 0]]
+    key, counts = np.unique(c0.astype(np.int64) << 32 | c1, return_counts=True)
+    u, v = int(key[np.argmax(counts)] >> 32), int(key[np.argmax(counts)] & 0xffffffff)
+    sel = (c0 == u) & (c1 == v)
+    want = {x: wt * (1 / p if x == u else (1.0 if u in adj.get(x, {}) else 1 / q)) for x, wt in adj[v].items()}
+    total = sum(want.values())
+    got = np.bincount(c2[sel], minlength=60) / sel.sum()
+    for x, wt in want.items():
+        assert abs(got[x] - wt / total) < 4 * np.sqrt(wt / total / sel.sum()) + 0.01
 
 
 def test_custom_schedule_and_optimizers():
