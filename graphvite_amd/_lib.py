@@ -39,7 +39,7 @@ class FillConfig(C.Structure):
                 ("tail_partition", C.c_int)]
 
 
-MODE_EDGE, MODE_WALK, MODE_BIASED_WALK = 0, 1, 2
+MODE_EDGE, MODE_WALK, MODE_BIASED_WALK, MODE_BIASED_REJECT = 0, 1, 2, 3
 
 
 class WalkGraph(C.Structure):

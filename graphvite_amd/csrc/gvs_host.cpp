@@ -454,6 +454,7 @@ struct gvs_sampler {
     std::vector<float> nb_prob;
     std::vector<uint32_t> nb_alias;
     std::vector<uint64_t> ee_offsets;
+    std::vector<uint32_t> sorted_nb;  // BIASED_REJECT: out-neighbours of every vertex, ascending
     std::vector<uint64_t> positions;
     // EDGE mode with a tail-partition filter: a table over just the edges whose tail lives in that partition
     // (the exact conditional distribution) instead of drawing from all edges and dropping (P - 1) / P of them
@@ -576,7 +577,8 @@ void fill_walks(FillShared *sh, int thread, int64_t start, int64_t end, uint64_t
     const gvs_sampler &s = *sh->s;
     HostRng rng(s.seed, (uint32_t)thread, *position);
     if (start >= end) return;
-    const bool biased = sh->c.mode == GVS_MODE_BIASED_WALK;
+    const bool biased = sh->c.mode == GVS_MODE_BIASED_WALK, reject = sh->c.mode == GVS_MODE_BIASED_REJECT;
+    const float fmax = std::max(1.0f, std::max(1.0f / s.p, 1.0f / s.q));
     BlockCursor cur(s.P, sh->c.tail_partition, start, end);
     const int L = sh->c.walk_length, nb = sh->c.walk_batch, aug = sh->c.augmentation_step;
     const int64_t sb = sh->c.shuffle_base, stride = (int64_t)(sh->pool_size / (uint64_t)sb);
@@ -592,8 +594,9 @@ void fill_walks(FillShared *sh, int thread, int64_t start, int64_t end, uint64_t
     // of paying every one of them serially.  Uniforms are consumed in that lockstep order, two per draw.
     std::vector<uint64_t> index(nb), edge_id(nb), base(nb);
     std::vector<uint32_t> current(nb);
-    std::vector<float> u(nb);
-    std::vector<int> live(nb);
+    std::vector<float> u(nb), accept(nb);
+    std::vector<int> live(nb), pending(nb);
+    std::vector<uint64_t> proposal(nb);
     int idle = 0;
     while (!cur.done() && !sh->error.load(std::memory_order_relaxed)) {
         for (int i = 0; i < nb; i++) {
@@ -625,31 +628,55 @@ void fill_walks(FillShared *sh, int thread, int64_t start, int64_t end, uint64_t
         }
         for (int j = 2; j <= L && num_live; j++) {
             int kept = 0;
-            for (int n = 0; n < num_live; n++) {  // draw a neighbour slot for every live walk
+            for (int n = 0; n < num_live; n++) {  // walks standing on a node without out-edges stop here
                 const int i = live[n];
-                const uint64_t first = flat[current[i]], degree = flat[current[i] + 1] - first;
-                if (degree == 0) {  // dead end: the chain stops (graph.cuh:346-349,421-424)
-                    lengths[i] = j - 1;
-                    continue;
-                }
-                const double r1 = rng.next(), r2 = rng.next();
-                base[i] = biased ? s.ee_offsets[edge_id[i]] : first;
-                index[i] = (uint64_t)(r1 * (double)degree);
-                u[i] = (float)r2;
-                __builtin_prefetch(&s.nb_prob[base[i] + index[i]]);
-                __builtin_prefetch(&s.nb_alias[base[i] + index[i]]);
-                live[kept++] = i;
+                if (flat[current[i] + 1] == flat[current[i]])
+                    lengths[i] = j - 1;  // graph.cuh:346-349,421-424
+                else
+                    live[kept++] = i;
             }
             num_live = kept;
-            for (int n = 0; n < num_live; n++) {
-                const int i = live[n];
-                const uint64_t slot = base[i] + index[i];
-                const uint32_t neighbor = u[i] < s.nb_prob[slot] ? (uint32_t)index[i] : s.nb_alias[slot];
-                edge_id[i] = flat[current[i]] + neighbor;
-                __builtin_prefetch(&edges[2 * edge_id[i] + 1]);
+            // proposal rounds: one for the table-driven walks; node2vec by rejection repeats for the rejected walks
+            int num_pending = num_live;
+            for (int n = 0; n < num_live; n++) pending[n] = live[n];
+            while (num_pending) {
+                for (int n = 0; n < num_pending; n++) {
+                    const int i = pending[n];
+                    const uint64_t first = flat[current[i]], degree = flat[current[i] + 1] - first;
+                    const double r1 = rng.next(), r2 = rng.next();
+                    if (reject) accept[i] = (float)rng.next();
+                    base[i] = biased ? s.ee_offsets[edge_id[i]] : first;
+                    index[i] = (uint64_t)(r1 * (double)degree);
+                    u[i] = (float)r2;
+                    __builtin_prefetch(&s.nb_prob[base[i] + index[i]]);
+                    __builtin_prefetch(&s.nb_alias[base[i] + index[i]]);
+                }
+                for (int n = 0; n < num_pending; n++) {
+                    const int i = pending[n];
+                    const uint64_t slot = base[i] + index[i];
+                    const uint32_t neighbor = u[i] < s.nb_prob[slot] ? (uint32_t)index[i] : s.nb_alias[slot];
+                    proposal[i] = flat[current[i]] + neighbor;
+                    __builtin_prefetch(&edges[2 * proposal[i] + 1]);
+                }
+                if (!reject) break;
+                int rejected = 0;
+                for (int n = 0; n < num_pending; n++) {
+                    const int i = pending[n];
+                    const uint32_t x = edges[2 * proposal[i] + 1], prev = edges[2 * edge_id[i]];
+                    float f;
+                    if (x == prev)
+                        f = 1.0f / s.p;
+                    else if (std::binary_search(s.sorted_nb.begin() + flat[x], s.sorted_nb.begin() + flat[x + 1], prev))
+                        f = 1.0f;
+                    else
+                        f = 1.0f / s.q;
+                    if (!(accept[i] * fmax < f)) pending[rejected++] = i;
+                }
+                num_pending = rejected;
             }
             for (int n = 0; n < num_live; n++) {
                 const int i = live[n];
+                edge_id[i] = proposal[i];
                 current[i] = edges[2 * edge_id[i] + 1];
                 __builtin_prefetch(&s.location[current[i]]);
                 __builtin_prefetch(&flat[current[i]]);
@@ -788,7 +815,7 @@ void gvs_sampler_destroy(gvs_sampler *s) { delete s; }
 
 int gvs_sampler_prepare(gvs_sampler *s, int mode, float p, float q, int num_thread) {
     if (!s) return gvk_fail(GVK_EINVAL, "gvs_sampler_prepare: null sampler");
-    if (mode != GVS_MODE_EDGE && mode != GVS_MODE_WALK && mode != GVS_MODE_BIASED_WALK)
+    if (mode != GVS_MODE_EDGE && mode != GVS_MODE_WALK && mode != GVS_MODE_BIASED_WALK && mode != GVS_MODE_BIASED_REJECT)
         return gvk_fail(GVK_EINVAL, "gvs_sampler_prepare: unknown mode %d", mode);
     return guarded("gvs_sampler_prepare", [&]() {
         const gvs_graph *g = s->g;
@@ -798,8 +825,20 @@ int gvs_sampler_prepare(gvs_sampler *s, int mode, float p, float q, int num_thre
         decltype(s->nb_prob)().swap(s->nb_prob);
         decltype(s->nb_alias)().swap(s->nb_alias);
         decltype(s->ee_offsets)().swap(s->ee_offsets);
+        decltype(s->sorted_nb)().swap(s->sorted_nb);
         s->prepared = GVS_MODE_EDGE;
-        if (mode == GVS_MODE_WALK) {
+        if (mode == GVS_MODE_BIASED_REJECT) {
+            if (!(p > 0) || !(q > 0)) return gvk_fail(GVK_EINVAL, "gvs_sampler_prepare: p and q must be positive");
+            s->p = p;
+            s->q = q;
+            s->sorted_nb.resize(D);
+            for (uint64_t e = 0; e < D; e++) s->sorted_nb[e] = g->edges_uv[2 * e + 1];
+            parallel_ranges(g->num_vertex, num_thread, [&](uint64_t b, uint64_t e) {
+                for (uint64_t v = b; v < e; v++)
+                    std::sort(s->sorted_nb.begin() + flat[v], s->sorted_nb.begin() + flat[v + 1]);
+            });
+        }
+        if (mode == GVS_MODE_WALK || mode == GVS_MODE_BIASED_REJECT) {
             s->nb_prob.resize(D);
             s->nb_alias.resize(D);
             parallel_ranges(g->num_vertex, num_thread, [&](uint64_t b, uint64_t e) {
@@ -839,7 +878,7 @@ int gvs_sampler_fill(gvs_sampler *s, uint32_t *const *pools, uint64_t pool_size,
     if (c->tail_partition >= s->P) return gvk_fail(GVK_EINVAL, "gvs_sampler_fill: tail_partition out of range");
     if (c->mode == GVS_MODE_EDGE) {
         if (c->sample_batch_size < 1) return gvk_fail(GVK_EINVAL, "gvs_sampler_fill: sample_batch_size must be >= 1");
-    } else if (c->mode == GVS_MODE_WALK || c->mode == GVS_MODE_BIASED_WALK) {
+    } else if (c->mode == GVS_MODE_WALK || c->mode == GVS_MODE_BIASED_WALK || c->mode == GVS_MODE_BIASED_REJECT) {
         if (s->prepared != c->mode)
             return gvk_fail(GVK_EINVAL, "gvs_sampler_fill: call gvs_sampler_prepare for this mode first");
         if (c->augmentation_step < 1)

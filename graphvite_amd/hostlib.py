@@ -38,7 +38,8 @@ def host_uniforms(seed, stream, first, n):
 class Sampler(object):
     """The multi-threaded CPU positive sampler (edge / random walk / node2vec) of one worker."""
 
-    MODES = {"edge": _lib.MODE_EDGE, "walk": _lib.MODE_WALK, "biased_walk": _lib.MODE_BIASED_WALK}
+    MODES = {"edge": _lib.MODE_EDGE, "walk": _lib.MODE_WALK, "biased_walk": _lib.MODE_BIASED_WALK,
+             "biased_reject": _lib.MODE_BIASED_REJECT}
 
     def __init__(self, graph, part, local, num_partition, seed):
         self._lib = _lib.lib()

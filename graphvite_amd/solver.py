@@ -94,6 +94,7 @@ class GraphSolver(object):
         self.gpu_memory_limit = gpu_memory_limit
         self.gpu_memory_cost = 0
         self.seed = seed
+        self.node2vec_table_limit = 1 << 30  # entries (8 B each) of per-edge alias tables before switching to rejection
         # extension: draw LINE's positive edge samples on the GPU instead of CPU threads
         self.device_sampling = bool(device_sampling)
         self.graph = None
@@ -256,6 +257,14 @@ class GraphSolver(object):
                                  negative_sample_exponent, negative_weight, log_frequency)
         t1 = time.time()
         state = self._upload_state()
+        if self.device_sampling:
+            if self._mode != "edge" and self.num_partition != 1:
+                raise ValueError("device_sampling of random walks needs a single partition (one GPU); with several "
+                                 "GPUs the random-walk models use the CPU samplers")
+            if self._mode == "edge":
+                self._upload_block_tables(state)
+            else:
+                self._upload_walk_graph(state)
         t2 = time.time()
         first_batch = self.batch_id
 
@@ -272,14 +281,7 @@ class GraphSolver(object):
                         (self.batch_id - first_batch) * self.batch_size / max(t3 - t2, 1e-9) / 1e6, t4 - t3)
 
         if self.device_sampling:
-            if self._mode != "edge" and self.num_partition != 1:
-                raise ValueError("device_sampling of random walks needs a single partition (one GPU); with several "
-                                 "GPUs the random-walk models use the CPU samplers")
             try:
-                if self._mode == "edge":
-                    self._upload_block_tables(state)
-                else:
-                    self._upload_walk_graph(state)
                 while self.batch_id < self.num_batch:
                     self._train_episode_device_sampling(state)
             finally:
@@ -353,6 +355,16 @@ class GraphSolver(object):
         self._predict_cache = None
 
         mode = "edge" if self.augmentation_step == 1 else ("biased_walk" if model == "node2vec" else "walk")
+        if mode == "biased_walk":
+            # the reference's per-edge alias tables need sum over edges of deg(head) entries (graph.cuh:656-677) and
+            # run it out of memory on hub-heavy graphs (doc/source/benchmark.rst:53-54); past the limit the same
+            # transition distribution is sampled by rejection over the per-vertex tables (gvs.h GVS_MODE_BIASED_REJECT)
+            degree = np.diff(self.graph.flat_offsets.astype(np.int64))
+            entries = int(degree[self.graph.edges[:, 1]].sum())
+            if entries > self.node2vec_table_limit:
+                logger.warning("node2vec: %d per-edge table entries exceed the limit of %d; sampling by rejection",
+                               entries, self.node2vec_table_limit)
+                mode = "biased_reject"
         self._mode = mode
         if self.device_sampling and (mode == "edge" or self.num_partition == 1):
             return  # positives are drawn on the device: no CPU sampler needed
@@ -495,8 +507,8 @@ class GraphSolver(object):
                 "edge_table": packed_to_device(edge_packed, self.device),
                 "neighbor_table": packed_to_device(nb, self.device),
                 "local": self._to_device(self._local.view(np.int32)),
-                "biased": self._mode == "biased_walk", "p": self.p, "q": self.q}
-        if self._mode == "biased_walk":
+                "biased": self._mode in ("biased_walk", "biased_reject"), "p": self.p, "q": self.q}
+        if walk["biased"]:
             order = np.lexsort((edges[:, 1], edges[:, 0]))  # ascending neighbour ids inside each vertex's segment
             walk["sorted_neighbors"] = self._to_device(np.ascontiguousarray(edges[order, 1]).view(np.int32))
         state["walk_graph"] = walk

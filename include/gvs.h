@@ -84,7 +84,10 @@ int gvs_schedule(int num_partition, int num_worker, int32_t *out, size_t out_len
 
 #define GVS_MODE_EDGE 0        /* SamplerMixin::sample: every model when augmentation_step == 1 */
 #define GVS_MODE_WALK 1        /* sample_random_walk: DeepWalk, and LINE when augmentation_step > 1 */
-#define GVS_MODE_BIASED_WALK 2 /* sample_biased_random_walk: node2vec */
+#define GVS_MODE_BIASED_WALK 2 /* sample_biased_random_walk: node2vec through per-edge alias tables (sum of deg^2) */
+#define GVS_MODE_BIASED_REJECT 3 /* node2vec by rejection over the per-vertex tables: the same transition
+                                    distribution with O(|E|) memory (propose x by edge weight, accept with probability
+                                    f(x) / max(1/p, 1, 1/q); f as in graph.cuh:664-669).  Three uniforms per proposal. */
 
 /* The graph must outlive the sampler (the reference borrows it the same way, solver.h:289).  part / local are
  * copied.  Builds the edge alias table over the flattened edge weights. */
@@ -92,8 +95,8 @@ gvs_sampler *gvs_sampler_create(const gvs_graph *g, const int32_t *part, const u
                                 uint64_t seed);
 void gvs_sampler_destroy(gvs_sampler *s);
 
-/* Builds what `mode` needs with num_thread threads: per-vertex alias tables (WALK) or node2vec per-edge tables
- * with return parameter p and in-out parameter q (BIASED_WALK; sum of deg^2 entries). */
+/* Builds what `mode` needs with num_thread threads: per-vertex alias tables (WALK, BIASED_REJECT) or node2vec
+ * per-edge tables with return parameter p and in-out parameter q (BIASED_WALK; sum of deg^2 entries). */
 int gvs_sampler_prepare(gvs_sampler *s, int mode, float p, float q, int num_thread);
 
 typedef struct {

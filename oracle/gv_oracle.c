@@ -471,7 +471,7 @@ size_t gvo_sample_walks(int biased, const uint32_t *edges_uv, const float *edge_
                         const uint32_t *nb_alias, const uint64_t *ee_offsets, const int32_t *part,
                         const uint32_t *local, int P, uint32_t **pools, int pool_size, int start, int end,
                         int walk_length, int walk_batch, int augmentation_step, int shuffle_base, int tail_filter,
-                        const double *rnd, size_t n_rnd) {
+                        const uint32_t *sorted_nb, float p, float q, const double *rnd, size_t n_rnd) {
     gvo_rand g = {rnd, n_rnd, 0};
     if (start >= end) return 0;
     if (pool_size % shuffle_base) return (size_t)-2;
@@ -484,6 +484,13 @@ size_t gvo_sample_walks(int biased, const uint32_t *edges_uv, const float *edge_
     const int target = tail_filter < 0 ? P * P : P; /* walks: pairs ending elsewhere are drawn, then dropped */
     uint64_t *edge_ids = (uint64_t *)malloc(sizeof(uint64_t) * walk_batch);
     uint32_t *currents = (uint32_t *)malloc(sizeof(uint32_t) * walk_batch);
+    uint64_t *proposals = (uint64_t *)malloc(sizeof(uint64_t) * walk_batch);
+    int *pending = (int *)malloc(sizeof(int) * walk_batch);
+    float fmax = 1.0f;
+    if (biased == 2) {
+        if (1.0f / p > fmax) fmax = 1.0f / p;
+        if (1.0f / q > fmax) fmax = 1.0f / q;
+    }
     while (num_complete < target) {
         /* This repo's samplers advance the walks of a round in lockstep (all start edges, then step 2 of every
          * live walk, ...), where the reference finishes walk i before starting walk i + 1; the walk itself —
@@ -498,22 +505,45 @@ size_t gvo_sample_walks(int biased, const uint32_t *edges_uv, const float *edge_
             chain[1] = currents[i];
             lengths[i] = L;
         }
-        for (int j = 2; j <= L; j++)
+        for (int j = 2; j <= L; j++) {
+            int num_pending = 0;
             for (int i = 0; i < walk_batch; i++) {
                 if (lengths[i] < L) continue; /* stopped earlier */
-                uint32_t current = currents[i];
-                uint64_t deg = flat_offsets[current + 1] - flat_offsets[current];
-                if (deg == 0) {
+                if (flat_offsets[currents[i] + 1] == flat_offsets[currents[i]])
                     lengths[i] = j - 1;
-                    continue;
+                else
+                    pending[num_pending++] = i;
+            }
+            int num_live = num_pending;
+            /* biased == 2 (this repo's O(|E|)-memory node2vec): propose from the per-vertex table, accept with
+             * probability f / fmax (third uniform), re-propose for the rejected walks until all have moved */
+            while (num_pending) {
+                int rejected = 0;
+                for (int n = 0; n < num_pending; n++) {
+                    int i = pending[n];
+                    uint32_t current = currents[i];
+                    uint64_t deg = flat_offsets[current + 1] - flat_offsets[current];
+                    double r1 = gvo_next(&g), r2 = gvo_next(&g);
+                    float r3 = biased == 2 ? (float)gvo_next(&g) : 0.0f;
+                    uint64_t base = biased == 1 ? ee_offsets[edge_ids[i]] : flat_offsets[current];
+                    uint32_t nb = (uint32_t)gvo_alias_sample(nb_prob + base, nb_alias + base, 4, deg, r1, r2);
+                    proposals[i] = flat_offsets[current] + nb;
+                    if (biased == 2) {
+                        uint32_t x = edges_uv[2 * proposals[i] + 1], prev = edges_uv[2 * edge_ids[i]];
+                        float f = x == prev ? 1.0f / p : (gvo_sorted_has(sorted_nb, flat_offsets, x, prev) ? 1.0f : 1.0f / q);
+                        if (!(r3 * fmax < f)) pending[rejected++] = i;
+                    }
                 }
-                double r1 = gvo_next(&g), r2 = gvo_next(&g);
-                uint64_t base = biased ? ee_offsets[edge_ids[i]] : flat_offsets[current];
-                uint32_t nb = (uint32_t)gvo_alias_sample(nb_prob + base, nb_alias + base, 4, deg, r1, r2);
-                edge_ids[i] = flat_offsets[current] + nb;
+                num_pending = rejected;
+            }
+            (void)num_live;
+            for (int i = 0; i < walk_batch; i++) {
+                if (lengths[i] < L) continue;
+                edge_ids[i] = proposals[i];
                 currents[i] = edges_uv[2 * edge_ids[i] + 1];
                 chains[(size_t)i * (L + 1) + j] = currents[i];
             }
+        }
         for (int i = 0; i < walk_batch; i++) {
             const uint32_t *chain = chains + (size_t)i * (L + 1);
             for (int j = 0; j < lengths[i]; j++)
@@ -538,6 +568,8 @@ size_t gvo_sample_walks(int biased, const uint32_t *edges_uv, const float *edge_
     free(lengths);
     free(edge_ids);
     free(currents);
+    free(proposals);
+    free(pending);
     return g.pos > g.n ? (size_t)-1 : g.pos;
 }
 

@@ -266,6 +266,48 @@ def test_walk_samplers_bit_exact(oracle, mode):
         assert (column[(h, 1)] == want[h * P + 1]).all()
 
 
+def test_node2vec_rejection_sampler(oracle):
+    """GVS_MODE_BIASED_REJECT: bit-exact against the oracle, and the same transition distribution as the reference's
+    per-edge tables (weights w/p, w, w/q of graph.cuh:664-669) without their sum-of-deg^2 memory."""
+    g = small_graph(seed=5, n=80, e=700)
+    P, T, pool_size, L, nb, aug, p, q = 1, 2, 3 * 40000, 2, 50, 2, 0.25, 4.0
+    part, local, _ = hostlib.partition(g.vertex_weights, P)
+    s = hostlib.Sampler(g, part, local, P, seed=8)
+    s.prepare("biased_reject", p=p, q=q, num_thread=2)
+    D, fo, E = g.num_directed_edge, g.flat_offsets, g.edges
+    nbp, nba = s.neighbor_tables(D)
+    sorted_nb = np.ascontiguousarray(E[np.lexsort((E[:, 1], E[:, 0])), 1])
+    pools = {(0, 0): np.zeros(pool_size * 2, np.uint32)}
+    s.fill(pools, pool_size, "biased_reject", T, walk_length=L, walk_batch=nb, augmentation_step=aug, shuffle_base=1)
+    want = [np.zeros(pool_size * 2, np.uint32)]
+    work = (pool_size + T - 1) // T
+    for t in range(T):
+        rnd = oracle.host_uniforms(8, t, 0, 3000000)
+        used = oracle.sample_walks(2, E, s.edge_prob, s.edge_alias, fo, nbp, nba, None, part, local, P, want, pool_size,
+                                   work * t, min(work * (t + 1), pool_size), L, nb, aug, 1, rnd, sorted_nb=sorted_nb,
+                                   p=p, q=q)
+        assert used == s.stream_position(t)
+    assert (pools[(0, 0)] == want[0]).all()
+    # walks of length 2 emit (c0,c1) (c0,c2) (c1,c2): transition frequencies from the most frequent (u -> v)
+    inv = np.argsort(local)
+    rec = pools[(0, 0)].reshape(-1, 3, 2)
+    c0, c1, c2 = inv[rec[:, 0, 1]], inv[rec[:, 0, 0]], inv[rec[:, 1, 0]]
+    ok = (inv[rec[:, 1, 1]] == c0) & (inv[rec[:, 2, 1]] == c1) & (inv[rec[:, 2, 0]] == c2)
+    assert ok.mean() > 0.99  # thread-slice boundaries may cut a walk
+    key, counts = np.unique(c0[ok].astype(np.int64) << 32 | c1[ok], return_counts=True)
+    u, v = int(key[np.argmax(counts)] >> 32), int(key[np.argmax(counts)] & 0xffffffff)
+    adj = {}
+    for (a, b), x in zip(E.tolist(), g.edge_weights.tolist()):
+        adj.setdefault(a, {})
+        adj[a][b] = adj[a].get(b, 0) + x
+    want_p = {x: wt * (1 / p if x == u else (1.0 if u in adj.get(x, {}) else 1 / q)) for x, wt in adj[v].items()}
+    total = sum(want_p.values())
+    sel = ok & (c0 == u) & (c1 == v)
+    got = np.bincount(c2[sel], minlength=g.num_vertex) / sel.sum()
+    for x, wt in want_p.items():
+        assert abs(got[x] - wt / total) < 4 * np.sqrt(wt / total / sel.sum()) + 0.01
+
+
 def test_edge_sampler_column_mode_bit_exact(oracle):
     """One GPU's column: EDGE mode draws from an alias table over exactly the edges that end in that partition."""
     g = small_graph(seed=9)

@@ -189,6 +189,15 @@ def test_device_walk_sampler_semantics(oracle):
         assert abs(got[x] - wt / total) < 4 * np.sqrt(wt / total / sel.sum()) + 0.01
 
 
+def test_node2vec_switches_to_rejection_past_the_table_limit():
+    g = make_graph(200, 1500, seed=2)
+    s = gv.solver.GraphSolver(32, kernels=OracleKernels(), num_sampler_per_worker=2)
+    s.build(g, batch_size=300, episode_size=4)
+    s.node2vec_table_limit = 10  # force the O(|E|)-memory sampler
+    s.train("node2vec", num_epoch=2, augmentation_step=2, random_walk_length=8, random_walk_batch_size=5, p=0.5, q=2.0)
+    assert s._mode == "biased_reject" and np.abs(s.context_embeddings).max() > 0
+
+
 def test_custom_schedule_and_optimizers():
     g = make_graph(150, 900, seed=4)
     k = OracleKernels()
