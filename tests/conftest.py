@@ -11,6 +11,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the native library normally arrives prebuilt (python -c "import __graft_entry__ as g; g.build()"); build it if
+    # this checkout has not been built yet — hipcc cross-compiles without a GPU
+    lib = os.path.join(ROOT, "graphvite_amd", "libgvk.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "graphvite_amd", "csrc")])
 
 
 @pytest.fixture(scope="session")

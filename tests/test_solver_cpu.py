@@ -326,7 +326,7 @@ def _worker(rank, world, port, out_dir, model, aug):
         s.build(g, batch_size=400, episode_size=3)
         assert s.num_worker == world and s.num_partition == world
         s.train(model, num_epoch=4, augmentation_step=aug, random_walk_length=6, random_walk_batch_size=4,
-                log_frequency=100000)
+                p=0.25, q=0.25, log_frequency=100000)
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), v=s.vertex_embeddings, c=s.context_embeddings,
                  ids=np.array([b for b, _ in k.launches]), lrs=np.array([lr for _, lr in k.launches]),
                  batch_id=s.batch_id, num_batch=s.num_batch, tails=np.array(s._my_tails))
@@ -334,7 +334,7 @@ def _worker(rank, world, port, out_dir, model, aug):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("model,aug", [("LINE", 1), ("DeepWalk", 2)])
+@pytest.mark.parametrize("model,aug", [("LINE", 1), ("DeepWalk", 2), ("node2vec", 2)])
 def test_two_process_training_over_gloo(tmp_path, model, aug):
     world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path), model, aug), nprocs=world, join=True)

@@ -123,6 +123,35 @@ def test_quick_start_shaped_run_learns():
     np.testing.assert_allclose(logits, want, rtol=1e-5, atol=1e-7)
 
 
+def test_dim_96_end_to_end():
+    """The Friendster configuration's dimension (config/graph/line_friendster.yaml: dim 96) through the whole path."""
+    edges = synthetic.community_edges(20000, 400000, num_community=100, seed=5)
+    train, (valid, test) = synthetic.link_prediction_split(edges, (100, 3, 3))
+    g, s = run(train, None, 96, batch_size=20000, episode_size=20, model="LINE", num_epoch=200, augmentation_step=1,
+               log_frequency=1 << 30)
+    auc = auc_of(g, s, test)
+    print("dim 96 LINE AUC %.6f" % auc)
+    assert auc > 0.9 and s.vertex_embeddings.shape == (g.num_vertex, 96)
+
+
+def test_device_sampling_end_to_end():
+    """Opt-in device-side positive sampling learns as well as the CPU-sampled pipeline (LINE edges, DeepWalk walks,
+    node2vec by rejection)."""
+    edges = synthetic.community_edges(20000, 400000, num_community=100, seed=3)
+    train, (valid, test) = synthetic.link_prediction_split(edges, (100, 3, 3))
+    gv.init_logging(logging.ERROR)
+    for model, aug in (("LINE", 1), ("DeepWalk", 2), ("node2vec", 2)):
+        g = gv.graph.Graph()
+        g.load(train)
+        s = gv.solver.GraphSolver(128, num_sampler_per_worker=2, seed=17, device_sampling=True)
+        s.build(g, batch_size=20000, episode_size=20)
+        s.train(model=model, num_epoch=200, augmentation_step=aug, random_walk_length=10, p=0.5, q=2.0,
+                log_frequency=1 << 30)
+        auc = auc_of(g, s, test)
+        print("device sampling %s AUC %.6f" % (model, auc))
+        assert auc > 0.9 and s._sampler is None
+
+
 def test_moment_optimizer_end_to_end():
     edges = synthetic.power_law_edges(5000, 50000, seed=8)
     g = gv.graph.Graph()
