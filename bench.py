@@ -142,7 +142,7 @@ def main():
     solver._configure_training("LINE", epochs, False, 1, 40, 100, gv.auto, 1, 1, 1, 0.75, 5.0, 1 << 30)
     solver.num_batch = total_batches  # the lr schedule spans exactly the batches this run trains
     state = solver._upload_state()
-    pools = solver._host_pools()[0]
+    pools = solver._host_pools(sets=1)[0]
     t0 = time.perf_counter()
     solver._fill(pools)
     fill_s = time.perf_counter() - t0

@@ -428,19 +428,44 @@ class GraphSolver(object):
             _, _, packed = alias_build(w)
             state["negative_tables"][tp] = packed_to_device(packed, self.device)
         state["loss"] = torch.zeros(self.batch_size, dtype=torch.float32, device=self.device)
-        pool_elems = self.episode_size * self.batch_size * 2
-        state["pool_dev"] = [torch.empty(pool_elems, dtype=torch.int32, device=self.device) for _ in range(2)]
+        # The pools are the elastic part, as in the reference: when they do not fit, the episode is halved
+        # (solver.h:437-455) — the device pair of buffers here, the pinned host sets in _host_pools.
+        while True:
+            try:
+                pool_elems = self.episode_size * self.batch_size * 2
+                state["pool_dev"] = [torch.empty(pool_elems, dtype=torch.int32, device=self.device) for _ in range(2)]
+                break
+            except (RuntimeError, MemoryError):
+                state.pop("pool_dev", None)
+                self._halve_episode("GPU")
         if self.device.type == "cuda":
             state["copy_stream"] = torch.cuda.Stream(self.device)
         self._device_state = state
         return state
 
-    def _host_pools(self):
-        """Two sets (double buffer) of pinned host pools, one per block this worker trains in an episode."""
-        pool_elems = self.episode_size * self.batch_size * 2
+    def _halve_episode(self, where):
+        if self.episode_size <= 1:
+            raise MemoryError("Out of %s memory. Try to reduce the size of your graph or the dimension of your "
+                              "embeddings." % where)
+        base = max(self.shuffle_base, 1) if self.augmentation_step > 1 else 1
+        half = self.episode_size // 2
+        while half > 1 and (half * self.batch_size) % base:
+            half -= 1
+        logger.warning("Fail to allocate %s memory for episode size of %d. Use %d instead.", where,
+                       self.episode_size, half)
+        self.episode_size = max(half, 1)
+
+    def _host_pools(self, sets=2):
+        """`sets` (double buffer) sets of pinned host pools, one pool per block this worker trains in an episode."""
         blocks = sorted({(int(step[self.rank][0]), int(step[self.rank][1])) for step in self._schedule})
         pin = self.device.type == "cuda"
-        return [{b: torch.empty(pool_elems, dtype=torch.int32, pin_memory=pin) for b in blocks} for _ in range(2)]
+        while True:
+            pool_elems = self.episode_size * self.batch_size * 2
+            try:
+                return [{b: torch.empty(pool_elems, dtype=torch.int32, pin_memory=pin) for b in blocks}
+                        for _ in range(sets)]
+            except (RuntimeError, MemoryError):
+                self._halve_episode("host")
 
     # ---- sampling -----------------------------------------------------------------------------------------
     def _fill(self, pools):
