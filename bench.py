@@ -56,6 +56,9 @@ def parse():
                         "auto episode size for this graph (solver.h:426-436), capped at 250")
     p.add_argument("--lanes", type=int, default=0, help="A/B knob: lanes per pair (0 = per-dim default)")
     p.add_argument("--variant", type=int, default=0, help="A/B knob: kernel build variant (gvk.h GVK_TUNE_VARIANT)")
+    p.add_argument("--xcd-bucket", choices=["head", "tail"], default=None,
+                   help="experiment: reorder every batch so that block b (16 pairs, XCD b % 8) holds pairs whose "
+                        "head / tail row id is congruent to b mod 8")
     p.add_argument("--sampler-threads", type=int, default=0, help="0 = host cores / GPUs")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=3.0, help="wall seconds given to the CPU baseline")
@@ -147,6 +150,24 @@ def main():
     solver._fill(pools)
     fill_s = time.perf_counter() - t0
     blocks = [(int(s[rank][0]), int(s[rank][1])) for s in solver._schedule]
+    if args.xcd_bucket:
+        column = 1 if args.xcd_bucket == "head" else 0
+        for pool in pools.values():
+            rec = pool.numpy().view(np.uint32).reshape(-1, B, 2)
+            for i in range(rec.shape[0]):
+                cls = rec[i, :, column] % 8
+                order = np.argsort(cls, kind="stable")
+                counts = np.bincount(cls, minlength=8)
+                nmin = int(counts.min()) // 16
+                starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+                within = np.arange(B) - starts[cls[order]]          # rank of the pair inside its class
+                placed = within < nmin * 16
+                dest = np.empty(B, np.int64)
+                dest[placed] = (8 * (within[placed] // 16) + cls[order][placed]) * 16 + within[placed] % 16
+                dest[~placed] = nmin * 16 * 8 + np.arange(int((~placed).sum()))
+                out = np.empty_like(rec[i])
+                out[dest] = rec[i][order]
+                rec[i] = out
     dev_pools = {b: pools[b].to(dev) for b in blocks}  # every block pool of this GPU's column, resident in HBM
     sampled = len(blocks) * args.block_batches * B
 

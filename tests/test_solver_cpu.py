@@ -312,7 +312,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_dir, model, aug):
+def _worker(rank, world, port, out_dir, model, aug, num_partition=0):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world))
@@ -323,8 +323,8 @@ def _worker(rank, world, port, out_dir, model, aug):
         g = make_graph(240, 2400, seed=6)
         k = OracleKernels()
         s = gv.solver.GraphSolver(32, kernels=k, num_sampler_per_worker=2, seed=9)
-        s.build(g, batch_size=400, episode_size=3)
-        assert s.num_worker == world and s.num_partition == world
+        s.build(g, batch_size=400, episode_size=3, num_partition=num_partition)
+        assert s.num_worker == world and s.num_partition == (num_partition or world)
         s.train(model, num_epoch=4, augmentation_step=aug, random_walk_length=6, random_walk_batch_size=4,
                 p=0.25, q=0.25, log_frequency=100000)
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), v=s.vertex_embeddings, c=s.context_embeddings,
@@ -351,3 +351,15 @@ def test_two_process_training_over_gloo(tmp_path, model, aug):
     for i in range(world):
         want = 0.025 * np.maximum(1 - r[i]["ids"] / float(r[i]["num_batch"]), 1e-4)
         np.testing.assert_allclose(r[i]["lrs"], want, rtol=1e-6)
+
+
+def test_more_partitions_than_workers_over_gloo(tmp_path):
+    """P = 4 partitions on 2 workers (solver.h:562-574 with x, y groups): each worker owns two context shards."""
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), "LINE", 1, 4), nprocs=world, join=True)
+    r = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % i)) for i in range(world)]
+    assert (r[0]["v"] == r[1]["v"]).all() and (r[0]["c"] == r[1]["c"]).all()
+    assert r[0]["tails"].tolist() == [0, 2] and r[1]["tails"].tolist() == [1, 3]
+    ids = np.sort(np.concatenate([r[0]["ids"], r[1]["ids"]]))
+    assert (ids == np.arange(len(ids))).all() and len(ids) % (4 * 4 * 3) == 0  # whole episodes of P^2 blocks
+    assert np.abs(r[0]["c"]).max() > 0
