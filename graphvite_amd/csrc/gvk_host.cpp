@@ -74,7 +74,7 @@ int gvk_alias_build(const float *weights, size_t n, float *prob, void *alias, in
                     gvk_alias_entry *packed) {
     if (!weights || !prob || !alias) return gvk_fail(GVK_EINVAL, "gvk_alias_build: null pointer");
     if (n == 0) return gvk_fail(GVK_EINVAL, "gvk_alias_build: invalid sampling distribution (empty)");
-    if (n >= ((size_t)1 << 31)) return gvk_fail(GVK_EINVAL, "gvk_alias_build: n must be < 2^31");
+    if (index_bytes == 4 && n > 0xffffffffu) return gvk_fail(GVK_EINVAL, "gvk_alias_build: n needs 8-byte indexes");
     if (index_bytes != 4 && index_bytes != 8) return gvk_fail(GVK_EINVAL, "gvk_alias_build: index_bytes must be 4 or 8");
     if (packed && index_bytes != 4) return gvk_fail(GVK_EINVAL, "gvk_alias_build: packed form needs 4-byte indexes");
     try {

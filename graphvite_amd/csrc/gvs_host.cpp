@@ -466,6 +466,31 @@ struct gvs_sampler {
     };
     std::vector<Column> columns;
 
+    // The alias table over ALL flattened edges (the reference's edge_table, solver.h:123,259-260).  Built on first
+    // use: a multi-GPU LINE run only ever draws from its column tables and never needs it.
+    int ensure_edge_table() {
+        if (!edge_slots.empty()) return GVK_OK;
+        const size_t D = g->edge_weights.size();
+        std::vector<float> prob(D);
+        std::vector<uint64_t> alias(D);
+        const int rc = gvk_alias_build(g->edge_weights.data(), D, prob.data(), alias.data(), 8, nullptr);
+        if (rc != GVK_OK) return rc;
+        edge_slots.resize(D);
+        for (size_t e = 0; e < D; e++) edge_slots[e] = EdgeSlot{prob[e], 0, alias[e]};
+        return GVK_OK;
+    }
+
+    // split copies for hosts that want the reference's two-array form (tests)
+    void materialize_split_table() {
+        if (edge_prob.size() == edge_slots.size()) return;
+        edge_prob.resize(edge_slots.size());
+        edge_alias.resize(edge_slots.size());
+        for (size_t e = 0; e < edge_slots.size(); e++) {
+            edge_prob[e] = edge_slots[e].prob;
+            edge_alias[e] = edge_slots[e].alias;
+        }
+    }
+
     inline uint64_t sample_edge(HostRng &rng) const {
         const double r1 = rng.next(), r2 = rng.next();
         const uint64_t index = (uint64_t)(r1 * (double)edge_slots.size());
@@ -794,15 +819,6 @@ gvs_sampler *gvs_sampler_create(const gvs_graph *g, const int32_t *part, const u
             }
             s->location[v] = pack_location(part[v], local[v]);
         }
-        s->edge_prob.resize(D);
-        s->edge_alias.resize(D);
-        if (gvk_alias_build(g->edge_weights.data(), D, s->edge_prob.data(), s->edge_alias.data(), 8, nullptr) !=
-            GVK_OK) {
-            delete s;
-            return nullptr;
-        }
-        s->edge_slots.resize(D);
-        for (size_t e = 0; e < D; e++) s->edge_slots[e] = EdgeSlot{s->edge_prob[e], 0, s->edge_alias[e]};
     } catch (const std::bad_alloc &) {
         delete s;
         gvk_fail(GVK_ENOMEM, "gvs_sampler_create: out of host memory");
@@ -900,6 +916,11 @@ int gvs_sampler_fill(gvs_sampler *s, uint32_t *const *pools, uint64_t pool_size,
                 return gvk_fail(GVK_EINVAL, "gvs_sampler_fill: pool (%d, %d) is null", hp, tp);
     return guarded("gvs_sampler_fill", [&]() {
         if ((int)s->positions.size() < c->num_thread) s->positions.resize(c->num_thread, 0);
+        const bool column_mode = c->mode == GVS_MODE_EDGE && c->tail_partition >= 0 && s->P > 1;
+        if (!column_mode) {
+            const int rc = s->ensure_edge_table();
+            if (rc != GVK_OK) return rc;
+        }
         if (c->mode == GVS_MODE_EDGE && c->tail_partition >= 0 && s->P > 1) {
             if (s->columns.empty()) s->columns.resize(s->P);
             gvs_sampler::Column &col = s->columns[c->tail_partition];
@@ -956,8 +977,18 @@ int gvs_sampler_set_stream_position(gvs_sampler *s, int thread, uint64_t positio
     return GVK_OK;
 }
 
-const float *gvs_sampler_edge_prob(const gvs_sampler *s) { return s ? s->edge_prob.data() : nullptr; }
-const uint64_t *gvs_sampler_edge_alias(const gvs_sampler *s) { return s ? s->edge_alias.data() : nullptr; }
+const float *gvs_sampler_edge_prob(const gvs_sampler *s) {
+    gvs_sampler *m = const_cast<gvs_sampler *>(s);
+    if (!m || m->ensure_edge_table() != GVK_OK) return nullptr;
+    m->materialize_split_table();
+    return m->edge_prob.data();
+}
+const uint64_t *gvs_sampler_edge_alias(const gvs_sampler *s) {
+    gvs_sampler *m = const_cast<gvs_sampler *>(s);
+    if (!m || m->ensure_edge_table() != GVK_OK) return nullptr;
+    m->materialize_split_table();
+    return m->edge_alias.data();
+}
 const float *gvs_sampler_neighbor_prob(const gvs_sampler *s) { return s ? s->nb_prob.data() : nullptr; }
 const uint32_t *gvs_sampler_neighbor_alias(const gvs_sampler *s) { return s ? s->nb_alias.data() : nullptr; }
 const uint64_t *gvs_sampler_edge_edge_offsets(const gvs_sampler *s) { return s ? s->ee_offsets.data() : nullptr; }

@@ -164,8 +164,9 @@ int gvk_sample_walks(void *stream, const gvk_walk_graph *graph, uint64_t seed, u
                      size_t pool_pairs, int walk_length, int augmentation_step, int shuffle_base);
 
 /* Host: Vose alias construction exactly as the reference orders it (FIFO queues, double mean).
- * index_bytes 4 -> uint32 alias[], 8 -> uint64 alias[].  n must be > 0 and < 2^31 (the reference's
- * loop counters are int).  packed (optional, index_bytes 4 only) receives the interleaved device form. */
+ * index_bytes 4 -> uint32 alias[] (n <= 2^32 - 1), 8 -> uint64 alias[].  n must be > 0.  (The reference's loop
+ * counters are int, alias_table.cuh:93-100, so it overflows past 2^31 entries; this builder does not.)
+ * packed (optional, index_bytes 4 only) receives the interleaved device form. */
 int gvk_alias_build(const float *weights, size_t n, float *prob, void *alias, int index_bytes,
                     gvk_alias_entry *packed);
 

@@ -90,7 +90,7 @@ int gvs_schedule(int num_partition, int num_worker, int32_t *out, size_t out_len
                                     f(x) / max(1/p, 1, 1/q); f as in graph.cuh:664-669).  Three uniforms per proposal. */
 
 /* The graph must outlive the sampler (the reference borrows it the same way, solver.h:289).  part / local are
- * copied.  Builds the edge alias table over the flattened edge weights. */
+ * copied.  The alias table over all flattened edge weights is built at the first fill that needs it. */
 gvs_sampler *gvs_sampler_create(const gvs_graph *g, const int32_t *part, const uint32_t *local, int num_partition,
                                 uint64_t seed);
 void gvs_sampler_destroy(gvs_sampler *s);
