@@ -142,14 +142,13 @@ def main():
                  batch_size=B, episode_size=args.block_batches)
     total_batches = (args.warmup + args.steps) * world
     epochs = total_batches * B // graph.num_edge + 1
-    solver._configure_training("LINE", epochs, False, 1, 40, 100, gv.auto, 1, 1, 1, 0.75, 5.0, 1 << 30)
+    session = solver.session(model="LINE", num_epoch=epochs, augmentation_step=1, log_frequency=1 << 30)
     solver.num_batch = total_batches  # the lr schedule spans exactly the batches this run trains
-    state = solver._upload_state()
-    pools = solver._host_pools(sets=1)[0]
+    pools = session.new_host_pools()
     t0 = time.perf_counter()
-    solver._fill(pools)
+    session.fill(pools)
     fill_s = time.perf_counter() - t0
-    blocks = [(int(s[rank][0]), int(s[rank][1])) for s in solver._schedule]
+    blocks = session.blocks
     if args.xcd_bucket:
         column = 1 if args.xcd_bucket == "head" else 0
         for pool in pools.values():
@@ -168,7 +167,7 @@ def main():
                 out = np.empty_like(rec[i])
                 out[dest] = rec[i][order]
                 rec[i] = out
-    dev_pools = {b: pools[b].to(dev) for b in blocks}  # every block pool of this GPU's column, resident in HBM
+    dev_pools = session.upload(pools)  # every block pool of this GPU's column, resident in HBM
     sampled = len(blocks) * args.block_batches * B
 
     kernel_events = []
@@ -179,19 +178,16 @@ def main():
         while done < num_batches:
             hp, tp = blocks[step % len(blocks)]
             n = min(args.block_batches, num_batches - done)
-            solver.episode_size = n
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            solver._train_block(state, hp, tp, dev_pools[(hp, tp)])
+            session.train_block(hp, tp, dev_pools[(hp, tp)], n)
             if timed:
                 e1.record()
                 kernel_events.append((e0, e1, n))
-            if world > 1:
-                solver._exchange(state, step % len(blocks))
+            session.exchange(step)
             done += n
             step += 1
-        solver.episode_size = args.block_batches
 
     def fence():
         torch.cuda.synchronize()
@@ -200,8 +196,7 @@ def main():
         torch.cuda.synchronize()
 
     run(args.warmup, False)
-    if world > 1:  # the first collective creates the RCCL communicator and its buffers: keep that out of the timing
-        solver._exchange(state, 0)
+    session.exchange(0)  # the first collective creates the RCCL communicator and its buffers: keep it out of the timing
     fence()
     t0 = time.perf_counter()
     run(args.steps, True)
@@ -212,7 +207,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     kernel_ms = sum(a.elapsed_time(b) for a, b, _ in kernel_events) / sum(n for _, _, n in kernel_events)
-    final_loss = float(state["loss"].mean().item())
+    final_loss = float(session.loss.mean().item())
 
     bytes_per_launch = algorithmic_bytes(dim, k) * B
     achieved = bytes_per_launch / (kernel_ms * 1e-3)
@@ -222,7 +217,7 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "r1", "pmc_summary_bench_n1.json")
     if world == 1 and dim == 128 and k == 1 and B == 100000 and N == 1000000 and os.path.exists(pmc):
         traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
-    lanes = args.lanes or 16
+    lanes = args.lanes or {32: 8, 64: 16, 96: 8, 128: 16, 256: 16, 512: 32}[dim]
     result = {
         "metric": "million edge-samples/sec at dim=%d" % dim,
         "value": world * args.steps * B / wall / 1e6,
@@ -248,8 +243,7 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         tp = blocks[0][1]
-        packed = state["negative_tables"][tp].cpu().numpy().view(np.dtype([("prob", np.float32),
-                                                                           ("alias", np.uint32)]))
+        packed = session.negative_table(tp).cpu().numpy().view(np.dtype([("prob", np.float32), ("alias", np.uint32)]))
         pool0 = pools[blocks[0]].numpy().view(np.uint32).reshape(-1, 2)
         result["cpu_baseline"] = cpu_baseline(args, solver, pool0, packed)
     if rank == 0:

@@ -42,6 +42,71 @@ def _dist():
     return dist if dist.is_available() and dist.is_initialized() else None
 
 
+class TrainingSession(object):
+    """The pieces `GraphSolver.train()` is made of, exposed step by step (benchmarks, custom loops).
+
+        session = solver.session(model="LINE", num_epoch=10, augmentation_step=1)
+        pools = session.new_host_pools()          # pinned host pools, one per block this GPU trains
+        session.fill(pools)                       # native CPU samplers
+        resident = session.upload(pools)          # -> HBM
+        for step, (hp, tp) in enumerate(session.blocks):
+            session.train_block(hp, tp, resident[(hp, tp)])
+            session.exchange(step)                # all-gather of the head shards (no-op on one GPU)
+        session.finish()                          # device tables -> solver.vertex_embeddings / context_embeddings
+    """
+
+    def __init__(self, solver, **train_kwargs):
+        defaults = dict(model="LINE", num_epoch=2000, resume=False, augmentation_step=auto, random_walk_length=40,
+                        random_walk_batch_size=100, shuffle_base=auto, p=1, q=1, positive_reuse=1,
+                        negative_sample_exponent=0.75, negative_weight=5, log_frequency=1000)
+        unknown = set(train_kwargs) - set(defaults)
+        if unknown:
+            raise TypeError("unexpected training argument(s): %s" % ", ".join(sorted(unknown)))
+        defaults.update(train_kwargs)
+        self.solver = solver
+        solver._configure_training(**defaults)
+        self.state = solver._upload_state()
+        #: (head partition, tail partition) this GPU trains at each schedule step of an episode
+        self.blocks = [(int(step[solver.rank][0]), int(step[solver.rank][1])) for step in solver._schedule]
+
+    def new_host_pools(self, sets=1):
+        pools = self.solver._host_pools(sets)
+        return pools[0] if sets == 1 else pools
+
+    def fill(self, pools):
+        self.solver._fill(pools)
+
+    def upload(self, pools):
+        return {block: pool.to(self.solver.device) for block, pool in pools.items()}
+
+    def train_block(self, hp, tp, pool, num_batches=None):
+        """Train `num_batches` (default: episode_size) batches of block (hp, tp) from a device-resident pool."""
+        solver = self.solver
+        saved = solver.episode_size
+        if num_batches is not None:
+            solver.episode_size = int(num_batches)
+        try:
+            solver._train_block(self.state, hp, tp, pool)
+        finally:
+            solver.episode_size = saved
+
+    def exchange(self, step_index):
+        if self.solver.num_worker > 1:
+            self.solver._exchange(self.state, step_index % len(self.blocks))
+
+    @property
+    def loss(self):
+        """Per-sample loss of the most recent batch (device tensor)."""
+        return self.state["loss"]
+
+    def negative_table(self, tail_partition):
+        return self.state["negative_tables"][tail_partition]
+
+    def finish(self):
+        self.solver._write_back(self.state)
+        self.state = None
+
+
 class GraphSolver(object):
     """
     GraphSolver(dim, float_type=dtype.float32, index_type=dtype.uint32, device_ids=[], num_sampler_per_worker=auto,
@@ -309,6 +374,11 @@ class GraphSolver(object):
                 current ^= 1
         finally:
             report()
+
+    def session(self, **train_kwargs):
+        """Configure a training run (same keyword arguments as train()), move the tables to HBM and return the
+        TrainingSession that drives it block by block."""
+        return TrainingSession(self, **train_kwargs)
 
     def _configure_training(self, model, num_epoch, resume, augmentation_step, random_walk_length,
                             random_walk_batch_size, shuffle_base, p, q, positive_reuse, negative_sample_exponent,

@@ -198,6 +198,32 @@ def test_node2vec_switches_to_rejection_past_the_table_limit():
     assert s._mode == "biased_reject" and np.abs(s.context_embeddings).max() > 0
 
 
+def test_training_session_steps_equal_train():
+    """solver.session(): the public step-by-step form of train() produces the same tables as train() itself."""
+    g = make_graph(250, 2500, seed=3)
+    kw = dict(model="LINE", num_epoch=2, augmentation_step=1, log_frequency=100000)
+    a = gv.solver.GraphSolver(32, kernels=OracleKernels(), num_sampler_per_worker=2, seed=5)
+    a.build(g, batch_size=500, episode_size=5)
+    a.train(**kw)
+    b = gv.solver.GraphSolver(32, kernels=OracleKernels(), num_sampler_per_worker=2, seed=5)
+    b.build(g, batch_size=500, episode_size=5)
+    session = b.session(**kw)
+    assert session.blocks == [(0, 0)]
+    while b.batch_id < b.num_batch:
+        pools = session.new_host_pools()
+        session.fill(pools)
+        resident = session.upload(pools)
+        for step, (hp, tp) in enumerate(session.blocks):
+            session.train_block(hp, tp, resident[(hp, tp)])
+            session.exchange(step)
+    assert session.loss.numel() == 500
+    session.finish()
+    assert a.batch_id == b.batch_id
+    assert (a.vertex_embeddings == b.vertex_embeddings).all() and (a.context_embeddings == b.context_embeddings).all()
+    with pytest.raises(TypeError):
+        b.session(modle="LINE")
+
+
 def test_custom_schedule_and_optimizers():
     g = make_graph(150, 900, seed=4)
     k = OracleKernels()
