@@ -439,6 +439,19 @@ struct EdgeSlot {
 
 inline uint64_t pack_location(int32_t part, uint32_t local) { return ((uint64_t)(uint32_t)part << 32) | local; }
 
+// One cache line per edge draw: the slot's probability plus the packed (partition, local id) locations of both
+// outcomes (keep the slot's own edge / take its alias).  The draw itself is unchanged — same slot, same comparison —
+// but the dependent misses into edges[] and the location table disappear: at 255 threads the edge sampler is bound by
+// random DRAM lines per second, and this is one line per sample instead of two plus two cache-resident lookups.
+struct alignas(64) FatSlot {
+    float prob;
+    uint32_t pad;
+    uint64_t self_head, self_tail, alias_head, alias_tail;
+};
+
+// tables above this many entries keep the 16-byte slots (64 B x 2^27 = 8 GiB)
+constexpr size_t kFatSlotLimit = (size_t)1 << 27;
+
 }  // namespace
 
 struct gvs_sampler {
@@ -463,8 +476,22 @@ struct gvs_sampler {
         std::vector<float> prob;
         std::vector<uint64_t> alias;
         std::vector<EdgeSlot> slots;
+        std::vector<FatSlot> fat;
     };
     std::vector<Column> columns;
+    std::vector<FatSlot> edge_fat;
+
+    // fat[i] for slot i of a table whose entry j stands for flattened edge ids[j] (ids == nullptr: entry j is edge j)
+    void build_fat(const std::vector<EdgeSlot> &slots, const uint64_t *ids, std::vector<FatSlot> *fat) const {
+        if (!fat->empty() || slots.size() > kFatSlotLimit) return;
+        const uint32_t *edges = g->edges_uv.data();
+        fat->resize(slots.size());
+        for (size_t i = 0; i < slots.size(); i++) {
+            const uint64_t self = ids ? ids[i] : i, other = ids ? ids[slots[i].alias] : slots[i].alias;
+            (*fat)[i] = FatSlot{slots[i].prob, 0, location[edges[2 * self]], location[edges[2 * self + 1]],
+                                location[edges[2 * other]], location[edges[2 * other + 1]]};
+        }
+    }
 
     // The alias table over ALL flattened edges (the reference's edge_table, solver.h:123,259-260).  Built on first
     // use: a multi-GPU LINE run only ever draws from its column tables and never needs it.
@@ -557,29 +584,43 @@ void fill_edges(FillShared *sh, int thread, int64_t start, int64_t end, uint64_t
     // Uniforms are still consumed two per sample, in sample order.
     std::vector<uint64_t> index(n), edge(n), heads(n), tails(n);
     std::vector<float> u(n);
+    const std::vector<FatSlot> &fat_table = column ? column->fat : s.edge_fat;
+    const FatSlot *fat = fat_table.empty() ? nullptr : fat_table.data();
     int idle = 0;
     while (!cur.done() && !sh->error.load(std::memory_order_relaxed)) {
         for (int i = 0; i < n; i++) {
             const double r1 = rng.next(), r2 = rng.next();
             index[i] = (uint64_t)(r1 * count);
             u[i] = (float)r2;
-            __builtin_prefetch(&slots[index[i]]);
+            if (fat)
+                __builtin_prefetch(&fat[index[i]]);
+            else
+                __builtin_prefetch(&slots[index[i]]);
         }
-        for (int i = 0; i < n; i++) {
-            const EdgeSlot &slot = slots[index[i]];
-            const uint64_t pick = u[i] < slot.prob ? index[i] : slot.alias;
-            edge[i] = column ? column->edge_ids[pick] : pick;
-            __builtin_prefetch(&edges[2 * edge[i]]);
-        }
-        for (int i = 0; i < n; i++) {
-            heads[i] = edges[2 * edge[i]];
-            tails[i] = edges[2 * edge[i] + 1];
-            __builtin_prefetch(&s.location[heads[i]]);
-            __builtin_prefetch(&s.location[tails[i]]);
-        }
-        for (int i = 0; i < n; i++) {
-            heads[i] = s.location[heads[i]];
-            tails[i] = s.location[tails[i]];
+        if (fat) {
+            for (int i = 0; i < n; i++) {
+                const FatSlot &slot = fat[index[i]];
+                const bool self = u[i] < slot.prob;
+                heads[i] = self ? slot.self_head : slot.alias_head;
+                tails[i] = self ? slot.self_tail : slot.alias_tail;
+            }
+        } else {
+            for (int i = 0; i < n; i++) {
+                const EdgeSlot &slot = slots[index[i]];
+                const uint64_t pick = u[i] < slot.prob ? index[i] : slot.alias;
+                edge[i] = column ? column->edge_ids[pick] : pick;
+                __builtin_prefetch(&edges[2 * edge[i]]);
+            }
+            for (int i = 0; i < n; i++) {
+                heads[i] = edges[2 * edge[i]];
+                tails[i] = edges[2 * edge[i] + 1];
+                __builtin_prefetch(&s.location[heads[i]]);
+                __builtin_prefetch(&s.location[tails[i]]);
+            }
+            for (int i = 0; i < n; i++) {
+                heads[i] = s.location[heads[i]];
+                tails[i] = s.location[tails[i]];
+            }
         }
         bool wrote = false;
         for (int i = 0; i < n; i++) {
@@ -920,6 +961,7 @@ int gvs_sampler_fill(gvs_sampler *s, uint32_t *const *pools, uint64_t pool_size,
         if (!column_mode) {
             const int rc = s->ensure_edge_table();
             if (rc != GVK_OK) return rc;
+            if (c->mode == GVS_MODE_EDGE) s->build_fat(s->edge_slots, nullptr, &s->edge_fat);
         }
         if (c->mode == GVS_MODE_EDGE && c->tail_partition >= 0 && s->P > 1) {
             if (s->columns.empty()) s->columns.resize(s->P);
@@ -941,6 +983,7 @@ int gvs_sampler_fill(gvs_sampler *s, uint32_t *const *pools, uint64_t pool_size,
                 col.slots.resize(weights.size());
                 for (size_t i = 0; i < weights.size(); i++) col.slots[i] = EdgeSlot{col.prob[i], 0, col.alias[i]};
             }
+            s->build_fat(col.slots, col.edge_ids.data(), &col.fat);
         }
         FillShared sh;
         sh.s = s;
