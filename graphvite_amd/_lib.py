@@ -136,6 +136,8 @@ def lib():
     l.gvs_sampler_destroy.argtypes = [vp]
     l.gvs_sampler_prepare.restype = i32
     l.gvs_sampler_prepare.argtypes = [vp, i32, f, f, i32]
+    l.gvs_sampler_prepare_column.restype = i32
+    l.gvs_sampler_prepare_column.argtypes = [vp, i32, i32]
     l.gvs_sampler_fill.restype = i32
     l.gvs_sampler_fill.argtypes = [vp, P(vp), u64, P(FillConfig)]
     l.gvs_sampler_stream_position.restype = u64

@@ -482,15 +482,47 @@ struct gvs_sampler {
     std::vector<FatSlot> edge_fat;
 
     // fat[i] for slot i of a table whose entry j stands for flattened edge ids[j] (ids == nullptr: entry j is edge j)
-    void build_fat(const std::vector<EdgeSlot> &slots, const uint64_t *ids, std::vector<FatSlot> *fat) const {
+    void build_fat(const std::vector<EdgeSlot> &slots, const uint64_t *ids, std::vector<FatSlot> *fat,
+                   int num_thread) const {
         if (!fat->empty() || slots.size() > kFatSlotLimit) return;
         const uint32_t *edges = g->edges_uv.data();
         fat->resize(slots.size());
-        for (size_t i = 0; i < slots.size(); i++) {
-            const uint64_t self = ids ? ids[i] : i, other = ids ? ids[slots[i].alias] : slots[i].alias;
-            (*fat)[i] = FatSlot{slots[i].prob, 0, location[edges[2 * self]], location[edges[2 * self + 1]],
-                                location[edges[2 * other]], location[edges[2 * other + 1]]};
+        FatSlot *out = fat->data();
+        const size_t n = slots.size(), T = (size_t)std::max(1, num_thread), work = (n + T - 1) / T;
+        std::vector<std::thread> threads;
+        for (size_t t = 0; t < T && t * work < n; t++)
+            threads.emplace_back([&, t]() {
+                for (size_t i = t * work; i < std::min(n, (t + 1) * work); i++) {
+                    const uint64_t self = ids ? ids[i] : i, other = ids ? ids[slots[i].alias] : slots[i].alias;
+                    out[i] = FatSlot{slots[i].prob, 0, location[edges[2 * self]], location[edges[2 * self + 1]],
+                                     location[edges[2 * other]], location[edges[2 * other + 1]]};
+                }
+            });
+        for (auto &t : threads) t.join();
+    }
+
+    // Column table of tail partition r: alias table over exactly the edges that end in r (+ its fat form).
+    int ensure_column(int r, int num_thread) {
+        if (columns.empty()) columns.resize(P);
+        Column &col = columns[r];
+        if (col.slots.empty()) {
+            const size_t D = g->edge_weights.size();
+            std::vector<float> weights;
+            for (size_t e = 0; e < D; e++)
+                if ((int)(location[g->edges_uv[2 * e + 1]] >> 32) == r) {
+                    col.edge_ids.push_back(e);
+                    weights.push_back(g->edge_weights[e]);
+                }
+            if (weights.empty()) return gvk_fail(GVK_EINVAL, "no edge ends in partition %d", r);
+            col.prob.resize(weights.size());
+            col.alias.resize(weights.size());
+            const int rc = gvk_alias_build(weights.data(), weights.size(), col.prob.data(), col.alias.data(), 8, nullptr);
+            if (rc != GVK_OK) return rc;
+            col.slots.resize(weights.size());
+            for (size_t i = 0; i < weights.size(); i++) col.slots[i] = EdgeSlot{col.prob[i], 0, col.alias[i]};
         }
+        build_fat(col.slots, col.edge_ids.data(), &col.fat, num_thread);
+        return GVK_OK;
     }
 
     // The alias table over ALL flattened edges (the reference's edge_table, solver.h:123,259-260).  Built on first
@@ -884,6 +916,15 @@ int gvs_sampler_prepare(gvs_sampler *s, int mode, float p, float q, int num_thre
         decltype(s->ee_offsets)().swap(s->ee_offsets);
         decltype(s->sorted_nb)().swap(s->sorted_nb);
         s->prepared = GVS_MODE_EDGE;
+        if (mode == GVS_MODE_EDGE && s->P == 1) {  // single partition: every fill draws from the global table
+            const int rc = s->ensure_edge_table();
+            if (rc != GVK_OK) return rc;
+            s->build_fat(s->edge_slots, nullptr, &s->edge_fat, num_thread);
+        }
+        if (mode != GVS_MODE_EDGE) {
+            const int rc = s->ensure_edge_table();  // walks start from a weighted edge draw
+            if (rc != GVK_OK) return rc;
+        }
         if (mode == GVS_MODE_BIASED_REJECT) {
             if (!(p > 0) || !(q > 0)) return gvk_fail(GVK_EINVAL, "gvs_sampler_prepare: p and q must be positive");
             s->p = p;
@@ -928,6 +969,12 @@ int gvs_sampler_prepare(gvs_sampler *s, int mode, float p, float q, int num_thre
     });
 }
 
+int gvs_sampler_prepare_column(gvs_sampler *s, int tail_partition, int num_thread) {
+    if (!s || tail_partition < 0 || tail_partition >= s->P)
+        return gvk_fail(GVK_EINVAL, "gvs_sampler_prepare_column: bad argument");
+    return guarded("gvs_sampler_prepare_column", [&]() { return s->ensure_column(tail_partition, num_thread); });
+}
+
 int gvs_sampler_fill(gvs_sampler *s, uint32_t *const *pools, uint64_t pool_size, const gvs_fill_config *c) {
     if (!s || !pools || !c) return gvk_fail(GVK_EINVAL, "gvs_sampler_fill: null argument");
     if (c->num_thread < 1) return gvk_fail(GVK_EINVAL, "gvs_sampler_fill: num_thread must be >= 1");
@@ -961,29 +1008,11 @@ int gvs_sampler_fill(gvs_sampler *s, uint32_t *const *pools, uint64_t pool_size,
         if (!column_mode) {
             const int rc = s->ensure_edge_table();
             if (rc != GVK_OK) return rc;
-            if (c->mode == GVS_MODE_EDGE) s->build_fat(s->edge_slots, nullptr, &s->edge_fat);
+            if (c->mode == GVS_MODE_EDGE) s->build_fat(s->edge_slots, nullptr, &s->edge_fat, c->num_thread);
         }
-        if (c->mode == GVS_MODE_EDGE && c->tail_partition >= 0 && s->P > 1) {
-            if (s->columns.empty()) s->columns.resize(s->P);
-            gvs_sampler::Column &col = s->columns[c->tail_partition];
-            if (col.slots.empty()) {
-                const size_t D = s->g->edge_weights.size();
-                std::vector<float> weights;
-                for (size_t e = 0; e < D; e++)
-                    if ((int)(s->location[s->g->edges_uv[2 * e + 1]] >> 32) == c->tail_partition) {
-                        col.edge_ids.push_back(e);
-                        weights.push_back(s->g->edge_weights[e]);
-                    }
-                if (weights.empty())
-                    return gvk_fail(GVK_EINVAL, "gvs_sampler_fill: no edge ends in partition %d", c->tail_partition);
-                col.prob.resize(weights.size());
-                col.alias.resize(weights.size());
-                int rc = gvk_alias_build(weights.data(), weights.size(), col.prob.data(), col.alias.data(), 8, nullptr);
-                if (rc != GVK_OK) return rc;
-                col.slots.resize(weights.size());
-                for (size_t i = 0; i < weights.size(); i++) col.slots[i] = EdgeSlot{col.prob[i], 0, col.alias[i]};
-            }
-            s->build_fat(col.slots, col.edge_ids.data(), &col.fat);
+        if (column_mode) {
+            const int rc = s->ensure_column(c->tail_partition, c->num_thread);
+            if (rc != GVK_OK) return rc;
         }
         FillShared sh;
         sh.s = s;

@@ -63,6 +63,10 @@ class Sampler(object):
         _lib.check(self._lib.gvs_sampler_prepare(self._handle, self.MODES[mode], p, q, num_thread),
                    "gvs_sampler_prepare")
 
+    def prepare_column(self, tail_partition, num_thread=1):
+        _lib.check(self._lib.gvs_sampler_prepare_column(self._handle, tail_partition, num_thread),
+                   "gvs_sampler_prepare_column")
+
     def fill(self, pools, pool_size, mode, num_thread, sample_batch_size=4000, walk_length=40, walk_batch=100,
              augmentation_step=1, shuffle_base=1, tail_partition=-1):
         """pools: dict {(hp, tp): uint32 array/tensor-backed buffer of >= pool_size*2 elements} or a P*P list."""

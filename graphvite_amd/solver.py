@@ -444,6 +444,9 @@ class GraphSolver(object):
         key = (mode, self.p, self.q)
         if self._sampler_mode != key:  # get_sample_function, graph.cuh:680-721
             self._sampler.prepare(mode, self.p, self.q, self.num_sampler_per_worker + 1)
+            if mode == "edge" and self.num_partition > 1:
+                for tp in self._my_tails:
+                    self._sampler.prepare_column(tp, self.num_sampler_per_worker + 1)
             self._sampler_mode = key
         self._mode = mode
 

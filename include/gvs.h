@@ -99,6 +99,10 @@ void gvs_sampler_destroy(gvs_sampler *s);
  * per-edge tables with return parameter p and in-out parameter q (BIASED_WALK; sum of deg^2 entries). */
 int gvs_sampler_prepare(gvs_sampler *s, int mode, float p, float q, int num_thread);
 
+/* EDGE mode, several partitions: builds the column table of one tail partition ahead of the first fill that uses
+ * it (fills build it on demand otherwise). */
+int gvs_sampler_prepare_column(gvs_sampler *s, int tail_partition, int num_thread);
+
 typedef struct {
     int mode;
     int num_thread;         /* sampler threads; thread t fills slice [t*L, min((t+1)*L, pool_size)), L = ceil(pool_size / T) */
