@@ -75,7 +75,8 @@ def cpu_baseline(args, solver, pool, table_packed):
         ref = Reference(fast=True)
     except (FileNotFoundError, OSError):
         return None
-    cores = os.cpu_count() or 1
+    from graphvite_amd.base import cpu_budget
+    cores = cpu_budget()  # CPUs the container may really use (cgroup quota), not the 256 hardware threads it sees
     B, k = args.batch, args.negatives
     rng = np.random.default_rng(args.seed + 7)
     prob, alias = np.ascontiguousarray(table_packed["prob"]), np.ascontiguousarray(table_packed["alias"])
@@ -97,9 +98,9 @@ def cpu_baseline(args, solver, pool, table_packed):
         if el >= args.cpu_seconds and done >= 2:
             break
     return {"value": done * B / el / 1e6, "unit": "million edge-samples/sec", "cores": cores, "kind": "reference",
-            "sample": "%d batches of %d edge-samples of rank 0's first block pool (%.1f s wall, %d threads, Hogwild; "
-                      "-Ofast x86-64-v3 host build of the reference's own LINE::forward/backward + sgd_update)"
-                      % (done, B, el, cores)}
+            "sample": "%d batches of %d edge-samples of rank 0's first block pool (%.1f s wall, %d threads = the "
+                      "container's CPU quota on a %d-thread host, Hogwild; -Ofast x86-64-v3 host build of the "
+                      "reference's own LINE::forward/backward + sgd_update)" % (done, B, el, cores, os.cpu_count() or 1)}
 
 
 def main():
@@ -128,7 +129,8 @@ def main():
         if world == 1:
             auto = max(auto, int(2e7) // B)
         args.block_batches = min(auto, 250)
-    threads = args.sampler_threads or max((os.cpu_count() or 1) // world, 1)
+    from graphvite_amd.base import cpu_budget
+    threads = args.sampler_threads or max(cpu_budget() // world, 1)
 
     # ---- product path up to the resident state ----
     graph = gv.graph.Graph()

@@ -36,7 +36,7 @@ class NegativeSource(C.Structure):
 class FillConfig(C.Structure):
     _fields_ = [("mode", C.c_int), ("num_thread", C.c_int), ("sample_batch_size", C.c_int), ("walk_length", C.c_int),
                 ("walk_batch", C.c_int), ("augmentation_step", C.c_int), ("shuffle_base", C.c_int),
-                ("tail_partition", C.c_int)]
+                ("tail_partition", C.c_int), ("os_threads", C.c_int), ("cpu_offset", C.c_int)]
 
 
 MODE_EDGE, MODE_WALK, MODE_BIASED_WALK, MODE_BIASED_REJECT = 0, 1, 2, 3

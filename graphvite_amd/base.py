@@ -80,3 +80,35 @@ def init_logging(level=logging.INFO, dir="", verbose=False):
         fh = logging.FileHandler(os.path.join(dir, "graphvite_amd.log"))
         fh.setFormatter(logging.Formatter(fmt))
         logger.addHandler(fh)
+
+
+def cpu_budget():
+    """CPUs this process can really use: the smaller of its affinity mask and its cgroup CPU quota.
+    `os.cpu_count()` reports the machine (256 hardware threads on the MI355X boxes) even when the container is capped
+    (e.g. cpu.max = "1600000 100000" = 16 CPUs); running 255 sampler threads under such a cap gets them throttled for
+    most of every 100 ms period."""
+    import math
+    import os
+    try:
+        count = len(os.sched_getaffinity(0))
+    except AttributeError:
+        count = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2
+            q, period = f.read().split()
+            if q != "max":
+                quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = float(f.read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        count = min(count, max(int(math.floor(quota)), 1))
+    return max(count, 1)

@@ -18,13 +18,20 @@
 // and in lockstep order (see fill_walks) by the walk samplers.
 
 #include <math.h>
+#include <pthread.h>
+#include <sched.h>
+#include <sys/mman.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -34,6 +41,44 @@
 #include "gvk.h"
 #include "gvk_internal.h"
 #include "gvs.h"
+
+// Big randomly-accessed tables (edge slots, CSR arrays, locations) live in 2 MiB pages where the kernel grants them:
+// with 4 KiB pages every draw is also a TLB miss, and the kernel's periodic page scans (NUMA balancing) turn a
+// 1.3 GB table into hundreds of thousands of hinting faults — observed as every other fill running 10x slower.
+template <class T>
+struct HugeAllocator {
+    typedef T value_type;
+    static constexpr size_t kHuge = (size_t)2 << 20, kThreshold = (size_t)4 << 20;
+    HugeAllocator() = default;
+    template <class U>
+    HugeAllocator(const HugeAllocator<U> &) {}
+    T *allocate(size_t n) {
+        const size_t bytes = n * sizeof(T);
+        if (bytes < kThreshold) {
+            void *p = malloc(bytes ? bytes : 1);
+            if (!p) throw std::bad_alloc();
+            return static_cast<T *>(p);
+        }
+        const size_t rounded = (bytes + kHuge - 1) / kHuge * kHuge;
+        void *p = mmap(nullptr, rounded, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (p == MAP_FAILED) throw std::bad_alloc();
+        madvise(p, rounded, MADV_HUGEPAGE);
+        return static_cast<T *>(p);
+    }
+    void deallocate(T *p, size_t n) {
+        const size_t bytes = n * sizeof(T);
+        if (bytes < kThreshold)
+            free(p);
+        else
+            munmap(p, (bytes + kHuge - 1) / kHuge * kHuge);
+    }
+    template <class U>
+    bool operator==(const HugeAllocator<U> &) const { return true; }
+    template <class U>
+    bool operator!=(const HugeAllocator<U> &) const { return false; }
+};
+template <class T>
+using HugeVector = std::vector<T, HugeAllocator<T>>;
 
 // ---- graph ---------------------------------------------------------------------------------------------
 
@@ -51,9 +96,9 @@ struct gvs_graph {
     std::vector<float> w;
     // flattened
     std::vector<float> vertex_weights;
-    std::vector<uint32_t> edges_uv;
-    std::vector<float> edge_weights;
-    std::vector<uint64_t> flat_offsets;
+    HugeVector<uint32_t> edges_uv;
+    HugeVector<float> edge_weights;
+    HugeVector<uint64_t> flat_offsets;
 
     void clear() {
         num_vertex = 0;
@@ -454,20 +499,117 @@ constexpr size_t kFatSlotLimit = (size_t)1 << 27;
 
 }  // namespace
 
+// A persistent pool of OS threads that runs the "virtual" sampler threads of a fill.  Creating hundreds of
+// std::threads per fill (the reference does, solver.h:633-635) costs little on average but stalls for tens of
+// milliseconds every few fills when the new threads fight over the process's mmap lock (stacks, malloc arenas);
+// with the pool a fill is a wake-up.  Slice t and uniform stream t still belong to virtual thread t, whichever OS
+// thread happens to run it, so a fill remains a pure function of (seed, num_thread, stream positions).
+class WorkerPool {
+public:
+    ~WorkerPool() { shutdown(); }
+
+    void run(int total, int os_threads, int cpu_offset, const std::function<void(int)> &job) {
+        const int hw = std::max(1, (int)std::thread::hardware_concurrency());
+        resize(std::min(total, os_threads > 0 ? os_threads : hw));
+        pin(cpu_offset);
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            job_ = &job;
+            total_ = total;
+            next_.store(0);
+            pending_ = (int)threads_.size();
+            generation_++;
+        }
+        wake_.notify_all();
+        std::unique_lock<std::mutex> lock(mutex_);
+        done_.wait(lock, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+private:
+    // thread k -> the (offset + k)-th CPU of the process's affinity mask; done once per offset
+    void pin(int offset) {
+        if (offset < 0 || offset == pinned_offset_ && pinned_count_ == threads_.size()) return;
+        cpu_set_t allowed;
+        if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+        std::vector<int> cpus;
+        for (int c = 0; c < CPU_SETSIZE; c++)
+            if (CPU_ISSET(c, &allowed)) cpus.push_back(c);
+        if (cpus.empty()) return;
+        for (size_t k = 0; k < threads_.size(); k++) {
+            cpu_set_t one;
+            CPU_ZERO(&one);
+            CPU_SET(cpus[((size_t)offset + k) % cpus.size()], &one);
+            pthread_setaffinity_np(threads_[k].native_handle(), sizeof(one), &one);
+        }
+        pinned_offset_ = offset;
+        pinned_count_ = threads_.size();
+    }
+
+    void resize(int n) {
+        if ((int)threads_.size() >= n) return;
+        while ((int)threads_.size() < n) {
+            const uint64_t seen = generation_;
+            threads_.emplace_back([this, seen] { loop(seen); });
+        }
+    }
+
+    void loop(uint64_t seen) {
+        for (;;) {
+            const std::function<void(int)> *job;
+            int total;
+            {
+                std::unique_lock<std::mutex> lock(mutex_);
+                wake_.wait(lock, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+                job = job_;
+                total = total_;
+            }
+            for (int i; (i = next_.fetch_add(1)) < total;) (*job)(i);
+            {
+                std::lock_guard<std::mutex> lock(mutex_);
+                if (--pending_ == 0) done_.notify_all();
+            }
+        }
+    }
+
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            stop_ = true;
+        }
+        wake_.notify_all();
+        for (auto &t : threads_) t.join();
+        threads_.clear();
+    }
+
+    std::vector<std::thread> threads_;
+    std::mutex mutex_;
+    std::condition_variable wake_, done_;
+    const std::function<void(int)> *job_ = nullptr;
+    std::atomic<int> next_{0};
+    int total_ = 0, pending_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+    int pinned_offset_ = -1;
+    size_t pinned_count_ = 0;
+};
+
 struct gvs_sampler {
     const gvs_graph *g = nullptr;
     int P = 1;
     uint64_t seed = 0;
-    std::vector<uint64_t> location;  // (part << 32) | local, per vertex
+    HugeVector<uint64_t> location;  // (part << 32) | local, per vertex
     std::vector<float> edge_prob;
     std::vector<uint64_t> edge_alias;
-    std::vector<EdgeSlot> edge_slots;  // the same table, one cache line touch per draw
+    HugeVector<EdgeSlot> edge_slots;  // the same table, one cache line touch per draw
     int prepared = GVS_MODE_EDGE;
     float p = 1, q = 1;
-    std::vector<float> nb_prob;
-    std::vector<uint32_t> nb_alias;
-    std::vector<uint64_t> ee_offsets;
-    std::vector<uint32_t> sorted_nb;  // BIASED_REJECT: out-neighbours of every vertex, ascending
+    HugeVector<float> nb_prob;
+    HugeVector<uint32_t> nb_alias;
+    HugeVector<uint64_t> ee_offsets;
+    HugeVector<uint32_t> sorted_nb;  // BIASED_REJECT: out-neighbours of every vertex, ascending
     std::vector<uint64_t> positions;
     // EDGE mode with a tail-partition filter: a table over just the edges whose tail lives in that partition
     // (the exact conditional distribution) instead of drawing from all edges and dropping (P - 1) / P of them
@@ -475,14 +617,15 @@ struct gvs_sampler {
         std::vector<uint64_t> edge_ids;
         std::vector<float> prob;
         std::vector<uint64_t> alias;
-        std::vector<EdgeSlot> slots;
-        std::vector<FatSlot> fat;
+        HugeVector<EdgeSlot> slots;
+        HugeVector<FatSlot> fat;
     };
     std::vector<Column> columns;
-    std::vector<FatSlot> edge_fat;
+    HugeVector<FatSlot> edge_fat;
+    WorkerPool pool;
 
     // fat[i] for slot i of a table whose entry j stands for flattened edge ids[j] (ids == nullptr: entry j is edge j)
-    void build_fat(const std::vector<EdgeSlot> &slots, const uint64_t *ids, std::vector<FatSlot> *fat,
+    void build_fat(const HugeVector<EdgeSlot> &slots, const uint64_t *ids, HugeVector<FatSlot> *fat,
                    int num_thread) const {
         if (!fat->empty() || slots.size() > kFatSlotLimit) return;
         const uint32_t *edges = g->edges_uv.data();
@@ -614,9 +757,12 @@ void fill_edges(FillShared *sh, int thread, int64_t start, int64_t end, uint64_t
     // caches.  The reference walks that chain one sample at a time (solver.h:1022-1035); here every stage runs over
     // the whole inner round with the next stage's lines prefetched, so a thread keeps tens of misses in flight.
     // Uniforms are still consumed two per sample, in sample order.
-    std::vector<uint64_t> index(n), edge(n), heads(n), tails(n);
-    std::vector<float> u(n);
-    const std::vector<FatSlot> &fat_table = column ? column->fat : s.edge_fat;
+    // scratch lives with the (persistent) OS thread: per-fill allocation of these buffers by hundreds of threads at once
+    // makes malloc trim and re-fault its arenas, which serialises on the process's mmap lock (fills 10x slower)
+    static thread_local std::vector<uint64_t> index, edge, heads, tails;
+    static thread_local std::vector<float> u;
+    index.resize(n), edge.resize(n), heads.resize(n), tails.resize(n), u.resize(n);
+    const HugeVector<FatSlot> &fat_table = column ? column->fat : s.edge_fat;
     const FatSlot *fat = fat_table.empty() ? nullptr : fat_table.data();
     int idle = 0;
     while (!cur.done() && !sh->error.load(std::memory_order_relaxed)) {
@@ -680,8 +826,13 @@ void fill_walks(FillShared *sh, int thread, int64_t start, int64_t end, uint64_t
     BlockCursor cur(s.P, sh->c.tail_partition, start, end);
     const int L = sh->c.walk_length, nb = sh->c.walk_batch, aug = sh->c.augmentation_step;
     const int64_t sb = sh->c.shuffle_base, stride = (int64_t)(sh->pool_size / (uint64_t)sb);
-    std::vector<uint64_t> chains((size_t)nb * (L + 1));
-    std::vector<int> lengths(nb);
+    static thread_local std::vector<uint64_t> chains, index, edge_id, base, proposal;
+    static thread_local std::vector<int> lengths, live, pending;
+    static thread_local std::vector<uint32_t> current;
+    static thread_local std::vector<float> u, accept;
+    chains.resize((size_t)nb * (L + 1));
+    lengths.resize(nb), live.resize(nb), pending.resize(nb), current.resize(nb), u.resize(nb), accept.resize(nb);
+    index.resize(nb), edge_id.resize(nb), base.resize(nb), proposal.resize(nb);
     const uint32_t *edges = s.g->edges_uv.data();
     const uint64_t *flat = s.g->flat_offsets.data();
     const EdgeSlot *slots = s.edge_slots.data();
@@ -690,11 +841,6 @@ void fill_walks(FillShared *sh, int thread, int64_t start, int64_t end, uint64_t
     // (the reference finishes one walk before it starts the next, graph.cuh:322-350,400-425).  Each stage runs over
     // the whole round with the next stage's cache lines prefetched, so a thread overlaps ~walk_batch misses instead
     // of paying every one of them serially.  Uniforms are consumed in that lockstep order, two per draw.
-    std::vector<uint64_t> index(nb), edge_id(nb), base(nb);
-    std::vector<uint32_t> current(nb);
-    std::vector<float> u(nb), accept(nb);
-    std::vector<int> live(nb), pending(nb);
-    std::vector<uint64_t> proposal(nb);
     int idle = 0;
     while (!cur.done() && !sh->error.load(std::memory_order_relaxed)) {
         for (int i = 0; i < nb; i++) {
@@ -1020,16 +1166,33 @@ int gvs_sampler_fill(gvs_sampler *s, uint32_t *const *pools, uint64_t pool_size,
         sh.pool_size = pool_size;
         sh.c = *c;
         const int64_t work = ((int64_t)pool_size + c->num_thread - 1) / c->num_thread;  // solver.h:616-617
-        std::vector<std::thread> threads;
-        for (int t = 0; t < c->num_thread; t++) {
+        const bool timing = getenv("GVS_TIMING") != nullptr;
+        std::vector<double> slice_ms(timing ? c->num_thread : 0);
+        const auto now = [] { return std::chrono::duration<double, std::milli>(
+                                         std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const std::function<void(int)> job = [&](int t) {
             const int64_t b = work * t, e = std::min(work * (t + 1), (int64_t)pool_size);
             uint64_t *position = &s->positions[t];
+            const double t0 = timing ? now() : 0;
             if (c->mode == GVS_MODE_EDGE)
-                threads.emplace_back(fill_edges, &sh, t, b, e, position);
+                fill_edges(&sh, t, b, e, position);
             else
-                threads.emplace_back(fill_walks, &sh, t, b, e, position);
+                fill_walks(&sh, t, b, e, position);
+            if (timing) slice_ms[t] = now() - t0;
+        };
+        const double t0 = timing ? now() : 0;
+        s->pool.run(c->num_thread, c->os_threads, c->cpu_offset, job);
+        if (timing) {
+            double total = now() - t0, sum = 0, mx = 0;
+            int slow = 0;
+            for (double x : slice_ms) {
+                sum += x;
+                mx = std::max(mx, x);
+                slow += x > 5;
+            }
+            fprintf(stderr, "[gvs] fill %.1f ms: %d slices, sum %.1f ms, max %.2f ms, %d slices > 5 ms\n", total,
+                    c->num_thread, sum, mx, slow);
         }
-        for (auto &t : threads) t.join();
         if (sh.error.load())
             return gvk_fail(GVK_EINVAL,
                             "gvs_sampler_fill: a block pool cannot be filled (no positive sample falls into it); "

@@ -68,7 +68,7 @@ class Sampler(object):
                    "gvs_sampler_prepare_column")
 
     def fill(self, pools, pool_size, mode, num_thread, sample_batch_size=4000, walk_length=40, walk_batch=100,
-             augmentation_step=1, shuffle_base=1, tail_partition=-1):
+             augmentation_step=1, shuffle_base=1, tail_partition=-1, os_threads=0, cpu_offset=-1):
         """pools: dict {(hp, tp): uint32 array/tensor-backed buffer of >= pool_size*2 elements} or a P*P list."""
         P = self.num_partition
         ptrs = (C.c_void_p * (P * P))()
@@ -83,7 +83,7 @@ class Sampler(object):
                     raise ValueError("pool (%d, %d) holds %d values, needs %d" % (hp, tp, n, pool_size * 2))
                 ptrs[hp * P + tp] = ptr
         cfg = _lib.FillConfig(self.MODES[mode], num_thread, sample_batch_size, walk_length, walk_batch,
-                              augmentation_step, shuffle_base, tail_partition)
+                              augmentation_step, shuffle_base, tail_partition, os_threads, cpu_offset)
         _lib.check(self._lib.gvs_sampler_fill(self._handle, ptrs, pool_size, C.byref(cfg)), "gvs_sampler_fill")
 
     def stream_position(self, thread):

@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from . import hostlib
-from .base import auto, dtype, io, logger
+from .base import auto, cpu_budget, dtype, io, logger
 from .graph import Graph
 from .optimizer import SGD, Optimizer
 
@@ -153,7 +153,8 @@ class GraphSolver(object):
             self.device = torch.device(getattr(kernels, "device", "cpu"))
         self.kernels = kernels
         if num_sampler_per_worker == auto:
-            num_sampler_per_worker = max((os.cpu_count() or 1) // max(self._local_world(), 1) - 1, 1)
+            # the reference takes hardware_concurrency / #GPU - 1 (solver.h:193-194); the usable CPUs are what counts
+            num_sampler_per_worker = max(cpu_budget() // max(self._local_world(), 1) - 1, 1)
         self.num_sampler_per_worker = int(num_sampler_per_worker)
         self.num_sampler = self.num_sampler_per_worker * self.num_worker
         self.gpu_memory_limit = gpu_memory_limit
@@ -340,7 +341,7 @@ class GraphSolver(object):
             self._write_back(state)
             t4 = time.time()
             self.timing = {"configure": t1 - t0, "upload": t2 - t1, "episodes": t3 - t2, "write_back": t4 - t3,
-                           "batches": self.batch_id - first_batch}
+                           "batches": self.batch_id - first_batch, "loop": getattr(self, "_loop_timing", None)}
             logger.info("[time] configure %.2f s, upload %.2f s, %d batches in %.2f s (%.1f M edge-samples/s), "
                         "write back %.2f s", t1 - t0, t2 - t1, self.batch_id - first_batch, t3 - t2,
                         (self.batch_id - first_batch) * self.batch_size / max(t3 - t2, 1e-9) / 1e6, t4 - t3)
@@ -357,18 +358,26 @@ class GraphSolver(object):
         try:
             self._fill(pools[0])
             current = 0
+            self._loop_timing = {"wait_upload": 0.0, "enqueue": 0.0, "wait_fill": 0.0, "fill": 0.0}
             while self.batch_id < self.num_batch:  # solver.h:629-649 — one iteration = one episode
                 # the samplers may only overwrite a pool set once the GPU has finished copying it out; this also
                 # keeps the host at most one episode ahead of the device (producer / consumer, double buffer)
+                ta = time.time()
                 for event in uploads[current ^ 1]:
                     event.synchronize()
                 uploads[current ^ 1] = []
+                tb = time.time()
                 filler = threading.Thread(target=self._fill_guarded, args=(pools[current ^ 1],))
                 filler.start()
                 try:
                     uploads[current] = self._train_episode(state, pools[current])
                 finally:
+                    tc = time.time()
                     filler.join()
+                td = time.time()
+                self._loop_timing["wait_upload"] += tb - ta
+                self._loop_timing["enqueue"] += tc - tb
+                self._loop_timing["wait_fill"] += td - tc
                 if self._fill_error is not None:
                     raise self._fill_error
                 current ^= 1
@@ -548,19 +557,25 @@ class GraphSolver(object):
         # this worker's blocks form whole columns (hp ranges over all partitions for each owned tail)
         for tp in sorted(tails):
             column = {(hp, tp): pools[(hp, tp)] for hp in range(P)}
-            self._sampler.fill(column, pool_size, self._mode, self.num_sampler_per_worker,
+            # 4 slices per OS thread: a thread that gets descheduled delays a quarter-size slice, not the whole fill
+            self._sampler.fill(column, pool_size, self._mode, 4 * self.num_sampler_per_worker,
                                sample_batch_size=self.sample_batch_size, walk_length=self.random_walk_length,
                                walk_batch=self.random_walk_batch_size, augmentation_step=self.augmentation_step,
-                               shuffle_base=self.shuffle_base, tail_partition=tp if P > 1 else -1)
+                               shuffle_base=self.shuffle_base, tail_partition=tp if P > 1 else -1,
+                               os_threads=self.num_sampler_per_worker)
 
     _fill_error = None
 
     def _fill_guarded(self, pools):
+        import time
         self._fill_error = None
+        t0 = time.time()
         try:
             self._fill(pools)
         except BaseException as e:  # surfaced on the training thread
             self._fill_error = e
+        if getattr(self, "_loop_timing", None) is not None:
+            self._loop_timing["fill"] += time.time() - t0
 
     # ---- device-side positive sampling (edge mode) ---------------------------------------------------------
     def _upload_block_tables(self, state):
@@ -636,38 +651,49 @@ class GraphSolver(object):
 
     # ---- one episode ----------------------------------------------------------------------------------------
     def _train_episode(self, state, pools):
+        """One episode from host pools: block g's pool is copied into device buffer g & 1 on the copy stream while
+        block g - 1 trains; a buffer is overwritten only after the kernels that read it (two blocks earlier) are
+        done.  The counter g runs across episodes, so the first upload of an episode overlaps the last block of
+        the previous one.  Returns the upload events (the host pools may be refilled once they have fired)."""
         W, r = self.num_worker, self.rank
         cuda = self.device.type == "cuda"
         steps = [(int(s[r][0]), int(s[r][1])) for s in self._schedule]
-        # prefetch step 0's pool; afterwards step i + 1 is uploaded while step i trains
-        events = [None, None]
+        uploaded = state.setdefault("uploaded", [None, None])   # per device buffer: its H2D copy has landed
+        released = state.setdefault("released", [None, None])   # per device buffer: its last reader has finished
+        base = state.get("global_step", 0)
         issued = []
 
         def upload(i):
-            buf = state["pool_dev"][i & 1]
+            b = (base + i) & 1
+            buf = state["pool_dev"][b]
             if cuda:
                 with torch.cuda.stream(state["copy_stream"]):
+                    if released[b] is not None:
+                        state["copy_stream"].wait_event(released[b])
                     buf.copy_(pools[steps[i]], non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record()
-                events[i & 1] = ev
+                uploaded[b] = ev
                 issued.append(ev)
             else:
                 buf.copy_(pools[steps[i]])
 
-        if cuda:  # the previous episode's kernels may still be reading the buffers
-            state["copy_stream"].wait_stream(torch.cuda.current_stream(self.device))
         upload(0)
         for i, (hp, tp) in enumerate(steps):
+            b = (base + i) & 1
+            compute = torch.cuda.current_stream(self.device) if cuda else None
             if cuda:
-                torch.cuda.current_stream(self.device).wait_event(events[i & 1])
+                compute.wait_event(uploaded[b])
             if i + 1 < len(steps):
-                if cuda:
-                    state["copy_stream"].wait_stream(torch.cuda.current_stream(self.device))
                 upload(i + 1)
-            self._train_block(state, hp, tp, state["pool_dev"][i & 1])
+            self._train_block(state, hp, tp, state["pool_dev"][b])
+            if cuda:
+                ev = torch.cuda.Event()
+                ev.record(compute)
+                released[b] = ev
             if W > 1:
                 self._exchange(state, i)
+        state["global_step"] = base + len(steps)
         return issued
 
     def _tables(self, state, hp, tp):

@@ -115,6 +115,13 @@ typedef struct {
                                EDGE mode then draws from an alias table over just the edges whose tail lives in
                                partition r (the exact conditional distribution, nothing dropped); the walk modes
                                draw as usual and drop pairs that end elsewhere. */
+    int os_threads;         /* OS threads that execute the num_thread slices (0 = one per slice, capped at the
+                               hardware concurrency).  Fewer OS threads than slices balances stragglers; the
+                               result depends on num_thread only. */
+    int cpu_offset;         /* >= 0: pin OS thread k of the pool to the (cpu_offset + k)-th CPU this process may run on
+                               (modulo their number); -1: leave placement to the scheduler.  A fill lasts a few
+                               milliseconds — shorter than the scheduler takes to spread hundreds of freshly woken
+                               threads over the cores — so unpinned fills are bimodal (10x slower when they stack up). */
 } gvs_fill_config;
 
 /* pools[hp * P + tp] -> pool_size {tail, head} records (entries of unfilled blocks may be NULL).

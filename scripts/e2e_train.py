@@ -35,3 +35,5 @@ for label, kw, train_kw in (("cpu-samplers", {}, {}), ("cpu-samplers reuse=4", {
           "%d batches %.2f + write-back %.2f (%d sampler threads)" % (
               label, tm["batches"] * 100000 / tm["episodes"] / 1e6, el, tm["configure"], tm["upload"], tm["batches"],
               tm["episodes"], tm["write_back"], solver.num_sampler_per_worker), flush=True)
+    if tm.get("loop"):
+        print("      host loop: " + ", ".join("%s %.2f s" % kv for kv in tm["loop"].items()), flush=True)
