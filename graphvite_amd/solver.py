@@ -622,8 +622,10 @@ class GraphSolver(object):
                 "local": self._to_device(self._local.view(np.int32)),
                 "biased": self._mode in ("biased_walk", "biased_reject"), "p": self.p, "q": self.q}
         if walk["biased"]:
-            order = np.lexsort((edges[:, 1], edges[:, 0]))  # ascending neighbour ids inside each vertex's segment
-            walk["sorted_neighbors"] = self._to_device(np.ascontiguousarray(edges[order, 1]).view(np.int32))
+            # ascending neighbour ids inside each vertex's CSR segment: one device sort of (u << 32 | v) keys
+            uv = walk["edges_uv"].view(-1, 2).to(torch.int64) & 0xFFFFFFFF
+            keys = (uv[:, 0] << 32) | uv[:, 1]
+            walk["sorted_neighbors"] = (torch.sort(keys).values & 0xFFFFFFFF).to(torch.int32).contiguous()
         state["walk_graph"] = walk
         state["positive_index"] = 0
 

@@ -160,3 +160,41 @@ def test_moment_optimizer_end_to_end():
     s.build(g, optimizer=gv.optimizer.Adam(1e-3, 0, 0.9, 0.999), batch_size=5000, episode_size=10)
     s.train("LINE", num_epoch=20, augmentation_step=1, log_frequency=1 << 30)
     assert np.isfinite(s.vertex_embeddings).all() and np.abs(s.context_embeddings).max() > 0
+
+
+def test_exchange_runs_on_rccl():
+    """The collective of the multi-GPU path on the real backend ("nccl" is RCCL on ROCm).  A 1-GPU box cannot form a
+    multi-rank RCCL group (one device per rank), so this is a single-rank group: it checks that the exact calls the
+    solver makes — all_gather into views of the partition-major table — are accepted by RCCL and leave the table
+    as it was; rank interplay is covered by the 2-process gloo tests."""
+    import os
+    import socket
+    import torch.distributed as dist
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        gv.init_logging(logging.ERROR)
+        g = gv.graph.Graph()
+        g.load(synthetic.community_edges(5000, 50000, num_community=10, seed=1))
+        s = gv.solver.GraphSolver(128, num_sampler_per_worker=2)
+        assert s.num_worker == 1 and s.rank == 0
+        s.build(g, optimizer=gv.optimizer.Adam(1e-3), batch_size=5000, episode_size=4)
+        session = s.session(model="LINE", num_epoch=2, augmentation_step=1)
+        before = {k: session.state[k].clone() for k in ("vertex", "vertex_m0", "vertex_m1")}
+        s._exchange(session.state, 0)
+        torch.cuda.synchronize()
+        for k, v in before.items():
+            assert torch.equal(session.state[k], v)
+        out = [torch.empty_like(session.state["context"])]
+        dist.all_gather(out, session.state["context"])
+        assert torch.equal(out[0], session.state["context"])
+        t = torch.tensor([1.5], dtype=torch.float64, device="cuda:0")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        session.finish()
+    finally:
+        dist.destroy_process_group()
