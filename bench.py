@@ -124,8 +124,10 @@ def main():
     gv.init_logging(logging.ERROR)
 
     N, E, B, k, dim = args.vertices, args.edges, args.batch, args.negatives, args.dim
+    # two head groups per GPU (P = 2 * #GPU) let the all-gather of one group overlap the training on the other
+    partitions = world if world == 1 else 2 * world
     if not args.block_batches:
-        auto = max(int(float(N) * 175 / world / B), 1)
+        auto = max(int(float(N) * 175 / partitions / B), 1)
         if world == 1:
             auto = max(auto, int(2e7) // B)
         args.block_batches = min(auto, 250)
@@ -140,7 +142,7 @@ def main():
         solver.kernels.set_lanes_per_pair(args.lanes)
     if args.variant:
         solver.kernels.set_variant(args.variant)
-    solver.build(graph, optimizer=gv.optimizer.SGD(0.025, 0.005, "linear"), num_partition=world, num_negative=k,
+    solver.build(graph, optimizer=gv.optimizer.SGD(0.025, 0.005, "linear"), num_partition=partitions, num_negative=k,
                  batch_size=B, episode_size=args.block_batches)
     total_batches = (args.warmup + args.steps) * world
     epochs = total_batches * B // graph.num_edge + 1
@@ -180,6 +182,7 @@ def main():
         while done < num_batches:
             hp, tp = blocks[step % len(blocks)]
             n = min(args.block_batches, num_batches - done)
+            session.wait_exchange(hp)  # fence first, so that the events below bracket kernels only
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -199,9 +202,11 @@ def main():
 
     run(args.warmup, False)
     session.exchange(0)  # the first collective creates the RCCL communicator and its buffers: keep it out of the timing
+    session.wait_exchange()
     fence()
     t0 = time.perf_counter()
     run(args.steps, True)
+    session.wait_exchange()
     fence()
     wall = time.perf_counter() - t0
     if world > 1:
@@ -231,8 +236,8 @@ def main():
         "config": {"workload": "LINE (augmentation_step 1) on synthetic power-law %d nodes / %d edges, dim %d, "
                                "batch %d edge-samples per GPU per step, num_negative %d, SGD lr 0.025 wd 0.005 linear, "
                                "negatives drawn in-kernel, block pools resident in HBM" % (N, E, dim, B, k),
-                   "parallelism": "%d GPU(s), %d vertex partition(s), context shard pinned per GPU, all-gather of "
-                                  "head shards every %d batches" % (world, world, args.block_batches),
+                   "parallelism": "%d GPU(s), %d vertex partition(s), context shards pinned per GPU, asynchronous "
+                                  "all-gather of head shards every %d batches" % (world, partitions, args.block_batches),
                    "lanes_per_pair": lanes},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "traffic": traffic,

@@ -91,8 +91,15 @@ class TrainingSession(object):
             solver.episode_size = saved
 
     def exchange(self, step_index):
+        """Start the (asynchronous) all-gather of the head shards trained at this schedule step."""
         if self.solver.num_worker > 1:
             self.solver._exchange(self.state, step_index % len(self.blocks))
+
+    def wait_exchange(self, hp=None):
+        """Fence the compute stream behind the pending all-gather of head partition hp's group (all groups if None);
+        train_block() does this itself — call it first only to keep the wait out of a timed region."""
+        if self.solver.num_worker > 1:
+            self.solver._wait_exchange(self.state, None if hp is None else hp // self.solver.num_worker)
 
     @property
     def loss(self):
@@ -248,7 +255,7 @@ class GraphSolver(object):
         self._row_of_vertex = self._part.astype(np.int64) * S + self._local.astype(np.int64)
         self._vertex_of_row = np.zeros(P * S, np.int64)  # padding slots point at vertex 0 and are never trained
         self._vertex_of_row[self._row_of_vertex] = np.arange(self.num_vertex, dtype=np.int64)
-        self._schedule = hostlib.schedule(P, W)
+        self._schedule = self._overlap_order(hostlib.schedule(P, W), P, W)
         self._my_tails = sorted({int(step[self.rank][1]) for step in self._schedule})
 
         if episode_size == auto:  # solver.h:426-436
@@ -267,6 +274,19 @@ class GraphSolver(object):
         self._moments_host = None
         self._sampler = None  # the CPU sampler (edge alias table over all edges) is built at the first train()
         self._sampler_mode = None
+
+    @staticmethod
+    def _overlap_order(schedule, P, W):
+        """The reference walks the block groups x-major (solver.h:562-574): all steps that use head partitions
+        x .. x + W - 1 come back to back, and each needs the exchange of the one before.  An episode may visit its P^2
+        blocks in any order, so with P = m * W (m > 1) the steps are interleaved across the m head groups: the
+        all-gather of group x's shards then runs on the collective stream while the next m - 1 steps train on the
+        other groups.  With P == W there is a single group and the order is the reference's."""
+        m = P // W if P > 1 else 1
+        if m <= 1:
+            return schedule
+        order = [(xi * m + yi) * W + o for yi in range(m) for o in range(W) for xi in range(m)]
+        return schedule[order]
 
     def _memory_demand(self, P):
         """Bytes of HBM this design keeps resident per GPU with P partitions."""
@@ -710,6 +730,8 @@ class GraphSolver(object):
 
     def _train_block(self, state, hp, tp, pool):
         """WorkerMixin::train (solver.h:1511-1522): positive_reuse x episode_size batches of one block."""
+        if self.num_worker > 1:
+            self._wait_exchange(state, hp // self.num_worker)  # this block reads head group hp // W
         vertex, context, moments = self._tables(state, hp, tp)
         table = state["negative_tables"][tp]
         spec = self.optimizer.spec()
@@ -743,15 +765,28 @@ class GraphSolver(object):
         self.batch_id += self.episode_size * self.positive_reuse * W
 
     def _exchange(self, state, step_index):
-        """After a schedule step every worker has trained a different head partition: all-gather those shards so
-        that each GPU again holds the whole, current vertex table (RCCL over xGMI; gloo in the CPU tests)."""
+        """After a schedule step every worker has trained a different head partition of one head group: all-gather
+        those shards so that each GPU again holds the whole, current vertex table (RCCL over xGMI; gloo in the CPU
+        tests).  The collective is asynchronous; `_wait_exchange` fences the next block that reads that group."""
         import torch.distributed as dist
         heads = [int(a[0]) for a in self._schedule[step_index]]
+        group = min(heads) // self.num_worker
+        self._wait_exchange(state, group)
         names = ["vertex"] + ["vertex_m%d" % j for j in range(self.num_moment)]
+        works = []
         for name in names:
             table = state[name]
             outputs = [table[hp] for hp in heads]
-            dist.all_gather(outputs, table[heads[self.rank]].clone())
+            works.append(dist.all_gather(outputs, table[heads[self.rank]].clone(), async_op=True))
+        state.setdefault("pending_exchange", {})[group] = works
+
+    def _wait_exchange(self, state, group=None):
+        pending = state.get("pending_exchange")
+        if not pending:
+            return
+        for g in ([group] if group is not None else list(pending)):
+            for work in pending.pop(g, []):
+                work.wait()
 
     def _write_back(self, state):
         """Device -> the stable host arrays behind the numpy views (WorkerMixin::write_back, solver.h:1498-1504).
@@ -760,6 +795,7 @@ class GraphSolver(object):
             return
         import torch.distributed as dist
         W, P, S = self.num_worker, self.num_partition, self._part_size
+        self._wait_exchange(state)
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
 

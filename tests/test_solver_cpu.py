@@ -198,6 +198,22 @@ def test_node2vec_switches_to_rejection_past_the_table_limit():
     assert s._mode == "biased_reject" and np.abs(s.context_embeddings).max() > 0
 
 
+def test_schedule_interleaves_head_groups_for_overlap():
+    from graphvite_amd import hostlib
+    for P, W in ((4, 2), (8, 4), (16, 8), (12, 4)):
+        ref = hostlib.schedule(P, W)
+        new = gv.solver.GraphSolver._overlap_order(ref, P, W)
+        assert sorted(map(tuple, new.reshape(-1, 2).tolist())) == sorted(map(tuple, ref.reshape(-1, 2).tolist()))
+        assert len({tuple(b) for b in new.reshape(-1, 2).tolist()}) == P * P       # every block once per episode
+        for step in new:
+            assert len(set(step[:, 0])) == W and len(set(step[:, 1])) == W           # orthogonal within a step
+            assert len({h // W for h in step[:, 0]}) == 1                             # one head group per step
+        groups = [int(step[0, 0]) // W for step in new]
+        assert all(a != b for a, b in zip(groups, groups[1:]))  # consecutive steps never touch the same head group
+    same = hostlib.schedule(4, 4)
+    assert (gv.solver.GraphSolver._overlap_order(same, 4, 4) == same).all()
+
+
 def test_training_session_steps_equal_train():
     """solver.session(): the public step-by-step form of train() produces the same tables as train() itself."""
     g = make_graph(250, 2500, seed=3)
