@@ -317,6 +317,60 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_kernel(const TrainArgs a)
     if constexpr (NM >= 2) store_row<DIM, G>(a.vm2, head, lane, reinterpret_cast<float(&)[V]>(vm2));
 }
 
+// ---- A/B baseline: the reference's kernel SHAPE on wave64 ---------------------------------------------------------
+// One wavefront per pair in a grid-stride loop, the vertex row staged in LDS, context rows read-modify-written in
+// global memory one element pair per lane, shuffle-down reduction + broadcast — i.e. include/instance/gpu/graph.cuh:
+// 36-95 with kWarpSize = 64 and the draw fused.  It exists only so that bench.py --variant 3 can measure what a
+// warp-shaped translation reaches on this chip next to the shipped layout; nothing else launches it.
+template <int DIM>
+__global__ void __launch_bounds__(512) train_kernel_reference_shape(const TrainArgs a) {
+    __shared__ float buffer[512 / 64][DIM];
+    const int lane = threadIdx.x % 64, wave = threadIdx.x / 64;
+    const int waves = gridDim.x * (512 / 64);
+    float *vertex_buffer = buffer[wave];
+    const int k = a.k;
+    for (int s = blockIdx.x * (512 / 64) + wave; s < a.batch_size; s += waves) {
+        const uint32_t tail = a.pairs[2 * s], head = a.pairs[2 * s + 1];
+        float *vertex = a.vertex + (size_t)head * DIM;
+        for (int i = lane; i < DIM; i += 64) vertex_buffer[i] = vertex[i];
+        float sample_loss = 0;
+        for (int j = 0; j <= k; j++) {
+            uint32_t id = tail;
+            if (j < k) {
+                if (a.negatives) {
+                    id = a.negatives[(size_t)s * k + j];
+                } else {
+                    const Draw d = negative_slot(a.seed, a.batch_id, (uint32_t)s, (uint32_t)j, a.count);
+                    id = resolve(d, a.table[d.index]);
+                }
+            }
+            float *context = a.context + (size_t)id * DIM;
+            float x = 0;
+            for (int i = lane; i < DIM; i += 64) x += vertex_buffer[i] * context[i];
+            for (int delta = 1; delta < 64; delta *= 2) x += __shfl_down(x, delta);
+            const float logit = __shfl(x, 0);
+            const float prob = sigmoidf(logit);
+            float gradient, weight;
+            if (j == k) {
+                gradient = prob - 1;
+                weight = 1;
+                sample_loss += weight * -logf(prob + kEpsilon);
+            } else {
+                gradient = prob;
+                weight = a.neg_weight;
+                sample_loss += weight * -logf(1 - prob + kEpsilon);
+            }
+            for (int i = lane; i < DIM; i += 64) {
+                const float v = vertex_buffer[i], c = context[i];
+                vertex_buffer[i] -= a.lr * weight * (gradient * c + a.wd * v);
+                context[i] -= a.lr * weight * (gradient * v + a.wd * c);
+            }
+        }
+        if (lane == 0) a.loss[s] = sample_loss / (1 + k * a.neg_weight);
+        for (int i = lane; i < DIM; i += 64) vertex[i] = vertex_buffer[i];
+    }
+}
+
 // ---- predict / alias kernels ------------------------------------------------------------------------------
 
 template <int DIM, int G>
@@ -554,6 +608,15 @@ int launch_train(hipStream_t stream, int dim, const gvk_optimizer *o, float lr, 
         }
 #undef GVK_K1
     }
+    if (g_variant == 3 && dim == 128 && o->type == GVK_SGD) {  // the reference's launch shape, graph.cuh:487-490
+        TrainArgs r;
+        memset(&r, 0, sizeof(r));
+        r.vertex = t->vertex; r.context = t->context; r.pairs = pairs; r.negatives = neg->negatives;
+        r.table = neg->table; r.loss = loss; r.seed = neg->seed; r.count = neg->count; r.batch_id = batch_id;
+        r.batch_size = batch_size; r.k = k; r.lr = lr; r.wd = o->weight_decay; r.neg_weight = negative_weight;
+        hipLaunchKernelGGL(train_kernel_reference_shape<128>, dim3(8192), dim3(512), 0, stream, r);
+        return check_launch("gvk_train (reference-shape variant)");
+    }
     if (!kernel) return fail(GVK_EINVAL, "gvk_train: no kernel for this (dim, lanes, optimizer)");
     TrainArgs a;
     a.vertex = t->vertex; a.context = t->context;
@@ -694,7 +757,7 @@ int gvk_set_tuning(int key, int value) {
         return GVK_OK;
     }
     if (key == GVK_TUNE_VARIANT) {
-        if (value < 0 || value > 1) return fail(GVK_EINVAL, "gvk_set_tuning: variant must be 0 or 1");
+        if (value < 0 || value > 3 || value == 2) return fail(GVK_EINVAL, "gvk_set_tuning: variant must be 0, 1 or 3");
         g_variant = value;
         return GVK_OK;
     }

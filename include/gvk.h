@@ -173,7 +173,9 @@ int gvk_alias_build(const float *weights, size_t n, float *prob, void *alias, in
 /* Tuning knobs for A/B measurement (bench.py --variant); they never change results beyond
  * floating-point summation order.  Returns GVK_EINVAL for an unknown key or unsupported value. */
 #define GVK_TUNE_LANES_PER_PAIR 1 /* 0 = per-dim default; else 8, 16, 32 or 64 */
-#define GVK_TUNE_VARIANT 2        /* 0 = default (k = 1 SGD uses the compile-time-k build), 1 = always the generic build */
+#define GVK_TUNE_VARIANT 2        /* 0 = default (k = 1 SGD uses the compile-time-k build), 1 = always the generic build,
+                                     3 = dim-128 SGD in the reference's kernel shape (one wavefront per pair, vertex row
+                                     in LDS, 8192 x 512 grid-stride launch) — A/B baseline only */
 int gvk_set_tuning(int key, int value);
 
 const char *gvk_last_error(void);

@@ -108,6 +108,26 @@ def test_lane_group_variants_agree(hip, oracle, lanes):
     np.testing.assert_allclose(hloss, oloss, rtol=RTOL, atol=1e-6)
 
 
+def test_reference_shape_variant_is_also_correct(hip, oracle):
+    """The A/B baseline kernel (the reference's launch shape on wave64) computes the same thing."""
+    rng = np.random.default_rng(41)
+    N, B, k, dim = 4096, 1500, 1, 128
+    v, c = init_tables(rng, N, N, dim)
+    v *= 20
+    c *= 20
+    pairs, negs = conflict_free_batch(rng, N, N, B, k)
+    ov, oc = v.copy(), c.copy()
+    oloss = oracle.train(ov, oc, pairs, negs, 0.025, 0.005, 5.0)
+    hip.set_variant(3)
+    try:
+        hv, hc, hloss, _ = run_hip(hip, v, c, pairs, negs, OPTS["SGD"][1], 5.0)
+    finally:
+        hip.set_variant(0)
+    np.testing.assert_allclose(hv, ov, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(hc, oc, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(hloss, oloss, rtol=RTOL, atol=1e-6)
+
+
 def test_pair_sees_its_own_negative_update(hip, oracle):
     """negative == positive tail (and repeated negatives): the pair must read its own updated row, as the
     reference's sequential warp does (include/instance/gpu/graph.cuh:62-88)."""
