@@ -107,6 +107,7 @@ struct gvs_graph {
         decltype(name2id)().swap(name2id);
         decltype(id2name)().swap(id2name);
         decltype(label2id)().swap(label2id);
+        decltype(dense_label2id)().swap(dense_label2id);
         decltype(labels)().swap(labels);
         decltype(src)().swap(src);
         decltype(dst)().swap(dst);
@@ -127,7 +128,23 @@ struct gvs_graph {
         return id;
     }
 
+    // labels below 2^28 are resolved through a flat table (4 B per possible label, grown on demand): integer edge
+    // lists are usually dense, and a hash lookup per endpoint dominates the load time of a billion-edge list
+    static constexpr uint32_t kDenseLabels = 1u << 28, kNoId = 0xffffffffu;
+    std::vector<uint32_t> dense_label2id;
+
     uint32_t id_of_label(uint32_t label) {
+        if (label < kDenseLabels) {
+            if (label >= dense_label2id.size())
+                dense_label2id.resize(std::max<size_t>((size_t)label + 1, dense_label2id.size() * 2), kNoId);
+            uint32_t &slot = dense_label2id[label];
+            if (slot == kNoId) {
+                slot = num_vertex++;
+                labels.push_back(label);
+                vertex_weights.push_back(0);
+            }
+            return slot;
+        }
         auto it = label2id.find(label);
         if (it != label2id.end()) return it->second;
         uint32_t id = num_vertex++;
@@ -339,6 +356,10 @@ int64_t gvs_graph_name2id(const gvs_graph *g, const char *name) {
         char *end = nullptr;
         unsigned long long label = strtoull(name, &end, 10);
         if (end == name || *end || label > UINT32_MAX) return -1;
+        if (label < gvs_graph::kDenseLabels) {
+            if (label >= g->dense_label2id.size() || g->dense_label2id[label] == gvs_graph::kNoId) return -1;
+            return (int64_t)g->dense_label2id[label];
+        }
         auto it = g->label2id.find((uint32_t)label);
         return it == g->label2id.end() ? -1 : (int64_t)it->second;
     }

@@ -123,6 +123,23 @@ def test_quick_start_shaped_run_learns():
     np.testing.assert_allclose(logits, want, rtol=1e-5, atol=1e-7)
 
 
+def test_several_partitions_on_one_gpu():
+    """num_partition > #GPU: the episode walks P^2 blocks, pools are uploaded block by block through the two device
+    buffers, partitions never leave HBM; both sampling paths."""
+    edges = synthetic.community_edges(20000, 400000, num_community=100, seed=3)
+    train, (valid, test) = synthetic.link_prediction_split(edges, (100, 3, 3))
+    gv.init_logging(logging.ERROR)
+    for device_sampling in (False, True):
+        g = gv.graph.Graph()
+        g.load(train)
+        s = gv.solver.GraphSolver(128, num_sampler_per_worker=4, seed=17, device_sampling=device_sampling)
+        s.build(g, num_partition=3, batch_size=10000, episode_size=5)
+        s.train(model="LINE", num_epoch=200, augmentation_step=1, log_frequency=1 << 30)
+        auc = auc_of(g, s, test)
+        print("3 partitions on one GPU (device_sampling=%s) AUC %.6f" % (device_sampling, auc))
+        assert auc > 0.9 and s.batch_id % (9 * 5) == 0
+
+
 def test_dim_96_end_to_end():
     """The Friendster configuration's dimension (config/graph/line_friendster.yaml: dim 96) through the whole path."""
     edges = synthetic.community_edges(20000, 400000, num_community=100, seed=5)
