@@ -373,6 +373,12 @@ class GraphSolver(object):
             finally:
                 report()
             return
+        if self.num_worker > 1 and self._mode != "edge":
+            try:
+                self._train_routed(state)
+            finally:
+                report()
+            return
         pools = self._host_pools()
         uploads = [[], []]  # per pool set: events of the async H2D copies still reading its pinned buffers
         try:
@@ -592,6 +598,108 @@ class GraphSolver(object):
         t0 = time.time()
         try:
             self._fill(pools)
+        except BaseException as e:  # surfaced on the training thread
+            self._fill_error = e
+        if getattr(self, "_loop_timing", None) is not None:
+            self._loop_timing["fill"] += time.time() - t0
+
+    # ---- several GPUs, random-walk models: every rank samples a slice of EVERY block, pairs are routed ------------
+    def _train_routed(self, state):
+        """A walk yields pairs for all P^2 blocks, so with W ranks each rank's samplers fill the 1/W-th slice of every
+        block pool (no pair is thrown away for belonging to another GPU, unlike a per-column filter), the slices are
+        uploaded and one all-to-all hands every block's W slices to the GPU that trains it.  Pipeline per episode:
+        CPU fill (e + 1) || copy stream + RCCL: H2D, all_to_all, un-interleave (e) || compute stream: train (e - 1)."""
+        import time
+        import torch.distributed as dist
+        W, r, P, B = self.num_worker, self.rank, self.num_partition, self.batch_size
+        n = self.episode_size * B
+        if n % W:
+            raise ValueError("episode_size * batch_size (%d) must be a multiple of the number of GPUs (%d) for the "
+                             "random-walk models" % (n, W))
+        n_slice = n // W
+        if self.augmentation_step > 1 and n_slice % self.shuffle_base:
+            raise ValueError("Can't perform pseudo shuffle on %d elements by a shuffle base of %d" %
+                             (n_slice, self.shuffle_base))
+        cuda = self.device.type == "cuda"
+        tails_of = [sorted({int(step[w][1]) for step in self._schedule}) for w in range(W)]
+        bpr = P * len(tails_of[0])                      # blocks each rank trains
+        order = [[(hp, tp) for tp in tails_of[w] for hp in range(P)] for w in range(W)]  # canonical per-owner order
+        mine = {block: i for i, block in enumerate(order[r])}
+        elems = n_slice * 2
+        host = [torch.empty((W, bpr, elems), dtype=torch.int32, pin_memory=cuda) for _ in range(2)]
+        send = [torch.empty((W, bpr, elems), dtype=torch.int32, device=self.device) for _ in range(2)]
+        recv = torch.empty((W, bpr, elems), dtype=torch.int32, device=self.device)
+        pools = [torch.empty((bpr, W, elems), dtype=torch.int32, device=self.device) for _ in range(2)]
+        views = [{order[w][i]: host[s][w, i] for w in range(W) for i in range(bpr)} for s in range(2)]
+        route_stream = torch.cuda.Stream(self.device) if cuda else None
+        copied, routed, trained = [None, None], [None, None], [None, None]
+
+        def fill(s):
+            self._sampler.fill(views[s], n_slice, self._mode, 4 * self.num_sampler_per_worker,
+                               sample_batch_size=self.sample_batch_size, walk_length=self.random_walk_length,
+                               walk_batch=self.random_walk_batch_size, augmentation_step=self.augmentation_step,
+                               shuffle_base=self.shuffle_base, tail_partition=-1,
+                               os_threads=self.num_sampler_per_worker)
+
+        def route(s):
+            """host[s] -> send[s] -> (all_to_all) recv -> pools[s], on the side stream."""
+            if not cuda:
+                send[s].copy_(host[s])
+                dist.all_to_all_single(recv.view(-1), send[s].view(-1))
+                pools[s].copy_(recv.permute(1, 0, 2))
+                return
+            with torch.cuda.stream(route_stream):
+                if trained[s] is not None:
+                    route_stream.wait_event(trained[s])  # pools[s] was last read by the episode two back
+                send[s].copy_(host[s], non_blocking=True)
+                copied[s] = torch.cuda.Event()
+                copied[s].record()
+                dist.all_to_all_single(recv.view(-1), send[s].view(-1))
+                pools[s].copy_(recv.permute(1, 0, 2))
+                routed[s] = torch.cuda.Event()
+                routed[s].record()
+
+        def train(s):
+            compute = torch.cuda.current_stream(self.device) if cuda else None
+            if cuda:
+                compute.wait_event(routed[s])
+            for i, step in enumerate(self._schedule):
+                hp, tp = int(step[r][0]), int(step[r][1])
+                self._train_block(state, hp, tp, pools[s][mine[(hp, tp)]].view(-1))
+                self._exchange(state, i)
+            if cuda:
+                trained[s] = torch.cuda.Event()
+                trained[s].record(compute)
+
+        self._loop_timing = {"wait_upload": 0.0, "enqueue": 0.0, "wait_fill": 0.0, "fill": 0.0}
+        fill(0)
+        current = 0
+        while self.batch_id < self.num_batch:
+            route(current)
+            ta = time.time()
+            if cuda and copied[current ^ 1] is not None:
+                copied[current ^ 1].synchronize()  # the other host set may be refilled once its H2D has landed
+            tb = time.time()
+            filler = threading.Thread(target=self._fill_guarded_call, args=(fill, current ^ 1))
+            filler.start()
+            try:
+                train(current)
+            finally:
+                tc = time.time()
+                filler.join()
+            self._loop_timing["wait_upload"] += tb - ta
+            self._loop_timing["enqueue"] += tc - tb
+            self._loop_timing["wait_fill"] += time.time() - tc
+            if self._fill_error is not None:
+                raise self._fill_error
+            current ^= 1
+
+    def _fill_guarded_call(self, fn, arg):
+        import time
+        self._fill_error = None
+        t0 = time.time()
+        try:
+            fn(arg)
         except BaseException as e:  # surfaced on the training thread
             self._fill_error = e
         if getattr(self, "_loop_timing", None) is not None:
