@@ -367,6 +367,23 @@ def _worker(rank, world, port, out_dir, model, aug, num_partition=0):
         s = gv.solver.GraphSolver(32, kernels=k, num_sampler_per_worker=2, seed=9)
         s.build(g, batch_size=400, episode_size=3, num_partition=num_partition)
         assert s.num_worker == world and s.num_partition == (num_partition or world)
+        # every pair a worker trains on must be a real (walk) pair of the graph that lives in the block being trained
+        E = g.edges
+        nbrs = [set() for _ in range(g.num_vertex)]
+        for u, v in E.tolist():
+            nbrs[u].add(v)
+        inv = {(int(p), int(l)): v for v, (p, l) in enumerate(zip(s._part, s._local))}
+        original = s._train_block
+
+        def checked(state, hp, tp, pool):
+            rec = pool.numpy().view(np.uint32).reshape(-1, 2)[:s.episode_size * s.batch_size:37]
+            for t_local, h_local in rec.tolist():
+                h, t = inv[(hp, h_local)], inv[(tp, t_local)]        # KeyError = a pair routed to the wrong block
+                reach = nbrs[h] if aug == 1 else nbrs[h] | set().union(*[nbrs[x] for x in nbrs[h]])
+                assert t in reach, "pair (%d, %d) is not within %d steps" % (h, t, aug)
+            return original(state, hp, tp, pool)
+
+        s._train_block = checked
         s.train(model, num_epoch=4, augmentation_step=aug, random_walk_length=6, random_walk_batch_size=4,
                 p=0.25, q=0.25, log_frequency=100000)
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), v=s.vertex_embeddings, c=s.context_embeddings,
