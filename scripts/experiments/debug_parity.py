@@ -6,7 +6,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")  # run from the repo root
 import graphvite_amd as gv
 from fake_kernels import OracleKernels
 from graphvite_amd import synthetic

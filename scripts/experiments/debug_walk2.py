@@ -5,7 +5,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")  # run from the repo root
 import graphvite_amd as gv
 from fake_kernels import OracleKernels
 from graphvite_amd import synthetic
