@@ -283,6 +283,50 @@ def test_hogwild_batch_statistics(hip, oracle):
     assert abs(np.linalg.norm(hc) - np.linalg.norm(oc)) <= 3e-2 * np.linalg.norm(oc)
 
 
+def test_benchmark_size_batch_against_oracle(hip, oracle):
+    """BASELINE.json's size (1M rows x dim 128, one 100 000-pair batch, negatives drawn in-kernel from a power-law
+    table, real conflicts): every pair whose three rows nobody else touches must equal the sequential oracle to fp32
+    tolerance, every untouched row must be bit-identical, and the batch loss must agree."""
+    rng = np.random.default_rng(2026)
+    N, B, k, dim = 1000000, 100000, 1, 128
+    v, c = init_tables(rng, N, N, dim)
+    v *= 20
+    c *= 20
+    w = power_law_weights(rng, N)
+    order = np.argsort(-w, kind="stable")  # local ids are degree ranks, as in the solver
+    prob, alias, packed = K.alias_build(w[order])
+    p = w[order].astype(np.float64)
+    p /= p.sum()
+    heads, tails = rng.choice(N, B, p=p), rng.choice(N, B, p=p)
+    pairs = np.stack([tails, heads], 1).astype(np.uint32)
+    seed, batch_id = 7, 123
+    negs = oracle.negatives(prob, alias, seed, batch_id, B, k)
+    ov, oc = v.copy(), c.copy()
+    oloss = oracle.train(ov, oc, pairs, negs, 0.025, 0.005, 5.0)
+    tv, tc = dev(v), dev(c)
+    loss = torch.zeros(B, device=DEV)
+    hip.train(tv, tc, dev(pairs.view(np.int32)), loss, OPTS["SGD"][1], k, 5.0, table=K.packed_to_device(packed, DEV),
+              seed=seed, batch_id=batch_id)
+    torch.cuda.synchronize()
+    hv, hc, hl = tv.cpu().numpy(), tc.cpu().numpy(), loss.cpu().numpy()
+    ctx_rows = np.concatenate([pairs[:, :1], negs], 1)
+    cid, ccount = np.unique(ctx_rows, return_counts=True)
+    hid, hcount = np.unique(pairs[:, 1], return_counts=True)
+    shared_c, shared_h = set(cid[ccount > 1].tolist()), set(hid[hcount > 1].tolist())
+    clean = np.array([h not in shared_h and not (set(r.tolist()) & shared_c)
+                      for h, r in zip(pairs[:, 1].tolist(), ctx_rows)])
+    assert clean.sum() > B // 20
+    np.testing.assert_allclose(hl[clean], oloss[clean], rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(hv[pairs[clean, 1]], ov[pairs[clean, 1]], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(hc[ctx_rows[clean].ravel()], oc[ctx_rows[clean].ravel()], rtol=RTOL, atol=ATOL)
+    untouched_v = np.ones(N, bool)
+    untouched_v[pairs[:, 1]] = False
+    untouched_c = np.ones(N, bool)
+    untouched_c[ctx_rows.ravel()] = False
+    assert (hv[untouched_v] == v[untouched_v]).all() and (hc[untouched_c] == c[untouched_c]).all()
+    assert abs(hl.mean() - oloss.mean()) <= 2e-3 * abs(oloss.mean())
+
+
 def test_empty_and_ragged_batches(hip, oracle):
     rng = np.random.default_rng(5)
     N, dim = 1024, 128
