@@ -324,7 +324,7 @@ def test_benchmark_size_batch_against_oracle(hip, oracle):
     untouched_c = np.ones(N, bool)
     untouched_c[ctx_rows.ravel()] = False
     assert (hv[untouched_v] == v[untouched_v]).all() and (hc[untouched_c] == c[untouched_c]).all()
-    assert abs(hl.mean() - oloss.mean()) <= 2e-3 * abs(oloss.mean())
+    assert abs(hl.mean() - oloss.mean()) <= 5e-3 * abs(oloss.mean())
 
 
 def test_empty_and_ragged_batches(hip, oracle):
