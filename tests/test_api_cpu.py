@@ -1,0 +1,77 @@
+"""The module-level surface the reference binds in libgraphvite (src/graphvite.cu:62-105, include/bind.h:757-999):
+optimizer helper classes and their defaults, learning-rate schedules, dtype names, size helpers."""
+import numpy as np
+import pytest
+
+import graphvite_amd as gv
+from graphvite_amd.base import cpu_budget
+
+
+def test_module_constants_and_helpers():
+    assert gv.auto == 0 and gv.KiB(2) == 2048 and gv.MiB(1) == 1 << 20 and gv.GiB(3) == 3 << 30
+    assert gv.dtype2name == {gv.uint32: "j", gv.uint64: "m", gv.float32: "f", gv.float64: "d"}  # bind.h:53-76
+    assert gv.io.yes_no(True) == "yes" and gv.io.yes_no(0) == "no"
+    assert gv.io.size_string(1536) == "1.5 KiB" and gv.io.size_string(3 << 30) == "3 GiB"
+    assert "Training" in gv.io.header("Training") and gv.io.block("x").count("\n") == 3
+    assert cpu_budget() >= 1
+
+
+def test_optimizer_helper_defaults_match_the_reference():
+    # include/core/optimizer.h:272-319
+    o = gv.optimizer.SGD()
+    assert (o.type, o.num_moment, o.init_lr, o.weight_decay, o.schedule.type) == ("SGD", 0, 1e-4, 0, "linear")
+    o = gv.optimizer.Momentum()
+    assert (o.type, o.num_moment, o.momentum) == ("Momentum", 1, 0.999)
+    o = gv.optimizer.AdaGrad()
+    assert (o.num_moment, o.epsilon) == (1, 1e-10)
+    o = gv.optimizer.RMSprop()
+    assert (o.num_moment, o.alpha, o.epsilon) == (1, 0.999, 1e-8)
+    o = gv.optimizer.Adam()
+    assert (o.num_moment, o.beta1, o.beta2, o.epsilon) == (2, 0.999, 0.99999, 1e-8)
+    spec = gv.optimizer.Adam(1e-3, 0.01, 0.9, 0.99, 1e-6, "constant").spec()
+    assert (spec.type, spec.lr, spec.weight_decay, spec.hp0, spec.hp1, spec.epsilon, spec.schedule) == \
+        ("Adam", 1e-3, 0.01, 0.9, 0.99, 1e-6, "constant")
+    assert gv.optimizer.RMSprop(alpha=0.9).spec().hp0 == 0.9 and gv.optimizer.Momentum(momentum=0.5).spec().hp0 == 0.5
+
+
+def test_optimizer_factory_and_implicit_conversions():
+    # python/graphvite/optimizer.py:30-46 and the float / auto conversions of bind.h:793-794
+    assert isinstance(gv.optimizer.Optimizer("Adam", lr=0.1), gv.optimizer.Adam)
+    assert gv.optimizer.Optimizer("SGD", 0.5).init_lr == 0.5
+    d = gv.optimizer.Optimizer()
+    assert d.type == "Default" and d.init_lr == 0
+    assert gv.optimizer.Optimizer(0.05).init_lr == pytest.approx(0.05)
+    same = gv.optimizer.SGD(0.1)
+    assert gv.optimizer.Optimizer(same) is same
+    with pytest.raises(ValueError):
+        gv.optimizer.Optimizer("Adagrad")  # the reference spells it AdaGrad
+    with pytest.raises(ValueError):
+        gv.optimizer.Optimizer(3)
+    assert "learning rate: 0.1" in repr(same) and "weight decay" in repr(same)
+
+
+def test_lr_schedules():
+    s = gv.optimizer.LRSchedule("linear")
+    assert s(0, 100) == 1 and s(50, 100) == 0.5 and s(100, 100) == pytest.approx(1e-4) and s(1000, 100) == 1e-4
+    assert gv.optimizer.LRSchedule("constant")(7, 9) == 1 and gv.optimizer.LRSchedule()(1, 2) == 1
+    custom = gv.optimizer.LRSchedule(lambda b, n: 1 - (b / n) ** 2)
+    assert custom.type == "custom" and custom(5, 10) == 0.75
+    with pytest.raises(ValueError):
+        gv.optimizer.LRSchedule("cosine")
+    o = gv.optimizer.SGD(0.2, 0, custom)
+    o.apply_schedule(5, 10)
+    assert o.lr == pytest.approx(0.15) and o.init_lr == 0.2
+
+
+def test_kernel_wrappers_refuse_cpu_tensors():
+    """No CPU fallback anywhere: handing host tensors to the kernel wrappers is an error, not a slow path."""
+    import torch
+    from graphvite_amd.kernels import HipKernels, OptimizerSpec
+    hip = HipKernels()
+    v = torch.zeros((4, 128))
+    with pytest.raises(ValueError, match="GPU memory"):
+        hip.train(v, v.clone(), torch.zeros((1, 2), dtype=torch.int32), torch.zeros(1), OptimizerSpec(), 0, 5.0)
+    with pytest.raises(ValueError):
+        hip.predict(v, v, torch.zeros((1, 2), dtype=torch.int32), torch.zeros(1))
+    with pytest.raises(ValueError):
+        OptimizerSpec("Nadam")
