@@ -152,7 +152,8 @@ def main():
         solver.kernels.set_variant(args.variant)
     solver.build(graph, optimizer=gv.optimizer.SGD(0.025, 0.005, "linear"), num_partition=partitions, num_negative=k,
                  batch_size=B, episode_size=args.block_batches)
-    total_batches = (args.warmup + args.steps) * world
+    residency = 2 * (partitions * partitions // world)  # two batches of every block before the warm-up steps
+    total_batches = (residency + args.warmup + args.steps) * world
     epochs = total_batches * B // graph.num_edge + 1
     session = solver.session(model="LINE", num_epoch=epochs, augmentation_step=1, log_frequency=1 << 30)
     solver.num_batch = total_batches  # the lr schedule spans exactly the batches this run trains
