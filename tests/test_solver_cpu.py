@@ -412,10 +412,12 @@ def test_two_process_training_over_gloo(tmp_path, model, aug):
         np.testing.assert_allclose(r[i]["lrs"], want, rtol=1e-6)
 
 
-def test_more_partitions_than_workers_over_gloo(tmp_path):
-    """P = 4 partitions on 2 workers (solver.h:562-574 with x, y groups): each worker owns two context shards."""
+@pytest.mark.parametrize("model,aug", [("LINE", 1), ("DeepWalk", 2)])
+def test_more_partitions_than_workers_over_gloo(tmp_path, model, aug):
+    """P = 4 partitions on 2 workers (solver.h:562-574 with x, y groups): each worker owns two context shards; the
+    steps interleave the two head groups and the exchange is asynchronous; walk models route their pairs."""
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), "LINE", 1, 4), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), model, aug, 4), nprocs=world, join=True)
     r = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % i)) for i in range(world)]
     assert (r[0]["v"] == r[1]["v"]).all() and (r[0]["c"] == r[1]["c"]).all()
     assert r[0]["tails"].tolist() == [0, 2] and r[1]["tails"].tolist() == [1, 3]
