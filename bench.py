@@ -62,6 +62,8 @@ def parse():
     p.add_argument("--partitions", type=int, default=0,
                    help="experiment: vertex partitions (default: 1 on one GPU, 2 x #GPU otherwise); on one GPU this shows "
                         "the kernel at the shard size of a multi-GPU run")
+    p.add_argument("--optimizer", choices=["SGD", "Momentum", "AdaGrad", "RMSprop", "Adam"], default="SGD",
+                   help="experiment: moment optimizers move (1 + m) x the row bytes (m = 1, Adam 2)")
     p.add_argument("--graph", choices=["power-law", "community"], default="power-law",
                    help="experiment: 'community' swaps in a hub-free planted-partition graph of the same size")
     p.add_argument("--sampler-threads", type=int, default=0, help="0 = host cores / GPUs")
@@ -150,7 +152,9 @@ def main():
         solver.kernels.set_lanes_per_pair(args.lanes)
     if args.variant:
         solver.kernels.set_variant(args.variant)
-    solver.build(graph, optimizer=gv.optimizer.SGD(0.025, 0.005, "linear"), num_partition=partitions, num_negative=k,
+    optimizer = gv.optimizer.SGD(0.025, 0.005, "linear") if args.optimizer == "SGD" else \
+        gv.optimizer.Optimizer(args.optimizer, 1e-3, 0.005)
+    solver.build(graph, optimizer=optimizer, num_partition=partitions, num_negative=k,
                  batch_size=B, episode_size=args.block_batches)
     residency = 2 * (partitions * partitions // world)  # two batches of every block before the warm-up steps
     total_batches = (residency + args.warmup + args.steps) * world
@@ -231,13 +235,14 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b, _ in kernel_events) / sum(n for _, _, n in kernel_events)
     final_loss = float(session.loss.mean().item())
 
-    bytes_per_launch = algorithmic_bytes(dim, k) * B
+    moments = optimizer.num_moment
+    bytes_per_launch = (8 * dim * (k + 2) * (1 + moments) + 16) * B  # moment tables are rows read + written too
     achieved = bytes_per_launch / (kernel_ms * 1e-3)
     # HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM); bench.py cannot read PMCs itself
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "r1", "pmc_summary_bench_n1.json")
-    if world == 1 and dim == 128 and k == 1 and B == 100000 and N == 1000000 and os.path.exists(pmc):
+    if world == 1 and dim == 128 and k == 1 and B == 100000 and N == 1000000 and moments == 0 and os.path.exists(pmc):
         traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
     lanes = args.lanes or {32: 8, 64: 16, 96: 8, 128: 16, 256: 16, 512: 32}[dim]
     result = {
@@ -257,7 +262,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "traffic": traffic,
                      "traffic_source": "profiles/r1/pmc_summary_bench_n1.json" if traffic else None,
-                     "kernel": "train_kernel<%d,%d,SGD>" % (dim, lanes), "kernel_ms": kernel_ms,
+                     "kernel": "train_kernel<%d,%d,%s>" % (dim, lanes, args.optimizer), "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": bytes_per_launch},
         "sampler": {"value": sampled / fill_s / 1e6, "unit": "million edge-samples/sec per GPU", "threads": threads,
                     "note": "CPU edge sampler filling this GPU's block pools before the timed region"},
