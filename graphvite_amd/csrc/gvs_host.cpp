@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <immintrin.h>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -463,37 +464,139 @@ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
 
 constexpr uint32_t kTagHost = 0x686f7374u;
 
-struct HostRng {
-    uint32_t k0, k1, stream;
-    uint64_t pos;  // doubles consumed
-    double cached;
-    bool has_cached;
+// Philox is most of the cost of a draw once the table misses are pipelined (~30 cycles per call scalar, one call per
+// edge sample), and calls are independent by construction: run 8 of them per iteration in 64-bit AVX2 lanes
+// (vpmuludq reads the low halves only, so the high halves may hold garbage until the final mask).  Same words, same
+// doubles as the scalar routine above (tests pin both against the oracle).
+// (((hi << 32) | lo) >> 11) * 2^-53 for 4 lanes, exactly as the scalar conversion (both halves via the 2^52 / 2^84 trick)
+__attribute__((target("avx2"))) inline __m256d words_to_double_avx2(__m256i w_lo, __m256i w_hi) {
+    const __m256i low = _mm256_set1_epi64x(0xffffffffll);
+    const __m256i magic_lo = _mm256_set1_epi64x(0x4330000000000000ll), magic_hi = _mm256_set1_epi64x(0x4530000000000000ll);
+    const __m256d bias = _mm256_set1_pd(19342813118337666422669312.0 /* 2^84 + 2^52 */);
+    const __m256i x = _mm256_srli_epi64(_mm256_or_si256(_mm256_slli_epi64(w_hi, 32), _mm256_and_si256(w_lo, low)), 11);
+    const __m256d lo = _mm256_castsi256_pd(_mm256_or_si256(_mm256_and_si256(x, low), magic_lo));
+    const __m256d hi = _mm256_castsi256_pd(_mm256_or_si256(_mm256_srli_epi64(x, 32), magic_hi));
+    return _mm256_mul_pd(_mm256_add_pd(_mm256_sub_pd(hi, bias), lo), _mm256_set1_pd(1.0 / 9007199254740992.0));
+}
 
-    HostRng(uint64_t seed, uint32_t stream_, uint64_t pos_)
-        : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)), stream(stream_), pos(pos_), cached(0), has_cached(false) {}
-
-    static double to_double(uint32_t hi, uint32_t lo) {
-        return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+__attribute__((target("avx2"))) void philox_doubles_avx2(uint64_t call0, int num_call, uint32_t stream, uint32_t k0,
+                                                         uint32_t k1, double *out) {
+    const __m256i M0 = _mm256_set1_epi64x(0xD2511F53ll), M1 = _mm256_set1_epi64x(0xCD9E8D57ll);
+    __m256i K0[10], K1[10];
+    for (int r = 0; r < 10; r++) {
+        K0[r] = _mm256_set1_epi64x((long long)(uint32_t)(k0 + (uint32_t)r * 0x9E3779B9u));
+        K1[r] = _mm256_set1_epi64x((long long)(uint32_t)(k1 + (uint32_t)r * 0xBB67AE85u));
     }
-
-    inline double next() {
-        if (has_cached) {
-            has_cached = false;
-            pos++;
-            return cached;
+    const __m256i c2_init = _mm256_set1_epi64x((long long)stream), c3_init = _mm256_set1_epi64x((long long)kTagHost);
+    for (int j = 0; j < num_call; j += 8) {
+        const __m256i ia = _mm256_add_epi64(_mm256_set1_epi64x((long long)(call0 + (uint64_t)j)), _mm256_set_epi64x(3, 2, 1, 0));
+        const __m256i ib = _mm256_add_epi64(ia, _mm256_set1_epi64x(4));
+        __m256i a0 = ia, a1 = _mm256_srli_epi64(ia, 32), a2 = c2_init, a3 = c3_init;
+        __m256i b0 = ib, b1 = _mm256_srli_epi64(ib, 32), b2 = c2_init, b3 = c3_init;
+        for (int r = 0; r < 10; r++) {
+            const __m256i pa0 = _mm256_mul_epu32(M0, a0), pa1 = _mm256_mul_epu32(M1, a2);
+            const __m256i pb0 = _mm256_mul_epu32(M0, b0), pb1 = _mm256_mul_epu32(M1, b2);
+            a0 = _mm256_xor_si256(_mm256_xor_si256(_mm256_srli_epi64(pa1, 32), a1), K0[r]);
+            a2 = _mm256_xor_si256(_mm256_xor_si256(_mm256_srli_epi64(pa0, 32), a3), K1[r]);
+            a1 = pa1, a3 = pa0;
+            b0 = _mm256_xor_si256(_mm256_xor_si256(_mm256_srli_epi64(pb1, 32), b1), K0[r]);
+            b2 = _mm256_xor_si256(_mm256_xor_si256(_mm256_srli_epi64(pb0, 32), b3), K1[r]);
+            b1 = pb1, b3 = pb0;
         }
-        const uint64_t i = pos >> 1;
+        const __m256d ad0 = words_to_double_avx2(a0, a1), ad1 = words_to_double_avx2(a2, a3),
+                      bd0 = words_to_double_avx2(b0, b1), bd1 = words_to_double_avx2(b2, b3);
+        const __m256d al = _mm256_unpacklo_pd(ad0, ad1), ah = _mm256_unpackhi_pd(ad0, ad1);
+        const __m256d bl = _mm256_unpacklo_pd(bd0, bd1), bh = _mm256_unpackhi_pd(bd0, bd1);
+        _mm256_storeu_pd(out + 2 * j, _mm256_permute2f128_pd(al, ah, 0x20));
+        _mm256_storeu_pd(out + 2 * j + 4, _mm256_permute2f128_pd(al, ah, 0x31));
+        _mm256_storeu_pd(out + 2 * j + 8, _mm256_permute2f128_pd(bl, bh, 0x20));
+        _mm256_storeu_pd(out + 2 * j + 12, _mm256_permute2f128_pd(bl, bh, 0x31));
+    }
+}
+
+// the same, 16 calls per iteration, where the CPU has AVX-512 (F + DQ for the u64 -> f64 conversion)
+__attribute__((target("avx512f,avx512dq"))) void philox_doubles_avx512(uint64_t call0, int num_call, uint32_t stream,
+                                                                       uint32_t k0, uint32_t k1, double *out) {
+    const __m512i M0 = _mm512_set1_epi64(0xD2511F53ll), M1 = _mm512_set1_epi64(0xCD9E8D57ll);
+    const __m512i low = _mm512_set1_epi64(0xffffffffll);
+    const __m512d scale = _mm512_set1_pd(1.0 / 9007199254740992.0);
+    const __m512i even = _mm512_set_epi64(11, 3, 10, 2, 9, 1, 8, 0), odd = _mm512_set_epi64(15, 7, 14, 6, 13, 5, 12, 4);
+    __m512i K0[10], K1[10];
+    for (int r = 0; r < 10; r++) {
+        K0[r] = _mm512_set1_epi64((long long)(uint32_t)(k0 + (uint32_t)r * 0x9E3779B9u));
+        K1[r] = _mm512_set1_epi64((long long)(uint32_t)(k1 + (uint32_t)r * 0xBB67AE85u));
+    }
+    const __m512i c2_init = _mm512_set1_epi64((long long)stream), c3_init = _mm512_set1_epi64((long long)kTagHost);
+    for (int j = 0; j < num_call; j += 16) {
+        const __m512i ia = _mm512_add_epi64(_mm512_set1_epi64((long long)(call0 + (uint64_t)j)),
+                                            _mm512_set_epi64(7, 6, 5, 4, 3, 2, 1, 0));
+        const __m512i ib = _mm512_add_epi64(ia, _mm512_set1_epi64(8));
+        __m512i a0 = ia, a1 = _mm512_srli_epi64(ia, 32), a2 = c2_init, a3 = c3_init;
+        __m512i b0 = ib, b1 = _mm512_srli_epi64(ib, 32), b2 = c2_init, b3 = c3_init;
+        for (int r = 0; r < 10; r++) {
+            const __m512i pa0 = _mm512_mul_epu32(M0, a0), pa1 = _mm512_mul_epu32(M1, a2);
+            const __m512i pb0 = _mm512_mul_epu32(M0, b0), pb1 = _mm512_mul_epu32(M1, b2);
+            a0 = _mm512_xor_si512(_mm512_xor_si512(_mm512_srli_epi64(pa1, 32), a1), K0[r]);
+            a2 = _mm512_xor_si512(_mm512_xor_si512(_mm512_srli_epi64(pa0, 32), a3), K1[r]);
+            a1 = pa1, a3 = pa0;
+            b0 = _mm512_xor_si512(_mm512_xor_si512(_mm512_srli_epi64(pb1, 32), b1), K0[r]);
+            b2 = _mm512_xor_si512(_mm512_xor_si512(_mm512_srli_epi64(pb0, 32), b3), K1[r]);
+            b1 = pb1, b3 = pb0;
+        }
+#define GVS_TO_DOUBLE(w_lo, w_hi)                                                                                    \
+    _mm512_mul_pd(_mm512_cvtepu64_pd(_mm512_srli_epi64(                                                              \
+                      _mm512_or_si512(_mm512_slli_epi64(w_hi, 32), _mm512_and_si512(w_lo, low)), 11)),               \
+                  scale)
+        const __m512d ad0 = GVS_TO_DOUBLE(a0, a1), ad1 = GVS_TO_DOUBLE(a2, a3);
+        const __m512d bd0 = GVS_TO_DOUBLE(b0, b1), bd1 = GVS_TO_DOUBLE(b2, b3);
+#undef GVS_TO_DOUBLE
+        _mm512_storeu_pd(out + 2 * j, _mm512_permutex2var_pd(ad0, even, ad1));
+        _mm512_storeu_pd(out + 2 * j + 8, _mm512_permutex2var_pd(ad0, odd, ad1));
+        _mm512_storeu_pd(out + 2 * j + 16, _mm512_permutex2var_pd(bd0, even, bd1));
+        _mm512_storeu_pd(out + 2 * j + 24, _mm512_permutex2var_pd(bd0, odd, bd1));
+    }
+}
+
+inline double words_to_double(uint32_t hi, uint32_t lo) {
+    return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+void philox_doubles(uint64_t call0, int num_call, uint32_t stream, uint32_t k0, uint32_t k1, double *out) {
+    static const bool avx2 = __builtin_cpu_supports("avx2") && getenv("GVS_NO_AVX2") == nullptr;
+    static const bool avx512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") &&
+                               getenv("GVS_NO_AVX512") == nullptr;
+    if (avx512 && num_call % 16 == 0) return philox_doubles_avx512(call0, num_call, stream, k0, k1, out);
+    if (avx2 && num_call % 8 == 0) return philox_doubles_avx2(call0, num_call, stream, k0, k1, out);
+    for (int j = 0; j < num_call; j++) {
+        const uint64_t i = call0 + (uint64_t)j;
         uint32_t w[4];
         philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), stream, kTagHost, k0, k1, w);
-        const double d0 = to_double(w[1], w[0]), d1 = to_double(w[3], w[2]);
-        if (pos & 1) {
-            pos++;
-            return d1;
+        out[2 * j] = words_to_double(w[1], w[0]);
+        out[2 * j + 1] = words_to_double(w[3], w[2]);
+    }
+}
+
+// Per-thread stream of doubles: call i of the thread's Philox stream yields doubles 2i and 2i+1.  `pos` (doubles
+// consumed) is the whole state; doubles are produced a block at a time and handed out in order.
+struct HostRng {
+    static constexpr int kBlockCalls = 128;
+    uint32_t k0, k1, stream;
+    uint64_t pos;        // doubles consumed
+    uint64_t block_pos;  // double index of block[0]; pos + 1 = no block yet (the distance below wraps to 2^64 - 1)
+    double block[2 * kBlockCalls];
+
+    HostRng(uint64_t seed, uint32_t stream_, uint64_t pos_)
+        : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)), stream(stream_), pos(pos_), block_pos(pos_ + 1) {}
+
+    inline double next() {
+        uint64_t at = pos - block_pos;
+        if (__builtin_expect(at >= (uint64_t)(2 * kBlockCalls), 0)) {  // also taken for the first draw
+            block_pos = pos & ~(uint64_t)1;
+            philox_doubles(block_pos >> 1, kBlockCalls, stream, k0, k1, block);
+            at = pos - block_pos;
         }
-        cached = d1;
-        has_cached = true;
         pos++;
-        return d0;
+        return block[at];
     }
 };
 

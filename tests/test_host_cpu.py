@@ -76,6 +76,20 @@ def test_host_uniform_stream_bit_exact(oracle):
         assert (hostlib.host_uniforms(seed, stream, first, n) == oracle.host_uniforms(seed, stream, first, n)).all()
 
 
+@pytest.mark.parametrize("env", [{"GVS_NO_AVX512": "1"}, {"GVS_NO_AVX512": "1", "GVS_NO_AVX2": "1"}])
+def test_host_uniform_stream_same_on_every_simd_path(env):
+    """The Philox block generator has AVX-512, AVX2 and scalar forms chosen at run time; all yield the same doubles."""
+    import os
+    import subprocess
+    import sys
+    code = ("import numpy as np, sys; from graphvite_amd import hostlib; "
+            "sys.stdout.buffer.write(hostlib.host_uniforms(2**63 + 5, 77, 12345, 5001).tobytes())")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, check=True,
+                         env=dict(os.environ, **env)).stdout
+    assert np.frombuffer(out, np.float64).tobytes() == hostlib.host_uniforms(2 ** 63 + 5, 77, 12345, 5001).tobytes()
+
+
 @pytest.mark.parametrize("P", [1, 2, 3, 8])
 def test_partition_bit_exact(oracle, P):
     rng = np.random.default_rng(P)
