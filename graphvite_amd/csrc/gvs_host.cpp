@@ -618,8 +618,36 @@ struct alignas(64) FatSlot {
     uint64_t self_head, self_tail, alias_head, alias_tail;
 };
 
+// What a random walk reads when it steps onto a vertex: its packed location (for the pool record) and the range of its
+// out-edges (for the next draw) — one line instead of one miss into location[] and one into flat_offsets[].
+struct alignas(32) WalkVertex {
+    uint64_t location, first;
+    uint64_t degree;
+    uint64_t pad;
+};
+
+// Walks on graphs below the fat-slot limit read the outcome of a draw from the slot itself: the vertices of both
+// outcomes (keep the slot's edge / take its alias) sit next to the probability, so a step touches the slot and the
+// WalkVertex of where it lands — two lines instead of slot, edge list, location and offsets.
+struct alignas(32) WalkStartSlot {  // over the global edge table: a walk starts with a weighted edge (graph.cuh:322-333)
+    float prob;
+    uint32_t self_from, self_to, alias_from, alias_to;
+    uint32_t pad[3];
+};
+struct WalkStepSlot {  // per-vertex tables, CSR-aligned
+    float prob;
+    uint32_t alias;  // kept for completeness: local index of the alias neighbour
+    uint32_t self_to, alias_to;
+};
+
 // tables above this many entries keep the 16-byte slots (64 B x 2^27 = 8 GiB)
 constexpr size_t kFatSlotLimit = (size_t)1 << 27;
+
+// GVS_FAT_SLOT_LIMIT=0 forces the thin tables (tests run both forms against the oracle)
+inline size_t fat_slot_limit() {
+    const char *env = getenv("GVS_FAT_SLOT_LIMIT");
+    return env ? (size_t)strtoull(env, nullptr, 10) : kFatSlotLimit;
+}
 
 }  // namespace
 
@@ -730,8 +758,12 @@ struct gvs_sampler {
     HugeVector<EdgeSlot> edge_slots;  // the same table, one cache line touch per draw
     int prepared = GVS_MODE_EDGE;
     float p = 1, q = 1;
-    HugeVector<float> nb_prob;
-    HugeVector<uint32_t> nb_alias;
+    HugeVector<gvk_alias_entry> nb_slots;  // per-vertex (WALK / REJECT) or per-edge (BIASED) tables, {prob, alias} per slot
+    HugeVector<WalkVertex> walk_vertex;    // what a walk needs when it arrives at a vertex, in one cache line
+    HugeVector<WalkStartSlot> walk_start;  // WALK / REJECT below the fat-slot limit
+    HugeVector<WalkStepSlot> walk_step;
+    std::vector<float> nb_prob;            // split copies of nb_slots for hosts that ask for them (tests, device upload)
+    std::vector<uint32_t> nb_alias;
     HugeVector<uint64_t> ee_offsets;
     HugeVector<uint32_t> sorted_nb;  // BIASED_REJECT: out-neighbours of every vertex, ascending
     std::vector<uint64_t> positions;
@@ -751,7 +783,7 @@ struct gvs_sampler {
     // fat[i] for slot i of a table whose entry j stands for flattened edge ids[j] (ids == nullptr: entry j is edge j)
     void build_fat(const HugeVector<EdgeSlot> &slots, const uint64_t *ids, HugeVector<FatSlot> *fat,
                    int num_thread) const {
-        if (!fat->empty() || slots.size() > kFatSlotLimit) return;
+        if (!fat->empty() || slots.size() > fat_slot_limit()) return;
         const uint32_t *edges = g->edges_uv.data();
         fat->resize(slots.size());
         FatSlot *out = fat->data();
@@ -827,7 +859,8 @@ struct gvs_sampler {
     inline uint32_t sample_neighbor(HostRng &rng, uint64_t base, uint64_t count) const {
         const double r1 = rng.next(), r2 = rng.next();
         const uint64_t index = (uint64_t)(r1 * (double)count);
-        return (float)r2 < nb_prob[base + index] ? (uint32_t)index : nb_alias[base + index];
+        const gvk_alias_entry &slot = nb_slots[base + index];
+        return (float)r2 < slot.prob ? (uint32_t)index : slot.alias;
     }
 };
 
@@ -941,6 +974,8 @@ void fill_edges(FillShared *sh, int thread, int64_t start, int64_t end, uint64_t
     *position = rng.pos;
 }
 
+// FAT: WALK / REJECT with walk_start / walk_step built.  Same draws, same uniforms, same pools as the thin form.
+template <bool FAT>
 void fill_walks(FillShared *sh, int thread, int64_t start, int64_t end, uint64_t *position) {
     const gvs_sampler &s = *sh->s;
     HostRng rng(s.seed, (uint32_t)thread, *position);
@@ -952,15 +987,19 @@ void fill_walks(FillShared *sh, int thread, int64_t start, int64_t end, uint64_t
     const int64_t sb = sh->c.shuffle_base, stride = (int64_t)(sh->pool_size / (uint64_t)sb);
     static thread_local std::vector<uint64_t> chains, index, edge_id, base, proposal;
     static thread_local std::vector<int> lengths, live, pending;
-    static thread_local std::vector<uint32_t> current;
+    static thread_local std::vector<uint32_t> current, previous, next;
     static thread_local std::vector<float> u, accept;
     chains.resize((size_t)nb * (L + 1));
     lengths.resize(nb), live.resize(nb), pending.resize(nb), current.resize(nb), u.resize(nb), accept.resize(nb);
-    index.resize(nb), edge_id.resize(nb), base.resize(nb), proposal.resize(nb);
+    index.resize(nb), edge_id.resize(nb), base.resize(nb), proposal.resize(nb), previous.resize(nb), next.resize(nb);
     const uint32_t *edges = s.g->edges_uv.data();
-    const uint64_t *flat = s.g->flat_offsets.data();
     const EdgeSlot *slots = s.edge_slots.data();
     const double edge_count = (double)s.edge_slots.size();
+    const WalkVertex *wv = s.walk_vertex.data();
+    const gvk_alias_entry *nb_slots = s.nb_slots.data();
+    const WalkStartSlot *walk_start = s.walk_start.data();
+    const WalkStepSlot *walk_step = s.walk_step.data();
+    const uint32_t *sorted_nb = s.sorted_nb.data();
     // The walks of one inner round advance in LOCKSTEP: all start edges, then step 2 of every live walk, step 3, ...
     // (the reference finishes one walk before it starts the next, graph.cuh:322-350,400-425).  Each stage runs over
     // the whole round with the next stage's cache lines prefetched, so a thread overlaps ~walk_batch misses instead
@@ -971,26 +1010,38 @@ void fill_walks(FillShared *sh, int thread, int64_t start, int64_t end, uint64_t
             const double r1 = rng.next(), r2 = rng.next();
             index[i] = (uint64_t)(r1 * edge_count);
             u[i] = (float)r2;
-            __builtin_prefetch(&slots[index[i]]);
+            if (FAT)
+                __builtin_prefetch(&walk_start[index[i]]);
+            else
+                __builtin_prefetch(&slots[index[i]]);
         }
-        for (int i = 0; i < nb; i++) {
-            const EdgeSlot &slot = slots[index[i]];
-            edge_id[i] = u[i] < slot.prob ? index[i] : slot.alias;
-            __builtin_prefetch(&edges[2 * edge_id[i]]);
-        }
-        for (int i = 0; i < nb; i++) {
-            const uint32_t c0 = edges[2 * edge_id[i]];
-            current[i] = edges[2 * edge_id[i] + 1];
-            index[i] = c0;
-            __builtin_prefetch(&s.location[c0]);
-            __builtin_prefetch(&s.location[current[i]]);
-            __builtin_prefetch(&flat[current[i]]);
+        if (FAT) {
+            for (int i = 0; i < nb; i++) {
+                const WalkStartSlot &slot = walk_start[index[i]];
+                const bool self = u[i] < slot.prob;
+                previous[i] = self ? slot.self_from : slot.alias_from;
+                current[i] = self ? slot.self_to : slot.alias_to;
+                __builtin_prefetch(&wv[previous[i]]);
+                __builtin_prefetch(&wv[current[i]]);
+            }
+        } else {
+            for (int i = 0; i < nb; i++) {
+                const EdgeSlot &slot = slots[index[i]];
+                edge_id[i] = u[i] < slot.prob ? index[i] : slot.alias;
+                __builtin_prefetch(&edges[2 * edge_id[i]]);
+            }
+            for (int i = 0; i < nb; i++) {
+                previous[i] = edges[2 * edge_id[i]];
+                current[i] = edges[2 * edge_id[i] + 1];
+                __builtin_prefetch(&wv[previous[i]]);
+                __builtin_prefetch(&wv[current[i]]);
+            }
         }
         int num_live = 0;
         for (int i = 0; i < nb; i++) {
             uint64_t *chain = chains.data() + (size_t)i * (L + 1);
-            chain[0] = s.location[index[i]];
-            chain[1] = s.location[current[i]];
+            chain[0] = wv[previous[i]].location;
+            chain[1] = wv[current[i]].location;
             lengths[i] = L;
             live[num_live++] = i;
         }
@@ -998,7 +1049,7 @@ void fill_walks(FillShared *sh, int thread, int64_t start, int64_t end, uint64_t
             int kept = 0;
             for (int n = 0; n < num_live; n++) {  // walks standing on a node without out-edges stop here
                 const int i = live[n];
-                if (flat[current[i] + 1] == flat[current[i]])
+                if (wv[current[i]].degree == 0)
                     lengths[i] = j - 1;  // graph.cuh:346-349,421-424
                 else
                     live[kept++] = i;
@@ -1010,48 +1061,60 @@ void fill_walks(FillShared *sh, int thread, int64_t start, int64_t end, uint64_t
             while (num_pending) {
                 for (int n = 0; n < num_pending; n++) {
                     const int i = pending[n];
-                    const uint64_t first = flat[current[i]], degree = flat[current[i] + 1] - first;
+                    const WalkVertex &at = wv[current[i]];
                     const double r1 = rng.next(), r2 = rng.next();
                     if (reject) accept[i] = (float)rng.next();
-                    base[i] = biased ? s.ee_offsets[edge_id[i]] : first;
-                    index[i] = (uint64_t)(r1 * (double)degree);
+                    base[i] = biased ? s.ee_offsets[edge_id[i]] : at.first;
+                    index[i] = (uint64_t)(r1 * (double)at.degree);
                     u[i] = (float)r2;
-                    __builtin_prefetch(&s.nb_prob[base[i] + index[i]]);
-                    __builtin_prefetch(&s.nb_alias[base[i] + index[i]]);
+                    if (FAT)
+                        __builtin_prefetch(&walk_step[base[i] + index[i]]);
+                    else
+                        __builtin_prefetch(&nb_slots[base[i] + index[i]]);
                 }
-                for (int n = 0; n < num_pending; n++) {
-                    const int i = pending[n];
-                    const uint64_t slot = base[i] + index[i];
-                    const uint32_t neighbor = u[i] < s.nb_prob[slot] ? (uint32_t)index[i] : s.nb_alias[slot];
-                    proposal[i] = flat[current[i]] + neighbor;
-                    __builtin_prefetch(&edges[2 * proposal[i] + 1]);
+                if (FAT) {
+                    for (int n = 0; n < num_pending; n++) {
+                        const int i = pending[n];
+                        const WalkStepSlot &slot = walk_step[base[i] + index[i]];
+                        next[i] = u[i] < slot.prob ? slot.self_to : slot.alias_to;
+                        __builtin_prefetch(&wv[next[i]]);
+                    }
+                } else {
+                    for (int n = 0; n < num_pending; n++) {
+                        const int i = pending[n];
+                        const gvk_alias_entry &slot = nb_slots[base[i] + index[i]];
+                        const uint32_t neighbor = u[i] < slot.prob ? (uint32_t)index[i] : slot.alias;
+                        proposal[i] = wv[current[i]].first + neighbor;
+                        __builtin_prefetch(&edges[2 * proposal[i] + 1]);
+                    }
+                    for (int n = 0; n < num_pending; n++) {
+                        const int i = pending[n];
+                        next[i] = edges[2 * proposal[i] + 1];
+                        __builtin_prefetch(&wv[next[i]]);
+                    }
                 }
                 if (!reject) break;
                 int rejected = 0;
                 for (int n = 0; n < num_pending; n++) {
                     const int i = pending[n];
-                    const uint32_t x = edges[2 * proposal[i] + 1], prev = edges[2 * edge_id[i]];
+                    const uint32_t x = next[i], prev = previous[i];
                     float f;
-                    if (x == prev)
+                    if (x == prev) {
                         f = 1.0f / s.p;
-                    else if (std::binary_search(s.sorted_nb.begin() + flat[x], s.sorted_nb.begin() + flat[x + 1], prev))
-                        f = 1.0f;
-                    else
-                        f = 1.0f / s.q;
+                    } else {
+                        const uint32_t *first = sorted_nb + wv[x].first;
+                        f = std::binary_search(first, first + wv[x].degree, prev) ? 1.0f : 1.0f / s.q;
+                    }
                     if (!(accept[i] * fmax < f)) pending[rejected++] = i;
                 }
                 num_pending = rejected;
             }
             for (int n = 0; n < num_live; n++) {
                 const int i = live[n];
-                edge_id[i] = proposal[i];
-                current[i] = edges[2 * edge_id[i] + 1];
-                __builtin_prefetch(&s.location[current[i]]);
-                __builtin_prefetch(&flat[current[i]]);
-            }
-            for (int n = 0; n < num_live; n++) {
-                const int i = live[n];
-                chains[(size_t)i * (L + 1) + j] = s.location[current[i]];
+                edge_id[i] = proposal[i];  // only the per-edge tables of BIASED_WALK (never FAT) read it
+                previous[i] = current[i];
+                current[i] = next[i];
+                chains[(size_t)i * (L + 1) + j] = wv[current[i]].location;
             }
         }
         bool wrote = false;
@@ -1082,11 +1145,14 @@ void fill_walks(FillShared *sh, int thread, int64_t start, int64_t end, uint64_t
 // CSR-aligned alias tables: one table per vertex over its out-edge weights (graph.cuh:645-653)
 void build_vertex_tables(gvs_sampler *s, uint32_t begin, uint32_t end, std::atomic<int> *error) {
     const uint64_t *flat = s->g->flat_offsets.data();
+    std::vector<float> prob;
+    std::vector<uint32_t> alias;
     for (uint32_t u = begin; u < end; u++) {
         const uint64_t off = flat[u], deg = flat[u + 1] - off;
         if (!deg) continue;
-        if (gvk_alias_build(s->g->edge_weights.data() + off, deg, s->nb_prob.data() + off, s->nb_alias.data() + off,
-                            4, nullptr) != GVK_OK)
+        prob.resize(deg), alias.resize(deg);
+        if (gvk_alias_build(s->g->edge_weights.data() + off, deg, prob.data(), alias.data(), 4,
+                            s->nb_slots.data() + off) != GVK_OK)
             error->store(1);
     }
 }
@@ -1097,12 +1163,13 @@ void build_edge_tables(gvs_sampler *s, const std::vector<uint32_t> *sorted_nb, u
     const uint32_t *edges = s->g->edges_uv.data();
     const uint64_t *flat = s->g->flat_offsets.data();
     const float *ew = s->g->edge_weights.data();
-    std::vector<float> weights;
+    std::vector<float> weights, prob;
+    std::vector<uint32_t> alias;
     for (uint64_t e = begin; e < end; e++) {
         const uint32_t u = edges[2 * e], v = edges[2 * e + 1];
         const uint64_t off = flat[v], deg = flat[v + 1] - off;
         if (!deg) continue;
-        weights.resize(deg);
+        weights.resize(deg), prob.resize(deg), alias.resize(deg);
         for (uint64_t f = 0; f < deg; f++) {
             const uint32_t x = edges[2 * (off + f) + 1];
             const float w = ew[off + f];
@@ -1114,8 +1181,7 @@ void build_edge_tables(gvs_sampler *s, const std::vector<uint32_t> *sorted_nb, u
             }
         }
         const uint64_t base = s->ee_offsets[e];
-        if (gvk_alias_build(weights.data(), deg, s->nb_prob.data() + base, s->nb_alias.data() + base, 4, nullptr) !=
-            GVK_OK)
+        if (gvk_alias_build(weights.data(), deg, prob.data(), alias.data(), 4, s->nb_slots.data() + base) != GVK_OK)
             error->store(1);
     }
 }
@@ -1181,6 +1247,10 @@ int gvs_sampler_prepare(gvs_sampler *s, int mode, float p, float q, int num_thre
         const uint64_t D = g->edge_weights.size();
         const uint64_t *flat = g->flat_offsets.data();
         std::atomic<int> error{0};
+        decltype(s->nb_slots)().swap(s->nb_slots);
+        decltype(s->walk_vertex)().swap(s->walk_vertex);
+        decltype(s->walk_start)().swap(s->walk_start);
+        decltype(s->walk_step)().swap(s->walk_step);
         decltype(s->nb_prob)().swap(s->nb_prob);
         decltype(s->nb_alias)().swap(s->nb_alias);
         decltype(s->ee_offsets)().swap(s->ee_offsets);
@@ -1194,6 +1264,11 @@ int gvs_sampler_prepare(gvs_sampler *s, int mode, float p, float q, int num_thre
         if (mode != GVS_MODE_EDGE) {
             const int rc = s->ensure_edge_table();  // walks start from a weighted edge draw
             if (rc != GVK_OK) return rc;
+            s->walk_vertex.resize(g->num_vertex);
+            parallel_ranges(g->num_vertex, num_thread, [&](uint64_t b, uint64_t e) {
+                for (uint64_t v = b; v < e; v++)
+                    s->walk_vertex[v] = WalkVertex{s->location[v], flat[v], flat[v + 1] - flat[v], 0};
+            });
         }
         if (mode == GVS_MODE_BIASED_REJECT) {
             if (!(p > 0) || !(q > 0)) return gvk_fail(GVK_EINVAL, "gvs_sampler_prepare: p and q must be positive");
@@ -1207,8 +1282,7 @@ int gvs_sampler_prepare(gvs_sampler *s, int mode, float p, float q, int num_thre
             });
         }
         if (mode == GVS_MODE_WALK || mode == GVS_MODE_BIASED_REJECT) {
-            s->nb_prob.resize(D);
-            s->nb_alias.resize(D);
+            s->nb_slots.resize(D);
             parallel_ranges(g->num_vertex, num_thread, [&](uint64_t b, uint64_t e) {
                 build_vertex_tables(s, (uint32_t)b, (uint32_t)e, &error);
             });
@@ -1223,8 +1297,7 @@ int gvs_sampler_prepare(gvs_sampler *s, int mode, float p, float q, int num_thre
                 s->ee_offsets[e + 1] = s->ee_offsets[e] + (flat[v + 1] - flat[v]);
             }
             const uint64_t total = s->ee_offsets[D];
-            s->nb_prob.resize(total);  // sum over edges of deg(head): the reference's node2vec memory hog
-            s->nb_alias.resize(total);
+            s->nb_slots.resize(total);  // sum over edges of deg(head): the reference's node2vec memory hog
             std::vector<uint32_t> sorted_nb(D);
             for (uint64_t e = 0; e < D; e++) sorted_nb[e] = g->edges_uv[2 * e + 1];
             parallel_ranges(g->num_vertex, num_thread, [&](uint64_t b, uint64_t e) {
@@ -1234,6 +1307,26 @@ int gvs_sampler_prepare(gvs_sampler *s, int mode, float p, float q, int num_thre
                             [&](uint64_t b, uint64_t e) { build_edge_tables(s, &sorted_nb, b, e, &error); });
         }
         if (error.load()) return gvk_fail(GVK_EINVAL, "gvs_sampler_prepare: alias table construction failed");
+        if ((mode == GVS_MODE_WALK || mode == GVS_MODE_BIASED_REJECT) && D <= fat_slot_limit()) {
+            const uint32_t *edges = g->edges_uv.data();
+            s->walk_start.resize(D);
+            s->walk_step.resize(D);
+            parallel_ranges(D, num_thread, [&](uint64_t b, uint64_t e) {
+                for (uint64_t i = b; i < e; i++) {
+                    const uint64_t other = s->edge_slots[i].alias;
+                    s->walk_start[i] = WalkStartSlot{s->edge_slots[i].prob, edges[2 * i], edges[2 * i + 1],
+                                                     edges[2 * other], edges[2 * other + 1], {0, 0, 0}};
+                }
+            });
+            parallel_ranges(g->num_vertex, num_thread, [&](uint64_t b, uint64_t e) {
+                for (uint64_t v = b; v < e; v++)
+                    for (uint64_t i = flat[v]; i < flat[v + 1]; i++) {
+                        const gvk_alias_entry &slot = s->nb_slots[i];
+                        s->walk_step[i] = WalkStepSlot{slot.prob, slot.alias, edges[2 * i + 1],
+                                                       edges[2 * (flat[v] + slot.alias) + 1]};
+                    }
+            });
+        }
         s->prepared = mode;
         return GVK_OK;
     });
@@ -1301,7 +1394,10 @@ int gvs_sampler_fill(gvs_sampler *s, uint32_t *const *pools, uint64_t pool_size,
             if (c->mode == GVS_MODE_EDGE)
                 fill_edges(&sh, t, b, e, position);
             else
-                fill_walks(&sh, t, b, e, position);
+                if (s->walk_step.empty())
+                    fill_walks<false>(&sh, t, b, e, position);
+                else
+                    fill_walks<true>(&sh, t, b, e, position);
             if (timing) slice_ms[t] = now() - t0;
         };
         const double t0 = timing ? now() : 0;
@@ -1348,8 +1444,26 @@ const uint64_t *gvs_sampler_edge_alias(const gvs_sampler *s) {
     m->materialize_split_table();
     return m->edge_alias.data();
 }
-const float *gvs_sampler_neighbor_prob(const gvs_sampler *s) { return s ? s->nb_prob.data() : nullptr; }
-const uint32_t *gvs_sampler_neighbor_alias(const gvs_sampler *s) { return s ? s->nb_alias.data() : nullptr; }
+static void materialize_split_neighbor_tables(gvs_sampler *m) {
+    if (m->nb_prob.size() == m->nb_slots.size()) return;
+    m->nb_prob.resize(m->nb_slots.size());
+    m->nb_alias.resize(m->nb_slots.size());
+    for (size_t i = 0; i < m->nb_slots.size(); i++) {
+        m->nb_prob[i] = m->nb_slots[i].prob;
+        m->nb_alias[i] = m->nb_slots[i].alias;
+    }
+}
+const float *gvs_sampler_neighbor_prob(const gvs_sampler *s) {
+    if (!s) return nullptr;
+    materialize_split_neighbor_tables(const_cast<gvs_sampler *>(s));
+    return s->nb_prob.data();
+}
+const uint32_t *gvs_sampler_neighbor_alias(const gvs_sampler *s) {
+    if (!s) return nullptr;
+    materialize_split_neighbor_tables(const_cast<gvs_sampler *>(s));
+    return s->nb_alias.data();
+}
+const gvk_alias_entry *gvs_sampler_neighbor_slots(const gvs_sampler *s) { return s ? s->nb_slots.data() : nullptr; }
 const uint64_t *gvs_sampler_edge_edge_offsets(const gvs_sampler *s) { return s ? s->ee_offsets.data() : nullptr; }
 
 int gvs_sampler_column(const gvs_sampler *s, int tail_partition, uint64_t *count, const uint64_t **edge_ids,

@@ -135,6 +135,8 @@ const float *gvs_sampler_edge_prob(const gvs_sampler *s);
 const uint64_t *gvs_sampler_edge_alias(const gvs_sampler *s);
 const float *gvs_sampler_neighbor_prob(const gvs_sampler *s);      /* WALK: [D]; BIASED: [sum deg^2] */
 const uint32_t *gvs_sampler_neighbor_alias(const gvs_sampler *s);
+/* the same tables in the interleaved {prob, alias} form the samplers (and gvk_sample_walks) read; no copy */
+const gvk_alias_entry *gvs_sampler_neighbor_slots(const gvs_sampler *s);
 const uint64_t *gvs_sampler_edge_edge_offsets(const gvs_sampler *s); /* BIASED: [D + 1] */
 
 /* EDGE-mode column table of tail partition r (built by the first filtered fill): the flattened edge ids it

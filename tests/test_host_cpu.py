@@ -399,3 +399,16 @@ def test_sampler_argument_errors():
         s.fill({(0, 0): np.zeros(10, np.uint32)}, 1000, "edge", 1)
     with pytest.raises(ValueError):
         hostlib.Sampler(g, part[:-1], local[:-1], 1, seed=0)
+
+
+def test_samplers_bit_exact_with_thin_tables():
+    """Below 2^27 table entries the samplers read 'fat' slots (draw outcome inline); above, the plain tables.  The
+    sampler tests above ran the fat form; run them again with the thin form forced."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", __file__, "-k",
+                          "edge_sampler_bit_exact or walk_samplers_bit_exact or node2vec_rejection or column_mode"],
+                         cwd=root, capture_output=True, text=True, env=dict(os.environ, GVS_FAT_SLOT_LIMIT="0"))
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
