@@ -108,6 +108,8 @@ def lib():
     l.gvs_graph_load_labels.argtypes = [vp, vp, vp, vp, sz, i32, i32]
     l.gvs_graph_save.restype = i32
     l.gvs_graph_save.argtypes = [vp, cp, i32, i32]
+    l.gvs_graph_neighbor_tables.restype = i32
+    l.gvs_graph_neighbor_tables.argtypes = [vp, i32, vp]
     l.gvs_graph_num_vertex.restype = u32
     l.gvs_graph_num_vertex.argtypes = [vp]
     l.gvs_graph_num_edge.restype = u64

@@ -1143,16 +1143,15 @@ void fill_walks(FillShared *sh, int thread, int64_t start, int64_t end, uint64_t
 }
 
 // CSR-aligned alias tables: one table per vertex over its out-edge weights (graph.cuh:645-653)
-void build_vertex_tables(gvs_sampler *s, uint32_t begin, uint32_t end, std::atomic<int> *error) {
-    const uint64_t *flat = s->g->flat_offsets.data();
+void build_vertex_tables(const gvs_graph *g, gvk_alias_entry *out, uint32_t begin, uint32_t end, std::atomic<int> *error) {
+    const uint64_t *flat = g->flat_offsets.data();
     std::vector<float> prob;
     std::vector<uint32_t> alias;
     for (uint32_t u = begin; u < end; u++) {
         const uint64_t off = flat[u], deg = flat[u + 1] - off;
         if (!deg) continue;
         prob.resize(deg), alias.resize(deg);
-        if (gvk_alias_build(s->g->edge_weights.data() + off, deg, prob.data(), alias.data(), 4,
-                            s->nb_slots.data() + off) != GVK_OK)
+        if (gvk_alias_build(g->edge_weights.data() + off, deg, prob.data(), alias.data(), 4, out + off) != GVK_OK)
             error->store(1);
     }
 }
@@ -1238,6 +1237,16 @@ gvs_sampler *gvs_sampler_create(const gvs_graph *g, const int32_t *part, const u
 
 void gvs_sampler_destroy(gvs_sampler *s) { delete s; }
 
+int gvs_graph_neighbor_tables(const gvs_graph *g, int num_thread, gvk_alias_entry *out) {
+    if (!g || !out) return gvk_fail(GVK_EINVAL, "gvs_graph_neighbor_tables: null argument");
+    return guarded("gvs_graph_neighbor_tables", [&]() {
+        std::atomic<int> error{0};
+        parallel_ranges(g->num_vertex, num_thread,
+                        [&](uint64_t b, uint64_t e) { build_vertex_tables(g, out, (uint32_t)b, (uint32_t)e, &error); });
+        return error.load() ? gvk_fail(GVK_EINVAL, "gvs_graph_neighbor_tables: alias table construction failed") : GVK_OK;
+    });
+}
+
 int gvs_sampler_prepare(gvs_sampler *s, int mode, float p, float q, int num_thread) {
     if (!s) return gvk_fail(GVK_EINVAL, "gvs_sampler_prepare: null sampler");
     if (mode != GVS_MODE_EDGE && mode != GVS_MODE_WALK && mode != GVS_MODE_BIASED_WALK && mode != GVS_MODE_BIASED_REJECT)
@@ -1284,7 +1293,7 @@ int gvs_sampler_prepare(gvs_sampler *s, int mode, float p, float q, int num_thre
         if (mode == GVS_MODE_WALK || mode == GVS_MODE_BIASED_REJECT) {
             s->nb_slots.resize(D);
             parallel_ranges(g->num_vertex, num_thread, [&](uint64_t b, uint64_t e) {
-                build_vertex_tables(s, (uint32_t)b, (uint32_t)e, &error);
+                build_vertex_tables(g, s->nb_slots.data(), (uint32_t)b, (uint32_t)e, &error);
             });
         } else if (mode == GVS_MODE_BIASED_WALK) {
             if (!(p > 0) || !(q > 0)) return gvk_fail(GVK_EINVAL, "gvs_sampler_prepare: p and q must be positive");

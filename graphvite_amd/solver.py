@@ -24,7 +24,7 @@ import threading
 import numpy as np
 import torch
 
-from . import hostlib
+from . import _lib, hostlib
 from .base import auto, cpu_budget, dtype, io, logger
 from .graph import Graph
 from .optimizer import SGD, Optimizer
@@ -734,15 +734,8 @@ class GraphSolver(object):
         _, _, edge_packed = alias_build(weights)
         entry = np.dtype([("prob", np.float32), ("alias", np.uint32)])
         nb = np.zeros(D, entry)
-        degree = np.diff(flat.astype(np.int64))
-        if (weights == weights[0]).all():  # unweighted: every neighbour table is uniform (prob 1, alias self)
-            nb["prob"] = 1
-            nb["alias"] = (np.arange(D, dtype=np.int64) - np.repeat(flat[:-1].astype(np.int64), degree)).astype(np.uint32)
-        else:
-            for u in np.nonzero(degree)[0]:
-                b, e = int(flat[u]), int(flat[u + 1])
-                _, _, packed = alias_build(weights[b:e])
-                nb[b:e] = packed
+        _lib.check(_lib.lib().gvs_graph_neighbor_tables(g._handle, self.num_sampler_per_worker + 1, nb.ctypes.data),
+                   "gvs_graph_neighbor_tables")
         walk = {"flat_offsets": self._to_device(flat.astype(np.int64)),
                 "edges_uv": self._to_device(edges.astype(np.uint32).view(np.int32).reshape(-1)),
                 "edge_table": packed_to_device(edge_packed, self.device),

@@ -70,6 +70,10 @@ const float *gvs_graph_edge_weights(const gvs_graph *g);
 const uint64_t *gvs_graph_flat_offsets(const gvs_graph *g);
 const float *gvs_graph_vertex_weights(const gvs_graph *g);
 
+/* CSR-aligned alias tables, one per vertex over the weights of its out-edges (the reference's build_vertex_edge,
+ * include/instance/graph.cuh:645-653), in the interleaved form gvk_sample_walks reads: out[num_directed_edge]. */
+int gvs_graph_neighbor_tables(const gvs_graph *g, int num_thread, gvk_alias_entry *out);
+
 /* ---- partition / schedule ------------------------------------------------------------------------------ */
 
 /* Sort vertices by weight descending (ties: ascending id — the reference leaves ties to std::sort), deal them

@@ -412,3 +412,23 @@ def test_samplers_bit_exact_with_thin_tables():
                           "edge_sampler_bit_exact or walk_samplers_bit_exact or node2vec_rejection or column_mode"],
                          cwd=root, capture_output=True, text=True, env=dict(os.environ, GVS_FAT_SLOT_LIMIT="0"))
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+
+
+def test_graph_neighbor_tables_match_the_sampler_tables(oracle):
+    """gvs_graph_neighbor_tables (what the device walk sampler uploads) = the walk sampler's per-vertex tables."""
+    from graphvite_amd import _lib
+    g = small_graph(seed=7, as_undirected=False)
+    D = g.num_directed_edge
+    packed = np.zeros(D, np.dtype([("prob", np.float32), ("alias", np.uint32)]))
+    _lib.check(_lib.lib().gvs_graph_neighbor_tables(g._handle, 3, packed.ctypes.data), "gvs_graph_neighbor_tables")
+    part, local, _ = hostlib.partition(g.vertex_weights, 1)
+    s = hostlib.Sampler(g, part, local, 1, seed=1)
+    s.prepare("walk", num_thread=2)
+    prob, alias = s.neighbor_tables(D)
+    assert (packed["prob"] == prob).all() and (packed["alias"] == alias).all()
+    fo = g.flat_offsets
+    for u in range(0, g.num_vertex, 17):
+        if fo[u + 1] > fo[u]:
+            oprob, oalias = oracle.alias_build(g.edge_weights[fo[u]:fo[u + 1]], 4)
+            assert (oprob == prob[fo[u]:fo[u + 1]]).all() and (oalias == alias[fo[u]:fo[u + 1]]).all()
+    assert _lib.lib().gvs_graph_neighbor_tables(g._handle, 1, None) != 0
