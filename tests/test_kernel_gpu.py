@@ -361,3 +361,38 @@ def test_errors_are_returned_not_aborted(hip):
     with pytest.raises(ValueError):  # Adam without moment tables
         hip.train(v, v.clone(), torch.zeros((1, 2), dtype=torch.int32, device=DEV), torch.zeros(1, device=DEV),
                   OPTS["Adam"][1], 0, 5.0)
+
+
+def test_rows_beyond_4_gib(hip, oracle):
+    """Friendster-sized shards: row ids whose byte offsets need more than 32 bits (9.4M rows x 128 x 4 B = 4.8 GB per
+    table).  The device tables hold the full row range; the oracle gets the touched rows compacted."""
+    dim, N, B, k = 128, 9_400_000, 512, 2
+    rng = np.random.default_rng(77)
+    lo = (1 << 32) // (dim * 4)  # first row whose offset does not fit in 32 bits
+    heads = (lo + rng.permutation(N - lo)[:B]).astype(np.uint32)
+    ctx = (lo + rng.permutation(N - lo)[:B * (k + 1)]).astype(np.uint32)
+    pairs = np.stack([ctx[:B], heads], 1).astype(np.uint32)
+    negs = np.ascontiguousarray(ctx[B:].reshape(B, k))
+    tv = torch.zeros((N, dim), dtype=torch.float32, device=DEV)
+    tc = torch.zeros((N, dim), dtype=torch.float32, device=DEV)
+    v_rows, c_rows = init_tables(rng, B, B * (k + 1), dim)
+    v_rows *= 20
+    c_rows *= 20
+    tv[torch.from_numpy(heads.astype(np.int64)).to(DEV)] = dev(v_rows)
+    tc[torch.from_numpy(ctx.astype(np.int64)).to(DEV)] = dev(c_rows)
+    # compact ids for the oracle: head i -> i, context row ctx[j] -> j
+    opairs = np.stack([np.arange(B), np.arange(B)], 1).astype(np.uint32)
+    onegs = np.ascontiguousarray(np.arange(B, B * (k + 1)).reshape(B, k).astype(np.uint32))
+    ov, oc = v_rows.copy(), c_rows.copy()
+    oloss = oracle.train(ov, oc, opairs, onegs, 0.025, 0.005, 5.0)
+    loss = torch.zeros(B, dtype=torch.float32, device=DEV)
+    hip.train(tv, tc, dev(pairs.view(np.int32)), loss, OPTS["SGD"][1], k, 5.0, negatives=dev(negs.view(np.int32)))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(tv[torch.from_numpy(heads.astype(np.int64)).to(DEV)].cpu().numpy(), ov, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(tc[torch.from_numpy(ctx.astype(np.int64)).to(DEV)].cpu().numpy(), oc, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(loss.cpu().numpy(), oloss, rtol=RTOL, atol=1e-6)
+    logits = torch.zeros(B, device=DEV)
+    hip.predict(tv, tc, dev(pairs.view(np.int32)), logits)
+    np.testing.assert_allclose(logits.cpu().numpy(), oracle.predict(ov, oc, opairs), rtol=1e-5, atol=1e-8)
+    # nothing below the 4 GiB line moved
+    assert float(tv[:lo].abs().max()) == 0.0 and float(tc[:lo].abs().max()) == 0.0
