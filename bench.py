@@ -62,6 +62,11 @@ def parse():
     p.add_argument("--partitions", type=int, default=0,
                    help="experiment: vertex partitions (default: 1 on one GPU, 2 x #GPU otherwise); on one GPU this shows "
                         "the kernel at the shard size of a multi-GPU run")
+    p.add_argument("--xcd-sorted", action="store_true",
+                   help="experiment: with --xcd-bucket, also sort each bucket by row (same-row pairs adjacent in time)")
+    p.add_argument("--pair-order", choices=["auto", "sampled", "grouped"], default="auto",
+                   help="GraphSolver(pair_order=...): auto (the product default) regroups the pairs of a batch by head "
+                        "row on the device when a partition's table exceeds 32 MiB")
     p.add_argument("--optimizer", choices=["SGD", "Momentum", "AdaGrad", "RMSprop", "Adam"], default="SGD",
                    help="experiment: moment optimizers move (1 + m) x the row bytes (m = 1, Adam 2)")
     p.add_argument("--graph", choices=["power-law", "community"], default="power-law",
@@ -147,7 +152,9 @@ def main():
         graph.load(synthetic.community_edges(N, E, num_community=max(N // 1000, 1), seed=args.seed))
     else:
         graph.load(synthetic.power_law_edges(N, E, seed=args.seed))
-    solver = gv.solver.GraphSolver(dim, num_sampler_per_worker=threads, seed=args.seed)
+    if args.xcd_bucket or args.xcd_sorted:
+        args.pair_order = "sampled"  # the placement experiments lay the batches out themselves
+    solver = gv.solver.GraphSolver(dim, num_sampler_per_worker=threads, seed=args.seed, pair_order=gv.auto if args.pair_order == "auto" else args.pair_order)
     if args.lanes:
         solver.kernels.set_lanes_per_pair(args.lanes)
     if args.variant:
@@ -166,13 +173,18 @@ def main():
     session.fill(pools)
     fill_s = time.perf_counter() - t0
     blocks = session.blocks
+    if args.xcd_sorted and not args.xcd_bucket:  # experiment: whole batch sorted by head row, no XCD placement
+        for pool in pools.values():
+            rec = pool.numpy().view(np.uint32).reshape(-1, B, 2)
+            for i in range(rec.shape[0]):
+                rec[i] = rec[i][np.argsort(rec[i, :, 1], kind="stable")]
     if args.xcd_bucket:
         column = 1 if args.xcd_bucket == "head" else 0
         for pool in pools.values():
             rec = pool.numpy().view(np.uint32).reshape(-1, B, 2)
             for i in range(rec.shape[0]):
                 cls = rec[i, :, column] % 8
-                order = np.argsort(cls, kind="stable")
+                order = np.lexsort((rec[i, :, column], cls)) if args.xcd_sorted else np.argsort(cls, kind="stable")
                 counts = np.bincount(cls, minlength=8)
                 nmin = int(counts.min()) // 16
                 starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
@@ -184,28 +196,62 @@ def main():
                 out = np.empty_like(rec[i])
                 out[dest] = rec[i][order]
                 rec[i] = out
-    dev_pools = session.upload(pools)  # every block pool of this GPU's column, resident in HBM
+    landed = session.upload(pools, group=False)  # every block pool of this GPU's column, resident in HBM
     sampled = len(blocks) * args.block_batches * B
+    # With pair_order "grouped" the episode loop regroups a pool on the copy stream after its H2D copy, while the
+    # previous block trains (GraphSolver._train_episode).  The timed loop below does the same for every block visit —
+    # everything except the PCIe copy — so the cost of the regrouping pass is inside the measurement.
+    grouped = solver.pair_order == "grouped"
+    work = [torch.empty_like(next(iter(landed.values()))) for _ in range(2)] if grouped else [None, None]
+    copy_stream = torch.cuda.Stream(dev)
+    ready, released = [None, None], [None, None]
+
+    def stage(step):
+        pool = landed[blocks[step % len(blocks)]]
+        if not grouped:
+            return pool
+        b = step & 1
+        with torch.cuda.stream(copy_stream):
+            if released[b] is not None:
+                copy_stream.wait_event(released[b])
+            session.stage(pool, work[b])
+            ready[b] = torch.cuda.Event()
+            ready[b].record()
+        return work[b]
 
     kernel_events = []
+    walk = {"step": 0, "pool": None}  # the schedule walk continues across residency pass, warm-up and timed steps
 
     def run(num_batches, timed):
-        """num_batches per GPU, walking the schedule block by block with the exchange after every block."""
-        done, step = 0, 0
+        """num_batches per GPU, walking the schedule block by block with the exchange after every block.  As in the
+        episode loop, the pool of the NEXT block visit is staged while this one trains — also at the end of a run, so
+        a run of V visits contains V staging passes (the first visit's own pass belongs to the run before it)."""
+        compute = torch.cuda.current_stream(dev)
+        done = 0
+        if walk["pool"] is None:
+            walk["pool"] = stage(walk["step"])
         while done < num_batches:
+            step = walk["step"]
             hp, tp = blocks[step % len(blocks)]
             n = min(args.block_batches, num_batches - done)
+            pool = walk["pool"]
+            if grouped:
+                compute.wait_event(ready[step & 1])
+            walk["pool"] = stage(step + 1)
             session.wait_exchange(hp)  # fence first, so that the events below bracket kernels only
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            session.train_block(hp, tp, dev_pools[(hp, tp)], n)
+            session.train_block(hp, tp, pool, n)
             if timed:
                 e1.record()
                 kernel_events.append((e0, e1, n))
+            if grouped:
+                released[step & 1] = torch.cuda.Event()
+                released[step & 1].record(compute)
             session.exchange(step)
             done += n
-            step += 1
+            walk["step"] = step + 1
 
     def fence():
         torch.cuda.synchronize()
@@ -216,9 +262,8 @@ def main():
     # Residency pass before the W warm-up steps: two batches of every block (code-object load, first touch of every
     # table / pool, runtime pools growing) and the first collective (RCCL communicator + buffers).  One-time costs of
     # tens of milliseconds otherwise land inside a timed region that is itself only tens of milliseconds long.
-    for step, (hp, tp) in enumerate(blocks):
-        session.train_block(hp, tp, dev_pools[(hp, tp)], min(2, args.block_batches))
-        session.exchange(step)
+    for _ in blocks:
+        run(min(2, args.block_batches), False)
     session.wait_exchange()
     run(args.warmup, False)
     session.wait_exchange()
@@ -258,7 +303,8 @@ def main():
                                "negatives drawn in-kernel, block pools resident in HBM" % (N, E, dim, B, k),
                    "parallelism": "%d GPU(s), %d vertex partition(s), context shards pinned per GPU, asynchronous "
                                   "all-gather of head shards every %d batches" % (world, partitions, args.block_batches),
-                   "lanes_per_pair": lanes},
+                   "lanes_per_pair": lanes, "pair_order": solver.pair_order +
+                   (" (gvk_group_pairs per block visit on the copy stream, inside the timed region)" if grouped else "")},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "traffic": traffic,
                      "traffic_source": "profiles/r1/pmc_summary_bench_n1.json" if traffic else None,

@@ -88,6 +88,8 @@ def lib():
     l.gvk_sample_pairs.argtypes = [vp, vp, vp, u32, u64, u64, vp, C.c_size_t]
     l.gvk_sample_walks.restype = i32
     l.gvk_sample_walks.argtypes = [vp, P(WalkGraph), u64, u64, vp, C.c_size_t, i32, i32, i32]
+    l.gvk_group_pairs.restype = i32
+    l.gvk_group_pairs.argtypes = [vp, vp, vp, vp, P(C.c_size_t), i32, i32, i32]
     l.gvk_alias_build.restype = i32
     l.gvk_alias_build.argtypes = [vp, C.c_size_t, vp, vp, i32, vp]
     l.gvk_set_tuning.restype = i32

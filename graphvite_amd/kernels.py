@@ -176,6 +176,24 @@ class HipKernels(object):
                                        first_index, _ptr(pool), n)
         _lib.check(rc, "gvk_sample_pairs")
 
+    def group_pairs(self, pool_in, pool_out, batch_size, num_batch, num_row):
+        """pool_out = pool_in with the pairs of every batch that share a head row made adjacent (gvk_group_pairs).
+        Runs on the current stream; the scratch buffer comes from torch's caching allocator."""
+        dev = pool_in.device
+        _need(pool_in, torch.int32, "pool_in", dev)
+        _need(pool_out, torch.int32, "pool_out", dev)
+        n = 2 * batch_size * num_batch
+        if pool_in.numel() < n or pool_out.numel() < n:
+            raise ValueError("pools hold fewer than %d batches of %d pairs" % (num_batch, batch_size))
+        row_bits = max(int(num_row - 1).bit_length(), 1)
+        need = C.c_size_t(0)
+        _lib.check(self.lib.gvk_group_pairs(None, None, None, None, C.byref(need), batch_size, num_batch, row_bits),
+                   "gvk_group_pairs")
+        work = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        rc = self.lib.gvk_group_pairs(self._stream(pool_in), _ptr(pool_in), _ptr(pool_out), _ptr(work), C.byref(need),
+                                      batch_size, num_batch, row_bits)
+        _lib.check(rc, "gvk_group_pairs")
+
     def sample_walks(self, walk_graph, seed, first_walk, pool, pool_pairs, walk_length, augmentation_step,
                      shuffle_base):
         """pool[:pool_pairs] = random-walk positive pairs drawn on the device (gvk_sample_walks).

@@ -163,6 +163,16 @@ typedef struct {
 int gvk_sample_walks(void *stream, const gvk_walk_graph *graph, uint64_t seed, uint64_t first_walk, uint32_t *pool,
                      size_t pool_pairs, int walk_length, int augmentation_step, int shuffle_base);
 
+/* Optional pool pre-pass: inside each of the num_batch batches (batch_size {tail, head} records each) of pool_in, make
+ * the records that share a head row adjacent, writing the regrouped pool to pool_out (distinct from pool_in).  Each
+ * batch keeps exactly its records; their order becomes ascending in the low row_bits bits of the head row, stable
+ * otherwise (deterministic).  The order of the samples inside a batch has no meaning to gvk_train / the reference's
+ * kernel (they run concurrently); adjacency makes a head row that several samples of a batch share one HBM fetch.
+ * Two-call protocol, nothing is allocated here: workspace == NULL stores the scratch size this shape needs in
+ * *workspace_bytes; otherwise workspace must hold *workspace_bytes bytes of device memory. */
+int gvk_group_pairs(void *stream, const uint32_t *pool_in, uint32_t *pool_out, void *workspace,
+                    size_t *workspace_bytes, int batch_size, int num_batch, int row_bits);
+
 /* Host: Vose alias construction exactly as the reference orders it (FIFO queues, double mean).
  * index_bytes 4 -> uint32 alias[] (n <= 2^32 - 1), 8 -> uint64 alias[].  n must be > 0.  (The reference's loop
  * counters are int, alias_table.cuh:93-100, so it overflows past 2^31 entries; this builder does not.)

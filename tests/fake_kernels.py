@@ -51,6 +51,14 @@ class OracleKernels(object):
             self.train(vertex, context, pairs, loss, optimizer, num_negative, negative_weight, table=table, seed=seed,
                        batch_id=bid, moments=moments, lr=np.float32(optimizer.lr) * np.float32(scale))
 
+    def group_pairs(self, pool_in, pool_out, batch_size, num_batch, num_row):
+        """Per batch: stable sort of the records by the low row bits of the head (what gvk_group_pairs promises)."""
+        bits = max(int(num_row - 1).bit_length(), 1)
+        rec = pool_in.numpy().view(np.uint32)[:2 * batch_size * num_batch].reshape(num_batch, batch_size, 2)
+        out = pool_out.numpy().view(np.uint32)[:2 * batch_size * num_batch].reshape(num_batch, batch_size, 2)
+        for i in range(num_batch):
+            out[i] = rec[i][np.argsort(rec[i, :, 1] & np.uint32((1 << bits) - 1), kind="stable")]
+
     def sample_pairs(self, table, block_pairs, seed, first_index, pool, n):
         packed = table.numpy().view(np.dtype([("prob", np.float32), ("alias", np.uint32)]))
         out = self.oracle.sample_pairs(np.ascontiguousarray(packed["prob"]), np.ascontiguousarray(packed["alias"]),

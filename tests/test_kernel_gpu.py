@@ -396,3 +396,36 @@ def test_rows_beyond_4_gib(hip, oracle):
     np.testing.assert_allclose(logits.cpu().numpy(), oracle.predict(ov, oc, opairs), rtol=1e-5, atol=1e-8)
     # nothing below the 4 GiB line moved
     assert float(tv[:lo].abs().max()) == 0.0 and float(tc[:lo].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("nb,B,rows", [(1, 1, 2), (3, 1000, 777), (7, 4097, 1 << 20), (217, 100000, 1000000)])
+def test_group_pairs_is_a_stable_per_batch_sort_on_head(hip, nb, B, rows):
+    rng = np.random.default_rng(nb * B)
+    pool = np.stack([rng.integers(0, 2 ** 32, nb * B, dtype=np.uint64).astype(np.uint32),
+                     (rng.pareto(1.2, nb * B) * 20).astype(np.uint64).astype(np.uint32) % np.uint32(rows)], 1)
+    tin, tout = dev(pool.view(np.int32)), torch.zeros((nb * B, 2), dtype=torch.int32, device=DEV)
+    hip.group_pairs(tin, tout, B, nb, rows)
+    torch.cuda.synchronize()
+    got = tout.cpu().numpy().view(np.uint32).reshape(nb, B, 2)
+    rec = pool.reshape(nb, B, 2)
+    for i in range(0, nb, max(nb // 7, 1)):
+        want = rec[i][np.argsort(rec[i, :, 1], kind="stable")]
+        assert (got[i] == want).all()
+    assert (tin.cpu().numpy().view(np.uint32) == pool).all()  # the input pool is left alone
+
+
+def test_group_pairs_edge_cases(hip):
+    from graphvite_amd import _lib
+    import ctypes as C
+    a = torch.zeros((8, 2), dtype=torch.int32, device=DEV)
+    b = torch.full((8, 2), -1, dtype=torch.int32, device=DEV)
+    hip.group_pairs(a, b, 4, 0, 10)  # no batches: nothing written
+    torch.cuda.synchronize()
+    assert (b.cpu().numpy() == -1).all()
+    need = C.c_size_t(64)
+    lib = _lib.lib()
+    assert lib.gvk_group_pairs(None, a.data_ptr(), a.data_ptr(), a.data_ptr(), C.byref(need), 4, 2, 10) == _lib.GVK_EINVAL
+    assert lib.gvk_group_pairs(None, a.data_ptr(), b.data_ptr(), a.data_ptr(), C.byref(need), 4, 2, 0) == _lib.GVK_EINVAL
+    assert lib.gvk_group_pairs(None, None, None, None, None, 4, 2, 10) == _lib.GVK_EINVAL
+    with pytest.raises(ValueError):
+        hip.group_pairs(a, b, 4, 3, 10)

@@ -79,6 +79,36 @@ def test_train_accounting_and_determinism():
     assert s.num_batch == 30 + 6 and s.batch_id == 36 and not (s.vertex_embeddings == before).all()
 
 
+def test_grouped_pair_order_permutes_inside_batches_only():
+    """pair_order="grouped": every batch trains the same multiset of pairs as with "sampled", heads adjacent."""
+    g = make_graph()
+
+    class Recording(OracleKernels):
+        def __init__(self):
+            OracleKernels.__init__(self)
+            self.batches = []
+
+        def train(self, vertex, context, pairs, *args, **kwargs):
+            self.batches.append(self._np(pairs).copy())
+            return OracleKernels.train(self, vertex, context, pairs, *args, **kwargs)
+
+    seen = {}
+    for order in ("sampled", "grouped"):
+        k = Recording()
+        s = gv.solver.GraphSolver(32, kernels=k, num_sampler_per_worker=2, seed=3, pair_order=order)
+        s.build(g, batch_size=500, episode_size=3)
+        s.train("LINE", num_epoch=2, augmentation_step=1, log_frequency=1 << 30)
+        seen[order] = k.batches
+    assert len(seen["sampled"]) == len(seen["grouped"]) > 0
+    for a, b in zip(seen["sampled"], seen["grouped"]):
+        a, b = a.reshape(-1, 2), b.reshape(-1, 2)
+        assert (np.diff(b[:, 1].astype(np.int64)) >= 0).all() and not (a == b).all()
+        key = lambda x: np.sort(x[:, 1].astype(np.int64) << 32 | x[:, 0].astype(np.int64))
+        assert (key(a) == key(b)).all()
+    with pytest.raises(ValueError):
+        gv.solver.GraphSolver(32, kernels=OracleKernels(), pair_order="sorted")
+
+
 @pytest.mark.parametrize("model,aug", [("LINE", 1), ("DeepWalk", 3), ("node2vec", 2)])
 def test_models_and_samplers_run(model, aug):
     g = make_graph(200, 1500, seed=2)

@@ -20,7 +20,8 @@ def run(edges, kernels, dim, **train):
     gv.init_logging(logging.ERROR)
     g = gv.graph.Graph()
     g.load(edges)
-    s = gv.solver.GraphSolver(dim, kernels=kernels, num_sampler_per_worker=4, seed=17)
+    s = gv.solver.GraphSolver(dim, kernels=kernels, num_sampler_per_worker=4, seed=17,
+                              pair_order=train.pop("pair_order", "sampled"))
     s.build(g, batch_size=train.pop("batch_size"), episode_size=train.pop("episode_size"),
             num_negative=train.pop("num_negative", 1))
     s.train(**train)
@@ -85,6 +86,20 @@ def test_deepwalk_and_node2vec_learn():
         auc = auc_of(g, s, test)
         print("%s AUC %.6f" % (model, auc))
         assert auc > 0.85
+
+
+def test_grouped_pair_order_keeps_auc_parity():
+    """pair_order="grouped" (pairs of a batch that share a head row made adjacent on the device): same T3 protocol,
+    both pipelines train the regrouped batches."""
+    edges = synthetic.community_edges(20000, 400000, num_community=100, seed=3)
+    train, (valid, test) = synthetic.link_prediction_split(edges, (100, 3, 3))
+    cfg = dict(batch_size=500, episode_size=200, model="LINE", num_epoch=50, augmentation_step=1,
+               log_frequency=1 << 30, pair_order="grouped")
+    g1, hip = run(train, None, 128, **dict(cfg))
+    g2, ora = run(train, OracleKernels(), 128, **dict(cfg))
+    a_hip, a_ora = auc_of(g1, hip, test), auc_of(g2, ora, test)
+    print("grouped pair order: AUC hip %.6f oracle %.6f" % (a_hip, a_ora))
+    assert a_ora > 0.9 and abs(a_hip - a_ora) <= 0.002
 
 
 def test_power_law_graph_learns_like_the_oracle():
