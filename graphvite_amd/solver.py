@@ -666,6 +666,7 @@ class GraphSolver(object):
         send = [torch.empty((W, bpr, elems), dtype=torch.int32, device=self.device) for _ in range(2)]
         recv = torch.empty((W, bpr, elems), dtype=torch.int32, device=self.device)
         pools = [torch.empty((bpr, W, elems), dtype=torch.int32, device=self.device) for _ in range(2)]
+        landing = torch.empty_like(pools[0]) if self.pair_order == "grouped" else None  # regrouped into pools[s]
         views = [{order[w][i]: host[s][w, i] for w in range(W) for i in range(bpr)} for s in range(2)]
         route_stream = torch.cuda.Stream(self.device) if cuda else None
         copied, routed, trained = [None, None], [None, None], [None, None]
@@ -682,7 +683,9 @@ class GraphSolver(object):
             if not cuda:
                 send[s].copy_(host[s])
                 dist.all_to_all_single(recv.view(-1), send[s].view(-1))
-                pools[s].copy_(recv.permute(1, 0, 2))
+                (pools[s] if landing is None else landing).copy_(recv.permute(1, 0, 2))
+                if landing is not None:
+                    self._group_pairs(landing.view(-1), pools[s].view(-1))
                 return
             with torch.cuda.stream(route_stream):
                 if trained[s] is not None:
@@ -691,7 +694,9 @@ class GraphSolver(object):
                 copied[s] = torch.cuda.Event()
                 copied[s].record()
                 dist.all_to_all_single(recv.view(-1), send[s].view(-1))
-                pools[s].copy_(recv.permute(1, 0, 2))
+                (pools[s] if landing is None else landing).copy_(recv.permute(1, 0, 2))
+                if landing is not None:
+                    self._group_pairs(landing.view(-1), pools[s].view(-1))
                 routed[s] = torch.cuda.Event()
                 routed[s].record()
 

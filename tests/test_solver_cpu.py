@@ -384,7 +384,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_dir, model, aug, num_partition=0):
+def _worker(rank, world, port, out_dir, model, aug, num_partition=0, pair_order="sampled"):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world))
@@ -394,7 +394,7 @@ def _worker(rank, world, port, out_dir, model, aug, num_partition=0):
         gv.init_logging(logging.ERROR)
         g = make_graph(240, 2400, seed=6)
         k = OracleKernels()
-        s = gv.solver.GraphSolver(32, kernels=k, num_sampler_per_worker=2, seed=9)
+        s = gv.solver.GraphSolver(32, kernels=k, num_sampler_per_worker=2, seed=9, pair_order=pair_order)
         s.build(g, batch_size=400, episode_size=3, num_partition=num_partition)
         assert s.num_worker == world and s.num_partition == (num_partition or world)
         # every pair a worker trains on must be a real (walk) pair of the graph that lives in the block being trained
@@ -406,7 +406,10 @@ def _worker(rank, world, port, out_dir, model, aug, num_partition=0):
         original = s._train_block
 
         def checked(state, hp, tp, pool):
-            rec = pool.numpy().view(np.uint32).reshape(-1, 2)[:s.episode_size * s.batch_size:37]
+            rec = pool.numpy().view(np.uint32).reshape(-1, 2)[:s.episode_size * s.batch_size]
+            if pair_order == "grouped":  # every batch arrives in ascending head-row order
+                assert (np.diff(rec[:, 1].astype(np.int64).reshape(-1, s.batch_size), axis=1) >= 0).all()
+            rec = rec[::37]
             for t_local, h_local in rec.tolist():
                 h, t = inv[(hp, h_local)], inv[(tp, t_local)]        # KeyError = a pair routed to the wrong block
                 reach = nbrs[h] if aug == 1 else nbrs[h] | set().union(*[nbrs[x] for x in nbrs[h]])
@@ -454,3 +457,15 @@ def test_more_partitions_than_workers_over_gloo(tmp_path, model, aug):
     ids = np.sort(np.concatenate([r[0]["ids"], r[1]["ids"]]))
     assert (ids == np.arange(len(ids))).all() and len(ids) % (4 * 4 * 3) == 0  # whole episodes of P^2 blocks
     assert np.abs(r[0]["c"]).max() > 0
+
+
+@pytest.mark.parametrize("model,aug", [("LINE", 1), ("DeepWalk", 2)])
+def test_grouped_pair_order_over_gloo(tmp_path, model, aug):
+    """pair_order="grouped" on 2 workers / 4 partitions: uploaded (LINE) and routed (walk) pools are regrouped batch by
+    batch before they are trained; everything else as above."""
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), model, aug, 4, "grouped"), nprocs=world, join=True)
+    r = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % i)) for i in range(world)]
+    assert (r[0]["v"] == r[1]["v"]).all() and (r[0]["c"] == r[1]["c"]).all()
+    ids = np.sort(np.concatenate([r[0]["ids"], r[1]["ids"]]))
+    assert (ids == np.arange(len(ids))).all() and np.abs(r[0]["c"]).max() > 0
