@@ -66,7 +66,7 @@ def parse():
                    help="experiment: with --xcd-bucket, also sort each bucket by row (same-row pairs adjacent in time)")
     p.add_argument("--pair-order", choices=["auto", "sampled", "grouped"], default="auto",
                    help="GraphSolver(pair_order=...): auto (the product default) regroups the pairs of a batch by head "
-                        "row on the device when a partition's table exceeds 32 MiB")
+                        "row on the device when a partition's table reaches 16 MiB")
     p.add_argument("--optimizer", choices=["SGD", "Momentum", "AdaGrad", "RMSprop", "Adam"], default="SGD",
                    help="experiment: moment optimizers move (1 + m) x the row bytes (m = 1, Adam 2)")
     p.add_argument("--graph", choices=["power-law", "community"], default="power-law",
