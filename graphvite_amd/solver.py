@@ -153,7 +153,7 @@ class GraphSolver(object):
     pairs of a batch that share a head row are made adjacent on the device first (gvk_group_pairs; same samples, same
     batches — the order inside a batch has no meaning to a kernel that processes the batch concurrently — but a row
     shared by k samples is fetched from HBM once); auto (default): grouped when a partition's table is too large for
-    the caches to do that by themselves (>= 16 MiB), sampled below.
+    the caches to do that by themselves (>= 16 MiB) and dim >= 64, sampled otherwise.
     """
 
     available_dims = (32, 64, 96, 128, 256, 512)  # src/graphvite.cu:52-59
@@ -278,7 +278,8 @@ class GraphSolver(object):
         self._part, self._local, self._part_sizes = hostlib.partition(graph.vertex_weights, P)
         self._part_size = int(self._part_sizes.max())
         if self._pair_order_request == auto:  # small tables stay cache-resident; the regrouping pass would only cost
-            big = self._part_size * self.dim * 4 >= MiB(16)
+            # ... and at dim 32 a batch trains in 16 us: the pass (same cost at every dim) would take a third of the GPU
+            big = self._part_size * self.dim * 4 >= MiB(16) and self.dim >= 64
             self.pair_order = "grouped" if big and self.device.type == "cuda" else "sampled"
         order = np.argsort(self._part.astype(np.int64) * (1 << 32) + self._local, kind="stable")
         starts = np.concatenate([[0], np.cumsum(self._part_sizes.astype(np.int64))]).astype(np.int64)
