@@ -413,6 +413,7 @@ class GraphSolver(object):
             finally:
                 report()
             return
+        per_episode = len(self._schedule) * self.episode_size * self.positive_reuse * self.num_worker
         pools = self._host_pools()
         uploads = [[], []]  # per pool set: events of the async H2D copies still reading its pinned buffers
         try:
@@ -427,13 +428,17 @@ class GraphSolver(object):
                     event.synchronize()
                 uploads[current ^ 1] = []
                 tb = time.time()
-                filler = threading.Thread(target=self._fill_guarded, args=(pools[current ^ 1],))
-                filler.start()
+                self._fill_error = None
+                filler = None
+                if self.batch_id + per_episode < self.num_batch:  # no pools for an episode that will not run
+                    filler = threading.Thread(target=self._fill_guarded, args=(pools[current ^ 1],))
+                    filler.start()
                 try:
                     uploads[current] = self._train_episode(state, pools[current])
                 finally:
                     tc = time.time()
-                    filler.join()
+                    if filler is not None:
+                        filler.join()
                 td = time.time()
                 self._loop_timing["wait_upload"] += tb - ta
                 self._loop_timing["enqueue"] += tc - tb
@@ -714,6 +719,7 @@ class GraphSolver(object):
                 trained[s].record(compute)
 
         self._loop_timing = {"wait_upload": 0.0, "enqueue": 0.0, "wait_fill": 0.0, "fill": 0.0}
+        per_episode = len(self._schedule) * self.episode_size * self.positive_reuse * W
         fill(0)
         current = 0
         while self.batch_id < self.num_batch:
@@ -722,13 +728,17 @@ class GraphSolver(object):
             if cuda and copied[current ^ 1] is not None:
                 copied[current ^ 1].synchronize()  # the other host set may be refilled once its H2D has landed
             tb = time.time()
-            filler = threading.Thread(target=self._fill_guarded_call, args=(fill, current ^ 1))
-            filler.start()
+            self._fill_error = None
+            filler = None
+            if self.batch_id + per_episode < self.num_batch:  # no pools for an episode that will not run
+                filler = threading.Thread(target=self._fill_guarded_call, args=(fill, current ^ 1))
+                filler.start()
             try:
                 train(current)
             finally:
                 tc = time.time()
-                filler.join()
+                if filler is not None:
+                    filler.join()
             self._loop_timing["wait_upload"] += tb - ta
             self._loop_timing["enqueue"] += tc - tb
             self._loop_timing["wait_fill"] += time.time() - tc
