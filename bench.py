@@ -3,11 +3,12 @@
 
 A "step" is one batch (100 000 edge-samples, num_negative 1) of negative-sampling SGD PER GPU on the synthetic
 power-law graph BASELINE.json's metric is quoted on (configs[1]: 1M nodes / 10M edges, dim 128, fp32, LINE,
-augmentation_step 1), driven through the product path: Graph -> GraphSolver.build (degree partition, one
-partition per GPU) -> the native CPU edge sampler fills the block pools -> pools uploaded to HBM ->
-gvk_train_episode (negatives drawn in-kernel, lr schedule per batch).  With N > 1 each GPU owns context shard
-`rank`, trains block (head (rank + step) mod N, tail rank) for `--block-batches` batches, then all GPUs
-all-gather the head shards they just trained (RCCL over xGMI) — the exchange is inside the timed region.
+augmentation_step 1), driven through the product path: Graph -> GraphSolver.build (degree partition; one
+partition at N = 1, 2N at N > 1) -> the native CPU edge sampler fills the block pools -> pools uploaded to HBM ->
+per block, as in the episode loop: [regrouping pass gvk_group_pairs on the copy stream while the previous block
+trains] -> gvk_train_episode (negatives drawn in-kernel, lr schedule per batch) for `--block-batches` batches ->
+with N > 1 all GPUs all-gather the head shards they just trained (RCCL over xGMI, asynchronous).  The K timed
+steps are the next K batches of that walk: regrouping passes and exchanges are inside the timed region.
 
     python bench.py [--steps K] [--warmup W]                                                     (N = 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -207,6 +208,7 @@ def main():
     ready, released = [None, None], [None, None]
 
     def stage(step):
+        """Stage the pool of block visit `step`: the regrouping pass, on the copy stream."""
         pool = landed[blocks[step % len(blocks)]]
         if not grouped:
             return pool
@@ -220,38 +222,40 @@ def main():
         return work[b]
 
     kernel_events = []
-    walk = {"step": 0, "pool": None}  # the schedule walk continues across residency pass, warm-up and timed steps
+    # The walk over the schedule continues across the residency pass, the warm-up and the timed steps, block by block
+    # as the episode loop walks it: block_batches batches of a block, the exchange, the next block — whose pool was
+    # staged while this one trained.  A run of K steps simply trains the next K batches of that walk.
+    walk = {"step": 0, "offset": 0, "pool": None, "next": None}
 
-    def run(num_batches, timed):
-        """num_batches per GPU, walking the schedule block by block with the exchange after every block.  As in the
-        episode loop, the pool of the NEXT block visit is staged while this one trains — also at the end of a run, so
-        a run of V visits contains V staging passes (the first visit's own pass belongs to the run before it)."""
+    def run(num_batches, timed, leave_block=False):
         compute = torch.cuda.current_stream(dev)
         done = 0
-        if walk["pool"] is None:
-            walk["pool"] = stage(walk["step"])
         while done < num_batches:
             step = walk["step"]
             hp, tp = blocks[step % len(blocks)]
-            n = min(args.block_batches, num_batches - done)
-            pool = walk["pool"]
-            if grouped:
-                compute.wait_event(ready[step & 1])
-            walk["pool"] = stage(step + 1)
-            session.wait_exchange(hp)  # fence first, so that the events below bracket kernels only
+            if walk["offset"] == 0:  # entering a block
+                if walk["pool"] is None:
+                    walk["pool"] = stage(step)
+                if grouped:
+                    compute.wait_event(ready[step & 1])
+                walk["next"] = stage(step + 1)
+                session.wait_exchange(hp)  # fence here, so that the events below bracket kernels only
+            n = min(args.block_batches - walk["offset"], num_batches - done)
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            session.train_block(hp, tp, pool, n)
+            session.train_block(hp, tp, walk["pool"][walk["offset"] * B * 2:], n)
             if timed:
                 e1.record()
                 kernel_events.append((e0, e1, n))
-            if grouped:
-                released[step & 1] = torch.cuda.Event()
-                released[step & 1].record(compute)
-            session.exchange(step)
             done += n
-            walk["step"] = step + 1
+            walk["offset"] += n
+            if walk["offset"] == args.block_batches or (leave_block and done == num_batches):
+                if grouped:
+                    released[step & 1] = torch.cuda.Event()
+                    released[step & 1].record(compute)
+                session.exchange(step)
+                walk.update(step=step + 1, offset=0, pool=walk["next"], next=None)
 
     def fence():
         torch.cuda.synchronize()
@@ -263,14 +267,12 @@ def main():
     # table / pool, runtime pools growing) and the first collective (RCCL communicator + buffers).  One-time costs of
     # tens of milliseconds otherwise land inside a timed region that is itself only tens of milliseconds long.
     for _ in blocks:
-        run(min(2, args.block_batches), False)
+        run(min(2, args.block_batches), False, leave_block=True)
     session.wait_exchange()
     run(args.warmup, False)
-    session.wait_exchange()
     fence()
     t0 = time.perf_counter()
     run(args.steps, True)
-    session.wait_exchange()
     fence()
     wall = time.perf_counter() - t0
     if world > 1:

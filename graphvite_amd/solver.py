@@ -89,12 +89,13 @@ class TrainingSession(object):
                 out[block] = landed
         return out
 
-    def stage(self, landed, out):
-        """What the episode loop does to a pool after its H2D copy: with pair_order "grouped", regroup `landed` into
-        `out` on the current stream and return `out`; otherwise return `landed` untouched."""
+    def stage(self, landed, out, num_batches=None):
+        """What the episode loop does to a pool after its H2D copy: with pair_order "grouped", regroup (the first
+        `num_batches` batches of) `landed` into `out` on the current stream and return `out`; otherwise return
+        `landed` untouched."""
         if self.solver.pair_order != "grouped":
             return landed
-        self.solver._group_pairs(landed, out)
+        self.solver._group_pairs(landed, out, num_batches)
         return out
 
     def train_block(self, hp, tp, pool, num_batches=None):
@@ -877,7 +878,7 @@ class GraphSolver(object):
         state["global_step"] = base + len(steps)
         return issued
 
-    def _group_pairs(self, pool, out):
+    def _group_pairs(self, pool, out, num_batches=None):
         """pair_order="grouped": inside every batch of a device-resident pool, bring the pairs that share a head row
         next to each other (gvk_group_pairs, on the current stream; `out` is `pool` itself when nothing is to be done).
         The order of the samples inside a batch carries no meaning — they are i.i.d. draws that the kernel processes
@@ -886,7 +887,9 @@ class GraphSolver(object):
         power-law graph are repeats)."""
         if self.pair_order != "grouped":
             return
-        self.kernels.group_pairs(pool, out, self.batch_size, pool.numel() // 2 // self.batch_size, self._part_size)
+        if num_batches is None:
+            num_batches = pool.numel() // 2 // self.batch_size
+        self.kernels.group_pairs(pool, out, self.batch_size, num_batches, self._part_size)
 
     def _tables(self, state, hp, tp):
         ti = self._my_tails.index(tp)
