@@ -68,6 +68,9 @@ def parse():
     p.add_argument("--pair-order", choices=["auto", "sampled", "grouped"], default="auto",
                    help="GraphSolver(pair_order=...): auto (the product default) regroups the pairs of a batch by head "
                         "row on the device when a partition's table reaches 16 MiB")
+    p.add_argument("--dry-run-cpu", action="store_true",
+                   help="LOGIC TEST ONLY (tests/test_api_cpu.py): walk the same loop on the CPU with the test suite's "
+                        "oracle stand-in for the kernels and gloo for the collectives; the numbers mean nothing")
     p.add_argument("--optimizer", choices=["SGD", "Momentum", "AdaGrad", "RMSprop", "Adam"], default="SGD",
                    help="experiment: moment optimizers move (1 + m) x the row bytes (m = 1, Adam 2)")
     p.add_argument("--graph", choices=["power-law", "community"], default="power-law",
@@ -127,10 +130,19 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with `python -m torch.distributed.run "
                          "--nproc-per-node %d ... bench.py --gpus %d`" % (args.gpus, world, args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    cuda = not args.dry_run_cpu
+    if not cuda:
+        args.no_cpu_baseline = True
+    if cuda:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device("cpu")
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if cuda:
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     import graphvite_amd as gv
     from graphvite_amd import synthetic
@@ -155,7 +167,12 @@ def main():
         graph.load(synthetic.power_law_edges(N, E, seed=args.seed))
     if args.xcd_bucket or args.xcd_sorted:
         args.pair_order = "sampled"  # the placement experiments lay the batches out themselves
-    solver = gv.solver.GraphSolver(dim, num_sampler_per_worker=threads, seed=args.seed, pair_order=gv.auto if args.pair_order == "auto" else args.pair_order)
+    stand_in = None
+    if not cuda:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from fake_kernels import OracleKernels
+        stand_in = OracleKernels()
+    solver = gv.solver.GraphSolver(dim, num_sampler_per_worker=threads, seed=args.seed, kernels=stand_in, pair_order=gv.auto if args.pair_order == "auto" else args.pair_order)
     if args.lanes:
         solver.kernels.set_lanes_per_pair(args.lanes)
     if args.variant:
@@ -204,7 +221,7 @@ def main():
     # everything except the PCIe copy — so the cost of the regrouping pass is inside the measurement.
     grouped = solver.pair_order == "grouped"
     work = [torch.empty_like(next(iter(landed.values()))) for _ in range(2)] if grouped else [None, None]
-    copy_stream = torch.cuda.Stream(dev)
+    copy_stream = torch.cuda.Stream(dev) if cuda else None
     ready, released = [None, None], [None, None]
 
     def stage(step):
@@ -213,6 +230,8 @@ def main():
         if not grouped:
             return pool
         b = step & 1
+        if not cuda:
+            return session.stage(pool, work[b])
         with torch.cuda.stream(copy_stream):
             if released[b] is not None:
                 copy_stream.wait_event(released[b])
@@ -228,7 +247,7 @@ def main():
     walk = {"step": 0, "offset": 0, "pool": None, "next": None}
 
     def run(num_batches, timed, leave_block=False):
-        compute = torch.cuda.current_stream(dev)
+        compute = torch.cuda.current_stream(dev) if cuda else None
         done = 0
         while done < num_batches:
             step = walk["step"]
@@ -236,32 +255,34 @@ def main():
             if walk["offset"] == 0:  # entering a block
                 if walk["pool"] is None:
                     walk["pool"] = stage(step)
-                if grouped:
+                if grouped and cuda:
                     compute.wait_event(ready[step & 1])
                 walk["next"] = stage(step + 1)
                 session.wait_exchange(hp)  # fence here, so that the events below bracket kernels only
             n = min(args.block_batches - walk["offset"], num_batches - done)
-            if timed:
+            if timed and cuda:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             session.train_block(hp, tp, walk["pool"][walk["offset"] * B * 2:], n)
-            if timed:
+            if timed and cuda:
                 e1.record()
                 kernel_events.append((e0, e1, n))
             done += n
             walk["offset"] += n
             if walk["offset"] == args.block_batches or (leave_block and done == num_batches):
-                if grouped:
+                if grouped and cuda:
                     released[step & 1] = torch.cuda.Event()
                     released[step & 1].record(compute)
                 session.exchange(step)
                 walk.update(step=step + 1, offset=0, pool=walk["next"], next=None)
 
     def fence():
-        torch.cuda.synchronize()
+        if cuda:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if cuda:
+            torch.cuda.synchronize()
 
     # Residency pass before the W warm-up steps: two batches of every block (code-object load, first touch of every
     # table / pool, runtime pools growing) and the first collective (RCCL communicator + buffers).  One-time costs of
@@ -279,7 +300,10 @@ def main():
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
-    kernel_ms = sum(a.elapsed_time(b) for a, b, _ in kernel_events) / sum(n for _, _, n in kernel_events)
+    if cuda:
+        kernel_ms = sum(a.elapsed_time(b) for a, b, _ in kernel_events) / sum(n for _, _, n in kernel_events)
+    else:
+        kernel_ms = wall / args.steps * 1e3  # dry run: nothing to measure
     final_loss = float(session.loss.mean().item())
 
     moments = optimizer.num_moment
@@ -299,7 +323,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic" if cuda else "DRY RUN on the CPU with the test stand-in: logic test, not a result",
         "config": {"workload": "LINE (augmentation_step 1) on synthetic power-law %d nodes / %d edges, dim %d, "
                                "batch %d edge-samples per GPU per step, num_negative %d, SGD lr 0.025 wd 0.005 linear, "
                                "negatives drawn in-kernel, block pools resident in HBM" % (N, E, dim, B, k),

@@ -75,3 +75,38 @@ def test_kernel_wrappers_refuse_cpu_tensors():
         hip.predict(v, v, torch.zeros((1, 2), dtype=torch.int32), torch.zeros(1))
     with pytest.raises(ValueError):
         OptimizerSpec("Nadam")
+
+
+@pytest.mark.parametrize("world,order", [(1, "sampled"), (2, "grouped"), (2, "sampled")])
+def test_bench_loop_dry_run(world, order):
+    """bench.py's own loop (block walk across warm-up / timed steps, staging pass, asynchronous exchange, max over
+    ranks, one JSON line from rank 0) executed on the CPU: gloo instead of RCCL, the oracle stand-in instead of the HIP
+    kernels.  The 8-GPU run belongs to the driver; this is the part of it that can be exercised without GPUs."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["bench.py", "--gpus", str(world), "--dry-run-cpu", "--vertices", "400", "--edges", "4000", "--batch", "200",
+            "--dim", "32", "--steps", "23", "--warmup", "3", "--block-batches", "4", "--pair-order", order,
+            "--sampler-threads", "1"]
+    if world > 1:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
+    else:
+        cmd = [sys.executable] + args
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    run = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == world and r["steps"] == 23 and r["warmup"] == 3 and r["value"] > 0
+    assert r["config"]["pair_order"].startswith(order) and "DRY RUN" in r["data"]
+    assert ("cpu_baseline" in r) == False
+    assert "%d vertex partition" % (1 if world == 1 else 2 * world) in r["config"]["parallelism"]
