@@ -153,8 +153,9 @@ class GraphSolver(object):
     the GPU) and `pair_order` — "sampled": a batch is trained in the order the samplers produced it; "grouped": the
     pairs of a batch that share a head row are made adjacent on the device first (gvk_group_pairs; same samples, same
     batches — the order inside a batch has no meaning to a kernel that processes the batch concurrently — but a row
-    shared by k samples is fetched from HBM once); auto (default): grouped when a partition's table is too large for
-    the caches to do that by themselves (>= 16 MiB) and dim >= 64, sampled otherwise.
+    shared by k samples is fetched from HBM once); auto (default): grouped for independent edge draws (LINE,
+    augmentation_step 1) when a partition's table is too large for the caches to do that by themselves (>= 16 MiB)
+    and dim >= 64, sampled otherwise.
     """
 
     available_dims = (32, 64, 96, 128, 256, 512)  # src/graphvite.cu:52-59
@@ -278,10 +279,6 @@ class GraphSolver(object):
         # partitions (heads and tails are the same partition, solver.h:389-390)
         self._part, self._local, self._part_sizes = hostlib.partition(graph.vertex_weights, P)
         self._part_size = int(self._part_sizes.max())
-        if self._pair_order_request == auto:  # small tables stay cache-resident; the regrouping pass would only cost
-            # ... and at dim 32 a batch trains in 16 us: the pass (same cost at every dim) would take a third of the GPU
-            big = self._part_size * self.dim * 4 >= MiB(16) and self.dim >= 64
-            self.pair_order = "grouped" if big and self.device.type == "cuda" else "sampled"
         order = np.argsort(self._part.astype(np.int64) * (1 << 32) + self._local, kind="stable")
         starts = np.concatenate([[0], np.cumsum(self._part_sizes.astype(np.int64))]).astype(np.int64)
         self._part_ids = [order[starts[p]:starts[p + 1]] for p in range(P)]  # global ids in local order
@@ -511,6 +508,13 @@ class GraphSolver(object):
                                entries, self.node2vec_table_limit)
                 mode = "biased_reject"
         self._mode = mode
+        if self._pair_order_request == auto:
+            # Regroup (gvk_group_pairs) where it was measured to pay: independent edge draws (random-walk pools come in
+            # the reference's pseudo-shuffled walk order, which already has locality: DeepWalk end to end -16 % when
+            # regrouped), tables too large to stay cache-resident, and not dim 32 (a batch trains in 16 us there; the
+            # pass, which costs the same at every dim, would take a third of the GPU).
+            big = self._part_size * self.dim * 4 >= MiB(16) and self.dim >= 64
+            self.pair_order = "grouped" if big and mode == "edge" and self.device.type == "cuda" else "sampled"
         if self.device_sampling and (mode == "edge" or self.num_partition == 1):
             return  # positives are drawn on the device: no CPU sampler needed
         if self._sampler is None:
