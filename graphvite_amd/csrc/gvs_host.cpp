@@ -848,20 +848,6 @@ struct gvs_sampler {
             edge_alias[e] = edge_slots[e].alias;
         }
     }
-
-    inline uint64_t sample_edge(HostRng &rng) const {
-        const double r1 = rng.next(), r2 = rng.next();
-        const uint64_t index = (uint64_t)(r1 * (double)edge_slots.size());
-        const EdgeSlot &s = edge_slots[index];
-        return (float)r2 < s.prob ? index : s.alias;
-    }
-
-    inline uint32_t sample_neighbor(HostRng &rng, uint64_t base, uint64_t count) const {
-        const double r1 = rng.next(), r2 = rng.next();
-        const uint64_t index = (uint64_t)(r1 * (double)count);
-        const gvk_alias_entry &slot = nb_slots[base + index];
-        return (float)r2 < slot.prob ? (uint32_t)index : slot.alias;
-    }
 };
 
 namespace {
