@@ -16,7 +16,7 @@ def pytest_configure(config):
     lib = os.path.join(ROOT, "graphvite_amd", "libgvk.so")
     if not os.path.exists(lib):
         import subprocess
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "graphvite_amd", "csrc")])
+        subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(ROOT, "graphvite_amd", "csrc")])
 
 
 @pytest.fixture(scope="session")
