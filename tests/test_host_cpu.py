@@ -432,3 +432,22 @@ def test_graph_neighbor_tables_match_the_sampler_tables(oracle):
             oprob, oalias = oracle.alias_build(g.edge_weights[fo[u]:fo[u + 1]], 4)
             assert (oprob == prob[fo[u]:fo[u + 1]]).all() and (oalias == alias[fo[u]:fo[u + 1]]).all()
     assert _lib.lib().gvs_graph_neighbor_tables(g._handle, 1, None) != 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_alias_table_reconstructs_the_distribution(seed):
+    """Size-independent property of Vose's construction: slot i keeps prob_i of its 1/n mass and hands the rest to
+    alias_i, so the masses must add back up to w / sum(w) (float32 construction: 1e-5 absolute on n * p)."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(1, 5000))
+    w = (rng.pareto(1.1, n) + (rng.random(n) < 0.1) * 50).astype(np.float32)
+    w[rng.random(n) < 0.05] = 0  # zero-weight entries must never be drawn
+    if not w.any():
+        w[0] = 1
+    prob, alias, _ = K.alias_build(w)
+    mass = prob.astype(np.float64).copy()
+    np.add.at(mass, alias.astype(np.int64), 1.0 - prob.astype(np.float64))
+    want = w.astype(np.float64) / w.astype(np.float64).sum() * n
+    np.testing.assert_allclose(mass, want, atol=2e-4 * max(1.0, want.max()))
+    assert (mass[w == 0] < 1e-4).all()
+    assert ((prob >= 0) & (prob <= 1.0 + 1e-3)).all() and (alias < n).all()  # residual rounding may exceed 1 slightly
