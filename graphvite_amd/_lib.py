@@ -104,6 +104,8 @@ def lib():
     l.gvs_graph_destroy.restype = None
     l.gvs_graph_load_file.restype = i32
     l.gvs_graph_load_file.argtypes = [vp, cp, i32, i32, cp, cp]
+    l.gvs_graph_load_corpus.restype = i32
+    l.gvs_graph_load_corpus.argtypes = [vp, cp, i32, i32, i32, cp, cp]
     l.gvs_graph_load_names.restype = i32
     l.gvs_graph_load_names.argtypes = [vp, P(cp), P(cp), vp, sz, i32, i32]
     l.gvs_graph_load_labels.restype = i32

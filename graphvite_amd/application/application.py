@@ -134,9 +134,6 @@ class ApplicationMixin(object):
         return tuple([d[name] for name, k in zip(column, keep) if k] for d, column in zip(dicts, names))
 
 
-Application = ApplicationMixin
-
-
 class GraphApplication(ApplicationMixin):
     """
     Node embedding application (DeepWalk, LINE, node2vec).
@@ -311,3 +308,33 @@ def linear_classification(embeddings, labels, portion, normalization=False, time
             micro_f1s.append((2 * tp.sum() / (t.sum() + p.sum())).item())
     return {"macro-F1@%g%%" % (portion * 100): float(np.mean(macro_f1s)),
             "micro-F1@%g%%" % (portion * 100): float(np.mean(micro_f1s))}
+
+
+class WordGraphApplication(GraphApplication):
+    """
+    Word node embedding application: the graph of word co-occurrences of a corpus (WordGraph), embedded with the same
+    solver and the same training path as GraphApplication (application.py:536-573).
+
+    Parameters: as GraphApplication.
+    """
+
+    def get_graph(self, **kwargs):
+        return graph_module.WordGraph(self.index_type)
+
+
+class Application(object):
+    """
+    Application(type, *args, **kwargs)
+    Create an application instance of any type (application.py:1371-1393).
+
+    Parameters:
+        type (str): application type: 'graph' or 'word graph' ('knowledge graph' and 'visualization' belong to other
+            solvers of the reference and are not part of this package)
+    """
+
+    application = {"graph": GraphApplication, "word graph": WordGraphApplication}
+
+    def __new__(cls, type, *args, **kwargs):
+        if type in cls.application:
+            return cls.application[type](*args, **kwargs)
+        raise ValueError("Unknown application `%s`" % type)

@@ -34,14 +34,15 @@ def load_config(config_file):
 def run_main(args):
     cfg = load_config(args.config)
     init_logging(logging.INFO)
-    if cfg.get("application", "graph") != "graph":
-        raise ValueError("only the `graph` (node embedding) application is implemented")
+    kind = cfg.get("application", "graph")
+    if kind not in application.Application.application:
+        raise ValueError("only the `graph` and `word graph` (node embedding) applications are implemented, not `%s`" % kind)
     resource = dict(cfg.get("resource", {}))
     if args.gpu is not None:
         resource["gpus"] = [args.gpu]
     if args.cpu is not None:
         resource["cpu_per_gpu"] = args.cpu
-    app = application.GraphApplication(**resource)
+    app = application.Application(kind, **resource)
     if "format" in cfg:
         app.set_format(**cfg["format"])
     app.load(**cfg["graph"])

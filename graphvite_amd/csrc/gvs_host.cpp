@@ -283,6 +283,95 @@ int gvs_graph_load_file(gvs_graph *g, const char *file_name, int as_undirected, 
     });
 }
 
+// WordGraph::load_file_compact (include/instance/word_graph.cuh:73-181): a corpus becomes the graph of word
+// co-occurrences within `window` tokens of a line; repeated co-occurrences add up in the edge weight.  Two passes over
+// the file like the reference (frequencies, then pairs), but the pair counts live in ONE hash map keyed by (u, v) next
+// to an insertion-ordered edge list — finalize() then groups them by source — instead of one hash map per vertex.
+// The reference leaves the order of a vertex's neighbours to unordered_map iteration; here it is first co-occurrence.
+int gvs_graph_load_corpus(gvs_graph *g, const char *file_name, int window, int min_count, int normalization,
+                          const char *delimiters, const char *comment) {
+    if (!g || !file_name) return gvk_fail(GVK_EINVAL, "gvs_graph_load_corpus: null argument");
+    if (window < 0) return gvk_fail(GVK_EINVAL, "gvs_graph_load_corpus: negative window");
+    if (!delimiters) delimiters = " \t\r\n";
+    if (!comment) comment = "#";
+    return guarded("gvs_graph_load_corpus", [&]() {
+        FILE *fin = fopen(file_name, "r");
+        if (!fin) return gvk_fail(GVK_EINVAL, "File `%s` doesn't exist", file_name);
+        g->clear();
+        g->as_undirected = true;
+        g->normalization = normalization != 0;
+        char *line = nullptr;
+        size_t cap = 0;
+        auto strip_comment = [&](char *text) {
+            if (*comment) {
+                char *c = strstr(text, comment);
+                if (c) *c = 0;
+            }
+        };
+        // pass 1: word frequencies, ids in first-seen order
+        std::unordered_map<std::string, uint32_t> seen;
+        std::vector<std::string> words;
+        std::vector<uint64_t> frequency;
+        while (getline(&line, &cap, fin) >= 0) {
+            strip_comment(line);
+            char *cursor = line;
+            while (char *word = next_token(&cursor, delimiters)) {
+                auto it = seen.find(word);
+                if (it != seen.end()) {
+                    frequency[it->second]++;
+                } else {
+                    seen.emplace(word, (uint32_t)words.size());
+                    words.emplace_back(word);
+                    frequency.push_back(1);
+                }
+            }
+        }
+        decltype(seen)().swap(seen);
+        for (size_t i = 0; i < words.size(); i++)
+            if (frequency[i] >= (uint64_t)std::max(min_count, 0)) g->id_of_name(words[i].c_str());
+        decltype(words)().swap(words);
+        decltype(frequency)().swap(frequency);
+        // pass 2: co-occurrence counts
+        std::unordered_map<uint64_t, uint64_t> edge_of;  // (u << 32 | v) -> index into src / dst / w
+        auto count = [&](uint32_t u, uint32_t v) {
+            const uint64_t key = ((uint64_t)u << 32) | v;
+            auto it = edge_of.find(key);
+            if (it == edge_of.end()) {
+                edge_of.emplace(key, g->src.size());
+                g->src.push_back(u);
+                g->dst.push_back(v);
+                g->w.push_back(1.f);
+            } else {
+                g->w[it->second] += 1.f;
+            }
+        };
+        rewind(fin);
+        std::vector<uint32_t> sentence;
+        while (getline(&line, &cap, fin) >= 0) {
+            strip_comment(line);
+            sentence.clear();
+            char *cursor = line;
+            while (char *word = next_token(&cursor, delimiters)) {
+                auto it = g->name2id.find(word);
+                if (it != g->name2id.end()) sentence.push_back(it->second);
+            }
+            for (size_t i = 0; i < sentence.size(); i++)
+                for (size_t j = 1; j <= (size_t)window && i + j < sentence.size(); j++) {
+                    const uint32_t u = sentence[i], v = sentence[i + j];
+                    count(u, v);
+                    count(v, u);
+                    g->vertex_weights[u] += 1.f;
+                    g->vertex_weights[v] += 1.f;
+                }
+        }
+        free(line);
+        fclose(fin);
+        g->num_edge = g->src.size();  // every (u, v) entry counts, both directions (word_graph.cuh:156-160)
+        g->finalize();
+        return GVK_OK;
+    });
+}
+
 int gvs_graph_load_names(gvs_graph *g, const char *const *u_names, const char *const *v_names, const float *weights,
                          size_t n, int as_undirected, int normalization) {
     if (!g || (n && (!u_names || !v_names))) return gvk_fail(GVK_EINVAL, "gvs_graph_load_names: null argument");

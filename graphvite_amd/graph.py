@@ -185,3 +185,40 @@ class Graph(object):
             io.yes_no(self.normalization))
 
     __repr__ = info
+
+
+class WordGraph(Graph):
+    """
+    WordGraph(index_type=dtype.uint32)
+    Normal graphs of word co-occurrences (include/bind.h:189-234, include/instance/word_graph.cuh).
+
+    Parameters:
+        index_type (dtype): type of node indexes
+    """
+
+    def load(self, file_name, window=5, min_count=5, normalization=False, delimiters=" \t\r\n", comment="#"):
+        """
+        load(file_name, window=5, min_count=5, normalization=False, delimiters=' \\t\\r\\n', comment='#')
+        Load a word graph from a corpus file (one sentence per line).
+
+        Parameters:
+            file_name (str): file name
+            window (int, optional): word pairs with distance <= window are counted as edges
+            min_count (int, optional): words with occurrence < min_count are discarded
+            normalization (bool, optional): normalize the adjacency matrix or not
+            delimiters (str, optional): string of delimiter characters
+            comment (str, optional): prefix of comment strings
+        """
+        logger.info("generating graph from corpus %s", file_name)
+        rc = self._lib.gvs_graph_load_corpus(self._handle, file_name.encode() if isinstance(file_name, str) else file_name,
+                                             int(window), int(min_count), bool(normalization), delimiters.encode(),
+                                             comment.encode())
+        _lib.check(rc, "WordGraph.load")
+        logger.warning(io.block(repr(self)))
+
+    def info(self):
+        return "WordGraph<%s>\n%s\n#vertex: %d, #edge: %d\nas undirected: %s, normalization: %s" % (
+            "uint32", io.header("Graph"), self.num_vertex, self.num_edge, io.yes_no(self.as_undirected),
+            io.yes_no(self.normalization))
+
+    __repr__ = info

@@ -51,6 +51,11 @@ int gvs_graph_load_names(gvs_graph *g, const char *const *u_names, const char *c
 /* Edge list of integer labels (the name of a vertex is the decimal form of its label). Same id assignment. */
 int gvs_graph_load_labels(gvs_graph *g, const uint32_t *u_labels, const uint32_t *v_labels, const float *weights,
                           size_t n, int as_undirected, int normalization);
+/* WordGraph::load_file_compact (include/instance/word_graph.cuh:73-181): the graph of word co-occurrences of a corpus,
+ * one sentence per line; words seen fewer than min_count times are dropped, every pair of kept words at most `window`
+ * tokens apart adds 1 to the weight of (u, v) and of (v, u).  num_edge counts both directions, as the reference does. */
+int gvs_graph_load_corpus(gvs_graph *g, const char *file_name, int window, int min_count, int normalization,
+                          const char *delimiters, const char *comment);
 int gvs_graph_save(const gvs_graph *g, const char *file_name, int weighted, int anonymous);
 
 uint32_t gvs_graph_num_vertex(const gvs_graph *g);

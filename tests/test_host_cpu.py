@@ -451,3 +451,80 @@ def test_alias_table_reconstructs_the_distribution(seed):
     np.testing.assert_allclose(mass, want, atol=2e-4 * max(1.0, want.max()))
     assert (mass[w == 0] < 1e-4).all()
     assert ((prob >= 0) & (prob <= 1.0 + 1e-3)).all() and (alias < n).all()  # residual rounding may exceed 1 slightly
+
+
+def _corpus_oracle(lines, window, min_count, delimiters=" \t\r\n", comment="#"):
+    """Plain restatement of WordGraph::load_file_compact (include/instance/word_graph.cuh:73-181)."""
+    import re
+    split = re.compile("[%s]+" % re.escape(delimiters))
+    sentences = []
+    for line in lines:
+        if comment and comment in line:
+            line = line[:line.index(comment)]
+        sentences.append([t for t in split.split(line) if t])
+    frequency, order = {}, []
+    for words in sentences:
+        for word in words:
+            if word not in frequency:
+                order.append(word)
+            frequency[word] = frequency.get(word, 0) + 1
+    names = [word for word in order if frequency[word] >= min_count]
+    ids = {word: i for i, word in enumerate(names)}
+    weight, vertex_weight = {}, [0.0] * len(names)
+    for words in sentences:
+        s = [ids[word] for word in words if word in ids]
+        for i in range(len(s)):
+            for j in range(1, window + 1):
+                if i + j >= len(s):
+                    break
+                u, v = s[i], s[i + j]
+                weight[(u, v)] = weight.get((u, v), 0) + 1
+                weight[(v, u)] = weight.get((v, u), 0) + 1
+                vertex_weight[u] += 1
+                vertex_weight[v] += 1
+    return names, weight, vertex_weight
+
+
+@pytest.mark.parametrize("window,min_count", [(5, 1), (2, 3), (1, 2), (0, 1)])
+def test_word_graph_from_corpus(tmp_path, window, min_count):
+    rng = np.random.default_rng(window * 10 + min_count)
+    vocab = ["w%d" % i for i in range(40)]
+    lines = []
+    for _ in range(60):
+        n = int(rng.integers(0, 25))
+        words = [vocab[int(min(rng.zipf(1.4), 40)) - 1] for _ in range(n)]
+        lines.append(" ".join(words) + ("  # trailing comment w0 w0" if rng.random() < 0.2 else ""))
+    lines.append("the the the the")  # a word next to itself: both directions land on the same entry
+    path = tmp_path / "corpus.txt"
+    path.write_text("\n".join(lines) + "\n")
+    names, weight, vertex_weight = _corpus_oracle(lines, window, min_count)
+
+    g = gv.graph.WordGraph()
+    g.load(str(path), window=window, min_count=min_count)
+    assert repr(g).startswith("WordGraph<uint32>") and g.as_undirected and not g.normalization
+    assert g.num_vertex == len(names) and [g.id2name[i] for i in range(g.num_vertex)] == names
+    assert g.num_edge == len(weight) == g.num_directed_edge  # both directions are counted (word_graph.cuh:156-160)
+    got = {(int(u), int(v)): float(w) for (u, v), w in zip(g.edges.tolist(), g.edge_weights.tolist())}
+    assert got == {k: float(v) for k, v in weight.items()}
+    np.testing.assert_array_equal(g.vertex_weights, np.array(vertex_weight, np.float32))
+    fo = g.flat_offsets
+    assert (np.diff(g.edges[:, 0].astype(np.int64)) >= 0).all() and fo[-1] == len(weight)  # CSR by source
+
+    gn = gv.graph.WordGraph()
+    gn.load(str(path), window=window, min_count=min_count, normalization=True)
+    if len(weight):
+        out_w = np.array(vertex_weight)
+        in_w = np.zeros(len(names))
+        for (u, v), w in weight.items():
+            in_w[v] += w
+        want = {k: w / np.sqrt(out_w[k[0]] * in_w[k[1]]) for k, w in weight.items()}  # graph.cuh:103-121
+        gotn = {(int(u), int(v)): float(w) for (u, v), w in zip(gn.edges.tolist(), gn.edge_weights.tolist())}
+        assert gotn.keys() == want.keys()
+        for k in want:
+            assert gotn[k] == pytest.approx(want[k], rel=1e-5)
+    with pytest.raises(ValueError):
+        g.load(str(tmp_path / "missing.txt"))
+    # a word graph trains through the same solver (WordGraphApplication)
+    assert isinstance(gv.application.Application("word graph", dim=32), gv.application.WordGraphApplication)
+    with pytest.raises(ValueError):
+        gv.application.Application("knowledge graph", dim=32)

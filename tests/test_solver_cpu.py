@@ -469,3 +469,29 @@ def test_grouped_pair_order_over_gloo(tmp_path, model, aug):
     assert (r[0]["v"] == r[1]["v"]).all() and (r[0]["c"] == r[1]["c"]).all()
     ids = np.sort(np.concatenate([r[0]["ids"], r[1]["ids"]]))
     assert (ids == np.arange(len(ids))).all() and np.abs(r[0]["c"]).max() > 0
+
+
+def test_word_graph_application_trains_a_corpus(tmp_path):
+    """WordGraphApplication (application.py:536-573): corpus -> co-occurrence graph -> the same GraphSolver path."""
+    rng = np.random.default_rng(0)
+    topics = [["cat", "dog", "pet", "vet", "fur"], ["gpu", "hbm", "wave", "lane", "simd"]]
+    lines = [" ".join(rng.choice(topics[i % 2], 12)) for i in range(400)]
+    path = tmp_path / "corpus.txt"
+    path.write_text("\n".join(lines) + "\n")
+    real = gv.application.GraphApplication.get_solver
+    gv.application.GraphApplication.get_solver = lambda self, **kw: gv.solver.GraphSolver(
+        self.dim, kernels=OracleKernels(), num_sampler_per_worker=2)
+    try:
+        app = gv.application.Application("word graph", dim=32)
+        app.load(file_name=str(path), window=3, min_count=5)
+        app.build(batch_size=200, episode_size=5)
+        app.train(model="LINE", num_epoch=300, augmentation_step=1, log_frequency=1 << 30)
+    finally:
+        gv.application.GraphApplication.get_solver = real
+    assert isinstance(app.graph, gv.graph.WordGraph) and app.graph.num_vertex == 10
+    v, c = app.solver.vertex_embeddings, app.solver.context_embeddings
+    score = v @ c.T
+    ids = [[app.graph.name2id[w] for w in topic] for topic in topics]
+    inside = np.mean([score[np.ix_(t, t)].mean() for t in ids])
+    across = np.mean([score[np.ix_(ids[0], ids[1])].mean(), score[np.ix_(ids[1], ids[0])].mean()])
+    assert inside > across + 0.5  # words of a topic co-occur, words of different topics never do
