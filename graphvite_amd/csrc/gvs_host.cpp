@@ -63,7 +63,8 @@ struct HugeAllocator {
         const size_t rounded = (bytes + kHuge - 1) / kHuge * kHuge;
         void *p = mmap(nullptr, rounded, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (p == MAP_FAILED) throw std::bad_alloc();
-        madvise(p, rounded, MADV_HUGEPAGE);
+        static const bool huge = getenv("GVS_NO_HUGEPAGE") == nullptr;
+        if (huge) madvise(p, rounded, MADV_HUGEPAGE);
         return static_cast<T *>(p);
     }
     void deallocate(T *p, size_t n) {
@@ -83,12 +84,98 @@ using HugeVector = std::vector<T, HugeAllocator<T>>;
 
 // ---- graph ---------------------------------------------------------------------------------------------
 
+// name -> id for the text loaders.  A billion-edge list is two lookups per line into a table of up to 10^8 names, each
+// a cache miss: std::unordered_map<std::string, ...> pays three or four of them (bucket, node, key bytes — 0.8 us per
+// lookup measured on 1M names) plus a temporary std::string.  Here a probe touches ONE 32-byte slot that holds the
+// 64-bit hash, the id and the name itself when it has at most 18 bytes (node names almost always do); longer names
+// are compared against id2name.  Linear probing, power-of-two capacity, at most half full.
+class NameTable {
+public:
+    static constexpr uint32_t kNone = 0xffffffffu;
+
+    void clear() {
+        decltype(slots_)().swap(slots_);
+        count_ = 0;
+    }
+    size_t size() const { return count_; }
+
+    uint32_t find(const char *name, size_t len, const std::vector<std::string> &id2name) const {
+        if (slots_.empty()) return kNone;
+        const uint64_t h = hash(name, len);
+        for (size_t i = h & (slots_.size() - 1);; i = (i + 1) & (slots_.size() - 1)) {
+            const Slot &s = slots_[i];
+            if (s.id == kNone) return kNone;
+            if (s.hash == h && equal(s, name, len, id2name)) return s.id;
+        }
+    }
+
+    // name must not be present
+    void insert(const char *name, size_t len, uint32_t id) {
+        if ((count_ + 1) * 2 > slots_.size()) grow();
+        Slot s;
+        s.hash = hash(name, len);
+        s.id = id;
+        s.len = (uint8_t)(len <= kInline ? len : 255);
+        memset(s.text, 0, sizeof(s.text));
+        if (len <= kInline) memcpy(s.text, name, len);
+        place(s);
+        count_++;
+    }
+
+private:
+    static constexpr size_t kInline = 18;
+    struct Slot {
+        uint64_t hash;
+        uint32_t id = kNone;
+        uint8_t len;
+        char text[kInline + 1];
+    };
+    static_assert(sizeof(Slot) == 32, "one slot = half a cache line");
+
+    HugeVector<Slot> slots_;
+    size_t count_ = 0;
+
+    static uint64_t hash(const char *p, size_t len) {  // 8 bytes at a time, multiply-fold (wyhash-style mixing)
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (len * 0xff51afd7ed558ccdull);
+        while (len >= 8) {
+            uint64_t k;
+            memcpy(&k, p, 8);
+            h = mix(h ^ k);
+            p += 8, len -= 8;
+        }
+        uint64_t k = 0;
+        memcpy(&k, p, len);
+        return mix(h ^ k ^ ((uint64_t)len << 56));
+    }
+    static uint64_t mix(uint64_t x) {
+        const __uint128_t m = (__uint128_t)x * 0xD6E8FEB86659FD93ull;
+        return (uint64_t)m ^ (uint64_t)(m >> 64);
+    }
+    static bool equal(const Slot &s, const char *name, size_t len, const std::vector<std::string> &id2name) {
+        if (s.len != 255) return s.len == len && memcmp(s.text, name, len) == 0;
+        const std::string &full = id2name[s.id];
+        return full.size() == len && memcmp(full.data(), name, len) == 0;
+    }
+    void place(const Slot &s) {
+        size_t i = s.hash & (slots_.size() - 1);
+        while (slots_[i].id != kNone) i = (i + 1) & (slots_.size() - 1);
+        slots_[i] = s;
+    }
+    void grow() {
+        HugeVector<Slot> old;
+        old.swap(slots_);
+        slots_.resize(old.empty() ? 1024 : old.size() * 2);
+        for (const Slot &s : old)
+            if (s.id != kNone) place(s);
+    }
+};
+
 struct gvs_graph {
     uint32_t num_vertex = 0;
     uint64_t num_edge = 0;
     bool as_undirected = true, normalization = false;
     bool label_mode = false;
-    std::unordered_map<std::string, uint32_t> name2id;
+    NameTable name2id;
     std::vector<std::string> id2name;
     std::unordered_map<uint32_t, uint32_t> label2id;
     std::vector<uint32_t> labels;
@@ -105,7 +192,7 @@ struct gvs_graph {
         num_vertex = 0;
         num_edge = 0;
         label_mode = false;
-        decltype(name2id)().swap(name2id);
+        name2id.clear();
         decltype(id2name)().swap(id2name);
         decltype(label2id)().swap(label2id);
         decltype(dense_label2id)().swap(dense_label2id);
@@ -120,11 +207,12 @@ struct gvs_graph {
     }
 
     uint32_t id_of_name(const char *name) {
-        auto it = name2id.find(name);
-        if (it != name2id.end()) return it->second;
+        const size_t len = strlen(name);
+        const uint32_t known = name2id.find(name, len, id2name);
+        if (known != NameTable::kNone) return known;
         uint32_t id = num_vertex++;
-        name2id.emplace(name, id);
-        id2name.emplace_back(name);
+        id2name.emplace_back(name, len);
+        name2id.insert(name, len, id);
         vertex_weights.push_back(0);
         return id;
     }
@@ -246,6 +334,7 @@ int gvs_graph_load_file(gvs_graph *g, const char *file_name, int as_undirected, 
     return guarded("gvs_graph_load_file", [&]() {
         FILE *fin = fopen(file_name, "r");
         if (!fin) return gvk_fail(GVK_EINVAL, "File `%s` doesn't exist", file_name);
+        const auto t_start = std::chrono::steady_clock::now();
         g->clear();
         g->as_undirected = as_undirected != 0;
         g->normalization = normalization != 0;
@@ -278,7 +367,12 @@ int gvs_graph_load_file(gvs_graph *g, const char *file_name, int as_undirected, 
             g->clear();
             return rc;
         }
+        const auto t_parsed = std::chrono::steady_clock::now();
         g->finalize();
+        if (getenv("GVS_TIMING"))
+            fprintf(stderr, "[gvs] load_file: parse %.2f s, flatten %.2f s\n",
+                    std::chrono::duration<double>(t_parsed - t_start).count(),
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_parsed).count());
         return GVK_OK;
     });
 }
@@ -352,8 +446,8 @@ int gvs_graph_load_corpus(gvs_graph *g, const char *file_name, int window, int m
             sentence.clear();
             char *cursor = line;
             while (char *word = next_token(&cursor, delimiters)) {
-                auto it = g->name2id.find(word);
-                if (it != g->name2id.end()) sentence.push_back(it->second);
+                const uint32_t id = g->name2id.find(word, strlen(word), g->id2name);
+                if (id != NameTable::kNone) sentence.push_back(id);
             }
             for (size_t i = 0; i < sentence.size(); i++)
                 for (size_t j = 1; j <= (size_t)window && i + j < sentence.size(); j++) {
@@ -453,8 +547,8 @@ int64_t gvs_graph_name2id(const gvs_graph *g, const char *name) {
         auto it = g->label2id.find((uint32_t)label);
         return it == g->label2id.end() ? -1 : (int64_t)it->second;
     }
-    auto it = g->name2id.find(name);
-    return it == g->name2id.end() ? -1 : (int64_t)it->second;
+    const uint32_t id = g->name2id.find(name, strlen(name), g->id2name);
+    return id == NameTable::kNone ? -1 : (int64_t)id;
 }
 
 int64_t gvs_graph_id2name(const gvs_graph *g, uint32_t id, char *buf, size_t buflen) {
