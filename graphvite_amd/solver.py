@@ -808,26 +808,64 @@ class GraphSolver(object):
         state["positive_index"] = 0
 
     def _train_episode_device_sampling(self, state):
+        """One episode with the positive samples drawn on the device.  Same pipeline as `_train_episode`, with a
+        sampling kernel where that one has an H2D copy: block g's pool is drawn (and regrouped, pair_order "grouped")
+        into device buffer g & 1 on the copy stream while block g - 1 trains on the compute stream."""
         n = self.episode_size * self.batch_size
         seed = (self.seed * 0x9E3779B1 + 0x706f73 + self.rank) & (2 ** 64 - 1)
-        if self._mode != "edge":  # single partition: one block, walks drawn on the device
-            pool = state["pool_dev"][0]
-            L, aug = self.random_walk_length, self.augmentation_step
-            self.kernels.sample_walks(state["walk_graph"], seed, state["positive_index"], pool, n, L, aug,
-                                      self.shuffle_base)
-            per_walk = aug * L - aug * (aug - 1) // 2
-            state["positive_index"] += (n + per_walk - 1) // per_walk
-            self._train_block(state, 0, 0, pool)
-            return
-        for i, step in enumerate(self._schedule):
-            hp, tp = int(step[self.rank][0]), int(step[self.rank][1])
-            table, pairs = state["block_tables"][(hp, tp)]
-            pool = state["pool_dev"][i & 1]
-            self.kernels.sample_pairs(table, pairs, seed, state["positive_index"], pool, n)
-            state["positive_index"] += n
-            self._train_block(state, hp, tp, pool)
+        cuda = self.device.type == "cuda"
+        walks = self._mode != "edge"  # single partition: one block, walks drawn on the device
+        steps = [(0, 0)] if walks else [(int(s[self.rank][0]), int(s[self.rank][1])) for s in self._schedule]
+        ready = state.setdefault("uploaded", [None, None])      # per device buffer: its pool has been drawn
+        released = state.setdefault("released", [None, None])   # per device buffer: its last reader has finished
+        base = state.get("global_step", 0)
+
+        def draw(g, block):
+            """Pool of `block` for global step g into device buffer g & 1 (on the current stream)."""
+            buf = state["pool_dev"][g & 1]
+            landing = state.get("pool_stage", buf)
+            if walks:
+                L, aug = self.random_walk_length, self.augmentation_step
+                self.kernels.sample_walks(state["walk_graph"], seed, state["positive_index"], landing, n, L, aug,
+                                          self.shuffle_base)
+                per_walk = aug * L - aug * (aug - 1) // 2
+                state["positive_index"] += (n + per_walk - 1) // per_walk
+            else:
+                table, pairs = state["block_tables"][block]
+                self.kernels.sample_pairs(table, pairs, seed, state["positive_index"], landing, n)
+                state["positive_index"] += n
+            self._group_pairs(landing, buf)
+
+        def produce(g, block):
+            if not cuda:
+                return draw(g, block)
+            with torch.cuda.stream(state["copy_stream"]):
+                if released[g & 1] is not None:
+                    state["copy_stream"].wait_event(released[g & 1])
+                draw(g, block)
+                ready[g & 1] = torch.cuda.Event()
+                ready[g & 1].record()
+
+        per_episode = len(steps) * self.episode_size * self.positive_reuse * self.num_worker
+        if state.get("produced_for") != base:  # the first pool of a training run; later ones are drawn one block ahead
+            produce(base, steps[0])
+        for i, (hp, tp) in enumerate(steps):
+            g = base + i
+            compute = torch.cuda.current_stream(self.device) if cuda else None
+            if cuda:
+                compute.wait_event(ready[g & 1])
+            if i + 1 < len(steps):
+                produce(g + 1, steps[i + 1])
+            elif self.batch_id + per_episode < self.num_batch:  # next episode's first block, while this one's last trains
+                produce(g + 1, steps[0])
+                state["produced_for"] = g + 1
+            self._train_block(state, hp, tp, state["pool_dev"][g & 1])
+            if cuda:
+                released[g & 1] = torch.cuda.Event()
+                released[g & 1].record(compute)
             if self.num_worker > 1:
                 self._exchange(state, i)
+        state["global_step"] = base + len(steps)
 
     # ---- one episode ----------------------------------------------------------------------------------------
     def _train_episode(self, state, pools):
