@@ -398,11 +398,16 @@ def test_rows_beyond_4_gib(hip, oracle):
     assert float(tv[:lo].abs().max()) == 0.0 and float(tc[:lo].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("nb,B,rows", [(1, 1, 2), (3, 1000, 777), (7, 4097, 1 << 20), (217, 100000, 1000000)])
+@pytest.mark.parametrize("nb,B,rows", [(1, 1, 2), (3, 1000, 777), (7, 4097, 1 << 20), (217, 100000, 1000000),
+                                       (2, 5001, 1 << 24), (2, 3000, 2 ** 31), (1, 70000, 2 ** 32)])
 def test_group_pairs_is_a_stable_per_batch_sort_on_head(hip, nb, B, rows):
+    """1, 2, 3 and 4 counting passes (10 bits of the head row per pass); ties keep their input order."""
     rng = np.random.default_rng(nb * B)
-    pool = np.stack([rng.integers(0, 2 ** 32, nb * B, dtype=np.uint64).astype(np.uint32),
-                     (rng.pareto(1.2, nb * B) * 20).astype(np.uint64).astype(np.uint32) % np.uint32(rows)], 1)
+    if rows > 1 << 20:  # heads all over the row range, with repeats
+        heads = rng.integers(0, rows, max(nb * B // 3, 1), dtype=np.uint64)[rng.integers(0, max(nb * B // 3, 1), nb * B)]
+    else:
+        heads = (rng.pareto(1.2, nb * B) * 20).astype(np.uint64) % np.uint64(rows)
+    pool = np.stack([rng.integers(0, 2 ** 32, nb * B, dtype=np.uint64).astype(np.uint32), heads.astype(np.uint32)], 1)
     tin, tout = dev(pool.view(np.int32)), torch.zeros((nb * B, 2), dtype=torch.int32, device=DEV)
     hip.group_pairs(tin, tout, B, nb, rows)
     torch.cuda.synchronize()
