@@ -63,6 +63,9 @@ def parse():
     p.add_argument("--partitions", type=int, default=0,
                    help="experiment: vertex partitions (default: 1 on one GPU, 2 x #GPU otherwise); on one GPU this shows "
                         "the kernel at the shard size of a multi-GPU run")
+    p.add_argument("--host-order", choices=["head", "head+tail", "tail"], default=None,
+                   help="experiment: batches pre-ordered on the host (no device pass): by head row; by head row with the "
+                        "pairs whose head is unique in the batch ordered by tail row instead; by tail row")
     p.add_argument("--xcd-sorted", action="store_true",
                    help="experiment: with --xcd-bucket, also sort each bucket by row (same-row pairs adjacent in time)")
     p.add_argument("--pair-order", choices=["auto", "sampled", "grouped"], default="auto",
@@ -165,7 +168,7 @@ def main():
         graph.load(synthetic.community_edges(N, E, num_community=max(N // 1000, 1), seed=args.seed))
     else:
         graph.load(synthetic.power_law_edges(N, E, seed=args.seed))
-    if args.xcd_bucket or args.xcd_sorted:
+    if args.xcd_bucket or args.xcd_sorted or args.host_order:
         args.pair_order = "sampled"  # the placement experiments lay the batches out themselves
     stand_in = None
     if not cuda:
@@ -191,6 +194,23 @@ def main():
     session.fill(pools)
     fill_s = time.perf_counter() - t0
     blocks = session.blocks
+    if args.host_order:
+        for pool in pools.values():
+            rec = pool.numpy().view(np.uint32).reshape(-1, B, 2)
+            for i in range(rec.shape[0]):
+                r = rec[i]
+                if args.host_order == "tail":
+                    rec[i] = r[np.argsort(r[:, 0], kind="stable")]
+                    continue
+                r = r[np.argsort(r[:, 1], kind="stable")]
+                if args.host_order == "head+tail":
+                    h = r[:, 1]
+                    single = np.ones(B, bool)
+                    single[1:] &= h[1:] != h[:-1]
+                    single[:-1] &= h[:-1] != h[1:]
+                    lone = r[single]
+                    r = np.concatenate([r[~single], lone[np.argsort(lone[:, 0], kind="stable")]])
+                rec[i] = r
     if args.xcd_sorted and not args.xcd_bucket:  # experiment: whole batch sorted by head row, no XCD placement
         for pool in pools.values():
             rec = pool.numpy().view(np.uint32).reshape(-1, B, 2)
