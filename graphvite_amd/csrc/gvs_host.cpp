@@ -99,9 +99,18 @@ public:
     }
     size_t size() const { return count_; }
 
+    static uint64_t hash_of(const char *name, size_t len) { return hash(name, len); }
+    // start fetching the slot a name with this hash would probe first (the table may still grow before the lookup —
+    // then the prefetch was for nothing, which is harmless)
+    void prefetch(uint64_t h) const {
+        if (!slots_.empty()) __builtin_prefetch(&slots_[h & (slots_.size() - 1)]);
+    }
+
     uint32_t find(const char *name, size_t len, const std::vector<std::string> &id2name) const {
+        return find(name, len, hash(name, len), id2name);
+    }
+    uint32_t find(const char *name, size_t len, uint64_t h, const std::vector<std::string> &id2name) const {
         if (slots_.empty()) return kNone;
-        const uint64_t h = hash(name, len);
         for (size_t i = h & (slots_.size() - 1);; i = (i + 1) & (slots_.size() - 1)) {
             const Slot &s = slots_[i];
             if (s.id == kNone) return kNone;
@@ -110,10 +119,11 @@ public:
     }
 
     // name must not be present
-    void insert(const char *name, size_t len, uint32_t id) {
+    void insert(const char *name, size_t len, uint32_t id) { insert(name, len, hash(name, len), id); }
+    void insert(const char *name, size_t len, uint64_t h, uint32_t id) {
         if ((count_ + 1) * 2 > slots_.size()) grow();
         Slot s;
-        s.hash = hash(name, len);
+        s.hash = h;
         s.id = id;
         s.len = (uint8_t)(len <= kInline ? len : 255);
         memset(s.text, 0, sizeof(s.text));
@@ -208,11 +218,14 @@ struct gvs_graph {
 
     uint32_t id_of_name(const char *name) {
         const size_t len = strlen(name);
-        const uint32_t known = name2id.find(name, len, id2name);
+        return id_of_name(name, len, NameTable::hash_of(name, len));
+    }
+    uint32_t id_of_name(const char *name, size_t len, uint64_t hash) {
+        const uint32_t known = name2id.find(name, len, hash, id2name);
         if (known != NameTable::kNone) return known;
         uint32_t id = num_vertex++;
         id2name.emplace_back(name, len);
-        name2id.insert(name, len, id);
+        name2id.insert(name, len, hash, id);
         vertex_weights.push_back(0);
         return id;
     }
@@ -338,30 +351,59 @@ int gvs_graph_load_file(gvs_graph *g, const char *file_name, int as_undirected, 
         g->clear();
         g->as_undirected = as_undirected != 0;
         g->normalization = normalization != 0;
-        char *line = nullptr;
-        size_t cap = 0;
+        // Two name lookups per line, each a cache miss into a table of up to 10^8 names: lines are tokenised and hashed
+        // kLookahead lines before their ids are resolved, with the table slots of both names prefetched meanwhile.
+        // Ids are still assigned in the order of the file.
+        constexpr int kLookahead = 16;
+        struct Parsed {
+            char *text = nullptr;
+            size_t cap = 0;
+            char *u_name, *v_name;
+            size_t u_len, v_len;
+            uint64_t u_hash, v_hash;
+            float weight;
+        } ring[kLookahead];
         int rc = GVK_OK;
-        for (size_t i = 1; getline(&line, &cap, fin) >= 0; i++) {
-            if (*comment) {
-                char *c = strstr(line, comment);
-                if (c) *c = 0;
+        size_t line_number = 0, head = 0, tail = 0;  // ring[head % k .. tail % k) are parsed and waiting
+        bool eof = false;
+        auto resolve = [&](const Parsed &p) {
+            const uint32_t u = g->id_of_name(p.u_name, p.u_len, p.u_hash);
+            const uint32_t v = g->id_of_name(p.v_name, p.v_len, p.v_hash);
+            g->add_edge(u, v, p.weight);
+        };
+        while (rc == GVK_OK && (!eof || head < tail)) {
+            if (!eof && tail - head < (size_t)kLookahead) {
+                Parsed &p = ring[tail % kLookahead];
+                if (getline(&p.text, &p.cap, fin) < 0) {
+                    eof = true;
+                    continue;
+                }
+                line_number++;
+                if (*comment) {
+                    char *c = strstr(p.text, comment);
+                    if (c) *c = 0;
+                }
+                char *cursor = p.text;
+                p.u_name = next_token(&cursor, delimiters);
+                if (!p.u_name) continue;
+                p.v_name = next_token(&cursor, delimiters);
+                char *w_str = next_token(&cursor, delimiters);
+                char *more = next_token(&cursor, delimiters);
+                if (!p.v_name || more) {
+                    rc = gvk_fail(GVK_EINVAL, "Invalid format at line %zu of `%s`", line_number, file_name);
+                    break;
+                }
+                p.weight = w_str ? (float)atof(w_str) : 1.f;
+                p.u_len = strlen(p.u_name), p.v_len = strlen(p.v_name);
+                p.u_hash = NameTable::hash_of(p.u_name, p.u_len), p.v_hash = NameTable::hash_of(p.v_name, p.v_len);
+                g->name2id.prefetch(p.u_hash);
+                g->name2id.prefetch(p.v_hash);
+                tail++;
+                continue;
             }
-            char *cursor = line;
-            char *u_name = next_token(&cursor, delimiters);
-            if (!u_name) continue;
-            char *v_name = next_token(&cursor, delimiters);
-            char *w_str = next_token(&cursor, delimiters);
-            char *more = next_token(&cursor, delimiters);
-            if (!v_name || more) {
-                rc = gvk_fail(GVK_EINVAL, "Invalid format at line %zu of `%s`", i, file_name);
-                break;
-            }
-            const float weight = w_str ? (float)atof(w_str) : 1.f;
-            const uint32_t u = g->id_of_name(u_name);
-            const uint32_t v = g->id_of_name(v_name);
-            g->add_edge(u, v, weight);
+            resolve(ring[head++ % kLookahead]);
         }
-        free(line);
+        for (Parsed &p : ring) free(p.text);
         fclose(fin);
         if (rc != GVK_OK) {
             g->clear();
