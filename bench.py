@@ -42,7 +42,7 @@ def algorithmic_bytes(dim, k):
     return 8 * dim * (k + 2) + 16
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=400)
@@ -71,9 +71,6 @@ def parse():
     p.add_argument("--pair-order", choices=["auto", "sampled", "grouped"], default="auto",
                    help="GraphSolver(pair_order=...): auto (the product default) regroups the pairs of a batch by head "
                         "row on the device when a partition's table reaches 16 MiB")
-    p.add_argument("--dry-run-cpu", action="store_true",
-                   help="LOGIC TEST ONLY (tests/test_api_cpu.py): walk the same loop on the CPU with the test suite's "
-                        "oracle stand-in for the kernels and gloo for the collectives; the numbers mean nothing")
     p.add_argument("--optimizer", choices=["SGD", "Momentum", "AdaGrad", "RMSprop", "Adam"], default="SGD",
                    help="experiment: moment optimizers move (1 + m) x the row bytes (m = 1, Adam 2)")
     p.add_argument("--graph", choices=["power-law", "community"], default="power-law",
@@ -82,7 +79,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=3.0, help="wall seconds given to the CPU baseline")
     p.add_argument("--seed", type=int, default=1024)
-    return p.parse_args()
+    return p.parse_args(argv)
 
 
 def cpu_baseline(args, solver, pool, table_packed):
@@ -122,8 +119,10 @@ def cpu_baseline(args, solver, pool, table_packed):
                       "reference's own LINE::forward/backward + sgd_update)" % (done, B, el, cores, os.cpu_count() or 1)}
 
 
-def main():
-    args = parse()
+def main(argv=None, stand_in_kernels=None):
+    """stand_in_kernels is the test seam of tests/bench_dry_run.py: with a kernel stand-in injected, the same loop runs on
+    the CPU over gloo (a logic test of the multi-rank walk; the JSON line says so).  bench.py itself never sets it."""
+    args = parse(argv)
     import torch
     import torch.distributed as dist
 
@@ -133,7 +132,7 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with `python -m torch.distributed.run "
                          "--nproc-per-node %d ... bench.py --gpus %d`" % (args.gpus, world, args.gpus, args.gpus))
-    cuda = not args.dry_run_cpu
+    cuda = stand_in_kernels is None
     if not cuda:
         args.no_cpu_baseline = True
     if cuda:
@@ -170,12 +169,7 @@ def main():
         graph.load(synthetic.power_law_edges(N, E, seed=args.seed))
     if args.xcd_bucket or args.xcd_sorted or args.host_order:
         args.pair_order = "sampled"  # the placement experiments lay the batches out themselves
-    stand_in = None
-    if not cuda:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from fake_kernels import OracleKernels
-        stand_in = OracleKernels()
-    solver = gv.solver.GraphSolver(dim, num_sampler_per_worker=threads, seed=args.seed, kernels=stand_in, pair_order=gv.auto if args.pair_order == "auto" else args.pair_order)
+    solver = gv.solver.GraphSolver(dim, num_sampler_per_worker=threads, seed=args.seed, kernels=stand_in_kernels, pair_order=gv.auto if args.pair_order == "auto" else args.pair_order)
     if args.lanes:
         solver.kernels.set_lanes_per_pair(args.lanes)
     if args.variant:

@@ -88,7 +88,7 @@ def test_bench_loop_dry_run(world, order):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    args = ["bench.py", "--gpus", str(world), "--dry-run-cpu", "--vertices", "400", "--edges", "4000", "--batch", "200",
+    args = [os.path.join("tests", "bench_dry_run.py"), "--gpus", str(world), "--vertices", "400", "--edges", "4000", "--batch", "200",
             "--dim", "32", "--steps", "23", "--warmup", "3", "--block-batches", "4", "--pair-order", order,
             "--sampler-threads", "1"]
     if world > 1:
