@@ -462,7 +462,9 @@ class GraphSolver(object):
         if model not in self.available_models:
             raise ValueError("Invalid model `%s`" % model)
         if augmentation_step == auto:  # graph.cuh:781-784
-            augmentation_step = int(math.log(kExpectedDegree) / math.log(float(self.num_edge) / self.num_vertex))
+            density = math.log(float(self.num_edge) / self.num_vertex)
+            # as many edges as vertices: the reference divides by log(1) = 0 and fails the checks below on the result
+            augmentation_step = int(math.log(kExpectedDegree) / density) if density else random_walk_length + 1
         if shuffle_base == auto:
             shuffle_base = augmentation_step
         if model in ("DeepWalk", "node2vec"):
