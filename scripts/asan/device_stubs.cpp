@@ -1,0 +1,13 @@
+#include "gvk.h"
+#include "gvk_internal.h"
+extern "C" {
+int gvk_train(void *, int, const gvk_optimizer *, const gvk_tables *, const uint32_t *, const gvk_negative_source *, uint32_t, float *, int, int, float) { return GVK_EHIP; }
+int gvk_train_episode(void *, int, const gvk_optimizer *, int, const gvk_tables *, const uint32_t *, const gvk_negative_source *, uint32_t, uint32_t, uint32_t, int, float *, int, int, float) { return GVK_EHIP; }
+int gvk_predict(void *, int, const float *, const float *, const uint32_t *, float *, int) { return GVK_EHIP; }
+int gvk_alias_sample(void *, const gvk_alias_entry *, uint32_t, const double *, uint32_t *, int) { return GVK_EHIP; }
+int gvk_negative_draw(void *, const gvk_alias_entry *, uint32_t, uint64_t, uint32_t, uint32_t *, int, int) { return GVK_EHIP; }
+int gvk_sample_pairs(void *, const gvk_alias_entry *, const uint32_t *, uint32_t, uint64_t, uint64_t, uint32_t *, size_t) { return GVK_EHIP; }
+int gvk_sample_walks(void *, const gvk_walk_graph *, uint64_t, uint64_t, uint32_t *, size_t, int, int, int) { return GVK_EHIP; }
+int gvk_group_pairs(void *, const uint32_t *, uint32_t *, void *, size_t *, int, int, int) { return GVK_EHIP; }
+int gvk_set_tuning(int, int) { return GVK_OK; }
+}
