@@ -384,7 +384,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_dir, model, aug, num_partition=0, pair_order="sampled"):
+def _worker(rank, world, port, out_dir, model, aug, num_partition=0, pair_order="sampled", device_sampling=False):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world))
@@ -394,7 +394,8 @@ def _worker(rank, world, port, out_dir, model, aug, num_partition=0, pair_order=
         gv.init_logging(logging.ERROR)
         g = make_graph(240, 2400, seed=6)
         k = OracleKernels()
-        s = gv.solver.GraphSolver(32, kernels=k, num_sampler_per_worker=2, seed=9, pair_order=pair_order)
+        s = gv.solver.GraphSolver(32, kernels=k, num_sampler_per_worker=2, seed=9, pair_order=pair_order,
+                                  device_sampling=device_sampling)
         s.build(g, batch_size=400, episode_size=3, num_partition=num_partition)
         assert s.num_worker == world and s.num_partition == (num_partition or world)
         # every pair a worker trains on must be a real (walk) pair of the graph that lives in the block being trained
@@ -495,3 +496,14 @@ def test_word_graph_application_trains_a_corpus(tmp_path):
     inside = np.mean([score[np.ix_(t, t)].mean() for t in ids])
     across = np.mean([score[np.ix_(ids[0], ids[1])].mean(), score[np.ix_(ids[1], ids[0])].mean()])
     assert inside > across + 0.5  # words of a topic co-occur, words of different topics never do
+
+
+def test_device_sampling_over_gloo(tmp_path):
+    """device_sampling=True on 2 workers / 4 partitions (LINE): every worker draws the pools of its own blocks one block
+    ahead (gvk_sample_pairs from the block's alias table), regroups them, trains, exchanges."""
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), "LINE", 1, 4, "grouped", True), nprocs=world, join=True)
+    r = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % i)) for i in range(world)]
+    assert (r[0]["v"] == r[1]["v"]).all() and (r[0]["c"] == r[1]["c"]).all()
+    ids = np.sort(np.concatenate([r[0]["ids"], r[1]["ids"]]))
+    assert (ids == np.arange(len(ids))).all() and len(ids) % (4 * 4 * 3) == 0 and np.abs(r[0]["c"]).max() > 0
