@@ -1,5 +1,6 @@
 """Generates tests/golden/reference_arithmetic.npz from the REFERENCE's own model / optimizer code compiled for
-the host (oracle/ref_harness.cpp -> oracle/_ref/libgvref.so, built from /root/reference/include by oracle/Makefile).
+the host (oracle/ref_harness.cpp -> oracle/_ref/libgvref.so, built from /root/reference/include by oracle/Makefile),
+and tests/golden/reference_alias.npz from the reference's own AliasTable (oracle/ref_alias_harness.cpp).
 
 Run here (the container that has /root/reference):   python tests/golden/make_golden.py
 The fixture travels to the GPU box; /root/reference does not.  Every case stores the inputs and what the
@@ -54,6 +55,30 @@ def main():
     path = os.path.join(HERE, "reference_arithmetic.npz")
     np.savez_compressed(path, **out)
     print("wrote %s (%d arrays, %.1f KiB)" % (path, len(out), os.path.getsize(path) / 1024))
+
+    # the reference's own AliasTable (oracle/ref_alias_harness.cpp -> oracle/_ref/libgvref_alias.so): build + sample
+    alias = {}
+    rng = np.random.default_rng(20260924)
+    cases = {"one": np.array([3.0], np.float32), "uniform": np.ones(17, np.float32),
+             "two_to_one": np.array([2, 1], np.float32), "tiny": np.full(5, 1e-30, np.float32),
+             "with_zeros": np.array([0, 0, 1, 0, 4, 0.5, 0], np.float32),
+             "pareto": (rng.pareto(1.2, 1000) + 1e-3).astype(np.float32),
+             "degree_075": np.floor(rng.pareto(1.5, 4097) + 1).astype(np.float32) ** np.float32(0.75),
+             "small_ints": rng.integers(1, 4, 333).astype(np.float32),
+             "sparse": np.where(rng.random(2500) < 0.3, rng.random(2500), 0).astype(np.float32)}
+    for name, w in cases.items():
+        alias[name + "_w"] = w
+        alias[name + "_prob"], alias[name + "_alias"] = ref.alias_build(w, 4)
+        prob64, alias64 = ref.alias_build(w, 8)
+        assert (prob64 == alias[name + "_prob"]).all() and (alias64 == alias[name + "_alias"]).all()
+        rand = rng.random((257, 2))
+        rand[0] = (0.0, 0.0)
+        rand[1] = (np.nextafter(1.0, 0.0), np.nextafter(1.0, 0.0))
+        alias[name + "_rand"] = rand
+        alias[name + "_draws"] = ref.alias_sample(w, rand)
+    path = os.path.join(HERE, "reference_alias.npz")
+    np.savez_compressed(path, **alias)
+    print("wrote %s (%d arrays, %.1f KiB)" % (path, len(alias), os.path.getsize(path) / 1024))
 
 
 if __name__ == "__main__":

@@ -238,10 +238,42 @@ class Reference(object):
         lib.gvref_lr.restype = C.c_float
         lib.gvref_lr.argtypes = [C.c_float, C.c_int, C.c_int, C.c_int]
 
+        # the reference's own AliasTable (oracle/ref_alias_harness.cpp)
+        alias_path = os.path.join(ORACLE_DIR, "_ref", "libgvref_alias.so")
+        self.alias_lib = None
+        if os.path.exists(alias_path):
+            self.alias_lib = al = C.CDLL(alias_path)
+            al.gvref_alias_build.restype = C.c_int
+            al.gvref_alias_build.argtypes = [_f32p, C.c_uint32, _f32p, _u32p]
+            al.gvref_alias_build64.restype = C.c_int
+            al.gvref_alias_build64.argtypes = [_f32p, C.c_uint64, _f32p, C.c_void_p]
+            al.gvref_alias_sample.restype = C.c_int
+            al.gvref_alias_sample.argtypes = [_f32p, C.c_uint32, C.c_void_p, C.c_uint32, _u32p]
+
     @staticmethod
     def available():
         return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libgvref.so")) or os.path.exists(
             "/root/reference/include/instance/model/graph.h")
+
+    def alias_build(self, weights, index_bytes=4):
+        """AliasTable<float, uint32_t / size_t>::build of the reference (alias_table.cuh:84-128)."""
+        w = np.ascontiguousarray(weights, np.float32)
+        prob = np.zeros(w.size, np.float32)
+        if index_bytes == 4:
+            alias = np.zeros(w.size, np.uint32)
+            assert self.alias_lib.gvref_alias_build(w, w.size, prob, alias) == 0
+        else:
+            alias = np.zeros(w.size, np.uint64)
+            assert self.alias_lib.gvref_alias_build64(w, w.size, prob, alias.ctypes.data) == 0
+        return prob, alias
+
+    def alias_sample(self, weights, rand):
+        """AliasTable::sample(rand1, rand2) (alias_table.cuh:148-152) for uniforms rand[m, 2] (float64)."""
+        w = np.ascontiguousarray(weights, np.float32)
+        r = np.ascontiguousarray(rand, np.float64).reshape(-1, 2)
+        out = np.zeros(r.shape[0], np.uint32)
+        assert self.alias_lib.gvref_alias_sample(w, w.size, r.ctypes.data, r.shape[0], out) == 0
+        return out
 
     def train(self, vertex, context, batch, negatives, lr, wd, negative_weight, optimizer=SGD, moments=None,
               hp=(0, 0, 0)):
