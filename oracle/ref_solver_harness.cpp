@@ -1,0 +1,176 @@
+// TEST INFRASTRUCTURE ONLY — never linked into or loaded by the product.
+//
+// Host build of the reference's OWN solver front end — Graph (include/instance/graph.cuh:62-276), SolverMixin::build
+// with partition() and get_schedule() (include/core/solver.h:270-575,873-887), GraphSolver::get_sample_function with its
+// vertex / edge alias tables (graph.cuh:645-721) and the three CPU samplers (solver.h:1012-1055, graph.cuh:298-450) —
+// compiled from /root/reference where it lies, nothing copied, over the emulated CUDA runtime and cuRAND of
+// ref_stubs/ (device memory = malloc; curandGenerateUniformDouble = whatever source the test installs, i.e. the same
+// per-thread Philox stream the oracle and the product's samplers consume).  The GPU workers are constructed (their
+// buffers are plain memory here) but never run.
+//
+//   hipcc -x hip --cuda-host-only ... (oracle/Makefile) -> oracle/_ref/libgvref_solver.so
+#include <cstdint>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include <cuda_runtime.h>
+#include <curand.h>
+
+int gvref_device_count = 1;
+size_t gvref_device_memory = (size_t)16 << 30;  // a P100's 16 GB, the card the reference's defaults were tuned on
+gvref_uniform_source_t gvref_uniform_source = nullptr;
+int gvref_generator_count = 0;
+
+#include "instance/graph.cuh"
+
+// The GPU workers never run here.  Their two dispatch functions are the only code that instantiates the reference's CUDA
+// kernels (instance/gpu/graph.cuh, written for nvcc: `model.backward<...>` without the `template` disambiguator does
+// not parse under clang), so they are specialised away before anything instantiates the worker class.
+namespace graphvite {
+typedef SolverMixin<128, float, uint32_t, Graph, GraphSampler, GraphWorker> HarnessSolverBase;
+template <>
+void AliasTable<float, uint32_t>::device_sample(const Memory<double, int> &, Memory<uint32_t, int> *) {}  // gpu::Sample launch
+template <>
+bool GraphWorker<HarnessSolverBase>::train_dispatch() { return false; }
+template <>
+bool GraphWorker<HarnessSolverBase>::predict_dispatch() { return false; }
+}  // namespace graphvite
+
+namespace {
+typedef graphvite::Graph<uint32_t> GraphT;
+typedef graphvite::GraphSolver<128, float, uint32_t> SolverT;
+struct Handle {
+    GraphT graph;
+    SolverT *solver = nullptr;
+    ~Handle() { delete solver; }
+};
+}  // namespace
+
+extern "C" {
+
+void gvref_set_uniform_source(gvref_uniform_source_t source) { gvref_uniform_source = source; }
+
+void *gvref_solver_create(const uint32_t *edges, const float *weights, uint64_t n, int as_undirected, int num_worker,
+                          int num_sampler_per_worker, int num_partition, int num_negative, int batch_size,
+                          int episode_size) {
+    Handle *h = new Handle();
+    if (weights) {
+        std::vector<std::tuple<std::string, std::string, float>> list;
+        for (uint64_t i = 0; i < n; i++)
+            list.emplace_back(std::to_string(edges[2 * i]), std::to_string(edges[2 * i + 1]), weights[i]);
+        h->graph.load_weighted_edge_list(list, as_undirected != 0, false);
+    } else {
+        std::vector<std::tuple<std::string, std::string>> list;
+        for (uint64_t i = 0; i < n; i++) list.emplace_back(std::to_string(edges[2 * i]), std::to_string(edges[2 * i + 1]));
+        h->graph.load_edge_list(list, as_undirected != 0, false);
+    }
+    std::vector<int> devices;
+    for (int i = 0; i < num_worker; i++) devices.push_back(i);
+    gvref_generator_count = 0;  // generator index == sampler index (SolverMixin constructor, solver.h:212-214)
+    h->solver = new SolverT(devices, num_sampler_per_worker);
+    h->solver->build(h->graph, graphvite::kAuto, num_partition, num_negative, batch_size, episode_size);
+    return h;
+}
+
+void gvref_solver_destroy(void *handle) { delete static_cast<Handle *>(handle); }
+
+// out: num_vertex, num_edge, num_directed_edge, num_partition, episode_size, head_partition_size, num_sampler, num_worker
+void gvref_solver_info(void *handle, int64_t *out) {
+    Handle *h = static_cast<Handle *>(handle);
+    SolverT &s = *h->solver;
+    h->graph.flatten();
+    out[0] = s.num_vertex, out[1] = s.num_edge, out[2] = (int64_t)h->graph.edges.size(), out[3] = s.num_partition;
+    out[4] = s.episode_size, out[5] = s.head_partition_size, out[6] = s.num_sampler, out[7] = s.num_worker;
+}
+
+// names[v] = the decimal label the vertex was loaded with; (part, local) = head_locations (solver.h:399-410)
+void gvref_solver_partition(void *handle, uint32_t *labels, int32_t *part, uint32_t *local, float *vertex_weights) {
+    Handle *h = static_cast<Handle *>(handle);
+    SolverT &s = *h->solver;
+    for (uint32_t v = 0; v < s.num_vertex; v++) {
+        labels[v] = (uint32_t)std::stoul(h->graph.id2name[v]);
+        part[v] = s.head_locations[v].first;
+        local[v] = s.head_locations[v].second;
+        vertex_weights[v] = h->graph.vertex_weights[v];
+    }
+}
+
+// flattened directed edges {u, v} and weights in the order GraphMixin::flatten emits them (core/graph.h:87-101)
+void gvref_solver_edges(void *handle, uint32_t *uv, float *weights) {
+    Handle *h = static_cast<Handle *>(handle);
+    h->graph.flatten();
+    for (size_t e = 0; e < h->graph.edges.size(); e++) {
+        uv[2 * e] = std::get<0>(h->graph.edges[e]);
+        uv[2 * e + 1] = std::get<1>(h->graph.edges[e]);
+        weights[e] = h->graph.edge_weights[e];
+    }
+}
+
+// get_schedule() (solver.h:519-575): out[(step * num_worker + worker) * 2 + {0, 1}]; returns the number of steps
+int gvref_solver_schedule(void *handle, int32_t *out, int capacity_steps) {
+    SolverT &s = *static_cast<Handle *>(handle)->solver;
+    auto schedule = s.get_schedule();
+    int step = 0;
+    for (auto &&assignment : schedule) {
+        if (step >= capacity_steps) return -1;
+        for (size_t w = 0; w < assignment.size(); w++) {
+            out[(step * s.num_worker + w) * 2] = assignment[w].first;
+            out[(step * s.num_worker + w) * 2 + 1] = assignment[w].second;
+        }
+        step++;
+    }
+    return step;
+}
+
+// What train() does before the first episode (graph.cuh:770-793, solver.h:588-625): configure, get_sample_function()
+// (builds the alias tables), then every sampler fills its slice [work_load * i, ...) of the pools of pool_id ^ 1 —
+// run one after the other here; the slices are disjoint.  pools: [P][P][pool_size] {tail, head} local ids.
+int gvref_solver_sample(void *handle, const char *model, int augmentation_step, int walk_length, int walk_batch,
+                        int shuffle_base, float p, float q, uint32_t *pools) {
+    Handle *h = static_cast<Handle *>(handle);
+    SolverT &s = *h->solver;
+    s.model = model;
+    s.augmentation_step = augmentation_step;
+    s.random_walk_length = walk_length;
+    s.random_walk_batch_size = walk_batch;
+    s.shuffle_base = (s.model == "DeepWalk" || s.model == "node2vec") ? 1 : shuffle_base;
+    s.p = p;
+    s.q = q;
+    s.sample_batch_size = walk_length * walk_batch;
+    s.pool_id = 0;
+    auto sample_function = s.get_sample_function();
+    const int num_sample = s.episode_size * s.batch_size;
+    const int work_load = (num_sample + s.num_sampler - 1) / s.num_sampler;
+    for (int i = 0; i < s.num_sampler; i++)
+        sample_function(s.samplers[i], work_load * i, std::min(work_load * (i + 1), num_sample));
+    const int P = s.num_partition;
+    auto &pool_set = s.sample_pools[s.pool_id ^ 1];
+    for (int hp = 0; hp < P; hp++)
+        for (int tp = 0; tp < P; tp++)
+            for (int i = 0; i < num_sample; i++) {
+                const auto &sample = pool_set[hp][tp][i];
+                uint32_t *record = pools + (((size_t)hp * P + tp) * num_sample + i) * 2;
+                record[0] = std::get<1>(sample);  // tail
+                record[1] = std::get<0>(sample);  // head
+            }
+    return num_sample;
+}
+
+// alias tables get_sample_function() built: which = 0 the global edge table, 1 vertex_edge_tables[index],
+// 2 edge_edge_tables[index]; returns the table size (0 when the vertex / edge has no table)
+uint64_t gvref_solver_table(void *handle, int which, uint64_t index, float *prob, uint64_t *alias, uint64_t capacity) {
+    SolverT &s = *static_cast<Handle *>(handle)->solver;
+    uint64_t count = 0;
+    if (which == 0) {
+        count = s.edge_table.count;
+        for (uint64_t i = 0; i < count && i < capacity; i++) prob[i] = s.edge_table.prob_table[i], alias[i] = s.edge_table.alias_table[i];
+    } else {
+        auto &table = which == 1 ? s.vertex_edge_tables[index] : s.edge_edge_tables[index];
+        count = table.count;
+        for (uint64_t i = 0; i < count && i < capacity; i++) prob[i] = table.prob_table[i], alias[i] = table.alias_table[i];
+    }
+    return count;
+}
+
+}  // extern "C"

@@ -24,6 +24,17 @@ inline cudaError_t cudaMalloc(T **ptr, size_t bytes) { return cudaMallocHost(ptr
 inline cudaError_t cudaFreeHost(void *ptr) { free(ptr); return cudaSuccess; }
 inline cudaError_t cudaFree(void *ptr) { free(ptr); return cudaSuccess; }
 inline cudaError_t cudaSetDevice(int) { return cudaSuccess; }
+extern int gvref_device_count;           // what cudaGetDeviceCount reports (set by the harness)
+extern size_t gvref_device_memory;       // what cudaMemGetInfo reports as free and total
+inline cudaError_t cudaGetDeviceCount(int *count) { *count = gvref_device_count; return cudaSuccess; }
+inline cudaError_t cudaMemGetInfo(size_t *free_bytes, size_t *total) {
+    if (free_bytes) *free_bytes = gvref_device_memory;
+    if (total) *total = gvref_device_memory;
+    return cudaSuccess;
+}
+inline cudaError_t cudaStreamCreate(cudaStream_t *stream) { *stream = nullptr; return cudaSuccess; }
+inline cudaError_t cudaStreamDestroy(cudaStream_t) { return cudaSuccess; }
+inline cudaError_t cudaDeviceSynchronize() { return cudaSuccess; }
 inline cudaError_t cudaStreamSynchronize(cudaStream_t) { return cudaSuccess; }
 inline cudaError_t cudaMemcpyAsync(void *dst, const void *src, size_t bytes, cudaMemcpyKind, cudaStream_t) {
     memcpy(dst, src, bytes);

@@ -1,10 +1,10 @@
-// TEST INFRASTRUCTURE ONLY (oracle). Minimal stand-in for <glog/logging.h> so the
-// reference's host-compilable arithmetic headers (core/optimizer.h, which uses CHECK at
-// optimizer.h:52,116) build without glog. A failed CHECK aborts, as glog's would.
+// TEST INFRASTRUCTURE ONLY (oracle). Minimal stand-in for <glog/logging.h> so that the reference's headers build
+// without glog: CHECK aborts with its message like glog's, LOG(FATAL) aborts, every other log line is swallowed.
 #pragma once
 #include <cstdlib>
 #include <iostream>
 #include <sstream>
+#include <string>
 namespace gv_ref_stub {
 struct CheckSink {
     bool failed;
@@ -20,6 +20,17 @@ struct CheckSink {
         if (failed) ss << v;
         return *this;
     }
+    CheckSink &operator<<(std::ostream &(*)(std::ostream &)) { return *this; }
 };
 }  // namespace gv_ref_stub
+namespace google {
+enum { INFO = 0, WARNING = 1, ERROR = 2, FATAL = 3 };
+inline void InitGoogleLogging(const char *) {}
+}  // namespace google
+static int FLAGS_minloglevel = 0;
+static bool FLAGS_logtostderr = true, FLAGS_log_prefix = false;
+static std::string FLAGS_log_dir;
 #define CHECK(cond) gv_ref_stub::CheckSink(!(cond))
+#define LOG(severity) gv_ref_stub::CheckSink(google::severity == google::FATAL)
+#define LOG_IF(severity, cond) gv_ref_stub::CheckSink(google::severity == google::FATAL && (cond))
+#define LOG_EVERY_N(severity, n) gv_ref_stub::CheckSink(false)

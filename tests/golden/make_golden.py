@@ -1,6 +1,7 @@
 """Generates tests/golden/reference_arithmetic.npz from the REFERENCE's own model / optimizer code compiled for
 the host (oracle/ref_harness.cpp -> oracle/_ref/libgvref.so, built from /root/reference/include by oracle/Makefile),
-and tests/golden/reference_alias.npz from the reference's own AliasTable (oracle/ref_alias_harness.cpp).
+and tests/golden/reference_alias.npz from the reference's own AliasTable (oracle/ref_alias_harness.cpp), and
+tests/golden/reference_solver.npz from its solver front end and CPU samplers (oracle/ref_solver_harness.cpp).
 
 Run here (the container that has /root/reference):   python tests/golden/make_golden.py
 The fixture travels to the GPU box; /root/reference does not.  Every case stores the inputs and what the
@@ -14,7 +15,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from oracle_lib import ADAGRAD, ADAM, MOMENTUM, RMSPROP, SGD, Reference  # noqa: E402
+from oracle_lib import ADAGRAD, ADAM, MOMENTUM, RMSPROP, SGD, Oracle, Reference, ReferenceSolver  # noqa: E402
 
 HP = {SGD: (0, 0, 0), MOMENTUM: (0.9, 0, 0), ADAGRAD: (0, 0, 1e-10), RMSPROP: (0.99, 0, 1e-8),
       ADAM: (0.9, 0.99, 1e-8)}
@@ -79,6 +80,57 @@ def main():
     path = os.path.join(HERE, "reference_alias.npz")
     np.savez_compressed(path, **alias)
     print("wrote %s (%d arrays, %.1f KiB)" % (path, len(alias), os.path.getsize(path) / 1024))
+
+    # the reference's own solver front end (oracle/ref_solver_harness.cpp): graph store, partition, schedule, auto
+    # episode size, alias tables, and the pools its three CPU samplers fill from the oracle's uniform streams
+    oracle = Oracle()
+    solver = {}
+    rng = np.random.default_rng(20260925)
+    n_vertex, n_edge = 300, 3000
+    edges = np.stack([rng.integers(0, n_vertex, n_edge), rng.zipf(1.6, n_edge) % n_vertex], 1).astype(np.uint32)
+    weights = (rng.pareto(2.0, n_edge) + 0.1).astype(np.float32)  # distinct weights: no ties in the partition
+    solver["edges"], solver["weights"] = edges, weights
+    seed = 20260925
+    solver["seed"] = np.int64(seed)
+    configs = {  # name: (weighted, undirected, workers, samplers per worker, partitions, batch, episode)
+        "w_p4": (True, True, 2, 2, 4, 200, 3), "u_p4": (False, True, 2, 2, 4, 200, 3),
+        "w_p1": (True, True, 1, 3, 1, 500, 2), "w_dir_p2": (True, False, 1, 2, 2, 300, 2),
+        "auto_p": (True, True, 4, 1, 0, 250, 0), "auto_1": (False, True, 1, 1, 0, 100000, 0)}
+    for name, (weighted, undirected, W, spw, P, B, episode) in configs.items():
+        rs = ReferenceSolver(oracle, seed, edges, weights if weighted else None, undirected, W, spw, P, 1, B, episode)
+        key = "cfg_" + name
+        solver[key + "_args"] = np.array([weighted, undirected, W, spw, P, B, episode], np.int64)
+        solver[key + "_info"] = np.array([rs.num_vertex, rs.num_edge, rs.num_directed_edge, rs.num_partition,
+                                          rs.episode_size, rs.partition_size, rs.num_sampler, rs.num_worker], np.int64)
+        labels, part, local, vw = rs.partition()
+        uv, ew = rs.edges()
+        solver[key + "_labels"], solver[key + "_part"], solver[key + "_local"] = labels, part, local
+        solver[key + "_vertex_weights"], solver[key + "_uv"], solver[key + "_edge_weights"] = vw, uv, ew
+        solver[key + "_schedule"] = rs.schedule()
+        if name.startswith("auto"):
+            continue
+        solver[key + "_edge_pools"] = rs.sample("LINE", 1)
+        prob, alias = rs.table(0)
+        solver[key + "_edge_prob"], solver[key + "_edge_alias"] = prob, alias
+    # walk modes on one partition: tables bit for bit, pools for distribution tests
+    for name, (model, aug, length, batch, shuffle) in {"line2": ("LINE", 2, 5, 10, 2), "deepwalk": ("DeepWalk", 3, 8, 10, 1),
+                                                       "node2vec": ("node2vec", 2, 6, 10, 1)}.items():
+        rs = ReferenceSolver(oracle, seed, edges, weights, True, 1, 3, 1, 1, 200, 300)
+        pools = rs.sample(model, aug, length, batch, shuffle, 0.5, 2.0)
+        key = "walk_" + name
+        solver[key + "_args"] = np.array([aug, length, batch, shuffle], np.int64)
+        solver[key + "_pool"] = pools[0, 0]
+        which = 2 if model == "node2vec" else 1
+        count = rs.num_directed_edge if which == 2 else rs.num_vertex
+        probs, aliases, sizes = [], [], []
+        for i in range(count):
+            prob, alias = rs.table(which, i)
+            probs.append(prob), aliases.append(alias.astype(np.uint32)), sizes.append(len(prob))
+        solver[key + "_table_prob"], solver[key + "_table_alias"] = np.concatenate(probs), np.concatenate(aliases)
+        solver[key + "_table_sizes"] = np.array(sizes, np.int64)
+    path = os.path.join(HERE, "reference_solver.npz")
+    np.savez_compressed(path, **solver)
+    print("wrote %s (%d arrays, %.1f KiB)" % (path, len(solver), os.path.getsize(path) / 1024))
 
 
 if __name__ == "__main__":

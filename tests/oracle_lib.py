@@ -316,3 +316,97 @@ def link_prediction_auc(vertex, context, H, T, Y):
     hit = np.cumsum(y)
     total = int((y == 0).sum()) * int((y == 1).sum())
     return float(hit[y == 0].sum()) / total
+
+
+class ReferenceSolver(object):
+    """The reference's own Graph / GraphSolver::build / get_schedule / get_sample_function / CPU samplers, compiled for
+    the host as written (oracle/ref_solver_harness.cpp -> oracle/_ref/libgvref_solver.so).  The uniforms its samplers
+    draw (cuRAND in the reference) are served from the oracle's per-thread Philox stream — the one the product's
+    samplers consume — so that the edge sampler can be compared draw for draw.  One instance = one built solver."""
+
+    PATH = os.path.join(ORACLE_DIR, "_ref", "libgvref_solver.so")
+    _lib = None
+    _callback = None
+
+    @classmethod
+    def available(cls):
+        return os.path.exists(cls.PATH)
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            cls._lib = lib = C.CDLL(cls.PATH)
+            lib.gvref_solver_create.restype = C.c_void_p
+            lib.gvref_solver_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64] + [C.c_int] * 7
+            lib.gvref_solver_destroy.argtypes = [C.c_void_p]
+            lib.gvref_solver_info.argtypes = [C.c_void_p, C.c_void_p]
+            lib.gvref_solver_partition.argtypes = [C.c_void_p] * 5
+            lib.gvref_solver_edges.argtypes = [C.c_void_p] * 3
+            lib.gvref_solver_schedule.restype = C.c_int
+            lib.gvref_solver_schedule.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+            lib.gvref_solver_sample.restype = C.c_int
+            lib.gvref_solver_sample.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                                C.c_float, C.c_void_p]
+            lib.gvref_solver_table.restype = C.c_uint64
+            lib.gvref_solver_table.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
+        return cls._lib
+
+    def __init__(self, oracle, seed, edges, weights=None, as_undirected=True, num_worker=1, num_sampler_per_worker=1,
+                 num_partition=0, num_negative=1, batch_size=100000, episode_size=0):
+        lib = self.lib()
+        source_type = C.CFUNCTYPE(None, C.c_int, C.c_ulonglong, C.POINTER(C.c_double), C.c_size_t)
+
+        def source(generator, position, out, n):  # generator index == sampler index == uniform stream
+            u = oracle.host_uniforms(seed, generator, position, n)
+            C.memmove(out, u.ctypes.data, n * 8)
+
+        ReferenceSolver._callback = source_type(source)  # kept alive: the library holds the pointer
+        lib.gvref_set_uniform_source(ReferenceSolver._callback)
+        e = np.ascontiguousarray(edges, np.uint32)
+        w = None if weights is None else np.ascontiguousarray(weights, np.float32)
+        self.handle = lib.gvref_solver_create(e.ctypes.data, None if w is None else w.ctypes.data, len(e),
+                                              int(as_undirected), num_worker, num_sampler_per_worker, num_partition,
+                                              num_negative, batch_size, episode_size)
+        info = np.zeros(8, np.int64)
+        lib.gvref_solver_info(self.handle, info.ctypes.data)
+        (self.num_vertex, self.num_edge, self.num_directed_edge, self.num_partition, self.episode_size,
+         self.partition_size, self.num_sampler, self.num_worker) = [int(x) for x in info]
+        self.batch_size = batch_size
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self.lib().gvref_solver_destroy(h)
+
+    def partition(self):
+        """(labels, part, local, vertex_weights) per vertex id."""
+        N = self.num_vertex
+        labels, part = np.zeros(N, np.uint32), np.zeros(N, np.int32)
+        local, weights = np.zeros(N, np.uint32), np.zeros(N, np.float32)
+        self.lib().gvref_solver_partition(self.handle, labels.ctypes.data, part.ctypes.data, local.ctypes.data,
+                                          weights.ctypes.data)
+        return labels, part, local, weights
+
+    def edges(self):
+        uv, w = np.zeros((self.num_directed_edge, 2), np.uint32), np.zeros(self.num_directed_edge, np.float32)
+        self.lib().gvref_solver_edges(self.handle, uv.ctypes.data, w.ctypes.data)
+        return uv, w
+
+    def schedule(self):
+        out = np.zeros(4096 * self.num_worker * 2, np.int32)
+        steps = self.lib().gvref_solver_schedule(self.handle, out.ctypes.data, 4096)
+        return out[:steps * self.num_worker * 2].reshape(steps, self.num_worker, 2)
+
+    def sample(self, model="LINE", augmentation_step=1, walk_length=40, walk_batch=100, shuffle_base=1, p=1.0, q=1.0):
+        """Pools [P][P][episode_size * batch_size][2] = {tail, head} of the first episode's fill."""
+        P, n = self.num_partition, self.episode_size * self.batch_size
+        pools = np.zeros((P, P, n, 2), np.uint32)
+        self.lib().gvref_solver_sample(self.handle, model.encode(), augmentation_step, walk_length, walk_batch,
+                                       shuffle_base, p, q, pools.ctypes.data)
+        return pools
+
+    def table(self, which, index=0, capacity=1 << 16):
+        """which: 0 the global edge table, 1 vertex_edge_tables[index], 2 edge_edge_tables[index] (after sample())."""
+        prob, alias = np.zeros(capacity, np.float32), np.zeros(capacity, np.uint64)
+        n = self.lib().gvref_solver_table(self.handle, which, index, prob.ctypes.data, alias.ctypes.data, capacity)
+        return prob[:n], alias[:n]

@@ -173,3 +173,73 @@ def test_conflict_free_batch_is_order_independent(oracle):
     perm = rng.permutation(100)
     l2 = oracle.train(v2, c2, pairs[perm], negs[perm], 0.025, 0.005, 5.0)
     assert (v1 == v2).all() and (c1 == c2).all() and (l1[perm] == l2).all()
+
+
+# ---- the reference's own solver front end (tests/golden/reference_solver.npz, oracle/ref_solver_harness.cpp) ----------
+SOLVER_GOLDEN = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_solver.npz"))
+SOLVER_CONFIGS = sorted(k[4:-5] for k in SOLVER_GOLDEN.files if k.startswith("cfg_") and k.endswith("_args"))
+
+
+def equal_up_to_ties(part_a, local_a, part_b, local_b, weights, P):
+    """Two partitions deal the same weight to every (partition, position): they differ at most in which of several
+    equally heavy vertices sits where (the reference leaves that to std::sort, solver.h:878-882)."""
+    S = int(max(local_a.max(), local_b.max())) + 1
+    a, b = np.full((P, S), -1.0), np.full((P, S), -1.0)
+    a[part_a, local_a] = weights
+    b[part_b, local_b] = weights
+    return np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", SOLVER_CONFIGS)
+def test_partition_and_schedule_match_the_reference_solver(oracle, name):
+    G = SOLVER_GOLDEN
+    weighted, undirected, W, spw, P_arg, B, episode = [int(x) for x in G["cfg_%s_args" % name]]
+    P = int(G["cfg_%s_info" % name][3])
+    vw = G["cfg_%s_vertex_weights" % name]
+    part, local, _ = oracle.partition(vw, P)
+    gpart, glocal = G["cfg_%s_part" % name], G["cfg_%s_local" % name]
+    if weighted:  # distinct vertex weights: the partition is determined
+        assert (part == gpart).all() and (local == glocal).all()
+    else:
+        assert equal_up_to_ties(part, local, gpart, glocal, vw, P)
+    want = G["cfg_%s_schedule" % name]
+    got = oracle.schedule(P, int(G["cfg_%s_info" % name][7]))
+    assert got.shape == want.shape and (got == want).all()
+
+
+@pytest.mark.parametrize("name", [n for n in SOLVER_CONFIGS if not n.startswith("auto")])
+def test_edge_sampler_matches_the_reference_sampler_draw_for_draw(oracle, name):
+    """SamplerMixin::sample (solver.h:1012-1055) run as written on the oracle's uniform streams fills exactly the pools
+    gvo_sample_edges fills."""
+    G = SOLVER_GOLDEN
+    key = "cfg_%s_" % name
+    P, episode, num_sampler = [int(G[key + "info"][i]) for i in (3, 4, 6)]
+    B = int(G[key + "args"][5])
+    n = episode * B
+    prob, alias = oracle.alias_build(G[key + "edge_weights"], 8)
+    assert (prob == G[key + "edge_prob"]).all() and (alias == G[key + "edge_alias"]).all()
+    pools = [np.zeros((n, 2), np.uint32) for _ in range(P * P)]
+    work = (n + num_sampler - 1) // num_sampler
+    for t in range(num_sampler):
+        rnd = oracle.host_uniforms(int(G["seed"]), t, 0, 40 * n + 1000)
+        oracle.sample_edges(G[key + "uv"], prob, alias, G[key + "part"], G[key + "local"], P, pools, work * t,
+                            min(work * (t + 1), n), 4000, rnd)
+    want = G[key + "edge_pools"]
+    for hp in range(P):
+        for tp in range(P):
+            assert (pools[hp * P + tp] == want[hp, tp]).all(), (hp, tp)
+
+
+def test_solver_golden_equals_live_reference_solver(oracle):
+    """Where oracle/_ref/libgvref_solver.so is built (this container): the reference's solver run now reproduces the
+    committed fixture — partition, schedule, edge pools."""
+    from oracle_lib import ReferenceSolver
+    if not ReferenceSolver.available():
+        pytest.skip("oracle/_ref/libgvref_solver.so is not built")
+    G = SOLVER_GOLDEN
+    weighted, undirected, W, spw, P, B, episode = [int(x) for x in G["cfg_w_p4_args"]]
+    rs = ReferenceSolver(oracle, int(G["seed"]), G["edges"], G["weights"], undirected, W, spw, P, 1, B, episode)
+    labels, part, local, vw = rs.partition()
+    assert (part == G["cfg_w_p4_part"]).all() and (local == G["cfg_w_p4_local"]).all()
+    assert (rs.schedule() == G["cfg_w_p4_schedule"]).all()
+    assert (rs.sample("LINE", 1) == G["cfg_w_p4_edge_pools"]).all()

@@ -507,3 +507,16 @@ def test_device_sampling_over_gloo(tmp_path):
     assert (r[0]["v"] == r[1]["v"]).all() and (r[0]["c"] == r[1]["c"]).all()
     ids = np.sort(np.concatenate([r[0]["ids"], r[1]["ids"]]))
     assert (ids == np.arange(len(ids))).all() and len(ids) % (4 * 4 * 3) == 0 and np.abs(r[0]["c"]).max() > 0
+
+
+def test_auto_build_rules_match_the_reference_solver():
+    """num_partition = auto and episode_size = auto as SolverMixin::build of the reference resolved them
+    (solver.h:365-434; tests/golden/reference_solver.npz, one worker)."""
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_solver.npz"))
+    args, info = G["cfg_auto_1_args"], G["cfg_auto_1_info"]
+    g = gv.graph.Graph()
+    g.load(G["edges"].astype(np.int64), as_undirected=bool(args[1]))
+    s = gv.solver.GraphSolver(128, kernels=OracleKernels(), num_sampler_per_worker=1)
+    s.build(g, batch_size=int(args[5]))
+    assert (s.num_vertex, s.num_edge) == (int(info[0]), int(info[1]))
+    assert s.num_partition == int(info[3]) and s.episode_size == int(info[4])
