@@ -29,11 +29,16 @@
  * gvo_host_uniforms (include/gvk.h "RNG contract").
  *
  * Parity status: the reference ships no tests or golden vectors, so this
- * oracle is pinned against the reference's own arithmetic compiled for the host
- * (oracle/ref_harness.cpp -> oracle/_ref/libgvref.so) and against fixtures generated
- * from that build (tests/golden/, script committed).  Pieces the reference cannot
- * compile here (alias table, partition, schedule, samplers: they need CUDA/glog headers)
- * are "parity unpinned" restatements, checked by known-answer and property tests.
+ * oracle is pinned against the reference's own code compiled for the host, and against
+ * fixtures generated from those builds (tests/golden/, script committed):
+ *   - arithmetic (model, optimizers, schedule, sigmoid): oracle/ref_harness.cpp -> _ref/libgvref.so;
+ *   - alias table build / sample: oracle/ref_alias_harness.cpp -> _ref/libgvref_alias.so;
+ *   - partition, schedule, edge sampler (pools record for record), the alias tables of the
+ *     walk samplers: oracle/ref_solver_harness.cpp -> _ref/libgvref_solver.so (the
+ *     reference's solver front end over an emulated CUDA runtime / cuRAND, ref_stubs/).
+ * The walk samplers consume their uniforms in lockstep order here (see gvo_sample_walks), not
+ * in the reference's walk-by-walk order: pinned in distribution, not record for record.
+ * gvo_sample_pairs / gvo_sample_walks_device restate device samplers the reference lacks.
  */
 #include <math.h>
 #include <stdint.h>
