@@ -112,6 +112,8 @@ def lib():
     l.gvs_graph_load_labels.argtypes = [vp, vp, vp, vp, sz, i32, i32]
     l.gvs_graph_save.restype = i32
     l.gvs_graph_save.argtypes = [vp, cp, i32, i32]
+    l.gvs_negative_weights.restype = i32
+    l.gvs_negative_weights.argtypes = [vp, vp, u64, f32, vp]
     l.gvs_graph_neighbor_tables.restype = i32
     l.gvs_graph_neighbor_tables.argtypes = [vp, i32, vp]
     l.gvs_graph_num_vertex.restype = u32

@@ -1448,6 +1448,15 @@ gvs_sampler *gvs_sampler_create(const gvs_graph *g, const int32_t *part, const u
 
 void gvs_sampler_destroy(gvs_sampler *s) { delete s; }
 
+// WorkerMixin::build_negative_sampler (solver.h:1263-1278): weight of vertex ids[i] in a partition's negative sampler =
+// std::pow(vertex_weight, exponent) in single precision — libm's powf, which is what the reference's host code calls
+// (numpy's float32 power is a different implementation and differs from it in the last bit for some inputs).
+int gvs_negative_weights(const float *vertex_weights, const uint32_t *ids, uint64_t n, float exponent, float *out) {
+    if (n && (!vertex_weights || !ids || !out)) return gvk_fail(GVK_EINVAL, "gvs_negative_weights: null argument");
+    for (uint64_t i = 0; i < n; i++) out[i] = powf(vertex_weights[ids[i]], exponent);
+    return GVK_OK;
+}
+
 int gvs_graph_neighbor_tables(const gvs_graph *g, int num_thread, gvk_alias_entry *out) {
     if (!g || !out) return gvk_fail(GVK_EINVAL, "gvs_graph_neighbor_tables: null argument");
     return guarded("gvs_graph_neighbor_tables", [&]() {

@@ -29,6 +29,16 @@ def schedule(num_partition, num_worker):
     return out[:steps * nw * 2].reshape(steps, nw, 2).copy()
 
 
+def negative_weights(vertex_weights, ids, exponent):
+    """powf(vertex_weights[ids], exponent) as the reference's host code computes it (solver.h:1263-1278)."""
+    w = np.ascontiguousarray(vertex_weights, np.float32)
+    ids = np.ascontiguousarray(ids, np.uint32)
+    out = np.zeros(ids.size, np.float32)
+    _lib.check(_lib.lib().gvs_negative_weights(w.ctypes.data, ids.ctypes.data, ids.size, float(exponent),
+                                               out.ctypes.data), "gvs_negative_weights")
+    return out
+
+
 def host_uniforms(seed, stream, first, n):
     out = np.empty(n, np.float64)
     _lib.lib().gvs_host_uniforms(seed, stream, first, n, out.ctypes.data)

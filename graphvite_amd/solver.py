@@ -578,7 +578,7 @@ class GraphSolver(object):
         weights = self.graph.vertex_weights
         state["negative_tables"] = {}
         for tp in self._my_tails:
-            w = np.power(weights[self._part_ids[tp]], np.float32(self.negative_sample_exponent)).astype(np.float32)
+            w = hostlib.negative_weights(weights, self._part_ids[tp], self.negative_sample_exponent)
             _, _, packed = alias_build(w)
             state["negative_tables"][tp] = packed_to_device(packed, self.device)
         state["loss"] = torch.zeros(self.batch_size, dtype=torch.float32, device=self.device)

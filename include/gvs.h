@@ -79,6 +79,10 @@ const float *gvs_graph_vertex_weights(const gvs_graph *g);
  * include/instance/graph.cuh:645-653), in the interleaved form gvk_sample_walks reads: out[num_directed_edge]. */
 int gvs_graph_neighbor_tables(const gvs_graph *g, int num_thread, gvk_alias_entry *out);
 
+/* out[i] = powf(vertex_weights[ids[i]], exponent): the weights of a partition's negative sampler
+ * (WorkerMixin::build_negative_sampler, include/core/solver.h:1263-1278), in the order of ids. */
+int gvs_negative_weights(const float *vertex_weights, const uint32_t *ids, uint64_t n, float exponent, float *out);
+
 /* ---- partition / schedule ------------------------------------------------------------------------------ */
 
 /* Sort vertices by weight descending (ties: ascending id — the reference leaves ties to std::sort), deal them

@@ -157,6 +157,20 @@ int gvref_solver_sample(void *handle, const char *model, int augmentation_step, 
     return num_sample;
 }
 
+// WorkerMixin::load_partition -> build_negative_sampler (solver.h:1263-1278,1435-1496) of worker `worker` for block
+// (head_partition, tail_partition): the negative sampler GraphSolver binds to the tail partition, degree^exponent in
+// the partition's local order.  Returns the table size.
+uint64_t gvref_solver_negative_table(void *handle, int worker, int head_partition, int tail_partition, float exponent,
+                                     float *prob, uint32_t *alias, uint64_t capacity) {
+    SolverT &s = *static_cast<Handle *>(handle)->solver;
+    s.negative_sample_exponent = exponent;
+    s.is_train = false;  // nothing to write back
+    s.workers[worker]->load_partition(head_partition, tail_partition);
+    auto &table = s.workers[worker]->negative_sampler;
+    for (uint64_t i = 0; i < table.count && i < capacity; i++) prob[i] = table.prob_table[i], alias[i] = table.alias_table[i];
+    return table.count;
+}
+
 // alias tables get_sample_function() built: which = 0 the global edge table, 1 vertex_edge_tables[index],
 // 2 edge_edge_tables[index]; returns the table size (0 when the vertex / edge has no table)
 uint64_t gvref_solver_table(void *handle, int which, uint64_t index, float *prob, uint64_t *alias, uint64_t capacity) {

@@ -109,6 +109,9 @@ def main():
         solver[key + "_schedule"] = rs.schedule()
         if name.startswith("auto"):
             continue
+        # WorkerMixin::build_negative_sampler for every tail partition (degree ^ 0.75 in local order)
+        for tp in range(rs.num_partition):
+            solver[key + "_negative_prob_%d" % tp], solver[key + "_negative_alias_%d" % tp] = rs.negative_table(0, tp)
         solver[key + "_edge_pools"] = rs.sample("LINE", 1)
         prob, alias = rs.table(0)
         solver[key + "_edge_prob"], solver[key + "_edge_alias"] = prob, alias

@@ -347,6 +347,9 @@ class ReferenceSolver(object):
             lib.gvref_solver_sample.restype = C.c_int
             lib.gvref_solver_sample.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                                 C.c_float, C.c_void_p]
+            lib.gvref_solver_negative_table.restype = C.c_uint64
+            lib.gvref_solver_negative_table.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                                        C.c_void_p, C.c_uint64]
             lib.gvref_solver_table.restype = C.c_uint64
             lib.gvref_solver_table.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
         return cls._lib
@@ -404,6 +407,13 @@ class ReferenceSolver(object):
         self.lib().gvref_solver_sample(self.handle, model.encode(), augmentation_step, walk_length, walk_batch,
                                        shuffle_base, p, q, pools.ctypes.data)
         return pools
+
+    def negative_table(self, head_partition, tail_partition, exponent=0.75, worker=0):
+        """WorkerMixin::build_negative_sampler for the block: (prob, alias) over the tail partition's vertices."""
+        prob, alias = np.zeros(self.partition_size, np.float32), np.zeros(self.partition_size, np.uint32)
+        n = self.lib().gvref_solver_negative_table(self.handle, worker, head_partition, tail_partition, exponent,
+                                                   prob.ctypes.data, alias.ctypes.data, self.partition_size)
+        return prob[:n], alias[:n]
 
     def table(self, which, index=0, capacity=1 << 16):
         """which: 0 the global edge table, 1 vertex_edge_tables[index], 2 edge_edge_tables[index] (after sample())."""
