@@ -23,6 +23,7 @@ gvref_uniform_source_t gvref_uniform_source = nullptr;
 int gvref_generator_count = 0;
 
 #include "instance/graph.cuh"
+#include "instance/word_graph.cuh"
 
 // The GPU workers never run here.  Their two dispatch functions are the only code that instantiates the reference's CUDA
 // kernels (instance/gpu/graph.cuh, written for nvcc: `model.backward<...>` without the `template` disambiguator does
@@ -169,6 +170,54 @@ uint64_t gvref_solver_negative_table(void *handle, int worker, int head_partitio
     auto &table = s.workers[worker]->negative_sampler;
     for (uint64_t i = 0; i < table.count && i < capacity; i++) prob[i] = table.prob_table[i], alias[i] = table.alias_table[i];
     return table.count;
+}
+
+// ---- the reference's text loaders on their own --------------------------------------------------------------------
+// kind 0: Graph::load_file (graph.cuh:163-201); kind 1: WordGraph::load_file_compact (word_graph.cuh:73-181), for
+// which a = window, b = min_count.  The graph is returned flattened (core/graph.h:87-101).
+struct LoadedGraph {
+    GraphT graph;
+    graphvite::WordGraph<uint32_t> words;
+    graphvite::Graph<uint32_t> *which = nullptr;
+};
+
+void *gvref_graph_load(int kind, const char *file_name, int a, int b, int normalization, const char *delimiters,
+                       const char *comment) {
+    LoadedGraph *g = new LoadedGraph();
+    if (kind == 0) {
+        g->graph.load_file(file_name, a != 0, normalization != 0, delimiters, comment);
+        g->which = &g->graph;
+    } else {
+        g->words.load_file_compact(file_name, a, b, normalization != 0, delimiters, comment);
+        g->which = &g->words;
+    }
+    g->which->flatten();
+    return g;
+}
+
+void gvref_graph_destroy(void *handle) { delete static_cast<LoadedGraph *>(handle); }
+
+// out: num_vertex, num_edge, number of flattened edges, total bytes of the names joined by '\n'
+void gvref_graph_info(void *handle, int64_t *out) {
+    auto *g = static_cast<LoadedGraph *>(handle)->which;
+    size_t bytes = 0;
+    for (auto &&name : g->id2name) bytes += name.size() + 1;
+    out[0] = g->num_vertex, out[1] = g->num_edge, out[2] = (int64_t)g->edges.size(), out[3] = (int64_t)bytes;
+}
+
+void gvref_graph_data(void *handle, char *names, uint32_t *uv, float *edge_weights, float *vertex_weights) {
+    auto *g = static_cast<LoadedGraph *>(handle)->which;
+    for (auto &&name : g->id2name) {
+        memcpy(names, name.data(), name.size());
+        names += name.size();
+        *names++ = '\n';
+    }
+    for (size_t e = 0; e < g->edges.size(); e++) {
+        uv[2 * e] = std::get<0>(g->edges[e]);
+        uv[2 * e + 1] = std::get<1>(g->edges[e]);
+        edge_weights[e] = g->edge_weights[e];
+    }
+    for (size_t v = 0; v < g->vertex_weights.size(); v++) vertex_weights[v] = g->vertex_weights[v];
 }
 
 // alias tables get_sample_function() built: which = 0 the global edge table, 1 vertex_edge_tables[index],

@@ -15,7 +15,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from oracle_lib import ADAGRAD, ADAM, MOMENTUM, RMSPROP, SGD, Oracle, Reference, ReferenceSolver  # noqa: E402
+from oracle_lib import (ADAGRAD, ADAM, MOMENTUM, RMSPROP, SGD, Oracle, Reference, ReferenceSolver,  # noqa: E402
+                        reference_load)
 
 HP = {SGD: (0, 0, 0), MOMENTUM: (0.9, 0, 0), ADAGRAD: (0, 0, 1e-10), RMSPROP: (0.99, 0, 1e-8),
       ADAM: (0.9, 0.99, 1e-8)}
@@ -131,6 +132,38 @@ def main():
             probs.append(prob), aliases.append(alias.astype(np.uint32)), sizes.append(len(prob))
         solver[key + "_table_prob"], solver[key + "_table_alias"] = np.concatenate(probs), np.concatenate(aliases)
         solver[key + "_table_sizes"] = np.array(sizes, np.int64)
+    # the reference's text loaders: Graph::load_file and WordGraph::load_file_compact on committed inputs
+    import tempfile
+    rng = np.random.default_rng(20260926)
+    names = ["n%d" % i for i in range(25)] + ["7", "007", "a-b", "x_y"]
+    lines = ["# an edge list with comments, blank lines, weights and repeats", ""]
+    for _ in range(120):
+        u, v = rng.choice(names, 2)
+        kind = rng.random()
+        line = "%s %s" % (u, v) if kind < 0.4 else ("%s\t%s\t%.3f" % (u, v, rng.random() * 3 + 0.1))
+        lines.append(line + ("   # trailing comment" if rng.random() < 0.1 else ""))
+    lines += ["n1 n1 2.5", "", "n2   n3", "#n4 n5"]
+    edge_text = "\n".join(lines) + "\n"
+    vocab = ["w%d" % i for i in range(30)]
+    corpus_text = "\n".join(" ".join(rng.choice(vocab, int(rng.integers(0, 20)))) +
+                            ("  # note w0 w0" if rng.random() < 0.2 else "") for _ in range(80)) + "\nthe the the the\n"
+    solver["loader_edge_text"] = np.frombuffer(edge_text.encode(), np.uint8)
+    solver["loader_corpus_text"] = np.frombuffer(corpus_text.encode(), np.uint8)
+    with tempfile.TemporaryDirectory() as tmp:
+        edge_path, corpus_path = os.path.join(tmp, "edges.txt"), os.path.join(tmp, "corpus.txt")
+        open(edge_path, "w").write(edge_text)
+        open(corpus_path, "w").write(corpus_text)
+        cases = {"file_und": (0, edge_path, 1, 0, False), "file_dir": (0, edge_path, 0, 0, False),
+                 "file_und_norm": (0, edge_path, 1, 0, True), "file_dir_norm": (0, edge_path, 0, 0, True),
+                 "corpus_w5_c1": (1, corpus_path, 5, 1, False), "corpus_w2_c3": (1, corpus_path, 2, 3, False),
+                 "corpus_w3_c2_norm": (1, corpus_path, 3, 2, True)}
+        for name, (kind, path, a, b, norm) in cases.items():
+            got_names, uv, ew, vw, num_edge = reference_load(kind, path, a, b, norm)
+            key = "loader_" + name
+            solver[key + "_args"] = np.array([kind, a, b, norm], np.int64)
+            solver[key + "_names"] = np.frombuffer("\n".join(got_names).encode(), np.uint8)
+            solver[key + "_uv"], solver[key + "_edge_weights"], solver[key + "_vertex_weights"] = uv, ew, vw
+            solver[key + "_num_edge"] = np.int64(num_edge)
     path = os.path.join(HERE, "reference_solver.npz")
     np.savez_compressed(path, **solver)
     print("wrote %s (%d arrays, %.1f KiB)" % (path, len(solver), os.path.getsize(path) / 1024))

@@ -420,3 +420,24 @@ class ReferenceSolver(object):
         prob, alias = np.zeros(capacity, np.float32), np.zeros(capacity, np.uint64)
         n = self.lib().gvref_solver_table(self.handle, which, index, prob.ctypes.data, alias.ctypes.data, capacity)
         return prob[:n], alias[:n]
+
+
+def reference_load(kind, path, a, b=0, normalization=False, delimiters=" \t\r\n", comment="#"):
+    """The reference's own text loaders (oracle/ref_solver_harness.cpp): kind 0 = Graph::load_file(as_undirected=a),
+    kind 1 = WordGraph::load_file_compact(window=a, min_count=b).  Returns (names, uv, edge_weights, vertex_weights,
+    num_edge) of the flattened graph."""
+    lib = ReferenceSolver.lib()
+    lib.gvref_graph_load.restype = C.c_void_p
+    lib.gvref_graph_load.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
+    lib.gvref_graph_destroy.argtypes = [C.c_void_p]
+    lib.gvref_graph_info.argtypes = [C.c_void_p, C.c_void_p]
+    lib.gvref_graph_data.argtypes = [C.c_void_p] * 5
+    h = lib.gvref_graph_load(kind, path.encode(), int(a), int(b), int(normalization), delimiters.encode(), comment.encode())
+    info = np.zeros(4, np.int64)
+    lib.gvref_graph_info(h, info.ctypes.data)
+    N, num_edge, D, name_bytes = [int(x) for x in info]
+    names = C.create_string_buffer(max(name_bytes, 1))
+    uv, ew, vw = np.zeros((D, 2), np.uint32), np.zeros(D, np.float32), np.zeros(N, np.float32)
+    lib.gvref_graph_data(h, names, uv.ctypes.data, ew.ctypes.data, vw.ctypes.data)
+    lib.gvref_graph_destroy(h)
+    return names.raw[:name_bytes].decode().split("\n")[:-1] if name_bytes else [], uv, ew, vw, num_edge
