@@ -17,6 +17,12 @@
 #include <cuda_runtime.h>
 #include <curand.h>
 
+// From here on every `__device__` function of the reference (the optimizer updates, core/optimizer.h:162-213) is
+// host-callable as well: the GPU workers' kernel is emulated below by a sequential host loop over the reference's own
+// model and optimizer code.
+#undef __device__
+#define __device__ __attribute__((device)) __attribute__((host))
+
 int gvref_device_count = 1;
 size_t gvref_device_memory = (size_t)16 << 30;  // a P100's 16 GB, the card the reference's defaults were tuned on
 gvref_uniform_source_t gvref_uniform_source = nullptr;
@@ -30,10 +36,60 @@ int gvref_generator_count = 0;
 // not parse under clang), so they are specialised away before anything instantiates the worker class.
 namespace graphvite {
 typedef SolverMixin<128, float, uint32_t, Graph, GraphSampler, GraphWorker> HarnessSolverBase;
+// gpu::Sample (alias_table.cuh:176-185) run on the host: one draw per pair of uniforms, narrowed to Float as the kernel
+// narrows them, through the table's own sample().
 template <>
-void AliasTable<float, uint32_t>::device_sample(const Memory<double, int> &, Memory<uint32_t, int> *) {}  // gpu::Sample launch
+void AliasTable<float, uint32_t>::device_sample(const Memory<double, int> &rand, Memory<uint32_t, int> *result) {
+    for (int i = 0; i < result->count; i++) {
+        float rand1 = rand.device_ptr[i * 2], rand2 = rand.device_ptr[i * 2 + 1];
+        result->device_ptr[i] = sample(rand1, rand2);
+    }
+}
+
+// gpu::graph::train<Vector, Index, Model, kSGD> (instance/gpu/graph.cuh:36-95) as a sequential host loop over the
+// reference's own model code — the same restatement as oracle/ref_harness.cpp, here on the worker's buffers, so that
+// the reference's WHOLE training loop (sampler threads, schedule, partition loads and write-backs, negative sampler,
+// lr schedule) runs on the CPU.  Samples of a batch are applied one after the other (no lost updates).
 template <>
-bool GraphWorker<HarnessSolverBase>::train_dispatch() { return false; }
+bool GraphWorker<HarnessSolverBase>::train_dispatch() {
+    auto *solver = reinterpret_cast<graphvite::GraphSolver<128, float, uint32_t> *>(this->solver);
+    if (num_moment != 0 || optimizer.type != "SGD") return false;
+    typedef graphvite::Vector<128, float> Vec;
+    typedef LINE<Vec> Model;  // DeepWalk and Node2Vec are the same arithmetic (model/graph.h:60-85)
+    Vec *vertex_embeddings = embeddings[0]->device_ptr, *context_embeddings = embeddings[1]->device_ptr;
+    const uint32_t *samples = batch.device_ptr, *negatives = negative_batch.device_ptr;
+    const int num_sample = batch.count / 2, k = negative_batch.count / num_sample;
+    const float negative_weight = solver->negative_weight;
+    Vec vertex_buffer;
+    for (int sample_id = 0; sample_id < num_sample; sample_id++) {
+        const uint32_t head_id = samples[sample_id * 2 + 1];  // each positive sample is {tail, head}
+        Vec &vertex = vertex_embeddings[head_id];
+        vertex_buffer = vertex;
+        float sample_loss = 0;
+        for (int s = 0; s <= k; s++) {
+            const bool label = s == k;
+            const uint32_t tail_id = label ? samples[sample_id * 2] : negatives[sample_id * k + s];
+            Vec &context = context_embeddings[tail_id];
+            float logit;
+            Model::forward(vertex_buffer, context, logit);
+            const float prob = sigmoid(logit);
+            float gradient, weight;
+            if (label) {
+                gradient = prob - 1;
+                weight = 1;
+                sample_loss += weight * -log(prob + kEpsilon);
+            } else {
+                gradient = prob;
+                weight = negative_weight;
+                sample_loss += weight * -log(1 - prob + kEpsilon);
+            }
+            Model::template backward<kSGD>(vertex_buffer, context, gradient, optimizer, weight);
+        }
+        loss.device_ptr[sample_id] = sample_loss / (1 + k * negative_weight);
+        vertex = vertex_buffer;
+    }
+    return true;
+}
 template <>
 bool GraphWorker<HarnessSolverBase>::predict_dispatch() { return false; }
 }  // namespace graphvite
@@ -156,6 +212,22 @@ int gvref_solver_sample(void *handle, const char *model, int augmentation_step, 
                 record[1] = std::get<0>(sample);  // head
             }
     return num_sample;
+}
+
+// GraphSolver::train (graph.cuh:770-793 -> solver.h:588-654) as written: sampler threads and worker threads, episode
+// after episode; only the kernel launch and the negative draw inside a worker are the host loops above.  Afterwards
+// vertex / context receive the embeddings (num_vertex x 128 each, global ids).
+int gvref_solver_train(void *handle, const char *model, int num_epoch, int augmentation_step, int walk_length,
+                       int walk_batch, int shuffle_base, float p, float q, float negative_sample_exponent,
+                       float negative_weight, float *vertex, float *context) {
+    SolverT &s = *static_cast<Handle *>(handle)->solver;
+    s.train(model, num_epoch, false, augmentation_step, walk_length, walk_batch, shuffle_base, p, q, 1,
+            negative_sample_exponent, negative_weight, 1 << 30);
+    for (uint32_t v = 0; v < s.num_vertex; v++) {
+        memcpy(vertex + (size_t)v * 128, &(*s.vertex_embeddings)[v], 128 * sizeof(float));
+        memcpy(context + (size_t)v * 128, &(*s.context_embeddings)[v], 128 * sizeof(float));
+    }
+    return (int)s.batch_id;
 }
 
 // WorkerMixin::load_partition -> build_negative_sampler (solver.h:1263-1278,1435-1496) of worker `worker` for block

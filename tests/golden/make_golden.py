@@ -16,7 +16,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle_lib import (ADAGRAD, ADAM, MOMENTUM, RMSPROP, SGD, Oracle, Reference, ReferenceSolver,  # noqa: E402
-                        reference_load)
+                        link_prediction_auc, reference_load, reference_train)
 
 HP = {SGD: (0, 0, 0), MOMENTUM: (0.9, 0, 0), ADAGRAD: (0, 0, 1e-10), RMSPROP: (0.99, 0, 1e-8),
       ADAM: (0.9, 0.99, 1e-8)}
@@ -164,6 +164,24 @@ def main():
             solver[key + "_names"] = np.frombuffer("\n".join(got_names).encode(), np.uint8)
             solver[key + "_uv"], solver[key + "_edge_weights"], solver[key + "_vertex_weights"] = uv, ew, vw
             solver[key + "_num_edge"] = np.int64(num_edge)
+    # The reference's WHOLE training loop (GraphSolver::train as written: sampler threads, schedule, partition loads,
+    # negative sampler, lr schedule; the worker's kernel emulated by a sequential host loop over its own model code) on
+    # the graph of the T3 parity test, three uniform seeds: link-prediction AUC.
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from graphvite_amd import synthetic  # the graph generator only; nothing of the product trains here
+    community = synthetic.community_edges(20000, 400000, num_community=100, seed=3)
+    train_edges, (valid, test) = synthetic.link_prediction_split(community, (100, 3, 3))
+    aucs = []
+    for train_seed in (17, 18, 19):
+        rs = ReferenceSolver(oracle, train_seed, train_edges.astype(np.uint32), None, True, 1, 4, 1, 1, 500, 200)
+        vertex, context, batch_id = reference_train(rs, "LINE", 50, 1)
+        labels = rs.partition()[0]
+        name2id = {int(label): i for i, label in enumerate(labels)}
+        keep = [(name2id[int(h)], name2id[int(t)], y) for h, t, y in zip(*test) if int(h) in name2id and int(t) in name2id]
+        aucs.append(link_prediction_auc(vertex, context, [k[0] for k in keep], [k[1] for k in keep], [k[2] for k in keep]))
+        print("reference training loop, seed %d: %d batches, AUC %.6f" % (train_seed, batch_id, aucs[-1]), flush=True)
+    solver["train_line_community_auc"] = np.array(aucs, np.float64)
+    solver["train_line_community_args"] = np.array([20000, 400000, 100, 3, 500, 200, 50], np.int64)
     path = os.path.join(HERE, "reference_solver.npz")
     np.savez_compressed(path, **solver)
     print("wrote %s (%d arrays, %.1f KiB)" % (path, len(solver), os.path.getsize(path) / 1024))

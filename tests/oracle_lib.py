@@ -441,3 +441,19 @@ def reference_load(kind, path, a, b=0, normalization=False, delimiters=" \t\r\n"
     lib.gvref_graph_data(h, names, uv.ctypes.data, ew.ctypes.data, vw.ctypes.data)
     lib.gvref_graph_destroy(h)
     return names.raw[:name_bytes].decode().split("\n")[:-1] if name_bytes else [], uv, ew, vw, num_edge
+
+
+def reference_train(rs, model="LINE", num_epoch=50, augmentation_step=1, walk_length=40, walk_batch=100, shuffle_base=1,
+                    p=1.0, q=1.0, negative_sample_exponent=0.75, negative_weight=5.0):
+    """GraphSolver::train of the reference as written on a built ReferenceSolver, with the worker's kernel and negative
+    draw emulated by sequential host loops over its own model code (oracle/ref_solver_harness.cpp).  Returns
+    (vertex_embeddings, context_embeddings, batch_id)."""
+    lib = ReferenceSolver.lib()
+    lib.gvref_solver_train.restype = C.c_int
+    lib.gvref_solver_train.argtypes = [C.c_void_p, C.c_char_p] + [C.c_int] * 5 + [C.c_float] * 4 + [C.c_void_p] * 2
+    vertex = np.zeros((rs.num_vertex, 128), np.float32)
+    context = np.zeros((rs.num_vertex, 128), np.float32)
+    batch_id = lib.gvref_solver_train(rs.handle, model.encode(), num_epoch, augmentation_step, walk_length, walk_batch,
+                                      shuffle_base, p, q, negative_sample_exponent, negative_weight,
+                                      vertex.ctypes.data, context.ctypes.data)
+    return vertex, context, batch_id

@@ -230,3 +230,30 @@ def test_exchange_runs_on_rccl():
         session.finish()
     finally:
         dist.destroy_process_group()
+
+
+def test_auc_matches_the_reference_training_loop():
+    """The reference's WHOLE training loop — GraphSolver::train as written: its sampler threads, schedule, partition
+    loads and write-backs, negative sampler and lr schedule, with only the CUDA kernel replaced by a sequential host loop
+    over its own model code (oracle/ref_solver_harness.cpp) — was run on this graph for three uniform seeds; its
+    link-prediction AUCs are in tests/golden/reference_solver.npz.  The two pipelines share no random stream (cuRAND /
+    mt19937 there, Philox / numpy here), so the comparison is between means: within the north_star's +-0.002."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_solver.npz"))
+    n, e, communities, graph_seed, batch, episode, epochs = [int(x) for x in G["train_line_community_args"]]
+    reference = G["train_line_community_auc"]
+    edges = synthetic.community_edges(n, e, num_community=communities, seed=graph_seed)
+    train, (valid, test) = synthetic.link_prediction_split(edges, (100, 3, 3))
+    gv.init_logging(logging.ERROR)
+    g = gv.graph.Graph()
+    g.load(train)
+    aucs = []
+    for seed in (17, 18, 19):
+        s = gv.solver.GraphSolver(128, num_sampler_per_worker=4, seed=seed)
+        s.build(g, batch_size=batch, episode_size=episode)
+        s.train(model="LINE", num_epoch=epochs, augmentation_step=1, log_frequency=1 << 30)
+        aucs.append(auc_of(g, s, test))
+    print("AUC here %s (mean %.6f) | reference training loop %s (mean %.6f)" % (
+        " ".join("%.6f" % a for a in aucs), np.mean(aucs), " ".join("%.6f" % a for a in reference), reference.mean()))
+    assert abs(np.mean(aucs) - reference.mean()) <= 0.002
+    assert min(aucs) > reference.min() - 0.003 and max(aucs) < reference.max() + 0.003
