@@ -182,6 +182,21 @@ def main():
         print("reference training loop, seed %d: %d batches, AUC %.6f" % (train_seed, batch_id, aucs[-1]), flush=True)
     solver["train_line_community_auc"] = np.array(aucs, np.float64)
     solver["train_line_community_args"] = np.array([20000, 400000, 100, 3, 500, 200, 50], np.int64)
+    # ... and with several workers on a smaller graph: the reference's partition loads / write-backs through host memory
+    # between its worker threads (what this repo replaces by pinned context shards + an all-gather of head shards)
+    small = synthetic.community_edges(4000, 80000, num_community=40, seed=5)
+    small_train, (valid, small_test) = synthetic.link_prediction_split(small, (100, 3, 3))
+    for W, P in ((1, 1), (2, 2), (2, 4)):
+        rs = ReferenceSolver(oracle, 3, small_train.astype(np.uint32), None, True, W, 2, P, 1, 200, 40)
+        vertex, context, batch_id = reference_train(rs, "LINE", 150, 1)
+        labels = rs.partition()[0]
+        name2id = {int(label): i for i, label in enumerate(labels)}
+        keep = [(name2id[int(h)], name2id[int(t)], y) for h, t, y in zip(*small_test)
+                if int(h) in name2id and int(t) in name2id]
+        auc = link_prediction_auc(vertex, context, [k[0] for k in keep], [k[1] for k in keep], [k[2] for k in keep])
+        print("reference training loop, %d workers / %d partitions: AUC %.6f" % (W, P, auc), flush=True)
+        solver["train_small_w%d_p%d_auc" % (W, P)] = np.float64(auc)
+    solver["train_small_args"] = np.array([4000, 80000, 40, 5, 200, 40, 150], np.int64)
     path = os.path.join(HERE, "reference_solver.npz")
     np.savez_compressed(path, **solver)
     print("wrote %s (%d arrays, %.1f KiB)" % (path, len(solver), os.path.getsize(path) / 1024))

@@ -520,3 +520,46 @@ def test_auto_build_rules_match_the_reference_solver():
     s.build(g, batch_size=int(args[5]))
     assert (s.num_vertex, s.num_edge) == (int(info[0]), int(info[1]))
     assert s.num_partition == int(info[3]) and s.episode_size == int(info[4])
+
+
+def _auc_worker(rank, world, port, out_path, num_partition):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import logging
+        gv.init_logging(logging.ERROR)
+        G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_solver.npz"))
+        n, e, communities, graph_seed, batch, episode, epochs = [int(x) for x in G["train_small_args"]]
+        edges = synthetic.community_edges(n, e, num_community=communities, seed=graph_seed)
+        train, (valid, test) = synthetic.link_prediction_split(edges, (100, 3, 3))
+        g = gv.graph.Graph()
+        g.load(train)
+        s = gv.solver.GraphSolver(128, kernels=OracleKernels(), num_sampler_per_worker=2, seed=3)
+        s.build(g, batch_size=batch, episode_size=episode, num_partition=num_partition)
+        s.train(model="LINE", num_epoch=epochs, augmentation_step=1, log_frequency=1 << 30)
+        if rank == 0:
+            n2i = g.name2id
+            keep = [(n2i[str(h)], n2i[str(t)], y) for h, t, y in zip(*test) if str(h) in n2i and str(t) in n2i]
+            auc = link_prediction_auc(s.vertex_embeddings, s.context_embeddings, [k[0] for k in keep],
+                                      [k[1] for k in keep], [k[2] for k in keep])
+            np.save(out_path, np.array([auc]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_workers_learn_what_the_reference_two_workers_learn(tmp_path):
+    """Learning quality of the multi-GPU data path.  The reference's own training loop with 2 worker threads and 4
+    partitions (partition loads and write-backs through host memory, solver.h:1349-1504; run on the host by
+    oracle/ref_solver_harness.cpp) reached the link-prediction AUC stored in tests/golden/reference_solver.npz; two
+    gloo workers of this repo (context shards pinned per worker, asynchronous all-gather of head shards, head groups
+    interleaved) must reach it too.  A stale or misplaced shard costs far more than the +-0.002 of seed noise."""
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_solver.npz"))
+    world, port, out = 2, _free_port(), str(tmp_path / "auc.npy")
+    mp.spawn(_auc_worker, args=(world, port, out, 4), nprocs=world, join=True)
+    auc = float(np.load(out)[0])
+    ref2, ref1 = float(G["train_small_w2_p4_auc"]), float(G["train_small_w1_p1_auc"])
+    print("2 workers / 4 partitions: AUC %.6f | reference loop: %.6f (2 workers / 4 partitions), %.6f (1 worker)"
+          % (auc, ref2, ref1))
+    assert abs(auc - ref2) <= 0.006 and abs(auc - ref1) <= 0.006
