@@ -37,11 +37,15 @@ int gvref_generator_count = 0;
 namespace graphvite {
 typedef SolverMixin<128, float, uint32_t, Graph, GraphSampler, GraphWorker> HarnessSolverBase;
 // gpu::Sample (alias_table.cuh:176-185) run on the host: one draw per pair of uniforms, narrowed to Float as the kernel
-// narrows them, through the table's own sample().
+// narrows them, through the table's own sample().  One guard the kernel does not have: a double uniform within 2^-25
+// of 1 narrows to 1.0f, sample() then computes index == count and reads one entry past both tables (AddressSanitizer
+// caught exactly that here, one draw in 3 * 10^7) — on the GPU a silent garbage negative, on the host a wild row index
+// that corrupts the heap.  Such a uniform is moved to the last slot instead.
 template <>
 void AliasTable<float, uint32_t>::device_sample(const Memory<double, int> &rand, Memory<uint32_t, int> *result) {
     for (int i = 0; i < result->count; i++) {
         float rand1 = rand.device_ptr[i * 2], rand2 = rand.device_ptr[i * 2 + 1];
+        if (rand1 >= 1.0f) rand1 = 0.99999994f;  // the largest float below 1
         result->device_ptr[i] = sample(rand1, rand2);
     }
 }
