@@ -57,6 +57,7 @@ def parse(argv=None):
                         "auto episode size for this graph (solver.h:426-436), capped at 250")
     p.add_argument("--lanes", type=int, default=0, help="A/B knob: lanes per pair (0 = per-dim default)")
     p.add_argument("--variant", type=int, default=0, help="A/B knob: kernel build variant (gvk.h GVK_TUNE_VARIANT)")
+    p.add_argument("--run-cap", type=int, default=0, help="A/B knob: longest same-head run per lane group (gvk.h GVK_TUNE_RUN_CAP)")
     p.add_argument("--xcd-bucket", choices=["head", "tail"], default=None,
                    help="experiment: reorder every batch so that block b (16 pairs, XCD b % 8) holds pairs whose "
                         "head / tail row id is congruent to b mod 8")
@@ -174,6 +175,8 @@ def main(argv=None, stand_in_kernels=None):
         solver.kernels.set_lanes_per_pair(args.lanes)
     if args.variant:
         solver.kernels.set_variant(args.variant)
+    if args.run_cap:
+        solver.kernels.set_run_cap(args.run_cap)
     optimizer = gv.optimizer.SGD(0.025, 0.005, "linear") if args.optimizer == "SGD" else \
         gv.optimizer.Optimizer(args.optimizer, 1e-3, 0.005)
     solver.build(graph, optimizer=optimizer, num_partition=partitions, num_negative=k,

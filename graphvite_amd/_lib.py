@@ -12,6 +12,8 @@ GVK_OK, GVK_EINVAL, GVK_EDIM, GVK_EHIP, GVK_ENOMEM = 0, -1, -2, -3, -4
 SGD, MOMENTUM, ADAGRAD, RMSPROP, ADAM = range(5)
 TUNE_LANES_PER_PAIR = 1
 TUNE_VARIANT = 2
+TUNE_RUN_CAP = 3
+TUNE_GENERATION = 4
 
 
 class AliasEntry(C.Structure):
@@ -94,6 +96,8 @@ def lib():
     l.gvk_alias_build.argtypes = [vp, C.c_size_t, vp, vp, i32, vp]
     l.gvk_set_tuning.restype = i32
     l.gvk_set_tuning.argtypes = [i32, i32]
+    l.gvk_describe_train.restype = i32
+    l.gvk_describe_train.argtypes = [i32, i32, i32, i32, i32, C.c_char_p, C.c_size_t]
     l.gvk_last_error.restype = C.c_char_p
     l.gvk_version.restype = C.c_char_p
     # ---- host runtime (include/gvs.h) ----

@@ -39,6 +39,8 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 int g_lanes_per_pair = 0;  // GVK_TUNE_LANES_PER_PAIR
 int g_variant = 0;         // GVK_TUNE_VARIANT
+int g_run_cap = 0;         // GVK_TUNE_RUN_CAP (0 = from the batch size, run_cap_for)
+int g_generation = 0;      // GVK_TUNE_GENERATION (0 = one launch per batch)
 
 struct TrainArgs {
     float *vertex, *context, *vm1, *cm1, *vm2, *cm2;
@@ -49,6 +51,8 @@ struct TrainArgs {
     uint64_t seed;
     uint32_t count, batch_id;
     int batch_size, k;
+    int run_cap;  // train_runs_kernel: longest run of adjacent same-head pairs one lane group trains in sequence
+    int first_sample;  // train_kernel: this launch trains samples [first_sample, batch_size) of the batch (GVK_TUNE_GENERATION)
     float lr, wd, neg_weight, hp0, hp1, eps;
 };
 
@@ -204,7 +208,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_kernel(const TrainArgs a)
     constexpr int M1 = NM >= 1 ? V : 1, M2 = NM >= 2 ? V : 1;
 
     const int tid = blockIdx.x * kBlock + threadIdx.x;
-    const int s = tid / G, lane = tid % G;
+    const int s = a.first_sample + tid / G, lane = tid % G;
     if (s >= a.batch_size) return;  // whole groups leave together: G divides 64
 
     const int k = KT > 0 ? KT : a.k;
@@ -312,6 +316,185 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_kernel(const TrainArgs a)
     }
 
     if (lane == 0) __builtin_nontemporal_store(sample_loss / (1 + k * a.neg_weight), a.loss + s);
+    store_row<DIM, G>(a.vertex, head, lane, v);
+    if constexpr (NM >= 1) store_row<DIM, G>(a.vm1, head, lane, reinterpret_cast<float(&)[V]>(vm1));
+    if constexpr (NM >= 2) store_row<DIM, G>(a.vm2, head, lane, reinterpret_cast<float(&)[V]>(vm2));
+}
+
+// ---- training kernel, runs of same-head pairs ------------------------------------------------------------------
+//
+// The shipped kernel.  Same lane layout, loads, arithmetic and negative draw as train_kernel above (which stays as
+// the per-pair A/B build, GVK_TUNE_VARIANT 2); the unit of work of a lane group is a RUN instead of a pair: the pairs
+// j = s, s + 1, ... that sit next to each other in the batch, share the head row of pair s and lie in the same
+// run_cap-aligned segment of the batch.  The lane group of the run's first pair keeps the head row in registers over
+// the whole run — one load, one store, every pair of the run sees the updates of the pairs before it, exactly like
+// consecutive iterations of one warp's grid-stride loop in the reference (gpu/graph.cuh:54-94) — and the lane groups
+// of the other pairs of the run retire at once.  Sample j keeps its own identity: negatives are drawn for (batch, j),
+// loss goes to loss[j].
+//
+// Batches in sampler order have almost no adjacent same-head pairs and behave as before.  After gvk_group_pairs
+// every head row of a batch is one or more runs: the row crosses HBM once per run instead of once per pair, and of
+// the m pairs of a batch that share a hub row, min(m, run_cap) consecutive updates survive instead of one (the
+// remaining ceil(m / run_cap) - 1 lane groups train the same row concurrently from the same start; the last store wins, as it
+// does between any two concurrent warps of the reference).  run_cap = batch_size / 5120, rounded up, is how many
+// times the reference's <<<8192, 512>>> launch refills a V100 (5120 resident warps) within one batch, i.e. how many
+// generations of updates to one row that launch can chain.
+//
+// Pipelining inside a run: the header of pair j + 1 is loaded one pair ahead, its first alias slot as soon as the
+// header says the run continues, and its first target row while the positive target of pair j is computed — the
+// one-ahead row prefetch of the per-pair kernel carried across pairs.
+template <int DIM, int G, int OPT, int KT = 0, int DRAW = -1, int WAVES = 4>
+__global__ void __launch_bounds__(kBlock, WAVES) train_runs_kernel(const TrainArgs a) {
+    constexpr int V = DIM / G;
+    constexpr int NM = OPT == GVK_SGD ? 0 : (OPT == GVK_ADAM ? 2 : 1);  // moments per row
+    constexpr int M1 = NM >= 1 ? V : 1, M2 = NM >= 2 ? V : 1;
+
+    const int tid = blockIdx.x * kBlock + threadIdx.x;
+    const int s = tid / G, lane = tid % G;
+    if (s >= a.batch_size) return;  // whole groups leave together: G divides 64
+
+    const int k = KT > 0 ? KT : a.k;
+    const bool draw = DRAW < 0 ? a.negatives == nullptr : DRAW != 0;
+    const int R = a.run_cap;
+    const u32x2 *records = reinterpret_cast<const u32x2 *>(a.pairs);
+
+    // round trip 1: the pair, its neighbours in the segment, and the first negative's alias slot
+    Draw d0 = {0, 0};
+    gvk_alias_entry e0 = {0, 0};
+    uint32_t neg0 = 0;
+    if (k > 0) {
+        if (draw) {
+            d0 = negative_slot(a.seed, a.batch_id, (uint32_t)s, 0, a.count);
+            e0 = a.table[d0.index];
+        } else {
+            neg0 = __builtin_nontemporal_load(a.negatives + (size_t)s * k);
+        }
+    }
+    const u32x2 pr = records[s];
+    uint32_t tail = pr.x;
+    const uint32_t head = pr.y;  // records are {tail, head}
+    const int first_of_segment = s - s % R;
+    const int limit = first_of_segment + R < a.batch_size ? first_of_segment + R : a.batch_size;
+    u32x2 next_pr = {0, 0};
+    if (s + 1 < limit) next_pr = records[s + 1];
+    if (s > first_of_segment && records[s - 1].y == head) return;  // this pair belongs to the run of a pair before it
+
+    // round trip 2: vertex row (+ moments) and the first target row
+    float v[V], vm1[M1], vm2[M2];
+    load_row<DIM, G>(a.vertex, head, lane, v);
+    if constexpr (NM >= 1) load_row<DIM, G>(a.vm1, head, lane, reinterpret_cast<float(&)[V]>(vm1));
+    if constexpr (NM >= 2) load_row<DIM, G>(a.vm2, head, lane, reinterpret_cast<float(&)[V]>(vm2));
+
+    uint32_t id_cur = k > 0 ? (draw ? resolve(d0, e0) : neg0) : tail;
+    float cur[V], cur1[M1], cur2[M2];
+    load_row<DIM, G>(a.context, id_cur, lane, cur);
+    if constexpr (NM >= 1) load_row<DIM, G>(a.cm1, id_cur, lane, reinterpret_cast<float(&)[V]>(cur1));
+    if constexpr (NM >= 2) load_row<DIM, G>(a.cm2, id_cur, lane, reinterpret_cast<float(&)[V]>(cur2));
+
+    int j = s;  // the pair being trained
+    while (true) {
+        // does the run go on with pair j + 1?  If so its first alias slot and the header of pair j + 2 are requested
+        // now; both are back long before the positive step below needs them.
+        const bool more = j + 1 < limit && next_pr.y == head;
+        Draw dn = {0, 0};
+        gvk_alias_entry en = {0, 0};
+        uint32_t negn = 0;
+        u32x2 after_pr = {0, 0};
+        if (more) {
+            if (k > 0) {
+                if (draw) {
+                    dn = negative_slot(a.seed, a.batch_id, (uint32_t)(j + 1), 0, a.count);
+                    en = a.table[dn.index];
+                } else {
+                    negn = __builtin_nontemporal_load(a.negatives + (size_t)(j + 1) * k);
+                }
+            }
+            if (j + 2 < limit) after_pr = records[j + 2];
+        }
+
+        float sample_loss = 0;
+        auto target_step = [&](const int t) __attribute__((always_inline)) {
+            // request the next target row before touching the current one: the next negative, the positive, or —
+            // at the positive — the first target of the next pair of the run
+            const bool has_next = t < k || more;
+            uint32_t id_nxt = 0;
+            float nxt[V], nxt1[M1], nxt2[M2];
+            if (has_next) {
+                if (t + 1 < k) {
+                    if (draw) {
+                        Draw d = negative_slot(a.seed, a.batch_id, (uint32_t)j, (uint32_t)(t + 1), a.count);
+                        id_nxt = resolve(d, a.table[d.index]);
+                    } else {
+                        id_nxt = __builtin_nontemporal_load(a.negatives + (size_t)j * k + t + 1);
+                    }
+                } else if (t < k) {
+                    id_nxt = tail;
+                } else {
+                    id_nxt = k > 0 ? (draw ? resolve(dn, en) : negn) : next_pr.x;
+                }
+                load_row<DIM, G>(a.context, id_nxt, lane, nxt);
+                if constexpr (NM >= 1) load_row<DIM, G>(a.cm1, id_nxt, lane, reinterpret_cast<float(&)[V]>(nxt1));
+                if constexpr (NM >= 2) load_row<DIM, G>(a.cm2, id_nxt, lane, reinterpret_cast<float(&)[V]>(nxt2));
+            }
+
+            // forward: model/graph.h:40-45
+            float partial = 0;
+#pragma unroll
+            for (int i = 0; i < V; i++) partial += v[i] * cur[i];
+            const float logit = group_sum<G>(partial);
+            const float prob = sigmoidf(logit);
+            // gpu/graph.cuh:77-87
+            float gradient, weight;
+            if (t == k) {
+                gradient = prob - 1;
+                weight = 1;
+                sample_loss += weight * -logf(prob + kEpsilon);
+            } else {
+                gradient = prob;
+                weight = a.neg_weight;
+                sample_loss += weight * -logf(1 - prob + kEpsilon);
+            }
+            // backward: model/graph.h:47-58 — both updates use the pre-update v and c
+#pragma unroll
+            for (int i = 0; i < V; i++) {
+                const float vi = v[i], ci = cur[i];
+                v[i] -= update<OPT>(a, vi, gradient * ci, weight, vm1[NM >= 1 ? i : 0], vm2[NM >= 2 ? i : 0]);
+                cur[i] -= update<OPT>(a, ci, gradient * vi, weight, cur1[NM >= 1 ? i : 0], cur2[NM >= 2 ? i : 0]);
+            }
+            store_row<DIM, G>(a.context, id_cur, lane, cur);
+            if constexpr (NM >= 1) store_row<DIM, G>(a.cm1, id_cur, lane, reinterpret_cast<float(&)[V]>(cur1));
+            if constexpr (NM >= 2) store_row<DIM, G>(a.cm2, id_cur, lane, reinterpret_cast<float(&)[V]>(cur2));
+
+            if (has_next) {
+                // The next row was requested before this one was updated.  If it is the same row, carry the updated
+                // registers forward so that the run sees its own update, as the reference's sequential warp does.
+                const bool same = id_nxt == id_cur;
+#pragma unroll
+                for (int i = 0; i < V; i++) cur[i] = same ? cur[i] : nxt[i];
+                if constexpr (NM >= 1) {
+#pragma unroll
+                    for (int i = 0; i < V; i++) cur1[i] = same ? cur1[i] : nxt1[i];
+                }
+                if constexpr (NM >= 2) {
+#pragma unroll
+                    for (int i = 0; i < V; i++) cur2[i] = same ? cur2[i] : nxt2[i];
+                }
+                id_cur = id_nxt;
+            }
+        };
+        if constexpr (KT > 0) {
+#pragma unroll
+            for (int t = 0; t <= KT; t++) target_step(t);
+        } else {
+            for (int t = 0; t <= k; t++) target_step(t);
+        }
+        if (lane == 0) __builtin_nontemporal_store(sample_loss / (1 + k * a.neg_weight), a.loss + j);
+        if (!more) break;
+        j++;
+        tail = next_pr.x;
+        next_pr = after_pr;
+    }
+
     store_row<DIM, G>(a.vertex, head, lane, v);
     if constexpr (NM >= 1) store_row<DIM, G>(a.vm1, head, lane, reinterpret_cast<float(&)[V]>(vm1));
     if constexpr (NM >= 2) store_row<DIM, G>(a.vm2, head, lane, reinterpret_cast<float(&)[V]>(vm2));
@@ -541,28 +724,28 @@ bool lanes_ok(int dim, int g) {
 
 typedef void (*TrainKernel)(const TrainArgs);
 
-// non-default lane groups exist for A/B measurement of the SGD kernel only
-template <int DIM, int G>
+// RUNS picks train_runs_kernel (shipped) or train_kernel (per-pair A/B build).  Non-default lane groups exist for A/B
+// measurement of the SGD kernel only.
+template <int DIM, int G, bool RUNS>
 TrainKernel pick_sgd(int opt) {
-    return opt == GVK_SGD ? train_kernel<DIM, G, GVK_SGD> : nullptr;
+    if (opt != GVK_SGD) return nullptr;
+    return RUNS ? train_runs_kernel<DIM, G, GVK_SGD> : train_kernel<DIM, G, GVK_SGD>;
 }
 
-template <int DIM, int G>
+template <int DIM, int G, bool RUNS>
 TrainKernel pick_any(int opt) {
-    switch (opt) {
-        case GVK_SGD: return train_kernel<DIM, G, GVK_SGD>;
-        case GVK_MOMENTUM: return train_kernel<DIM, G, GVK_MOMENTUM>;
-        case GVK_ADAGRAD: return train_kernel<DIM, G, GVK_ADAGRAD>;
-        case GVK_RMSPROP: return train_kernel<DIM, G, GVK_RMSPROP>;
-        case GVK_ADAM: return train_kernel<DIM, G, GVK_ADAM>;
-    }
+#define GVK_OPT(O) \
+    case O: return RUNS ? train_runs_kernel<DIM, G, O> : train_kernel<DIM, G, O>;
+    switch (opt) { GVK_OPT(GVK_SGD) GVK_OPT(GVK_MOMENTUM) GVK_OPT(GVK_ADAGRAD) GVK_OPT(GVK_RMSPROP) GVK_OPT(GVK_ADAM) }
+#undef GVK_OPT
     return nullptr;
 }
 
+template <bool RUNS>
 TrainKernel pick_train(int dim, int g, int opt) {
     const bool def = g == default_lanes(dim);
 #define GVK_CASE(D, GG)                                                      \
-    if (dim == D && g == GG) return def ? pick_any<D, GG>(opt) : pick_sgd<D, GG>(opt);
+    if (dim == D && g == GG) return def ? pick_any<D, GG, RUNS>(opt) : pick_sgd<D, GG, RUNS>(opt);
     GVK_CASE(32, 8) GVK_CASE(32, 16)
     GVK_CASE(64, 8) GVK_CASE(64, 16)
     GVK_CASE(96, 8) GVK_CASE(96, 16)
@@ -571,6 +754,18 @@ TrainKernel pick_train(int dim, int g, int opt) {
     GVK_CASE(512, 32) GVK_CASE(512, 64)
 #undef GVK_CASE
     return nullptr;
+}
+
+// Longest run one lane group trains in sequence (train_runs_kernel): how many times the reference's launch refills
+// the card it was written for within one batch — 8192 x 512 threads = one warp per sample (util/gpu.cuh:41-43), a
+// V100 holds 80 SMs x 2048 threads = 5120 of those warps at a time.
+constexpr int kReferenceResidentWarps = 5120;
+constexpr int kMaxRunCap = 64;
+
+int run_cap_for(int batch_size) {
+    if (g_run_cap > 0) return g_run_cap;
+    const int generations = (batch_size + kReferenceResidentWarps - 1) / kReferenceResidentWarps;
+    return generations < 1 ? 1 : (generations > kMaxRunCap ? kMaxRunCap : generations);
 }
 
 int validate_train(int dim, const gvk_optimizer *o, const gvk_tables *t, const uint32_t *pairs,
@@ -591,44 +786,77 @@ int validate_train(int dim, const gvk_optimizer *o, const gvk_tables *t, const u
     return 1;
 }
 
-int launch_train(hipStream_t stream, int dim, const gvk_optimizer *o, float lr, const gvk_tables *t,
-                 const uint32_t *pairs, const gvk_negative_source *neg, uint32_t batch_id, float *loss,
-                 int batch_size, int k, float negative_weight) {
-    int g = g_lanes_per_pair && lanes_ok(dim, g_lanes_per_pair) && o->type == GVK_SGD ? g_lanes_per_pair
-                                                                                      : default_lanes(dim);
-    TrainKernel kernel = pick_train(dim, g, o->type);
+// What launch_train would launch for this configuration under the current tuning (also what gvk_describe_train reports).
+struct Choice {
+    TrainKernel kernel = nullptr;
+    int lanes = 0, run_cap = 1;
+    bool runs = false, fixed_k = false, reference_shape = false;
+};
+
+Choice choose_train(int dim, int opt, int k, bool explicit_negatives, int batch_size) {
+    Choice c;
+    if (g_variant == 3 && dim == 128 && opt == GVK_SGD) {  // the reference's launch shape, graph.cuh:487-490
+        c.reference_shape = true;
+        c.lanes = 64;
+        return c;
+    }
+    c.lanes = g_lanes_per_pair && lanes_ok(dim, g_lanes_per_pair) && opt == GVK_SGD ? g_lanes_per_pair
+                                                                                    : default_lanes(dim);
+    c.runs = g_variant != 2 && g_generation == 0;
+    c.run_cap = c.runs ? run_cap_for(batch_size) : 1;
+    c.kernel = c.runs ? pick_train<true>(dim, c.lanes, opt) : pick_train<false>(dim, c.lanes, opt);
     // SGD with one negative (every shipped configuration of the reference): compile-time k, fixed negative
-    // source -> straight-line code, 62 VGPRs, 8 waves/SIMD.  GVK_TUNE_VARIANT 1 forces the generic build (A/B).
-    if (o->type == GVK_SGD && k == 1 && g == default_lanes(dim) && g_variant == 0) {
-        const bool draw = neg->negatives == nullptr;
-#define GVK_K1(D, GG) \
-    case D: kernel = draw ? train_kernel<D, GG, GVK_SGD, 1, 1> : train_kernel<D, GG, GVK_SGD, 1, 0>; break;
+    // source -> straight-line code.  GVK_TUNE_VARIANT 1 forces the generic build (A/B).
+    if (opt == GVK_SGD && k == 1 && c.lanes == default_lanes(dim) && g_variant != 1) {
+        const bool draw = !explicit_negatives;
+        c.fixed_k = true;
+#define GVK_K1(D, GG)                                                                                         \
+    case D:                                                                                                   \
+        c.kernel = c.runs ? (draw ? train_runs_kernel<D, GG, GVK_SGD, 1, 1> : train_runs_kernel<D, GG, GVK_SGD, 1, 0>) \
+                          : (draw ? train_kernel<D, GG, GVK_SGD, 1, 1> : train_kernel<D, GG, GVK_SGD, 1, 0>);   \
+        break;
         switch (dim) {
             GVK_K1(32, 8) GVK_K1(64, 16) GVK_K1(96, 8) GVK_K1(128, 16) GVK_K1(256, 16) GVK_K1(512, 32)
         }
 #undef GVK_K1
     }
-    if (g_variant == 3 && dim == 128 && o->type == GVK_SGD) {  // the reference's launch shape, graph.cuh:487-490
-        TrainArgs r;
-        memset(&r, 0, sizeof(r));
-        r.vertex = t->vertex; r.context = t->context; r.pairs = pairs; r.negatives = neg->negatives;
-        r.table = neg->table; r.loss = loss; r.seed = neg->seed; r.count = neg->count; r.batch_id = batch_id;
-        r.batch_size = batch_size; r.k = k; r.lr = lr; r.wd = o->weight_decay; r.neg_weight = negative_weight;
-        hipLaunchKernelGGL(train_kernel_reference_shape<128>, dim3(8192), dim3(512), 0, stream, r);
-        return check_launch("gvk_train (reference-shape variant)");
-    }
-    if (!kernel) return fail(GVK_EINVAL, "gvk_train: no kernel for this (dim, lanes, optimizer)");
+    return c;
+}
+
+int launch_train(hipStream_t stream, int dim, const gvk_optimizer *o, float lr, const gvk_tables *t,
+                 const uint32_t *pairs, const gvk_negative_source *neg, uint32_t batch_id, float *loss,
+                 int batch_size, int k, float negative_weight) {
+    const Choice c = choose_train(dim, o->type, k, neg->negatives != nullptr, batch_size);
     TrainArgs a;
+    memset(&a, 0, sizeof(a));
     a.vertex = t->vertex; a.context = t->context;
     a.vm1 = t->vertex_moment1; a.cm1 = t->context_moment1;
     a.vm2 = t->vertex_moment2; a.cm2 = t->context_moment2;
     a.pairs = pairs; a.negatives = neg->negatives; a.table = neg->table; a.loss = loss;
     a.seed = neg->seed; a.count = neg->count; a.batch_id = batch_id;
-    a.batch_size = batch_size; a.k = k;
+    a.batch_size = batch_size; a.k = k; a.run_cap = c.run_cap;
     a.lr = lr; a.wd = o->weight_decay; a.neg_weight = negative_weight;
     a.hp0 = o->hp0; a.hp1 = o->hp1; a.eps = o->epsilon;
-    const unsigned grid = (unsigned)(((int64_t)batch_size * g + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, a);
+    if (c.reference_shape) {
+        hipLaunchKernelGGL(train_kernel_reference_shape<128>, dim3(8192), dim3(512), 0, stream, a);
+        return check_launch("gvk_train (reference-shape variant)");
+    }
+    if (!c.kernel) return fail(GVK_EINVAL, "gvk_train: no kernel for this (dim, lanes, optimizer)");
+    if (g_generation > 0) {
+        // Parity experiment: the batch as consecutive launches of at most g_generation samples each, per-pair kernel —
+        // every launch is small enough to be resident at once, so the samples of a launch run concurrently from the
+        // same table state and a later launch sees everything the earlier ones wrote: the concurrency structure of
+        // the reference's launch on a card that holds g_generation warps.  Same samples, same negatives.
+        for (int first = 0; first < batch_size; first += g_generation) {
+            a.first_sample = first;
+            a.batch_size = first + g_generation < batch_size ? first + g_generation : batch_size;
+            const unsigned grid = (unsigned)(((int64_t)(a.batch_size - first) * c.lanes + kBlock - 1) / kBlock);
+            hipLaunchKernelGGL(c.kernel, dim3(grid), dim3(kBlock), 0, stream, a);
+        }
+        return check_launch("gvk_train (generations)");
+    }
+    const unsigned grid = (unsigned)(((int64_t)batch_size * c.lanes + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(c.kernel, dim3(grid), dim3(kBlock), 0, stream, a);
     return check_launch("gvk_train");
 }
 
@@ -749,6 +977,24 @@ int gvk_sample_walks(void *stream, const gvk_walk_graph *graph, uint64_t seed, u
     return check_launch("gvk_sample_walks");
 }
 
+int gvk_describe_train(int dim, int optimizer_type, int num_negative, int explicit_negatives, int batch_size,
+                       char *name, size_t capacity) {
+    if (!default_lanes(dim)) return fail(GVK_EDIM, "gvk_describe_train: dim must be one of 32, 64, 96, 128, 256, 512");
+    if (optimizer_type < GVK_SGD || optimizer_type > GVK_ADAM || !name || !capacity)
+        return fail(GVK_EINVAL, "gvk_describe_train: unknown optimizer type or no buffer");
+    static const char *const kOptimizers[] = {"SGD", "Momentum", "AdaGrad", "RMSprop", "Adam"};
+    const Choice c = choose_train(dim, optimizer_type, num_negative, explicit_negatives != 0, batch_size);
+    if (c.reference_shape)
+        snprintf(name, capacity, "train_kernel_reference_shape<%d> grid 8192x512", dim);
+    else if (!c.kernel)
+        return fail(GVK_EINVAL, "gvk_describe_train: no kernel for this (dim, lanes, optimizer)");
+    else
+        snprintf(name, capacity, "%s<%d,%d,%s%s> run_cap %d%s", c.runs ? "train_runs_kernel" : "train_kernel", dim, c.lanes,
+                 kOptimizers[optimizer_type], c.fixed_k ? ",k=1" : "", c.run_cap,
+                 g_generation > 0 ? " in launches of one generation" : "");
+    return GVK_OK;
+}
+
 int gvk_set_tuning(int key, int value) {
     if (key == GVK_TUNE_LANES_PER_PAIR) {
         if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64)
@@ -757,8 +1003,18 @@ int gvk_set_tuning(int key, int value) {
         return GVK_OK;
     }
     if (key == GVK_TUNE_VARIANT) {
-        if (value < 0 || value > 3 || value == 2) return fail(GVK_EINVAL, "gvk_set_tuning: variant must be 0, 1 or 3");
+        if (value < 0 || value > 3) return fail(GVK_EINVAL, "gvk_set_tuning: variant must be 0, 1, 2 or 3");
         g_variant = value;
+        return GVK_OK;
+    }
+    if (key == GVK_TUNE_GENERATION) {
+        if (value < 0) return fail(GVK_EINVAL, "gvk_set_tuning: generation size must be >= 0");
+        g_generation = value;
+        return GVK_OK;
+    }
+    if (key == GVK_TUNE_RUN_CAP) {
+        if (value < 0 || value > kMaxRunCap) return fail(GVK_EINVAL, "gvk_set_tuning: run cap must be in [0, 64]");
+        g_run_cap = value;
         return GVK_OK;
     }
     return fail(GVK_EINVAL, "gvk_set_tuning: unknown key");

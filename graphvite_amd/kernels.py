@@ -228,3 +228,19 @@ class HipKernels(object):
 
     def set_variant(self, variant):
         _lib.check(self.lib.gvk_set_tuning(_lib.TUNE_VARIANT, variant), "gvk_set_tuning")
+
+    def set_run_cap(self, run_cap):
+        """Longest run of adjacent same-head pairs one lane group trains in sequence (0 = from the batch size)."""
+        _lib.check(self.lib.gvk_set_tuning(_lib.TUNE_RUN_CAP, run_cap), "gvk_set_tuning")
+
+    def set_generation(self, samples):
+        """Parity experiment: train every batch as consecutive launches of at most `samples` samples (0 = off)."""
+        _lib.check(self.lib.gvk_set_tuning(_lib.TUNE_GENERATION, samples), "gvk_set_tuning")
+
+    def describe_train(self, dim, optimizer_type="SGD", num_negative=1, explicit_negatives=False, batch_size=100000):
+        """Name of the kernel gvk_train launches for this configuration under the current tuning."""
+        name = C.create_string_buffer(160)
+        _lib.check(self.lib.gvk_describe_train(dim, OPTIMIZER_TYPES[optimizer_type], num_negative,
+                                               int(explicit_negatives), batch_size, name, len(name)),
+                   "gvk_describe_train")
+        return name.value.decode()

@@ -192,8 +192,10 @@ class GraphSolver(object):
             num_sampler_per_worker = max(cpu_budget() // max(self._local_world(), 1) - 1, 1)
         self.num_sampler_per_worker = int(num_sampler_per_worker)
         self.num_sampler = self.num_sampler_per_worker * self.num_worker
+        self._gpu_memory_request = gpu_memory_limit
         self.gpu_memory_limit = gpu_memory_limit
         self.gpu_memory_cost = 0
+        self._upload_chunk_bytes = 256 << 20  # host <-> device table traffic goes through chunks of this size
         self.seed = seed
         self.node2vec_table_limit = 1 << 30  # entries (8 B each) of per-edge alias tables before switching to rejection
         # extension: draw LINE's positive edge samples on the GPU instead of CPU threads
@@ -255,12 +257,13 @@ class GraphSolver(object):
         self.batch_id = 0
         W = self.num_worker
         min_partition = W  # get_min_partition, non-tied (solver.h:269-276)
-        limit = self.gpu_memory_limit
+        limit = self._gpu_memory_request  # what the user asked for; `auto` is resolved anew at every build
         if limit == auto:
             limit = torch.cuda.mem_get_info(self.device)[0] if self.device.type == "cuda" else 1 << 62
+        self.episode_size = 0  # nothing of a previous build enters the estimates below
         if num_partition == auto:
             num_partition = min_partition
-            while num_partition < kMaxPartition and self._memory_demand(num_partition) >= limit:
+            while num_partition < kMaxPartition and self._memory_demand(num_partition, episode_size) >= limit:
                 num_partition += min_partition
         else:
             if num_partition < min_partition:
@@ -272,7 +275,7 @@ class GraphSolver(object):
                                kMaxPartition, num_partition)
         self.num_partition = P = int(num_partition)
         self.gpu_memory_limit = limit
-        self.gpu_memory_cost = self._memory_demand(P)
+        self.gpu_memory_cost = self._memory_demand(P, episode_size)
         if self.gpu_memory_cost >= limit:
             raise MemoryError("Can't satisfy the specified GPU memory limit")
 
@@ -289,6 +292,7 @@ class GraphSolver(object):
         self._vertex_of_row[self._row_of_vertex] = np.arange(self.num_vertex, dtype=np.int64)
         self._schedule = self._overlap_order(hostlib.schedule(P, W), P, W)
         self._my_tails = sorted({int(step[self.rank][1]) for step in self._schedule})
+        self._step_heads = None
 
         if episode_size == auto:  # solver.h:426-436
             expected = int(float(self.num_vertex) * kSamplePerVertex / P / self.batch_size)
@@ -320,17 +324,20 @@ class GraphSolver(object):
         order = [(xi * m + yi) * W + o for yi in range(m) for o in range(W) for xi in range(m)]
         return schedule[order]
 
-    def _memory_demand(self, P):
-        """Bytes of HBM this design keeps resident per GPU with P partitions."""
+    def _memory_demand(self, P, episode_size=auto):
+        """Bytes of HBM this design keeps resident per GPU with P partitions (episode_size: the requested one)."""
         S = (self.num_vertex + P - 1) // P
         tails = max(P // self.num_worker, 1)
         rows = P * S + tails * S
         demand = rows * self.dim * 4 * (1 + self.num_moment)
         demand += tails * S * 8                                   # negative alias tables
         demand += self.batch_size * 4                             # loss
-        episode = self.episode_size if getattr(self, "episode_size", 0) else max(
-            int(float(self.num_vertex) * kSamplePerVertex / P / self.batch_size), 1)
-        demand += 2 * episode * self.batch_size * 8               # two device pool buffers
+        if episode_size == auto:
+            episode_size = max(int(float(self.num_vertex) * kSamplePerVertex / P / self.batch_size), 1)
+            if P == 1:
+                episode_size = max(episode_size, kMinEpisodeSample // self.batch_size)
+        demand += 3 * int(episode_size) * self.batch_size * 8     # two device pool buffers + the regrouping landing buffer
+        demand += 2 * self._upload_chunk_bytes                    # upload / write-back transient: one chunk + its row ids
         return demand
 
     # ------------------------------------------------------------------------------------------------ info
@@ -386,11 +393,13 @@ class GraphSolver(object):
         t2 = time.time()
         first_batch = self.batch_id
 
-        def report():
+        def report(failed=False):
+            """Write-back and timing.  On the error path (an exception is propagating on this rank while its peers may be
+            inside training collectives) nothing collective is issued: local shards only, then the error is re-raised."""
             if self.device.type == "cuda":
                 torch.cuda.synchronize(self.device)
             t3 = time.time()
-            self._write_back(state)
+            self._write_back(state, collective=not failed)
             t4 = time.time()
             self.timing = {"configure": t1 - t0, "upload": t2 - t1, "episodes": t3 - t2, "write_back": t4 - t3,
                            "batches": self.batch_id - first_batch, "loop": getattr(self, "_loop_timing", None)}
@@ -398,23 +407,29 @@ class GraphSolver(object):
                         "write back %.2f s", t1 - t0, t2 - t1, self.batch_id - first_batch, t3 - t2,
                         (self.batch_id - first_batch) * self.batch_size / max(t3 - t2, 1e-9) / 1e6, t4 - t3)
 
-        if self.device_sampling:
+        def guarded(loop):
             try:
+                loop()
+            except BaseException:
+                try:
+                    report(failed=True)
+                except Exception:  # the original error is the one to surface
+                    pass
+                raise
+            report()
+
+        if self.device_sampling:
+            def loop():
                 while self.batch_id < self.num_batch:
                     self._train_episode_device_sampling(state)
-            finally:
-                report()
-            return
+            return guarded(loop)
         if self.num_worker > 1 and self._mode != "edge":
-            try:
-                self._train_routed(state)
-            finally:
-                report()
-            return
+            return guarded(lambda: self._train_routed(state))
         per_episode = len(self._schedule) * self.episode_size * self.positive_reuse * self.num_worker
         pools = self._host_pools()
         uploads = [[], []]  # per pool set: events of the async H2D copies still reading its pinned buffers
-        try:
+
+        def loop():
             self._fill(pools[0])
             current = 0
             self._loop_timing = {"wait_upload": 0.0, "enqueue": 0.0, "wait_fill": 0.0, "fill": 0.0}
@@ -444,8 +459,7 @@ class GraphSolver(object):
                 if self._fill_error is not None:
                     raise self._fill_error
                 current ^= 1
-        finally:
-            report()
+        guarded(loop)
 
     def session(self, **train_kwargs):
         """Configure a training run (same keyword arguments as train()), move the tables to HBM and return the
@@ -548,31 +562,42 @@ class GraphSolver(object):
         return t.to(self.device, non_blocking=False)
 
     def _upload_state(self):
-        """Partition-major device tables: vertex [P][S][dim] (all partitions), context [S][dim] per owned tail."""
+        """Partition-major device tables.  state["head"]: [P slots][1 + m][S][dim] — a slot holds one head partition's
+        vertex rows followed by its m moment tables, so that the W shards a schedule step trains form ONE contiguous
+        slab per head group and the exchange is a single in-place all-gather (`_exchange`); state["slot_of"][hp] says
+        where partition hp lives (identity on one GPU).  state["context"] (+ moments): [S][dim] per owned tail."""
         P, S, dim = self.num_partition, self._part_size, self.dim
         nm = self.num_moment
+        chunk_rows = max(self._upload_chunk_bytes // (dim * 4), 1)
 
-        def gather(host, parts):
-            """host [N][dim] (global ids) -> device [len(parts)][S][dim] (local ids); the permutation runs on the
-            device, the host only streams the table once."""
-            full = self._to_device(host)
-            rows = np.concatenate([self._vertex_of_row[p * S:(p + 1) * S] for p in parts])
-            out = full[self._to_device(rows)].view(len(parts), S, dim)
-            del full
-            return out
+        def scatter_in(dest, host, parts, tables=1, table=0):
+            """host [N][dim] (global ids) -> dest [len(parts) slots][tables][S][dim], table `table`, for the vertices whose
+            partition is in `parts` (slot = position in `parts`).  The host table is streamed once, in contiguous chunks
+            of at most 256 MiB; the permutation runs on the device, so the transient is one chunk, not a second table."""
+            slot = np.full(P, -1, np.int64)
+            slot[list(parts)] = np.arange(len(parts))
+            flat = dest.view(-1, dim)
+            for start in range(0, self.num_vertex, chunk_rows):
+                stop = min(start + chunk_rows, self.num_vertex)
+                where = slot[self._part[start:stop]]
+                keep = where >= 0
+                if not keep.any():
+                    continue
+                rows = (where[keep] * tables + table) * S + self._local[start:stop][keep].astype(np.int64)
+                block = host[start:stop] if keep.all() else host[start:stop][keep]
+                flat[self._to_device(rows)] = self._to_device(block)
 
-        state = {"vertex": gather(self.vertex_embeddings, list(range(P))),
-                 "context": gather(self.context_embeddings, self._my_tails)}
-        if nm:
-            mh = self._moments_host if self.resume and self._moments_host is not None else None
-            for j in range(nm):
-                if mh:
-                    state["vertex_m%d" % j] = gather(mh["vertex"][j], list(range(P)))
-                    state["context_m%d" % j] = gather(mh["context"][j], self._my_tails)
-                else:
-                    state["vertex_m%d" % j] = torch.zeros((P, S, dim), dtype=torch.float32, device=self.device)
-                    state["context_m%d" % j] = torch.zeros((len(self._my_tails), S, dim), dtype=torch.float32,
-                                                           device=self.device)
+        head = torch.zeros((P, 1 + nm, S, dim), dtype=torch.float32, device=self.device)
+        context = torch.zeros((len(self._my_tails), S, dim), dtype=torch.float32, device=self.device)
+        scatter_in(head, self.vertex_embeddings, range(P), 1 + nm, 0)
+        scatter_in(context, self.context_embeddings, self._my_tails)
+        state = {"head": head, "context": context, "slot_of": list(range(P)), "part_at": list(range(P))}
+        mh = self._moments_host if self.resume and self._moments_host is not None else None
+        for j in range(nm):
+            state["context_m%d" % j] = torch.zeros((len(self._my_tails), S, dim), dtype=torch.float32, device=self.device)
+            if mh:
+                scatter_in(head, mh["vertex"][j], range(P), 1 + nm, 1 + j)
+                scatter_in(state["context_m%d" % j], mh["context"][j], self._my_tails)
         # negative sampler per owned tail partition: deg^exponent in local order (solver.h:1264-1278)
         from .kernels import alias_build, packed_to_device
         weights = self.graph.vertex_weights
@@ -937,18 +962,46 @@ class GraphSolver(object):
 
     def _tables(self, state, hp, tp):
         ti = self._my_tails.index(tp)
+        slot = state["head"][state["slot_of"][hp]]
         moments = None
         if self.num_moment:
             moments = [None] * 4
             for j in range(self.num_moment):
-                moments[2 * j] = state["vertex_m%d" % j][hp]
+                moments[2 * j] = slot[1 + j]
                 moments[2 * j + 1] = state["context_m%d" % j][ti]
-        return state["vertex"][hp], state["context"][ti], moments
+        return slot[0], state["context"][ti], moments
+
+    def _claim_slot(self, state, hp):
+        """Several GPUs: bring head partition hp to THIS rank's slot of its head group (slot x * W + rank) before it is
+        trained, so that the group's slab is [what rank 0 trained][what rank 1 trained]... and the exchange is one
+        in-place all-gather.  One device-local copy of a shard, at most; whatever partition sat in the slot is trained by
+        another rank in this very step and arrives with the gather.  All ranks apply the same bookkeeping."""
+        W, r = self.num_worker, self.rank
+        group = hp // W
+        step = state.setdefault("claimed", {}).get(group)
+        if step is not None and step[r] == hp:
+            return
+        heads = self._heads_of_step(hp)
+        target = group * W + r
+        source = state["slot_of"][hp]
+        if source != target:
+            state["head"][target].copy_(state["head"][source])
+        for q, part in enumerate(heads):  # after the gather of this step, slot x * W + q holds what rank q trained
+            state["slot_of"][part] = group * W + q
+            state["part_at"][group * W + q] = part
+        state["claimed"][group] = heads
+
+    def _heads_of_step(self, hp):
+        """The head partitions the W ranks train (rank order) in the schedule steps in which THIS rank trains hp."""
+        if getattr(self, "_step_heads", None) is None:
+            self._step_heads = {int(step[self.rank][0]): [int(a[0]) for a in step] for step in self._schedule}
+        return self._step_heads[hp]
 
     def _train_block(self, state, hp, tp, pool):
         """WorkerMixin::train (solver.h:1511-1522): positive_reuse x episode_size batches of one block."""
         if self.num_worker > 1:
             self._wait_exchange(state, hp // self.num_worker)  # this block reads head group hp // W
+            self._claim_slot(state, hp)
         vertex, context, moments = self._tables(state, hp, tp)
         table = state["negative_tables"][tp]
         spec = self.optimizer.spec()
@@ -982,20 +1035,21 @@ class GraphSolver(object):
         self.batch_id += self.episode_size * self.positive_reuse * W
 
     def _exchange(self, state, step_index):
-        """After a schedule step every worker has trained a different head partition of one head group: all-gather
-        those shards so that each GPU again holds the whole, current vertex table (RCCL over xGMI; gloo in the CPU
-        tests).  The collective is asynchronous; `_wait_exchange` fences the next block that reads that group."""
+        """After a schedule step every worker has trained a different head partition of one head group, each in its own
+        slot of the group's slab (`_claim_slot`): ONE in-place all-gather of the slab — vertex rows and moment tables
+        together — gives every GPU the whole, current group again (RCCL over xGMI; gloo in the CPU tests).  The collective
+        is asynchronous; `_wait_exchange` fences the next block that reads that group."""
         import torch.distributed as dist
+        W, r = self.num_worker, self.rank
         heads = [int(a[0]) for a in self._schedule[step_index]]
-        group = min(heads) // self.num_worker
+        group = min(heads) // W
         self._wait_exchange(state, group)
-        names = ["vertex"] + ["vertex_m%d" % j for j in range(self.num_moment)]
-        works = []
-        for name in names:
-            table = state[name]
-            outputs = [table[hp] for hp in heads]
-            works.append(dist.all_gather(outputs, table[heads[self.rank]].clone(), async_op=True))
-        state.setdefault("pending_exchange", {})[group] = works
+        self._claim_slot(state, heads[r])
+        slab = state["head"][group * W:(group + 1) * W]
+        work = dist.all_gather_into_tensor(slab.view(-1), slab[r].view(-1), async_op=True)
+        state.setdefault("pending_exchange", {})[group] = [work]
+        state["exchanged_bytes"] = state.get("exchanged_bytes", 0) + slab[r].numel() * 4 * (W - 1)
+        state["exchanges"] = state.get("exchanges", 0) + 1
 
     def _wait_exchange(self, state, group=None):
         pending = state.get("pending_exchange")
@@ -1005,51 +1059,64 @@ class GraphSolver(object):
             for work in pending.pop(g, []):
                 work.wait()
 
-    def _write_back(self, state):
+    def _write_back(self, state, collective=True):
         """Device -> the stable host arrays behind the numpy views (WorkerMixin::write_back, solver.h:1498-1504).
-        Context shards (and context moments) of the other workers arrive by all-gather."""
+        Context shards (and context moments) of the other workers arrive by all-gather; with collective=False (an error
+        is propagating on this rank: its peers may be anywhere in their own collectives) only what this rank holds is
+        written back and nothing is exchanged."""
         if state is None:
             return
         import torch.distributed as dist
         W, P, S = self.num_worker, self.num_partition, self._part_size
-        self._wait_exchange(state)
+        if collective:
+            self._wait_exchange(state)
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
 
-        def scatter(host, dev, parts):
-            """device [len(parts)][S][dim] -> host [N][dim]: un-permute on the device, one D2H per table."""
-            slot = np.full(P, -1, np.int64)
-            slot[list(parts)] = np.arange(len(parts))
+        def scatter(host, dev, slot_of_part, tables=1, table=0):
+            """device [slots][tables][S][dim], table `table` -> host [N][dim] for the partitions that have a slot:
+            un-permute on the device in chunks of at most 256 MiB, one D2H per chunk."""
+            slot = np.asarray(slot_of_part, np.int64)
             owned = slot[self._part] >= 0
-            rows = slot[self._part[owned]] * S + self._local[owned].astype(np.int64)
-            values = dev.reshape(-1, self.dim)[self._to_device(rows)].cpu().numpy()
-            if owned.all():
-                np.copyto(host, values)
-            else:
-                host[owned] = values
+            rows = (slot[self._part[owned]] * tables + table) * S + self._local[owned].astype(np.int64)
+            flat = dev.view(-1, self.dim)
+            ids = np.flatnonzero(owned) if not owned.all() else None
+            step = max(self._upload_chunk_bytes // (self.dim * 4), 1)
+            for start in range(0, len(rows), step):
+                values = flat[self._to_device(rows[start:start + step])].cpu().numpy()
+                if ids is None:
+                    host[start:start + len(values)] = values
+                else:
+                    host[ids[start:start + len(values)]] = values
 
-        def full_context(name):
+        def context_slots(name):
+            """(device tensor, slot of every partition or -1) of a context-side table, all workers' shards included."""
             mine = state[name]
-            if W == 1:
-                return mine, self._my_tails
-            gathered = [torch.empty_like(mine) for _ in range(W)]
-            dist.all_gather(gathered, mine)
+            slot = np.full(P, -1, np.int64)
+            if W == 1 or not collective:
+                slot[self._my_tails] = np.arange(len(self._my_tails))
+                return mine, slot
+            gathered = torch.empty((W,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+            dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1))
             tails = []
             for rank in range(W):
                 tails += sorted({int(step[rank][1]) for step in self._schedule})
-            return torch.cat(gathered, 0), tails
+            slot[tails] = np.arange(len(tails))
+            return gathered, slot
 
-        scatter(self.vertex_embeddings, state["vertex"], list(range(P)))
-        ctx, tails = full_context("context")
-        scatter(self.context_embeddings, ctx, tails)
+        head_slot, nt = np.asarray(state["slot_of"], np.int64), 1 + self.num_moment
+        scatter(self.vertex_embeddings, state["head"], head_slot, nt, 0)
+        ctx, slot = context_slots("context")
+        scatter(self.context_embeddings, ctx, slot)
         if self.num_moment:
             shape = (self.num_vertex, self.dim)
             self._moments_host = {"vertex": [np.zeros(shape, np.float32) for _ in range(self.num_moment)],
                                   "context": [np.zeros(shape, np.float32) for _ in range(self.num_moment)]}
             for j in range(self.num_moment):
-                scatter(self._moments_host["vertex"][j], state["vertex_m%d" % j], list(range(P)))
-                cm, tails = full_context("context_m%d" % j)
-                scatter(self._moments_host["context"][j], cm, tails)
+                scatter(self._moments_host["vertex"][j], state["head"], head_slot, nt, 1 + j)
+                cm, slot = context_slots("context_m%d" % j)
+                scatter(self._moments_host["context"][j], cm, slot)
+        self.exchange_stats = {"exchanges": state.get("exchanges", 0), "bytes_sent_per_gpu": state.get("exchanged_bytes", 0)}
         self._device_state = None
 
     # ------------------------------------------------------------------------------------------------ predict

@@ -82,3 +82,42 @@ def community_edges(num_vertex, num_edge, num_community=50, p_in=0.9, seed=7):
         out[filled:filled + m, 1] = v[keep]
         filled += m
     return out
+
+
+def hub_community_edges(num_vertex, num_edge, gamma=2.3, num_community=40, p_in=0.7, seed=7):
+    """Degree-corrected planted partition: hub-heavy like `power_law_edges` (u drawn from the same Zipf-like node
+    distribution) AND learnable like `community_edges` (with probability p_in, v is drawn from the same distribution
+    restricted to u's community; communities are the residue classes of the degree rank, so every community has its
+    share of hubs).  The stand-in for the reference's social-network datasets (BlogCatalog: 10 312 nodes, 333 983 edges,
+    39 groups, maximum degree 3 992), which need the network (python/graphvite/dataset.py:182-211)."""
+    rng = np.random.default_rng(seed)
+    K = int(num_community)
+    w = np.arange(1, num_vertex + 1, dtype=np.float64) ** (-1.0 / (gamma - 1.0))
+    cdf = np.cumsum(w)
+    cdf /= cdf[-1]
+    members = [np.arange(k, num_vertex, K) for k in range(K)]          # ranks of community k, ascending
+    member_cdf = []
+    for m in members:
+        c = np.cumsum(w[m])
+        member_cdf.append(c / c[-1])
+    label = rng.permutation(num_vertex).astype(np.uint32)
+    out = np.empty((num_edge, 2), np.uint32)
+    filled = 0
+    while filled < num_edge:
+        n = num_edge - filled
+        u = np.minimum(np.searchsorted(cdf, rng.random(n), side="right"), num_vertex - 1)
+        v = np.minimum(np.searchsorted(cdf, rng.random(n), side="right"), num_vertex - 1)
+        inside = rng.random(n) < p_in
+        r = rng.random(n)
+        community = u % K
+        for k in range(K):
+            pick = np.nonzero(inside & (community == k))[0]
+            if pick.size:
+                j = np.minimum(np.searchsorted(member_cdf[k], r[pick], side="right"), len(members[k]) - 1)
+                v[pick] = members[k][j]
+        keep = u != v
+        m = int(keep.sum())
+        out[filled:filled + m, 0] = label[u[keep]]
+        out[filled:filled + m, 1] = label[v[keep]]
+        filled += m
+    return out

@@ -96,7 +96,10 @@ typedef struct {
 /* One batch of negative-sampling SGD: for every {tail, head} pair, num_negative negative steps then the
  * positive step on a progressively updated copy of vertex[head]; context rows are updated in place,
  * Hogwild (no atomics), loss[s] = sample loss / (1 + num_negative * negative_weight).
- * `stream` is a hipStream_t (NULL = default stream).  `batch_id` only feeds the negative draw. */
+ * Pairs that sit next to each other in the batch and share a head row are trained as one run by one lane group —
+ * one after the other on the same register copy of the row, as consecutive iterations of one warp in the reference
+ * (include/instance/gpu/graph.cuh:54-94) — up to the run cap (GVK_TUNE_RUN_CAP); samples keep their own negatives
+ * and loss slots.  `stream` is a hipStream_t (NULL = default stream).  `batch_id` only feeds the negative draw. */
 int gvk_train(void *stream, int dim, const gvk_optimizer *optimizer, const gvk_tables *tables,
               const uint32_t *pairs, const gvk_negative_source *negative, uint32_t batch_id, float *loss,
               int batch_size, int num_negative, float negative_weight);
@@ -183,10 +186,22 @@ int gvk_alias_build(const float *weights, size_t n, float *prob, void *alias, in
 /* Tuning knobs for A/B measurement (bench.py --variant); they never change results beyond
  * floating-point summation order.  Returns GVK_EINVAL for an unknown key or unsupported value. */
 #define GVK_TUNE_LANES_PER_PAIR 1 /* 0 = per-dim default; else 8, 16, 32 or 64 */
-#define GVK_TUNE_VARIANT 2        /* 0 = default (k = 1 SGD uses the compile-time-k build), 1 = always the generic build,
-                                     3 = dim-128 SGD in the reference's kernel shape (one wavefront per pair, vertex row
-                                     in LDS, 8192 x 512 grid-stride launch) — A/B baseline only */
+#define GVK_TUNE_VARIANT 2        /* 0 = default (runs of same-head pairs; k = 1 SGD uses the compile-time-k build),
+                                     1 = always the generic build, 2 = the per-pair kernel (one lane group per pair, no
+                                     runs), 3 = dim-128 SGD in the reference's kernel shape (one wavefront per pair,
+                                     vertex row in LDS, 8192 x 512 grid-stride launch) — 2 and 3 are A/B baselines only */
+#define GVK_TUNE_RUN_CAP 3        /* longest run of adjacent same-head pairs a lane group trains in sequence: 0 = from the
+                                     batch size (batch_size / 5120 rounded up: the generations of the reference's launch
+                                     on the card it was written for), 1 = every pair on its own, up to 64 */
+#define GVK_TUNE_GENERATION 4     /* parity experiment: C > 0 trains a batch as consecutive launches of at most C samples
+                                     (per-pair kernel), the concurrency structure of the reference's launch on a card
+                                     that keeps C warps resident; 0 = one launch per batch (default) */
 int gvk_set_tuning(int key, int value);
+
+/* The kernel gvk_train / gvk_train_episode launch for this configuration under the current tuning, as text
+ * ("train_runs_kernel<128,16,SGD,k=1> run_cap 20") — what a benchmark should label its measurement with. */
+int gvk_describe_train(int dim, int optimizer_type, int num_negative, int explicit_negatives, int batch_size,
+                       char *name, size_t capacity);
 
 const char *gvk_last_error(void);
 const char *gvk_version(void);

@@ -50,10 +50,35 @@ void AliasTable<float, uint32_t>::device_sample(const Memory<double, int> &rand,
     }
 }
 
-// gpu::graph::train<Vector, Index, Model, kSGD> (instance/gpu/graph.cuh:36-95) as a sequential host loop over the
-// reference's own model code — the same restatement as oracle/ref_harness.cpp, here on the worker's buffers, so that
-// the reference's WHOLE training loop (sampler threads, schedule, partition loads and write-backs, negative sampler,
-// lr schedule) runs on the CPU.  Samples of a batch are applied one after the other (no lost updates).
+// gpu::graph::train<Vector, Index, Model, kSGD> (instance/gpu/graph.cuh:36-95) on the worker's buffers, over the
+// reference's own model code, so that the reference's WHOLE training loop (sampler threads, schedule, partition loads
+// and write-backs, negative sampler, lr schedule) runs on the CPU.  Two execution models of the launch:
+//
+//   gvref_kernel_chunk == 0: SEQUENTIAL.  Samples of a batch are applied one after the other (no lost updates).
+//
+//   gvref_kernel_chunk == C > 0: CHUNK-SYNCHRONOUS, a model of the concurrency the launch has on the card the
+//   reference was written for.  The kernel is launched <<<8192, 512>>> (util/gpu.cuh:41-43, graph.cuh:487-490): one
+//   32-lane warp per sample, 131 072 warps, so with the default batch of 100 000 every sample has its own warp and
+//   sample i runs in block i / 16.  A V100 keeps 80 SMs x 2048 threads = 320 such blocks = C = 5120 warps resident
+//   and dispatches blocks in index order, so samples [0, C) run together, then [C, 2C), ...  Inside a chunk the warps
+//   execute the same straight-line code at the same pace, which is modelled as lock step over the kernel's own
+//   phases (graph.cuh:54-94): (1) every warp copies its vertex row into its shared-memory buffer; (2) for s = 0 ..
+//   num_negative: every warp reads its context row, computes forward / backward on (buffer, row) with the reference's
+//   own Model code, then every warp writes its context row back; (3) every warp writes its buffer back to the vertex
+//   row.  Two warps of a chunk that write the same row: the higher sample index wins (the hardware leaves the winner
+//   open; any fixed rule is one of its outcomes).  A later chunk sees everything earlier chunks wrote.  C >=
+//   batch size is the fully concurrent launch, C == 1 the sequential loop.
+//
+//   gvref_kernel_reads == 1 (with C > 0): the harsher variant "all reads at chunk start": every warp of the chunk
+//   fetches its vertex row AND all its num_negative + 1 context rows before any warp of the chunk writes anything (a
+//   warp still sees its own writes when two of its targets are the same row); all writes land at the end of the chunk,
+//   higher sample index / later target last.  This is what a launch of C samples does on hardware that requests every
+//   row of a sample up front (the product's kernel does), and a lower bracket for the reference's kernel, whose
+//   context rows are read at the point of use.
+int gvref_kernel_chunk = 0;
+int gvref_kernel_reads = 0;
+int gvref_kernel_threads = 1;  // host threads that share the (independent) per-warp arithmetic of a phase
+
 template <>
 bool GraphWorker<HarnessSolverBase>::train_dispatch() {
     auto *solver = reinterpret_cast<graphvite::GraphSolver<128, float, uint32_t> *>(this->solver);
@@ -64,33 +89,98 @@ bool GraphWorker<HarnessSolverBase>::train_dispatch() {
     const uint32_t *samples = batch.device_ptr, *negatives = negative_batch.device_ptr;
     const int num_sample = batch.count / 2, k = negative_batch.count / num_sample;
     const float negative_weight = solver->negative_weight;
-    Vec vertex_buffer;
-    for (int sample_id = 0; sample_id < num_sample; sample_id++) {
-        const uint32_t head_id = samples[sample_id * 2 + 1];  // each positive sample is {tail, head}
-        Vec &vertex = vertex_embeddings[head_id];
-        vertex_buffer = vertex;
-        float sample_loss = 0;
+    const Optimizer opt = optimizer;
+    // one target of one sample: graph.cuh:63-88
+    auto target = [&](Vec &vertex_buffer, Vec &context, bool label, float &sample_loss) {
+        float logit;
+        Model::forward(vertex_buffer, context, logit);
+        const float prob = sigmoid(logit);
+        float gradient, weight;
+        if (label) {
+            gradient = prob - 1;
+            weight = 1;
+            sample_loss += weight * -log(prob + kEpsilon);
+        } else {
+            gradient = prob;
+            weight = negative_weight;
+            sample_loss += weight * -log(1 - prob + kEpsilon);
+        }
+        Model::template backward<kSGD>(vertex_buffer, context, gradient, opt, weight);
+    };
+    if (gvref_kernel_chunk <= 0) {
+        Vec vertex_buffer;
+        for (int sample_id = 0; sample_id < num_sample; sample_id++) {
+            const uint32_t head_id = samples[sample_id * 2 + 1];  // each positive sample is {tail, head}
+            Vec &vertex = vertex_embeddings[head_id];
+            vertex_buffer = vertex;
+            float sample_loss = 0;
+            for (int s = 0; s <= k; s++) {
+                const bool label = s == k;
+                const uint32_t tail_id = label ? samples[sample_id * 2] : negatives[sample_id * k + s];
+                target(vertex_buffer, context_embeddings[tail_id], label, sample_loss);
+            }
+            loss.device_ptr[sample_id] = sample_loss / (1 + k * negative_weight);
+            vertex = vertex_buffer;
+        }
+        return true;
+    }
+    const int C = gvref_kernel_chunk, T = gvref_kernel_threads > 0 ? gvref_kernel_threads : 1;
+    if (gvref_kernel_reads == 1) {
+        std::vector<Vec> vertex_buffers(C), context_rows((size_t)C * (k + 1));
+        auto target_id = [&](int sample_id, int s) {
+            return s == k ? samples[sample_id * 2] : negatives[sample_id * k + s];
+        };
+        for (int first = 0; first < num_sample; first += C) {
+            const int n = std::min(C, num_sample - first);
+#pragma omp parallel for num_threads(T) schedule(static)
+            for (int i = 0; i < n; i++) {
+                const int sample_id = first + i;
+                Vec *rows = &context_rows[(size_t)i * (k + 1)];
+                vertex_buffers[i] = vertex_embeddings[samples[sample_id * 2 + 1]];
+                for (int s = 0; s <= k; s++) rows[s] = context_embeddings[target_id(sample_id, s)];
+                float sample_loss = 0;
+                for (int s = 0; s <= k; s++) {
+                    for (int e = 0; e < s; e++)  // the warp's own earlier write to the same row
+                        if (target_id(sample_id, e) == target_id(sample_id, s)) rows[s] = rows[e];
+                    target(vertex_buffers[i], rows[s], s == k, sample_loss);
+                }
+                loss.device_ptr[sample_id] = sample_loss / (1 + k * negative_weight);
+            }
+            for (int i = 0; i < n; i++) {
+                const int sample_id = first + i;
+                for (int s = 0; s <= k; s++) context_embeddings[target_id(sample_id, s)] = context_rows[(size_t)i * (k + 1) + s];
+                vertex_embeddings[samples[sample_id * 2 + 1]] = vertex_buffers[i];
+            }
+        }
+        return true;
+    }
+    std::vector<Vec> vertex_buffers(C), context_rows(C);
+    std::vector<float> sample_losses(C);
+    for (int first = 0; first < num_sample; first += C) {
+        const int n = std::min(C, num_sample - first);
+#pragma omp parallel for num_threads(T) schedule(static)
+        for (int i = 0; i < n; i++) {
+            vertex_buffers[i] = vertex_embeddings[samples[(first + i) * 2 + 1]];
+            sample_losses[i] = 0;
+        }
         for (int s = 0; s <= k; s++) {
             const bool label = s == k;
-            const uint32_t tail_id = label ? samples[sample_id * 2] : negatives[sample_id * k + s];
-            Vec &context = context_embeddings[tail_id];
-            float logit;
-            Model::forward(vertex_buffer, context, logit);
-            const float prob = sigmoid(logit);
-            float gradient, weight;
-            if (label) {
-                gradient = prob - 1;
-                weight = 1;
-                sample_loss += weight * -log(prob + kEpsilon);
-            } else {
-                gradient = prob;
-                weight = negative_weight;
-                sample_loss += weight * -log(1 - prob + kEpsilon);
+#pragma omp parallel for num_threads(T) schedule(static)
+            for (int i = 0; i < n; i++) {
+                const int sample_id = first + i;
+                const uint32_t tail_id = label ? samples[sample_id * 2] : negatives[sample_id * k + s];
+                context_rows[i] = context_embeddings[tail_id];
+                target(vertex_buffers[i], context_rows[i], label, sample_losses[i]);
             }
-            Model::template backward<kSGD>(vertex_buffer, context, gradient, optimizer, weight);
+            for (int i = 0; i < n; i++) {
+                const int sample_id = first + i;
+                context_embeddings[label ? samples[sample_id * 2] : negatives[sample_id * k + s]] = context_rows[i];
+            }
         }
-        loss.device_ptr[sample_id] = sample_loss / (1 + k * negative_weight);
-        vertex = vertex_buffer;
+        for (int i = 0; i < n; i++) {
+            loss.device_ptr[first + i] = sample_losses[i] / (1 + k * negative_weight);
+            vertex_embeddings[samples[(first + i) * 2 + 1]] = vertex_buffers[i];
+        }
     }
     return true;
 }
@@ -111,6 +201,14 @@ struct Handle {
 extern "C" {
 
 void gvref_set_uniform_source(gvref_uniform_source_t source) { gvref_uniform_source = source; }
+
+// Execution model of the emulated kernel launch (see train_dispatch above): chunk 0 = sequential, C > 0 =
+// chunk-synchronous with C resident warps (reads_at_start 1: its harsher variant); threads = host threads for the per-warp arithmetic (results do not depend on it).
+void gvref_set_kernel_model(int chunk, int reads_at_start, int threads) {
+    graphvite::gvref_kernel_chunk = chunk;
+    graphvite::gvref_kernel_reads = reads_at_start;
+    graphvite::gvref_kernel_threads = threads;
+}
 
 void *gvref_solver_create(const uint32_t *edges, const float *weights, uint64_t n, int as_undirected, int num_worker,
                           int num_sampler_per_worker, int num_partition, int num_negative, int batch_size,

@@ -444,11 +444,17 @@ def reference_load(kind, path, a, b=0, normalization=False, delimiters=" \t\r\n"
 
 
 def reference_train(rs, model="LINE", num_epoch=50, augmentation_step=1, walk_length=40, walk_batch=100, shuffle_base=1,
-                    p=1.0, q=1.0, negative_sample_exponent=0.75, negative_weight=5.0):
+                    p=1.0, q=1.0, negative_sample_exponent=0.75, negative_weight=5.0, kernel_chunk=0, threads=1,
+                    reads_at_start=False):
     """GraphSolver::train of the reference as written on a built ReferenceSolver, with the worker's kernel and negative
-    draw emulated by sequential host loops over its own model code (oracle/ref_solver_harness.cpp).  Returns
-    (vertex_embeddings, context_embeddings, batch_id)."""
+    draw emulated by host loops over its own model code (oracle/ref_solver_harness.cpp).  kernel_chunk 0: the samples
+    of a batch one after the other; C > 0: chunk-synchronous model of the <<<8192, 512>>> launch with C warps resident
+    (5120 on a V100) — lock step inside a chunk (reads_at_start: every row of the chunk read before any is written),
+    last writer wins.  Returns (vertex_embeddings, context_embeddings,
+    batch_id)."""
     lib = ReferenceSolver.lib()
+    lib.gvref_set_kernel_model.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.gvref_set_kernel_model(int(kernel_chunk), int(bool(reads_at_start)), int(threads))
     lib.gvref_solver_train.restype = C.c_int
     lib.gvref_solver_train.argtypes = [C.c_void_p, C.c_char_p] + [C.c_int] * 5 + [C.c_float] * 4 + [C.c_void_p] * 2
     vertex = np.zeros((rs.num_vertex, 128), np.float32)

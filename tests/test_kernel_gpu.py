@@ -147,6 +147,105 @@ def test_pair_sees_its_own_negative_update(hip, oracle):
     np.testing.assert_allclose(hloss, oloss, rtol=RTOL, atol=1e-6)
 
 
+def _run_batch(rng, N, B, k, run_lengths):
+    """A batch whose heads come in adjacent runs of the given lengths (cycled); tails and negatives all distinct."""
+    pairs, negs = conflict_free_batch(rng, N, N, B, k)
+    heads, i, r = pairs[:, 1].copy(), 0, 0
+    while i < B:
+        n = min(run_lengths[r % len(run_lengths)], B - i)
+        heads[i:i + n] = heads[i]
+        i, r = i + n, r + 1
+    pairs[:, 1] = heads
+    return pairs, negs
+
+
+@pytest.mark.parametrize("dim,k", [(128, 1), (128, 3), (96, 1), (32, 2), (512, 1), (128, 0)])
+def test_runs_of_one_head_train_in_sequence(hip, oracle, dim, k):
+    """Adjacent pairs that share a head row are one run: one lane group applies them one after the other on the same
+    register copy of the row (the reference's warp does that with consecutive iterations of its loop,
+    gpu/graph.cuh:54-94), so with distinct context rows the result equals the SEQUENTIAL oracle — no update of the
+    head row is lost — and every sample keeps its own negatives and loss slot."""
+    rng = np.random.default_rng(dim + k)
+    N, B = 8192, 1500
+    v, c = init_tables(rng, N, N, dim)
+    v *= 20
+    c *= 20
+    pairs, negs = _run_batch(rng, N, B, k, [1, 2, 1, 5, 3, 1, 1, 9, 16, 2])
+    ov, oc = v.copy(), c.copy()
+    oloss = oracle.train(ov, oc, pairs, negs, 0.025, 0.005, 5.0)
+    hip.set_run_cap(16)
+    try:
+        assert "train_runs_kernel" in hip.describe_train(dim, "SGD", k, True, B)
+        # a segment boundary every 16 pairs may cut a run in two; keep runs inside segments for the exact comparison
+        first = np.flatnonzero(np.r_[True, pairs[1:, 1] != pairs[:-1, 1]])
+        last = np.r_[first[1:], B] - 1
+        whole = first // 16 == last // 16
+        hv, hc, hloss, _ = run_hip(hip, v, c, pairs, negs if k else None, OPTS["SGD"][1], 5.0, k=k)
+    finally:
+        hip.set_run_cap(0)
+    np.testing.assert_allclose(hc, oc, rtol=RTOL, atol=ATOL) if whole.all() else None
+    rows = pairs[first[whole], 1]
+    np.testing.assert_allclose(hv[rows], ov[rows], rtol=RTOL, atol=ATOL)
+    in_whole = np.repeat(whole, last - first + 1)
+    np.testing.assert_allclose(hloss[in_whole], oloss[in_whole], rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(hc[pairs[in_whole, 0]], oc[pairs[in_whole, 0]], rtol=RTOL, atol=ATOL)
+    assert whole.sum() > len(whole) // 2 and (~whole).sum() > 0
+
+
+@pytest.mark.parametrize("name", ["Momentum", "Adam"])
+def test_runs_with_moment_optimizers(hip, oracle, name):
+    opt_id, spec, hp = OPTS[name]
+    rng = np.random.default_rng(11)
+    N, B, k, dim = 4096, 600, 1, 128
+    v, c = init_tables(rng, N, N, dim)
+    v *= 20
+    c *= 20
+    nm = spec.num_moment
+    moments = [rng.uniform(0, 1e-3, (N, dim)).astype(np.float32) if i < 2 * nm else None for i in range(4)]
+    pairs, negs = _run_batch(rng, N, B, k, [4, 1, 2, 1])  # runs of 4, 1, 2, 1: none crosses a multiple of 8
+    ov, oc, om = v.copy(), c.copy(), [None if m is None else m.copy() for m in moments]
+    oloss = oracle.train(ov, oc, pairs, negs, spec.lr, spec.weight_decay, 5.0, opt_id, om, hp)
+    hip.set_run_cap(8)
+    try:
+        hv, hc, hloss, hm = run_hip(hip, v, c, pairs, negs, spec, 5.0, moments=moments)
+    finally:
+        hip.set_run_cap(0)
+    np.testing.assert_allclose(hv, ov, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(hc, oc, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(hloss, oloss, rtol=1e-5, atol=1e-6)
+    for a, b in zip(hm, om):
+        if a is not None:
+            np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-8)
+
+
+def test_run_cap_splits_long_runs(hip, oracle):
+    """A run longer than the cap is trained by several lane groups, each from the row as the launch found it; the row
+    ends up as ONE of their results (last store wins, as between two concurrent warps of the reference).  Cap 1 is the
+    per-pair behaviour, and so is the per-pair A/B kernel (variant 2)."""
+    rng = np.random.default_rng(5)
+    N, B, k, dim = 4096, 64, 1, 128
+    v, c = init_tables(rng, N, N, dim)
+    v *= 20
+    c *= 20
+    pairs, negs = _run_batch(rng, N, B, k, [64])
+    row = int(pairs[0, 1])
+    for cap, variant in ((4, 0), (16, 0), (1, 0), (0, 2)):
+        candidates = []
+        for start in range(0, B, max(cap, 1)):
+            ov, oc = v.copy(), c.copy()
+            oracle.train(ov, oc, pairs[start:start + max(cap, 1)], negs[start:start + max(cap, 1)], 0.025, 0.005, 5.0)
+            candidates.append(ov[row])
+        hip.set_run_cap(cap)
+        hip.set_variant(variant)
+        try:
+            hv, hc, hloss, _ = run_hip(hip, v, c, pairs, negs, OPTS["SGD"][1], 5.0)
+        finally:
+            hip.set_run_cap(0)
+            hip.set_variant(0)
+        assert any(np.allclose(hv[row], cand, rtol=RTOL, atol=ATOL) for cand in candidates), (cap, variant)
+        assert np.isfinite(hloss).all()
+
+
 def test_negative_draw_bit_exact(hip, oracle):
     """The on-device draw is integer work: bit-exact against the oracle's restatement of the RNG contract."""
     rng = np.random.default_rng(11)

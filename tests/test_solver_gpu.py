@@ -197,7 +197,7 @@ def test_moment_optimizer_end_to_end():
 def test_exchange_runs_on_rccl():
     """The collective of the multi-GPU path on the real backend ("nccl" is RCCL on ROCm).  A 1-GPU box cannot form a
     multi-rank RCCL group (one device per rank), so this is a single-rank group: it checks that the exact calls the
-    solver makes — all_gather into views of the partition-major table — are accepted by RCCL and leave the table
+    solver makes — an in-place all_gather_into_tensor on a head group's slab — are accepted by RCCL and leave the table
     as it was; rank interplay is covered by the 2-process gloo tests."""
     import os
     import socket
@@ -216,13 +216,14 @@ def test_exchange_runs_on_rccl():
         assert s.num_worker == 1 and s.rank == 0
         s.build(g, optimizer=gv.optimizer.Adam(1e-3), batch_size=5000, episode_size=4)
         session = s.session(model="LINE", num_epoch=2, augmentation_step=1)
-        before = {k: session.state[k].clone() for k in ("vertex", "vertex_m0", "vertex_m1")}
+        assert session.state["head"].shape[1] == 3  # vertex rows + Adam's two moment tables share a slot
+        before = session.state["head"].clone()
         s._exchange(session.state, 0)
+        s._wait_exchange(session.state)
         torch.cuda.synchronize()
-        for k, v in before.items():
-            assert torch.equal(session.state[k], v)
-        out = [torch.empty_like(session.state["context"])]
-        dist.all_gather(out, session.state["context"])
+        assert torch.equal(session.state["head"], before)
+        out = torch.empty((1,) + tuple(session.state["context"].shape), device="cuda:0")
+        dist.all_gather_into_tensor(out.view(-1), session.state["context"].view(-1))
         assert torch.equal(out[0], session.state["context"])
         t = torch.tensor([1.5], dtype=torch.float64, device="cuda:0")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
