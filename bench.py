@@ -5,10 +5,13 @@ A "step" is one batch (100 000 edge-samples, num_negative 1) of negative-samplin
 power-law graph BASELINE.json's metric is quoted on (configs[1]: 1M nodes / 10M edges, dim 128, fp32, LINE,
 augmentation_step 1), driven through the product path: Graph -> GraphSolver.build (degree partition; one
 partition at N = 1, 2N at N > 1) -> the native CPU edge sampler fills the block pools -> pools uploaded to HBM ->
-per block, as in the episode loop: [regrouping pass gvk_group_pairs on the copy stream while the previous block
+per block visit, as in the episode loop: [regrouping pass gvk_group_pairs on the copy stream while the previous block
 trains] -> gvk_train_episode (negatives drawn in-kernel, lr schedule per batch) for `--block-batches` batches ->
-with N > 1 all GPUs all-gather the head shards they just trained (RCCL over xGMI, asynchronous).  The K timed
-steps are the next K batches of that walk: regrouping passes and exchanges are inside the timed region.
+with N > 1 all GPUs all-gather the head shards they just trained (RCCL over xGMI, asynchronous).
+
+The timed region is WHOLE block visits: it starts on a block boundary and `--block-batches` defaults to at most
+`--steps`, so every block visit whose batches are timed has its regrouping pass, its staging and its exchange
+inside the region too, at any --steps (`regroup` reports the passes that ran inside it).
 
     python bench.py [--steps K] [--warmup W]                                                     (N = 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -16,11 +19,14 @@ steps are the next K batches of that walk: regrouping passes and exchanges are i
 
 Rank 0 prints ONE JSON line.  The sample pools, alias tables and embedding tables are resident in HBM when
 the timed region starts (sampling is a CPU producer that runs concurrently in real training; its rate is
-reported separately as `sampler`).  `roofline` is for the training kernel (HBM-bound): achieved =
-algorithmic bytes per launch (3088 B per edge-sample at dim 128, k = 1) / the average launch
-duration measured with HIP events on the launch stream over the timed region.  `cpu_baseline` (N = 1, rank 0)
-times the reference's own host-compiled arithmetic (oracle/_ref, Hogwild over all host cores) on a bounded
-sample of the same batches.
+reported separately as `sampler`, and `end_to_end` times GraphSolver.train() itself — the reference's figure of merit
+`[time] GraphApplication.train`, python/graphvite/util.py:158-166 — with the CPU samplers and with device-side
+sampling).  `roofline` is for the training kernel (HBM-bound): achieved = algorithmic bytes per launch (3088 B per
+edge-sample at dim 128, k = 1) / the average launch duration measured with HIP events on the launch
+stream over the timed region; `roofline.kernel` is what the library says it launched (gvk_describe_train).
+`cpu_baseline` (N = 1, rank 0) times the reference's own host-compiled arithmetic (oracle/_ref, Hogwild over all host
+cores) on a bounded sample of the same batches — on this workload (configs[1]) and on the BlogCatalog-sized
+quick-start shape (configs[0]).
 """
 import argparse
 import json
@@ -54,10 +60,16 @@ def parse(argv=None):
     p.add_argument("--negatives", type=int, default=1)
     p.add_argument("--block-batches", type=int, default=0,
                    help="batches per (head, tail) block pool = batches between two exchanges; 0 = the solver's "
-                        "auto episode size for this graph (solver.h:426-436), capped at 250")
+                        "auto episode size for this graph (solver.h:426-436), capped at 250 and at --steps (so that "
+                        "the timed region is made of whole block visits)")
+    p.add_argument("--no-end-to-end", action="store_true", help="skip the GraphSolver.train() runs (`end_to_end`)")
+    p.add_argument("--end-to-end-batches", type=int, default=2000, help="batches per GPU of each end-to-end run")
     p.add_argument("--lanes", type=int, default=0, help="A/B knob: lanes per pair (0 = per-dim default)")
     p.add_argument("--variant", type=int, default=0, help="A/B knob: kernel build variant (gvk.h GVK_TUNE_VARIANT)")
     p.add_argument("--run-cap", type=int, default=0, help="A/B knob: longest same-head run per lane group (gvk.h GVK_TUNE_RUN_CAP)")
+    p.add_argument("--segment-steps", type=int, default=0, help="A/B knob: pairs per lane group and wavefront (GVK_TUNE_SEGMENT_STEPS)")
+    p.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                   help="A/B knob: any GVK_TUNE_* key of include/gvk.h by number, e.g. --tune 6=1")
     p.add_argument("--xcd-bucket", choices=["head", "tail"], default=None,
                    help="experiment: reorder every batch so that block b (16 pairs, XCD b % 8) holds pairs whose "
                         "head / tail row id is congruent to b mod 8")
@@ -83,22 +95,11 @@ def parse(argv=None):
     return p.parse_args(argv)
 
 
-def cpu_baseline(args, solver, pool, table_packed):
-    """Reference arithmetic (oracle/_ref/libgvref_fast.so), Hogwild over all host cores, on the first batches of
-    rank 0's first block pool, starting from the same initial tables.  Bench infrastructure only."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle_lib import Reference
-    try:
-        ref = Reference(fast=True)
-    except (FileNotFoundError, OSError):
-        return None
-    from graphvite_amd.base import cpu_budget
-    cores = cpu_budget()  # CPUs the container may really use (cgroup quota), not the 256 hardware threads it sees
-    B, k = args.batch, args.negatives
-    rng = np.random.default_rng(args.seed + 7)
-    prob, alias = np.ascontiguousarray(table_packed["prob"]), np.ascontiguousarray(table_packed["alias"])
-    n = len(solver._part_ids[0])
-    v = solver.vertex_embeddings[solver._part_ids[0]].copy()   # partition-local tables, like the GPU's
+def time_reference(ref, cores, v, pool, prob, alias, B, k, seconds, seed):
+    """Hogwild over `cores` threads with the reference's own arithmetic on batches of `pool` ({tail, head} records,
+    partition-local ids), negatives from the given alias table.  Returns (edge-samples/s, batches, seconds)."""
+    rng = np.random.default_rng(seed)
+    n = len(v)
     c = np.zeros_like(v)
     nb = pool.shape[0] // B
     negs = []
@@ -112,12 +113,89 @@ def cpu_baseline(args, solver, pool, table_packed):
         ref.train_mt(v, c, pool[b * B:(b + 1) * B], negs[done % len(negs)], 0.025, 0.005, 5.0, cores)
         done += 1
         el = time.perf_counter() - t0
-        if el >= args.cpu_seconds and done >= 2:
-            break
-    return {"value": done * B / el / 1e6, "unit": "million edge-samples/sec", "cores": cores, "kind": "reference",
-            "sample": "%d batches of %d edge-samples of rank 0's first block pool (%.1f s wall, %d threads = the "
-                      "container's CPU quota on a %d-thread host, Hogwild; -Ofast x86-64-v3 host build of the "
-                      "reference's own LINE::forward/backward + sgd_update)" % (done, B, el, cores, os.cpu_count() or 1)}
+        if el >= seconds and done >= 2:
+            return done * B / el, done, el
+
+
+def cpu_baseline(args, solver, pool, table_packed):
+    """Reference arithmetic (oracle/_ref/libgvref_fast.so), Hogwild over all host cores, on the first batches of
+    rank 0's first block pool, starting from the same initial tables; then the same on the quick-start shape
+    (configs[0]: a BlogCatalog-sized graph, whose 5 MB tables live in the CPU caches).  Bench infrastructure only."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import Reference
+    try:
+        ref = Reference(fast=True)
+    except (FileNotFoundError, OSError):
+        return None
+    from graphvite_amd.base import cpu_budget
+    cores = cpu_budget()  # CPUs the container may really use (cgroup quota), not the 256 hardware threads it sees
+    B, k = args.batch, args.negatives
+    prob, alias = np.ascontiguousarray(table_packed["prob"]), np.ascontiguousarray(table_packed["alias"])
+    v = solver.vertex_embeddings[solver._part_ids[0]].copy()   # partition-local tables, like the GPU's
+    rate, done, el = time_reference(ref, cores, v, pool, prob, alias, B, k, args.cpu_seconds, args.seed + 7)
+    how = ("%.1f s wall, %d threads = the container's CPU quota on a %d-thread host, Hogwild; -Ofast x86-64-v3 host "
+           "build of the reference's own LINE::forward/backward + sgd_update" % (el, cores, os.cpu_count() or 1))
+    out = {"value": rate / 1e6, "unit": "million edge-samples/sec", "cores": cores, "kind": "reference",
+           "sample": "%d batches of %d edge-samples of rank 0's first block pool (%s)" % (done, B, how)}
+    # configs[0]: the reference's CPU-runnable case — quick-start hyper-parameters on a BlogCatalog-sized graph
+    import graphvite_amd as gv
+    from graphvite_amd import hostlib, synthetic
+    from graphvite_amd.kernels import alias_build
+    graph = gv.graph.Graph()
+    graph.load(synthetic.hub_community_edges(10312, 333983, gamma=2.8, num_community=39, seed=args.seed))
+    part, local, sizes = hostlib.partition(graph.vertex_weights, 1)
+    sampler = hostlib.Sampler(graph, part, local, 1, args.seed)
+    sampler.prepare("walk", 1.0, 1.0, cores)
+    pool1 = np.zeros((20 * B, 2), np.uint32)
+    import torch
+    sampler.fill({(0, 0): torch.from_numpy(pool1.view(np.int32).reshape(-1))}, 20 * B, "walk", 4 * cores,
+                 sample_batch_size=4000, walk_length=40, walk_batch=100, augmentation_step=2, shuffle_base=2,
+                 tail_partition=-1, os_threads=cores)
+    order = np.argsort(local)
+    w = hostlib.negative_weights(graph.vertex_weights, order, 0.75)
+    prob1, alias1, _ = alias_build(w)
+    rng = np.random.default_rng(args.seed)
+    v1 = ((rng.random((graph.num_vertex, args.dim), dtype=np.float32) - np.float32(0.5)) / np.float32(args.dim))
+    rate1, done1, el1 = time_reference(ref, cores, v1, pool1, prob1, alias1, B, k, args.cpu_seconds, args.seed + 8)
+    out["c1"] = {"value": rate1 / 1e6, "unit": "million edge-samples/sec", "cores": cores, "kind": "reference",
+                 "sample": "configs[0] shape: %d batches of %d edge-samples (LINE, augmentation_step 2 walk sampler) on a "
+                           "synthetic BlogCatalog-sized graph (10 312 nodes / 333 983 edges), %.1f s wall, same build and "
+                           "threads" % (done1, B, el1)}
+    return out
+
+
+def end_to_end(args, gv, graph, world, threads, partitions):
+    """GraphSolver.train() as a user calls it, timed by this process: the reference's own figure of merit is the wall
+    time of GraphApplication.train (python/graphvite/util.py:158-166).  Two runs: CPU sampler threads feeding the GPU
+    (the north_star pipeline) and positives drawn on the device.  `value` counts the episode loop (sampling, uploads,
+    regrouping, kernels, exchanges — everything between the first and the last batch); `train_seconds` is the whole
+    call including embedding init, table upload and write-back."""
+    import torch
+    out = {}
+    B = args.batch
+    epochs = max(args.end_to_end_batches * world * B // graph.num_edge, 1)
+    for name, device_sampling in (("cpu_samplers", False), ("device_sampling", True)):
+        solver = gv.solver.GraphSolver(args.dim, num_sampler_per_worker=threads, seed=args.seed,
+                                       device_sampling=device_sampling,
+                                       pair_order=gv.auto if args.pair_order == "auto" else args.pair_order)
+        solver.build(graph, optimizer=gv.optimizer.SGD(0.025, 0.005, "linear"), num_partition=partitions,
+                     num_negative=args.negatives, batch_size=B)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        solver.train(model="LINE", num_epoch=epochs, augmentation_step=1, log_frequency=1 << 30)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        timing = solver.timing
+        out[name] = {"value": timing["batches"] * B / timing["episodes"] / 1e6, "unit": "million edge-samples/sec",
+                     "batches": timing["batches"], "episode_seconds": timing["episodes"], "train_seconds": wall,
+                     "sampler_threads_per_gpu": 0 if device_sampling else threads, "pair_order": solver.pair_order,
+                     "episode_size": solver.episode_size,
+                     "exchange_bytes_sent_per_gpu_per_step": (solver.exchange_stats["bytes_sent_per_gpu"] //
+                                                              max(solver.exchange_stats["exchanges"], 1))}
+        solver.clear()
+        del solver
+        torch.cuda.empty_cache()
+    return out
 
 
 def main(argv=None, stand_in_kernels=None):
@@ -158,7 +236,7 @@ def main(argv=None, stand_in_kernels=None):
         auto = max(int(float(N) * 175 / partitions / B), 1)
         if world == 1:
             auto = max(auto, int(2e7) // B)
-        args.block_batches = min(auto, 250)
+        args.block_batches = max(min(auto, 250, args.steps), 1)
     from graphvite_amd.base import cpu_budget
     threads = args.sampler_threads or max(cpu_budget() // world, 1)
 
@@ -177,6 +255,11 @@ def main(argv=None, stand_in_kernels=None):
         solver.kernels.set_variant(args.variant)
     if args.run_cap:
         solver.kernels.set_run_cap(args.run_cap)
+    if args.segment_steps:
+        solver.kernels.set_segment_steps(args.segment_steps)
+    for item in args.tune:
+        key, value = item.split("=")
+        solver.kernels.set_tuning(int(key), int(value))
     optimizer = gv.optimizer.SGD(0.025, 0.005, "linear") if args.optimizer == "SGD" else \
         gv.optimizer.Optimizer(args.optimizer, 1e-3, 0.005)
     solver.build(graph, optimizer=optimizer, num_partition=partitions, num_negative=k,
@@ -240,6 +323,8 @@ def main(argv=None, stand_in_kernels=None):
     work = [torch.empty_like(next(iter(landed.values()))) for _ in range(2)] if grouped else [None, None]
     copy_stream = torch.cuda.Stream(dev) if cuda else None
     ready, released = [None, None], [None, None]
+    regroup_events = []  # (start, end) of every regrouping pass staged while `timing["on"]`
+    timing = {"on": False}
 
     def stage(step):
         """Stage the pool of block visit `step`: the regrouping pass, on the copy stream."""
@@ -252,7 +337,13 @@ def main(argv=None, stand_in_kernels=None):
         with torch.cuda.stream(copy_stream):
             if released[b] is not None:
                 copy_stream.wait_event(released[b])
+            if timing["on"]:
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record()
             session.stage(pool, work[b])
+            if timing["on"]:
+                g1.record()
+                regroup_events.append((g0, g1))
             ready[b] = torch.cuda.Event()
             ready[b].record()
         return work[b]
@@ -307,12 +398,17 @@ def main(argv=None, stand_in_kernels=None):
     for _ in blocks:
         run(min(2, args.block_batches), False, leave_block=True)
     session.wait_exchange()
-    run(args.warmup, False)
+    # the warm-up ends on a block boundary: the timed region then consists of whole block visits; as in the steady
+    # state of the episode loop every visit stages (regroups) the pool of the NEXT visit while it trains, so the
+    # region holds exactly one staging pass and one exchange per visit
+    run(args.warmup, False, leave_block=True)
     fence()
+    timing["on"] = True
     t0 = time.perf_counter()
     run(args.steps, True)
     fence()
     wall = time.perf_counter() - t0
+    timing["on"] = False
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -322,17 +418,22 @@ def main(argv=None, stand_in_kernels=None):
     else:
         kernel_ms = wall / args.steps * 1e3  # dry run: nothing to measure
     final_loss = float(session.loss.mean().item())
+    regroup_ms = sum(a.elapsed_time(b) for a, b in regroup_events) if cuda else 0.0
+    visits = -(-args.steps // args.block_batches)
+    exchange = {"exchanges": session.state.get("exchanges", 0), "bytes_sent_per_gpu": session.state.get("exchanged_bytes", 0)}
 
     moments = optimizer.num_moment
     bytes_per_launch = (8 * dim * (k + 2) * (1 + moments) + 16) * B  # moment tables are rows read + written too
     achieved = bytes_per_launch / (kernel_ms * 1e-3)
     # HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM); bench.py cannot read PMCs itself
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r1", "pmc_summary_bench_n1.json")
-    if world == 1 and dim == 128 and k == 1 and B == 100000 and N == 1000000 and moments == 0 and os.path.exists(pmc):
-        traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
-    lanes = args.lanes or {32: 8, 64: 16, 96: 8, 128: 16, 256: 16, 512: 32}[dim]
+    traffic, pmc_path = None, None
+    if world == 1 and dim == 128 and k == 1 and B == 100000 and N == 1000000 and moments == 0:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary_bench_n1.json")), reverse=True):
+            traffic, pmc_path = json.load(open(path)).get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT)
+            break
+    kernel_name = solver.kernels.describe_train(dim, args.optimizer, k, False, B) if cuda else "stand-in"
     result = {
         "metric": "million edge-samples/sec at dim=%d" % dim,
         "value": world * args.steps * B / wall / 1e6,
@@ -346,12 +447,20 @@ def main(argv=None, stand_in_kernels=None):
                                "negatives drawn in-kernel, block pools resident in HBM" % (N, E, dim, B, k),
                    "parallelism": "%d GPU(s), %d vertex partition(s), context shards pinned per GPU, asynchronous "
                                   "all-gather of head shards every %d batches" % (world, partitions, args.block_batches),
-                   "lanes_per_pair": lanes, "pair_order": solver.pair_order +
-                   (" (gvk_group_pairs per block visit on the copy stream, inside the timed region)" if grouped else "")},
+                   "block_batches": args.block_batches, "block_visits_timed": visits,
+                   "pair_order": solver.pair_order + (" (gvk_group_pairs once per block visit on the copy stream)"
+                                                      if grouped else "")},
+        "regroup": {"passes_in_timed_region": len(regroup_events), "ms_per_pass": regroup_ms / max(len(regroup_events), 1),
+                    "regroup_ms_per_step": regroup_ms / args.steps,
+                    "note": "runs on the copy stream concurrently with the previous block's kernels; ms_per_step "
+                            "(wall) already contains whatever of it was not hidden"} if grouped else None,
+        "exchange": {"collectives_total": exchange["exchanges"],
+                     "bytes_sent_per_gpu_per_collective": exchange["bytes_sent_per_gpu"] // max(exchange["exchanges"], 1),
+                     "note": "one in-place all_gather_into_tensor of a head group's slab per schedule step"}
+        if world > 1 else None,
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK, "traffic": traffic,
-                     "traffic_source": "profiles/r1/pmc_summary_bench_n1.json" if traffic else None,
-                     "kernel": "train_kernel<%d,%d,%s>" % (dim, lanes, args.optimizer), "kernel_ms": kernel_ms,
+                     "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": pmc_path,
+                     "kernel": kernel_name, "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": bytes_per_launch},
         "sampler": {"value": sampled / fill_s / 1e6, "unit": "million edge-samples/sec per GPU", "threads": threads,
                     "note": "CPU edge sampler filling this GPU's block pools before the timed region"},
@@ -362,6 +471,12 @@ def main(argv=None, stand_in_kernels=None):
         packed = session.negative_table(tp).cpu().numpy().view(np.dtype([("prob", np.float32), ("alias", np.uint32)]))
         pool0 = pools[blocks[0]].numpy().view(np.uint32).reshape(-1, 2)
         result["cpu_baseline"] = cpu_baseline(args, solver, pool0, packed)
+    if cuda and not args.no_end_to_end and args.optimizer == "SGD":
+        session.finish()
+        del landed, work, pools, session
+        solver.clear()
+        torch.cuda.empty_cache()
+        result["end_to_end"] = end_to_end(args, gv, graph, world, threads, partitions)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -14,6 +14,9 @@ TUNE_LANES_PER_PAIR = 1
 TUNE_VARIANT = 2
 TUNE_RUN_CAP = 3
 TUNE_GENERATION = 4
+TUNE_SEGMENT_STEPS = 5
+TUNE_SEGMENT_SUM = 6
+TUNE_SKIP_LOSS = 7
 
 
 class AliasEntry(C.Structure):

@@ -15,6 +15,59 @@ from ..base import auto, dtype, io
 logger = logging.getLogger("graphvite_amd")
 
 
+def easy_dict_class():
+    """The class the reference pickles its models as (easydict.EasyDict: a dict whose keys are attributes as well).
+    When the `easydict` package is not installed, a minimal stand-in is registered under that module name, so that
+    pickles written here name `easydict.EasyDict` (and load in the reference) and the reference's pickles load here."""
+    try:
+        from easydict import EasyDict
+        return EasyDict
+    except ImportError:
+        import sys
+        import types
+
+        class EasyDict(dict):
+            def __init__(self, *args, **kwargs):
+                super(EasyDict, self).__init__()
+                for key, value in dict(*args, **kwargs).items():
+                    self[key] = value
+
+            def __setitem__(self, key, value):
+                if isinstance(value, dict) and not isinstance(value, EasyDict):
+                    value = EasyDict(value)
+                super(EasyDict, self).__setitem__(key, value)
+
+            def __getattr__(self, name):
+                try:
+                    return self[name]
+                except KeyError:
+                    raise AttributeError(name)
+
+            def __setattr__(self, name, value):
+                self[name] = value
+
+            def __setstate__(self, state):  # the real class keeps a copy of its items in __dict__ and pickles it
+                for key, value in (state or {}).items():
+                    self[key] = value
+
+            def update(self, *args, **kwargs):
+                for key, value in dict(*args, **kwargs).items():
+                    self[key] = value
+
+        EasyDict.__module__, EasyDict.__qualname__ = "easydict", "EasyDict"
+        module = types.ModuleType("easydict")
+        module.EasyDict = EasyDict
+        sys.modules["easydict"] = module
+        return EasyDict
+
+
+def _field(record, name):
+    """record.name or record[name]: models arrive as EasyDicts, plain dicts (older files of this package) or objects."""
+    if isinstance(record, dict):
+        return record[name]
+    return getattr(record, name)
+
+
 def _timed(func):
     """@monitor.time of the reference (python/graphvite/util.py:148-167): logs the wall time of each stage."""
     def wrapper(self, *args, **kwargs):
@@ -89,30 +142,55 @@ class ApplicationMixin(object):
                 logger.warning("%s: %g", metric, value)
         return result
 
+    # what the reference's generic attribute filters pick up from its pybind objects (application.py:155-183 over
+    # bind.h:137-143, 415-436 and 824-989): name maps, embeddings, and the int / float / str read-only members
+    _GRAPH_HYPERPARAMETERS = ("num_vertex", "num_edge", "as_undirected", "normalization")
+    _SOLVER_HYPERPARAMETERS = ("num_partition", "num_negative", "negative_sample_exponent", "negative_weight", "model",
+                               "num_epoch", "resume", "episode_size", "batch_size", "augmentation_step",
+                               "random_walk_length", "random_walk_batch_size", "shuffle_base", "p", "q", "positive_reuse",
+                               "log_frequency", "num_worker", "num_sampler", "gpu_memory_limit", "gpu_memory_cost")
+
     @_timed
     def save_model(self, file_name, save_hyperparameter=False):
-        """Save the graph's name maps and the solver's embeddings with pickle (application.py:145-187)."""
+        """Save the graph's name maps and the solver's embeddings with pickle, in the reference's own layout
+        (application.py:145-187): an EasyDict {graph: {name2id, id2name}, solver: {vertex_embeddings,
+        context_embeddings}}, plus — with save_hyperparameter — the graph's and solver's scalar members and
+        solver.optimizer (its scalars, schedule as the schedule's type name).  A file written here loads in the reference
+        (`model.graph.name2id`, `model.solver.vertex_embeddings`) and the other way round."""
         logger.warning("save model to `%s`", file_name)
-        objects = {"graph": {"name2id": dict(self.graph.name2id), "id2name": list(self.graph.id2name)},
-                   "solver": {"vertex_embeddings": np.array(self.solver.vertex_embeddings),
-                              "context_embeddings": np.array(self.solver.context_embeddings)}}
+        EasyDict = easy_dict_class()
+        model = EasyDict()
+        model.graph = EasyDict(name2id=dict(self.graph.name2id), id2name=list(self.graph.id2name))
+        model.solver = EasyDict(vertex_embeddings=np.array(self.solver.vertex_embeddings),
+                                context_embeddings=np.array(self.solver.context_embeddings))
         if save_hyperparameter:
-            for name in ("model", "num_epoch", "num_partition", "num_negative", "batch_size", "episode_size",
-                         "augmentation_step", "random_walk_length", "shuffle_base", "p", "q", "positive_reuse",
-                         "negative_sample_exponent", "negative_weight"):
-                objects["solver"][name] = getattr(self.solver, name)
+            for name in self._GRAPH_HYPERPARAMETERS:
+                model.graph[name] = getattr(self.graph, name)
+            for name in self._SOLVER_HYPERPARAMETERS:
+                model.solver[name] = getattr(self.solver, name)
+            optimizer = self.solver.optimizer
+            extra = {"Momentum": ("momentum",), "AdaGrad": ("epsilon",), "RMSprop": ("alpha", "epsilon"),
+                     "Adam": ("beta1", "beta2", "epsilon")}.get(optimizer.type, ())
+            model.solver.optimizer = EasyDict(type=optimizer.type, lr=optimizer.init_lr,
+                                              weight_decay=optimizer.weight_decay)
+            for name in extra:
+                model.solver.optimizer[name] = getattr(optimizer, name)
+            model.solver.optimizer.schedule = optimizer.schedule.type
         with open(file_name, "wb") as fout:
-            pickle.dump(objects, fout, protocol=pickle.HIGHEST_PROTOCOL)
+            pickle.dump(model, fout, protocol=pickle.HIGHEST_PROTOCOL)
 
     @_timed
     def load_model(self, file_name):
-        """Load embeddings saved by save_model into the (already built) solver, matching nodes by name."""
+        """Load embeddings saved by save_model — here or by the reference — into the (already built) solver, matching
+        nodes by name (application.py:131-142)."""
         logger.warning("load model from `%s`", file_name)
+        easy_dict_class()  # a reference pickle names easydict.EasyDict; make sure something answers to that name
         with open(file_name, "rb") as fin:
-            objects = pickle.load(fin)
-        mapping = self.get_mapping(self.graph.id2name, objects["graph"]["name2id"])
-        self.solver.vertex_embeddings[:] = objects["solver"]["vertex_embeddings"][mapping]
-        self.solver.context_embeddings[:] = objects["solver"]["context_embeddings"][mapping]
+            model = pickle.load(fin)
+        graph, solver = _field(model, "graph"), _field(model, "solver")
+        mapping = self.get_mapping(self.graph.id2name, _field(graph, "name2id"))
+        self.solver.vertex_embeddings[:] = np.asarray(_field(solver, "vertex_embeddings"))[mapping]
+        self.solver.context_embeddings[:] = np.asarray(_field(solver, "context_embeddings"))[mapping]
 
     def get_mapping(self, id2name, name2id):
         mapping = []
@@ -127,6 +205,32 @@ class ApplicationMixin(object):
         if comment_start != -1:
             line = line[:comment_start]
         return [t for t in self.pattern.split(line) if t]
+
+    def read_columns(self, file_name, num_column, what):
+        """The columns of a delimiter-separated text file (comments and blank lines skipped) as `num_column` lists of
+        strings — the evaluation files of every task are of this form (application.py:318-327, 379-404)."""
+        columns = tuple([] for _ in range(num_column))
+        with open(file_name, "r") as fin:
+            for number, line in enumerate(fin, 1):
+                tokens = self.tokenize(line)
+                if not tokens:
+                    continue
+                if len(tokens) != num_column:
+                    raise ValueError("%s `%s`, line %d: expected %d fields, found %d" % (what, file_name, number,
+                                                                                       num_column, len(tokens)))
+                for column, token in zip(columns, tokens):
+                    column.append(token)
+        return columns
+
+    @staticmethod
+    def one_source(data, file_name, what):
+        """Evaluation input comes either as Python lists or as a file, never both, never neither."""
+        given = [d is not None for d in data]
+        if file_name and any(given):
+            raise ValueError("%s data and file should not be provided at the same time" % what)
+        if not file_name and not all(given):
+            raise ValueError("Either %s data or a file name should be provided" % what.lower())
+        return bool(file_name)
 
     def name_map(self, dicts, names):
         """Map columns of names to ids, dropping the rows with an unknown name (application.py:216-236)."""
@@ -170,26 +274,16 @@ class GraphApplication(ApplicationMixin):
         Returns:
             dict: macro-F1 & micro-F1 averaged over all trials
         """
-        if file_name:
-            if not (X is None and Y is None):
-                raise ValueError("Evaluation data and file should not be provided at the same time")
-            X, Y = [], []
-            with open(file_name, "r") as fin:
-                for line in fin:
-                    tokens = self.tokenize(line)
-                    if len(tokens) == 0:
-                        continue
-                    x, y = tokens
-                    X.append(x)
-                    Y.append(y)
-        if X is None or Y is None:
-            raise ValueError("Either evaluataion data (X, Y) or a file name should be provided")
+        if self.one_source((X, Y), file_name, "Evaluation"):
+            X, Y = self.read_columns(file_name, 2, "label file")
         name2id = self.graph.name2id
         class2id = {c: i for i, c in enumerate(np.unique(Y))}
         new_X, new_Y = self.name_map((name2id, class2id), ([str(x) for x in X], list(Y)))
         logger.info("effective labels: %d / %d", len(new_X), len(X))
+        # a (node, label) line that occurs n times counts n times, as in the reference's coo_matrix -> dense sum
+        # (application.py:336-338): it enters the node's label count for the top-k rule and the F1 totals
         labels = np.zeros((self.graph.num_vertex, len(class2id)), np.int64)
-        labels[np.asarray(new_X, np.int64), np.asarray(new_Y, np.int64)] = 1
+        np.add.at(labels, (np.asarray(new_X, np.int64), np.asarray(new_Y, np.int64)), 1)
         indexes = np.nonzero(labels.sum(1) > 0)[0]  # discard non-labeled nodes
         labels = labels[indexes]
         embeddings = np.array(self.solver.vertex_embeddings[indexes])
@@ -203,34 +297,12 @@ class GraphApplication(ApplicationMixin):
         Evaluate node embeddings on link prediction task: AUC of score = <vertex[h], context[t]>
         (application.py:353-453; scores are computed with the solver's predict kernel).
         """
-        if file_name:
-            if not (H is None and T is None and Y is None):
-                raise ValueError("Evaluation data and file should not be provided at the same time")
-            H, T, Y = [], [], []
-            with open(file_name, "r") as fin:
-                for line in fin:
-                    tokens = self.tokenize(line)
-                    if len(tokens) == 0:
-                        continue
-                    h, t, y = tokens
-                    H.append(h)
-                    T.append(t)
-                    Y.append(y)
-        if H is None or T is None or Y is None:
-            raise ValueError("Either evaluation data or file should be provided")
-        if filter_file:
-            if not (filter_H is None and filter_T is None):
-                raise ValueError("Filter data and file should not be provided at the same time")
-            filter_H, filter_T = [], []
-            with open(filter_file, "r") as fin:
-                for line in fin:
-                    tokens = self.tokenize(line)
-                    if len(tokens) == 0:
-                        continue
-                    h, t = tokens
-                    filter_H.append(h)
-                    filter_T.append(t)
-        elif filter_H is None:
+        if self.one_source((H, T, Y), file_name, "Evaluation"):
+            H, T, Y = self.read_columns(file_name, 3, "edge file")
+        if filter_file or filter_H is not None or filter_T is not None:
+            if self.one_source((filter_H, filter_T), filter_file, "Filter"):
+                filter_H, filter_T = self.read_columns(filter_file, 2, "filter file")
+        else:
             filter_H, filter_T = [], []
 
         name2id = self.graph.name2id
@@ -304,8 +376,9 @@ def linear_classification(embeddings, labels, portion, normalization=False, time
             predictions = (logits >= thresholds).long()
             tp = (predictions & test_y).sum(dim=0).float()
             t, p = test_y.sum(dim=0).float(), predictions.sum(dim=0).float()
-            macro_f1s.append((2 * tp / (t + p)).mean().item())
-            micro_f1s.append((2 * tp.sum() / (t.sum() + p.sum())).item())
+            # a class with neither true nor predicted test labels scores 0, not 0 / 0 (the reference divides blindly)
+            macro_f1s.append((2 * tp / (t + p).clamp(min=1)).mean().item())
+            micro_f1s.append((2 * tp.sum() / (t.sum() + p.sum()).clamp(min=1)).item())
     return {"macro-F1@%g%%" % (portion * 100): float(np.mean(macro_f1s)),
             "micro-F1@%g%%" % (portion * 100): float(np.mean(micro_f1s))}
 

@@ -41,6 +41,9 @@ int g_lanes_per_pair = 0;  // GVK_TUNE_LANES_PER_PAIR
 int g_variant = 0;         // GVK_TUNE_VARIANT
 int g_run_cap = 0;         // GVK_TUNE_RUN_CAP (0 = from the batch size, run_cap_for)
 int g_generation = 0;      // GVK_TUNE_GENERATION (0 = one launch per batch)
+int g_segment_steps = 0;   // GVK_TUNE_SEGMENT_STEPS (0 = per-dim default, default_steps)
+int g_segment_sum = 0;     // GVK_TUNE_SEGMENT_SUM (A/B: add up the changes of a run instead of chaining them)
+int g_skip_loss = 1;       // GVK_TUNE_SKIP_LOSS (gvk_train_episode leaves out the loss of batches nobody can read)
 
 struct TrainArgs {
     float *vertex, *context, *vm1, *cm1, *vm2, *cm2;
@@ -500,6 +503,206 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_runs_kernel(const TrainAr
     if constexpr (NM >= 2) store_row<DIM, G>(a.vm2, head, lane, reinterpret_cast<float(&)[V]>(vm2));
 }
 
+// ---- training kernel, SGD with one negative: a wavefront owns a segment of the batch --------------------------------
+//
+// The shipped kernel for the configuration every shipped setting of the reference uses (SGD, num_negative 1).  Lane
+// layout and arithmetic are those of train_kernel; the unit of work is a SEGMENT of S = (64 / G) * D consecutive pairs
+// per wavefront, trained in D steps of 64 / G pairs (one pair per lane group and step):
+//
+//   phase 1  all D pair headers of every lane group and the alias slots of their negatives           (1 round trip)
+//   phase 2  every row the segment needs — both context rows of every pair, and the head row of every pair that
+//            STARTS a run — requested at once: 2-3 x S x 512 B in flight per wavefront                (1 round trip)
+//   phase 3  arithmetic only.  Pairs of the segment that sit next to each other and share a head row form a run; a
+//            run is trained in sequence on ONE register copy of the row, which travels from lane group to lane group
+//            (ds_bpermute), exactly as consecutive iterations of one warp update its shared-memory copy in the
+//            reference (gpu/graph.cuh:54-94).  Pairs that start a run are independent of each other and run in the
+//            same step side by side.  The row is stored once, by the last pair of the run.
+//
+// With batches in sampler order runs are rare and this is the per-pair kernel with D pairs per lane group in flight.
+// After gvk_group_pairs every head row of a batch is a sequence of adjacent pairs: the row crosses HBM once per run
+// instead of once per pair (a 100k batch of the benchmark graph has 70k distinct head rows: a tenth of all row traffic
+// disappears), and of the pairs of a batch that share a hub row up to S consecutive updates survive instead of one.
+// Because every row was requested in phase 2, a run costs no memory round trip per pair — the dependent chain is
+// arithmetic only (about 0.1 us per pair), which is what train_runs_kernel above could not avoid.
+// SUM (A/B build, GVK_TUNE_SEGMENT_SUM): instead of passing the row along the run, every pair of a step trains its own
+// copy of the row side by side and the changes of the pairs of one run are ADDED up before the single store — no
+// serialisation inside a step, at the price of up to 64 / G updates computed from the same stale row.
+// LOSS = 0 builds leave the per-sample loss out: gvk_train_episode only needs it for the batch whose loss can still be
+// read afterwards (every batch overwrites the same loss buffer).
+template <int DIM, int G, int D, int DRAW, int WAVES, int SUM = 0, int LOSS = 1>
+__global__ void __launch_bounds__(kBlock, WAVES) train_segment_kernel(const TrainArgs a) {
+    constexpr int V = DIM / G;
+    constexpr int NG = 64 / G;  // lane groups of a wavefront = pairs per step
+    constexpr int S = NG * D;   // pairs per wavefront
+    constexpr uint32_t kNone = 0xffffffffu;  // row ids are below 2^32 - 1 (gvk_tables.n_vertex is a uint32 count)
+
+    const int wave = (blockIdx.x * kBlock + threadIdx.x) / 64;
+    const int lane64 = threadIdx.x % 64, g = lane64 / G, lane = lane64 % G;
+    const int base = wave * S;
+    if (base >= a.batch_size) return;  // whole wavefronts leave together
+    const bool draw = DRAW != 0;
+    const u32x2 *records = reinterpret_cast<const u32x2 *>(a.pairs);
+    const int before = (lane64 + 64 - G) & 63, after = (lane64 + G) & 63;  // same lane of the neighbouring lane groups
+
+    // phase 1: headers and alias slots
+    uint32_t head[D], tail[D], neg[D];
+    Draw dr[D];
+    gvk_alias_entry en[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        const int s = base + i * NG + g;
+        head[i] = kNone, tail[i] = 0, neg[i] = 0;
+        dr[i] = {0, 0};
+        en[i] = {0, 0};
+        if (s < a.batch_size) {
+            if (draw) {
+                dr[i] = negative_slot(a.seed, a.batch_id, (uint32_t)s, 0, a.count);
+                en[i] = a.table[dr[i].index];
+            } else {
+                neg[i] = __builtin_nontemporal_load(a.negatives + s);
+            }
+            const u32x2 pr = __builtin_nontemporal_load(records + s);
+            tail[i] = pr.x, head[i] = pr.y;
+        }
+    }
+    // run structure: cont = this pair continues the run of the pair before it; last = the run ends with this pair
+    bool cont[D], last[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        const uint32_t same_step = __shfl(head[i], before);
+        const uint32_t step_before = i > 0 ? __shfl(head[i - 1], before) : kNone;
+        const uint32_t pred = g > 0 ? same_step : step_before;
+        cont[i] = head[i] != kNone && pred == head[i];
+        const uint32_t next_same = __shfl(head[i], after);
+        const uint32_t step_after = i + 1 < D ? __shfl(head[i + 1], after) : kNone;
+        const uint32_t succ = g < NG - 1 ? next_same : step_after;
+        last[i] = succ != head[i];
+    }
+
+    // phase 2: every row of the segment
+    float vl[D][V], cn[D][V], cp[D][V];
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        if (head[i] != kNone) {
+            if (draw) neg[i] = resolve(dr[i], en[i]);
+            load_row<DIM, G>(a.context, neg[i], lane, cn[i]);
+            load_row<DIM, G>(a.context, tail[i], lane, cp[i]);
+            if (SUM || !cont[i]) load_row<DIM, G>(a.vertex, head[i], lane, vl[i]);
+        }
+    }
+
+    // phase 3
+    float v[V];
+#pragma unroll
+    for (int i = 0; i < V; i++) v[i] = 0;
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        const bool valid = head[i] != kNone;
+        // position in the chain of this step: 0 = nothing to wait for in this step (a run start, or lane group 0, whose
+        // predecessor finished in the step before), d = d lane groups of this step come first
+        int depth = 0;
+        {
+            const uint64_t chain = __ballot(cont[i]);
+            bool run = true;
+#pragma unroll
+            for (int r = 0; r < NG - 1; r++) {
+                const int gg = g - r;
+                run = run && gg >= 1 && ((chain >> (gg * G)) & 1);
+                depth += run ? 1 : 0;
+            }
+        }
+        auto train_pair = [&]() __attribute__((always_inline)) {
+            float sample_loss = 0;
+            // negative target, then the positive one (gpu/graph.cuh:63-88; model/graph.h:40-58)
+            {
+                float partial = 0;
+#pragma unroll
+                for (int x = 0; x < V; x++) partial += v[x] * cn[i][x];
+                const float prob = sigmoidf(group_sum<G>(partial));
+                if (LOSS) sample_loss += a.neg_weight * -logf(1 - prob + kEpsilon);
+                float m1 = 0, m2 = 0;
+#pragma unroll
+                for (int x = 0; x < V; x++) {
+                    const float vi = v[x], ci = cn[i][x];
+                    v[x] -= update<GVK_SGD>(a, vi, prob * ci, a.neg_weight, m1, m2);
+                    cn[i][x] -= update<GVK_SGD>(a, ci, prob * vi, a.neg_weight, m1, m2);
+                }
+                store_row<DIM, G>(a.context, neg[i], lane, cn[i]);
+                if (neg[i] == tail[i]) copy_row(cp[i], cn[i]);  // the pair sees its own update
+            }
+            {
+                float partial = 0;
+#pragma unroll
+                for (int x = 0; x < V; x++) partial += v[x] * cp[i][x];
+                const float prob = sigmoidf(group_sum<G>(partial));
+                if (LOSS) sample_loss += -logf(prob + kEpsilon);
+                float m1 = 0, m2 = 0;
+#pragma unroll
+                for (int x = 0; x < V; x++) {
+                    const float vi = v[x], ci = cp[i][x];
+                    v[x] -= update<GVK_SGD>(a, vi, (prob - 1) * ci, 1.0f, m1, m2);
+                    cp[i][x] -= update<GVK_SGD>(a, ci, (prob - 1) * vi, 1.0f, m1, m2);
+                }
+                store_row<DIM, G>(a.context, tail[i], lane, cp[i]);
+            }
+            if (LOSS && lane == 0)
+                __builtin_nontemporal_store(sample_loss / (1 + a.neg_weight), a.loss + base + i * NG + g);
+        };
+        if constexpr (SUM) {
+            // every pair from its own copy of the row, then the changes of a run travel down the run and add up;
+            // a run that continues from the step before starts from that step's result instead of the loaded row
+            float carried[V];
+#pragma unroll
+            for (int x = 0; x < V; x++) carried[x] = __shfl(v[x], before);
+            const bool from_before = valid && cont[i] && g == 0;
+            if (valid) {
+                if (from_before) copy_row(v, carried); else copy_row(v, vl[i]);
+            }
+            float start[V];
+            copy_row(start, v);
+            if (valid) train_pair();
+            float delta[V];
+#pragma unroll
+            for (int x = 0; x < V; x++) delta[x] = valid ? v[x] - start[x] : 0.0f;
+#pragma unroll
+            for (int r = 1; r < NG; r++) {  // delta of the pair r places up the run, if the run reaches that far
+                const int source = (lane64 + 64 - r * G) & 63;
+#pragma unroll
+                for (int x = 0; x < V; x++) {
+                    const float d = __shfl(delta[x], source);
+                    if (depth >= r) v[x] += d;
+                }
+            }
+            // all pairs of a run end up relative to the row its first pair of this step started from (the pairs
+            // further down started from their own loaded copy of the same row)
+            const int first = (lane64 + 64 - depth * G) & 63;
+#pragma unroll
+            for (int x = 0; x < V; x++) {
+                const float origin = __shfl(start[x], first);
+                if (depth > 0) v[x] += origin - start[x];
+            }
+            if (valid && last[i]) store_row<DIM, G>(a.vertex, head[i], lane, v);
+        } else {
+#pragma unroll 1
+            for (int t = 0; t < NG; t++) {
+                const bool mine = valid && depth == t;
+                if (!__any(mine)) break;  // depths are contiguous: nobody is deeper either
+                if (__any(mine && cont[i])) {  // the row of the run moves on to the next lane group
+                    float vin[V];
+#pragma unroll
+                    for (int x = 0; x < V; x++) vin[x] = __shfl(v[x], before);
+                    if (mine && cont[i]) copy_row(v, vin);
+                }
+                if (mine) {
+                    if (!cont[i]) copy_row(v, vl[i]);
+                    train_pair();
+                    if (last[i]) store_row<DIM, G>(a.vertex, head[i], lane, v);
+                }
+            }
+        }
+    }
+}
+
 // ---- A/B baseline: the reference's kernel SHAPE on wave64 ---------------------------------------------------------
 // One wavefront per pair in a grid-stride loop, the vertex row staged in LDS, context rows read-modify-written in
 // global memory one element pair per lane, shuffle-down reduction + broadcast — i.e. include/instance/gpu/graph.cuh:
@@ -789,11 +992,55 @@ int validate_train(int dim, const gvk_optimizer *o, const gvk_tables *t, const u
 // What launch_train would launch for this configuration under the current tuning (also what gvk_describe_train reports).
 struct Choice {
     TrainKernel kernel = nullptr;
-    int lanes = 0, run_cap = 1;
+    int lanes = 0, run_cap = 1, steps = 0;  // steps > 0: train_segment_kernel, (64 / lanes) * steps pairs per wavefront
     bool runs = false, fixed_k = false, reference_shape = false;
 };
 
-Choice choose_train(int dim, int opt, int k, bool explicit_negatives, int batch_size) {
+// pairs per lane group and wavefront of train_segment_kernel (D): what measured best per dim
+int default_steps(int dim) {
+    switch (dim) {
+        case 32: return 4;
+        case 64: return 4;
+        case 96: return 2;
+        case 128: return 2;
+        case 256: return 1;
+        case 512: return 1;
+    }
+    return 0;
+}
+
+// D pairs per lane group keep 3 * D rows of DIM / G floats in registers; past 128 VGPRs per lane the kernel is
+// built for 2 wavefronts per SIMD (256 VGPRs) instead of spilling, and D = 4 exists only where that suffices.
+template <int DIM, int G, int D>
+constexpr int segment_waves() {
+    return DIM / G * (3 * D + 2) + 40 <= 128 ? 4 : 2;
+}
+
+template <int DIM, int G, int D>
+TrainKernel segment_build(bool draw, bool sum, bool loss) {
+    if constexpr (DIM / G * (3 * D + 2) + 40 > 256) {
+        return nullptr;
+    } else {
+        constexpr int W = segment_waves<DIM, G, D>();
+        if (sum)  // A/B build: in-kernel draw only
+            return !draw ? nullptr : (loss ? train_segment_kernel<DIM, G, D, 1, W, 1, 1> : train_segment_kernel<DIM, G, D, 1, W, 1, 0>);
+        if (draw) return loss ? train_segment_kernel<DIM, G, D, 1, W, 0, 1> : train_segment_kernel<DIM, G, D, 1, W, 0, 0>;
+        return train_segment_kernel<DIM, G, D, 0, W, 0, 1>;
+    }
+}
+
+template <int DIM, int G>
+TrainKernel pick_segment(int steps, bool draw, bool sum, bool loss) {
+    switch (steps) {
+        case 1: return segment_build<DIM, G, 1>(draw, sum, loss);
+        case 2: return segment_build<DIM, G, 2>(draw, sum, loss);
+        case 4: return segment_build<DIM, G, 4>(draw, sum, loss);
+    }
+    return nullptr;
+}
+
+// want_loss = false: the caller promises that nobody can read this batch's loss (a later batch overwrites it)
+Choice choose_train(int dim, int opt, int k, bool explicit_negatives, int batch_size, bool want_loss = true) {
     Choice c;
     if (g_variant == 3 && dim == 128 && opt == GVK_SGD) {  // the reference's launch shape, graph.cuh:487-490
         c.reference_shape = true;
@@ -802,13 +1049,30 @@ Choice choose_train(int dim, int opt, int k, bool explicit_negatives, int batch_
     }
     c.lanes = g_lanes_per_pair && lanes_ok(dim, g_lanes_per_pair) && opt == GVK_SGD ? g_lanes_per_pair
                                                                                     : default_lanes(dim);
-    c.runs = g_variant != 2 && g_generation == 0;
+    const bool shipped_shape = opt == GVK_SGD && k == 1 && c.lanes == default_lanes(dim);
+    const bool draw = !explicit_negatives;
+    // SGD with one negative (every shipped configuration of the reference) on the default lane layout: a wavefront
+    // owns a segment (train_segment_kernel).  GVK_TUNE_VARIANT 1, 2 and 4 select the other builds for A/B.
+    if (shipped_shape && g_variant == 0 && g_generation == 0) {
+        c.steps = g_segment_steps ? g_segment_steps : default_steps(dim);
+#define GVK_SEGMENT(D, GG) \
+    case D: c.kernel = pick_segment<D, GG>(c.steps, draw, g_segment_sum != 0, want_loss || !g_skip_loss); break;
+        switch (dim) {
+            GVK_SEGMENT(32, 8) GVK_SEGMENT(64, 16) GVK_SEGMENT(96, 8) GVK_SEGMENT(128, 16) GVK_SEGMENT(256, 16)
+            GVK_SEGMENT(512, 32)
+        }
+#undef GVK_SEGMENT
+        if (c.kernel) {
+            c.fixed_k = true;
+            return c;
+        }
+        c.steps = 0;
+    }
+    c.runs = g_variant == 4 && g_generation == 0;
     c.run_cap = c.runs ? run_cap_for(batch_size) : 1;
     c.kernel = c.runs ? pick_train<true>(dim, c.lanes, opt) : pick_train<false>(dim, c.lanes, opt);
-    // SGD with one negative (every shipped configuration of the reference): compile-time k, fixed negative
-    // source -> straight-line code.  GVK_TUNE_VARIANT 1 forces the generic build (A/B).
-    if (opt == GVK_SGD && k == 1 && c.lanes == default_lanes(dim) && g_variant != 1) {
-        const bool draw = !explicit_negatives;
+    // compile-time k and negative source -> straight-line code.  GVK_TUNE_VARIANT 1 forces the generic build (A/B).
+    if (shipped_shape && g_variant != 1) {
         c.fixed_k = true;
 #define GVK_K1(D, GG)                                                                                         \
     case D:                                                                                                   \
@@ -825,8 +1089,8 @@ Choice choose_train(int dim, int opt, int k, bool explicit_negatives, int batch_
 
 int launch_train(hipStream_t stream, int dim, const gvk_optimizer *o, float lr, const gvk_tables *t,
                  const uint32_t *pairs, const gvk_negative_source *neg, uint32_t batch_id, float *loss,
-                 int batch_size, int k, float negative_weight) {
-    const Choice c = choose_train(dim, o->type, k, neg->negatives != nullptr, batch_size);
+                 int batch_size, int k, float negative_weight, bool want_loss = true) {
+    const Choice c = choose_train(dim, o->type, k, neg->negatives != nullptr, batch_size, want_loss);
     TrainArgs a;
     memset(&a, 0, sizeof(a));
     a.vertex = t->vertex; a.context = t->context;
@@ -855,7 +1119,12 @@ int launch_train(hipStream_t stream, int dim, const gvk_optimizer *o, float lr, 
         }
         return check_launch("gvk_train (generations)");
     }
-    const unsigned grid = (unsigned)(((int64_t)batch_size * c.lanes + kBlock - 1) / kBlock);
+    int64_t threads = (int64_t)batch_size * c.lanes;
+    if (c.steps > 0) {  // one wavefront per segment of (64 / lanes) * steps pairs
+        const int per_wave = 64 / c.lanes * c.steps;
+        threads = ((int64_t)batch_size + per_wave - 1) / per_wave * 64;
+    }
+    const unsigned grid = (unsigned)((threads + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(c.kernel, dim3(grid), dim3(kBlock), 0, stream, a);
     return check_launch("gvk_train");
 }
@@ -889,9 +1158,10 @@ int gvk_train_episode(void *stream, int dim, const gvk_optimizer *optimizer, int
             scale = 1 - float(int(id)) / int(total_batches);
             if (scale < 1e-4f) scale = 1e-4f;
         }
+        // every batch overwrites loss[]: only the last one's values can ever be read, the others skip computing them
         rc = launch_train((hipStream_t)stream, dim, optimizer, optimizer->lr * scale, tables,
                           pairs + (size_t)i * batch_size * 2, negative, id, loss, batch_size, num_negative,
-                          negative_weight);
+                          negative_weight, i == num_batches - 1);
         if (rc != GVK_OK) return rc;
     }
     return GVK_OK;
@@ -988,6 +1258,9 @@ int gvk_describe_train(int dim, int optimizer_type, int num_negative, int explic
         snprintf(name, capacity, "train_kernel_reference_shape<%d> grid 8192x512", dim);
     else if (!c.kernel)
         return fail(GVK_EINVAL, "gvk_describe_train: no kernel for this (dim, lanes, optimizer)");
+    else if (c.steps > 0)
+        snprintf(name, capacity, "train_segment_kernel<%d,%d,SGD,k=1> %d pairs per wavefront%s", dim, c.lanes,
+                 64 / c.lanes * c.steps, g_segment_sum ? ", run changes added up" : "");
     else
         snprintf(name, capacity, "%s<%d,%d,%s%s> run_cap %d%s", c.runs ? "train_runs_kernel" : "train_kernel", dim, c.lanes,
                  kOptimizers[optimizer_type], c.fixed_k ? ",k=1" : "", c.run_cap,
@@ -1003,8 +1276,19 @@ int gvk_set_tuning(int key, int value) {
         return GVK_OK;
     }
     if (key == GVK_TUNE_VARIANT) {
-        if (value < 0 || value > 3) return fail(GVK_EINVAL, "gvk_set_tuning: variant must be 0, 1, 2 or 3");
+        if (value < 0 || value > 4) return fail(GVK_EINVAL, "gvk_set_tuning: variant must be 0 ... 4");
         g_variant = value;
+        return GVK_OK;
+    }
+    if (key == GVK_TUNE_SEGMENT_STEPS) {
+        if (value != 0 && value != 1 && value != 2 && value != 4)
+            return fail(GVK_EINVAL, "gvk_set_tuning: segment steps must be 0, 1, 2 or 4");
+        g_segment_steps = value;
+        return GVK_OK;
+    }
+    if (key == GVK_TUNE_SEGMENT_SUM || key == GVK_TUNE_SKIP_LOSS) {
+        if (value != 0 && value != 1) return fail(GVK_EINVAL, "gvk_set_tuning: flag must be 0 or 1");
+        (key == GVK_TUNE_SEGMENT_SUM ? g_segment_sum : g_skip_loss) = value;
         return GVK_OK;
     }
     if (key == GVK_TUNE_GENERATION) {

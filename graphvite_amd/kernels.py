@@ -233,6 +233,14 @@ class HipKernels(object):
         """Longest run of adjacent same-head pairs one lane group trains in sequence (0 = from the batch size)."""
         _lib.check(self.lib.gvk_set_tuning(_lib.TUNE_RUN_CAP, run_cap), "gvk_set_tuning")
 
+    def set_segment_steps(self, steps):
+        """train_segment_kernel: pairs per lane group and wavefront (0 = per-dim default, 1, 2 or 4)."""
+        _lib.check(self.lib.gvk_set_tuning(_lib.TUNE_SEGMENT_STEPS, steps), "gvk_set_tuning")
+
+    def set_tuning(self, key, value):
+        """Any GVK_TUNE_* knob of include/gvk.h by number (experiments)."""
+        _lib.check(self.lib.gvk_set_tuning(int(key), int(value)), "gvk_set_tuning")
+
     def set_generation(self, samples):
         """Parity experiment: train every batch as consecutive launches of at most `samples` samples (0 = off)."""
         _lib.check(self.lib.gvk_set_tuning(_lib.TUNE_GENERATION, samples), "gvk_set_tuning")

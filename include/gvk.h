@@ -96,10 +96,10 @@ typedef struct {
 /* One batch of negative-sampling SGD: for every {tail, head} pair, num_negative negative steps then the
  * positive step on a progressively updated copy of vertex[head]; context rows are updated in place,
  * Hogwild (no atomics), loss[s] = sample loss / (1 + num_negative * negative_weight).
- * Pairs that sit next to each other in the batch and share a head row are trained as one run by one lane group —
- * one after the other on the same register copy of the row, as consecutive iterations of one warp in the reference
- * (include/instance/gpu/graph.cuh:54-94) — up to the run cap (GVK_TUNE_RUN_CAP); samples keep their own negatives
- * and loss slots.  `stream` is a hipStream_t (NULL = default stream).  `batch_id` only feeds the negative draw. */
+ * With SGD and num_negative == 1, pairs that sit next to each other in the batch, share a head row and fall into the
+ * same wavefront's segment (8 consecutive pairs at dim 128) are trained as one run — one after the other on one
+ * register copy of the row, as consecutive iterations of one warp in the reference (include/instance/gpu/graph.cuh:
+ * 54-94); samples keep their own negatives and loss slots.  `stream` is a hipStream_t (NULL = default stream).  `batch_id` only feeds the negative draw. */
 int gvk_train(void *stream, int dim, const gvk_optimizer *optimizer, const gvk_tables *tables,
               const uint32_t *pairs, const gvk_negative_source *negative, uint32_t batch_id, float *loss,
               int batch_size, int num_negative, float negative_weight);
@@ -109,7 +109,8 @@ int gvk_train(void *stream, int dim, const gvk_optimizer *optimizer, const gvk_t
  * counter, solver.h:142,1520, so W concurrent workers see ids W apart), and
  * lr = init_lr * schedule(id, total_batches) where schedule is max(1 - id / total, 1e-4) if linear_schedule
  * else 1 (`optimizer->lr` is init_lr here).  loss [batch_size] is overwritten by every batch, as in the
- * reference. One kernel launch per batch. */
+ * reference, so after the call it holds the losses of the LAST batch; the kernels of the earlier batches are built
+ * without the loss arithmetic (nothing could read it).  One kernel launch per batch. */
 int gvk_train_episode(void *stream, int dim, const gvk_optimizer *optimizer, int linear_schedule,
                       const gvk_tables *tables, const uint32_t *pairs, const gvk_negative_source *negative,
                       uint32_t first_batch_id, uint32_t batch_id_stride, uint32_t total_batches, int num_batches,
@@ -186,20 +187,28 @@ int gvk_alias_build(const float *weights, size_t n, float *prob, void *alias, in
 /* Tuning knobs for A/B measurement (bench.py --variant); they never change results beyond
  * floating-point summation order.  Returns GVK_EINVAL for an unknown key or unsupported value. */
 #define GVK_TUNE_LANES_PER_PAIR 1 /* 0 = per-dim default; else 8, 16, 32 or 64 */
-#define GVK_TUNE_VARIANT 2        /* 0 = default (runs of same-head pairs; k = 1 SGD uses the compile-time-k build),
-                                     1 = always the generic build, 2 = the per-pair kernel (one lane group per pair, no
-                                     runs), 3 = dim-128 SGD in the reference's kernel shape (one wavefront per pair,
-                                     vertex row in LDS, 8192 x 512 grid-stride launch) — 2 and 3 are A/B baselines only */
-#define GVK_TUNE_RUN_CAP 3        /* longest run of adjacent same-head pairs a lane group trains in sequence: 0 = from the
-                                     batch size (batch_size / 5120 rounded up: the generations of the reference's launch
-                                     on the card it was written for), 1 = every pair on its own, up to 64 */
+#define GVK_TUNE_VARIANT 2        /* 0 = default: SGD with one negative runs train_segment_kernel (a wavefront owns a
+                                     segment of the batch), everything else the per-pair kernel;
+                                     1 = the per-pair kernel, generic build (run-time k); 2 = the per-pair kernel with
+                                     compile-time k; 3 = dim-128 SGD in the reference's kernel shape (one wavefront per
+                                     pair, vertex row in LDS, 8192 x 512 grid-stride launch); 4 = train_runs_kernel (one
+                                     lane group trains a run of same-head pairs, rows fetched one target ahead).
+                                     1 - 4 are A/B baselines */
+#define GVK_TUNE_RUN_CAP 3        /* variant 4 only: longest run a lane group trains in sequence: 0 = from the batch size
+                                     (batch_size / 5120 rounded up), 1 = every pair on its own, up to 64 */
 #define GVK_TUNE_GENERATION 4     /* parity experiment: C > 0 trains a batch as consecutive launches of at most C samples
                                      (per-pair kernel), the concurrency structure of the reference's launch on a card
                                      that keeps C warps resident; 0 = one launch per batch (default) */
+#define GVK_TUNE_SEGMENT_STEPS 5  /* train_segment_kernel: pairs per lane group and wavefront — 0 = per-dim default, 1, 2
+                                     or 4 (a wavefront then owns 64 / lanes * steps consecutive pairs) */
+#define GVK_TUNE_SEGMENT_SUM 6    /* A/B: 1 = the pairs of a run inside a step train side by side from the same row and
+                                     their changes are added up (no serialisation); 0 = chained in sequence (default) */
+#define GVK_TUNE_SKIP_LOSS 7      /* 1 (default) = gvk_train_episode does not compute the per-sample loss of batches whose
+                                     loss[] a later batch of the same call overwrites; 0 = every batch computes it */
 int gvk_set_tuning(int key, int value);
 
 /* The kernel gvk_train / gvk_train_episode launch for this configuration under the current tuning, as text
- * ("train_runs_kernel<128,16,SGD,k=1> run_cap 20") — what a benchmark should label its measurement with. */
+ * ("train_segment_kernel<128,16,SGD,k=1> 8 pairs per wavefront") — what a benchmark should label its measurement with. */
 int gvk_describe_train(int dim, int optimizer_type, int num_negative, int explicit_negatives, int batch_size,
                        char *name, size_t capacity);
 

@@ -77,7 +77,7 @@ def test_kernel_wrappers_refuse_cpu_tensors():
         OptimizerSpec("Nadam")
 
 
-@pytest.mark.parametrize("world,order", [(1, "sampled"), (2, "grouped"), (2, "sampled")])
+@pytest.mark.parametrize("world,order", [(1, "sampled"), (2, "grouped"), (2, "sampled"), (8, "grouped")])
 def test_bench_loop_dry_run(world, order):
     """bench.py's own loop (block walk across warm-up / timed steps, staging pass, asynchronous exchange, max over
     ranks, one JSON line from rank 0) executed on the CPU: gloo instead of RCCL, the oracle stand-in instead of the HIP
@@ -110,3 +110,15 @@ def test_bench_loop_dry_run(world, order):
     assert r["config"]["pair_order"].startswith(order) and "DRY RUN" in r["data"]
     assert ("cpu_baseline" in r) == False
     assert "%d vertex partition" % (1 if world == 1 else 2 * world) in r["config"]["parallelism"]
+    if world > 1:
+        # one collective per schedule step: every GPU sends its own head shard (ceil(400 / P) rows of dim 32, fp32) to
+        # the W - 1 others, nothing else crosses the fabric in the data path of LINE
+        P = 2 * world
+        shard = -(-400 // P) * 32 * 4
+        assert r["exchange"]["bytes_sent_per_gpu_per_collective"] == shard * (world - 1)
+        # block visits that were completed: one per block in the residency pass, the warm-up's, the timed region's
+        # full ones (its last, partial visit has not reached its exchange when the run ends)
+        assert r["exchange"]["collectives_total"] == P * P // world + -(-3 // 4) + 23 // 4
+    else:
+        assert r["exchange"] is None
+    assert r["config"]["block_visits_timed"] == 6 and r["roofline"]["kernel"] == "stand-in"

@@ -159,12 +159,85 @@ def _run_batch(rng, N, B, k, run_lengths):
     return pairs, negs
 
 
+def _whole_runs(pairs, segment):
+    """(first index, last index, inside one `segment`-aligned window) of every run of adjacent same-head pairs."""
+    B = len(pairs)
+    first = np.flatnonzero(np.r_[True, pairs[1:, 1] != pairs[:-1, 1]])
+    last = np.r_[first[1:], B] - 1
+    return first, last, first // segment == last // segment
+
+
+def _check_runs(pairs, negs, v, c, ov, oc, oloss, hv, hc, hloss, segment):
+    """Runs that lie inside one segment must equal the sequential oracle; a run cut by a segment boundary is trained
+    by two lane groups / wavefronts concurrently and is only checked through its context rows' neighbours."""
+    first, last, whole = _whole_runs(pairs, segment)
+    rows = pairs[first[whole], 1]
+    np.testing.assert_allclose(hv[rows], ov[rows], rtol=RTOL, atol=ATOL)
+    in_whole = np.repeat(whole, last - first + 1)
+    np.testing.assert_allclose(hloss[in_whole], oloss[in_whole], rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(hc[pairs[in_whole, 0]], oc[pairs[in_whole, 0]], rtol=RTOL, atol=ATOL)
+    if negs is not None:
+        np.testing.assert_allclose(hc[negs[in_whole].ravel()], oc[negs[in_whole].ravel()], rtol=RTOL, atol=ATOL)
+    assert whole.sum() > len(whole) // 3
+
+
+@pytest.mark.parametrize("dim", [32, 64, 96, 128, 256, 512])
+@pytest.mark.parametrize("steps", [0, 1, 2, 4])
+@pytest.mark.parametrize("explicit", [True, False])
+def test_segment_kernel_trains_runs_in_sequence(hip, oracle, dim, steps, explicit):
+    """The shipped SGD / one-negative kernel: adjacent pairs that share a head row and lie in one wavefront's segment
+    are one run, trained one after the other on one register copy of the row (the reference's warp does that with
+    consecutive iterations of its loop, gpu/graph.cuh:54-94).  With distinct context rows the result equals the
+    SEQUENTIAL oracle — no update of the head row is lost — and every sample keeps its own negative and loss slot."""
+    rng = np.random.default_rng(dim + steps)
+    N, B, k = 8192, 1531, 1
+    v, c = init_tables(rng, N, N, dim)
+    v *= 20
+    c *= 20
+    pairs, negs = _run_batch(rng, N, B, k, [1, 2, 1, 5, 3, 1, 1, 9, 16, 2, 1, 1, 4, 33])
+    hip.set_segment_steps(steps)
+    try:
+        name = hip.describe_train(dim, "SGD", k, explicit, B)
+        if "train_segment_kernel" not in name:
+            pytest.skip("no %d-step build at dim %d: %s" % (steps, dim, name))
+        segment = int(name.split("> ")[1].split()[0])
+        if explicit:
+            hv, hc, hloss, _ = run_hip(hip, v, c, pairs, negs, OPTS["SGD"][1], 5.0)
+        else:  # in-kernel draw: feed the oracle the negatives of the RNG contract; drop pairs whose draw collides
+            w = rng.uniform(0.5, 1.5, N).astype(np.float32)  # a flat table: few draws collide in one batch
+            prob, alias, packed = K.alias_build(w)
+            negs = oracle.negatives(prob, alias, 9, 4, B, k)
+            tv, tc, loss = dev(v), dev(c), torch.zeros(B, device=DEV)
+            hip.train(tv, tc, dev(pairs.view(np.int32)), loss, OPTS["SGD"][1], k, 5.0,
+                      table=K.packed_to_device(packed, DEV), seed=9, batch_id=4)
+            torch.cuda.synchronize()
+            hv, hc, hloss = tv.cpu().numpy(), tc.cpu().numpy(), loss.cpu().numpy()
+    finally:
+        hip.set_segment_steps(0)
+    if explicit:
+        ov, oc = v.copy(), c.copy()
+        oloss = oracle.train(ov, oc, pairs, negs, 0.025, 0.005, 5.0)
+        _check_runs(pairs, negs, v, c, ov, oc, oloss, hv, hc, hloss, segment)
+    else:
+        # drawn negatives repeat (hubs) and hit tails: compare the samples whose context rows nobody else touches
+        ov, oc = v.copy(), c.copy()
+        oloss = oracle.train(ov, oc, pairs, negs, 0.025, 0.005, 5.0)
+        ctx = np.concatenate([pairs[:, :1], negs], 1)
+        ids, count = np.unique(ctx, return_counts=True)
+        shared = set(ids[count > 1].tolist())
+        first, last, whole = _whole_runs(pairs, segment)
+        clean_run = np.array([w and not (set(ctx[f:l + 1].ravel().tolist()) & shared) for f, l, w in zip(first, last, whole)])
+        assert clean_run.sum() > len(first) // 8
+        rows = pairs[first[clean_run], 1]
+        np.testing.assert_allclose(hv[rows], ov[rows], rtol=RTOL, atol=ATOL)
+        in_clean = np.repeat(clean_run, last - first + 1)
+        np.testing.assert_allclose(hloss[in_clean], oloss[in_clean], rtol=RTOL, atol=1e-6)
+
+
 @pytest.mark.parametrize("dim,k", [(128, 1), (128, 3), (96, 1), (32, 2), (512, 1), (128, 0)])
-def test_runs_of_one_head_train_in_sequence(hip, oracle, dim, k):
-    """Adjacent pairs that share a head row are one run: one lane group applies them one after the other on the same
-    register copy of the row (the reference's warp does that with consecutive iterations of its loop,
-    gpu/graph.cuh:54-94), so with distinct context rows the result equals the SEQUENTIAL oracle — no update of the
-    head row is lost — and every sample keeps its own negatives and loss slot."""
+def test_runs_kernel_trains_runs_in_sequence(hip, oracle, dim, k):
+    """train_runs_kernel (GVK_TUNE_VARIANT 4, the A/B build in which one lane group trains a whole run): same property,
+    any num_negative, runs cut at multiples of the run cap."""
     rng = np.random.default_rng(dim + k)
     N, B = 8192, 1500
     v, c = init_tables(rng, N, N, dim)
@@ -173,23 +246,17 @@ def test_runs_of_one_head_train_in_sequence(hip, oracle, dim, k):
     pairs, negs = _run_batch(rng, N, B, k, [1, 2, 1, 5, 3, 1, 1, 9, 16, 2])
     ov, oc = v.copy(), c.copy()
     oloss = oracle.train(ov, oc, pairs, negs, 0.025, 0.005, 5.0)
+    hip.set_variant(4)
     hip.set_run_cap(16)
     try:
         assert "train_runs_kernel" in hip.describe_train(dim, "SGD", k, True, B)
-        # a segment boundary every 16 pairs may cut a run in two; keep runs inside segments for the exact comparison
-        first = np.flatnonzero(np.r_[True, pairs[1:, 1] != pairs[:-1, 1]])
-        last = np.r_[first[1:], B] - 1
-        whole = first // 16 == last // 16
         hv, hc, hloss, _ = run_hip(hip, v, c, pairs, negs if k else None, OPTS["SGD"][1], 5.0, k=k)
     finally:
         hip.set_run_cap(0)
-    np.testing.assert_allclose(hc, oc, rtol=RTOL, atol=ATOL) if whole.all() else None
-    rows = pairs[first[whole], 1]
-    np.testing.assert_allclose(hv[rows], ov[rows], rtol=RTOL, atol=ATOL)
-    in_whole = np.repeat(whole, last - first + 1)
-    np.testing.assert_allclose(hloss[in_whole], oloss[in_whole], rtol=RTOL, atol=1e-6)
-    np.testing.assert_allclose(hc[pairs[in_whole, 0]], oc[pairs[in_whole, 0]], rtol=RTOL, atol=ATOL)
-    assert whole.sum() > len(whole) // 2 and (~whole).sum() > 0
+        hip.set_variant(0)
+    _check_runs(pairs, negs if k else None, v, c, ov, oc, oloss, hv, hc, hloss, 16)
+    first, last, whole = _whole_runs(pairs, 16)
+    assert (~whole).sum() > 0
 
 
 @pytest.mark.parametrize("name", ["Momentum", "Adam"])
@@ -205,11 +272,13 @@ def test_runs_with_moment_optimizers(hip, oracle, name):
     pairs, negs = _run_batch(rng, N, B, k, [4, 1, 2, 1])  # runs of 4, 1, 2, 1: none crosses a multiple of 8
     ov, oc, om = v.copy(), c.copy(), [None if m is None else m.copy() for m in moments]
     oloss = oracle.train(ov, oc, pairs, negs, spec.lr, spec.weight_decay, 5.0, opt_id, om, hp)
+    hip.set_variant(4)
     hip.set_run_cap(8)
     try:
         hv, hc, hloss, hm = run_hip(hip, v, c, pairs, negs, spec, 5.0, moments=moments)
     finally:
         hip.set_run_cap(0)
+        hip.set_variant(0)
     np.testing.assert_allclose(hv, ov, rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(hc, oc, rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(hloss, oloss, rtol=1e-5, atol=1e-6)
@@ -219,9 +288,10 @@ def test_runs_with_moment_optimizers(hip, oracle, name):
 
 
 def test_run_cap_splits_long_runs(hip, oracle):
-    """A run longer than the cap is trained by several lane groups, each from the row as the launch found it; the row
-    ends up as ONE of their results (last store wins, as between two concurrent warps of the reference).  Cap 1 is the
-    per-pair behaviour, and so is the per-pair A/B kernel (variant 2)."""
+    """A run longer than the cap (a wavefront's segment) is trained by several lane groups (wavefronts), each from the
+    row as the launch found it; the row ends up as ONE of their results (last store wins, as between two concurrent
+    warps of the reference).  (cap, variant): the runs kernel with caps 4, 16, 1; the per-pair kernel; the segment
+    kernel, whose segment is 8 pairs at dim 128."""
     rng = np.random.default_rng(5)
     N, B, k, dim = 4096, 64, 1, 128
     v, c = init_tables(rng, N, N, dim)
@@ -229,15 +299,17 @@ def test_run_cap_splits_long_runs(hip, oracle):
     c *= 20
     pairs, negs = _run_batch(rng, N, B, k, [64])
     row = int(pairs[0, 1])
-    for cap, variant in ((4, 0), (16, 0), (1, 0), (0, 2)):
+    for cap, variant in ((4, 4), (16, 4), (1, 4), (1, 2), (8, 0)):
         candidates = []
         for start in range(0, B, max(cap, 1)):
             ov, oc = v.copy(), c.copy()
             oracle.train(ov, oc, pairs[start:start + max(cap, 1)], negs[start:start + max(cap, 1)], 0.025, 0.005, 5.0)
             candidates.append(ov[row])
-        hip.set_run_cap(cap)
+        hip.set_run_cap(cap if variant == 4 else 0)
         hip.set_variant(variant)
         try:
+            if variant == 0:
+                assert "8 pairs per wavefront" in hip.describe_train(dim, "SGD", k, True, B)
             hv, hc, hloss, _ = run_hip(hip, v, c, pairs, negs, OPTS["SGD"][1], 5.0)
         finally:
             hip.set_run_cap(0)

@@ -323,6 +323,35 @@ def test_predict_and_link_prediction_pipeline(tmp_path):
     assert (app.solver.vertex_embeddings == old).all()
     with pytest.raises(ValueError):
         app.evaluate("node clustering")
+    # the file has the reference's layout (application.py:145-187): attribute access all the way down, the class the
+    # reference pickles (easydict.EasyDict), and with save_hyperparameter its key set including solver.optimizer
+    assert type(saved).__module__ == "easydict" and type(saved).__name__ == "EasyDict"
+    assert saved.graph.name2id["%d" % train[0, 0]] == app.graph.name2id["%d" % train[0, 0]]
+    assert saved.solver.vertex_embeddings is saved["solver"]["vertex_embeddings"]
+    app.save_model(path, save_hyperparameter=True)
+    full = pickle.load(open(path, "rb"))
+    assert full.solver.optimizer.type == "SGD" and full.solver.optimizer.schedule == "linear"
+    assert full.solver.optimizer.lr == pytest.approx(0.025) and full.solver.num_negative == 1
+    assert full.graph.num_vertex == app.graph.num_vertex and full.solver.model == "LINE"
+    assert full.solver.batch_size == 1000 and full.solver.random_walk_batch_size == 100
+    # what the reference's load_model does with such a file (application.py:131-142, 288-291): attribute access only
+    mapping = [full.graph.name2id[name] for name in app.graph.id2name]
+    assert (full.solver.vertex_embeddings[mapping] == old).all()
+    # and a file the way the reference writes it — object attributes gathered into nested EasyDicts, the name map an
+    # EasyDict too — or as older versions of this package wrote it (plain dicts) loads here
+    from graphvite_amd.application.application import easy_dict_class
+    EasyDict = easy_dict_class()
+    theirs = EasyDict()
+    theirs.graph = EasyDict()
+    theirs.graph["name2id"] = dict(app.graph.name2id)
+    theirs.graph["id2name"] = list(app.graph.id2name)
+    theirs.solver = EasyDict(vertex_embeddings=old * 2, context_embeddings=np.array(app.solver.context_embeddings))
+    for record in (theirs, {"graph": dict(theirs.graph), "solver": dict(theirs.solver)}):
+        with open(path, "wb") as fout:
+            pickle.dump(record, fout, protocol=pickle.HIGHEST_PROTOCOL)
+        app.solver.vertex_embeddings[:] = 0
+        app.load_model(path)
+        assert (app.solver.vertex_embeddings == old * 2).all()
 
 
 def test_node_classification_cli_and_embedding_file(tmp_path):
