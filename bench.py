@@ -63,7 +63,8 @@ def parse(argv=None):
                         "auto episode size for this graph (solver.h:426-436), capped at 250 and at --steps (so that "
                         "the timed region is made of whole block visits)")
     p.add_argument("--no-end-to-end", action="store_true", help="skip the GraphSolver.train() runs (`end_to_end`)")
-    p.add_argument("--end-to-end-batches", type=int, default=2000, help="batches per GPU of each end-to-end run")
+    p.add_argument("--end-to-end-batches", type=int, default=12000,
+                   help="batches per GPU of each end-to-end run (several episodes: the auto episode size is 1750 batches here)")
     p.add_argument("--lanes", type=int, default=0, help="A/B knob: lanes per pair (0 = per-dim default)")
     p.add_argument("--variant", type=int, default=0, help="A/B knob: kernel build variant (gvk.h GVK_TUNE_VARIANT)")
     p.add_argument("--run-cap", type=int, default=0, help="A/B knob: longest same-head run per lane group (gvk.h GVK_TUNE_RUN_CAP)")
@@ -433,7 +434,7 @@ def main(argv=None, stand_in_kernels=None):
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary_bench_n1.json")), reverse=True):
             traffic, pmc_path = json.load(open(path)).get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT)
             break
-    kernel_name = solver.kernels.describe_train(dim, args.optimizer, k, False, B) if cuda else "stand-in"
+    kernel_name = solver.kernels.describe_train(dim, args.optimizer, k, False, B, solver._part_size) if cuda else "stand-in"
     result = {
         "metric": "million edge-samples/sec at dim=%d" % dim,
         "value": world * args.steps * B / wall / 1e6,

@@ -93,6 +93,8 @@ def lib():
     l.gvk_sample_pairs.argtypes = [vp, vp, vp, u32, u64, u64, vp, C.c_size_t]
     l.gvk_sample_walks.restype = i32
     l.gvk_sample_walks.argtypes = [vp, P(WalkGraph), u64, u64, vp, C.c_size_t, i32, i32, i32]
+    l.gvk_sample_walks_blocks.restype = i32
+    l.gvk_sample_walks_blocks.argtypes = [vp, P(WalkGraph), vp, i32, u64, u64, u64, vp, vp, vp, u32, i32, i32, i32]
     l.gvk_group_pairs.restype = i32
     l.gvk_group_pairs.argtypes = [vp, vp, vp, vp, P(C.c_size_t), i32, i32, i32]
     l.gvk_alias_build.restype = i32
@@ -100,7 +102,10 @@ def lib():
     l.gvk_set_tuning.restype = i32
     l.gvk_set_tuning.argtypes = [i32, i32]
     l.gvk_describe_train.restype = i32
-    l.gvk_describe_train.argtypes = [i32, i32, i32, i32, i32, C.c_char_p, C.c_size_t]
+    l.gvk_describe_train.argtypes = [i32, i32, i32, i32, i32, u32, C.c_char_p, C.c_size_t]
+    l.gvk_range_push.restype = None
+    l.gvk_range_push.argtypes = [C.c_char_p]
+    l.gvk_range_pop.restype = None
     l.gvk_last_error.restype = C.c_char_p
     l.gvk_version.restype = C.c_char_p
     # ---- host runtime (include/gvs.h) ----
@@ -169,6 +174,21 @@ def lib():
     l.gvs_host_uniforms.argtypes = [u64, u32, u64, sz, vp]
     _lib = l
     return l
+
+
+class profiler_range(object):
+    """with profiler_range("Train Batch"): ... — a roctx range around a host phase (gvk_range_push / _pop), visible in
+    `rocprofv3 --marker-trace` next to the kernels it issued.  Costs two C calls; a no-op without a profiler."""
+
+    def __init__(self, name):
+        self.name = name.encode()
+
+    def __enter__(self):
+        lib().gvk_range_push(self.name)
+
+    def __exit__(self, *exc):
+        lib().gvk_range_pop()
+        return False
 
 
 def check(rc, what="gvk"):

@@ -4,12 +4,20 @@
 
 #include <vector>
 
+#include <roctracer/roctx.h>
+
 #include "gvk.h"
 #include "gvk_internal.h"
 
 namespace {
 thread_local char g_error[512] = "";
 }
+
+// Named ranges on the calling thread for rocprofv3 (--marker-trace): the reference's USE_TIMER scopes
+// (include/util/time.h:28-60; "Sample threads", "Train Batch", "Train Kernel" at include/core/solver.h:622,645,1526-1552)
+// become roctx ranges, so a trace shows which host phase issued which kernels and where the pipeline overlaps.
+extern "C" void gvk_range_push(const char *name) { roctxRangePushA(name ? name : ""); }
+extern "C" void gvk_range_pop(void) { roctxRangePop(); }
 
 int gvk_fail(int code, const char *fmt, ...) {
     va_list ap;

@@ -42,6 +42,8 @@ int g_variant = 0;         // GVK_TUNE_VARIANT
 int g_run_cap = 0;         // GVK_TUNE_RUN_CAP (0 = from the batch size, run_cap_for)
 int g_generation = 0;      // GVK_TUNE_GENERATION (0 = one launch per batch)
 int g_segment_steps = 0;   // GVK_TUNE_SEGMENT_STEPS (0 = per-dim default, default_steps)
+int g_streaming_stores = 0;  // GVK_TUNE_STREAMING_STORES
+int g_segment_stream = 0;  // GVK_TUNE_SEGMENT_STREAM (A/B: rows fetched one step ahead instead of all at once)
 int g_segment_sum = 0;     // GVK_TUNE_SEGMENT_SUM (A/B: add up the changes of a run instead of chaining them)
 int g_skip_loss = 1;       // GVK_TUNE_SKIP_LOSS (gvk_train_episode leaves out the loss of batches nobody can read)
 
@@ -55,6 +57,7 @@ struct TrainArgs {
     uint32_t count, batch_id;
     int batch_size, k;
     int run_cap;  // train_runs_kernel: longest run of adjacent same-head pairs one lane group trains in sequence
+    int streaming_stores;  // A/B (GVK_TUNE_STREAMING_STORES): context rows are written with non-temporal stores
     int first_sample;  // train_kernel: this launch trains samples [first_sample, batch_size) of the batch (GVK_TUNE_GENERATION)
     float lr, wd, neg_weight, hp0, hp1, eps;
 };
@@ -147,7 +150,8 @@ __device__ __forceinline__ void load_row(const float *table, uint32_t id, int la
 }
 
 template <int DIM, int G>
-__device__ __forceinline__ void store_row(float *table, uint32_t id, int lane, const float (&r)[DIM / G]) {
+__device__ __forceinline__ void store_row(float *table, uint32_t id, int lane, const float (&r)[DIM / G],
+                                          bool streaming = false) {
     typedef Layout<DIM, G> L;
     float *row = table + (size_t)id * DIM + lane * L::CW;
 #pragma unroll
@@ -155,7 +159,10 @@ __device__ __forceinline__ void store_row(float *table, uint32_t id, int lane, c
         float *p = row + c * G * L::CW;
         if (L::CW == 4) {
             f32x4 x = {r[c * 4 + 0], r[c * 4 + 1], r[c * 4 + 2], r[c * 4 + 3]};
-            *reinterpret_cast<f32x4 *>(p) = x;
+            if (streaming)
+                __builtin_nontemporal_store(x, reinterpret_cast<f32x4 *>(p));
+            else
+                *reinterpret_cast<f32x4 *>(p) = x;
         } else if (L::CW == 2) {
             f32x2 x = {r[c * 2 + 0], r[c * 2 + 1]};
             *reinterpret_cast<f32x2 *>(p) = x;
@@ -529,11 +536,15 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_runs_kernel(const TrainAr
 // serialisation inside a step, at the price of up to 64 / G updates computed from the same stale row.
 // LOSS = 0 builds leave the per-sample loss out: gvk_train_episode only needs it for the batch whose loss can still be
 // read afterwards (every batch overwrites the same loss buffer).
-template <int DIM, int G, int D, int DRAW, int WAVES, int SUM = 0, int LOSS = 1>
+// STREAM (A/B build, GVK_TUNE_SEGMENT_STREAM): the headers of all D steps are still fetched at once, but the rows only
+// one step ahead, through two register buffers — the first round trip (pair record + alias slot, a few bytes) is paid
+// once per D pairs instead of once per pair while the rows in flight per wavefront stay those of two steps.
+template <int DIM, int G, int D, int DRAW, int WAVES, int SUM = 0, int LOSS = 1, int STREAM = 0>
 __global__ void __launch_bounds__(kBlock, WAVES) train_segment_kernel(const TrainArgs a) {
     constexpr int V = DIM / G;
     constexpr int NG = 64 / G;  // lane groups of a wavefront = pairs per step
     constexpr int S = NG * D;   // pairs per wavefront
+    constexpr int NB = STREAM ? (D > 1 ? 2 : 1) : D;  // row buffers per lane
     constexpr uint32_t kNone = 0xffffffffu;  // row ids are below 2^32 - 1 (gvk_tables.n_vertex is a uint32 count)
 
     const int wave = (blockIdx.x * kBlock + threadIdx.x) / 64;
@@ -579,17 +590,20 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_segment_kernel(const Trai
         last[i] = succ != head[i];
     }
 
-    // phase 2: every row of the segment
-    float vl[D][V], cn[D][V], cp[D][V];
+    // phase 2: every row of the segment (STREAM: of its first step; the others follow one step ahead)
+    float vl_[NB][V], cn_[NB][V], cp_[NB][V];
 #pragma unroll
-    for (int i = 0; i < D; i++) {
+    for (int i = 0; i < D; i++)
+        if (draw && head[i] != kNone) neg[i] = resolve(dr[i], en[i]);
+    auto load_step = [&](const int i) __attribute__((always_inline)) {
         if (head[i] != kNone) {
-            if (draw) neg[i] = resolve(dr[i], en[i]);
-            load_row<DIM, G>(a.context, neg[i], lane, cn[i]);
-            load_row<DIM, G>(a.context, tail[i], lane, cp[i]);
-            if (SUM || !cont[i]) load_row<DIM, G>(a.vertex, head[i], lane, vl[i]);
+            load_row<DIM, G>(a.context, neg[i], lane, cn_[i % NB]);
+            load_row<DIM, G>(a.context, tail[i], lane, cp_[i % NB]);
+            if (SUM || !cont[i]) load_row<DIM, G>(a.vertex, head[i], lane, vl_[i % NB]);
         }
-    }
+    };
+#pragma unroll
+    for (int i = 0; i < (STREAM ? 1 : D); i++) load_step(i);
 
     // phase 3
     float v[V];
@@ -598,6 +612,10 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_segment_kernel(const Trai
 #pragma unroll
     for (int i = 0; i < D; i++) {
         const bool valid = head[i] != kNone;
+        if (STREAM && i + 1 < D) load_step(i + 1);  // the next step's rows travel while this step computes
+        float(&vl)[V] = vl_[i % NB];
+        float(&cn)[V] = cn_[i % NB];
+        float(&cp)[V] = cp_[i % NB];
         // position in the chain of this step: 0 = nothing to wait for in this step (a run start, or lane group 0, whose
         // predecessor finished in the step before), d = d lane groups of this step come first
         int depth = 0;
@@ -617,33 +635,33 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_segment_kernel(const Trai
             {
                 float partial = 0;
 #pragma unroll
-                for (int x = 0; x < V; x++) partial += v[x] * cn[i][x];
+                for (int x = 0; x < V; x++) partial += v[x] * cn[x];
                 const float prob = sigmoidf(group_sum<G>(partial));
                 if (LOSS) sample_loss += a.neg_weight * -logf(1 - prob + kEpsilon);
                 float m1 = 0, m2 = 0;
 #pragma unroll
                 for (int x = 0; x < V; x++) {
-                    const float vi = v[x], ci = cn[i][x];
+                    const float vi = v[x], ci = cn[x];
                     v[x] -= update<GVK_SGD>(a, vi, prob * ci, a.neg_weight, m1, m2);
-                    cn[i][x] -= update<GVK_SGD>(a, ci, prob * vi, a.neg_weight, m1, m2);
+                    cn[x] -= update<GVK_SGD>(a, ci, prob * vi, a.neg_weight, m1, m2);
                 }
-                store_row<DIM, G>(a.context, neg[i], lane, cn[i]);
-                if (neg[i] == tail[i]) copy_row(cp[i], cn[i]);  // the pair sees its own update
+                store_row<DIM, G>(a.context, neg[i], lane, cn, a.streaming_stores != 0);
+                if (neg[i] == tail[i]) copy_row(cp, cn);  // the pair sees its own update
             }
             {
                 float partial = 0;
 #pragma unroll
-                for (int x = 0; x < V; x++) partial += v[x] * cp[i][x];
+                for (int x = 0; x < V; x++) partial += v[x] * cp[x];
                 const float prob = sigmoidf(group_sum<G>(partial));
                 if (LOSS) sample_loss += -logf(prob + kEpsilon);
                 float m1 = 0, m2 = 0;
 #pragma unroll
                 for (int x = 0; x < V; x++) {
-                    const float vi = v[x], ci = cp[i][x];
+                    const float vi = v[x], ci = cp[x];
                     v[x] -= update<GVK_SGD>(a, vi, (prob - 1) * ci, 1.0f, m1, m2);
-                    cp[i][x] -= update<GVK_SGD>(a, ci, (prob - 1) * vi, 1.0f, m1, m2);
+                    cp[x] -= update<GVK_SGD>(a, ci, (prob - 1) * vi, 1.0f, m1, m2);
                 }
-                store_row<DIM, G>(a.context, tail[i], lane, cp[i]);
+                store_row<DIM, G>(a.context, tail[i], lane, cp, a.streaming_stores != 0);
             }
             if (LOSS && lane == 0)
                 __builtin_nontemporal_store(sample_loss / (1 + a.neg_weight), a.loss + base + i * NG + g);
@@ -656,7 +674,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_segment_kernel(const Trai
             for (int x = 0; x < V; x++) carried[x] = __shfl(v[x], before);
             const bool from_before = valid && cont[i] && g == 0;
             if (valid) {
-                if (from_before) copy_row(v, carried); else copy_row(v, vl[i]);
+                if (from_before) copy_row(v, carried); else copy_row(v, vl);
             }
             float start[V];
             copy_row(start, v);
@@ -694,7 +712,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_segment_kernel(const Trai
                     if (mine && cont[i]) copy_row(v, vin);
                 }
                 if (mine) {
-                    if (!cont[i]) copy_row(v, vl[i]);
+                    if (!cont[i]) copy_row(v, vl);
                     train_pair();
                     if (last[i]) store_row<DIM, G>(a.vertex, head[i], lane, v);
                 }
@@ -834,21 +852,17 @@ __device__ __forceinline__ bool has_neighbor(const gvk_walk_graph &g, uint32_t x
 
 constexpr int kMaxAugmentation = 16;
 
-__global__ void __launch_bounds__(kBlock) sample_walks_kernel(const gvk_walk_graph g, uint64_t seed, uint64_t first_walk,
-                                                              u32x2 *pool, size_t pool_pairs, int L, int aug,
-                                                              uint64_t pairs_per_walk, uint64_t sb, uint64_t num_walks) {
-    const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (t >= num_walks) return;
-    const uint64_t walk = first_walk + t;
+// One walk = one thread: chains of at most L steps, restarted from a fresh edge until the walk has produced `quota`
+// pairs; emit(head vertex, tail vertex) receives every pair (chain[j - k], chain[j]), k = 1 .. min(aug, j), in order.
+template <class Emit>
+__device__ __forceinline__ void walk_pairs(const gvk_walk_graph &g, uint64_t seed, uint64_t walk, uint64_t quota, int L,
+                                           int aug, Emit emit) {
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    const uint64_t begin = t * pairs_per_walk;
-    const uint64_t end = begin + pairs_per_walk < pool_pairs ? begin + pairs_per_walk : pool_pairs;
-    const uint64_t stride = pool_pairs / sb;
     const float fmax = fmaxf(1.0f, fmaxf(1.0f / g.p, 1.0f / g.q));
-    uint64_t offset = begin;
+    uint64_t emitted = 0;
     uint32_t draw = 0;
-    uint32_t window[kMaxAugmentation];  // rows of the last `aug` chain nodes, window[j % aug]
-    while (offset < end) {
+    uint32_t window[kMaxAugmentation];  // the last `aug` chain nodes, window[j % aug]
+    while (emitted < quota) {
         // start (or restart) a chain from a weighted random edge
         uint32_t w[4];
         philox4x32_10((uint32_t)walk, (uint32_t)(walk >> 32), draw++, kTagWalk, k0, k1, w);
@@ -857,20 +871,17 @@ __global__ void __launch_bounds__(kBlock) sample_walks_kernel(const gvk_walk_gra
         d.u = (float)(w[1] >> 8) * (1.0f / 16777216.0f);
         uint64_t edge = resolve(d, g.edge_table[d.index]);
         uint32_t previous = g.edges_uv[2 * edge], current = g.edges_uv[2 * edge + 1];
-        window[0] = g.local[previous];
+        window[0] = previous;
         int j = 1;  // index of `current` in the chain
         while (true) {
             // node j joined the chain: emit its pairs with the previous min(aug, j) nodes
-            const uint32_t row = g.local[current];
             const int back = j < aug ? j : aug;
-            for (int k = 1; k <= back && offset < end; k++) {
-                const uint64_t slot = offset % sb * stride + offset / sb;
-                u32x2 record = {row, window[(j - k) % aug]};
-                __builtin_nontemporal_store(record, pool + slot);
-                offset++;
+            for (int k = 1; k <= back && emitted < quota; k++) {
+                emit(window[(j - k) % aug], current, emitted);
+                emitted++;
             }
-            window[j % aug] = row;
-            if (j == L || offset >= end) break;
+            window[j % aug] = current;
+            if (j == L || emitted >= quota) break;
             const uint64_t base = g.flat_offsets[current], degree = g.flat_offsets[current + 1] - base;
             if (degree == 0) break;  // dead end: the chain stops here (graph.cuh:346-349,421-424)
             uint32_t next;
@@ -889,6 +900,52 @@ __global__ void __launch_bounds__(kBlock) sample_walks_kernel(const gvk_walk_gra
             j++;
         }
     }
+}
+
+__global__ void __launch_bounds__(kBlock) sample_walks_kernel(const gvk_walk_graph g, uint64_t seed, uint64_t first_walk,
+                                                              u32x2 *pool, size_t pool_pairs, int L, int aug,
+                                                              uint64_t pairs_per_walk, uint64_t sb, uint64_t num_walks) {
+    const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= num_walks) return;
+    const uint64_t begin = t * pairs_per_walk;
+    const uint64_t end = begin + pairs_per_walk < pool_pairs ? begin + pairs_per_walk : pool_pairs;
+    const uint64_t stride = pool_pairs / sb;
+    walk_pairs(g, seed, first_walk + t, end - begin, L, aug, [&](uint32_t head, uint32_t tail, uint64_t i) {
+        const uint64_t offset = begin + i, slot = offset % sb * stride + offset / sb;
+        u32x2 record = {g.local[tail], g.local[head]};
+        __builtin_nontemporal_store(record, pool + slot);
+    });
+}
+
+// Random walks for SEVERAL partitions: a walk yields pairs for every (head partition, tail partition) block, so every
+// pair is binned — block b = part[head] * P + part[tail], slot = atomic counter of b — into the pool of its block
+// (GraphSampler::sample_random_walk's per-block pools, graph.cuh:357-373, filled by GPU threads instead of CPU
+// threads).  Pairs for a block whose pool is full, or which this call does not collect, are dropped, as the reference
+// drops them (solver.h:1045-1052).  counters[b] keeps counting past the capacity, so the caller sees each block's share.
+struct BlockPools {
+    u32x2 *pools;
+    const uint64_t *offsets;  // [P * P] first pair of the block's pool, or ~0: not collected
+    uint32_t *counters;       // [P * P]
+    const int32_t *part;      // [num_vertex]
+    uint32_t capacity, sb;
+    int P;
+};
+
+__global__ void __launch_bounds__(kBlock) sample_walks_blocks_kernel(const gvk_walk_graph g, const BlockPools b, uint64_t seed,
+                                                                     uint64_t first_walk, int L, int aug, uint64_t pairs_per_walk,
+                                                                     uint64_t num_walks) {
+    const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= num_walks) return;
+    const uint32_t stride = b.capacity / b.sb;
+    walk_pairs(g, seed, first_walk + t, pairs_per_walk, L, aug, [&](uint32_t head, uint32_t tail, uint64_t) {
+        const int block = b.part[head] * b.P + b.part[tail];
+        const uint64_t first = b.offsets[block];
+        if (first == ~(uint64_t)0) return;
+        const uint32_t slot = atomicAdd(b.counters + block, 1u);
+        if (slot >= b.capacity) return;
+        u32x2 record = {g.local[tail], g.local[head]};
+        __builtin_nontemporal_store(record, b.pools + first + (slot % b.sb * stride + slot / b.sb));
+    });
 }
 
 // ---- dispatch ----------------------------------------------------------------------------------------------
@@ -996,17 +1053,16 @@ struct Choice {
     bool runs = false, fixed_k = false, reference_shape = false;
 };
 
-// pairs per lane group and wavefront of train_segment_kernel (D): what measured best per dim
-int default_steps(int dim) {
-    switch (dim) {
-        case 32: return 4;
-        case 64: return 4;
-        case 96: return 2;
-        case 128: return 2;
-        case 256: return 1;
-        case 512: return 1;
-    }
-    return 0;
+// Pairs per lane group and wavefront of train_segment_kernel (D).  One step (a segment of 64 / lanes pairs) is the
+// fastest shape at every dim.  Tables of less than 16 MiB — a BlogCatalog-sized graph — are cache-resident
+// and every batch touches every hub row hundreds of times: there the longest segment the registers allow is used, so
+// that up to 16 consecutive updates of a row survive per wavefront; that is what keeps link-prediction AUC within
+// 0.002 of sequential training on such graphs, and at that size the kernel time does not matter.
+constexpr size_t kResidentTableBytes = (size_t)16 << 20;
+
+int default_steps(int dim, uint32_t rows) {
+    if ((size_t)rows * dim * 4 >= kResidentTableBytes) return 1;
+    return dim <= 128 ? 4 : (dim == 256 ? 2 : 1);
 }
 
 // D pairs per lane group keep 3 * D rows of DIM / G floats in registers; past 128 VGPRs per lane the kernel is
@@ -1014,6 +1070,18 @@ int default_steps(int dim) {
 template <int DIM, int G, int D>
 constexpr int segment_waves() {
     return DIM / G * (3 * D + 2) + 40 <= 128 ? 4 : 2;
+}
+
+// A/B build: rows one step ahead (two buffers of 3 rows) + the headers of D steps
+template <int DIM, int G, int D>
+TrainKernel stream_build(bool loss) {
+    constexpr int need = DIM / G * 8 + 8 * D + 48;
+    if constexpr (need > 256) {
+        return nullptr;
+    } else {
+        constexpr int W = need <= 128 ? 4 : (need <= 168 ? 3 : 2);
+        return loss ? train_segment_kernel<DIM, G, D, 1, W, 0, 1, 1> : train_segment_kernel<DIM, G, D, 1, W, 0, 0, 1>;
+    }
 }
 
 template <int DIM, int G, int D>
@@ -1031,6 +1099,14 @@ TrainKernel segment_build(bool draw, bool sum, bool loss) {
 
 template <int DIM, int G>
 TrainKernel pick_segment(int steps, bool draw, bool sum, bool loss) {
+    if (g_segment_stream && draw && !sum) {
+        switch (steps) {
+            case 2: return stream_build<DIM, G, 2>(loss);
+            case 4: return stream_build<DIM, G, 4>(loss);
+            case 8: return stream_build<DIM, G, 8>(loss);
+        }
+        return nullptr;
+    }
     switch (steps) {
         case 1: return segment_build<DIM, G, 1>(draw, sum, loss);
         case 2: return segment_build<DIM, G, 2>(draw, sum, loss);
@@ -1040,7 +1116,8 @@ TrainKernel pick_segment(int steps, bool draw, bool sum, bool loss) {
 }
 
 // want_loss = false: the caller promises that nobody can read this batch's loss (a later batch overwrites it)
-Choice choose_train(int dim, int opt, int k, bool explicit_negatives, int batch_size, bool want_loss = true) {
+Choice choose_train(int dim, int opt, int k, bool explicit_negatives, int batch_size, uint32_t rows,
+                    bool want_loss = true) {
     Choice c;
     if (g_variant == 3 && dim == 128 && opt == GVK_SGD) {  // the reference's launch shape, graph.cuh:487-490
         c.reference_shape = true;
@@ -1054,7 +1131,7 @@ Choice choose_train(int dim, int opt, int k, bool explicit_negatives, int batch_
     // SGD with one negative (every shipped configuration of the reference) on the default lane layout: a wavefront
     // owns a segment (train_segment_kernel).  GVK_TUNE_VARIANT 1, 2 and 4 select the other builds for A/B.
     if (shipped_shape && g_variant == 0 && g_generation == 0) {
-        c.steps = g_segment_steps ? g_segment_steps : default_steps(dim);
+        c.steps = g_segment_steps ? g_segment_steps : default_steps(dim, rows);
 #define GVK_SEGMENT(D, GG) \
     case D: c.kernel = pick_segment<D, GG>(c.steps, draw, g_segment_sum != 0, want_loss || !g_skip_loss); break;
         switch (dim) {
@@ -1090,7 +1167,7 @@ Choice choose_train(int dim, int opt, int k, bool explicit_negatives, int batch_
 int launch_train(hipStream_t stream, int dim, const gvk_optimizer *o, float lr, const gvk_tables *t,
                  const uint32_t *pairs, const gvk_negative_source *neg, uint32_t batch_id, float *loss,
                  int batch_size, int k, float negative_weight, bool want_loss = true) {
-    const Choice c = choose_train(dim, o->type, k, neg->negatives != nullptr, batch_size, want_loss);
+    const Choice c = choose_train(dim, o->type, k, neg->negatives != nullptr, batch_size, t->n_vertex, want_loss);
     TrainArgs a;
     memset(&a, 0, sizeof(a));
     a.vertex = t->vertex; a.context = t->context;
@@ -1098,7 +1175,7 @@ int launch_train(hipStream_t stream, int dim, const gvk_optimizer *o, float lr, 
     a.vm2 = t->vertex_moment2; a.cm2 = t->context_moment2;
     a.pairs = pairs; a.negatives = neg->negatives; a.table = neg->table; a.loss = loss;
     a.seed = neg->seed; a.count = neg->count; a.batch_id = batch_id;
-    a.batch_size = batch_size; a.k = k; a.run_cap = c.run_cap;
+    a.batch_size = batch_size; a.k = k; a.run_cap = c.run_cap; a.streaming_stores = g_streaming_stores;
     a.lr = lr; a.wd = o->weight_decay; a.neg_weight = negative_weight;
     a.hp0 = o->hp0; a.hp1 = o->hp1; a.eps = o->epsilon;
     if (c.reference_shape) {
@@ -1247,20 +1324,49 @@ int gvk_sample_walks(void *stream, const gvk_walk_graph *graph, uint64_t seed, u
     return check_launch("gvk_sample_walks");
 }
 
+int gvk_sample_walks_blocks(void *stream, const gvk_walk_graph *graph, const int32_t *part, int num_partition, uint64_t seed,
+                            uint64_t first_walk, uint64_t num_walks, uint32_t *pools, const uint64_t *offsets,
+                            uint32_t *counters, uint32_t capacity, int walk_length, int augmentation_step, int shuffle_base) {
+    if (num_walks == 0) return GVK_OK;
+    if (!graph || !part || !pools || !offsets || !counters) return fail(GVK_EINVAL, "gvk_sample_walks_blocks: null pointer");
+    if (!graph->flat_offsets || !graph->edges_uv || !graph->edge_table || !graph->neighbor_table || !graph->local ||
+        !graph->num_edge_entries)
+        return fail(GVK_EINVAL, "gvk_sample_walks_blocks: incomplete graph description");
+    if (graph->biased && (!graph->sorted_neighbors || !(graph->p > 0) || !(graph->q > 0)))
+        return fail(GVK_EINVAL, "gvk_sample_walks_blocks: node2vec needs sorted_neighbors and positive p, q");
+    if (num_partition < 1 || capacity == 0) return fail(GVK_EINVAL, "gvk_sample_walks_blocks: no partitions / empty pools");
+    if (augmentation_step < 1 || augmentation_step > kMaxAugmentation)
+        return fail(GVK_EINVAL, "gvk_sample_walks_blocks: augmentation_step must be in [1, 16]");
+    if (augmentation_step > walk_length)
+        return fail(GVK_EINVAL, "`random_walk_length` should be no less than `augmentation_step`");
+    if (shuffle_base < 1 || capacity % (uint32_t)shuffle_base)
+        return fail(GVK_EINVAL, "gvk_sample_walks_blocks: pool size must be a multiple of the shuffle base");
+    const uint64_t per_walk = (uint64_t)augmentation_step * walk_length -
+                              (uint64_t)augmentation_step * (augmentation_step - 1) / 2;
+    const uint64_t blocks = (num_walks + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffu) return fail(GVK_EINVAL, "gvk_sample_walks_blocks: too many walks for one call");
+    BlockPools b;
+    b.pools = reinterpret_cast<u32x2 *>(pools), b.offsets = offsets, b.counters = counters, b.part = part;
+    b.capacity = capacity, b.sb = (uint32_t)shuffle_base, b.P = num_partition;
+    hipLaunchKernelGGL(sample_walks_blocks_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, *graph, b, seed,
+                       first_walk, walk_length, augmentation_step, per_walk, num_walks);
+    return check_launch("gvk_sample_walks_blocks");
+}
+
 int gvk_describe_train(int dim, int optimizer_type, int num_negative, int explicit_negatives, int batch_size,
-                       char *name, size_t capacity) {
+                       uint32_t n_vertex, char *name, size_t capacity) {
     if (!default_lanes(dim)) return fail(GVK_EDIM, "gvk_describe_train: dim must be one of 32, 64, 96, 128, 256, 512");
     if (optimizer_type < GVK_SGD || optimizer_type > GVK_ADAM || !name || !capacity)
         return fail(GVK_EINVAL, "gvk_describe_train: unknown optimizer type or no buffer");
     static const char *const kOptimizers[] = {"SGD", "Momentum", "AdaGrad", "RMSprop", "Adam"};
-    const Choice c = choose_train(dim, optimizer_type, num_negative, explicit_negatives != 0, batch_size);
+    const Choice c = choose_train(dim, optimizer_type, num_negative, explicit_negatives != 0, batch_size, n_vertex);
     if (c.reference_shape)
         snprintf(name, capacity, "train_kernel_reference_shape<%d> grid 8192x512", dim);
     else if (!c.kernel)
         return fail(GVK_EINVAL, "gvk_describe_train: no kernel for this (dim, lanes, optimizer)");
     else if (c.steps > 0)
         snprintf(name, capacity, "train_segment_kernel<%d,%d,SGD,k=1> %d pairs per wavefront%s", dim, c.lanes,
-                 64 / c.lanes * c.steps, g_segment_sum ? ", run changes added up" : "");
+                 64 / c.lanes * c.steps, g_segment_sum ? ", run changes added up" : (g_segment_stream ? ", rows one step ahead" : ""));
     else
         snprintf(name, capacity, "%s<%d,%d,%s%s> run_cap %d%s", c.runs ? "train_runs_kernel" : "train_kernel", dim, c.lanes,
                  kOptimizers[optimizer_type], c.fixed_k ? ",k=1" : "", c.run_cap,
@@ -1281,14 +1387,17 @@ int gvk_set_tuning(int key, int value) {
         return GVK_OK;
     }
     if (key == GVK_TUNE_SEGMENT_STEPS) {
-        if (value != 0 && value != 1 && value != 2 && value != 4)
-            return fail(GVK_EINVAL, "gvk_set_tuning: segment steps must be 0, 1, 2 or 4");
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
+            return fail(GVK_EINVAL, "gvk_set_tuning: segment steps must be 0, 1, 2, 4 or (streamed rows) 8");
         g_segment_steps = value;
         return GVK_OK;
     }
-    if (key == GVK_TUNE_SEGMENT_SUM || key == GVK_TUNE_SKIP_LOSS) {
+    if (key == GVK_TUNE_SEGMENT_SUM || key == GVK_TUNE_SKIP_LOSS || key == GVK_TUNE_SEGMENT_STREAM ||
+        key == GVK_TUNE_STREAMING_STORES) {
         if (value != 0 && value != 1) return fail(GVK_EINVAL, "gvk_set_tuning: flag must be 0 or 1");
-        (key == GVK_TUNE_SEGMENT_SUM ? g_segment_sum : g_skip_loss) = value;
+        int &flag = key == GVK_TUNE_SEGMENT_SUM ? g_segment_sum : (key == GVK_TUNE_SKIP_LOSS ? g_skip_loss :
+                    (key == GVK_TUNE_SEGMENT_STREAM ? g_segment_stream : g_streaming_stores));
+        flag = value;
         return GVK_OK;
     }
     if (key == GVK_TUNE_GENERATION) {

@@ -96,6 +96,11 @@ int cpu_budget() {
     return std::max(1u, n);
 }
 
+struct Range {  // roctx range around a host phase (gvk_range_push / _pop): the reference's Timer scopes, time.h:28-60
+    explicit Range(const char *name) { gvk_range_push(name); }
+    ~Range() { gvk_range_pop(); }
+};
+
 #define HIP_TRY(call)                                                                          \
     do {                                                                                       \
         hipError_t e_ = (call);                                                                \
@@ -604,6 +609,7 @@ int gvx_solver::write_back() {  // WorkerMixin::write_back, solver.h:1498-1504: 
 // ---- episode loop ---------------------------------------------------------------------------------------------------
 
 int gvx_solver::fill(std::vector<uint32_t *> &pools) {
+    Range range("Sample threads");  // solver.h:622
     gvs_fill_config f{};
     f.mode = mode;
     f.num_thread = 4 * num_sampler;  // 4 slices per OS thread: a descheduled thread delays a quarter-size slice
@@ -617,6 +623,7 @@ int gvx_solver::fill(std::vector<uint32_t *> &pools) {
 // WorkerMixin::train (solver.h:1511-1522): positive_reuse x episode_size batches of one block on the worker's compute
 // stream; batch ids interleave over the workers as the reference's shared atomic counter hands them out (solver.h:1520)
 int gvx_solver::train_block(Worker &w, int hp, int tp, uint32_t *pool) {
+    Range range("Train Batch");  // solver.h:1526 (one range per block: its batches are back-to-back launches)
     const int W = num_worker, r = (int)(&w - workers.data()), B = batch_size, nm = num_moment;
     const int ti = (int)(std::find(w.tails.begin(), w.tails.end(), tp) - w.tails.begin());
     gvk_tables t{};
@@ -682,7 +689,10 @@ int gvx_solver::episode_loop() {
                                 size_string((double)pool_elems * 4).c_str());
             }
     }
-    const bool grouped = mode == GVS_MODE_EDGE && (size_t)part_rows * dim * 4 >= ((size_t)16 << 20) && dim >= 64;
+    // regroup independent edge draws when the tables are too large for the caches, and everything when they are
+    // cache-resident (runs of same-head samples are then trained in sequence: DESIGN.md §3.1.1, §7); not at dim 32
+    const bool big = (size_t)part_rows * dim * 4 >= ((size_t)16 << 20);
+    const bool grouped = dim >= 64 && (!big || mode == GVS_MODE_EDGE);
     const int row_bits = std::max(32 - __builtin_clz(std::max(part_rows, 2u) - 1), 1);
     const uint64_t per_episode = (uint64_t)num_step * episode_size * config.positive_reuse * W;
     int rc = fill(sets[0]);
@@ -701,6 +711,7 @@ int gvx_solver::episode_loop() {
         if (batch_id + per_episode < num_batch)  // no pools for an episode that will not run
             filler = std::thread([&, current]() { fill_rc = fill(sets[current ^ 1]); });
         auto stage = [&](Worker &w, int step) -> int {  // H2D copy (+ regrouping) of the worker's block of `step`
+            Range upload_range("Upload");
             const int r = (int)(&w - workers.data());
             const int hp = schedule[((size_t)step * W + r) * 2], tp = schedule[((size_t)step * W + r) * 2 + 1];
             const int b = (int)((w.visits + (uint64_t)step) & 1);
@@ -712,6 +723,7 @@ int gvx_solver::episode_loop() {
             HIP_TRY(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(copied, w.copy));
             w.copied.push_back(copied);
+            Range regroup("Regroup");
             if (grouped)
                 GVK_TRY(gvk_group_pairs(w.copy, w.landing, w.pool[b], w.group_workspace, &w.group_workspace_bytes, batch_size,
                                         episode_size, row_bits));
@@ -739,6 +751,7 @@ int gvx_solver::episode_loop() {
                 hipEventRecord(w.trained, w.compute);
             }
             // exchange: the head shard a worker just trained goes straight into every other worker's replica
+            Range exchange_range("Exchange");
             for (int r = 0; r < W && rc == GVK_OK && W > 1; r++) {
                 Worker &w = workers[r];
                 const int hp = schedule[((size_t)step * W + r) * 2];
@@ -747,8 +760,11 @@ int gvx_solver::episode_loop() {
                 for (int q = 0; q < W; q++) {
                     if (q == r) continue;
                     Worker &u = workers[q];
-                    hipError_t e = hipMemcpyPeerAsync(head_table(u, hp, 0), u.device, head_table(w, hp, 0), w.device,
-                                                      slot_floats() * 4, w.exchange);
+                    hipError_t e = u.device == w.device  // two workers sharing a GPU (tests): a plain device copy
+                                       ? hipMemcpyAsync(head_table(u, hp, 0), head_table(w, hp, 0), slot_floats() * 4,
+                                                        hipMemcpyDeviceToDevice, w.exchange)
+                                       : hipMemcpyPeerAsync(head_table(u, hp, 0), u.device, head_table(w, hp, 0), w.device,
+                                                            slot_floats() * 4, w.exchange);
                     if (e != hipSuccess) rc = gvk_fail(GVK_EHIP, "exchange of head partition %d: %s", hp, hipGetErrorString(e));
                     hipEvent_t arrived;
                     hipEventCreateWithFlags(&arrived, hipEventDisableTiming);
@@ -759,7 +775,10 @@ int gvx_solver::episode_loop() {
             batch_id += (uint64_t)episode_size * config.positive_reuse * W;
         }
         for (Worker &w : workers) w.visits += (uint64_t)num_step;
-        if (filler.joinable()) filler.join();
+        {
+            Range wait("Wait for sample threads");  // solver.h:645
+            if (filler.joinable()) filler.join();
+        }
         if (rc == GVK_OK) rc = fill_rc;
         current ^= 1;
     }

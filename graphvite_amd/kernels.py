@@ -201,27 +201,72 @@ class HipKernels(object):
         packed alias entries), local (int32), optional sorted_neighbors (int32), plus biased / p / q."""
         g = walk_graph
         dev = g["edges_uv"].device
+        desc = self._walk_graph(g, dev)
+        _need(pool, torch.int32, "pool", dev)
+        if pool.numel() < 2 * pool_pairs:
+            raise ValueError("pool too small")
+        rc = self.lib.gvk_sample_walks(self._stream(pool), C.byref(desc), seed, first_walk, _ptr(pool), pool_pairs,
+                                       walk_length, augmentation_step, shuffle_base)
+        _lib.check(rc, "gvk_sample_walks")
+
+    @staticmethod
+    def _walk_graph(g, dev):
         _need(g["flat_offsets"], torch.int64, "flat_offsets", dev)
         _need(g["edges_uv"], torch.int32, "edges_uv", dev)
         _need(g["edge_table"], torch.int64, "edge_table", dev)
         _need(g["neighbor_table"], torch.int64, "neighbor_table", dev)
         _need(g["local"], torch.int32, "local", dev)
-        _need(pool, torch.int32, "pool", dev)
         biased = bool(g.get("biased", False))
         snb = g.get("sorted_neighbors")
         if biased:
             _need(snb, torch.int32, "sorted_neighbors", dev)
-        if pool.numel() < 2 * pool_pairs:
-            raise ValueError("pool too small")
         D = g["edge_table"].numel()
         if g["edges_uv"].numel() != 2 * D or g["neighbor_table"].numel() != D:
             raise ValueError("edge arrays / tables disagree in size")
-        desc = _lib.WalkGraph(_ptr(g["flat_offsets"]), _ptr(g["edges_uv"]), _ptr(g["edge_table"]),
+        return _lib.WalkGraph(_ptr(g["flat_offsets"]), _ptr(g["edges_uv"]), _ptr(g["edge_table"]),
                               _ptr(g["neighbor_table"]), _ptr(snb), _ptr(g["local"]), g["local"].numel(), D, int(biased),
                               float(g.get("p", 1.0)), float(g.get("q", 1.0)))
-        rc = self.lib.gvk_sample_walks(self._stream(pool), C.byref(desc), seed, first_walk, _ptr(pool), pool_pairs,
-                                       walk_length, augmentation_step, shuffle_base)
-        _lib.check(rc, "gvk_sample_walks")
+
+    def sample_walks_blocks(self, walk_graph, part, num_partition, seed, first_walk, pools, offsets, capacity, walk_length,
+                            augmentation_step, shuffle_base, max_rounds=64):
+        """Random-walk positives for SEVERAL partitions, drawn on the device (gvk_sample_walks_blocks): fills the pool
+        of every block b with offsets[b] >= 0 — `capacity` {tail, head} records at pools[2 * offsets[b]:] — repeating
+        the call until all of them are full.  part: int32 [num_vertex]; offsets: int64 [P * P] on the device (-1 = block
+        not collected).  The first round assumes equal block shares; later rounds are sized from the shares the counters
+        show.  Returns the number of walks consumed (the caller advances first_walk by it)."""
+        g = walk_graph
+        dev = g["edges_uv"].device
+        desc = self._walk_graph(g, dev)
+        _need(part, torch.int32, "part", dev)
+        _need(pools, torch.int32, "pools", dev)
+        _need(offsets, torch.int64, "offsets", dev)
+        P = int(num_partition)
+        if offsets.numel() != P * P or part.numel() != g["local"].numel():
+            raise ValueError("offsets must hold P * P entries and part one entry per vertex")
+        wanted = (offsets >= 0).cpu().numpy()
+        if not wanted.any():
+            return 0
+        aug, L = int(augmentation_step), int(walk_length)
+        per_walk = aug * L - aug * (aug - 1) // 2
+        counters = torch.zeros(P * P, dtype=torch.int32, device=dev)
+        walks = -(-capacity * P * P // per_walk)
+        used = 0
+        for _ in range(max_rounds):
+            rc = self.lib.gvk_sample_walks_blocks(self._stream(pools), C.byref(desc), _ptr(part), P, seed, first_walk + used,
+                                                  walks, _ptr(pools), _ptr(offsets), _ptr(counters), capacity, L, aug,
+                                                  shuffle_base)
+            _lib.check(rc, "gvk_sample_walks_blocks")
+            used += walks
+            count = counters.cpu().numpy().astype(np.int64)  # fences the stream: a handful of round trips per episode
+            deficit = np.maximum(capacity - count, 0)[wanted]
+            if not deficit.any():
+                return used
+            share = count[wanted] / float(used * per_walk)  # fraction of all pairs that fall into each wanted block
+            if (share[deficit > 0] == 0).any() and used * per_walk > 64 * capacity * P * P:
+                raise ValueError("a block of the partition grid receives no random-walk pairs; use fewer partitions")
+            need = deficit[deficit > 0] / np.maximum(share[deficit > 0], 1.0 / (64 * P * P)) / per_walk
+            walks = int(need.max() * 1.05) + 64
+        raise RuntimeError("gvk_sample_walks_blocks: pools not full after %d rounds" % max_rounds)
 
     def set_lanes_per_pair(self, lanes):
         _lib.check(self.lib.gvk_set_tuning(_lib.TUNE_LANES_PER_PAIR, lanes), "gvk_set_tuning")
@@ -245,10 +290,12 @@ class HipKernels(object):
         """Parity experiment: train every batch as consecutive launches of at most `samples` samples (0 = off)."""
         _lib.check(self.lib.gvk_set_tuning(_lib.TUNE_GENERATION, samples), "gvk_set_tuning")
 
-    def describe_train(self, dim, optimizer_type="SGD", num_negative=1, explicit_negatives=False, batch_size=100000):
-        """Name of the kernel gvk_train launches for this configuration under the current tuning."""
+    def describe_train(self, dim, optimizer_type="SGD", num_negative=1, explicit_negatives=False, batch_size=100000,
+                       num_row=1 << 20):
+        """Name of the kernel gvk_train launches for this configuration (num_row rows in the head table) under the
+        current tuning."""
         name = C.create_string_buffer(160)
         _lib.check(self.lib.gvk_describe_train(dim, OPTIMIZER_TYPES[optimizer_type], num_negative,
-                                               int(explicit_negatives), batch_size, name, len(name)),
+                                               int(explicit_negatives), batch_size, num_row, name, len(name)),
                    "gvk_describe_train")
         return name.value.decode()

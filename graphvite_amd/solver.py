@@ -25,6 +25,7 @@ import numpy as np
 import torch
 
 from . import _lib, hostlib
+from ._lib import profiler_range
 from .base import MiB, auto, cpu_budget, dtype, io, logger
 from .graph import Graph
 from .optimizer import SGD, Optimizer
@@ -152,10 +153,10 @@ class GraphSolver(object):
     Beyond the reference's arguments: `kernels` (test seam), `seed`, `device_sampling` (draw the positive samples on
     the GPU) and `pair_order` — "sampled": a batch is trained in the order the samplers produced it; "grouped": the
     pairs of a batch that share a head row are made adjacent on the device first (gvk_group_pairs; same samples, same
-    batches — the order inside a batch has no meaning to a kernel that processes the batch concurrently — but a row
-    shared by k samples is fetched from HBM once); auto (default): grouped for independent edge draws (LINE,
-    augmentation_step 1) when a partition's table is too large for the caches to do that by themselves (>= 16 MiB)
-    and dim >= 64, sampled otherwise.
+    batches; a row shared by k samples is fetched from HBM once and the k samples are trained as runs, one after the
+    other on one copy of the row); auto (default): grouped at dim >= 64 for independent edge draws (LINE,
+    augmentation_step 1) and for every model when a partition's table is cache-resident (< 16 MiB), sampled
+    otherwise.
     """
 
     available_dims = (32, 64, 96, 128, 256, 512)  # src/graphvite.cu:52-59
@@ -383,9 +384,6 @@ class GraphSolver(object):
         t1 = time.time()
         state = self._upload_state()
         if self.device_sampling:
-            if self._mode != "edge" and self.num_partition != 1:
-                raise ValueError("device_sampling of random walks needs a single partition (one GPU); with several "
-                                 "GPUs the random-walk models use the CPU samplers")
             if self._mode == "edge":
                 self._upload_block_tables(state)
             else:
@@ -418,12 +416,13 @@ class GraphSolver(object):
                 raise
             report()
 
-        if self.device_sampling:
+        walks_over_blocks = self._mode != "edge" and self.num_partition > 1
+        if self.device_sampling and not walks_over_blocks:
             def loop():
                 while self.batch_id < self.num_batch:
                     self._train_episode_device_sampling(state)
             return guarded(loop)
-        if self.num_worker > 1 and self._mode != "edge":
+        if walks_over_blocks and (self.num_worker > 1 or self.device_sampling):
             return guarded(lambda: self._train_routed(state))
         per_episode = len(self._schedule) * self.episode_size * self.positive_reuse * self.num_worker
         pools = self._host_pools()
@@ -451,7 +450,8 @@ class GraphSolver(object):
                 finally:
                     tc = time.time()
                     if filler is not None:
-                        filler.join()
+                        with profiler_range("Wait for sample threads"):  # solver.h:645
+                            filler.join()
                 td = time.time()
                 self._loop_timing["wait_upload"] += tb - ta
                 self._loop_timing["enqueue"] += tc - tb
@@ -525,13 +525,19 @@ class GraphSolver(object):
                 mode = "biased_reject"
         self._mode = mode
         if self._pair_order_request == auto:
-            # Regroup (gvk_group_pairs) where it was measured to pay: independent edge draws (random-walk pools come in
-            # the reference's pseudo-shuffled walk order, which already has locality: DeepWalk end to end -16 % when
-            # regrouped), tables too large to stay cache-resident, and not dim 32 (a batch trains in 16 us there; the
-            # pass, which costs the same at every dim, would take a third of the GPU).
-            big = self._part_size * self.dim * 4 >= MiB(16) and self.dim >= 64
-            self.pair_order = "grouped" if big and mode == "edge" and self.device.type == "cuda" else "sampled"
-        if self.device_sampling and (mode == "edge" or self.num_partition == 1):
+            # Regroup (gvk_group_pairs) in two regimes:
+            #   * tables too large for the caches (>= 16 MiB) and independent edge draws: a head row shared by several
+            #     samples of a batch crosses HBM once (random-walk pools come in the reference's pseudo-shuffled walk
+            #     order, which already has locality: DeepWalk end to end -16 % when regrouped);
+            #   * cache-resident tables (a BlogCatalog-sized graph): every batch hits every hub row hundreds of times;
+            #     adjacent same-head samples are trained as runs of up to 16 consecutive updates per wavefront, which
+            #     keeps link-prediction AUC within 0.002 of sequential training, and the pass costs nothing that matters.
+            # Not at dim 32: a batch trains in 16 us there and the pass, which costs the same at every dim, would take a
+            # third of the GPU.
+            big = self._part_size * self.dim * 4 >= MiB(16)
+            regroup = self.dim >= 64 and self.device.type == "cuda" and (not big or mode == "edge")
+            self.pair_order = "grouped" if regroup else "sampled"
+        if self.device_sampling:
             return  # positives are drawn on the device: no CPU sampler needed
         if self._sampler is None:
             self._sampler = hostlib.Sampler(self.graph, self._part, self._local, self.num_partition,
@@ -651,6 +657,10 @@ class GraphSolver(object):
 
     # ---- sampling -----------------------------------------------------------------------------------------
     def _fill(self, pools):
+        with profiler_range("Sample threads"):  # solver.h:622
+            self._fill_pools(pools)
+
+    def _fill_pools(self, pools):
         P = self.num_partition
         tails = {tp for (_, tp) in pools}
         pool_size = self.episode_size * self.batch_size
@@ -679,10 +689,13 @@ class GraphSolver(object):
 
     # ---- several GPUs, random-walk models: every rank samples a slice of EVERY block, pairs are routed ------------
     def _train_routed(self, state):
-        """A walk yields pairs for all P^2 blocks, so with W ranks each rank's samplers fill the 1/W-th slice of every
-        block pool (no pair is thrown away for belonging to another GPU, unlike a per-column filter), the slices are
-        uploaded and one all-to-all hands every block's W slices to the GPU that trains it.  Pipeline per episode:
-        CPU fill (e + 1) || copy stream + RCCL: H2D, all_to_all, un-interleave (e) || compute stream: train (e - 1)."""
+        """A walk yields pairs for all P^2 blocks, so with W ranks each rank samples the 1/W-th slice of every block pool
+        (no pair is thrown away for belonging to another GPU, unlike a per-column filter) and one all-to-all hands every
+        block's W slices to the GPU that trains it.  The slices come from this rank's CPU samplers — pipeline per episode:
+        CPU fill (e + 1) || copy stream + RCCL: H2D, all_to_all, un-interleave (e) || compute stream: train (e - 1) — or,
+        with device_sampling, from gvk_sample_walks_blocks on the side stream (walks binned per block on the GPU, no host
+        threads, no PCIe): sample + all_to_all (e + 1) || train (e).  Also the single-GPU path of device-sampled walks
+        over several partitions (W = 1: nothing to route)."""
         import time
         import torch.distributed as dist
         W, r, P, B = self.num_worker, self.rank, self.num_partition, self.batch_size
@@ -700,12 +713,28 @@ class GraphSolver(object):
         order = [[(hp, tp) for tp in tails_of[w] for hp in range(P)] for w in range(W)]  # canonical per-owner order
         mine = {block: i for i, block in enumerate(order[r])}
         elems = n_slice * 2
-        host = [torch.empty((W, bpr, elems), dtype=torch.int32, pin_memory=cuda) for _ in range(2)]
+        on_device = self.device_sampling
+        host = None if on_device else [torch.empty((W, bpr, elems), dtype=torch.int32, pin_memory=cuda) for _ in range(2)]
         send = [torch.empty((W, bpr, elems), dtype=torch.int32, device=self.device) for _ in range(2)]
-        recv = torch.empty((W, bpr, elems), dtype=torch.int32, device=self.device)
+        recv = torch.empty((W, bpr, elems), dtype=torch.int32, device=self.device) if W > 1 else None
         pools = [torch.empty((bpr, W, elems), dtype=torch.int32, device=self.device) for _ in range(2)]
         landing = torch.empty_like(pools[0]) if self.pair_order == "grouped" else None  # regrouped into pools[s]
-        views = [{order[w][i]: host[s][w, i] for w in range(W) for i in range(bpr)} for s in range(2)]
+        views = None if on_device else [{order[w][i]: host[s][w, i] for w in range(W) for i in range(bpr)} for s in range(2)]
+        if on_device:  # block (hp, tp) of owner w at index i starts (w * bpr + i) * n_slice pairs into send[s]
+            where = np.full(P * P, -1, np.int64)
+            for w in range(W):
+                for i, (hp, tp) in enumerate(order[w]):
+                    where[hp * P + tp] = (w * bpr + i) * n_slice
+            offsets = self._to_device(where)
+            walk_seed = (self.seed * 0x9E3779B1 + 0x77616c6b + r) & (2 ** 64 - 1)
+
+        def sample(s):
+            """This rank's slice of every block pool, drawn and binned on the device into send[s] (current stream)."""
+            with profiler_range("Sample walks (device)"):
+                used = self.kernels.sample_walks_blocks(state["walk_graph"], state["walk_graph"]["part"], P, walk_seed,
+                                                        state["positive_index"], send[s].view(-1), offsets, n_slice,
+                                                        self.random_walk_length, self.augmentation_step, self.shuffle_base)
+            state["positive_index"] += used
         route_stream = torch.cuda.Stream(self.device) if cuda else None
         copied, routed, trained = [None, None], [None, None], [None, None]
 
@@ -716,23 +745,31 @@ class GraphSolver(object):
                                shuffle_base=self.shuffle_base, tail_partition=-1,
                                os_threads=self.num_sampler_per_worker)
 
+        def exchange_slices(s):
+            """send[s] [owner][block][slice] -> (all_to_all) [sampler rank][block][slice]; one rank: nothing to route."""
+            if W == 1:
+                return send[s]
+            dist.all_to_all_single(recv.view(-1), send[s].view(-1))
+            return recv
+
         def route(s):
-            """host[s] -> send[s] -> (all_to_all) recv -> pools[s], on the side stream."""
+            """host[s] -> send[s] (or sampled straight into it) -> (all_to_all) recv -> pools[s], on the side stream."""
             if not cuda:
-                send[s].copy_(host[s])
-                dist.all_to_all_single(recv.view(-1), send[s].view(-1))
-                (pools[s] if landing is None else landing).copy_(recv.permute(1, 0, 2))
+                sample(s) if on_device else send[s].copy_(host[s])
+                (pools[s] if landing is None else landing).copy_(exchange_slices(s).permute(1, 0, 2))
                 if landing is not None:
                     self._group_pairs(landing.view(-1), pools[s].view(-1))
                 return
             with torch.cuda.stream(route_stream):
                 if trained[s] is not None:
                     route_stream.wait_event(trained[s])  # pools[s] was last read by the episode two back
-                send[s].copy_(host[s], non_blocking=True)
-                copied[s] = torch.cuda.Event()
-                copied[s].record()
-                dist.all_to_all_single(recv.view(-1), send[s].view(-1))
-                (pools[s] if landing is None else landing).copy_(recv.permute(1, 0, 2))
+                if on_device:
+                    sample(s)
+                else:
+                    send[s].copy_(host[s], non_blocking=True)
+                    copied[s] = torch.cuda.Event()
+                    copied[s].record()
+                (pools[s] if landing is None else landing).copy_(exchange_slices(s).permute(1, 0, 2))
                 if landing is not None:
                     self._group_pairs(landing.view(-1), pools[s].view(-1))
                 routed[s] = torch.cuda.Event()
@@ -745,13 +782,26 @@ class GraphSolver(object):
             for i, step in enumerate(self._schedule):
                 hp, tp = int(step[r][0]), int(step[r][1])
                 self._train_block(state, hp, tp, pools[s][mine[(hp, tp)]].view(-1))
-                self._exchange(state, i)
+                if W > 1:
+                    self._exchange(state, i)
             if cuda:
                 trained[s] = torch.cuda.Event()
                 trained[s].record(compute)
 
         self._loop_timing = {"wait_upload": 0.0, "enqueue": 0.0, "wait_fill": 0.0, "fill": 0.0}
         per_episode = len(self._schedule) * self.episode_size * self.positive_reuse * W
+        if on_device:
+            # sample + route episode e + 1 while episode e trains: train(e) is enqueued first, so the host round trips of
+            # the sampling rounds (reading the block counters) happen while the GPU is busy with the kernels of e
+            route(0)
+            current = 0
+            while self.batch_id < self.num_batch:
+                more = self.batch_id + per_episode < self.num_batch
+                train(current)
+                if more:
+                    route(current ^ 1)
+                current ^= 1
+            return
         fill(0)
         current = 0
         while self.batch_id < self.num_batch:
@@ -824,7 +874,7 @@ class GraphSolver(object):
                 "edges_uv": self._to_device(edges.astype(np.uint32).view(np.int32).reshape(-1)),
                 "edge_table": packed_to_device(edge_packed, self.device),
                 "neighbor_table": packed_to_device(nb, self.device),
-                "local": self._to_device(self._local.view(np.int32)),
+                "local": self._to_device(self._local.view(np.int32)), "part": self._to_device(self._part.astype(np.int32)),
                 "biased": self._mode in ("biased_walk", "biased_reject"), "p": self.p, "q": self.q}
         if walk["biased"]:
             # ascending neighbour ids inside each vertex's CSR segment: one device sort of (u << 32 | v) keys
@@ -958,7 +1008,8 @@ class GraphSolver(object):
             return
         if num_batches is None:
             num_batches = pool.numel() // 2 // self.batch_size
-        self.kernels.group_pairs(pool, out, self.batch_size, num_batches, self._part_size)
+        with profiler_range("Regroup"):
+            self.kernels.group_pairs(pool, out, self.batch_size, num_batches, self._part_size)
 
     def _tables(self, state, hp, tp):
         ti = self._my_tails.index(tp)
@@ -999,6 +1050,10 @@ class GraphSolver(object):
 
     def _train_block(self, state, hp, tp, pool):
         """WorkerMixin::train (solver.h:1511-1522): positive_reuse x episode_size batches of one block."""
+        with profiler_range("Train Batch"):  # solver.h:1526; one range per block: its batches are back-to-back launches
+            self._train_block_batches(state, hp, tp, pool)
+
+    def _train_block_batches(self, state, hp, tp, pool):
         if self.num_worker > 1:
             self._wait_exchange(state, hp // self.num_worker)  # this block reads head group hp // W
             self._claim_slot(state, hp)
@@ -1046,7 +1101,8 @@ class GraphSolver(object):
         self._wait_exchange(state, group)
         self._claim_slot(state, heads[r])
         slab = state["head"][group * W:(group + 1) * W]
-        work = dist.all_gather_into_tensor(slab.view(-1), slab[r].view(-1), async_op=True)
+        with profiler_range("Exchange"):
+            work = dist.all_gather_into_tensor(slab.view(-1), slab[r].view(-1), async_op=True)
         state.setdefault("pending_exchange", {})[group] = [work]
         state["exchanged_bytes"] = state.get("exchanged_bytes", 0) + slab[r].numel() * 4 * (W - 1)
         state["exchanges"] = state.get("exchanges", 0) + 1

@@ -97,7 +97,8 @@ typedef struct {
  * positive step on a progressively updated copy of vertex[head]; context rows are updated in place,
  * Hogwild (no atomics), loss[s] = sample loss / (1 + num_negative * negative_weight).
  * With SGD and num_negative == 1, pairs that sit next to each other in the batch, share a head row and fall into the
- * same wavefront's segment (8 consecutive pairs at dim 128) are trained as one run — one after the other on one
+ * same wavefront's segment (4 consecutive pairs at dim 128; 16 when the head table is smaller than 16 MiB) are trained
+ * as one run — one after the other on one
  * register copy of the row, as consecutive iterations of one warp in the reference (include/instance/gpu/graph.cuh:
  * 54-94); samples keep their own negatives and loss slots.  `stream` is a hipStream_t (NULL = default stream).  `batch_id` only feeds the negative draw. */
 int gvk_train(void *stream, int dim, const gvk_optimizer *optimizer, const gvk_tables *tables,
@@ -167,6 +168,20 @@ typedef struct {
 int gvk_sample_walks(void *stream, const gvk_walk_graph *graph, uint64_t seed, uint64_t first_walk, uint32_t *pool,
                      size_t pool_pairs, int walk_length, int augmentation_step, int shuffle_base);
 
+/* The same walks for SEVERAL partitions (any number of GPUs): a walk yields pairs for every (head partition, tail
+ * partition) block, so each pair is binned into the pool of block b = part[head] * P + part[tail] — the per-block pools
+ * of GraphSampler::sample_random_walk (include/instance/graph.cuh:357-373) filled by GPU threads.  Walk w (= first_walk +
+ * thread) draws exactly as in gvk_sample_walks and produces aug * L - aug * (aug - 1) / 2 pairs.  Block b's pool is
+ * pools + 2 * offsets[b] (offsets in pairs; ~0 = this call does not collect b), capacity pairs long; a pair takes slot
+ * s = atomic increment of counters[b] and is stored at position s % sb * (capacity / sb) + s / sb; pairs beyond the
+ * capacity are dropped (solver.h:1045-1052) but still counted, so counters[] tells the caller every block's share and
+ * which pools are full.  The caller zeroes counters[] once and repeats the call (advancing first_walk) until the pools
+ * it needs are full.  Which pairs land in which slot depends on the order the GPU retires the atomics; the MULTISET of
+ * pairs of a pool that did not overflow is a pure function of (seed, walk range). */
+int gvk_sample_walks_blocks(void *stream, const gvk_walk_graph *graph, const int32_t *part, int num_partition, uint64_t seed,
+                            uint64_t first_walk, uint64_t num_walks, uint32_t *pools, const uint64_t *offsets,
+                            uint32_t *counters, uint32_t capacity, int walk_length, int augmentation_step, int shuffle_base);
+
 /* Optional pool pre-pass: inside each of the num_batch batches (batch_size {tail, head} records each) of pool_in, make
  * the records that share a head row adjacent, writing the regrouped pool to pool_out (distinct from pool_in).  Each
  * batch keeps exactly its records; their order becomes ascending in the low row_bits bits of the head row, stable
@@ -199,18 +214,27 @@ int gvk_alias_build(const float *weights, size_t n, float *prob, void *alias, in
 #define GVK_TUNE_GENERATION 4     /* parity experiment: C > 0 trains a batch as consecutive launches of at most C samples
                                      (per-pair kernel), the concurrency structure of the reference's launch on a card
                                      that keeps C warps resident; 0 = one launch per batch (default) */
-#define GVK_TUNE_SEGMENT_STEPS 5  /* train_segment_kernel: pairs per lane group and wavefront — 0 = per-dim default, 1, 2
-                                     or 4 (a wavefront then owns 64 / lanes * steps consecutive pairs) */
+#define GVK_TUNE_SEGMENT_STEPS 5  /* train_segment_kernel: pairs per lane group and wavefront (a wavefront owns 64 / lanes *
+                                     steps consecutive pairs) — 0 = default: 1 step, or the longest build (4 up to dim 128)
+                                     when the head table is smaller than 16 MiB; else 1, 2 or 4 */
 #define GVK_TUNE_SEGMENT_SUM 6    /* A/B: 1 = the pairs of a run inside a step train side by side from the same row and
                                      their changes are added up (no serialisation); 0 = chained in sequence (default) */
 #define GVK_TUNE_SKIP_LOSS 7      /* 1 (default) = gvk_train_episode does not compute the per-sample loss of batches whose
                                      loss[] a later batch of the same call overwrites; 0 = every batch computes it */
+#define GVK_TUNE_SEGMENT_STREAM 8 /* A/B: 1 = train_segment_kernel fetches the rows one step ahead (two register buffers)
+                                     instead of all steps' rows at once; allows 8 steps */
+#define GVK_TUNE_STREAMING_STORES 9 /* A/B: 1 = train_segment_kernel writes context rows with non-temporal stores */
 int gvk_set_tuning(int key, int value);
 
 /* The kernel gvk_train / gvk_train_episode launch for this configuration under the current tuning, as text
  * ("train_segment_kernel<128,16,SGD,k=1> 8 pairs per wavefront") — what a benchmark should label its measurement with. */
 int gvk_describe_train(int dim, int optimizer_type, int num_negative, int explicit_negatives, int batch_size,
-                       char *name, size_t capacity);
+                       uint32_t n_vertex, char *name, size_t capacity);
+
+/* Named host ranges for profilers (roctx; `rocprofv3 --marker-trace`): the scopes the reference times with its
+ * USE_TIMER Timer (include/util/time.h:28-60, include/core/solver.h:622,645,1526-1552).  Nesting allowed, per thread. */
+void gvk_range_push(const char *name);
+void gvk_range_pop(void);
 
 const char *gvk_last_error(void);
 const char *gvk_version(void);

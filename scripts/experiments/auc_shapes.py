@@ -54,7 +54,7 @@ def main():
             print("%s epochs %d order %s seed %d: %d batches AUC %.6f (%.1f s)" % (shape, epochs, order, seed, s.batch_id,
                                                                                  aucs[-1], time.time() - t0), flush=True)
         print("%s epochs %d order %s [%s] %s: mean %.6f sd %.6f" % (shape, epochs, order, tag, tune.describe_train(
-            128, "SGD", 1, False, batch), np.mean(aucs), np.std(aucs)), flush=True)
+            128, "SGD", 1, False, batch, s._part_size), np.mean(aucs), np.std(aucs)), flush=True)
 
 
 if __name__ == "__main__":

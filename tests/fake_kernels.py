@@ -79,6 +79,43 @@ class OracleKernels(object):
             float(g.get("q", 1.0)), seed, first_walk, pool_pairs, walk_length, augmentation_step, shuffle_base)
         pool.numpy().view(np.uint32)[:2 * pool_pairs] = out.reshape(-1)
 
+    def sample_walks_blocks(self, walk_graph, part, num_partition, seed, first_walk, pools, offsets, capacity, walk_length,
+                            augmentation_step, shuffle_base, max_rounds=64):
+        """gvk_sample_walks_blocks restated: the walks of the single-partition oracle sampler (vertex ids instead of
+        rows), every pair binned into the pool of its block in walk order until the collected pools are full."""
+        g, P = walk_graph, int(num_partition)
+        entry = np.dtype([("prob", np.float32), ("alias", np.uint32)])
+        et, nt = g["edge_table"].numpy().view(entry), g["neighbor_table"].numpy().view(entry)
+        snb = g.get("sorted_neighbors")
+        local = g["local"].numpy().view(np.uint32)
+        part_of = part.numpy()
+        where = offsets.numpy()
+        out = pools.numpy().view(np.uint32).reshape(-1, 2)
+        aug, L = int(augmentation_step), int(walk_length)
+        per_walk = aug * L - aug * (aug - 1) // 2
+        count = np.zeros(P * P, np.int64)
+        walks, used = -(-capacity * P * P // per_walk), 0
+        for _ in range(max_rounds):
+            pairs = self.oracle.sample_walks_device(
+                g["flat_offsets"].numpy().view(np.uint64), g["edges_uv"].numpy().view(np.uint32).reshape(-1, 2),
+                np.ascontiguousarray(et["prob"]), np.ascontiguousarray(et["alias"]), np.ascontiguousarray(nt["prob"]),
+                np.ascontiguousarray(nt["alias"]), None if snb is None else snb.numpy().view(np.uint32),
+                np.arange(len(local), dtype=np.uint32), bool(g.get("biased", False)), float(g.get("p", 1.0)),
+                float(g.get("q", 1.0)), seed, first_walk + used, walks * per_walk, L, aug, 1)
+            used += walks
+            block = part_of[pairs[:, 1]].astype(np.int64) * P + part_of[pairs[:, 0]]
+            for b in np.flatnonzero(where >= 0):
+                mine = pairs[block == b]
+                take = mine[:max(capacity - count[b], 0)]
+                slot = count[b] + np.arange(len(take))
+                position = slot % shuffle_base * (capacity // shuffle_base) + slot // shuffle_base
+                out[where[b] + position] = np.stack([local[take[:, 0]], local[take[:, 1]]], 1)
+                count[b] += len(mine)
+            if (count[where >= 0] >= capacity).all():
+                return used
+            walks = max(walks // 2, 64)
+        raise RuntimeError("pools not full")
+
     def predict(self, vertex, context, pairs, logits):
         out = self.oracle.predict(vertex.numpy(), context.numpy(), np.ascontiguousarray(pairs.numpy().view(np.uint32)))
         logits.numpy()[:len(out)] = out

@@ -1,0 +1,105 @@
+"""-m gpu: the pybind11 module `libgraphvite` + the native solver engine (include/gvx.h) on a real MI355X, used the way
+the reference's Python package uses its own module: template-name dispatch (python/graphvite/helper.py:30-36,83-105,
+restated in two lines here because the reference tree does not travel to the GPU box), build / train / predict / numpy
+views / read-only members, several workers in one process, custom lr schedule, moment optimizers, resume."""
+import numpy as np
+import pytest
+
+from graphvite_amd import synthetic
+from oracle_lib import link_prediction_auc
+from test_bind_cpu import load_module
+
+pytestmark = pytest.mark.gpu
+
+
+def dispatch(lib, name, *parameters):
+    """helper.signature + TemplateHelper.__new__: GraphSolver(128, float32, uint32) -> lib.solver.GraphSolver_128_f_j"""
+    full = "_".join([name] + [lib.dtype2name[p] if isinstance(p, lib.dtype) else str(p) for p in parameters])
+    return getattr(lib.solver if "Solver" in name else lib.graph, full)
+
+
+@pytest.fixture(scope="module")
+def data():
+    lib = load_module()
+    lib.init_logging(lib.ERROR)
+    edges = synthetic.community_edges(20000, 400000, num_community=100, seed=3)
+    train, (valid, test) = synthetic.link_prediction_split(edges, (100, 3, 3))
+    graph = dispatch(lib, "Graph", lib.dtype.uint32)()
+    graph.load([(str(u), str(v)) for u, v in train.tolist()])
+    n2i = graph.name2id
+    keep = [(n2i[str(h)], n2i[str(t)], y) for h, t, y in zip(*test) if str(h) in n2i and str(t) in n2i]
+    return lib, graph, np.array(keep, np.int64)
+
+
+def auc_of(solver, keep):
+    return link_prediction_auc(solver.vertex_embeddings, solver.context_embeddings, keep[:, 0], keep[:, 1], keep[:, 2])
+
+
+def test_train_one_gpu_through_the_module(data):
+    lib, graph, keep = data
+    solver = dispatch(lib, "GraphSolver", 128, lib.dtype.float32, lib.dtype.uint32)(device_ids=[0], num_sampler_per_worker=4)
+    assert solver.num_worker == 1 and solver.num_sampler == 4
+    solver.build(graph, lib.optimizer.SGD(0.025, 0.005), num_negative=1, batch_size=20000, episode_size=20)
+    assert (solver.num_partition, solver.batch_size, solver.episode_size, solver.optimizer.type) == (1, 20000, 20, "SGD")
+    views = solver.vertex_embeddings, solver.context_embeddings
+    assert views[0].shape == (graph.num_vertex, 128) and views[0].dtype == np.float32
+    solver.train(model="LINE", num_epoch=200, augmentation_step=1, log_frequency=1 << 30)
+    assert solver.model == "LINE" and solver.num_epoch == 200 and solver.augmentation_step == 1
+    assert views[0] is not solver.vertex_embeddings and np.shares_memory(views[0], solver.vertex_embeddings)  # stable buffers
+    auc = auc_of(solver, keep)
+    print("module, 1 worker: AUC %.6f" % auc)
+    assert auc > 0.93
+    logits = solver.predict(keep[:1000, :2])
+    want = np.einsum("ij,ij->i", solver.vertex_embeddings[keep[:1000, 0]], solver.context_embeddings[keep[:1000, 1]])
+    np.testing.assert_allclose(logits, want, rtol=1e-5, atol=1e-7)
+    with pytest.raises(ValueError, match="shape"):
+        solver.predict(np.zeros((3, 3), np.int64))
+    with pytest.raises(ValueError, match="Invalid model"):
+        solver.train(model="TransE")
+    assert "GraphSolver<128, float32, uint32>" in repr(solver) and "#worker: 1" in repr(solver)
+    solver.clear()
+    assert np.abs(solver.vertex_embeddings).max() > 0  # clear() keeps the embeddings on the CPU
+
+
+def test_two_workers_in_one_process(data):
+    """device_ids=[0, 0]: two workers of ONE process (here sharing the only GPU of the box), two partitions, pinned
+    context shards, the head shards exchanged GPU to GPU after every schedule step — the reference's multi-GPU shape
+    (one process, device_ids=[...]) through the same module."""
+    lib, graph, keep = data
+    solver = lib.solver.GraphSolver_128_f_j(device_ids=[0, 0], num_sampler_per_worker=2)
+    solver.build(graph, batch_size=10000, episode_size=10)  # optimizer=auto: SGD 0.025 / 5e-3 / linear
+    assert solver.num_worker == 2 and solver.num_partition == 2 and solver.optimizer.type == "SGD"
+    assert solver.optimizer.lr == pytest.approx(0.025) and solver.optimizer.weight_decay == pytest.approx(5e-3)
+    for model, extra in (("LINE", dict(augmentation_step=1)), ("DeepWalk", dict(augmentation_step=2, random_walk_length=10))):
+        solver.train(model=model, num_epoch=200, log_frequency=1 << 30, **extra)
+        auc = auc_of(solver, keep)
+        print("module, 2 workers, %s: AUC %.6f" % (model, auc))
+        assert auc > 0.9 and solver.shuffle_base == (1 if model == "DeepWalk" else extra["augmentation_step"])
+
+
+def test_custom_schedule_moments_and_resume(data):
+    lib, graph, keep = data
+    calls = []
+
+    def schedule(batch_id, num_batch):
+        calls.append((batch_id, num_batch))
+        return max(1 - batch_id / num_batch, 1e-4)
+
+    solver = lib.solver.GraphSolver_64_f_j(device_ids=[0], num_sampler_per_worker=2)
+    solver.build(graph, lib.optimizer.SGD(0.025, 0.005, schedule), batch_size=20000, episode_size=5)
+    solver.train(model="LINE", num_epoch=20, augmentation_step=1, log_frequency=1 << 30)
+    # 20 epochs x 377k edges / 20000 = 377 batches, trained in whole episodes of 5: once per batch, on the host
+    assert len(calls) == 380 and calls[0] == (0, 377) and calls[-1][0] == 379
+    custom = solver.vertex_embeddings.copy()
+    linear = lib.solver.GraphSolver_64_f_j(device_ids=[0], num_sampler_per_worker=2)
+    linear.build(graph, lib.optimizer.SGD(0.025, 0.005, "linear"), batch_size=20000, episode_size=5)
+    linear.train(model="LINE", num_epoch=20, augmentation_step=1, log_frequency=1 << 30)
+    # the same schedule through the callback and natively: same training up to Hogwild noise
+    assert np.linalg.norm(custom - linear.vertex_embeddings) < 0.2 * np.linalg.norm(custom)
+    adam = lib.solver.GraphSolver_64_f_j(device_ids=[0], num_sampler_per_worker=2)
+    adam.build(graph, lib.optimizer.Adam(1e-3, 0, 0.9, 0.999), batch_size=20000, episode_size=5)
+    adam.train(model="LINE", num_epoch=40, augmentation_step=1, log_frequency=1 << 30)
+    first = auc_of(adam, keep)
+    adam.train(model="LINE", num_epoch=40, augmentation_step=1, resume=True, log_frequency=1 << 30)
+    print("Adam: AUC %.4f, after resume %.4f" % (first, auc_of(adam, keep)))
+    assert adam.resume and auc_of(adam, keep) > first > 0.6

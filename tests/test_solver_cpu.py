@@ -538,6 +538,34 @@ def test_device_sampling_over_gloo(tmp_path):
     assert (ids == np.arange(len(ids))).all() and len(ids) % (4 * 4 * 3) == 0 and np.abs(r[0]["c"]).max() > 0
 
 
+@pytest.mark.parametrize("model,aug,partitions", [("DeepWalk", 2, 2), ("node2vec", 2, 4)])
+def test_device_sampled_walks_over_gloo(tmp_path, model, aug, partitions):
+    """device_sampling=True for the random-walk models on 2 workers: every worker draws its half of EVERY block's pool
+    on the device (gvk_sample_walks_blocks: walks binned per (head, tail) block, restated by the stand-in), one
+    all_to_all routes the halves to the worker that trains the block — no CPU sampler exists on either rank.  The
+    worker-side checks make sure every trained pair is a walk pair of the block being trained."""
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), model, aug, partitions, "sampled", True), nprocs=world, join=True)
+    r = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % i)) for i in range(world)]
+    assert (r[0]["v"] == r[1]["v"]).all() and (r[0]["c"] == r[1]["c"]).all()
+    ids = np.sort(np.concatenate([r[0]["ids"], r[1]["ids"]]))
+    assert (ids == np.arange(len(ids))).all() and np.abs(r[0]["c"]).max() > 0
+
+
+def test_device_sampled_walks_on_several_partitions_of_one_gpu():
+    """One worker, 3 partitions, walks drawn on the device: the same routed path with nothing to route."""
+    g = make_graph(240, 2400, seed=6)
+    k = OracleKernels()
+    s = gv.solver.GraphSolver(32, kernels=k, num_sampler_per_worker=1, device_sampling=True, seed=3)
+    s.build(g, batch_size=300, episode_size=2, num_partition=3)
+    seen = []
+    original = s._train_block
+    s._train_block = lambda state, hp, tp, pool: (seen.append((hp, tp)), original(state, hp, tp, pool))[1]
+    s.train("DeepWalk", num_epoch=3, augmentation_step=2, random_walk_length=6, random_walk_batch_size=4)
+    assert s._sampler is None and set(seen) == {(hp, tp) for hp in range(3) for tp in range(3)}
+    assert s.batch_id % (9 * 2) == 0 and np.abs(s.context_embeddings).max() > 0
+
+
 def test_auto_build_rules_match_the_reference_solver():
     """num_partition = auto and episode_size = auto as SolverMixin::build of the reference resolved them
     (solver.h:365-434; tests/golden/reference_solver.npz, one worker)."""

@@ -3,6 +3,7 @@ kernels — against the same pipeline driven by the oracle (same graph, same sam
 the RNG contract, same init), i.e. the T3 protocol of SURVEY.md §8c: link-prediction AUC within ±0.002 ...
 on a graph large enough that Hogwild conflicts are as rare as in the benchmark configurations."""
 import logging
+import os
 
 import numpy as np
 import pytest
@@ -102,36 +103,77 @@ def test_grouped_pair_order_keeps_auc_parity():
     assert a_ora > 0.9 and abs(a_hip - a_ora) <= 0.002
 
 
-def test_power_law_graph_learns_like_the_oracle():
-    """On a hub-heavy graph a batch updates the same hub rows many times; the parallel kernel (like the
-    reference's) keeps one of those updates where the sequential oracle applies them all, so the two runs are
-    only required to learn comparably, not identically."""
-    edges = synthetic.power_law_edges(4000, 80000, seed=3)
-    train, (valid, test) = synthetic.link_prediction_split(edges, (100, 3, 3))
-    cfg = dict(batch_size=1000, episode_size=100, model="LINE", num_epoch=100, augmentation_step=1,
-               log_frequency=1 << 30)
-    g1, hip = run(train, None, 128, **dict(cfg))
-    g2, ora = run(train, OracleKernels(), 128, **dict(cfg))
-    a_hip, a_ora = auc_of(g1, hip, test), auc_of(g2, ora, test)
-    print("power-law AUC hip %.6f oracle %.6f" % (a_hip, a_ora))
-    assert a_hip > 0.6 and a_ora > 0.55 and abs(a_hip - a_ora) < 0.25
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_concurrency.npz")
 
 
-def test_quick_start_shaped_run_learns():
-    """BlogCatalog-sized synthetic graph with the quick-start hyper-parameters, shortened (config/demo/quick_start.yaml)."""
-    edges = synthetic.power_law_edges(10312, 333983, seed=1024)
-    train, (valid, test) = synthetic.link_prediction_split(edges)
+def _hub_shape(name):
+    """Graph, held-out edges and hyper-parameters of a hub-heavy parity shape, rebuilt from what the golden file
+    records (tests/golden/make_concurrency_golden.py)."""
+    G = np.load(GOLDEN)
+    n, e, communities, graph_seed, batch, episode, epochs, aug = [int(x) for x in G[name + "_args"]]
+    gamma, p_in = [float(x) for x in G[name + "_gamma_p_in"]]
+    edges = synthetic.hub_community_edges(n, e, gamma=gamma, num_community=communities, p_in=p_in, seed=graph_seed)
+    train, (valid, test) = synthetic.link_prediction_split(edges, (100, 1, 1))
+    golden = {model: G["%s_%s" % (name, model)] for model in ("sequential", "lock_step", "reads_at_start")}
+    return train, test, dict(batch_size=batch, episode_size=episode), dict(num_epoch=epochs, augmentation_step=aug), golden
+
+
+def _aucs(train, test, build, fit, pair_order, seeds):
+    gv.init_logging(logging.ERROR)
+    g = gv.graph.Graph()
+    g.load(train)
+    out = []
+    for seed in seeds:
+        s = gv.solver.GraphSolver(128, num_sampler_per_worker=8, seed=seed, pair_order=pair_order)
+        s.build(g, **build)
+        s.train(model="LINE", log_frequency=1 << 30, **fit)
+        out.append(auc_of(g, s, test))
+    return np.array(out), s
+
+
+@pytest.mark.parametrize("shape", ["blog", "hub100k"])
+def test_hub_heavy_shapes_match_the_reference_training_loop(shape):
+    """Learning quality on hub-heavy graphs of BASELINE.json's shapes, against the reference's OWN training loop run on the
+    host (oracle/ref_solver_harness.cpp; goldens in tests/golden/reference_concurrency.npz) under three models of its
+    kernel launch: sequential (the "reference CPU solver" the north_star names), and two chunk-synchronous models of
+    the launch on a V100 (5120 resident warps; lock step per kernel phase / all reads at chunk start).  "blog" is
+    configs[0]'s shape with config/demo/quick_start.yaml's hyper-parameters, "hub100k" a 100k-node graph at the default
+    batch of 100 000 — every batch hits a hub row hundreds of times, which is where execution order decides what is
+    learned.  The two pipelines share no random stream, so means over seeds are compared.
+
+    * the product as shipped (pair_order auto): link-prediction AUC within +-0.002 of the sequential reference;
+    * in sampler order (the per-pair concurrency of round 1) it stays inside the bracket the reference's own models
+      span, 0.002 around [chunk-synchronous, sequential];
+    * and the product is never below the chunk-synchronous models: what a lock-step launch loses, it does not."""
+    train, test, build, fit, golden = _hub_shape(shape)
+    sequential, floor = golden["sequential"].mean(), min(golden["lock_step"].mean(), golden["reads_at_start"].mean())
+    default, solver = _aucs(train, test, build, fit, gv.auto, (17, 18, 19, 20, 21))
+    sampled, _ = _aucs(train, test, build, fit, "sampled", (17, 18, 19))
+    print("%s: reference loop sequential %.6f | lock step %.6f | reads at start %.6f || here auto (%s) %.6f +- %.6f | "
+          "sampled %.6f" % (shape, sequential, golden["lock_step"].mean(), golden["reads_at_start"].mean(),
+                           solver.pair_order, default.mean(), default.std(), sampled.mean()))
+    assert solver.pair_order == "grouped"
+    assert abs(default.mean() - sequential) <= 0.002
+    assert floor - 0.002 <= sampled.mean() <= sequential + 0.002
+    assert default.mean() >= floor
+
+
+def test_quick_start_pipeline():
+    """BASELINE configs[0] end to end through GraphApplication — load, build, train, evaluate, predict — with
+    config/demo/quick_start.yaml's hyper-parameters on the BlogCatalog-sized stand-in of the parity test above."""
+    train, test, build, fit, golden = _hub_shape("blog")
     app = gv.application.GraphApplication(dim=128)
     gv.init_logging(logging.ERROR)
     app.load(edge_list=train)
-    app.build(optimizer=gv.optimizer.SGD(0.025, 0.005), num_negative=1, batch_size=100000, episode_size=500)
-    app.train(model="LINE", num_epoch=1000, negative_weight=5, augmentation_step=2, random_walk_length=40,
-              random_walk_batch_size=100, log_frequency=1000)
+    app.build(optimizer=gv.optimizer.SGD(0.025, 0.005), num_negative=1, **build)
+    app.train(model="LINE", negative_weight=5, random_walk_length=40, random_walk_batch_size=100, log_frequency=1000, **fit)
     H, T, Y = test
     result = app.evaluate("link prediction", H=[str(h) for h in H], T=[str(t) for t in T], Y=Y.tolist(),
                           filter_H=[str(h) for h in train[:, 0]], filter_T=[str(t) for t in train[:, 1]])
-    print("quick-start-shaped AUC", result)
-    assert result["AUC"] > 0.65  # ~0.70 +- 0.01 run to run (Hogwild on a 10k-node hub-heavy graph)
+    print("quick-start pipeline AUC", result)
+    # evaluate() filters the held-out pairs that also occur in the training edges, the golden protocol does not:
+    # same embeddings, slightly different test set
+    assert abs(result["AUC"] - golden["sequential"].mean()) <= 0.01
     assert app.solver.batch_id >= app.solver.num_batch
     logits = app.solver.predict(np.stack([np.arange(10), np.arange(10)[::-1]], 1))
     want = np.einsum("ij,ij->i", app.solver.vertex_embeddings[:10], app.solver.context_embeddings[:10][::-1])
@@ -182,6 +224,23 @@ def test_device_sampling_end_to_end():
         auc = auc_of(g, s, test)
         print("device sampling %s AUC %.6f" % (model, auc))
         assert auc > 0.9 and s._sampler is None
+
+
+def test_device_sampled_walks_over_partitions():
+    """DeepWalk and node2vec with the positives drawn on the device for SEVERAL partitions (gvk_sample_walks_blocks: the
+    path several GPUs use, here 3 partitions on the one GPU of the box): no CPU sampler exists, the embeddings learn."""
+    edges = synthetic.community_edges(20000, 400000, num_community=100, seed=3)
+    train, (valid, test) = synthetic.link_prediction_split(edges, (100, 3, 3))
+    gv.init_logging(logging.ERROR)
+    for model in ("DeepWalk", "node2vec"):
+        g = gv.graph.Graph()
+        g.load(train)
+        s = gv.solver.GraphSolver(128, num_sampler_per_worker=1, seed=17, device_sampling=True)
+        s.build(g, batch_size=20000, episode_size=6, num_partition=3)
+        s.train(model=model, num_epoch=200, augmentation_step=2, random_walk_length=10, p=0.5, q=2.0, log_frequency=1 << 30)
+        auc = auc_of(g, s, test)
+        print("device-sampled %s over 3 partitions: AUC %.6f" % (model, auc))
+        assert auc > 0.9 and s._sampler is None and s.batch_id % (9 * 6) == 0
 
 
 def test_moment_optimizer_end_to_end():
