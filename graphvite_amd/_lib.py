@@ -15,8 +15,7 @@ TUNE_VARIANT = 2
 TUNE_RUN_CAP = 3
 TUNE_GENERATION = 4
 TUNE_SEGMENT_STEPS = 5
-TUNE_SEGMENT_SUM = 6
-TUNE_SKIP_LOSS = 7
+TUNE_SKIP_LOSS = 6
 
 
 class AliasEntry(C.Structure):

@@ -42,9 +42,6 @@ int g_variant = 0;         // GVK_TUNE_VARIANT
 int g_run_cap = 0;         // GVK_TUNE_RUN_CAP (0 = from the batch size, run_cap_for)
 int g_generation = 0;      // GVK_TUNE_GENERATION (0 = one launch per batch)
 int g_segment_steps = 0;   // GVK_TUNE_SEGMENT_STEPS (0 = per-dim default, default_steps)
-int g_streaming_stores = 0;  // GVK_TUNE_STREAMING_STORES
-int g_segment_stream = 0;  // GVK_TUNE_SEGMENT_STREAM (A/B: rows fetched one step ahead instead of all at once)
-int g_segment_sum = 0;     // GVK_TUNE_SEGMENT_SUM (A/B: add up the changes of a run instead of chaining them)
 int g_skip_loss = 1;       // GVK_TUNE_SKIP_LOSS (gvk_train_episode leaves out the loss of batches nobody can read)
 
 struct TrainArgs {
@@ -57,7 +54,6 @@ struct TrainArgs {
     uint32_t count, batch_id;
     int batch_size, k;
     int run_cap;  // train_runs_kernel: longest run of adjacent same-head pairs one lane group trains in sequence
-    int streaming_stores;  // A/B (GVK_TUNE_STREAMING_STORES): context rows are written with non-temporal stores
     int first_sample;  // train_kernel: this launch trains samples [first_sample, batch_size) of the batch (GVK_TUNE_GENERATION)
     float lr, wd, neg_weight, hp0, hp1, eps;
 };
@@ -150,8 +146,7 @@ __device__ __forceinline__ void load_row(const float *table, uint32_t id, int la
 }
 
 template <int DIM, int G>
-__device__ __forceinline__ void store_row(float *table, uint32_t id, int lane, const float (&r)[DIM / G],
-                                          bool streaming = false) {
+__device__ __forceinline__ void store_row(float *table, uint32_t id, int lane, const float (&r)[DIM / G]) {
     typedef Layout<DIM, G> L;
     float *row = table + (size_t)id * DIM + lane * L::CW;
 #pragma unroll
@@ -159,10 +154,7 @@ __device__ __forceinline__ void store_row(float *table, uint32_t id, int lane, c
         float *p = row + c * G * L::CW;
         if (L::CW == 4) {
             f32x4 x = {r[c * 4 + 0], r[c * 4 + 1], r[c * 4 + 2], r[c * 4 + 3]};
-            if (streaming)
-                __builtin_nontemporal_store(x, reinterpret_cast<f32x4 *>(p));
-            else
-                *reinterpret_cast<f32x4 *>(p) = x;
+            *reinterpret_cast<f32x4 *>(p) = x;
         } else if (L::CW == 2) {
             f32x2 x = {r[c * 2 + 0], r[c * 2 + 1]};
             *reinterpret_cast<f32x2 *>(p) = x;
@@ -531,20 +523,13 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_runs_kernel(const TrainAr
 // disappears), and of the pairs of a batch that share a hub row up to S consecutive updates survive instead of one.
 // Because every row was requested in phase 2, a run costs no memory round trip per pair — the dependent chain is
 // arithmetic only (about 0.1 us per pair), which is what train_runs_kernel above could not avoid.
-// SUM (A/B build, GVK_TUNE_SEGMENT_SUM): instead of passing the row along the run, every pair of a step trains its own
-// copy of the row side by side and the changes of the pairs of one run are ADDED up before the single store — no
-// serialisation inside a step, at the price of up to 64 / G updates computed from the same stale row.
 // LOSS = 0 builds leave the per-sample loss out: gvk_train_episode only needs it for the batch whose loss can still be
 // read afterwards (every batch overwrites the same loss buffer).
-// STREAM (A/B build, GVK_TUNE_SEGMENT_STREAM): the headers of all D steps are still fetched at once, but the rows only
-// one step ahead, through two register buffers — the first round trip (pair record + alias slot, a few bytes) is paid
-// once per D pairs instead of once per pair while the rows in flight per wavefront stay those of two steps.
-template <int DIM, int G, int D, int DRAW, int WAVES, int SUM = 0, int LOSS = 1, int STREAM = 0>
+template <int DIM, int G, int D, int DRAW, int WAVES, int LOSS = 1>
 __global__ void __launch_bounds__(kBlock, WAVES) train_segment_kernel(const TrainArgs a) {
     constexpr int V = DIM / G;
     constexpr int NG = 64 / G;  // lane groups of a wavefront = pairs per step
     constexpr int S = NG * D;   // pairs per wavefront
-    constexpr int NB = STREAM ? (D > 1 ? 2 : 1) : D;  // row buffers per lane
     constexpr uint32_t kNone = 0xffffffffu;  // row ids are below 2^32 - 1 (gvk_tables.n_vertex is a uint32 count)
 
     const int wave = (blockIdx.x * kBlock + threadIdx.x) / 64;
@@ -590,20 +575,17 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_segment_kernel(const Trai
         last[i] = succ != head[i];
     }
 
-    // phase 2: every row of the segment (STREAM: of its first step; the others follow one step ahead)
-    float vl_[NB][V], cn_[NB][V], cp_[NB][V];
+    // phase 2: every row of the segment
+    float vl_[D][V], cn_[D][V], cp_[D][V];
 #pragma unroll
-    for (int i = 0; i < D; i++)
-        if (draw && head[i] != kNone) neg[i] = resolve(dr[i], en[i]);
-    auto load_step = [&](const int i) __attribute__((always_inline)) {
+    for (int i = 0; i < D; i++) {
         if (head[i] != kNone) {
-            load_row<DIM, G>(a.context, neg[i], lane, cn_[i % NB]);
-            load_row<DIM, G>(a.context, tail[i], lane, cp_[i % NB]);
-            if (SUM || !cont[i]) load_row<DIM, G>(a.vertex, head[i], lane, vl_[i % NB]);
+            if (draw) neg[i] = resolve(dr[i], en[i]);
+            load_row<DIM, G>(a.context, neg[i], lane, cn_[i]);
+            load_row<DIM, G>(a.context, tail[i], lane, cp_[i]);
+            if (!cont[i]) load_row<DIM, G>(a.vertex, head[i], lane, vl_[i]);
         }
-    };
-#pragma unroll
-    for (int i = 0; i < (STREAM ? 1 : D); i++) load_step(i);
+    }
 
     // phase 3
     float v[V];
@@ -612,10 +594,9 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_segment_kernel(const Trai
 #pragma unroll
     for (int i = 0; i < D; i++) {
         const bool valid = head[i] != kNone;
-        if (STREAM && i + 1 < D) load_step(i + 1);  // the next step's rows travel while this step computes
-        float(&vl)[V] = vl_[i % NB];
-        float(&cn)[V] = cn_[i % NB];
-        float(&cp)[V] = cp_[i % NB];
+        float(&vl)[V] = vl_[i];
+        float(&cn)[V] = cn_[i];
+        float(&cp)[V] = cp_[i];
         // position in the chain of this step: 0 = nothing to wait for in this step (a run start, or lane group 0, whose
         // predecessor finished in the step before), d = d lane groups of this step come first
         int depth = 0;
@@ -645,7 +626,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_segment_kernel(const Trai
                     v[x] -= update<GVK_SGD>(a, vi, prob * ci, a.neg_weight, m1, m2);
                     cn[x] -= update<GVK_SGD>(a, ci, prob * vi, a.neg_weight, m1, m2);
                 }
-                store_row<DIM, G>(a.context, neg[i], lane, cn, a.streaming_stores != 0);
+                store_row<DIM, G>(a.context, neg[i], lane, cn);
                 if (neg[i] == tail[i]) copy_row(cp, cn);  // the pair sees its own update
             }
             {
@@ -661,61 +642,25 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_segment_kernel(const Trai
                     v[x] -= update<GVK_SGD>(a, vi, (prob - 1) * ci, 1.0f, m1, m2);
                     cp[x] -= update<GVK_SGD>(a, ci, (prob - 1) * vi, 1.0f, m1, m2);
                 }
-                store_row<DIM, G>(a.context, tail[i], lane, cp, a.streaming_stores != 0);
+                store_row<DIM, G>(a.context, tail[i], lane, cp);
             }
             if (LOSS && lane == 0)
                 __builtin_nontemporal_store(sample_loss / (1 + a.neg_weight), a.loss + base + i * NG + g);
         };
-        if constexpr (SUM) {
-            // every pair from its own copy of the row, then the changes of a run travel down the run and add up;
-            // a run that continues from the step before starts from that step's result instead of the loaded row
-            float carried[V];
-#pragma unroll
-            for (int x = 0; x < V; x++) carried[x] = __shfl(v[x], before);
-            const bool from_before = valid && cont[i] && g == 0;
-            if (valid) {
-                if (from_before) copy_row(v, carried); else copy_row(v, vl);
-            }
-            float start[V];
-            copy_row(start, v);
-            if (valid) train_pair();
-            float delta[V];
-#pragma unroll
-            for (int x = 0; x < V; x++) delta[x] = valid ? v[x] - start[x] : 0.0f;
-#pragma unroll
-            for (int r = 1; r < NG; r++) {  // delta of the pair r places up the run, if the run reaches that far
-                const int source = (lane64 + 64 - r * G) & 63;
-#pragma unroll
-                for (int x = 0; x < V; x++) {
-                    const float d = __shfl(delta[x], source);
-                    if (depth >= r) v[x] += d;
-                }
-            }
-            // all pairs of a run end up relative to the row its first pair of this step started from (the pairs
-            // further down started from their own loaded copy of the same row)
-            const int first = (lane64 + 64 - depth * G) & 63;
-#pragma unroll
-            for (int x = 0; x < V; x++) {
-                const float origin = __shfl(start[x], first);
-                if (depth > 0) v[x] += origin - start[x];
-            }
-            if (valid && last[i]) store_row<DIM, G>(a.vertex, head[i], lane, v);
-        } else {
 #pragma unroll 1
-            for (int t = 0; t < NG; t++) {
-                const bool mine = valid && depth == t;
-                if (!__any(mine)) break;  // depths are contiguous: nobody is deeper either
-                if (__any(mine && cont[i])) {  // the row of the run moves on to the next lane group
-                    float vin[V];
+        for (int t = 0; t < NG; t++) {
+            const bool mine = valid && depth == t;
+            if (!__any(mine)) break;  // depths are contiguous: nobody is deeper either
+            if (__any(mine && cont[i])) {  // the row of the run moves on to the next lane group
+                float vin[V];
 #pragma unroll
-                    for (int x = 0; x < V; x++) vin[x] = __shfl(v[x], before);
-                    if (mine && cont[i]) copy_row(v, vin);
-                }
-                if (mine) {
-                    if (!cont[i]) copy_row(v, vl);
-                    train_pair();
-                    if (last[i]) store_row<DIM, G>(a.vertex, head[i], lane, v);
-                }
+                for (int x = 0; x < V; x++) vin[x] = __shfl(v[x], before);
+                if (mine && cont[i]) copy_row(v, vin);
+            }
+            if (mine) {
+                if (!cont[i]) copy_row(v, vl);
+                train_pair();
+                if (last[i]) store_row<DIM, G>(a.vertex, head[i], lane, v);
             }
         }
     }
@@ -1072,45 +1017,23 @@ constexpr int segment_waves() {
     return DIM / G * (3 * D + 2) + 40 <= 128 ? 4 : 2;
 }
 
-// A/B build: rows one step ahead (two buffers of 3 rows) + the headers of D steps
 template <int DIM, int G, int D>
-TrainKernel stream_build(bool loss) {
-    constexpr int need = DIM / G * 8 + 8 * D + 48;
-    if constexpr (need > 256) {
-        return nullptr;
-    } else {
-        constexpr int W = need <= 128 ? 4 : (need <= 168 ? 3 : 2);
-        return loss ? train_segment_kernel<DIM, G, D, 1, W, 0, 1, 1> : train_segment_kernel<DIM, G, D, 1, W, 0, 0, 1>;
-    }
-}
-
-template <int DIM, int G, int D>
-TrainKernel segment_build(bool draw, bool sum, bool loss) {
+TrainKernel segment_build(bool draw, bool loss) {
     if constexpr (DIM / G * (3 * D + 2) + 40 > 256) {
         return nullptr;
     } else {
         constexpr int W = segment_waves<DIM, G, D>();
-        if (sum)  // A/B build: in-kernel draw only
-            return !draw ? nullptr : (loss ? train_segment_kernel<DIM, G, D, 1, W, 1, 1> : train_segment_kernel<DIM, G, D, 1, W, 1, 0>);
-        if (draw) return loss ? train_segment_kernel<DIM, G, D, 1, W, 0, 1> : train_segment_kernel<DIM, G, D, 1, W, 0, 0>;
-        return train_segment_kernel<DIM, G, D, 0, W, 0, 1>;
+        if (draw) return loss ? train_segment_kernel<DIM, G, D, 1, W, 1> : train_segment_kernel<DIM, G, D, 1, W, 0>;
+        return train_segment_kernel<DIM, G, D, 0, W, 1>;
     }
 }
 
 template <int DIM, int G>
-TrainKernel pick_segment(int steps, bool draw, bool sum, bool loss) {
-    if (g_segment_stream && draw && !sum) {
-        switch (steps) {
-            case 2: return stream_build<DIM, G, 2>(loss);
-            case 4: return stream_build<DIM, G, 4>(loss);
-            case 8: return stream_build<DIM, G, 8>(loss);
-        }
-        return nullptr;
-    }
+TrainKernel pick_segment(int steps, bool draw, bool loss) {
     switch (steps) {
-        case 1: return segment_build<DIM, G, 1>(draw, sum, loss);
-        case 2: return segment_build<DIM, G, 2>(draw, sum, loss);
-        case 4: return segment_build<DIM, G, 4>(draw, sum, loss);
+        case 1: return segment_build<DIM, G, 1>(draw, loss);
+        case 2: return segment_build<DIM, G, 2>(draw, loss);
+        case 4: return segment_build<DIM, G, 4>(draw, loss);
     }
     return nullptr;
 }
@@ -1133,7 +1056,7 @@ Choice choose_train(int dim, int opt, int k, bool explicit_negatives, int batch_
     if (shipped_shape && g_variant == 0 && g_generation == 0) {
         c.steps = g_segment_steps ? g_segment_steps : default_steps(dim, rows);
 #define GVK_SEGMENT(D, GG) \
-    case D: c.kernel = pick_segment<D, GG>(c.steps, draw, g_segment_sum != 0, want_loss || !g_skip_loss); break;
+    case D: c.kernel = pick_segment<D, GG>(c.steps, draw, want_loss || !g_skip_loss); break;
         switch (dim) {
             GVK_SEGMENT(32, 8) GVK_SEGMENT(64, 16) GVK_SEGMENT(96, 8) GVK_SEGMENT(128, 16) GVK_SEGMENT(256, 16)
             GVK_SEGMENT(512, 32)
@@ -1175,7 +1098,7 @@ int launch_train(hipStream_t stream, int dim, const gvk_optimizer *o, float lr, 
     a.vm2 = t->vertex_moment2; a.cm2 = t->context_moment2;
     a.pairs = pairs; a.negatives = neg->negatives; a.table = neg->table; a.loss = loss;
     a.seed = neg->seed; a.count = neg->count; a.batch_id = batch_id;
-    a.batch_size = batch_size; a.k = k; a.run_cap = c.run_cap; a.streaming_stores = g_streaming_stores;
+    a.batch_size = batch_size; a.k = k; a.run_cap = c.run_cap;
     a.lr = lr; a.wd = o->weight_decay; a.neg_weight = negative_weight;
     a.hp0 = o->hp0; a.hp1 = o->hp1; a.eps = o->epsilon;
     if (c.reference_shape) {
@@ -1365,8 +1288,8 @@ int gvk_describe_train(int dim, int optimizer_type, int num_negative, int explic
     else if (!c.kernel)
         return fail(GVK_EINVAL, "gvk_describe_train: no kernel for this (dim, lanes, optimizer)");
     else if (c.steps > 0)
-        snprintf(name, capacity, "train_segment_kernel<%d,%d,SGD,k=1> %d pairs per wavefront%s", dim, c.lanes,
-                 64 / c.lanes * c.steps, g_segment_sum ? ", run changes added up" : (g_segment_stream ? ", rows one step ahead" : ""));
+        snprintf(name, capacity, "train_segment_kernel<%d,%d,SGD,k=1> %d pairs per wavefront", dim, c.lanes,
+                 64 / c.lanes * c.steps);
     else
         snprintf(name, capacity, "%s<%d,%d,%s%s> run_cap %d%s", c.runs ? "train_runs_kernel" : "train_kernel", dim, c.lanes,
                  kOptimizers[optimizer_type], c.fixed_k ? ",k=1" : "", c.run_cap,
@@ -1387,17 +1310,14 @@ int gvk_set_tuning(int key, int value) {
         return GVK_OK;
     }
     if (key == GVK_TUNE_SEGMENT_STEPS) {
-        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
-            return fail(GVK_EINVAL, "gvk_set_tuning: segment steps must be 0, 1, 2, 4 or (streamed rows) 8");
+        if (value != 0 && value != 1 && value != 2 && value != 4)
+            return fail(GVK_EINVAL, "gvk_set_tuning: segment steps must be 0, 1, 2 or 4");
         g_segment_steps = value;
         return GVK_OK;
     }
-    if (key == GVK_TUNE_SEGMENT_SUM || key == GVK_TUNE_SKIP_LOSS || key == GVK_TUNE_SEGMENT_STREAM ||
-        key == GVK_TUNE_STREAMING_STORES) {
+    if (key == GVK_TUNE_SKIP_LOSS) {
         if (value != 0 && value != 1) return fail(GVK_EINVAL, "gvk_set_tuning: flag must be 0 or 1");
-        int &flag = key == GVK_TUNE_SEGMENT_SUM ? g_segment_sum : (key == GVK_TUNE_SKIP_LOSS ? g_skip_loss :
-                    (key == GVK_TUNE_SEGMENT_STREAM ? g_segment_stream : g_streaming_stores));
-        flag = value;
+        g_skip_loss = value;
         return GVK_OK;
     }
     if (key == GVK_TUNE_GENERATION) {

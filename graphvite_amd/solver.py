@@ -154,9 +154,9 @@ class GraphSolver(object):
     the GPU) and `pair_order` — "sampled": a batch is trained in the order the samplers produced it; "grouped": the
     pairs of a batch that share a head row are made adjacent on the device first (gvk_group_pairs; same samples, same
     batches; a row shared by k samples is fetched from HBM once and the k samples are trained as runs, one after the
-    other on one copy of the row); auto (default): grouped at dim >= 64 for independent edge draws (LINE,
-    augmentation_step 1) and for every model when a partition's table is cache-resident (< 16 MiB), sampled
-    otherwise.
+    other on one copy of the row); auto (default): grouped at dim >= 64 when a partition's table is cache-resident
+    (< 16 MiB: every batch hits the hub rows hundreds of times and the runs keep training close to sequential), the
+    sampler's order otherwise.
     """
 
     available_dims = (32, 64, 96, 128, 256, 512)  # src/graphvite.cu:52-59
@@ -525,18 +525,15 @@ class GraphSolver(object):
                 mode = "biased_reject"
         self._mode = mode
         if self._pair_order_request == auto:
-            # Regroup (gvk_group_pairs) in two regimes:
-            #   * tables too large for the caches (>= 16 MiB) and independent edge draws: a head row shared by several
-            #     samples of a batch crosses HBM once (random-walk pools come in the reference's pseudo-shuffled walk
-            #     order, which already has locality: DeepWalk end to end -16 % when regrouped);
-            #   * cache-resident tables (a BlogCatalog-sized graph): every batch hits every hub row hundreds of times;
-            #     adjacent same-head samples are trained as runs of up to 16 consecutive updates per wavefront, which
-            #     keeps link-prediction AUC within 0.002 of sequential training, and the pass costs nothing that matters.
-            # Not at dim 32: a batch trains in 16 us there and the pass, which costs the same at every dim, would take a
-            # third of the GPU.
-            big = self._part_size * self.dim * 4 >= MiB(16)
-            regroup = self.dim >= 64 and self.device.type == "cuda" and (not big or mode == "edge")
-            self.pair_order = "grouped" if regroup else "sampled"
+            # Regroup (gvk_group_pairs) when the tables are cache-resident (< 16 MiB: a BlogCatalog-sized graph): every
+            # batch then hits every hub row hundreds of times, and with same-head samples adjacent the kernel trains
+            # them as runs of up to 16 consecutive updates per wavefront — that keeps link-prediction AUC within 0.002 of
+            # sequential training there, and at that size the pass costs nothing that matters.  Larger
+            # tables keep the sampler's order, as the reference does: conflicts are rare, the measured kernel gain of
+            # regrouping is within run-to-run noise and the pass is not free.  Not at dim 32 (a batch
+            # trains in 16 us there; the pass, which costs the same at every dim, would take a third of the GPU).
+            resident = self._part_size * self.dim * 4 < MiB(16)
+            self.pair_order = "grouped" if resident and self.dim >= 64 and self.device.type == "cuda" else "sampled"
         if self.device_sampling:
             return  # positives are drawn on the device: no CPU sampler needed
         if self._sampler is None:

@@ -217,13 +217,8 @@ int gvk_alias_build(const float *weights, size_t n, float *prob, void *alias, in
 #define GVK_TUNE_SEGMENT_STEPS 5  /* train_segment_kernel: pairs per lane group and wavefront (a wavefront owns 64 / lanes *
                                      steps consecutive pairs) — 0 = default: 1 step, or the longest build (4 up to dim 128)
                                      when the head table is smaller than 16 MiB; else 1, 2 or 4 */
-#define GVK_TUNE_SEGMENT_SUM 6    /* A/B: 1 = the pairs of a run inside a step train side by side from the same row and
-                                     their changes are added up (no serialisation); 0 = chained in sequence (default) */
-#define GVK_TUNE_SKIP_LOSS 7      /* 1 (default) = gvk_train_episode does not compute the per-sample loss of batches whose
+#define GVK_TUNE_SKIP_LOSS 6      /* 1 (default) = gvk_train_episode does not compute the per-sample loss of batches whose
                                      loss[] a later batch of the same call overwrites; 0 = every batch computes it */
-#define GVK_TUNE_SEGMENT_STREAM 8 /* A/B: 1 = train_segment_kernel fetches the rows one step ahead (two register buffers)
-                                     instead of all steps' rows at once; allows 8 steps */
-#define GVK_TUNE_STREAMING_STORES 9 /* A/B: 1 = train_segment_kernel writes context rows with non-temporal stores */
 int gvk_set_tuning(int key, int value);
 
 /* The kernel gvk_train / gvk_train_episode launch for this configuration under the current tuning, as text

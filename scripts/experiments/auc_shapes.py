@@ -37,7 +37,6 @@ def main():
     tune.set_run_cap(int(extra.get("run_cap", 0)))
     tune.set_generation(int(extra.get("generation", 0)))
     tune.set_segment_steps(int(extra.get("steps", 0)))
-    tune.set_tuning(6, int(extra.get("sum", 0)))
     tag = " ".join("%s=%s" % kv for kv in sorted(extra.items()))
     for order in orders:
         aucs = []

@@ -1,17 +1,19 @@
 """BASELINE.json configs[0]: the reference's quick start (config/demo/quick_start.yaml — LINE, dim 128, 2000 epochs,
-augmentation_step 2, batch 100000, episode 500) on a BlogCatalog-sized synthetic power-law graph (10 312 nodes /
-333 983 edges; the real dataset needs the network).  Prints stage times and the link-prediction AUC."""
+augmentation_step 2, batch 100000, episode 500) on the BlogCatalog-sized stand-in of the parity tests (10 312 nodes /
+333 983 edges, hub-heavy with communities; the real dataset needs the network).  Prints stage times and the
+link-prediction AUC."""
 import logging
+import os
 import sys
 import time
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import graphvite_amd as gv
 from graphvite_amd import synthetic
 
 gv.init_logging(logging.WARNING)
-edges = synthetic.power_law_edges(10312, 333983, seed=1024)
-train, (valid, test) = synthetic.link_prediction_split(edges)
+edges = synthetic.hub_community_edges(10312, 333983, gamma=2.8, num_community=39, p_in=0.7, seed=1024)
+train, (valid, test) = synthetic.link_prediction_split(edges, (100, 1, 1))
 app = gv.application.GraphApplication(dim=128)
 t0 = time.time()
 app.load(edge_list=train)

@@ -1,50 +1,109 @@
-"""Copies the judged summaries of a scripts/gpu_job.sh run from gpurun_out/ (scratch) into profiles/<round>/."""
+"""Copies the judged summaries of a scripts/gpu_job.sh run from gpurun_out/ (scratch) into profiles/<round>/.
+
+    python scripts/summarize_profiles.py r2
+"""
 import collections
 import csv
+import glob
 import json
 import os
 import shutil
 import sys
 
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r1"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r2"
 SRC, DST = "gpurun_out", os.path.join("profiles", ROUND)
 os.makedirs(DST, exist_ok=True)
-shutil.copy(os.path.join(SRC, "prof_r1", "r1_kernel_stats.csv"), os.path.join(DST, "kernel_stats_bench_n1.csv"))
-for name in ("bench_n1.json", "pytest_gpu_full.log", "smoke.log"):
-    if os.path.exists(os.path.join(SRC, name)):
+
+
+def find(directory, suffix):
+    hits = sorted(glob.glob(os.path.join(SRC, directory, "**", "*" + suffix), recursive=True))
+    return hits[0] if hits else None
+
+
+for name in ("bench_n1.json", "bench_n1_steps20.json", "configs_2_4.jsonl", "dim_sweep.jsonl", "pytest_gpu_full.log", "smoke.log"):
+    if os.path.exists(os.path.join(SRC, name)) and os.path.getsize(os.path.join(SRC, name)):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, name))
 
-out = {"command": "rocprofv3 --pmc <counter> --output-format csv -- python bench.py --steps 20 --warmup 5 "
-                  "--no-cpu-baseline (one pass per counter set: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum)",
-       "units": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch; FETCH_SIZE is doubled per MI355X_MICROARCH.md §HBM "
-                "(gfx950 tallies the 128-B requests of 16 B/lane loads at 64 B)"}
-kernel = None
-for name in ("FETCH_SIZE", "WRITE_SIZE", "L2"):
-    rows = list(csv.DictReader(open(os.path.join(SRC, "pmc_%s" % name, "pmc_counter_collection.csv"))))
-    acc = collections.defaultdict(list)
-    for r in rows:
-        if "train_kernel" in r["Kernel_Name"]:
-            kernel = r["Kernel_Name"]
-            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        out[k] = {"dispatches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}
-out["kernel"] = kernel
-f, w = out["FETCH_SIZE"]["mean"] * 1024, out["WRITE_SIZE"]["mean"] * 1024
-out["hbm_read_bytes_per_launch_corrected"] = 2 * f
-out["hbm_write_bytes_per_launch"] = w
-out["traffic_bytes_per_launch"] = 2 * f + w
-out["algorithmic_bytes_per_launch"] = 308800000
-out["l2_hit_rate"] = out["TCC_HIT_sum"]["mean"] / (out["TCC_HIT_sum"]["mean"] + out["TCC_MISS_sum"]["mean"])
-json.dump(out, open(os.path.join(DST, "pmc_summary_bench_n1.json"), "w"), indent=1)
+# ---- kernel trace -------------------------------------------------------------------------------------------------
+stats, trace = find("prof_kernel", "kernel_stats.csv"), find("prof_kernel", "kernel_trace.csv")
+if stats:
+    shutil.copy(stats, os.path.join(DST, "kernel_stats_bench_n1.csv"))
+if trace:
+    rows = [r for r in csv.DictReader(open(trace)) if "train_" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+    gap = sorted(int(rows[i + 1]["Start_Timestamp"]) - int(rows[i]["End_Timestamp"]) for i in range(len(rows) - 1))
+    by_name = collections.Counter(r["Kernel_Name"] for r in rows)
+    summary = {"command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline "
+                          "--no-end-to-end", "kernels": dict(by_name), "launches": len(rows), "mean_ns": sum(dur) / len(dur),
+               "min_ns": min(dur), "max_ns": max(dur), "median_gap_ns": gap[len(gap) // 2], "grid": rows[0]["Grid_Size_X"],
+               "workgroup": rows[0]["Workgroup_Size_X"], "achieved_GBps": 308800000 / (sum(dur) / len(dur)),
+               "fraction_of_hbm_peak": 308800000 / (sum(dur) / len(dur)) / 8000.0}
+    json.dump(summary, open(os.path.join(DST, "kernel_trace_summary_bench_n1.json"), "w"), indent=1)
+    print(json.dumps(summary, indent=1))
 
-rows = [r for r in csv.DictReader(open(os.path.join(SRC, "prof_r1", "r1_kernel_trace.csv")))
-        if "train_kernel" in r["Kernel_Name"]]
-rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
-gap = sorted(int(rows[i + 1]["Start_Timestamp"]) - int(rows[i]["End_Timestamp"]) for i in range(len(rows) - 1))
-summary = {"kernel": rows[0]["Kernel_Name"], "launches": len(rows), "mean_ns": sum(dur) / len(dur),
-           "min_ns": min(dur), "max_ns": max(dur), "median_gap_ns": gap[len(gap) // 2],
-           "grid": rows[0]["Grid_Size_X"], "workgroup": rows[0]["Workgroup_Size_X"]}
-json.dump(summary, open(os.path.join(DST, "kernel_trace_summary_bench_n1.json"), "w"), indent=1)
-print(json.dumps(summary, indent=1))
-print("traffic / algorithmic = %.3f, l2 hit rate %.3f" % (out["traffic_bytes_per_launch"] / 308800000, out["l2_hit_rate"]))
+# ---- PMC passes, per dim ---------------------------------------------------------------------------------------------
+by_dim = {"command": "rocprofv3 --pmc <counter> -- python bench.py --dim <d> --steps 20 --warmup 5 --no-cpu-baseline "
+                     "--no-end-to-end (one pass per counter: FETCH_SIZE | WRITE_SIZE; dim 128 also TCC_HIT_sum TCC_MISS_sum)",
+          "units": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch; FETCH_SIZE is doubled per MI355X_MICROARCH.md §HBM "
+                   "(gfx950 tallies the 128-B requests of 16 B/lane loads at 64 B)"}
+
+
+def counters(directory):
+    path = find(directory, "counter_collection.csv")
+    acc, kernel = collections.defaultdict(list), None
+    if path:
+        for r in csv.DictReader(open(path)):
+            if "train_" in r["Kernel_Name"]:
+                kernel = r["Kernel_Name"]
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {"dispatches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)} for k, v in acc.items()}, kernel
+
+
+for dim in (32, 64, 96, 128, 256, 512):
+    fetch, kernel = counters("pmc_FETCH_SIZE_%d" % dim)
+    write, _ = counters("pmc_WRITE_SIZE_%d" % dim)
+    if "FETCH_SIZE" not in fetch or "WRITE_SIZE" not in write:
+        continue
+    f, w = fetch["FETCH_SIZE"]["mean"] * 1024, write["WRITE_SIZE"]["mean"] * 1024
+    algorithmic = (8 * dim * 3 + 16) * 100000
+    entry = {"kernel": kernel, "FETCH_SIZE": fetch["FETCH_SIZE"], "WRITE_SIZE": write["WRITE_SIZE"],
+             "hbm_read_bytes_per_launch_corrected": 2 * f, "hbm_write_bytes_per_launch": w,
+             "traffic_bytes_per_launch": 2 * f + w, "algorithmic_bytes_per_launch": algorithmic,
+             "traffic_over_algorithmic": (2 * f + w) / algorithmic}
+    if dim == 128:
+        l2, _ = counters("pmc_L2_128")
+        if "TCC_HIT_sum" in l2:
+            entry.update(l2)
+            entry["l2_hit_rate"] = l2["TCC_HIT_sum"]["mean"] / (l2["TCC_HIT_sum"]["mean"] + l2["TCC_MISS_sum"]["mean"])
+        out = dict(by_dim, **entry)
+        json.dump(out, open(os.path.join(DST, "pmc_summary_bench_n1.json"), "w"), indent=1)
+    by_dim["dim_%d" % dim] = entry
+    print("dim %d: traffic / algorithmic = %.3f" % (dim, entry["traffic_over_algorithmic"]))
+if len(by_dim) > 2:
+    json.dump(by_dim, open(os.path.join(DST, "pmc_summary_by_dim.json"), "w"), indent=1)
+
+# ---- marker trace of an end-to-end run: roctx ranges next to the kernels ------------------------------------------------
+marker, kernels = find("prof_marker", "marker_api_trace.csv"), find("prof_marker", "kernel_trace.csv")
+if marker and kernels:
+    ranges = [r for r in csv.DictReader(open(marker))]
+    kernel_rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(kernels)))
+    t0 = min([int(r["Start_Timestamp"]) for r in ranges] + [k[0] for k in kernel_rows])
+    per_name = collections.defaultdict(lambda: {"count": 0, "total_ms": 0.0})
+    timeline = []
+    for r in sorted(ranges, key=lambda r: int(r["Start_Timestamp"])):
+        name = r.get("Function") or r.get("Message") or r.get("Name") or "?"
+        a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        per_name[name]["count"] += 1
+        per_name[name]["total_ms"] += (b - a) / 1e6
+        if len(timeline) < 80:
+            timeline.append({"range": name, "thread": r.get("Thread_Id"), "start_ms": (a - t0) / 1e6, "end_ms": (b - t0) / 1e6})
+    busy = collections.Counter()
+    for a, b, name in kernel_rows:
+        busy[name.split("(")[0][:60]] += (b - a) / 1e6
+    out = {"command": "rocprofv3 --marker-trace --kernel-trace -- python scripts/quick_start.py (configs[0] end to end)",
+           "ranges": per_name, "kernel_busy_ms": dict(busy.most_common(8)),
+           "first_kernel_ms": (kernel_rows[0][0] - t0) / 1e6, "last_kernel_ms": (kernel_rows[-1][1] - t0) / 1e6,
+           "timeline_first_80_ranges": timeline}
+    json.dump(out, open(os.path.join(DST, "marker_trace_summary_e2e.json"), "w"), indent=1)
+    print("marker ranges:", {k: v["count"] for k, v in per_name.items()})
