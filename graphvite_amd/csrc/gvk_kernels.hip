@@ -863,16 +863,20 @@ __global__ void __launch_bounds__(kBlock) sample_walks_kernel(const gvk_walk_gra
 }
 
 // Random walks for SEVERAL partitions: a walk yields pairs for every (head partition, tail partition) block, so every
-// pair is binned — block b = part[head] * P + part[tail], slot = atomic counter of b — into the pool of its block
-// (GraphSampler::sample_random_walk's per-block pools, graph.cuh:357-373, filled by GPU threads instead of CPU
-// threads).  Pairs for a block whose pool is full, or which this call does not collect, are dropped, as the reference
-// drops them (solver.h:1045-1052).  counters[b] keeps counting past the capacity, so the caller sees each block's share.
+// pair is binned into the pool of its block, b = part[head] * P + part[tail] (GraphSampler::sample_random_walk's
+// per-block pools, graph.cuh:357-373, filled by GPU threads instead of CPU threads).  Pairs for a block whose pool is
+// full, or which this call does not collect, are dropped, as the reference drops them (solver.h:1045-1052).
+// A pool is cut into `stripes` stripes with one slot counter each and a wavefront appends to stripe (wavefront id mod
+// stripes): a single counter per block would take every atomic of the launch on P * P addresses (measured: 0.36 G
+// pairs/s at 16 blocks), striped they spread over a few hundred times as many.  counters[b][stripe] keeps counting
+// past the stripe's capacity, so the caller sees each block's share and which stripes are full.
+
 struct BlockPools {
     u32x2 *pools;
     const uint64_t *offsets;  // [P * P] first pair of the block's pool, or ~0: not collected
-    uint32_t *counters;       // [P * P]
+    uint32_t *counters;       // [P * P][stripes]
     const int32_t *part;      // [num_vertex]
-    uint32_t capacity, sb;
+    uint32_t capacity, stripes, stripe_capacity, sb;
     int P;
 };
 
@@ -881,15 +885,16 @@ __global__ void __launch_bounds__(kBlock) sample_walks_blocks_kernel(const gvk_w
                                                                      uint64_t num_walks) {
     const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (t >= num_walks) return;
-    const uint32_t stride = b.capacity / b.sb;
+    const uint32_t stripe = (uint32_t)((t / 64) % b.stripes), stride = b.capacity / b.sb;
     walk_pairs(g, seed, first_walk + t, pairs_per_walk, L, aug, [&](uint32_t head, uint32_t tail, uint64_t) {
         const int block = b.part[head] * b.P + b.part[tail];
         const uint64_t first = b.offsets[block];
         if (first == ~(uint64_t)0) return;
-        const uint32_t slot = atomicAdd(b.counters + block, 1u);
-        if (slot >= b.capacity) return;
+        const uint32_t slot = atomicAdd(b.counters + (size_t)block * b.stripes + stripe, 1u);
+        if (slot >= b.stripe_capacity) return;
+        const uint32_t position = stripe * b.stripe_capacity + slot;
         u32x2 record = {g.local[tail], g.local[head]};
-        __builtin_nontemporal_store(record, b.pools + first + (slot % b.sb * stride + slot / b.sb));
+        __builtin_nontemporal_store(record, b.pools + first + (position % b.sb * stride + position / b.sb));
     });
 }
 
@@ -998,15 +1003,19 @@ struct Choice {
     bool runs = false, fixed_k = false, reference_shape = false;
 };
 
-// Pairs per lane group and wavefront of train_segment_kernel (D).  One step (a segment of 64 / lanes pairs) is the
-// fastest shape at every dim.  Tables of less than 16 MiB — a BlogCatalog-sized graph — are cache-resident
-// and every batch touches every hub row hundreds of times: there the longest segment the registers allow is used, so
-// that up to 16 consecutive updates of a row survive per wavefront; that is what keeps link-prediction AUC within
-// 0.002 of sequential training on such graphs, and at that size the kernel time does not matter.
+// Which kernel trains SGD / one negative, by the size of the head table:
+//   * cache-resident tables (< 16 MiB: a BlogCatalog-sized graph).  Every batch touches every hub row hundreds of
+//     times; the solver regroups the batches and train_segment_kernel chains the longest run the registers allow
+//     (D = 4: 16 pairs per wavefront up to dim 128), so that up to 16 consecutive updates of a row survive per
+//     wavefront — that keeps link-prediction AUC within 0.002 of sequential training there, and at that size the
+//     kernel time does not matter;
+//   * everything larger: the per-pair kernel (returns 0).  Chaining costs nothing when rows come from HBM (51.4-53.3 us
+//     against 51.7-52.6 us per batch on 512 MB tables) but a quarter of the rate when they come from the caches (32 MB
+//     shards, regrouped: 42.5 against 34.1 us), and conflicts are rare enough there that it changes no AUC.
 constexpr size_t kResidentTableBytes = (size_t)16 << 20;
 
 int default_steps(int dim, uint32_t rows) {
-    if ((size_t)rows * dim * 4 >= kResidentTableBytes) return 1;
+    if ((size_t)rows * dim * 4 >= kResidentTableBytes) return 0;
     return dim <= 128 ? 4 : (dim == 256 ? 2 : 1);
 }
 
@@ -1051,10 +1060,11 @@ Choice choose_train(int dim, int opt, int k, bool explicit_negatives, int batch_
                                                                                     : default_lanes(dim);
     const bool shipped_shape = opt == GVK_SGD && k == 1 && c.lanes == default_lanes(dim);
     const bool draw = !explicit_negatives;
-    // SGD with one negative (every shipped configuration of the reference) on the default lane layout: a wavefront
-    // owns a segment (train_segment_kernel).  GVK_TUNE_VARIANT 1, 2 and 4 select the other builds for A/B.
-    if (shipped_shape && g_variant == 0 && g_generation == 0) {
-        c.steps = g_segment_steps ? g_segment_steps : default_steps(dim, rows);
+    // SGD with one negative (every shipped configuration of the reference) on the default lane layout: small tables
+    // get train_segment_kernel (a wavefront owns a segment), see default_steps; GVK_TUNE_SEGMENT_STEPS forces it at any
+    // size, GVK_TUNE_VARIANT 1, 2 and 4 select the other builds for A/B.
+    c.steps = g_variant == 0 && g_generation == 0 && shipped_shape ? (g_segment_steps ? g_segment_steps : default_steps(dim, rows)) : 0;
+    if (c.steps > 0) {
 #define GVK_SEGMENT(D, GG) \
     case D: c.kernel = pick_segment<D, GG>(c.steps, draw, want_loss || !g_skip_loss); break;
         switch (dim) {
@@ -1249,7 +1259,8 @@ int gvk_sample_walks(void *stream, const gvk_walk_graph *graph, uint64_t seed, u
 
 int gvk_sample_walks_blocks(void *stream, const gvk_walk_graph *graph, const int32_t *part, int num_partition, uint64_t seed,
                             uint64_t first_walk, uint64_t num_walks, uint32_t *pools, const uint64_t *offsets,
-                            uint32_t *counters, uint32_t capacity, int walk_length, int augmentation_step, int shuffle_base) {
+                            uint32_t *counters, uint32_t capacity, int num_stripe, int walk_length, int augmentation_step,
+                            int shuffle_base) {
     if (num_walks == 0) return GVK_OK;
     if (!graph || !part || !pools || !offsets || !counters) return fail(GVK_EINVAL, "gvk_sample_walks_blocks: null pointer");
     if (!graph->flat_offsets || !graph->edges_uv || !graph->edge_table || !graph->neighbor_table || !graph->local ||
@@ -1264,13 +1275,15 @@ int gvk_sample_walks_blocks(void *stream, const gvk_walk_graph *graph, const int
         return fail(GVK_EINVAL, "`random_walk_length` should be no less than `augmentation_step`");
     if (shuffle_base < 1 || capacity % (uint32_t)shuffle_base)
         return fail(GVK_EINVAL, "gvk_sample_walks_blocks: pool size must be a multiple of the shuffle base");
+    if (num_stripe < 1 || capacity % (uint32_t)num_stripe)
+        return fail(GVK_EINVAL, "gvk_sample_walks_blocks: the number of stripes must divide the pool size");
     const uint64_t per_walk = (uint64_t)augmentation_step * walk_length -
                               (uint64_t)augmentation_step * (augmentation_step - 1) / 2;
     const uint64_t blocks = (num_walks + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffu) return fail(GVK_EINVAL, "gvk_sample_walks_blocks: too many walks for one call");
     BlockPools b;
     b.pools = reinterpret_cast<u32x2 *>(pools), b.offsets = offsets, b.counters = counters, b.part = part;
-    b.capacity = capacity, b.sb = (uint32_t)shuffle_base, b.P = num_partition;
+    b.capacity = capacity, b.stripes = (uint32_t)num_stripe, b.stripe_capacity = capacity / (uint32_t)num_stripe, b.sb = (uint32_t)shuffle_base, b.P = num_partition;
     hipLaunchKernelGGL(sample_walks_blocks_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, *graph, b, seed,
                        first_walk, walk_length, augmentation_step, per_walk, num_walks);
     return check_launch("gvk_sample_walks_blocks");

@@ -689,10 +689,11 @@ int gvx_solver::episode_loop() {
                                 size_string((double)pool_elems * 4).c_str());
             }
     }
-    // regroup when the tables are cache-resident (every batch hits the hub rows hundreds of times; adjacent same-head
-    // samples are then trained as runs, which keeps training close to sequential: DESIGN.md §3.1.1, §7); larger tables
-    // keep the sampler's order, as the reference does; not at dim 32
-    const bool grouped = dim >= 64 && (size_t)part_rows * dim * 4 < ((size_t)16 << 20);
+    // regroup by table size, at dim >= 64: cache-resident tables (< 16 MiB) always — adjacent
+    // same-head samples are then trained as runs, which keeps training close to sequential (§7); shard-sized tables
+    // (< 256 MiB) for independent edge draws — a shared head row becomes one fetch; larger tables keep the sampler's order
+    const size_t table_bytes = (size_t)part_rows * dim * 4;
+    const bool grouped = dim >= 64 && (table_bytes < ((size_t)16 << 20) || (table_bytes < ((size_t)256 << 20) && mode == GVS_MODE_EDGE));
     const int row_bits = std::max(32 - __builtin_clz(std::max(part_rows, 2u) - 1), 1);
     const uint64_t per_episode = (uint64_t)num_step * episode_size * config.positive_reuse * W;
     int rc = fill(sets[0]);

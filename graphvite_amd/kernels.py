@@ -248,24 +248,32 @@ class HipKernels(object):
             return 0
         aug, L = int(augmentation_step), int(walk_length)
         per_walk = aug * L - aug * (aug - 1) // 2
-        counters = torch.zeros(P * P, dtype=torch.int32, device=dev)
-        walks = -(-capacity * P * P // per_walk)
+        # stripes: slot counters per pool (one per wavefront-id class) — the largest divisor of the capacity up to 256
+        stripes = max(d for d in range(1, 257) if capacity % d == 0)
+        stripe_capacity = capacity // stripes
+        counters = torch.zeros(P * P * stripes, dtype=torch.int32, device=dev)
+        every = 64 * stripes  # walks per launch: every stripe gets the same number of wavefronts
+        walks = (-(-capacity * P * P // per_walk) // every + 1) * every
         used = 0
+        self.walk_rounds = []  # walks launched per round of the last call (diagnostics)
         for _ in range(max_rounds):
+            self.walk_rounds.append(walks)
             rc = self.lib.gvk_sample_walks_blocks(self._stream(pools), C.byref(desc), _ptr(part), P, seed, first_walk + used,
-                                                  walks, _ptr(pools), _ptr(offsets), _ptr(counters), capacity, L, aug,
-                                                  shuffle_base)
+                                                  walks, _ptr(pools), _ptr(offsets), _ptr(counters), capacity, stripes, L,
+                                                  aug, shuffle_base)
             _lib.check(rc, "gvk_sample_walks_blocks")
             used += walks
-            count = counters.cpu().numpy().astype(np.int64)  # fences the stream: a handful of round trips per episode
-            deficit = np.maximum(capacity - count, 0)[wanted]
+            # fences the stream: a handful of round trips per episode, while the GPU trains the episode before
+            count = counters.cpu().numpy().astype(np.int64).reshape(P * P, stripes)[wanted]
+            deficit = np.maximum(stripe_capacity - count, 0)
             if not deficit.any():
                 return used
-            share = count[wanted] / float(used * per_walk)  # fraction of all pairs that fall into each wanted block
+            share = count / float(used * per_walk)  # fraction of all pairs that fell into each wanted stripe
             if (share[deficit > 0] == 0).any() and used * per_walk > 64 * capacity * P * P:
                 raise ValueError("a block of the partition grid receives no random-walk pairs; use fewer partitions")
-            need = deficit[deficit > 0] / np.maximum(share[deficit > 0], 1.0 / (64 * P * P)) / per_walk
-            walks = int(need.max() * 1.05) + 64
+            floor = 1.0 / (64 * P * P * stripes)
+            need = deficit[deficit > 0] / np.maximum(share[deficit > 0], floor) / per_walk
+            walks = (int(need.max() * 1.1) // every + 1) * every
         raise RuntimeError("gvk_sample_walks_blocks: pools not full after %d rounds" % max_rounds)
 
     def set_lanes_per_pair(self, lanes):

@@ -154,9 +154,10 @@ class GraphSolver(object):
     the GPU) and `pair_order` — "sampled": a batch is trained in the order the samplers produced it; "grouped": the
     pairs of a batch that share a head row are made adjacent on the device first (gvk_group_pairs; same samples, same
     batches; a row shared by k samples is fetched from HBM once and the k samples are trained as runs, one after the
-    other on one copy of the row); auto (default): grouped at dim >= 64 when a partition's table is cache-resident
-    (< 16 MiB: every batch hits the hub rows hundreds of times and the runs keep training close to sequential), the
-    sampler's order otherwise.
+    other on one copy of the row when the table is small); auto (default), at dim >= 64: grouped when a partition's
+    table is cache-resident (< 16 MiB: every batch hits the hub rows hundreds of times and the runs keep training
+    close to sequential), grouped for independent edge draws up to 256 MiB (shards of multi-GPU runs: a shared head row
+    becomes one fetch), the sampler's order otherwise.
     """
 
     available_dims = (32, 64, 96, 128, 256, 512)  # src/graphvite.cu:52-59
@@ -525,15 +526,20 @@ class GraphSolver(object):
                 mode = "biased_reject"
         self._mode = mode
         if self._pair_order_request == auto:
-            # Regroup (gvk_group_pairs) when the tables are cache-resident (< 16 MiB: a BlogCatalog-sized graph): every
-            # batch then hits every hub row hundreds of times, and with same-head samples adjacent the kernel trains
-            # them as runs of up to 16 consecutive updates per wavefront — that keeps link-prediction AUC within 0.002 of
-            # sequential training there, and at that size the pass costs nothing that matters.  Larger
-            # tables keep the sampler's order, as the reference does: conflicts are rare, the measured kernel gain of
-            # regrouping is within run-to-run noise and the pass is not free.  Not at dim 32 (a batch
-            # trains in 16 us there; the pass, which costs the same at every dim, would take a third of the GPU).
-            resident = self._part_size * self.dim * 4 < MiB(16)
-            self.pair_order = "grouped" if resident and self.dim >= 64 and self.device.type == "cuda" else "sampled"
+            # Regroup (gvk_group_pairs) by the size of a partition's table, at dim >= 64:
+            #   < 16 MiB   (a BlogCatalog-sized graph) every batch hits every hub row hundreds of times; with same-head
+            #              samples adjacent the kernel trains them as runs of up to 16 consecutive updates per wavefront,
+            #              which keeps link-prediction AUC within 0.002 of sequential training; any sampler;
+            #   < 256 MiB  (the shards of multi-GPU runs) tables live in L2 / Infinity Cache: adjacent same-head samples
+            #              make a head row one fetch (2.3 -> 2.9 G edge-samples/s per GPU on 32 MB shards), AUC unchanged;
+            #              independent edge draws only — random-walk pools come in the reference's pseudo-shuffled walk
+            #              order, which already has locality (DeepWalk end to end -16 % when regrouped);
+            #   larger     the sampler's order, as the reference: the gain is within run-to-run noise and the pass is
+            #              not free (-12 % on a Friendster shard).
+            # Not at dim 32 (a batch trains in 16 us there; the pass costs the same at every dim).
+            table = self._part_size * self.dim * 4
+            regroup = table < MiB(16) or (table < MiB(256) and mode == "edge")
+            self.pair_order = "grouped" if regroup and self.dim >= 64 and self.device.type == "cuda" else "sampled"
         if self.device_sampling:
             return  # positives are drawn on the device: no CPU sampler needed
         if self._sampler is None:

@@ -96,9 +96,8 @@ typedef struct {
 /* One batch of negative-sampling SGD: for every {tail, head} pair, num_negative negative steps then the
  * positive step on a progressively updated copy of vertex[head]; context rows are updated in place,
  * Hogwild (no atomics), loss[s] = sample loss / (1 + num_negative * negative_weight).
- * With SGD and num_negative == 1, pairs that sit next to each other in the batch, share a head row and fall into the
- * same wavefront's segment (4 consecutive pairs at dim 128; 16 when the head table is smaller than 16 MiB) are trained
- * as one run — one after the other on one
+ * With SGD, num_negative == 1 and a head table smaller than 16 MiB, pairs that sit next to each other in the batch,
+ * share a head row and fall into the same wavefront's segment (16 consecutive pairs at dim 128) are trained as one run — one after the other on one
  * register copy of the row, as consecutive iterations of one warp in the reference (include/instance/gpu/graph.cuh:
  * 54-94); samples keep their own negatives and loss slots.  `stream` is a hipStream_t (NULL = default stream).  `batch_id` only feeds the negative draw. */
 int gvk_train(void *stream, int dim, const gvk_optimizer *optimizer, const gvk_tables *tables,
@@ -172,15 +171,17 @@ int gvk_sample_walks(void *stream, const gvk_walk_graph *graph, uint64_t seed, u
  * partition) block, so each pair is binned into the pool of block b = part[head] * P + part[tail] — the per-block pools
  * of GraphSampler::sample_random_walk (include/instance/graph.cuh:357-373) filled by GPU threads.  Walk w (= first_walk +
  * thread) draws exactly as in gvk_sample_walks and produces aug * L - aug * (aug - 1) / 2 pairs.  Block b's pool is
- * pools + 2 * offsets[b] (offsets in pairs; ~0 = this call does not collect b), capacity pairs long; a pair takes slot
- * s = atomic increment of counters[b] and is stored at position s % sb * (capacity / sb) + s / sb; pairs beyond the
- * capacity are dropped (solver.h:1045-1052) but still counted, so counters[] tells the caller every block's share and
- * which pools are full.  The caller zeroes counters[] once and repeats the call (advancing first_walk) until the pools
- * it needs are full.  Which pairs land in which slot depends on the order the GPU retires the atomics; the MULTISET of
- * pairs of a pool that did not overflow is a pure function of (seed, walk range). */
+ * pools + 2 * offsets[b] (offsets in pairs; ~0 = this call does not collect b), capacity pairs long, cut into num_stripe
+ * stripes (any divisor of capacity; a few hundred keeps the atomics off each other) of capacity / num_stripe slots with
+ * one counter each — counters[b * num_stripe + stripe]; a wavefront appends to stripe (wavefront index mod num_stripe):
+ * slot s of stripe k is position p = k * stripe capacity + s, stored at p % sb * (capacity / sb) + p / sb.  Pairs beyond a stripe's capacity are dropped (solver.h:1045-1052) but still counted, so the counters tell the
+ * caller every block's share and which stripes are full.  The caller zeroes the counters once and repeats the call
+ * (advancing first_walk) until the pools it needs are full.  Which pair lands in which slot depends on the order the
+ * GPU retires the atomics; the MULTISET of pairs of a stripe that did not overflow is a pure function of (seed, walks). */
 int gvk_sample_walks_blocks(void *stream, const gvk_walk_graph *graph, const int32_t *part, int num_partition, uint64_t seed,
                             uint64_t first_walk, uint64_t num_walks, uint32_t *pools, const uint64_t *offsets,
-                            uint32_t *counters, uint32_t capacity, int walk_length, int augmentation_step, int shuffle_base);
+                            uint32_t *counters, uint32_t capacity, int num_stripe, int walk_length, int augmentation_step,
+                            int shuffle_base);
 
 /* Optional pool pre-pass: inside each of the num_batch batches (batch_size {tail, head} records each) of pool_in, make
  * the records that share a head row adjacent, writing the regrouped pool to pool_out (distinct from pool_in).  Each
@@ -202,8 +203,8 @@ int gvk_alias_build(const float *weights, size_t n, float *prob, void *alias, in
 /* Tuning knobs for A/B measurement (bench.py --variant); they never change results beyond
  * floating-point summation order.  Returns GVK_EINVAL for an unknown key or unsupported value. */
 #define GVK_TUNE_LANES_PER_PAIR 1 /* 0 = per-dim default; else 8, 16, 32 or 64 */
-#define GVK_TUNE_VARIANT 2        /* 0 = default: SGD with one negative runs train_segment_kernel (a wavefront owns a
-                                     segment of the batch), everything else the per-pair kernel;
+#define GVK_TUNE_VARIANT 2        /* 0 = default: the per-pair kernel, except SGD with one negative on a head table smaller
+                                     than 16 MiB, which runs train_segment_kernel (a wavefront owns a segment of the batch);
                                      1 = the per-pair kernel, generic build (run-time k); 2 = the per-pair kernel with
                                      compile-time k; 3 = dim-128 SGD in the reference's kernel shape (one wavefront per
                                      pair, vertex row in LDS, 8192 x 512 grid-stride launch); 4 = train_runs_kernel (one
@@ -215,8 +216,9 @@ int gvk_alias_build(const float *weights, size_t n, float *prob, void *alias, in
                                      (per-pair kernel), the concurrency structure of the reference's launch on a card
                                      that keeps C warps resident; 0 = one launch per batch (default) */
 #define GVK_TUNE_SEGMENT_STEPS 5  /* train_segment_kernel: pairs per lane group and wavefront (a wavefront owns 64 / lanes *
-                                     steps consecutive pairs) — 0 = default: 1 step, or the longest build (4 up to dim 128)
-                                     when the head table is smaller than 16 MiB; else 1, 2 or 4 */
+                                     steps consecutive pairs) — 0 = default: the longest build (4 up to dim 128) when the
+                                     head table is smaller than 16 MiB, the per-pair kernel otherwise; 1, 2 or 4 = that
+                                     many steps at any table size */
 #define GVK_TUNE_SKIP_LOSS 6      /* 1 (default) = gvk_train_episode does not compute the per-sample loss of batches whose
                                      loss[] a later batch of the same call overwrites; 0 = every batch computes it */
 int gvk_set_tuning(int key, int value);

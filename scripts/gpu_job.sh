@@ -18,6 +18,10 @@ if [[ $WHAT == *measure* ]]; then
   for d in 32 64 96 256 512; do
     python bench.py --dim $d --no-cpu-baseline --no-end-to-end --steps 1000 --warmup 100
   done > gpurun_out/dim_sweep.jsonl 2> gpurun_out/dim_sweep.err
+  # the shard sizes of multi-GPU runs on the one GPU (what a GPU of an 8-GPU run trains: 16 partitions of 32 MB)
+  for parts in 4 8 16; do
+    python bench.py --partitions $parts --no-cpu-baseline --no-end-to-end --steps 1000 --warmup 100
+  done > gpurun_out/shard_sweep.jsonl 2> gpurun_out/shard_sweep.err
 fi
 if [[ $WHAT == *profile* ]]; then
   cd /tmp && export TMPDIR=/tmp

@@ -74,6 +74,7 @@ def main():
     run(graph, "configs[3] per-GPU shape of the 4-GPU run", "node2vec", e, threads, p=0.25, q=0.25, num_partition=4)
     run(graph, "configs[3] per-GPU shape of the 4-GPU run", "node2vec", e, threads, p=0.25, q=0.25, num_partition=4,
         device_sampling=True)
+    run(graph, "configs[2] over 4 partitions on the one GPU", "DeepWalk", e, threads, num_partition=4, device_sampling=True)
     del graph
     if not args.skip_friendster:
         for order in ("sampled", "grouped"):

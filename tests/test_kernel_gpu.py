@@ -198,6 +198,9 @@ def test_segment_kernel_trains_runs_in_sequence(hip, oracle, dim, steps, explici
     hip.set_segment_steps(steps)
     try:
         name = hip.describe_train(dim, "SGD", k, explicit, B, N)
+        if steps == 0:  # the default: the segment kernel on tables below 16 MiB, the per-pair kernel above
+            assert ("train_segment_kernel" in name) == (N * dim * 4 < 16 << 20), name
+            assert "train_kernel<" in hip.describe_train(dim, "SGD", k, explicit, B, 1 << 20)
         if "train_segment_kernel" not in name:
             pytest.skip("no %d-step build at dim %d: %s" % (steps, dim, name))
         segment = int(name.split("> ")[1].split()[0])
@@ -452,30 +455,35 @@ def test_sample_walks_blocks_matches_the_oracle_per_block(hip, oracle, biased):
     want = oracle.sample_walks_device(flat, E, edge_prob, edge_alias, nb_prob, nb_alias, sorted_nb, identity, biased, 0.5,
                                       2.0, seed, first, walks * per_walk, L, aug, 1)  # {tail vertex, head vertex}
     block = part[want[:, 1]].astype(np.int64) * P + part[want[:, 0]]
-    capacity = int(np.bincount(block, minlength=P * P).max()) + 6
-    capacity -= capacity % 3
+    stripes = 5
+    stripe_of = (np.arange(len(want)) // per_walk // 64) % stripes  # a wavefront (64 walks) appends to one stripe
+    per_stripe = max(np.bincount(block[stripe_of == k], minlength=P * P).max() for k in range(stripes))
     sb = 3
+    capacity = (int(per_stripe) + 3) * stripes
+    capacity += -capacity % (sb * stripes)
     where = np.arange(P * P, dtype=np.int64) * capacity
     where[4] = -1  # one block is not collected
     pools = torch.zeros(P * P * capacity * 2, dtype=torch.int32, device=DEV)
-    counters = torch.zeros(P * P, dtype=torch.int32, device=DEV)
+    counters = torch.zeros(P * P * stripes, dtype=torch.int32, device=DEV)
     desc = hip._walk_graph(walk, torch.device(DEV))
     part_dev, where_dev = dev(part.astype(np.int32)), dev(where)
     rc = hip.lib.gvk_sample_walks_blocks(None, C.byref(desc), part_dev.data_ptr(), P, seed, first, walks, pools.data_ptr(),
-                                         where_dev.data_ptr(), counters.data_ptr(), capacity, L, aug, sb)
+                                         where_dev.data_ptr(), counters.data_ptr(), capacity, stripes, L, aug, sb)
     assert rc == 0
     torch.cuda.synchronize()
-    got, count = pools.cpu().numpy().view(np.uint32).reshape(P * P, capacity, 2), counters.cpu().numpy()
+    got = pools.cpu().numpy().view(np.uint32).reshape(P * P, capacity, 2)
+    count = counters.cpu().numpy().reshape(P * P, stripes)
     for b in range(P * P):
-        mine = want[block == b]
         if b == 4:
-            assert count[b] == 0 and not got[b].any()
+            assert not count[b].any() and not got[b].any()
             continue
-        assert count[b] == len(mine)
-        slots = np.arange(len(mine))
-        stored = got[b][slots % sb * (capacity // sb) + slots // sb]
-        expect = np.stack([local[mine[:, 0]], local[mine[:, 1]]], 1)
-        assert sorted(map(tuple, stored.tolist())) == sorted(map(tuple, expect.tolist()))
+        for k in range(stripes):
+            mine = want[(block == b) & (stripe_of == k)]
+            assert count[b, k] == len(mine)
+            position = k * (capacity // stripes) + np.arange(len(mine))
+            stored = got[b][position % sb * (capacity // sb) + position // sb]
+            expect = np.stack([local[mine[:, 0]], local[mine[:, 1]]], 1)
+            assert sorted(map(tuple, stored.tolist())) == sorted(map(tuple, expect.tolist()))
     # the wrapper: small pools, repeated until every collected pool is full; only pairs of the block, local ids
     small = 600
     pools = torch.full((P * P * small * 2,), -1, dtype=torch.int32, device=DEV)
