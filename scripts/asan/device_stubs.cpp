@@ -8,6 +8,8 @@ int gvk_alias_sample(void *, const gvk_alias_entry *, uint32_t, const double *, 
 int gvk_negative_draw(void *, const gvk_alias_entry *, uint32_t, uint64_t, uint32_t, uint32_t *, int, int) { return GVK_EHIP; }
 int gvk_sample_pairs(void *, const gvk_alias_entry *, const uint32_t *, uint32_t, uint64_t, uint64_t, uint32_t *, size_t) { return GVK_EHIP; }
 int gvk_sample_walks(void *, const gvk_walk_graph *, uint64_t, uint64_t, uint32_t *, size_t, int, int, int) { return GVK_EHIP; }
+int gvk_sample_walks_blocks(void *, const gvk_walk_graph *, const int32_t *, int, uint64_t, uint64_t, uint64_t, uint32_t *, const uint64_t *, uint32_t *, uint32_t, int, int, int, int) { return GVK_EHIP; }
+int gvk_describe_train(int, int, int, int, int, uint32_t, char *, size_t) { return GVK_EHIP; }
 int gvk_group_pairs(void *, const uint32_t *, uint32_t *, void *, size_t *, int, int, int) { return GVK_EHIP; }
 int gvk_set_tuning(int, int) { return GVK_OK; }
 }

@@ -7,8 +7,9 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${TMPDIR:-/tmp}/gvk_asan
 mkdir -p $OUT
 g++ -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -std=c++17 -fPIC -shared -pthread \
-    -I$ROOT/include -I$ROOT/graphvite_amd/csrc $ROOT/graphvite_amd/csrc/gvs_host.cpp $ROOT/graphvite_amd/csrc/gvk_host.cpp \
-    $ROOT/scripts/asan/device_stubs.cpp -o $OUT/libgvk.so
+    -I$ROOT/include -I$ROOT/graphvite_amd/csrc -I/opt/rocm/include $ROOT/graphvite_amd/csrc/gvs_host.cpp \
+    $ROOT/graphvite_amd/csrc/gvk_host.cpp $ROOT/scripts/asan/device_stubs.cpp -L/opt/rocm/lib -lroctx64 \
+    -Wl,-rpath,/opt/rocm/lib -o $OUT/libgvk.so
 GCC_LIB=$(dirname $(g++ -print-file-name=libasan.so))
 run() {
   LD_PRELOAD=$GCC_LIB/libasan.so:$GCC_LIB/libubsan.so ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 python -c "
