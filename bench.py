@@ -477,7 +477,10 @@ def main(argv=None, stand_in_kernels=None):
         del landed, work, pools, session
         solver.clear()
         torch.cuda.empty_cache()
-        result["end_to_end"] = end_to_end(args, gv, graph, world, threads, partitions)
+        try:
+            result["end_to_end"] = end_to_end(args, gv, graph, world, threads, partitions)
+        except Exception as error:  # the headline measurement above stands on its own; say what happened to this one
+            result["end_to_end"] = {"error": "%s: %s" % (type(error).__name__, error)}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

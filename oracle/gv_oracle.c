@@ -36,8 +36,10 @@
  *   - partition, schedule, edge sampler (pools record for record), the alias tables of the
  *     walk samplers: oracle/ref_solver_harness.cpp -> _ref/libgvref_solver.so (the
  *     reference's solver front end over an emulated CUDA runtime / cuRAND, ref_stubs/).
- * The walk samplers consume their uniforms in lockstep order here (see gvo_sample_walks), not
- * in the reference's walk-by-walk order: pinned in distribution, not record for record.
+ * The walk samplers consume their uniforms in lockstep order (gvo_sample_walks, what the product's samplers do) or
+ * walk by walk (gvo_sample_walks_reference_order): the latter reproduces the pools of the reference's own
+ * sample_random_walk / sample_biased_random_walk record for record, the former is the same walk logic with the
+ * i.i.d. uniforms taken in another order (and is what the product is pinned against, bit for bit).
  * gvo_sample_pairs / gvo_sample_walks_device restate device samplers the reference lacks.
  */
 #include <math.h>
@@ -471,12 +473,14 @@ size_t gvo_sample_edges(const uint32_t *edges_uv, const float *edge_prob, const 
 
 /* Random-walk sampler (biased = 0: per-vertex tables indexed by CSR slot; biased = 1: node2vec
  * per-edge tables, table of directed edge e starts at ee_offsets[e] and has deg(v) entries). */
-size_t gvo_sample_walks(int biased, const uint32_t *edges_uv, const float *edge_prob, const uint64_t *edge_alias,
-                        uint64_t num_edge_entries, const uint64_t *flat_offsets /* [N+1] */, const float *nb_prob,
-                        const uint32_t *nb_alias, const uint64_t *ee_offsets, const int32_t *part,
-                        const uint32_t *local, int P, uint32_t **pools, int pool_size, int start, int end,
-                        int walk_length, int walk_batch, int augmentation_step, int shuffle_base, int tail_filter,
-                        const uint32_t *sorted_nb, float p, float q, const double *rnd, size_t n_rnd) {
+static size_t gvo_sample_walks_in_order(int reference_order, int biased, const uint32_t *edges_uv, const float *edge_prob,
+                                       const uint64_t *edge_alias, uint64_t num_edge_entries,
+                                       const uint64_t *flat_offsets /* [N+1] */, const float *nb_prob,
+                                       const uint32_t *nb_alias, const uint64_t *ee_offsets, const int32_t *part,
+                                       const uint32_t *local, int P, uint32_t **pools, int pool_size, int start, int end,
+                                       int walk_length, int walk_batch, int augmentation_step, int shuffle_base,
+                                       int tail_filter, const uint32_t *sorted_nb, float p, float q, const double *rnd,
+                                       size_t n_rnd) {
     gvo_rand g = {rnd, n_rnd, 0};
     if (start >= end) return 0;
     if (pool_size % shuffle_base) return (size_t)-2;
@@ -501,7 +505,30 @@ size_t gvo_sample_walks(int biased, const uint32_t *edges_uv, const float *edge_
          * live walk, ...), where the reference finishes walk i before starting walk i + 1; the walk itself —
          * start edge by weight, next node from the vertex / edge alias table, stop at a node without out-edges —
          * is the reference's.  Only the order in which the i.i.d. uniforms are consumed differs. */
-        for (int i = 0; i < walk_batch; i++) {
+        /* reference_order: the reference's own order (graph.cuh:320-348, 399-424) — walk i is finished before walk
+         * i + 1 starts, two uniforms per alias draw, taken as they come.  Same walks as below for the same uniforms
+         * per draw; used to pin this restatement record for record against pools the reference's samplers filled. */
+        for (int i = 0; reference_order && i < walk_batch; i++) {
+            uint32_t *chain = chains + (size_t)i * (L + 1);
+            double r1 = gvo_next(&g), r2 = gvo_next(&g);
+            uint64_t edge = gvo_alias_sample(edge_prob, edge_alias, 8, num_edge_entries, r1, r2);
+            uint32_t current = edges_uv[2 * edge + 1];
+            chain[0] = edges_uv[2 * edge], chain[1] = current;
+            lengths[i] = L;
+            for (int j = 2; j <= L; j++) {
+                uint64_t deg = flat_offsets[current + 1] - flat_offsets[current];
+                if (!deg) {
+                    lengths[i] = j - 1;
+                    break;
+                }
+                r1 = gvo_next(&g), r2 = gvo_next(&g);
+                uint64_t base = biased == 1 ? ee_offsets[edge] : flat_offsets[current];
+                edge = flat_offsets[current] + (uint32_t)gvo_alias_sample(nb_prob + base, nb_alias + base, 4, deg, r1, r2);
+                current = edges_uv[2 * edge + 1];
+                chain[j] = current;
+            }
+        }
+        for (int i = 0; !reference_order && i < walk_batch; i++) {
             uint32_t *chain = chains + (size_t)i * (L + 1);
             double r1 = gvo_next(&g), r2 = gvo_next(&g);
             edge_ids[i] = gvo_alias_sample(edge_prob, edge_alias, 8, num_edge_entries, r1, r2);
@@ -510,7 +537,7 @@ size_t gvo_sample_walks(int biased, const uint32_t *edges_uv, const float *edge_
             chain[1] = currents[i];
             lengths[i] = L;
         }
-        for (int j = 2; j <= L; j++) {
+        for (int j = 2; !reference_order && j <= L; j++) {
             int num_pending = 0;
             for (int i = 0; i < walk_batch; i++) {
                 if (lengths[i] < L) continue; /* stopped earlier */
@@ -576,6 +603,32 @@ size_t gvo_sample_walks(int biased, const uint32_t *edges_uv, const float *edge_
     free(proposals);
     free(pending);
     return g.pos > g.n ? (size_t)-1 : g.pos;
+}
+
+size_t gvo_sample_walks(int biased, const uint32_t *edges_uv, const float *edge_prob, const uint64_t *edge_alias,
+                        uint64_t num_edge_entries, const uint64_t *flat_offsets, const float *nb_prob,
+                        const uint32_t *nb_alias, const uint64_t *ee_offsets, const int32_t *part,
+                        const uint32_t *local, int P, uint32_t **pools, int pool_size, int start, int end,
+                        int walk_length, int walk_batch, int augmentation_step, int shuffle_base, int tail_filter,
+                        const uint32_t *sorted_nb, float p, float q, const double *rnd, size_t n_rnd) {
+    return gvo_sample_walks_in_order(0, biased, edges_uv, edge_prob, edge_alias, num_edge_entries, flat_offsets, nb_prob,
+                                     nb_alias, ee_offsets, part, local, P, pools, pool_size, start, end, walk_length,
+                                     walk_batch, augmentation_step, shuffle_base, tail_filter, sorted_nb, p, q, rnd, n_rnd);
+}
+
+/* The same sampler consuming its uniforms walk by walk, as GraphSampler::sample_random_walk (biased 0) and
+ * sample_biased_random_walk (biased 1) do (graph.cuh:376-450, 298-373); no rejection mode (biased 2 is this repo's). */
+size_t gvo_sample_walks_reference_order(int biased, const uint32_t *edges_uv, const float *edge_prob,
+                                        const uint64_t *edge_alias, uint64_t num_edge_entries,
+                                        const uint64_t *flat_offsets, const float *nb_prob, const uint32_t *nb_alias,
+                                        const uint64_t *ee_offsets, const int32_t *part, const uint32_t *local, int P,
+                                        uint32_t **pools, int pool_size, int start, int end, int walk_length,
+                                        int walk_batch, int augmentation_step, int shuffle_base, const double *rnd,
+                                        size_t n_rnd) {
+    if (biased != 0 && biased != 1) return (size_t)-2;
+    return gvo_sample_walks_in_order(1, biased, edges_uv, edge_prob, edge_alias, num_edge_entries, flat_offsets, nb_prob,
+                                     nb_alias, ee_offsets, part, local, P, pools, pool_size, start, end, walk_length,
+                                     walk_batch, augmentation_step, shuffle_base, -1, NULL, 1.0f, 1.0f, rnd, n_rnd);
 }
 
 static int gvo_has_neighbor(const uint32_t *edges_uv, const uint64_t *flat_offsets, uint32_t x, uint32_t u) {

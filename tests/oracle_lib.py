@@ -78,6 +78,11 @@ class Oracle(object):
                                          C.c_void_p, _i32p, _u32p, C.c_int, C.POINTER(C.c_void_p), C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                          C.c_float, C.c_float, _f64p, C.c_size_t]
+        lib.gvo_sample_walks_reference_order.restype = C.c_size_t
+        lib.gvo_sample_walks_reference_order.argtypes = [C.c_int, _u32p, _f32p, _u64p, C.c_uint64, _u64p, _f32p, _u32p,
+                                                         C.c_void_p, _i32p, _u32p, C.c_int, C.POINTER(C.c_void_p), C.c_int,
+                                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f64p,
+                                                         C.c_size_t]
         lib.gvo_edge_edge_weights.restype = None
         lib.gvo_edge_edge_weights.argtypes = [_u32p, _f32p, _u64p, C.c_uint64, C.c_float, C.c_float, _f32p]
 
@@ -205,6 +210,18 @@ class Oracle(object):
                                       None if sorted_nb is None else sorted_nb.ctypes.data_as(C.c_void_p), p, q, rnd,
                                       rnd.size)
         assert n < C.c_size_t(-2).value, "uniform stream too short / bad shuffle base"
+        return n
+
+    def sample_walks_reference_order(self, biased, edges_uv, edge_prob, edge_alias, flat_offsets, nb_prob, nb_alias,
+                                     ee_offsets, part, local, P, pools, pool_size, start, end, walk_length, walk_batch,
+                                     augmentation_step, shuffle_base, rnd):
+        """The walk sampler consuming its uniforms walk by walk, as the reference's samplers do (graph.cuh:298-450)."""
+        eo = None if ee_offsets is None else ee_offsets.ctypes.data_as(C.c_void_p)
+        n = self.lib.gvo_sample_walks_reference_order(int(biased), edges_uv.reshape(-1), edge_prob, edge_alias,
+                                                      edge_prob.size, flat_offsets, nb_prob, nb_alias, eo, part, local, P,
+                                                      self._pool_ptrs(pools), pool_size, start, end, walk_length,
+                                                      walk_batch, augmentation_step, shuffle_base, rnd, rnd.size)
+        assert n < C.c_size_t(-2).value, "uniform stream too short / bad arguments"
         return n
 
     def edge_edge_weights(self, edges_uv, edge_weights, flat_offsets, e, p, q):

@@ -135,3 +135,25 @@ def test_reference_template_dispatch_resolves_to_this_module():
             ref["solver"].GraphSolver(128, device_ids=[0])
     assert type(ref["optimizer"].Optimizer("SGD", 0.1)) is lib.optimizer.SGD
     assert ref["optimizer"].Optimizer().type == "Default"
+
+
+def build_c_client(out_dir):
+    """tests/c/abi_client.c — a plain C host of include/gvs.h + include/gvx.h — compiled with gcc against libgvk.so."""
+    import subprocess
+    binary = os.path.join(str(out_dir), "abi_client")
+    subprocess.check_call(["gcc", "-std=c11", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_client.c"), "-L", os.path.join(ROOT, "graphvite_amd"), "-lgvk",
+                           "-Wl,-rpath," + os.path.join(ROOT, "graphvite_amd"), "-lm", "-o", binary])
+    return binary
+
+
+def test_plain_c_host_links_and_fails_loudly_without_a_gpu(tmp_path):
+    """The boundary is a C ABI: a C11 program with nothing but the three headers and -lgvk loads a graph and asks for
+    a solver; without a GPU the library says so and the program exits with its "no GPU" code."""
+    import subprocess
+    import torch
+    binary = build_c_client(tmp_path)
+    run = subprocess.run([binary, "2000", "20000"], capture_output=True, text=True, timeout=300)
+    assert "graph: 2000 vertices, 20000 edges" in run.stdout
+    if not torch.cuda.is_available():
+        assert run.returncode == 3 and "No GPU devices found" in run.stderr

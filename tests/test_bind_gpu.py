@@ -103,3 +103,13 @@ def test_custom_schedule_moments_and_resume(data):
     adam.train(model="LINE", num_epoch=40, augmentation_step=1, resume=True, log_frequency=1 << 30)
     print("Adam: AUC %.4f, after resume %.4f" % (first, auc_of(adam, keep)))
     assert adam.resume and auc_of(adam, keep) > first > 0.6
+
+
+def test_plain_c_host_trains_through_the_c_abi(tmp_path):
+    """tests/c/abi_client.c: gvs_graph_* + gvx_solver_* from C — load, build, train LINE, predict; edges must score above
+    random pairs.  No Python, no C++, no torch in that process."""
+    import subprocess
+    from test_bind_cpu import build_c_client
+    run = subprocess.run([build_c_client(tmp_path), "5000", "100000"], capture_output=True, text=True, timeout=600)
+    print(run.stdout, run.stderr[-500:])
+    assert run.returncode == 0 and "trained" in run.stdout
