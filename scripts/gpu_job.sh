@@ -9,6 +9,8 @@ WHAT=${*:-tests measure profile}
 cd $REPO
 if [[ $WHAT == *tests* ]]; then
   python -m pytest tests -m gpu -q 2>&1 | tail -25 > gpurun_out/pytest_gpu_full.log
+  # the AUC tables the parity tests print (hub-heavy shapes against the reference's training loop, T3 protocol)
+  python -m pytest tests/test_solver_gpu.py -q -s -k "hub_heavy or reference_training_loop or parity" 2>&1 | grep -E "reference loop|AUC|passed|failed" > gpurun_out/parity_auc.log
   python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
 fi
 if [[ $WHAT == *measure* ]]; then

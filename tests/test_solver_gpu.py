@@ -173,10 +173,21 @@ def test_quick_start_pipeline():
     H, T, Y = test
     result = app.evaluate("link prediction", H=[str(h) for h in H], T=[str(t) for t in T], Y=Y.tolist(),
                           filter_H=[str(h) for h in train[:, 0]], filter_T=[str(t) for t in train[:, 1]])
-    print("quick-start pipeline AUC", result)
-    # evaluate() filters the held-out pairs that also occur in the training edges, the golden protocol does not:
-    # same embeddings, slightly different test set
-    assert abs(result["AUC"] - golden["sequential"].mean()) <= 0.01
+    # evaluate() drops the held-out pairs that also occur among the training edges (filter_H / filter_T; on this
+    # multigraph that removes the easiest positives), the golden protocol keeps them: the same embeddings scored by the
+    # golden protocol must sit at the sequential reference, and evaluate()'s number must be the numpy restatement of the
+    # reference's AUC (application.py:433-449) on the filtered pairs
+    n2i = app.graph.name2id
+    pairs = [(n2i[str(h)], n2i[str(t)], y) for h, t, y in zip(H, T, Y) if str(h) in n2i and str(t) in n2i]
+    unfiltered = link_prediction_auc(app.solver.vertex_embeddings, app.solver.context_embeddings, [p[0] for p in pairs],
+                                     [p[1] for p in pairs], [p[2] for p in pairs])
+    seen = {(n2i[str(h)], n2i[str(t)]) for h, t in train}
+    kept = [p for p in pairs if (p[0], p[1]) not in seen]
+    filtered = link_prediction_auc(app.solver.vertex_embeddings, app.solver.context_embeddings, [p[0] for p in kept],
+                                   [p[1] for p in kept], [p[2] for p in kept])
+    print("quick-start pipeline AUC", result, "golden protocol on the same embeddings %.6f" % unfiltered)
+    assert result["AUC"] == pytest.approx(filtered, abs=1e-9)
+    assert abs(unfiltered - golden["sequential"].mean()) <= 0.003  # one seed; the 5-seed mean is pinned above at 0.002
     assert app.solver.batch_id >= app.solver.num_batch
     logits = app.solver.predict(np.stack([np.arange(10), np.arange(10)[::-1]], 1))
     want = np.einsum("ij,ij->i", app.solver.vertex_embeddings[:10], app.solver.context_embeddings[:10][::-1])
