@@ -186,7 +186,7 @@ def test_quick_start_pipeline():
     filtered = link_prediction_auc(app.solver.vertex_embeddings, app.solver.context_embeddings, [p[0] for p in kept],
                                    [p[1] for p in kept], [p[2] for p in kept])
     print("quick-start pipeline AUC", result, "golden protocol on the same embeddings %.6f" % unfiltered)
-    assert result["AUC"] == pytest.approx(filtered, abs=1e-9)
+    assert result["AUC"] == pytest.approx(filtered, abs=1e-5)  # predict kernel vs einsum: last-bit score ties
     assert abs(unfiltered - golden["sequential"].mean()) <= 0.003  # one seed; the 5-seed mean is pinned above at 0.002
     assert app.solver.batch_id >= app.solver.num_batch
     logits = app.solver.predict(np.stack([np.arange(10), np.arange(10)[::-1]], 1))
