@@ -63,6 +63,9 @@ def parse(argv=None):
                         "auto episode size for this graph (solver.h:426-436), capped at 250 and at --steps (so that "
                         "the timed region is made of whole block visits)")
     p.add_argument("--no-end-to-end", action="store_true", help="skip the GraphSolver.train() runs (`end_to_end`)")
+    p.add_argument("--end-to-end", action="store_true",
+                   help="run `end_to_end` with several GPUs too (default: one GPU only — an error on one rank inside a "
+                        "training run would leave the others waiting in a collective, and the headline line with them)")
     p.add_argument("--end-to-end-batches", type=int, default=12000,
                    help="batches per GPU of each end-to-end run (several episodes: the auto episode size is 1750 batches here)")
     p.add_argument("--lanes", type=int, default=0, help="A/B knob: lanes per pair (0 = per-dim default)")
@@ -472,7 +475,7 @@ def main(argv=None, stand_in_kernels=None):
         packed = session.negative_table(tp).cpu().numpy().view(np.dtype([("prob", np.float32), ("alias", np.uint32)]))
         pool0 = pools[blocks[0]].numpy().view(np.uint32).reshape(-1, 2)
         result["cpu_baseline"] = cpu_baseline(args, solver, pool0, packed)
-    if cuda and not args.no_end_to_end and args.optimizer == "SGD":
+    if cuda and not args.no_end_to_end and args.optimizer == "SGD" and (world == 1 or args.end_to_end):
         session.finish()
         del landed, work, pools, session
         solver.clear()

@@ -61,6 +61,19 @@ def test_train_one_gpu_through_the_module(data):
     assert np.abs(solver.vertex_embeddings).max() > 0  # clear() keeps the embeddings on the CPU
 
 
+def test_one_worker_several_partitions(data):
+    """num_partition > #worker through the module: one worker walks 3 x 3 blocks per episode, partitions never leave HBM."""
+    lib, graph, keep = data
+    solver = lib.solver.GraphSolver_128_f_j(device_ids=[0], num_sampler_per_worker=4)
+    solver.build(graph, num_partition=3, batch_size=10000, episode_size=5)
+    solver.train(model="LINE", num_epoch=200, augmentation_step=1, log_frequency=1 << 30)
+    auc = auc_of(solver, keep)
+    print("module, 1 worker / 3 partitions: AUC %.6f" % auc)
+    assert auc > 0.9 and solver.num_partition == 3
+    with pytest.raises(ValueError, match="multiple of #worker"):
+        lib.solver.GraphSolver_128_f_j(device_ids=[0, 0]).build(graph, num_partition=3)
+
+
 def test_two_workers_in_one_process(data):
     """device_ids=[0, 0]: two workers of ONE process (here sharing the only GPU of the box), two partitions, pinned
     context shards, the head shards exchanged GPU to GPU after every schedule step — the reference's multi-GPU shape
