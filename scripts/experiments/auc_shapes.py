@@ -42,9 +42,9 @@ def main():
         aucs = []
         for seed in seeds:
             t0 = time.time()
-            s = gv.solver.GraphSolver(128, num_sampler_per_worker=int(extra.get("samplers", 8)), seed=seed, pair_order=order,
+            s = gv.solver.GraphSolver(128, num_sampler_per_worker=int(extra.get("samplers", 8)), seed=seed, pair_order=gv.auto if order == "auto" else order,
                                       device_sampling=extra.get("device_sampling", "0") == "1")
-            s.build(g, batch_size=batch, episode_size=episode)
+            s.build(g, batch_size=batch, episode_size=int(extra.get("episode", episode)), num_partition=int(extra.get("partitions", 0)))
             s.train(model="LINE", num_epoch=epochs, augmentation_step=train_kw["augmentation_step"],
                     random_walk_length=train_kw.get("walk_length", 40), random_walk_batch_size=train_kw.get("walk_batch", 100),
                     log_frequency=1 << 30)
