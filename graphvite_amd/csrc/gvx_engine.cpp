@@ -128,6 +128,8 @@ struct Worker {
     bool released_valid[2] = {false, false};
     std::vector<hipEvent_t> copied;     // H2D copies of the current pool set still reading pinned memory
     std::vector<hipEvent_t> incoming;   // peer copies into this worker's replica not yet fenced on its compute stream
+    hipEvent_t sent = nullptr;          // the peer copies of the head partition this worker trained last have left it
+    int sending = -1;                   // ... that partition (-1: nothing in flight)
     uint64_t visits = 0;
 };
 
@@ -180,6 +182,7 @@ struct gvx_solver {
                 if (w.released[b]) hipEventDestroy(w.released[b]);
             }
             if (w.trained) hipEventDestroy(w.trained);
+            if (w.sent) hipEventDestroy(w.sent);
             for (auto e : w.copied) hipEventDestroy(e);
             for (auto e : w.incoming) hipEventDestroy(e);
             if (w.compute) hipStreamDestroy(w.compute);
@@ -478,6 +481,7 @@ int gvx_solver::prepare_devices() {
             HIP_TRY(hipEventCreateWithFlags(&w.released[b], hipEventDisableTiming));
         }
         HIP_TRY(hipEventCreateWithFlags(&w.trained, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&w.sent, hipEventDisableTiming));
         // negative sampler per owned tail partition: degree^exponent in local order (solver.h:1263-1278)
         for (int tp : w.tails) {
             const std::vector<uint32_t> &ids = part_ids[tp];
@@ -745,6 +749,7 @@ int gvx_solver::episode_loop() {
                     hipEventDestroy(e);
                 }
                 w.incoming.clear();
+                if (w.sending == hp) hipStreamWaitEvent(w.compute, w.sent, 0);  // its copies to the peers still read this slot
                 if (rc == GVK_OK && step + 1 < num_step) rc = stage(w, step + 1);  // next block's pool while this one trains
                 if (rc == GVK_OK) rc = train_block(w, hp, tp, w.pool[b]);
                 hipEventRecord(w.released[b], w.compute);
@@ -772,6 +777,8 @@ int gvx_solver::episode_loop() {
                     hipEventRecord(arrived, w.exchange);
                     u.incoming.push_back(arrived);
                 }
+                hipEventRecord(w.sent, w.exchange);
+                w.sending = hp;
             }
             batch_id += (uint64_t)episode_size * config.positive_reuse * W;
         }
