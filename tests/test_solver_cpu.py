@@ -527,6 +527,22 @@ def test_word_graph_application_trains_a_corpus(tmp_path):
     assert inside > across + 0.5  # words of a topic co-occur, words of different topics never do
 
 
+def test_four_workers_eight_partitions_over_gloo(tmp_path):
+    """4 workers, 8 partitions (two head groups): every schedule step moves each rank's head partition into its own slot
+    of the group's slab and one in-place all-gather rebuilds the group on every rank (`_claim_slot`, `_exchange`) while
+    the other group trains.  After write-back all four ranks must hold the same, complete tables, every batch id exactly
+    once, and every trained pair in the block it was trained in (checked inside the workers)."""
+    world, port = 4, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), "LINE", 1, 8, "grouped"), nprocs=world, join=True)
+    r = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % i)) for i in range(world)]
+    for other in r[1:]:
+        assert (r[0]["v"] == other["v"]).all() and (r[0]["c"] == other["c"]).all()
+    assert np.abs(r[0]["c"]).max() > 0 and np.isfinite(r[0]["v"]).all()
+    assert [x["tails"].tolist() for x in r] == [[0, 4], [1, 5], [2, 6], [3, 7]]  # two pinned context shards per worker
+    ids = np.sort(np.concatenate([x["ids"] for x in r]))
+    assert (ids == np.arange(len(ids))).all() and len(ids) % (8 * 8 * 3) == 0
+
+
 def test_device_sampling_over_gloo(tmp_path):
     """device_sampling=True on 2 workers / 4 partitions (LINE): every worker draws the pools of its own blocks one block
     ahead (gvk_sample_pairs from the block's alias table), regroups them, trains, exchanges."""
