@@ -41,7 +41,7 @@ int g_lanes_per_pair = 0;  // GVK_TUNE_LANES_PER_PAIR
 int g_variant = 0;         // GVK_TUNE_VARIANT
 int g_run_cap = 0;         // GVK_TUNE_RUN_CAP (0 = from the batch size, run_cap_for)
 int g_generation = 0;      // GVK_TUNE_GENERATION (0 = one launch per batch)
-int g_segment_steps = 0;   // GVK_TUNE_SEGMENT_STEPS (0 = per-dim default, default_steps)
+int g_segment_steps = 0;   // GVK_TUNE_SEGMENT_STEPS (0 = off)
 int g_skip_loss = 1;       // GVK_TUNE_SKIP_LOSS (gvk_train_episode leaves out the loss of batches nobody can read)
 
 struct TrainArgs {
@@ -1003,21 +1003,18 @@ struct Choice {
     bool runs = false, fixed_k = false, reference_shape = false;
 };
 
-// Which kernel trains SGD / one negative, by the size of the head table:
+// Which kernel trains a batch, by the size of the head table:
 //   * cache-resident tables (< 16 MiB: a BlogCatalog-sized graph).  Every batch touches every hub row hundreds of
-//     times; the solver regroups the batches and train_segment_kernel chains the longest run the registers allow
-//     (D = 4: 16 pairs per wavefront up to dim 128), so that up to 16 consecutive updates of a row survive per
-//     wavefront — that keeps link-prediction AUC within 0.002 of sequential training there, and at that size the
-//     kernel time does not matter;
-//   * everything larger: the per-pair kernel (returns 0).  Chaining costs nothing when rows come from HBM (51.4-53.3 us
-//     against 51.7-52.6 us per batch on 512 MB tables) but a quarter of the rate when they come from the caches (32 MB
-//     shards, regrouped: 42.5 against 34.1 us), and conflicts are rare enough there that it changes no AUC.
+//     times; the solver regroups the batches and train_runs_kernel trains each run of adjacent same-head samples in
+//     sequence on one register copy of the row, up to run_cap_for(batch) = 20 of them at the default batch — that keeps
+//     link-prediction AUC within 0.002 of sequential training there (0.8745 against 0.8747; the per-pair kernel: 0.8716
+//     regrouped, 0.8734 in sampler order), for every optimizer and any number of negatives.  A run is a chain of
+//     dependent row fetches, which costs a third of the rate on large tables and nothing that matters here: a
+//     quick-start run (7000 batches) trains in well under a second either way;
+//   * everything larger: the per-pair kernel.  Conflicts are rare enough there that runs change no AUC (§7).
 constexpr size_t kResidentTableBytes = (size_t)16 << 20;
 
-int default_steps(int dim, uint32_t rows) {
-    if ((size_t)rows * dim * 4 >= kResidentTableBytes) return 0;
-    return dim <= 128 ? 4 : (dim == 256 ? 2 : 1);
-}
+bool resident_table(int dim, uint32_t rows) { return (size_t)rows * dim * 4 < kResidentTableBytes; }
 
 // D pairs per lane group keep 3 * D rows of DIM / G floats in registers; past 128 VGPRs per lane the kernel is
 // built for 2 wavefronts per SIMD (256 VGPRs) instead of spilling, and D = 4 exists only where that suffices.
@@ -1060,10 +1057,9 @@ Choice choose_train(int dim, int opt, int k, bool explicit_negatives, int batch_
                                                                                     : default_lanes(dim);
     const bool shipped_shape = opt == GVK_SGD && k == 1 && c.lanes == default_lanes(dim);
     const bool draw = !explicit_negatives;
-    // SGD with one negative (every shipped configuration of the reference) on the default lane layout: small tables
-    // get train_segment_kernel (a wavefront owns a segment), see default_steps; GVK_TUNE_SEGMENT_STEPS forces it at any
-    // size, GVK_TUNE_VARIANT 1, 2 and 4 select the other builds for A/B.
-    c.steps = g_variant == 0 && g_generation == 0 && shipped_shape ? (g_segment_steps ? g_segment_steps : default_steps(dim, rows)) : 0;
+    // GVK_TUNE_SEGMENT_STEPS: train_segment_kernel (a wavefront owns a segment), the A/B alternative to runs for SGD with
+    // one negative on the default lane layout
+    c.steps = g_variant == 0 && g_generation == 0 && shipped_shape ? g_segment_steps : 0;
     if (c.steps > 0) {
 #define GVK_SEGMENT(D, GG) \
     case D: c.kernel = pick_segment<D, GG>(c.steps, draw, want_loss || !g_skip_loss); break;
@@ -1078,7 +1074,8 @@ Choice choose_train(int dim, int opt, int k, bool explicit_negatives, int batch_
         }
         c.steps = 0;
     }
-    c.runs = g_variant == 4 && g_generation == 0;
+    // runs of same-head samples: cache-resident tables by default (resident_table), any table with GVK_TUNE_VARIANT 4
+    c.runs = g_generation == 0 && (g_variant == 4 || (g_variant == 0 && resident_table(dim, rows)));
     c.run_cap = c.runs ? run_cap_for(batch_size) : 1;
     c.kernel = c.runs ? pick_train<true>(dim, c.lanes, opt) : pick_train<false>(dim, c.lanes, opt);
     // compile-time k and negative source -> straight-line code.  GVK_TUNE_VARIANT 1 forces the generic build (A/B).

@@ -528,7 +528,7 @@ class GraphSolver(object):
         if self._pair_order_request == auto:
             # Regroup (gvk_group_pairs) by the size of a partition's table, at dim >= 64:
             #   < 16 MiB   (a BlogCatalog-sized graph) every batch hits every hub row hundreds of times; with same-head
-            #              samples adjacent the kernel trains them as runs of up to 16 consecutive updates per wavefront,
+            #              samples adjacent the kernel trains them as runs of up to 20 consecutive updates on one copy of the row,
             #              which keeps link-prediction AUC within 0.002 of sequential training; any sampler;
             #   < 256 MiB  (the shards of multi-GPU runs) tables live in L2 / Infinity Cache: adjacent same-head samples
             #              make a head row one fetch (2.3 -> 2.9 G edge-samples/s per GPU on 32 MB shards), AUC unchanged;

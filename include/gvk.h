@@ -96,8 +96,8 @@ typedef struct {
 /* One batch of negative-sampling SGD: for every {tail, head} pair, num_negative negative steps then the
  * positive step on a progressively updated copy of vertex[head]; context rows are updated in place,
  * Hogwild (no atomics), loss[s] = sample loss / (1 + num_negative * negative_weight).
- * With SGD, num_negative == 1 and a head table smaller than 16 MiB, pairs that sit next to each other in the batch,
- * share a head row and fall into the same wavefront's segment (16 consecutive pairs at dim 128) are trained as one run — one after the other on one
+ * On a head table smaller than 16 MiB, pairs that sit next to each other in the batch and share a head row (up to
+ * batch_size / 5120 of them, rounded up) are trained as one run — one after the other on one
  * register copy of the row, as consecutive iterations of one warp in the reference (include/instance/gpu/graph.cuh:
  * 54-94); samples keep their own negatives and loss slots.  `stream` is a hipStream_t (NULL = default stream).  `batch_id` only feeds the negative draw. */
 int gvk_train(void *stream, int dim, const gvk_optimizer *optimizer, const gvk_tables *tables,
@@ -203,22 +203,21 @@ int gvk_alias_build(const float *weights, size_t n, float *prob, void *alias, in
 /* Tuning knobs for A/B measurement (bench.py --variant); they never change results beyond
  * floating-point summation order.  Returns GVK_EINVAL for an unknown key or unsupported value. */
 #define GVK_TUNE_LANES_PER_PAIR 1 /* 0 = per-dim default; else 8, 16, 32 or 64 */
-#define GVK_TUNE_VARIANT 2        /* 0 = default: the per-pair kernel, except SGD with one negative on a head table smaller
-                                     than 16 MiB, which runs train_segment_kernel (a wavefront owns a segment of the batch);
+#define GVK_TUNE_VARIANT 2        /* 0 = default: the per-pair kernel; on a head table smaller than 16 MiB train_runs_kernel
+                                     (one lane group trains a run of adjacent same-head samples in sequence);
                                      1 = the per-pair kernel, generic build (run-time k); 2 = the per-pair kernel with
-                                     compile-time k; 3 = dim-128 SGD in the reference's kernel shape (one wavefront per
-                                     pair, vertex row in LDS, 8192 x 512 grid-stride launch); 4 = train_runs_kernel (one
-                                     lane group trains a run of same-head pairs, rows fetched one target ahead).
-                                     1 - 4 are A/B baselines */
-#define GVK_TUNE_RUN_CAP 3        /* variant 4 only: longest run a lane group trains in sequence: 0 = from the batch size
-                                     (batch_size / 5120 rounded up), 1 = every pair on its own, up to 64 */
+                                     compile-time k at any table size; 3 = dim-128 SGD in the reference's kernel shape (one
+                                     wavefront per pair, vertex row in LDS, 8192 x 512 grid-stride launch); 4 =
+                                     train_runs_kernel at any table size.  1 - 4 are A/B baselines */
+#define GVK_TUNE_RUN_CAP 3        /* train_runs_kernel: longest run a lane group trains in sequence: 0 = from the batch size
+                                     (batch_size / 5120 rounded up: the generations of the reference's launch on the card it
+                                     was written for), 1 = every pair on its own, up to 64 */
 #define GVK_TUNE_GENERATION 4     /* parity experiment: C > 0 trains a batch as consecutive launches of at most C samples
                                      (per-pair kernel), the concurrency structure of the reference's launch on a card
                                      that keeps C warps resident; 0 = one launch per batch (default) */
-#define GVK_TUNE_SEGMENT_STEPS 5  /* train_segment_kernel: pairs per lane group and wavefront (a wavefront owns 64 / lanes *
-                                     steps consecutive pairs) — 0 = default: the longest build (4 up to dim 128) when the
-                                     head table is smaller than 16 MiB, the per-pair kernel otherwise; 1, 2 or 4 = that
-                                     many steps at any table size */
+#define GVK_TUNE_SEGMENT_STEPS 5  /* A/B: 1, 2 or 4 = SGD with one negative runs train_segment_kernel (a wavefront owns 64 /
+                                     lanes * steps consecutive pairs and chains the same-head runs inside it through
+                                     registers, all rows requested up front); 0 = off (default) */
 #define GVK_TUNE_SKIP_LOSS 6      /* 1 (default) = gvk_train_episode does not compute the per-sample loss of batches whose
                                      loss[] a later batch of the same call overwrites; 0 = every batch computes it */
 int gvk_set_tuning(int key, int value);

@@ -185,8 +185,8 @@ def _check_runs(pairs, negs, v, c, ov, oc, oloss, hv, hc, hloss, segment):
 @pytest.mark.parametrize("steps", [0, 1, 2, 4])
 @pytest.mark.parametrize("explicit", [True, False])
 def test_segment_kernel_trains_runs_in_sequence(hip, oracle, dim, steps, explicit):
-    """The shipped SGD / one-negative kernel: adjacent pairs that share a head row and lie in one wavefront's segment
-    are one run, trained one after the other on one register copy of the row (the reference's warp does that with
+    """train_segment_kernel (GVK_TUNE_SEGMENT_STEPS; the A/B alternative to train_runs_kernel for SGD with one negative):
+    adjacent pairs that share a head row and lie in one wavefront's segment are one run, trained one after the other on one register copy of the row (the reference's warp does that with
     consecutive iterations of its loop, gpu/graph.cuh:54-94).  With distinct context rows the result equals the
     SEQUENTIAL oracle — no update of the head row is lost — and every sample keeps its own negative and loss slot."""
     rng = np.random.default_rng(dim + steps)
@@ -198,8 +198,8 @@ def test_segment_kernel_trains_runs_in_sequence(hip, oracle, dim, steps, explici
     hip.set_segment_steps(steps)
     try:
         name = hip.describe_train(dim, "SGD", k, explicit, B, N)
-        if steps == 0:  # the default: the segment kernel on tables below 16 MiB, the per-pair kernel above
-            assert ("train_segment_kernel" in name) == (N * dim * 4 < 16 << 20), name
+        if steps == 0:  # the default: runs of same-head samples on tables below 16 MiB, the per-pair kernel above
+            assert ("train_runs_kernel" in name) == (N * dim * 4 < 16 << 20), name
             assert "train_kernel<" in hip.describe_train(dim, "SGD", k, explicit, B, 1 << 20)
         if "train_segment_kernel" not in name:
             pytest.skip("no %d-step build at dim %d: %s" % (steps, dim, name))
@@ -311,9 +311,9 @@ def test_run_cap_splits_long_runs(hip, oracle):
         hip.set_run_cap(cap if variant == 4 else 0)
         hip.set_variant(variant)
         try:
-            if variant == 0:  # 4096 rows of dim 128 = 2 MiB: the long-segment build (16 pairs), explicitly set to 8 here
-                assert "16 pairs per wavefront" in hip.describe_train(dim, "SGD", k, True, B, N)
+            if variant == 0:  # the segment kernel, 2 steps = 8 pairs per wavefront at dim 128
                 hip.set_segment_steps(2)
+                assert "8 pairs per wavefront" in hip.describe_train(dim, "SGD", k, True, B, N)
             hv, hc, hloss, _ = run_hip(hip, v, c, pairs, negs, OPTS["SGD"][1], 5.0)
         finally:
             hip.set_run_cap(0)

@@ -141,9 +141,9 @@ def test_hub_heavy_shapes_match_the_reference_training_loop(shape):
     batch of 100 000 — every batch hits a hub row hundreds of times, which is where execution order decides what is
     learned.  The two pipelines share no random stream, so means over seeds are compared.
 
-    * the product as shipped (pair_order auto: regrouped batches on both — with 16-pair runs on the cache-resident
-      "blog" tables, the per-pair kernel on the 51 MB tables of "hub100k"): link-prediction AUC within +-0.002 of the
-      sequential reference;
+    * the product as shipped (pair_order auto: regrouped batches on both — trained as runs of up to 20 same-head
+      samples on the cache-resident "blog" tables, by the per-pair kernel on the 51 MB tables of "hub100k"):
+      link-prediction AUC within +-0.002 of the sequential reference;
     * in the other pair order it stays inside the bracket the reference's own models span, 0.002 around
       [chunk-synchronous, sequential];
     * and the product is never below the chunk-synchronous models: what a lock-step launch loses, it does not."""
