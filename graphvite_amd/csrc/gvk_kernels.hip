@@ -1078,6 +1078,14 @@ Choice choose_train(int dim, int opt, int k, bool explicit_negatives, int batch_
     c.runs = g_generation == 0 && (g_variant == 4 || (g_variant == 0 && resident_table(dim, rows)));
     c.run_cap = c.runs ? run_cap_for(batch_size) : 1;
     c.kernel = c.runs ? pick_train<true>(dim, c.lanes, opt) : pick_train<false>(dim, c.lanes, opt);
+    // A/B: compile-time-k builds for a few non-default lane groups (GVK_TUNE_LANES_PER_PAIR), so that the comparison
+    // with the shipped layout is like for like
+    if (opt == GVK_SGD && k == 1 && !c.runs && g_variant != 1 && c.lanes != default_lanes(dim)) {
+#define GVK_ALT(D, GG) \
+    if (dim == D && c.lanes == GG) c.kernel = draw ? train_kernel<D, GG, GVK_SGD, 1, 1> : train_kernel<D, GG, GVK_SGD, 1, 0>, c.fixed_k = true;
+        GVK_ALT(64, 8) GVK_ALT(96, 16) GVK_ALT(128, 8)
+#undef GVK_ALT
+    }
     // compile-time k and negative source -> straight-line code.  GVK_TUNE_VARIANT 1 forces the generic build (A/B).
     if (shipped_shape && g_variant != 1) {
         c.fixed_k = true;
