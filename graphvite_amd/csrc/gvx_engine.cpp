@@ -148,6 +148,10 @@ struct gvx_solver {
     uint32_t num_vertex = 0;
     uint64_t num_edge = 0;
     int num_partition = 0, num_negative = 0, batch_size = 0, episode_size = 0;
+    // false: every worker keeps all head partitions and its context shards in HBM (the design of this engine);
+    // true: the model does not fit that way — a worker holds ONE head and ONE tail partition and they travel through host
+    // memory between blocks, the reference's load_partition / write_back scheme (solver.h:1435-1504)
+    bool streamed = false;
     std::vector<int32_t> part;
     std::vector<uint32_t> local, part_sizes;
     uint32_t part_rows = 0;  // S
@@ -201,12 +205,16 @@ struct gvx_solver {
 
     size_t table_floats() const { return (size_t)part_rows * dim; }
     size_t slot_floats() const { return table_floats() * (1 + num_moment); }
-    float *head_table(Worker &w, int hp, int table) { return w.head + ((size_t)hp * (1 + num_moment) + table) * table_floats(); }
+    float *head_table(Worker &w, int hp, int table) {
+        return w.head + ((size_t)(streamed ? 0 : hp) * (1 + num_moment) + table) * table_floats();
+    }
     float *context_table(Worker &w, int ti, int table) {
-        return w.context + ((size_t)ti * (1 + num_moment) + table) * table_floats();
+        return w.context + ((size_t)(streamed ? 0 : ti) * (1 + num_moment) + table) * table_floats();
     }
 
-    size_t memory_demand(int P, int requested_episode) const;
+    size_t memory_demand(int P, int requested_episode, bool as_streamed = false) const;
+    int load_block(Worker &w, int hp, int tp);
+    int store_block(Worker &w, int hp, int tp);
     int configure(const gvx_train_config &c);
     int prepare_devices();
     int upload();
@@ -227,10 +235,11 @@ const char *optimizer_name(int type) {
 
 }  // namespace
 
-size_t gvx_solver::memory_demand(int P, int requested_episode) const {
+size_t gvx_solver::memory_demand(int P, int requested_episode, bool as_streamed) const {
     const size_t S = (num_vertex + P - 1) / P, tails = std::max(P / num_worker, 1);
-    size_t demand = (P * S + tails * S) * (size_t)dim * 4 * (1 + num_moment);
-    demand += tails * S * 8 + (size_t)batch_size * 4;
+    // resident: all P head partitions + the owned context shards; streamed: one head + one tail partition (solver.h:365-376)
+    size_t demand = (as_streamed ? 2 * S : P * S + tails * S) * (size_t)dim * 4 * (1 + num_moment);
+    demand += (as_streamed ? (size_t)P : tails) * S * 8 + (size_t)batch_size * 4;
     size_t episode = requested_episode;
     if (requested_episode == GVX_AUTO) {
         episode = std::max<size_t>((size_t)((double)num_vertex * kSamplePerVertex / P / batch_size), 1);
@@ -342,10 +351,22 @@ extern "C" int gvx_solver_build(gvx_solver *s, const gvs_graph *graph, const gvx
             limit = std::min(limit, free_bytes);
         }
     }
+    s->streamed = false;
     if (num_partition == GVX_AUTO) {
         num_partition = W;
         while (num_partition < kMaxPartition && s->memory_demand(num_partition, episode_size) >= limit) num_partition += W;
+        if (s->memory_demand(num_partition, episode_size) >= limit) {
+            // the resident design does not fit even with the most partitions: fall back to the reference's scheme — one
+            // head and one tail partition per worker in HBM, everything else in host memory (solver.h:365-384)
+            s->streamed = true;
+            num_partition = W;
+            while (num_partition < kMaxPartition && s->memory_demand(num_partition, episode_size, true) >= limit) num_partition += W;
+            log_message(1, "The vertex table does not fit the GPU memory limit next to the sample pools: partitions will "
+                           "travel through host memory between blocks (%d partitions)", num_partition);
+        }
     } else {
+        s->streamed = s->memory_demand(num_partition, episode_size) >= limit &&
+                      s->memory_demand(num_partition, episode_size, true) < limit;
         if (num_partition < W) return gvk_fail(GVK_EINVAL, "#partition should be no less than %d", W);
         if (num_partition % W) return gvk_fail(GVK_EINVAL, "#partition (%d) must be a multiple of #worker (%d)", num_partition, W);
         if (num_partition > kMaxPartition)
@@ -354,7 +375,7 @@ extern "C" int gvx_solver_build(gvx_solver *s, const gvs_graph *graph, const gvx
     }
     const int P = s->num_partition = num_partition;
     s->gpu_memory_limit = limit;
-    s->gpu_memory_cost = s->memory_demand(P, episode_size);
+    s->gpu_memory_cost = s->memory_demand(P, episode_size, s->streamed);
     if (s->gpu_memory_cost >= limit) return gvk_fail(GVK_ENOMEM, "Can't satisfy the specified GPU memory limit");
 
     s->part.assign(s->num_vertex, 0), s->local.assign(s->num_vertex, 0), s->part_sizes.assign(P, 0);
@@ -458,6 +479,10 @@ int gvx_solver::prepare_devices() {
             if (std::find(w.tails.begin(), w.tails.end(), tp) == w.tails.end()) w.tails.push_back(tp);
         }
         std::sort(w.tails.begin(), w.tails.end());
+        if (streamed) {  // any tail partition may come by: a negative sampler for each, tables for one at a time
+            w.tails.clear();
+            for (int p = 0; p < P; p++) w.tails.push_back(p);
+        }
         HIP_TRY(hipSetDevice(w.device));
         for (int q = 0; q < W; q++)  // direct GPU-to-GPU copies for the exchange
             if (device_ids[q] != w.device) {
@@ -470,10 +495,11 @@ int gvx_solver::prepare_devices() {
         HIP_TRY(hipStreamCreateWithFlags(&w.compute, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&w.copy, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&w.exchange, hipStreamNonBlocking));
-        HIP_TRY(hipMalloc(&w.head, (size_t)P * slot_floats() * 4));
-        HIP_TRY(hipMalloc(&w.context, w.tails.size() * slot_floats() * 4));
-        HIP_TRY(hipMemsetAsync(w.head, 0, (size_t)P * slot_floats() * 4, w.compute));
-        HIP_TRY(hipMemsetAsync(w.context, 0, w.tails.size() * slot_floats() * 4, w.compute));
+        const size_t head_slots = streamed ? 1 : (size_t)P, context_slots = streamed ? 1 : w.tails.size();
+        HIP_TRY(hipMalloc(&w.head, head_slots * slot_floats() * 4));
+        HIP_TRY(hipMalloc(&w.context, context_slots * slot_floats() * 4));
+        HIP_TRY(hipMemsetAsync(w.head, 0, head_slots * slot_floats() * 4, w.compute));
+        HIP_TRY(hipMemsetAsync(w.context, 0, context_slots * slot_floats() * 4, w.compute));
         HIP_TRY(hipMalloc(&w.loss, (size_t)batch_size * 4));
         HIP_TRY(hipMemsetAsync(w.loss, 0, (size_t)batch_size * 4, w.compute));
         for (int b = 0; b < 2; b++) {
@@ -567,6 +593,17 @@ int gvx_solver::move_table(bool to_device, Worker &w, float *device_table, std::
 }
 
 int gvx_solver::upload() {
+    if (streamed) {  // tables stay in host memory; moments start there, too
+        if (num_moment && !(config.resume && (int)vertex_moments.size() == num_moment)) {
+            vertex_moments.assign(num_moment, std::vector<float>((size_t)num_vertex * dim, 0.0f));
+            context_moments.assign(num_moment, std::vector<float>((size_t)num_vertex * dim, 0.0f));
+        }
+        for (Worker &w : workers) {
+            HIP_TRY(hipSetDevice(w.device));
+            HIP_TRY(hipStreamSynchronize(w.compute));
+        }
+        return GVK_OK;
+    }
     const bool moments = config.resume && (int)vertex_moments.size() == num_moment && num_moment > 0;
     for (Worker &w : workers) {
         HIP_TRY(hipSetDevice(w.device));
@@ -589,6 +626,7 @@ int gvx_solver::write_back() {  // WorkerMixin::write_back, solver.h:1498-1504: 
         HIP_TRY(hipSetDevice(w.device));
         HIP_TRY(hipDeviceSynchronize());
     }
+    if (streamed) return GVK_OK;  // every block was stored when it was left
     if (num_moment) {
         vertex_moments.assign(num_moment, std::vector<float>((size_t)num_vertex * dim, 0.0f));
         context_moments.assign(num_moment, std::vector<float>((size_t)num_vertex * dim, 0.0f));
@@ -606,6 +644,33 @@ int gvx_solver::write_back() {  // WorkerMixin::write_back, solver.h:1498-1504: 
             for (int j = 0; j < num_moment; j++)
                 GVK_TRY(move_table(false, w, context_table(w, (int)ti, 1 + j), context_moments[j], w.tails[ti]));
         }
+    }
+    return GVK_OK;
+}
+
+// Streamed mode (WorkerMixin::load_partition / write_back, solver.h:1435-1504): the head and tail partition of a block come
+// from the host tables before it trains and go back after.
+int gvx_solver::load_block(Worker &w, int hp, int tp) {
+    Range range("Load partition");
+    HIP_TRY(hipSetDevice(w.device));
+    GVK_TRY(move_table(true, w, head_table(w, hp, 0), vertex, hp));
+    GVK_TRY(move_table(true, w, context_table(w, tp, 0), context, tp));
+    for (int j = 0; j < num_moment; j++) {
+        GVK_TRY(move_table(true, w, head_table(w, hp, 1 + j), vertex_moments[j], hp));
+        GVK_TRY(move_table(true, w, context_table(w, tp, 1 + j), context_moments[j], tp));
+    }
+    return GVK_OK;
+}
+
+int gvx_solver::store_block(Worker &w, int hp, int tp) {
+    Range range("Write back partition");
+    HIP_TRY(hipSetDevice(w.device));
+    HIP_TRY(hipStreamSynchronize(w.compute));
+    GVK_TRY(move_table(false, w, head_table(w, hp, 0), vertex, hp));
+    GVK_TRY(move_table(false, w, context_table(w, tp, 0), context, tp));
+    for (int j = 0; j < num_moment; j++) {
+        GVK_TRY(move_table(false, w, head_table(w, hp, 1 + j), vertex_moments[j], hp));
+        GVK_TRY(move_table(false, w, context_table(w, tp, 1 + j), context_moments[j], tp));
     }
     return GVK_OK;
 }
@@ -751,14 +816,18 @@ int gvx_solver::episode_loop() {
                 w.incoming.clear();
                 if (w.sending == hp) hipStreamWaitEvent(w.compute, w.sent, 0);  // its copies to the peers still read this slot
                 if (rc == GVK_OK && step + 1 < num_step) rc = stage(w, step + 1);  // next block's pool while this one trains
+                if (rc == GVK_OK && streamed) rc = load_block(w, hp, tp);
                 if (rc == GVK_OK) rc = train_block(w, hp, tp, w.pool[b]);
                 hipEventRecord(w.released[b], w.compute);
                 w.released_valid[b] = true;
                 hipEventRecord(w.trained, w.compute);
             }
+            // streamed: the blocks of this step go back to the host tables (distinct head and tail partitions per worker)
+            for (int r = 0; r < W && rc == GVK_OK && streamed; r++)
+                rc = store_block(workers[r], schedule[((size_t)step * W + r) * 2], schedule[((size_t)step * W + r) * 2 + 1]);
             // exchange: the head shard a worker just trained goes straight into every other worker's replica
             Range exchange_range("Exchange");
-            for (int r = 0; r < W && rc == GVK_OK && W > 1; r++) {
+            for (int r = 0; r < W && rc == GVK_OK && W > 1 && !streamed; r++) {
                 Worker &w = workers[r];
                 const int hp = schedule[((size_t)step * W + r) * 2];
                 hipSetDevice(w.device);

@@ -6,6 +6,8 @@
  * each with its own HIP streams; a worker holds the whole vertex table and the context shards it owns for good,
  * and after a schedule step the workers copy the head shards they trained into each other's replicas directly,
  * GPU to GPU over xGMI (hipMemcpyPeerAsync) — no host staging, no collective library inside one process.
+ * When that does not fit gpu_memory_limit, the engine falls back to the reference's scheme: one head and one tail
+ * partition per worker in HBM, travelling through host memory between blocks (solver.h:1435-1504).
  * (Several processes, one GPU each, over RCCL: graphvite_amd.solver.GraphSolver.)
  *
  * Reference interfaces replaced:

@@ -74,6 +74,29 @@ def test_one_worker_several_partitions(data):
         lib.solver.GraphSolver_128_f_j(device_ids=[0, 0]).build(graph, num_partition=3)
 
 
+def test_partitions_travel_through_host_memory_when_the_model_does_not_fit(data):
+    """gpu_memory_limit below what the resident design needs (all head partitions + the context shard in HBM): the engine
+    falls back to the reference's scheme — one head and one tail partition per worker on the GPU, loaded before a block
+    and written back after it (WorkerMixin::load_partition / write_back, solver.h:1435-1504) — and picks the partition
+    count the way SolverMixin::build does (solver.h:365-384).  Same learning; moments travel, too."""
+    lib, graph, keep = data
+    limit = 9 << 20  # the vertex table alone is 20 000 x 128 x 4 B = 10 MB
+    solver = lib.solver.GraphSolver_128_f_j(device_ids=[0], num_sampler_per_worker=4, gpu_memory_limit=limit)
+    solver.build(graph, batch_size=10000, episode_size=10)
+    assert solver.num_partition in (3, 4) and solver.gpu_memory_cost < limit == solver.gpu_memory_limit
+    solver.train(model="LINE", num_epoch=200, augmentation_step=1, log_frequency=1 << 30)
+    auc = auc_of(solver, keep)
+    print("module, streamed partitions (%d): AUC %.6f" % (solver.num_partition, auc))
+    assert auc > 0.9
+    adam = lib.solver.GraphSolver_64_f_j(device_ids=[0, 0], num_sampler_per_worker=2, gpu_memory_limit=6 << 20)
+    adam.build(graph, lib.optimizer.Adam(1e-3, 0, 0.9, 0.999), batch_size=10000, episode_size=5)
+    adam.train(model="LINE", num_epoch=60, augmentation_step=1, log_frequency=1 << 30)
+    print("module, streamed partitions, 2 workers, Adam: %d partitions, AUC %.4f" % (adam.num_partition, auc_of(adam, keep)))
+    assert auc_of(adam, keep) > 0.6 and adam.gpu_memory_cost < (6 << 20)
+    with pytest.raises(MemoryError):
+        lib.solver.GraphSolver_128_f_j(device_ids=[0], gpu_memory_limit=1 << 20).build(graph, batch_size=10000, episode_size=10)
+
+
 def test_two_workers_in_one_process(data):
     """device_ids=[0, 0]: two workers of ONE process (here sharing the only GPU of the box), two partitions, pinned
     context shards, the head shards exchanged GPU to GPU after every schedule step — the reference's multi-GPU shape
