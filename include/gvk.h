@@ -109,8 +109,7 @@ int gvk_train(void *stream, int dim, const gvk_optimizer *optimizer, const gvk_t
  * counter, solver.h:142,1520, so W concurrent workers see ids W apart), and
  * lr = init_lr * schedule(id, total_batches) where schedule is max(1 - id / total, 1e-4) if linear_schedule
  * else 1 (`optimizer->lr` is init_lr here).  loss [batch_size] is overwritten by every batch, as in the
- * reference, so after the call it holds the losses of the LAST batch; the kernels of the earlier batches are built
- * without the loss arithmetic (nothing could read it).  One kernel launch per batch. */
+ * reference, so after the call it holds the losses of the LAST batch.  One kernel launch per batch. */
 int gvk_train_episode(void *stream, int dim, const gvk_optimizer *optimizer, int linear_schedule,
                       const gvk_tables *tables, const uint32_t *pairs, const gvk_negative_source *negative,
                       uint32_t first_batch_id, uint32_t batch_id_stride, uint32_t total_batches, int num_batches,
@@ -218,12 +217,14 @@ int gvk_alias_build(const float *weights, size_t n, float *prob, void *alias, in
 #define GVK_TUNE_SEGMENT_STEPS 5  /* A/B: 1, 2 or 4 = SGD with one negative runs train_segment_kernel (a wavefront owns 64 /
                                      lanes * steps consecutive pairs and chains the same-head runs inside it through
                                      registers, all rows requested up front); 0 = off (default) */
-#define GVK_TUNE_SKIP_LOSS 6      /* 1 (default) = gvk_train_episode does not compute the per-sample loss of batches whose
-                                     loss[] a later batch of the same call overwrites; 0 = every batch computes it */
+#define GVK_TUNE_SKIP_LOSS 6      /* train_segment_kernel only: 1 (default) = gvk_train_episode uses its loss-less build for
+                                     batches whose loss[] a later batch of the same call overwrites (nothing could read it);
+                                     0 = every batch computes it.  Measured gain: under 1 % */
 int gvk_set_tuning(int key, int value);
 
 /* The kernel gvk_train / gvk_train_episode launch for this configuration under the current tuning, as text
- * ("train_segment_kernel<128,16,SGD,k=1> 8 pairs per wavefront") — what a benchmark should label its measurement with. */
+ * ("train_kernel<128,16,SGD,k=1> run_cap 1", "train_runs_kernel<128,16,SGD,k=1> run_cap 20") — what a benchmark should label
+ * its measurement with.  n_vertex = rows of the head table (decides between the two). */
 int gvk_describe_train(int dim, int optimizer_type, int num_negative, int explicit_negatives, int batch_size,
                        uint32_t n_vertex, char *name, size_t capacity);
 
