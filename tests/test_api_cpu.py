@@ -122,3 +122,41 @@ def test_bench_loop_dry_run(world, order):
     else:
         assert r["exchange"] is None
     assert r["config"]["block_visits_timed"] == 6 and r["roofline"]["kernel"] == "stand-in"
+
+
+def test_kernel_choice_by_table_size():
+    """gvk_describe_train (a host function: no GPU needed) — which kernel a configuration launches: runs of same-head
+    samples on head tables below 16 MiB (any optimizer, any number of negatives), the per-pair kernel above; the A/B
+    builds only through gvk_set_tuning."""
+    import ctypes as C
+    from graphvite_amd import _lib
+    lib = _lib.lib()
+
+    def describe(dim, optimizer, k, rows, batch=100000, explicit=False):
+        name = C.create_string_buffer(160)
+        _lib.check(lib.gvk_describe_train(dim, optimizer, k, int(explicit), batch, rows, name, len(name)), "describe")
+        return name.value.decode()
+
+    assert describe(128, _lib.SGD, 1, 10312) == "train_runs_kernel<128,16,SGD,k=1> run_cap 20"     # BlogCatalog-sized: 5 MB
+    assert describe(128, _lib.SGD, 1, 10312, batch=5000) == "train_runs_kernel<128,16,SGD,k=1> run_cap 1"  # one generation
+    assert describe(128, _lib.SGD, 1, 32767) .startswith("train_runs_kernel") and \
+        describe(128, _lib.SGD, 1, 32768) == "train_kernel<128,16,SGD,k=1> run_cap 1"              # 16 MiB is the border
+    assert describe(128, _lib.SGD, 1, 1000000) == "train_kernel<128,16,SGD,k=1> run_cap 1"          # configs[1]
+    assert describe(96, _lib.SGD, 1, 8200000) == "train_kernel<96,8,SGD,k=1> run_cap 1"             # a Friendster shard
+    assert describe(128, _lib.ADAM, 5, 10312) == "train_runs_kernel<128,16,Adam> run_cap 20"
+    assert describe(128, _lib.ADAM, 5, 1000000) == "train_kernel<128,16,Adam> run_cap 1"
+    assert describe(32, _lib.SGD, 1, 100000).startswith("train_runs_kernel<32,8,SGD,k=1>")         # 12.8 MB at dim 32
+    try:
+        _lib.check(lib.gvk_set_tuning(_lib.TUNE_SEGMENT_STEPS, 4))
+        assert describe(128, _lib.SGD, 1, 1000000) == "train_segment_kernel<128,16,SGD,k=1> 16 pairs per wavefront"
+        assert describe(512, _lib.SGD, 1, 1000000).startswith("train_kernel<512")  # no 4-step build at dim 512: falls back
+        _lib.check(lib.gvk_set_tuning(_lib.TUNE_SEGMENT_STEPS, 0))
+        _lib.check(lib.gvk_set_tuning(_lib.TUNE_VARIANT, 3))
+        assert "reference_shape" in describe(128, _lib.SGD, 1, 1000000)
+        _lib.check(lib.gvk_set_tuning(_lib.TUNE_VARIANT, 2))
+        assert describe(128, _lib.SGD, 1, 10312) == "train_kernel<128,16,SGD,k=1> run_cap 1"
+    finally:
+        lib.gvk_set_tuning(_lib.TUNE_SEGMENT_STEPS, 0)
+        lib.gvk_set_tuning(_lib.TUNE_VARIANT, 0)
+    with pytest.raises(ValueError):
+        describe(100, _lib.SGD, 1, 1000)
