@@ -203,9 +203,11 @@ public:
     Optimizer optimizer;  // the Python-visible copy (bind.h:411); owns the schedule function the engine calls back
     py::object graph_keepalive;
 
-    GraphSolverBase(int dim, const std::vector<int> &device_ids, int num_sampler_per_worker, size_t gpu_memory_limit) {
+    GraphSolverBase(int dim, const std::vector<int> &device_ids, int num_sampler_per_worker, size_t gpu_memory_limit,
+                    bool device_sampling) {
         handle = gvx_solver_create(dim, device_ids.data(), (int)device_ids.size(), num_sampler_per_worker, gpu_memory_limit);
         if (!handle) raise(GVK_EINVAL, "GraphSolver");
+        check(gvx_solver_set(handle, GVX_DEVICE_SAMPLING, device_sampling), "GraphSolver");
     }
     ~GraphSolverBase() { gvx_solver_destroy(handle); }
     GraphSolverBase(const GraphSolverBase &) = delete;
@@ -280,8 +282,8 @@ public:
 template <int dim>
 class GraphSolver : public GraphSolverBase {
 public:
-    GraphSolver(const std::vector<int> &device_ids, int num_sampler_per_worker, size_t gpu_memory_limit)
-        : GraphSolverBase(dim, device_ids, num_sampler_per_worker, gpu_memory_limit) {}
+    GraphSolver(const std::vector<int> &device_ids, int num_sampler_per_worker, size_t gpu_memory_limit, bool device_sampling)
+        : GraphSolverBase(dim, device_ids, num_sampler_per_worker, gpu_memory_limit, device_sampling) {}
 };
 
 template <class T, class... Extra>
@@ -307,9 +309,12 @@ void bind_solver(py::module &solver) {
         "            index_type (dtype): type of node indexes\n"
         "            device_ids (list of int, optional): GPU ids, [] for auto\n"
         "            num_sampler_per_worker (int, optional): number of sampler thread per GPU\n"
-        "            gpu_memory_limit (int, optional): memory limit for each GPU in bytes\n        ");
-    cls.def(py::init<std::vector<int>, int, size_t>(), no_gil(), py::arg("device_ids") = std::vector<int>(),
-            py::arg("num_sampler_per_worker") = kAuto, py::arg("gpu_memory_limit") = kAuto);
+        "            gpu_memory_limit (int, optional): memory limit for each GPU in bytes\n"
+        "            device_sampling (bool, optional): beyond the reference — draw the positive samples on the GPUs\n"
+        "                instead of the CPU sampler threads\n        ");
+    cls.def(py::init<std::vector<int>, int, size_t, bool>(), no_gil(), py::arg("device_ids") = std::vector<int>(),
+            py::arg("num_sampler_per_worker") = kAuto, py::arg("gpu_memory_limit") = kAuto,
+            py::arg("device_sampling") = false);
 }
 
 }  // namespace
@@ -415,6 +420,9 @@ PYBIND11_MODULE(libgraphvite, module) {
     base.def_property_readonly("resume", [](GraphSolverBase &s) { return s.members().resume != 0; })
         .def_property_readonly("model", [](GraphSolverBase &s) { return std::string(s.members().model); })
         .def_readonly("optimizer", &GraphSolverBase::optimizer)
+        // beyond the reference: what its log prints as "[time] train: ... s" for the episode loop (util/time.h:28-60)
+        .def_property_readonly("train_seconds", [](GraphSolverBase &s) { return s.members().train_seconds; })
+        .def_property_readonly("batch_id", [](GraphSolverBase &s) { return s.members().batch_id; })
         .def_property_readonly("vertex_embeddings", [](GraphSolverBase &s) { return s.view(0); },
                                "Vertex node embeddings (2D numpy view).")
         .def_property_readonly("context_embeddings", [](GraphSolverBase &s) { return s.view(1); },

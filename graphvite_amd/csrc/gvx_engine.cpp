@@ -131,6 +131,23 @@ struct Worker {
     hipEvent_t sent = nullptr;          // the peer copies of the head partition this worker trained last have left it
     int sending = -1;                   // ... that partition (-1: nothing in flight)
     uint64_t visits = 0;
+    // positive samples drawn on the device (GVX_DEVICE_SAMPLING)
+    struct EdgeBlock {
+        gvk_alias_entry *table = nullptr;  // alias table over the weights of the block's edges
+        uint32_t *pairs = nullptr;         // their {tail, head} records (local ids)
+        uint32_t count = 0;
+    };
+    hipStream_t sample = nullptr;
+    hipEvent_t filled[2] = {nullptr, nullptr}, episode_end = nullptr;
+    bool episode_end_valid = false;
+    uint32_t *block_pools[2] = {nullptr, nullptr};  // [tails][P][n] records: the pools of every block it trains, two episodes
+    uint32_t *slices = nullptr;                     // walks, several workers: [P * P][n / W], its slice of EVERY block
+    std::vector<EdgeBlock> edge_blocks;             // edge mode: per block, index = tail index * P + head partition
+    gvk_walk_graph walk{};                          // walk modes: the graph in HBM
+    int32_t *walk_part = nullptr;
+    uint64_t *walk_offsets = nullptr;
+    uint32_t *walk_counters = nullptr;
+    uint64_t sample_seed = 0, sample_index = 0;
 };
 
 }  // namespace
@@ -152,6 +169,7 @@ struct gvx_solver {
     // true: the model does not fit that way — a worker holds ONE head and ONE tail partition and they travel through host
     // memory between blocks, the reference's load_partition / write_back scheme (solver.h:1435-1504)
     bool streamed = false;
+    bool device_sampling = false;  // gvx_solver_set(GVX_DEVICE_SAMPLING)
     std::vector<int32_t> part;
     std::vector<uint32_t> local, part_sizes;
     uint32_t part_rows = 0;  // S
@@ -181,6 +199,15 @@ struct gvx_solver {
             hipFree(w.head), hipFree(w.context), hipFree(w.loss), hipFree(w.pool[0]), hipFree(w.pool[1]);
             hipFree(w.landing), hipFree(w.group_workspace);
             for (auto *t : w.negative_tables) hipFree(t);
+            hipFree(w.block_pools[0]), hipFree(w.block_pools[1]), hipFree(w.slices);
+            for (auto &b : w.edge_blocks) hipFree(b.table), hipFree(b.pairs);
+            hipFree((void *)w.walk.flat_offsets), hipFree((void *)w.walk.edges_uv), hipFree((void *)w.walk.edge_table);
+            hipFree((void *)w.walk.neighbor_table), hipFree((void *)w.walk.sorted_neighbors), hipFree((void *)w.walk.local);
+            hipFree(w.walk_part), hipFree(w.walk_offsets), hipFree(w.walk_counters);
+            for (hipEvent_t e : w.filled)
+                if (e) hipEventDestroy(e);
+            if (w.episode_end) hipEventDestroy(w.episode_end);
+            if (w.sample) hipStreamDestroy(w.sample);
             for (int b = 0; b < 2; b++) {
                 if (w.uploaded[b]) hipEventDestroy(w.uploaded[b]);
                 if (w.released[b]) hipEventDestroy(w.released[b]);
@@ -223,6 +250,12 @@ struct gvx_solver {
     int episode_loop();
     int train_block(Worker &w, int hp, int tp, uint32_t *pool);
     int fill(std::vector<uint32_t *> &pools);
+    int prepare_device_sampling();
+    int device_fill(int set);
+    uint32_t *block_pool(Worker &w, int set, int hp, int tp) {
+        const size_t ti = std::find(w.tails.begin(), w.tails.end(), tp) - w.tails.begin();
+        return w.block_pools[set] + (ti * num_partition + hp) * (size_t)episode_size * batch_size * 2;
+    }
     void make_info();
 };
 
@@ -246,6 +279,8 @@ size_t gvx_solver::memory_demand(int P, int requested_episode, bool as_streamed)
         if (P == 1) episode = std::max<size_t>(episode, kMinEpisodeSample / batch_size);
     }
     demand += 3 * episode * batch_size * 8;  // two pool buffers + the regrouping landing buffer
+    if (device_sampling && !as_streamed)  // the pools of every block a worker trains, two episodes, + its slices on their way to the owners
+        demand += 3 * tails * P * episode * batch_size * 8;
     return demand;
 }
 
@@ -312,6 +347,14 @@ extern "C" gvx_solver *gvx_solver_create(int dim, const int *device_ids, int num
 }
 
 extern "C" void gvx_solver_destroy(gvx_solver *s) { delete s; }
+
+extern "C" int gvx_solver_set(gvx_solver *s, int option, int64_t value) {
+    if (!s) return gvk_fail(GVK_EINVAL, "gvx_solver_set: null solver");
+    if (option != GVX_DEVICE_SAMPLING || (value != 0 && value != 1))
+        return gvk_fail(GVK_EINVAL, "gvx_solver_set: unknown option %d or unsupported value %lld", option, (long long)value);
+    s->device_sampling = value != 0;
+    return GVK_OK;
+}
 
 extern "C" int gvx_solver_build(gvx_solver *s, const gvs_graph *graph, const gvx_optimizer *optimizer, int num_partition,
                                 int num_negative, int batch_size, int episode_size) {
@@ -454,6 +497,22 @@ int gvx_solver::configure(const gvx_train_config &in) {
             mode = GVS_MODE_BIASED_REJECT;
         }
     }
+    if (device_sampling) {  // the GPUs draw the positives: no CPU sampler, none of its tables
+        if (streamed)
+            return gvk_fail(GVK_EINVAL, "device sampling needs every partition resident in GPU memory; raise gpu_memory_limit "
+                                        "or use the CPU samplers");
+        if (gvs_graph_num_directed_edge(graph) >= ((uint64_t)1 << 32))
+            return gvk_fail(GVK_EINVAL, "device sampling supports graphs with fewer than 2^32 directed edges");
+        if (mode != GVS_MODE_EDGE) {
+            if (pool_size % num_worker)
+                return gvk_fail(GVK_EINVAL, "episode_size * batch_size (%zu) must be a multiple of #worker (%d) for the "
+                                "random-walk models", pool_size, num_worker);
+            if (pool_size / num_worker % c.shuffle_base)
+                return gvk_fail(GVK_EINVAL, "Can't perform pseudo shuffle on %zu elements by a shuffle base of %d",
+                                pool_size / num_worker, c.shuffle_base);
+        }
+        return GVK_OK;
+    }
     if (!sampler) {
         sampler = gvs_sampler_create(graph, part.data(), local.data(), num_partition, 0x9E3779B97F4A7C15ull);
         if (!sampler) return GVK_EINVAL;
@@ -554,6 +613,215 @@ int gvx_solver::prepare_devices() {
         const int row_bits = std::max(32 - __builtin_clz(std::max(part_rows, 2u) - 1), 1);
         GVK_TRY(gvk_group_pairs(nullptr, nullptr, nullptr, nullptr, &w.group_workspace_bytes, batch_size, episode_size, row_bits));
         HIP_TRY(hipMalloc(&w.group_workspace, std::max<size_t>(w.group_workspace_bytes, 16)));
+    }
+    return device_sampling ? prepare_device_sampling() : GVK_OK;
+}
+
+// ---- positive samples drawn on the device (GVX_DEVICE_SAMPLING) ------------------------------------------------------
+
+namespace {
+
+template <class T>
+int to_device(T **out, const T *host, size_t count) {  // on the current device
+    HIP_TRY(hipMalloc((void **)out, std::max<size_t>(count, 1) * sizeof(T)));
+    if (count) HIP_TRY(hipMemcpy(*out, host, count * sizeof(T), hipMemcpyHostToDevice));
+    return GVK_OK;
+}
+
+int largest_divisor(size_t n, int limit) {  // stripes of gvk_sample_walks_blocks: any divisor of the capacity
+    for (int d = limit; d > 1; d--)
+        if (n % d == 0) return d;
+    return 1;
+}
+
+}  // namespace
+
+// What the samplers of the device draw from: per block a worker trains, the block's edges and an alias table over their
+// weights (augmentation_step 1: a positive sample of a block is one of its edges, gvk_sample_pairs); for the walk modes
+// the whole graph — CSR, per-vertex alias tables, the global edge table, the partition map (gvk_sample_walks_blocks).
+int gvx_solver::prepare_device_sampling() {
+    const int P = num_partition, W = num_worker;
+    const uint64_t D = gvs_graph_num_directed_edge(graph);
+    const uint32_t *uv = gvs_graph_edges(graph);
+    const float *weights = gvs_graph_edge_weights(graph);
+    const size_t n = (size_t)episode_size * batch_size;
+    std::vector<std::vector<uint32_t>> of_block;
+    std::vector<gvk_alias_entry> edge_table, neighbor_table;
+    std::vector<uint32_t> sorted_neighbors;
+    const bool biased = mode == GVS_MODE_BIASED_WALK || mode == GVS_MODE_BIASED_REJECT;
+    if (mode == GVS_MODE_EDGE) {
+        of_block.assign((size_t)P * P, {});
+        for (uint64_t e = 0; e < D; e++) of_block[(size_t)part[uv[2 * e]] * P + part[uv[2 * e + 1]]].push_back((uint32_t)e);
+    } else {
+        std::vector<float> prob(D);
+        std::vector<uint32_t> alias(D);
+        edge_table.resize(D), neighbor_table.resize(D);
+        GVK_TRY(gvk_alias_build(weights, D, prob.data(), alias.data(), 4, edge_table.data()));
+        GVK_TRY(gvs_graph_neighbor_tables(graph, num_sampler + 1, neighbor_table.data()));
+        if (biased) {  // out-neighbours ascending inside each vertex's CSR segment (the acceptance test searches them)
+            const uint64_t *offsets = gvs_graph_flat_offsets(graph);
+            sorted_neighbors.resize(D);
+            for (uint64_t e = 0; e < D; e++) sorted_neighbors[e] = uv[2 * e + 1];
+            for (uint32_t v = 0; v < num_vertex; v++)
+                std::sort(sorted_neighbors.begin() + offsets[v], sorted_neighbors.begin() + offsets[v + 1]);
+        }
+    }
+    for (int r = 0; r < W; r++) {
+        Worker &w = workers[r];
+        HIP_TRY(hipSetDevice(w.device));
+        HIP_TRY(hipStreamCreateWithFlags(&w.sample, hipStreamNonBlocking));
+        for (hipEvent_t &e : w.filled) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&w.episode_end, hipEventDisableTiming));
+        w.sample_seed = 0x9E3779B97F4A7C15ull * (uint64_t)(r + 1) + 0x706f73;
+        const size_t blocks = w.tails.size() * P;
+        for (uint32_t *&pools : w.block_pools) HIP_TRY(hipMalloc(&pools, blocks * n * 8));
+        if (mode == GVS_MODE_EDGE) {
+            w.edge_blocks.assign(blocks, Worker::EdgeBlock());
+            for (size_t ti = 0; ti < w.tails.size(); ti++)
+                for (int hp = 0; hp < P; hp++) {
+                    const std::vector<uint32_t> &ids = of_block[(size_t)hp * P + w.tails[ti]];
+                    if (ids.empty())
+                        return gvk_fail(GVK_EINVAL, "block (%d, %d) has no edges; use fewer partitions for this graph", hp,
+                                        w.tails[ti]);
+                    std::vector<float> block_weights(ids.size()), prob(ids.size());
+                    std::vector<uint32_t> alias(ids.size()), pairs(2 * ids.size());
+                    std::vector<gvk_alias_entry> packed(ids.size());
+                    for (size_t i = 0; i < ids.size(); i++) {
+                        block_weights[i] = weights[ids[i]];
+                        pairs[2 * i] = local[uv[2 * (size_t)ids[i] + 1]], pairs[2 * i + 1] = local[uv[2 * (size_t)ids[i]]];
+                    }
+                    GVK_TRY(gvk_alias_build(block_weights.data(), ids.size(), prob.data(), alias.data(), 4, packed.data()));
+                    Worker::EdgeBlock &b = w.edge_blocks[ti * P + hp];
+                    b.count = (uint32_t)ids.size();
+                    GVK_TRY(to_device(&b.table, packed.data(), packed.size()));
+                    GVK_TRY(to_device(&b.pairs, pairs.data(), pairs.size()));
+                }
+            continue;
+        }
+        gvk_walk_graph &g = w.walk;
+        g.num_vertex = num_vertex, g.num_edge_entries = (uint32_t)D;
+        g.biased = biased, g.p = config.p, g.q = config.q;
+        GVK_TRY(to_device((uint64_t **)&g.flat_offsets, gvs_graph_flat_offsets(graph), (size_t)num_vertex + 1));
+        GVK_TRY(to_device((uint32_t **)&g.edges_uv, uv, 2 * D));
+        GVK_TRY(to_device((gvk_alias_entry **)&g.edge_table, edge_table.data(), D));
+        GVK_TRY(to_device((gvk_alias_entry **)&g.neighbor_table, neighbor_table.data(), D));
+        if (biased) GVK_TRY(to_device((uint32_t **)&g.sorted_neighbors, sorted_neighbors.data(), D));
+        GVK_TRY(to_device((uint32_t **)&g.local, local.data(), num_vertex));
+        GVK_TRY(to_device(&w.walk_part, part.data(), num_vertex));
+        // one worker: the walks land in the block pools themselves; several: in this worker's slice of every block
+        std::vector<uint64_t> offsets((size_t)P * P);
+        const size_t n_slice = n / W;
+        for (int hp = 0; hp < P; hp++)
+            for (int tp = 0; tp < P; tp++) {
+                const size_t ti = std::find(w.tails.begin(), w.tails.end(), tp) - w.tails.begin();
+                offsets[(size_t)hp * P + tp] = W == 1 ? (ti * P + hp) * n : ((size_t)hp * P + tp) * n_slice;
+            }
+        GVK_TRY(to_device(&w.walk_offsets, offsets.data(), offsets.size()));
+        if (W > 1) HIP_TRY(hipMalloc(&w.slices, (size_t)P * P * n_slice * 8));
+        HIP_TRY(hipMalloc(&w.walk_counters, (size_t)P * P * largest_divisor(n_slice, 256) * 4));
+    }
+    return GVK_OK;
+}
+
+// The pools of one episode (set 0 / 1) for every worker, drawn by the GPUs on their sampling streams — what fill() does
+// with CPU threads.  Edge mode: one gvk_sample_pairs per block, nothing to wait for.  Walk modes: rounds of
+// gvk_sample_walks_blocks until every stripe of every block is full (the host reads the counters between rounds —
+// a handful of round trips, on a thread of its own while the GPUs train the episode before), then each slice goes to
+// the worker that trains its block.
+int gvx_solver::device_fill(int set) {
+    Range range("Sample (device)");
+    const int P = num_partition, W = num_worker;
+    const size_t n = (size_t)episode_size * batch_size, n_slice = n / W;
+    for (Worker &w : workers) {  // the pools of `set` were read by the episode before the one that trains now
+        HIP_TRY(hipSetDevice(w.device));
+        for (Worker &u : workers)
+            if (u.episode_end_valid) HIP_TRY(hipStreamWaitEvent(w.sample, u.episode_end, 0));
+    }
+    if (mode == GVS_MODE_EDGE) {
+        for (Worker &w : workers) {
+            HIP_TRY(hipSetDevice(w.device));
+            for (size_t i = 0; i < w.edge_blocks.size(); i++) {
+                const Worker::EdgeBlock &b = w.edge_blocks[i];
+                GVK_TRY(gvk_sample_pairs(w.sample, b.table, b.pairs, b.count, w.sample_seed, w.sample_index,
+                                         w.block_pools[set] + i * n * 2, n));
+                w.sample_index += n;
+            }
+            HIP_TRY(hipEventRecord(w.filled[set], w.sample));
+        }
+        return GVK_OK;
+    }
+    const int L = config.random_walk_length, aug = config.augmentation_step;
+    const uint64_t per_walk = (uint64_t)aug * L - (uint64_t)aug * (aug - 1) / 2;
+    if (P == 1) {  // one block: every walk owns its slots of the pool, no binning, no rounds
+        Worker &w = workers[0];
+        GVK_TRY(gvk_sample_walks(w.sample, &w.walk, w.sample_seed, w.sample_index, w.block_pools[set], n, L, aug,
+                                 config.shuffle_base));
+        w.sample_index += (n + per_walk - 1) / per_walk;
+        HIP_TRY(hipEventRecord(w.filled[set], w.sample));
+        return GVK_OK;
+    }
+    const int stripes = largest_divisor(n_slice, 256);
+    const uint64_t stripe_capacity = n_slice / stripes, every = 64ull * stripes;  // the same number of wavefronts per stripe
+    const size_t num_counter = (size_t)P * P * stripes;
+    std::vector<uint64_t> walks(W, ((n_slice * P * P + per_walk - 1) / per_walk / every + 1) * every), used(W, 0);
+    std::vector<char> full(W, 0);
+    std::vector<uint32_t> counters(num_counter);
+    for (Worker &w : workers) {
+        HIP_TRY(hipSetDevice(w.device));
+        HIP_TRY(hipMemsetAsync(w.walk_counters, 0, num_counter * 4, w.sample));
+    }
+    for (int round = 0;; round++) {
+        if (round == 64) return gvk_fail(GVK_EINVAL, "device sampling: the block pools are not full after 64 rounds of walks");
+        for (int r = 0; r < W; r++) {
+            Worker &w = workers[r];
+            if (full[r]) continue;
+            HIP_TRY(hipSetDevice(w.device));
+            GVK_TRY(gvk_sample_walks_blocks(w.sample, &w.walk, w.walk_part, P, w.sample_seed, w.sample_index + used[r], walks[r],
+                                            W == 1 ? w.block_pools[set] : w.slices, w.walk_offsets, w.walk_counters,
+                                            (uint32_t)n_slice, stripes, L, aug, config.shuffle_base));
+            used[r] += walks[r];
+        }
+        bool all_full = true;
+        for (int r = 0; r < W; r++) {
+            Worker &w = workers[r];
+            if (full[r]) continue;
+            HIP_TRY(hipSetDevice(w.device));
+            HIP_TRY(hipMemcpyAsync(counters.data(), w.walk_counters, num_counter * 4, hipMemcpyDeviceToHost, w.sample));
+            HIP_TRY(hipStreamSynchronize(w.sample));
+            // next round from the share of all pairs each stripe still short has received so far
+            double need = 0;
+            for (size_t i = 0; i < num_counter; i++) {
+                if (counters[i] >= stripe_capacity) continue;
+                const double share = std::max((double)counters[i] / ((double)used[r] * per_walk), 1.0 / (64.0 * num_counter));
+                if (counters[i] == 0 && used[r] * per_walk > 64ull * n_slice * P * P)
+                    return gvk_fail(GVK_EINVAL, "block (%zu, %zu) of the partition grid receives no random-walk pairs; use "
+                                    "fewer partitions", i / stripes / P, i / stripes % P);
+                need = std::max(need, (double)(stripe_capacity - counters[i]) / share / per_walk);
+            }
+            full[r] = need == 0;
+            walks[r] = ((uint64_t)(need * 1.1) / every + 1) * every;
+            all_full = all_full && full[r];
+        }
+        if (all_full) break;
+    }
+    for (int r = 0; r < W; r++) {
+        Worker &w = workers[r];
+        w.sample_index += used[r];
+        HIP_TRY(hipSetDevice(w.device));
+        for (int b = 0; b < P * P && W > 1; b++) {  // slice r of block b to the worker that trains b
+            const int hp = b / P, tp = b % P;
+            for (Worker &u : workers) {
+                const size_t ti = std::find(u.tails.begin(), u.tails.end(), tp) - u.tails.begin();
+                if (ti == u.tails.size()) continue;
+                uint32_t *to = u.block_pools[set] + ((ti * P + hp) * n + (size_t)r * n_slice) * 2;
+                const uint32_t *from = w.slices + (size_t)b * n_slice * 2;
+                hipError_t e = u.device == w.device
+                                   ? hipMemcpyAsync(to, from, n_slice * 8, hipMemcpyDeviceToDevice, w.sample)
+                                   : hipMemcpyPeerAsync(to, u.device, from, w.device, n_slice * 8, w.sample);
+                if (e != hipSuccess) return gvk_fail(GVK_EHIP, "routing of block (%d, %d): %s", hp, tp, hipGetErrorString(e));
+            }
+        }
+        HIP_TRY(hipEventRecord(w.filled[set], w.sample));
     }
     return GVK_OK;
 }
@@ -743,13 +1011,15 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, uint32_t *pool) {
 int gvx_solver::episode_loop() {
     const int P = num_partition, W = num_worker;
     const size_t pool_elems = (size_t)episode_size * batch_size * 2;
-    // pinned host pools, two sets (the samplers fill one while the GPUs read the other), one pool per block
+    // pinned host pools, two sets (the samplers fill one while the GPUs read the other), one pool per block;
+    // with device sampling the two sets are Worker::block_pools, in HBM
     std::vector<uint32_t *> sets[2];
     auto free_sets = [&]() {
         for (auto &set : sets)
             for (uint32_t *p : set) hipHostFree(p);
     };
     for (auto &set : sets) {
+        if (device_sampling) break;
         set.assign((size_t)P * P, nullptr);
         for (auto &p : set)
             if (hipHostMalloc(&p, pool_elems * 4, hipHostMallocDefault) != hipSuccess) {
@@ -765,7 +1035,8 @@ int gvx_solver::episode_loop() {
     const bool grouped = dim >= 64 && (table_bytes < ((size_t)16 << 20) || (table_bytes < ((size_t)256 << 20) && mode == GVS_MODE_EDGE));
     const int row_bits = std::max(32 - __builtin_clz(std::max(part_rows, 2u) - 1), 1);
     const uint64_t per_episode = (uint64_t)num_step * episode_size * config.positive_reuse * W;
-    int rc = fill(sets[0]);
+    auto produce = [&](int set) { return device_sampling ? device_fill(set) : fill(sets[set]); };
+    int rc = produce(0);
     int current = 0;
     while (rc == GVK_OK && batch_id < num_batch) {
         // the samplers may overwrite the other set once every copy out of it has landed
@@ -779,7 +1050,14 @@ int gvx_solver::episode_loop() {
         int fill_rc = GVK_OK;
         std::thread filler;
         if (batch_id + per_episode < num_batch)  // no pools for an episode that will not run
-            filler = std::thread([&, current]() { fill_rc = fill(sets[current ^ 1]); });
+            filler = std::thread([&, current]() { fill_rc = produce(current ^ 1); });
+        for (Worker &w : workers)  // device sampling: the pools of this episode, slices from every worker included
+            for (Worker &u : workers) {
+                if (!device_sampling) break;
+                hipSetDevice(w.device);
+                hipStreamWaitEvent(w.copy, u.filled[current], 0);
+                hipStreamWaitEvent(w.compute, u.filled[current], 0);
+            }
         auto stage = [&](Worker &w, int step) -> int {  // H2D copy (+ regrouping) of the worker's block of `step`
             Range upload_range("Upload");
             const int r = (int)(&w - workers.data());
@@ -787,15 +1065,20 @@ int gvx_solver::episode_loop() {
             const int b = (int)((w.visits + (uint64_t)step) & 1);
             HIP_TRY(hipSetDevice(w.device));
             if (w.released_valid[b]) HIP_TRY(hipStreamWaitEvent(w.copy, w.released[b], 0));
-            uint32_t *target = grouped ? w.landing : w.pool[b];
-            HIP_TRY(hipMemcpyAsync(target, sets[current][(size_t)hp * P + tp], pool_elems * 4, hipMemcpyHostToDevice, w.copy));
-            hipEvent_t copied;
-            HIP_TRY(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
-            HIP_TRY(hipEventRecord(copied, w.copy));
-            w.copied.push_back(copied);
+            const uint32_t *source = w.landing;
+            if (device_sampling) {  // already in HBM: trained in place unless it is regrouped
+                source = block_pool(w, current, hp, tp);
+            } else {
+                uint32_t *target = grouped ? w.landing : w.pool[b];
+                HIP_TRY(hipMemcpyAsync(target, sets[current][(size_t)hp * P + tp], pool_elems * 4, hipMemcpyHostToDevice, w.copy));
+                hipEvent_t copied;
+                HIP_TRY(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
+                HIP_TRY(hipEventRecord(copied, w.copy));
+                w.copied.push_back(copied);
+            }
             Range regroup("Regroup");
             if (grouped)
-                GVK_TRY(gvk_group_pairs(w.copy, w.landing, w.pool[b], w.group_workspace, &w.group_workspace_bytes, batch_size,
+                GVK_TRY(gvk_group_pairs(w.copy, source, w.pool[b], w.group_workspace, &w.group_workspace_bytes, batch_size,
                                         episode_size, row_bits));
             HIP_TRY(hipEventRecord(w.uploaded[b], w.copy));
             return GVK_OK;
@@ -817,7 +1100,8 @@ int gvx_solver::episode_loop() {
                 if (w.sending == hp) hipStreamWaitEvent(w.compute, w.sent, 0);  // its copies to the peers still read this slot
                 if (rc == GVK_OK && step + 1 < num_step) rc = stage(w, step + 1);  // next block's pool while this one trains
                 if (rc == GVK_OK && streamed) rc = load_block(w, hp, tp);
-                if (rc == GVK_OK) rc = train_block(w, hp, tp, w.pool[b]);
+                if (rc == GVK_OK)
+                    rc = train_block(w, hp, tp, device_sampling && !grouped ? block_pool(w, current, hp, tp) : w.pool[b]);
                 hipEventRecord(w.released[b], w.compute);
                 w.released_valid[b] = true;
                 hipEventRecord(w.trained, w.compute);
@@ -857,6 +1141,12 @@ int gvx_solver::episode_loop() {
             if (filler.joinable()) filler.join();
         }
         if (rc == GVK_OK) rc = fill_rc;
+        for (Worker &w : workers) {  // device sampling: the pools of this episode may be redrawn once it has trained
+            if (!device_sampling) break;
+            hipSetDevice(w.device);
+            hipEventRecord(w.episode_end, w.compute);
+            w.episode_end_valid = true;
+        }
         current ^= 1;
     }
     for (Worker &w : workers) {

@@ -83,6 +83,15 @@ gvx_solver *gvx_solver_create(int dim, const int *device_ids, int num_device, in
                               size_t gpu_memory_limit);
 void gvx_solver_destroy(gvx_solver *s);
 
+/* Beyond the reference's arguments (off by default; takes effect at the next train()).
+ * GVX_DEVICE_SAMPLING 1: the positive samples are drawn by the GPUs themselves instead of the CPU sampler threads
+ * (solver.h:1012-1055) — gvk_sample_pairs over per-block edge alias tables for augmentation_step 1, gvk_sample_walks_blocks
+ * for the random-walk modes: every worker walks the whole graph, keeps a 1/#worker slice of every block pool and copies
+ * each slice to the worker that trains the block, GPU to GPU.  Resident (not streamed) mode only; graphs with fewer
+ * than 2^32 directed edges. */
+#define GVX_DEVICE_SAMPLING 1
+int gvx_solver_set(gvx_solver *s, int option, int64_t value);
+
 /* The graph is borrowed until the next build / destroy (solver.h:289).  num_partition / episode_size: GVX_AUTO. */
 int gvx_solver_build(gvx_solver *s, const gvs_graph *graph, const gvx_optimizer *optimizer, int num_partition,
                      int num_negative, int batch_size, int episode_size);

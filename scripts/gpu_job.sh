@@ -17,6 +17,7 @@ if [[ $WHAT == *measure* ]]; then
   python bench.py > gpurun_out/bench_n1.json 2> gpurun_out/bench_n1.err
   python bench.py --steps 20 --warmup 5 > gpurun_out/bench_n1_steps20.json 2>> gpurun_out/bench_n1.err
   python scripts/measure_configs.py > gpurun_out/configs_2_4.jsonl 2> gpurun_out/configs_2_4.err
+  python scripts/measure_engine.py --epochs 1000 > gpurun_out/engine_e2e.jsonl 2> gpurun_out/engine_e2e.err
   for d in 32 64 96 256 512; do
     python bench.py --dim $d --no-cpu-baseline --no-end-to-end --steps 1000 --warmup 100
   done > gpurun_out/dim_sweep.jsonl 2> gpurun_out/dim_sweep.err

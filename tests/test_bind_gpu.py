@@ -113,6 +113,31 @@ def test_two_workers_in_one_process(data):
         assert auc > 0.9 and solver.shuffle_base == (1 if model == "DeepWalk" else extra["augmentation_step"])
 
 
+@pytest.mark.parametrize("devices,partitions", [([0], 1), ([0], 3), ([0, 0], 2), ([0, 0], 4)])
+def test_positive_samples_drawn_on_the_device(data, devices, partitions):
+    """device_sampling=True (beyond the reference): no CPU sampler threads — gvk_sample_pairs over per-block edge tables for
+    augmentation_step 1; for the walk models gvk_sample_walks (one partition) or gvk_sample_walks_blocks, every worker
+    keeping a slice of EVERY block and handing it to the worker that trains the block.  Learning matches the CPU-sampled
+    runs of the tests above; a streamed model refuses."""
+    lib, graph, keep = data
+    solver = lib.solver.GraphSolver_128_f_j(device_ids=devices, num_sampler_per_worker=1, device_sampling=True)
+    solver.build(graph, num_partition=partitions, batch_size=10000, episode_size=6)
+    runs = (("LINE", dict(augmentation_step=1)), ("LINE", dict(augmentation_step=2, random_walk_length=6)),
+            ("DeepWalk", dict(augmentation_step=2, random_walk_length=10)),
+            ("node2vec", dict(augmentation_step=2, random_walk_length=10, p=0.5, q=2.0)))
+    for model, extra in runs:
+        solver.train(model=model, num_epoch=200, log_frequency=1 << 30, **extra)
+        auc = auc_of(solver, keep)
+        print("module, device sampling, %d worker(s) / %d partition(s), %s aug %d: AUC %.6f"
+              % (len(devices), partitions, model, extra["augmentation_step"], auc))
+        assert auc > 0.9 and solver.num_partition == partitions
+    if partitions == 1:
+        small = lib.solver.GraphSolver_128_f_j(device_ids=[0], gpu_memory_limit=9 << 20, device_sampling=True)
+        small.build(graph, batch_size=10000, episode_size=10)
+        with pytest.raises(ValueError, match="resident"):
+            small.train(model="LINE", num_epoch=1, augmentation_step=1)
+
+
 def test_custom_schedule_moments_and_resume(data):
     lib, graph, keep = data
     calls = []
