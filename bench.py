@@ -9,9 +9,15 @@ per block visit, as in the episode loop: [regrouping pass gvk_group_pairs on the
 trains] -> gvk_train_episode (negatives drawn in-kernel, lr schedule per batch) for `--block-batches` batches ->
 with N > 1 all GPUs all-gather the head shards they just trained (RCCL over xGMI, asynchronous).
 
-The timed region is WHOLE block visits: it starts on a block boundary and `--block-batches` defaults to at most
-`--steps`, so every block visit whose batches are timed has its regrouping pass, its staging and its exchange
-inside the region too, at any --steps (`regroup` reports the passes that ran inside it).
+The timed region is WHOLE block visits: it starts on a block boundary, so every block visit whose batches are timed
+has its regrouping pass, its staging and its exchange inside the region too (`regroup` / `exchange` report what ran
+inside it).  N = 1: `--block-batches` defaults to at most `--steps` and exactly K steps are timed.  N > 1: a block visit
+is as long as the reference's episode rule makes it for this graph and partition count (num_vertex * 175 / P /
+batch_size batches, solver.h:426-436; at most 250) — an exchange every 20 batches, 5 to 20 times as often as training
+ever does it, would make a short run measure the fabric instead of the path — and the K requested steps are rounded
+UP to whole visits, at least `--min-visits` of them: `steps` in the line is what was timed, `steps_requested` is K.
+The region starts with no exchange in flight and closes with a fence, so of its n exchanges n - 1 overlap the next
+visit (as in the episode loop) and the last one is fully exposed: the value is a lower bound of the steady state.
 
     python bench.py [--steps K] [--warmup W]                                                     (N = 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -62,6 +68,8 @@ def parse(argv=None):
                    help="batches per (head, tail) block pool = batches between two exchanges; 0 = the solver's "
                         "auto episode size for this graph (solver.h:426-436), capped at 250 and at --steps (so that "
                         "the timed region is made of whole block visits)")
+    p.add_argument("--min-visits", type=int, default=4,
+                   help="N > 1 without --block-batches: the timed region holds at least this many whole block visits")
     p.add_argument("--no-end-to-end", action="store_true", help="skip the GraphSolver.train() runs (`end_to_end`)")
     p.add_argument("--end-to-end", action="store_true",
                    help="run `end_to_end` with several GPUs too (default: one GPU only — an error on one rank inside a "
@@ -236,11 +244,15 @@ def main(argv=None, stand_in_kernels=None):
     N, E, B, k, dim = args.vertices, args.edges, args.batch, args.negatives, args.dim
     # two head groups per GPU (P = 2 * #GPU) let the all-gather of one group overlap the training on the other
     partitions = args.partitions or (world if world == 1 else 2 * world)
+    steps_requested = args.steps
     if not args.block_batches:
-        auto = max(int(float(N) * 175 / partitions / B), 1)
+        auto = max(int(float(N) * 175 / partitions / B), 1)  # the reference's episode size, solver.h:426-436
         if world == 1:
             auto = max(auto, int(2e7) // B)
-        args.block_batches = max(min(auto, 250, args.steps), 1)
+            args.block_batches = max(min(auto, 250, args.steps), 1)
+        else:  # whole visits of the real length, see the docstring
+            args.block_batches = max(min(auto, 250), 1)
+            args.steps = max(-(-args.steps // args.block_batches), args.min_visits) * args.block_batches
     from graphvite_amd.base import cpu_budget
     threads = args.sampler_threads or max(cpu_budget() // world, 1)
 
@@ -442,7 +454,7 @@ def main(argv=None, stand_in_kernels=None):
         "metric": "million edge-samples/sec at dim=%d" % dim,
         "value": world * args.steps * B / wall / 1e6,
         "unit": "million edge-samples/sec",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "steps": args.steps, "steps_requested": steps_requested, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic" if cuda else "DRY RUN on the CPU with the test stand-in: logic test, not a result",

@@ -124,6 +124,34 @@ def test_bench_loop_dry_run(world, order):
     assert r["config"]["block_visits_timed"] == 6 and r["roofline"]["kernel"] == "stand-in"
 
 
+def test_bench_rounds_a_multi_gpu_run_up_to_whole_block_visits():
+    """`bench.py --gpus 2 --steps 20` as the driver launches it (no --block-batches): a block visit has the length the
+    reference's episode rule gives it (num_vertex * 175 / P / batch_size, solver.h:426-436) and the timed region is whole
+    visits, at least four — the line says how many steps that was, and every visit's exchange ran."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join("tests", "bench_dry_run.py"), "--gpus", "2", "--vertices", "400",
+           "--edges", "4000", "--batch", "2000", "--dim", "32", "--steps", "20", "--warmup", "5", "--sampler-threads", "1"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    run = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    r = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][0])
+    block = 400 * 175 // 4 // 2000  # 8 batches per visit
+    assert r["config"]["block_batches"] == block and r["steps_requested"] == 20
+    assert r["steps"] == 4 * block and r["config"]["block_visits_timed"] == 4  # 20 steps round up to 3 visits; at least 4
+    assert r["exchange"]["collectives_total"] == 4 * 4 // 2 + 1 + 4        # residency, warm-up, the four timed visits
+    assert r["value"] == pytest.approx(2 * r["steps"] * 2000 / (r["ms_per_step"] * r["steps"] * 1e-3) / 1e6)
+
+
 def test_kernel_choice_by_table_size():
     """gvk_describe_train (a host function: no GPU needed) — which kernel a configuration launches: runs of same-head
     samples on head tables below 16 MiB (any optimizer, any number of negatives), the per-pair kernel above; the A/B
