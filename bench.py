@@ -102,6 +102,7 @@ def parse(argv=None):
                    help="experiment: 'community' swaps in a hub-free planted-partition graph of the same size")
     p.add_argument("--sampler-threads", type=int, default=0, help="0 = host cores / GPUs")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-access-pattern", action="store_true", help="skip the row-traffic probe (`roofline.access_pattern`)")
     p.add_argument("--cpu-seconds", type=float, default=3.0, help="wall seconds given to the CPU baseline")
     p.add_argument("--seed", type=int, default=1024)
     return p.parse_args(argv)
@@ -174,6 +175,37 @@ def cpu_baseline(args, solver, pool, table_packed):
                            "synthetic BlogCatalog-sized graph (10 312 nodes / 333 983 edges), %.1f s wall, same build and "
                            "threads" % (done1, B, el1)}
     return out
+
+
+def access_pattern(solver, session, landed, blocks, B, dim, launches=200):
+    """The ceiling of the memory system for what a training batch touches: gvk_probe_row_traffic reads and writes back
+    the head row, the tail row and one negative row per edge-sample of the SAME pools on the SAME tables (fresh negatives
+    per launch, drawn as the training kernel draws them), no arithmetic, no dependent draw.  HIP events around
+    back-to-back launches on the launch stream."""
+    import torch
+    hp, tp = blocks[0]
+    vertex, context, _ = solver._tables(session.state, hp, tp)
+    pool = landed[blocks[0]]
+    batches = min(pool.numel() // 2 // B, launches)
+    table = session.negative_table(tp)
+    negatives = torch.empty((batches, B), dtype=torch.int32, device=vertex.device)
+    for b in range(batches):
+        solver.kernels.negative_draw(table, 0x51ed, b, negatives[b], B, 1)
+
+    def sweep():
+        for i in range(launches):
+            b = i % batches
+            solver.kernels.probe_row_traffic(vertex, context, pool[b * B * 2:(b + 1) * B * 2], negatives[b])
+    sweep()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    sweep()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / launches
+    achieved = algorithmic_bytes(dim, 1) * B / (ms * 1e-3)
+    return {"kernel": "probe_rows_kernel: the rows of a batch read and written back, nothing else", "kernel_ms": ms,
+            "achieved": achieved / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "launches": launches}
 
 
 def end_to_end(args, gv, graph, world, threads, partitions):
@@ -482,6 +514,10 @@ def main(argv=None, stand_in_kernels=None):
                     "note": "CPU edge sampler filling this GPU's block pools before the timed region"},
         "final_batch_mean_loss": final_loss,
     }
+    if cuda and k == 1 and moments == 0 and not args.no_access_pattern:
+        # how close the training kernel is to what the memory system sustains for ITS access pattern
+        result["roofline"]["access_pattern"] = probe = access_pattern(solver, session, landed, blocks, B, dim)
+        probe["train_kernel_vs_probe"] = probe["kernel_ms"] / kernel_ms
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         tp = blocks[0][1]
         packed = session.negative_table(tp).cpu().numpy().view(np.dtype([("prob", np.float32), ("alias", np.uint32)]))

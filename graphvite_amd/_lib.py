@@ -84,6 +84,8 @@ def lib():
                                     i32, vp, i32, i32, f32]
     l.gvk_predict.restype = i32
     l.gvk_predict.argtypes = [vp, i32, vp, vp, vp, vp, i32]
+    l.gvk_probe_row_traffic.restype = i32
+    l.gvk_probe_row_traffic.argtypes = [vp, i32, vp, vp, vp, vp, C.c_float, i32]
     l.gvk_alias_sample.restype = i32
     l.gvk_alias_sample.argtypes = [vp, vp, u32, vp, vp, i32]
     l.gvk_negative_draw.restype = i32

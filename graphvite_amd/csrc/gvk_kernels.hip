@@ -740,6 +740,28 @@ __global__ void __launch_bounds__(kBlock) predict_kernel(const float *vertex, co
     if (lane == 0) logits[s] = logit;
 }
 
+// The memory traffic of train_kernel<DIM, G, SGD, k = 1> and nothing else (gvk_probe_row_traffic): the same lane layout,
+// the same rows read and written, no arithmetic to speak of and no dependent draw (the negative row is given).
+template <int DIM, int G>
+__global__ void __launch_bounds__(kBlock) probe_rows_kernel(float *vertex, float *context, const uint32_t *pairs,
+                                                            const uint32_t *negatives, float bump, int batch_size) {
+    constexpr int V = DIM / G;
+    const int tid = blockIdx.x * kBlock + threadIdx.x;
+    const int s = tid / G, lane = tid % G;
+    if (s >= batch_size) return;
+    const u32x2 pr = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pairs) + s);
+    const uint32_t negative = __builtin_nontemporal_load(negatives + s);
+    float v[V], c[V], n[V];
+    load_row<DIM, G>(vertex, pr.y, lane, v);
+    load_row<DIM, G>(context, pr.x, lane, c);
+    load_row<DIM, G>(context, negative, lane, n);
+#pragma unroll
+    for (int i = 0; i < V; i++) v[i] += bump, c[i] += bump, n[i] += bump;
+    store_row<DIM, G>(context, negative, lane, n);
+    store_row<DIM, G>(context, pr.x, lane, c);
+    store_row<DIM, G>(vertex, pr.y, lane, v);
+}
+
 __global__ void __launch_bounds__(kBlock) alias_sample_kernel(const gvk_alias_entry *table, uint32_t count,
                                                               const double *rand, uint32_t *result, int n) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -1200,6 +1222,24 @@ int gvk_predict(void *stream, int dim, const float *vertex, const float *context
     }
 #undef GVK_PREDICT
     return check_launch("gvk_predict");
+}
+
+int gvk_probe_row_traffic(void *stream, int dim, float *vertex, float *context, const uint32_t *pairs,
+                          const uint32_t *negatives, float bump, int batch_size) {
+    if (!default_lanes(dim)) return fail(GVK_EDIM, "gvk_probe_row_traffic: dim must be one of 32, 64, 96, 128, 256, 512");
+    if (batch_size <= 0) return GVK_OK;
+    if (!vertex || !context || !pairs || !negatives) return fail(GVK_EINVAL, "gvk_probe_row_traffic: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+#define GVK_PROBE(D, GG)                                                                                       \
+    case D:                                                                                                    \
+        hipLaunchKernelGGL((probe_rows_kernel<D, GG>), dim3((unsigned)(((int64_t)batch_size * GG + kBlock - 1) / kBlock)), \
+                           dim3(kBlock), 0, st, vertex, context, pairs, negatives, bump, batch_size);          \
+        break;
+    switch (dim) {  // the lane groups of gvk_train
+        GVK_PROBE(32, 8) GVK_PROBE(64, 16) GVK_PROBE(96, 8) GVK_PROBE(128, 16) GVK_PROBE(256, 16) GVK_PROBE(512, 32)
+    }
+#undef GVK_PROBE
+    return check_launch("gvk_probe_row_traffic");
 }
 
 int gvk_alias_sample(void *stream, const gvk_alias_entry *table, uint32_t count, const double *rand,

@@ -150,6 +150,21 @@ class HipKernels(object):
                                   _ptr(logits), pairs.shape[0])
         _lib.check(rc, "gvk_predict")
 
+    def probe_row_traffic(self, vertex, context, pairs, negatives, bump=0.0):
+        """Measurement aid (gvk_probe_row_traffic): read and write back the head, tail and given negative row of every
+        pair — the memory traffic of a training batch (SGD, one negative) without its arithmetic."""
+        dev = vertex.device
+        _need(vertex, torch.float32, "vertex")
+        _need(context, torch.float32, "context", dev)
+        _need(pairs, torch.int32, "pairs", dev)
+        _need(negatives, torch.int32, "negatives", dev)
+        n = pairs.numel() // 2
+        if negatives.numel() < n:
+            raise ValueError("one negative per pair")
+        rc = self.lib.gvk_probe_row_traffic(self._stream(vertex), vertex.shape[1], _ptr(vertex), _ptr(context), _ptr(pairs),
+                                            _ptr(negatives), bump, n)
+        _lib.check(rc, "gvk_probe_row_traffic")
+
     def alias_sample(self, table, rand, result):
         _need(table, torch.int64, "alias table")
         _need(rand, torch.float64, "rand", table.device)

@@ -199,6 +199,14 @@ int gvk_group_pairs(void *stream, const uint32_t *pool_in, uint32_t *pool_out, v
 int gvk_alias_build(const float *weights, size_t n, float *prob, void *alias, int index_bytes,
                     gvk_alias_entry *packed);
 
+/* Measurement aid (bench.py `roofline.access_pattern`): the memory traffic of gvk_train (SGD, one negative) with none
+ * of its arithmetic and none of its dependent loads — per sample the head row, the tail row and the GIVEN negative row
+ * are read, `bump` is added to every element and they are written back, in gvk_train's lane layout.  What this kernel
+ * sustains is the ceiling of the memory system for the access pattern of the hot path (random rows of dim * 4 bytes,
+ * half reads, half writes); gvk_train can at best match it. */
+int gvk_probe_row_traffic(void *stream, int dim, float *vertex, float *context, const uint32_t *pairs,
+                          const uint32_t *negatives, float bump, int batch_size);
+
 /* Tuning knobs for A/B measurement (bench.py --variant); they never change results beyond
  * floating-point summation order.  Returns GVK_EINVAL for an unknown key or unsupported value. */
 #define GVK_TUNE_LANES_PER_PAIR 1 /* 0 = per-dim default; else 8, 16, 32 or 64 */

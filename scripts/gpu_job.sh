@@ -21,6 +21,8 @@ if [[ $WHAT == *measure* ]]; then
   for d in 32 64 96 256 512; do
     python bench.py --dim $d --no-cpu-baseline --no-end-to-end --steps 1000 --warmup 100
   done > gpurun_out/dim_sweep.jsonl 2> gpurun_out/dim_sweep.err
+  # the same lines carry roofline.access_pattern (gvk_probe_row_traffic): the ceiling of the memory system per dim
+  cp gpurun_out/dim_sweep.jsonl gpurun_out/access_pattern_probe.jsonl
   # the shard sizes of multi-GPU runs on the one GPU (what a GPU of an 8-GPU run trains: 16 partitions of 32 MB)
   for parts in 4 8 16; do
     python bench.py --partitions $parts --no-cpu-baseline --no-end-to-end --steps 1000 --warmup 100

@@ -520,6 +520,27 @@ def test_predict_matches_oracle(hip, oracle, dim):
     np.testing.assert_allclose(logits.cpu().numpy(), oracle.predict(v, c, pairs), rtol=1e-5, atol=1e-8)
 
 
+@pytest.mark.parametrize("dim", [32, 64, 96, 128, 256, 512])
+def test_row_traffic_probe_touches_exactly_the_rows_of_a_batch(hip, dim):
+    """gvk_probe_row_traffic (bench.py's `roofline.access_pattern`): every element of the head, tail and negative row of
+    every pair read, bumped and written back, nothing else touched; bump 0 leaves the tables bit-identical."""
+    rng = np.random.default_rng(dim)
+    N, B = 4096, 777
+    v, c = init_tables(rng, N, N, dim)
+    pairs, negs = conflict_free_batch(rng, N, N, B, 1)
+    tv, tc, tp, tn = dev(v), dev(c), dev(pairs.view(np.int32)), dev(negs.view(np.int32).reshape(-1))
+    hip.probe_row_traffic(tv, tc, tp, tn)
+    assert (tv.cpu().numpy() == v).all() and (tc.cpu().numpy() == c).all()
+    hip.probe_row_traffic(tv, tc, tp, tn, bump=1.0)
+    want_v, want_c = v.copy(), c.copy()
+    want_v[pairs[:, 1]] += 1
+    want_c[pairs[:, 0]] += 1
+    want_c[negs[:, 0]] += 1
+    assert (tv.cpu().numpy() == want_v).all() and (tc.cpu().numpy() == want_c).all()
+    with pytest.raises(ValueError, match="dim"):
+        hip.probe_row_traffic(torch.zeros((4, 48), device=DEV), torch.zeros((4, 48), device=DEV), tp, tn)
+
+
 def test_hogwild_batch_statistics(hip, oracle):
     """Arbitrary batch with conflicts (T2): batch-mean loss and row norms track the sequential oracle."""
     rng = np.random.default_rng(21)
