@@ -111,6 +111,15 @@ def test_solver_without_gpu_fails_loudly():
     lib = load_module()
     with pytest.raises(ValueError, match="No GPU devices found"):  # solver.h:176; there is no CPU training path
         lib.solver.GraphSolver_128_f_j()
+    with pytest.raises(ValueError, match="No GPU devices found"):  # the keyword beyond the reference's is accepted
+        lib.solver.GraphSolver_128_f_j(device_ids=[0], num_sampler_per_worker=1, device_sampling=True)
+    with pytest.raises(TypeError):
+        lib.solver.GraphSolver_128_f_j(sample_on_device=True)
+    import ctypes as C
+    from graphvite_amd import _lib
+    gvk = _lib.lib()
+    gvk.gvx_solver_set.restype, gvk.gvx_solver_set.argtypes = C.c_int, [C.c_void_p, C.c_int, C.c_int64]
+    assert gvk.gvx_solver_set(None, 1, 1) == _lib.GVK_EINVAL and b"null solver" in gvk.gvk_last_error()
 
 
 @pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference tree is not on this machine")
