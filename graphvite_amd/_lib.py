@@ -92,6 +92,8 @@ def lib():
     l.gvk_negative_draw.argtypes = [vp, vp, u32, u64, u32, vp, i32, i32]
     l.gvk_sample_pairs.restype = i32
     l.gvk_sample_pairs.argtypes = [vp, vp, vp, u32, u64, u64, vp, C.c_size_t]
+    l.gvk_sample_edges.restype = i32
+    l.gvk_sample_edges.argtypes = [vp, vp, u32, u64, u64, vp, C.c_size_t]
     l.gvk_sample_walks.restype = i32
     l.gvk_sample_walks.argtypes = [vp, P(WalkGraph), u64, u64, vp, C.c_size_t, i32, i32, i32]
     l.gvk_sample_walks_blocks.restype = i32

@@ -36,6 +36,7 @@ constexpr int kBlock = 256;         // 4 wavefronts; no LDS, no barrier -> block
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 int g_lanes_per_pair = 0;  // GVK_TUNE_LANES_PER_PAIR
 int g_variant = 0;         // GVK_TUNE_VARIANT
@@ -801,6 +802,23 @@ __global__ void __launch_bounds__(kBlock) sample_pairs_kernel(const gvk_alias_en
     __builtin_nontemporal_store(block_pairs[edge], pool + t);
 }
 
+// the same draw from the packed form: the pair of a slot sits next to its probability, so a draw that keeps its slot
+// (every draw on an unweighted graph) is ONE random 16-byte read instead of a slot and then a pair
+__global__ void __launch_bounds__(kBlock) sample_edges_kernel(const gvk_edge_entry *table, uint32_t count, uint64_t seed,
+                                                              uint64_t first_index, u32x2 *pool, size_t n) {
+    const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n) return;
+    const uint64_t i = first_index + t;
+    uint32_t w[4];
+    philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), 0, kTagPositive, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    const uint32_t index = __umulhi(w[0], count);
+    const float u = (float)(w[1] >> 8) * (1.0f / 16777216.0f);
+    const u32x4 e = *reinterpret_cast<const u32x4 *>(table + index);
+    u32x2 pair = {e.z, e.w};
+    if (!(u < __uint_as_float(e.x))) pair = *reinterpret_cast<const u32x2 *>(&table[e.y].tail);
+    __builtin_nontemporal_store(pair, pool + t);
+}
+
 constexpr uint32_t kTagWalk = 0x77616c6bu;
 
 __device__ __forceinline__ bool has_neighbor(const gvk_walk_graph &g, uint32_t x, uint32_t u) {
@@ -1274,6 +1292,17 @@ int gvk_sample_pairs(void *stream, const gvk_alias_entry *table, const uint32_t 
                        reinterpret_cast<const u32x2 *>(block_pairs), count, seed, first_index,
                        reinterpret_cast<u32x2 *>(pool), n);
     return check_launch("gvk_sample_pairs");
+}
+
+int gvk_sample_edges(void *stream, const gvk_edge_entry *table, uint32_t count, uint64_t seed, uint64_t first_index,
+                     uint32_t *pool, size_t n) {
+    if (n == 0) return GVK_OK;
+    if (!table || !count || !pool) return fail(GVK_EINVAL, "gvk_sample_edges: null pointer / empty block");
+    const size_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > 0x7fffffffu) return fail(GVK_EINVAL, "gvk_sample_edges: pool too large for one call");
+    hipLaunchKernelGGL(sample_edges_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, table, count, seed,
+                       first_index, reinterpret_cast<u32x2 *>(pool), n);
+    return check_launch("gvk_sample_edges");
 }
 
 int gvk_sample_walks(void *stream, const gvk_walk_graph *graph, uint64_t seed, uint64_t first_walk, uint32_t *pool,

@@ -133,8 +133,7 @@ struct Worker {
     uint64_t visits = 0;
     // positive samples drawn on the device (GVX_DEVICE_SAMPLING)
     struct EdgeBlock {
-        gvk_alias_entry *table = nullptr;  // alias table over the weights of the block's edges
-        uint32_t *pairs = nullptr;         // their {tail, head} records (local ids)
+        gvk_edge_entry *table = nullptr;  // alias table over the weights of the block's edges + their {tail, head} records
         uint32_t count = 0;
     };
     hipStream_t sample = nullptr;
@@ -200,7 +199,7 @@ struct gvx_solver {
             hipFree(w.landing), hipFree(w.group_workspace);
             for (auto *t : w.negative_tables) hipFree(t);
             hipFree(w.block_pools[0]), hipFree(w.block_pools[1]), hipFree(w.slices);
-            for (auto &b : w.edge_blocks) hipFree(b.table), hipFree(b.pairs);
+            for (auto &b : w.edge_blocks) hipFree(b.table);
             hipFree((void *)w.walk.flat_offsets), hipFree((void *)w.walk.edges_uv), hipFree((void *)w.walk.edge_table);
             hipFree((void *)w.walk.neighbor_table), hipFree((void *)w.walk.sorted_neighbors), hipFree((void *)w.walk.local);
             hipFree(w.walk_part), hipFree(w.walk_offsets), hipFree(w.walk_counters);
@@ -637,7 +636,7 @@ int largest_divisor(size_t n, int limit) {  // stripes of gvk_sample_walks_block
 }  // namespace
 
 // What the samplers of the device draw from: per block a worker trains, the block's edges and an alias table over their
-// weights (augmentation_step 1: a positive sample of a block is one of its edges, gvk_sample_pairs); for the walk modes
+// weights (augmentation_step 1: a positive sample of a block is one of its edges, gvk_sample_edges); for the walk modes
 // the whole graph — CSR, per-vertex alias tables, the global edge table, the partition map (gvk_sample_walks_blocks).
 int gvx_solver::prepare_device_sampling() {
     const int P = num_partition, W = num_worker;
@@ -684,17 +683,15 @@ int gvx_solver::prepare_device_sampling() {
                         return gvk_fail(GVK_EINVAL, "block (%d, %d) has no edges; use fewer partitions for this graph", hp,
                                         w.tails[ti]);
                     std::vector<float> block_weights(ids.size()), prob(ids.size());
-                    std::vector<uint32_t> alias(ids.size()), pairs(2 * ids.size());
-                    std::vector<gvk_alias_entry> packed(ids.size());
-                    for (size_t i = 0; i < ids.size(); i++) {
-                        block_weights[i] = weights[ids[i]];
-                        pairs[2 * i] = local[uv[2 * (size_t)ids[i] + 1]], pairs[2 * i + 1] = local[uv[2 * (size_t)ids[i]]];
-                    }
-                    GVK_TRY(gvk_alias_build(block_weights.data(), ids.size(), prob.data(), alias.data(), 4, packed.data()));
+                    std::vector<uint32_t> alias(ids.size());
+                    std::vector<gvk_edge_entry> packed(ids.size());
+                    for (size_t i = 0; i < ids.size(); i++) block_weights[i] = weights[ids[i]];
+                    GVK_TRY(gvk_alias_build(block_weights.data(), ids.size(), prob.data(), alias.data(), 4, nullptr));
+                    for (size_t i = 0; i < ids.size(); i++)  // records are {tail, head} in local ids
+                        packed[i] = {prob[i], alias[i], local[uv[2 * (size_t)ids[i] + 1]], local[uv[2 * (size_t)ids[i]]]};
                     Worker::EdgeBlock &b = w.edge_blocks[ti * P + hp];
                     b.count = (uint32_t)ids.size();
                     GVK_TRY(to_device(&b.table, packed.data(), packed.size()));
-                    GVK_TRY(to_device(&b.pairs, pairs.data(), pairs.size()));
                 }
             continue;
         }
@@ -724,7 +721,7 @@ int gvx_solver::prepare_device_sampling() {
 }
 
 // The pools of one episode (set 0 / 1) for every worker, drawn by the GPUs on their sampling streams — what fill() does
-// with CPU threads.  Edge mode: one gvk_sample_pairs per block, nothing to wait for.  Walk modes: rounds of
+// with CPU threads.  Edge mode: one gvk_sample_edges per block, nothing to wait for.  Walk modes: rounds of
 // gvk_sample_walks_blocks until every stripe of every block is full (the host reads the counters between rounds —
 // a handful of round trips, on a thread of its own while the GPUs train the episode before), then each slice goes to
 // the worker that trains its block.
@@ -742,7 +739,7 @@ int gvx_solver::device_fill(int set) {
             HIP_TRY(hipSetDevice(w.device));
             for (size_t i = 0; i < w.edge_blocks.size(); i++) {
                 const Worker::EdgeBlock &b = w.edge_blocks[i];
-                GVK_TRY(gvk_sample_pairs(w.sample, b.table, b.pairs, b.count, w.sample_seed, w.sample_index,
+                GVK_TRY(gvk_sample_edges(w.sample, b.table, b.count, w.sample_seed, w.sample_index,
                                          w.block_pools[set] + i * n * 2, n));
                 w.sample_index += n;
             }

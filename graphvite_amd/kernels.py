@@ -191,6 +191,21 @@ class HipKernels(object):
                                        first_index, _ptr(pool), n)
         _lib.check(rc, "gvk_sample_pairs")
 
+    @staticmethod
+    def pack_edge_table(table, block_pairs):
+        """gvk_edge_entry[count] (int64 [count, 2]) from a block's alias table and its {tail, head} records."""
+        return torch.cat([table.view(torch.int32).view(-1, 2), block_pairs.view(-1, 2)], 1).contiguous().view(torch.int64)
+
+    def sample_edges(self, edge_table, seed, first_index, pool, n):
+        """pool[:n] = positive pairs of one block from its packed table (gvk_sample_edges): the draws of sample_pairs."""
+        _need(edge_table, torch.int64, "packed block table")
+        _need(pool, torch.int32, "pool", edge_table.device)
+        if edge_table.dim() != 2 or edge_table.shape[1] != 2 or pool.numel() < 2 * n:
+            raise ValueError("edge_table must be [count, 2] int64 (16-byte entries) and pool must hold 2 * n values")
+        rc = self.lib.gvk_sample_edges(self._stream(edge_table), _ptr(edge_table), edge_table.shape[0], seed, first_index,
+                                       _ptr(pool), n)
+        _lib.check(rc, "gvk_sample_edges")
+
     def group_pairs(self, pool_in, pool_out, batch_size, num_batch, num_row):
         """pool_out = pool_in with the pairs of every batch that share a head row made adjacent (gvk_group_pairs).
         Runs on the current stream; the scratch buffer comes from torch's caching allocator."""

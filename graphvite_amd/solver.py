@@ -845,7 +845,7 @@ class GraphSolver(object):
     # ---- device-side positive sampling (edge mode) ---------------------------------------------------------
     def _upload_block_tables(self, state):
         """Per block this worker trains: the block's directed edges as {tail, head} local-id records and an alias
-        table over their weights — what gvk_sample_pairs draws from."""
+        table over their weights, packed 16 bytes per edge — what gvk_sample_edges draws from."""
         from .kernels import alias_build, packed_to_device
         edges, weights = self.graph.edges, self.graph.edge_weights
         hp_of, tp_of = self._part[edges[:, 0]], self._part[edges[:, 1]]
@@ -856,8 +856,8 @@ class GraphSolver(object):
                 raise ValueError("block (%d, %d) has no edges; use fewer partitions for this graph" % (hp, tp))
             pairs = np.stack([self._local[edges[ids, 1]], self._local[edges[ids, 0]]], 1).astype(np.uint32)
             _, _, packed = alias_build(weights[ids])
-            state["block_tables"][(hp, tp)] = (packed_to_device(packed, self.device),
-                                                self._to_device(pairs.view(np.int32).reshape(-1)))
+            state["block_tables"][(hp, tp)] = self.kernels.pack_edge_table(
+                packed_to_device(packed, self.device), self._to_device(pairs.view(np.int32).reshape(-1)))
         state["positive_index"] = 0
 
     def _upload_walk_graph(self, state):
@@ -911,8 +911,7 @@ class GraphSolver(object):
                 per_walk = aug * L - aug * (aug - 1) // 2
                 state["positive_index"] += (n + per_walk - 1) // per_walk
             else:
-                table, pairs = state["block_tables"][block]
-                self.kernels.sample_pairs(table, pairs, seed, state["positive_index"], landing, n)
+                self.kernels.sample_edges(state["block_tables"][block], seed, state["positive_index"], landing, n)
                 state["positive_index"] += n
             self._group_pairs(landing, buf)
 

@@ -85,7 +85,7 @@ void gvx_solver_destroy(gvx_solver *s);
 
 /* Beyond the reference's arguments (off by default; takes effect at the next train()).
  * GVX_DEVICE_SAMPLING 1: the positive samples are drawn by the GPUs themselves instead of the CPU sampler threads
- * (solver.h:1012-1055) — gvk_sample_pairs over per-block edge alias tables for augmentation_step 1, gvk_sample_walks_blocks
+ * (solver.h:1012-1055) — gvk_sample_edges over per-block edge alias tables for augmentation_step 1, gvk_sample_walks_blocks
  * for the random-walk modes: every worker walks the whole graph, keeps a 1/#worker slice of every block pool and copies
  * each slice to the worker that trains the block, GPU to GPU.  Resident (not streamed) mode only; graphs with fewer
  * than 2^32 directed edges. */

@@ -5,6 +5,7 @@ schedule, sampling, pool handling, batch-id / lr accounting, the all-gather exch
 without a GPU.  It is injected explicitly (`GraphSolver(..., kernels=OracleKernels())`); the product never
 imports it and has no CPU fallback of its own."""
 import numpy as np
+import torch
 
 from oracle_lib import Oracle
 
@@ -64,6 +65,15 @@ class OracleKernels(object):
         out = self.oracle.sample_pairs(np.ascontiguousarray(packed["prob"]), np.ascontiguousarray(packed["alias"]),
                                        block_pairs.numpy().view(np.uint32), seed, first_index, n)
         pool.numpy().view(np.uint32)[:2 * n] = out.reshape(-1)
+
+    @staticmethod
+    def pack_edge_table(table, block_pairs):
+        return torch.cat([table.view(torch.int32).view(-1, 2), block_pairs.view(-1, 2)], 1).contiguous().view(torch.int64)
+
+    def sample_edges(self, edge_table, seed, first_index, pool, n):
+        words = edge_table.view(torch.int32).view(-1, 4)
+        self.sample_pairs(words[:, :2].contiguous().view(torch.int64).view(-1), words[:, 2:].contiguous().view(-1), seed,
+                          first_index, pool, n)
 
     def sample_walks(self, walk_graph, seed, first_walk, pool, pool_pairs, walk_length, augmentation_step,
                      shuffle_base):

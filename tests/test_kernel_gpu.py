@@ -384,6 +384,11 @@ def test_sample_pairs_bit_exact(hip, oracle):
     hip.sample_pairs(K.packed_to_device(packed, DEV), dev(block_pairs.view(np.int32).reshape(-1)), seed, first, pool, n)
     got = pool.cpu().numpy().view(np.uint32).reshape(n, 2)
     assert (got == oracle.sample_pairs(prob, alias, block_pairs, seed, first, n)).all()
+    # the packed form (gvk_sample_edges) draws the same pool
+    packed_pool = torch.zeros(2 * n, dtype=torch.int32, device=DEV)
+    edge_table = hip.pack_edge_table(K.packed_to_device(packed, DEV), dev(block_pairs.view(np.int32).reshape(-1)))
+    hip.sample_edges(edge_table, seed, first, packed_pool, n)
+    assert (packed_pool.cpu().numpy().view(np.uint32).reshape(-1, 2) == got).all()
 
 
 @pytest.mark.parametrize("biased", [False, True])

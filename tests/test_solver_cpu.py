@@ -142,10 +142,10 @@ def test_device_sampling_mode_host_logic(oracle):
     s._configure_training("LINE", 1, False, 1, 40, 100, 0, 1, 1, 1, 0.75, 5.0, 1000)
     state = s._upload_state()
     s._upload_block_tables(state)
-    table, pairs = state["block_tables"][(0, 0)]
-    assert table.numel() == g.num_directed_edge
+    table = state["block_tables"][(0, 0)]  # gvk_edge_entry per directed edge
+    assert table.shape == (g.num_directed_edge, 2)
     pool = torch.zeros(2 * 5000, dtype=torch.int32)
-    k.sample_pairs(table, pairs, 123, 0, pool, 5000)
+    k.sample_edges(table, 123, 0, pool, 5000)
     inv = np.argsort(s._local)  # local id -> global id (one partition)
     rec = pool.numpy().view(np.uint32).reshape(-1, 2)
     real = set(map(tuple, g.edges.tolist()))
