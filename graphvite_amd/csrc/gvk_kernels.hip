@@ -135,7 +135,11 @@ __device__ __forceinline__ void load_row(const float *table, uint32_t id, int la
     for (int c = 0; c < L::NC; c++) {
         const float *p = row + c * G * L::CW;
         if (L::CW == 4) {
+#if defined(GVK_EXPERIMENT_NT_ROWS)  // A/B build only (scripts/experiments/gpu_r2_nt.sh): rows marked streaming in the caches
+            f32x4 x = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+#else
             f32x4 x = *reinterpret_cast<const f32x4 *>(p);
+#endif
             r[c * 4 + 0] = x.x; r[c * 4 + 1] = x.y; r[c * 4 + 2] = x.z; r[c * 4 + 3] = x.w;
         } else if (L::CW == 2) {
             f32x2 x = *reinterpret_cast<const f32x2 *>(p);
@@ -155,7 +159,11 @@ __device__ __forceinline__ void store_row(float *table, uint32_t id, int lane, c
         float *p = row + c * G * L::CW;
         if (L::CW == 4) {
             f32x4 x = {r[c * 4 + 0], r[c * 4 + 1], r[c * 4 + 2], r[c * 4 + 3]};
+#if defined(GVK_EXPERIMENT_NT_ROWS) && GVK_EXPERIMENT_NT_ROWS >= 2
+            __builtin_nontemporal_store(x, reinterpret_cast<f32x4 *>(p));
+#else
             *reinterpret_cast<f32x4 *>(p) = x;
+#endif
         } else if (L::CW == 2) {
             f32x2 x = {r[c * 2 + 0], r[c * 2 + 1]};
             *reinterpret_cast<f32x2 *>(p) = x;
