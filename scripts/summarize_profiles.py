@@ -29,7 +29,9 @@ stats, trace = find("prof_kernel", "kernel_stats.csv"), find("prof_kernel", "ker
 if stats:
     shutil.copy(stats, os.path.join(DST, "kernel_stats_bench_n1.csv"))
 if trace:
-    rows = [r for r in csv.DictReader(open(trace)) if "train_" in r["Kernel_Name"]]
+    every = list(csv.DictReader(open(trace)))
+    rows = [r for r in every if "train_" in r["Kernel_Name"]]
+    probe = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in every if "probe_rows_kernel" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
     gap = sorted(int(rows[i + 1]["Start_Timestamp"]) - int(rows[i]["End_Timestamp"]) for i in range(len(rows) - 1))
@@ -39,6 +41,10 @@ if trace:
                "min_ns": min(dur), "max_ns": max(dur), "median_gap_ns": gap[len(gap) // 2], "grid": rows[0]["Grid_Size_X"],
                "workgroup": rows[0]["Workgroup_Size_X"], "achieved_GBps": 308800000 / (sum(dur) / len(dur)),
                "fraction_of_hbm_peak": 308800000 / (sum(dur) / len(dur)) / 8000.0}
+    if probe:  # roofline.access_pattern: the rows of a batch read and written back, nothing else
+        summary["access_pattern_probe"] = {"kernel": "probe_rows_kernel", "launches": len(probe),
+                                           "mean_ns": sum(probe) / len(probe),
+                                           "fraction_of_hbm_peak": 308800000 / (sum(probe) / len(probe)) / 8000.0}
     json.dump(summary, open(os.path.join(DST, "kernel_trace_summary_bench_n1.json"), "w"), indent=1)
     print(json.dumps(summary, indent=1))
 
