@@ -74,8 +74,10 @@ def parse(argv=None):
     p.add_argument("--end-to-end", action="store_true",
                    help="run `end_to_end` with several GPUs too (default: one GPU only — an error on one rank inside a "
                         "training run would leave the others waiting in a collective, and the headline line with them)")
-    p.add_argument("--end-to-end-batches", type=int, default=12000,
-                   help="batches per GPU of each end-to-end run (several episodes: the auto episode size is 1750 batches here)")
+    p.add_argument("--end-to-end-batches", type=int, default=36000,
+                   help="batches per GPU of each end-to-end run: about twenty episodes (the auto episode size is 1750 batches "
+                        "here), so that the first pool fill — the one nothing can overlap — is a twentieth of the run, not a "
+                        "seventh; real trainings run hundreds of episodes")
     p.add_argument("--lanes", type=int, default=0, help="A/B knob: lanes per pair (0 = per-dim default)")
     p.add_argument("--variant", type=int, default=0, help="A/B knob: kernel build variant (gvk.h GVK_TUNE_VARIANT)")
     p.add_argument("--run-cap", type=int, default=0, help="A/B knob: longest same-head run per lane group (gvk.h GVK_TUNE_RUN_CAP)")
