@@ -72,9 +72,10 @@ def main():
     run(graph, "configs[3]", "node2vec", e, threads, p=0.25, q=0.25, table_limit=1)         # forced rejection sampling
     run(graph, "configs[3]", "node2vec", e, threads, p=0.25, q=0.25, device_sampling=True)
     run(graph, "configs[3] per-GPU shape of the 4-GPU run", "node2vec", e, threads, p=0.25, q=0.25, num_partition=4)
-    run(graph, "configs[3] per-GPU shape of the 4-GPU run", "node2vec", e, threads, p=0.25, q=0.25, num_partition=4,
+    # (an episode is 16 blocks x 500 batches here: 5 x the epochs = 7 episodes instead of 2, whose first pool nothing overlaps)
+    run(graph, "configs[3] per-GPU shape of the 4-GPU run", "node2vec", 5 * e, threads, p=0.25, q=0.25, num_partition=4,
         device_sampling=True)
-    run(graph, "configs[2] over 4 partitions on the one GPU", "DeepWalk", e, threads, num_partition=4, device_sampling=True)
+    run(graph, "configs[2] over 4 partitions on the one GPU", "DeepWalk", 5 * e, threads, num_partition=4, device_sampling=True)
     del graph
     if not args.skip_friendster:
         for order in ("sampled", "grouped"):
