@@ -30,7 +30,7 @@ if [[ $WHAT == *measure* ]]; then
 fi
 if [[ $WHAT == *profile* ]]; then
   cd /tmp && export TMPDIR=/tmp
-  rm -rf $REPO/gpurun_out/prof_kernel $REPO/gpurun_out/pmc_* $REPO/gpurun_out/prof_marker
+  rm -rf $REPO/gpurun_out/prof_kernel $REPO/gpurun_out/pmc_* $REPO/gpurun_out/prof_marker $REPO/gpurun_out/prof_marker_engine
   Q="--no-cpu-baseline --no-end-to-end"
   rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_kernel -o trace -- python $REPO/bench.py --steps 200 --warmup 20 $Q > $REPO/gpurun_out/prof_kernel.log 2>&1
   for d in 32 64 96 128 256 512; do
@@ -41,6 +41,8 @@ if [[ $WHAT == *profile* ]]; then
   rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $REPO/gpurun_out/pmc_L2_128 -o pmc -- python $REPO/bench.py --steps 20 --warmup 5 $Q > $REPO/gpurun_out/pmc_L2_128.log 2>&1
   # roctx ranges ("Sample threads", "Upload", "Regroup", "Train Batch", "Exchange") next to the kernels of an end-to-end run
   rocprofv3 --marker-trace --kernel-trace --output-format csv -d $REPO/gpurun_out/prof_marker -o e2e -- python $REPO/scripts/quick_start.py > $REPO/gpurun_out/prof_marker.log 2>&1
+  # the same ranges from the native engine (C++ host loop) through the module, CPU samplers then device sampling
+  rocprofv3 --marker-trace --kernel-trace --output-format csv -d $REPO/gpurun_out/prof_marker_engine -o engine -- python $REPO/scripts/measure_engine.py --quick --epochs 300 > $REPO/gpurun_out/prof_marker_engine.log 2>&1
   cd $REPO
 fi
 tail -4 gpurun_out/pytest_gpu_full.log 2>/dev/null; tail -1 gpurun_out/smoke.log 2>/dev/null; tail -c 1200 gpurun_out/bench_n1.json 2>/dev/null

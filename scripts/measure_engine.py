@@ -38,6 +38,7 @@ def run(graph, name, model, epochs, threads, device_sampling, num_partition=lib.
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--epochs", type=int, default=100)
+    p.add_argument("--quick", action="store_true", help="LINE on one partition only (profiling runs)")
     args = p.parse_args()
     lib.init_logging(lib.ERROR)
     threads = max(cpu_budget() - 1, 1)
@@ -51,6 +52,8 @@ def main():
     walk = dict(augmentation_step=5, random_walk_length=40, random_walk_batch_size=100)
     for sampling in (False, True):
         run(graph, "configs[1]", "LINE", e, threads, sampling, augmentation_step=1)
+        if args.quick:
+            continue
         run(graph, "configs[2]", "DeepWalk", e, threads, sampling, **walk)
         run(graph, "configs[3]", "node2vec", e, threads, sampling, p=0.25, q=0.25, **walk)
         run(graph, "configs[1] over 4 partitions", "LINE", e, threads, sampling, num_partition=4, augmentation_step=1)

@@ -89,9 +89,11 @@ for dim in (32, 64, 96, 128, 256, 512):
 if len(by_dim) > 2:
     json.dump(by_dim, open(os.path.join(DST, "pmc_summary_by_dim.json"), "w"), indent=1)
 
-# ---- marker trace of an end-to-end run: roctx ranges next to the kernels ------------------------------------------------
-marker, kernels = find("prof_marker", "marker_api_trace.csv"), find("prof_marker", "kernel_trace.csv")
-if marker and kernels:
+# ---- marker traces of end-to-end runs: roctx ranges next to the kernels ---------------------------------------------------
+def marker_summary(directory, command, target):
+    marker, kernels = find(directory, "marker_api_trace.csv"), find(directory, "kernel_trace.csv")
+    if not (marker and kernels):
+        return
     ranges = [r for r in csv.DictReader(open(marker))]
     kernel_rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(kernels)))
     t0 = min([int(r["Start_Timestamp"]) for r in ranges] + [k[0] for k in kernel_rows])
@@ -107,9 +109,15 @@ if marker and kernels:
     busy = collections.Counter()
     for a, b, name in kernel_rows:
         busy[name.split("(")[0][:60]] += (b - a) / 1e6
-    out = {"command": "rocprofv3 --marker-trace --kernel-trace -- python scripts/quick_start.py (configs[0] end to end)",
-           "ranges": per_name, "kernel_busy_ms": dict(busy.most_common(8)),
+    out = {"command": command, "ranges": per_name, "kernel_busy_ms": dict(busy.most_common(8)),
            "first_kernel_ms": (kernel_rows[0][0] - t0) / 1e6, "last_kernel_ms": (kernel_rows[-1][1] - t0) / 1e6,
            "timeline_first_80_ranges": timeline}
-    json.dump(out, open(os.path.join(DST, "marker_trace_summary_e2e.json"), "w"), indent=1)
-    print("marker ranges:", {k: v["count"] for k, v in per_name.items()})
+    json.dump(out, open(os.path.join(DST, target), "w"), indent=1)
+    print(target, "marker ranges:", {k: v["count"] for k, v in per_name.items()})
+
+
+marker_summary("prof_marker", "rocprofv3 --marker-trace --kernel-trace -- python scripts/quick_start.py (configs[0] end to end)",
+               "marker_trace_summary_e2e.json")
+marker_summary("prof_marker_engine", "rocprofv3 --marker-trace --kernel-trace -- python scripts/measure_engine.py --quick "
+               "(the native engine through the libgraphvite module: LINE on a Youtube-sized graph, CPU samplers then device "
+               "sampling)", "marker_trace_summary_engine.json")
