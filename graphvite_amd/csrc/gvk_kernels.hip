@@ -1255,6 +1255,7 @@ int gvk_probe_row_traffic(void *stream, int dim, float *vertex, float *context, 
     if (!default_lanes(dim)) return fail(GVK_EDIM, "gvk_probe_row_traffic: dim must be one of 32, 64, 96, 128, 256, 512");
     if (batch_size <= 0) return GVK_OK;
     if (!vertex || !context || !pairs || !negatives) return fail(GVK_EINVAL, "gvk_probe_row_traffic: null pointer");
+    if ((int64_t)batch_size * 64 > INT32_MAX) return fail(GVK_EINVAL, "gvk_probe_row_traffic: batch_size too large");
     hipStream_t st = (hipStream_t)stream;
 #define GVK_PROBE(D, GG)                                                                                       \
     case D:                                                                                                    \
