@@ -169,6 +169,7 @@ struct gvx_solver {
     // memory between blocks, the reference's load_partition / write_back scheme (solver.h:1435-1504)
     bool streamed = false;
     bool device_sampling = false;  // gvx_solver_set(GVX_DEVICE_SAMPLING)
+    std::vector<uint64_t> sample_positions;  // per worker: draws (edge mode) / walks consumed since build()
     std::vector<int32_t> part;
     std::vector<uint32_t> local, part_sizes;
     uint32_t part_rows = 0;  // S
@@ -192,6 +193,10 @@ struct gvx_solver {
     ~gvx_solver() { release(); }
 
     void release_device() {
+        if (device_sampling && !workers.empty()) {  // the device samplers go on where they stopped at the next train()
+            sample_positions.assign(workers.size(), 0);
+            for (size_t r = 0; r < workers.size(); r++) sample_positions[r] = workers[r].sample_index;
+        }
         for (Worker &w : workers) {
             hipSetDevice(w.device);
             hipDeviceSynchronize();
@@ -382,6 +387,7 @@ extern "C" int gvx_solver_build(gvx_solver *s, const gvs_graph *graph, const gvx
     if (batch_size < kMinBatchSize)
         log_message(1, "It is recommended to a minimum batch size of %d, but %d is specified", kMinBatchSize, batch_size);
     s->batch_id = 0;
+    s->sample_positions.clear();
     const int W = s->num_worker;
     size_t limit = s->memory_request;
     if (limit == GVX_AUTO) {
@@ -672,6 +678,7 @@ int gvx_solver::prepare_device_sampling() {
         for (hipEvent_t &e : w.filled) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&w.episode_end, hipEventDisableTiming));
         w.sample_seed = 0x9E3779B97F4A7C15ull * (uint64_t)(r + 1) + 0x706f73;
+        w.sample_index = (size_t)r < sample_positions.size() ? sample_positions[r] : 0;
         const size_t blocks = w.tails.size() * P;
         for (uint32_t *&pools : w.block_pools) HIP_TRY(hipMalloc(&pools, blocks * n * 8));
         if (mode == GVS_MODE_EDGE) {

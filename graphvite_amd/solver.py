@@ -311,6 +311,7 @@ class GraphSolver(object):
         self.context_embeddings = np.zeros((self.num_vertex, self.dim), np.float32)
         self._moments_host = None
         self._sampler = None  # the CPU sampler (edge alias table over all edges) is built at the first train()
+        self._positive_index = 0  # ... and the device sampler's stream starts over
         self._sampler_mode = None
 
     @staticmethod
@@ -858,7 +859,7 @@ class GraphSolver(object):
             _, _, packed = alias_build(weights[ids])
             state["block_tables"][(hp, tp)] = self.kernels.pack_edge_table(
                 packed_to_device(packed, self.device), self._to_device(pairs.view(np.int32).reshape(-1)))
-        state["positive_index"] = 0
+        state["positive_index"] = getattr(self, "_positive_index", 0)
 
     def _upload_walk_graph(self, state):
         """CSR, per-vertex alias tables and the global edge table in HBM — what gvk_sample_walks walks on."""
@@ -885,7 +886,7 @@ class GraphSolver(object):
             keys = (uv[:, 0] << 32) | uv[:, 1]
             walk["sorted_neighbors"] = (torch.sort(keys).values & 0xFFFFFFFF).to(torch.int32).contiguous()
         state["walk_graph"] = walk
-        state["positive_index"] = 0
+        state["positive_index"] = getattr(self, "_positive_index", 0)
 
     def _train_episode_device_sampling(self, state):
         """One episode with the positive samples drawn on the device.  Same pipeline as `_train_episode`, with a
@@ -1124,6 +1125,8 @@ class GraphSolver(object):
         written back and nothing is exchanged."""
         if state is None:
             return
+        if "positive_index" in state:  # the device sampler's stream goes on where it stopped in the next train()
+            self._positive_index = state["positive_index"]
         import torch.distributed as dist
         W, P, S = self.num_worker, self.num_partition, self._part_size
         if collective:

@@ -132,6 +132,10 @@ def test_device_sampling_mode_host_logic(oracle):
     s.build(g, batch_size=400, episode_size=3)
     s.train("LINE", num_epoch=3, augmentation_step=1)
     assert s.batch_id == 15 and np.abs(s.context_embeddings).max() > 0
+    drawn = s._positive_index
+    assert drawn >= 15 * 400
+    s.train("LINE", num_epoch=3, augmentation_step=1, resume=True)  # the positive stream goes on, it does not start over
+    assert s.batch_id == 30 and s._positive_index >= drawn + 15 * 400
     # random-walk models sample on the device too when there is a single partition
     for model, aug in (("DeepWalk", 3), ("node2vec", 2), ("LINE", 2)):
         s.build(g, batch_size=300, episode_size=4)
