@@ -448,6 +448,11 @@ def main(argv=None, stand_in_kernels=None):
     for _ in blocks:
         run(min(2, args.block_batches), False, leave_block=True)
     session.wait_exchange()
+    # The ceiling of the access pattern is measured here, ahead of the warm-up: 400 launches that read and write back the
+    # rows of the pools' batches, tables unchanged (A/B'd against running it after the timed region: no difference).
+    probe = None
+    if cuda and k == 1 and optimizer.num_moment == 0 and not args.no_access_pattern:
+        probe = access_pattern(solver, session, landed, blocks, B, dim)
     # the warm-up ends on a block boundary: the timed region then consists of whole block visits; as in the steady
     # state of the episode loop every visit stages (regroups) the pool of the NEXT visit while it trains, so the
     # region holds exactly one staging pass and one exchange per visit
@@ -516,9 +521,8 @@ def main(argv=None, stand_in_kernels=None):
                     "note": "CPU edge sampler filling this GPU's block pools before the timed region"},
         "final_batch_mean_loss": final_loss,
     }
-    if cuda and k == 1 and moments == 0 and not args.no_access_pattern:
-        # how close the training kernel is to what the memory system sustains for ITS access pattern
-        result["roofline"]["access_pattern"] = probe = access_pattern(solver, session, landed, blocks, B, dim)
+    if probe is not None:  # how close the training kernel is to what the memory system sustains for ITS access pattern
+        result["roofline"]["access_pattern"] = probe
         probe["train_kernel_vs_probe"] = probe["kernel_ms"] / kernel_ms
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         tp = blocks[0][1]
