@@ -103,6 +103,9 @@ def parse(argv=None):
     p.add_argument("--graph", choices=["power-law", "community"], default="power-law",
                    help="experiment: 'community' swaps in a hub-free planted-partition graph of the same size")
     p.add_argument("--sampler-threads", type=int, default=0, help="0 = host cores / GPUs")
+    p.add_argument("--negative-table", choices=["auto", "rows", "classes"], default="auto",
+                   help="the negative sampler's table: one alias slot per row (the reference's), or an alias table over the "
+                        "classes of equal-degree rows (same distribution, cache-resident); auto = classes when 8x fewer")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-access-pattern", action="store_true", help="skip the row-traffic probe (`roofline.access_pattern`)")
     p.add_argument("--cpu-seconds", type=float, default=3.0, help="wall seconds given to the CPU baseline")
@@ -299,6 +302,7 @@ def main(argv=None, stand_in_kernels=None):
     if args.xcd_bucket or args.xcd_sorted or args.host_order:
         args.pair_order = "sampled"  # the placement experiments lay the batches out themselves
     solver = gv.solver.GraphSolver(dim, num_sampler_per_worker=threads, seed=args.seed, kernels=stand_in_kernels, pair_order=gv.auto if args.pair_order == "auto" else args.pair_order)
+    solver.negative_table = args.negative_table
     if args.lanes:
         solver.kernels.set_lanes_per_pair(args.lanes)
     if args.variant:
@@ -398,6 +402,9 @@ def main(argv=None, stand_in_kernels=None):
             ready[b].record()
         return work[b]
 
+    first_table = session.negative_table(blocks[0][1])
+    negative_table = ("%d weight classes (alias table over the classes of equal-degree rows, then a uniform row of the class)"
+                      % first_table.shape[0]) if first_table.dim() == 2 else "%d row slots" % first_table.numel()
     kernel_events = []
     # The walk over the schedule continues across the residency pass, the warm-up and the timed steps, block by block
     # as the episode loop walks it: block_batches batches of a block, the exchange, the next block — whose pool was
@@ -503,6 +510,7 @@ def main(argv=None, stand_in_kernels=None):
                    "parallelism": "%d GPU(s), %d vertex partition(s), context shards pinned per GPU, asynchronous "
                                   "all-gather of head shards every %d batches" % (world, partitions, args.block_batches),
                    "block_batches": args.block_batches, "block_visits_timed": visits,
+                   "negative_table": negative_table,
                    "pair_order": solver.pair_order + (" (gvk_group_pairs once per block visit on the copy stream)"
                                                       if grouped else "")},
         "regroup": {"passes_in_timed_region": len(regroup_events), "ms_per_pass": regroup_ms / max(len(regroup_events), 1),
@@ -526,7 +534,10 @@ def main(argv=None, stand_in_kernels=None):
         probe["train_kernel_vs_probe"] = probe["kernel_ms"] / kernel_ms
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         tp = blocks[0][1]
-        packed = session.negative_table(tp).cpu().numpy().view(np.dtype([("prob", np.float32), ("alias", np.uint32)]))
+        # the reference's own sampler: one alias slot per row of the tail partition (solver.h:1264-1278)
+        from graphvite_amd import hostlib
+        from graphvite_amd.kernels import alias_build
+        _, _, packed = alias_build(hostlib.negative_weights(graph.vertex_weights, solver._part_ids[tp], 0.75))
         pool0 = pools[blocks[0]].numpy().view(np.uint32).reshape(-1, 2)
         result["cpu_baseline"] = cpu_baseline(args, solver, pool0, packed)
     if cuda and not args.no_end_to_end and args.optimizer == "SGD" and (world == 1 or args.end_to_end):

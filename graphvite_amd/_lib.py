@@ -34,7 +34,8 @@ class Tables(C.Structure):
 
 
 class NegativeSource(C.Structure):
-    _fields_ = [("negatives", C.c_void_p), ("table", C.c_void_p), ("count", C.c_uint32), ("seed", C.c_uint64)]
+    _fields_ = [("negatives", C.c_void_p), ("table", C.c_void_p), ("count", C.c_uint32), ("seed", C.c_uint64),
+                ("classes", C.c_void_p), ("class_count", C.c_uint32)]
 
 
 class FillConfig(C.Structure):
@@ -90,6 +91,10 @@ def lib():
     l.gvk_alias_sample.argtypes = [vp, vp, u32, vp, vp, i32]
     l.gvk_negative_draw.restype = i32
     l.gvk_negative_draw.argtypes = [vp, vp, u32, u64, u32, vp, i32, i32]
+    l.gvk_class_table_build.restype = i32
+    l.gvk_class_table_build.argtypes = [vp, C.c_size_t, vp, vp]
+    l.gvk_negative_draw_classes.restype = i32
+    l.gvk_negative_draw_classes.argtypes = [vp, vp, u32, u64, u32, vp, i32, i32]
     l.gvk_sample_pairs.restype = i32
     l.gvk_sample_pairs.argtypes = [vp, vp, vp, u32, u64, u64, vp, C.c_size_t]
     l.gvk_sample_edges.restype = i32

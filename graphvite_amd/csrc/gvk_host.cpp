@@ -103,6 +103,32 @@ int gvk_alias_build(const float *weights, size_t n, float *prob, void *alias, in
     return GVK_OK;
 }
 
+int gvk_class_table_build(const float *weights, size_t n, gvk_class_entry *out, uint32_t *num_class) {
+    if (!weights || !out || !num_class) return gvk_fail(GVK_EINVAL, "gvk_class_table_build: null pointer");
+    if (n == 0 || n > 0xffffffffu) return gvk_fail(GVK_EINVAL, "gvk_class_table_build: 1 .. 2^32 - 1 rows");
+    try {
+        // classes: maximal runs of consecutive rows of equal weight (rows sorted by degree: one run per distinct weight)
+        std::vector<float> mass;
+        size_t classes = 0;
+        for (size_t i = 0; i < n;) {
+            size_t j = i + 1;
+            while (j < n && weights[j] == weights[i]) j++;
+            out[classes].first = (uint32_t)i, out[classes].count = (uint32_t)(j - i);
+            mass.push_back((float)((double)(j - i) * (double)weights[i]));
+            classes++;
+            i = j;
+        }
+        std::vector<float> prob(classes);
+        std::vector<uint32_t> alias(classes);
+        alias_build(mass.data(), classes, prob.data(), alias.data());
+        for (size_t c = 0; c < classes; c++) out[c].prob = prob[c], out[c].alias = alias[c];
+        *num_class = (uint32_t)classes;
+    } catch (const std::bad_alloc &) {
+        return gvk_fail(GVK_ENOMEM, "gvk_class_table_build: out of host memory");
+    }
+    return GVK_OK;
+}
+
 const char *gvk_last_error(void) { return g_error; }
 
 const char *gvk_version(void) { return "gvk 0.1 (gfx950)"; }

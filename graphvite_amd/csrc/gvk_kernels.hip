@@ -50,6 +50,7 @@ struct TrainArgs {
     const uint32_t *pairs;
     const uint32_t *negatives;
     const gvk_alias_entry *table;
+    const gvk_class_entry *classes;  // non-null: negatives are drawn by weight class (count = number of classes)
     float *loss;
     uint64_t seed;
     uint32_t count, batch_id;
@@ -97,9 +98,12 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 constexpr uint32_t kTagNegative = 0x6e656721u;
 
+constexpr uint32_t kTagNegativeClass = 0x6e656743u;
+
 struct Draw {
     uint32_t index;
     float u;
+    uint32_t v;  // class draws: the word that picks the row inside the class
 };
 
 __device__ __forceinline__ Draw negative_slot(uint64_t seed, uint32_t batch_id, uint32_t sample, uint32_t j,
@@ -115,6 +119,48 @@ __device__ __forceinline__ Draw negative_slot(uint64_t seed, uint32_t batch_id, 
 
 __device__ __forceinline__ uint32_t resolve(const Draw &d, const gvk_alias_entry &e) {
     return d.u < e.prob ? d.index : e.alias;
+}
+
+// The negative of (sample, j) inside the training kernels, from whichever structure the caller gave (the branch is
+// uniform over the launch).  Row table: one random 8-byte slot of a table as long as the partition (8 MB at 1M rows: a
+// memory request per draw).  Class table: rows of equal weight form a class — a few thousand classes, 16 bytes each,
+// resident in the caches — and the draw is class (alias method over the classes) then a uniform row of the class.
+struct NegEntry {
+    uint32_t prob_bits, alias, first, count;
+};
+
+__device__ __forceinline__ Draw negative_slot(const TrainArgs &a, uint32_t sample, uint32_t j) {
+    if (!a.classes) return negative_slot(a.seed, a.batch_id, sample, j, a.count);
+    uint32_t w[4];
+    philox4x32_10(sample, a.batch_id, j, kTagNegativeClass, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), w);
+    Draw d;
+    d.index = __umulhi(w[0], a.count);
+    d.u = (float)(w[1] >> 8) * (1.0f / 16777216.0f);
+    d.v = w[2];
+    return d;
+}
+
+__device__ __forceinline__ NegEntry load_entry(const TrainArgs &a, const Draw &d) {
+    NegEntry e = {0, 0, 0, 0};
+    if (a.classes) {
+        const u32x4 x = *reinterpret_cast<const u32x4 *>(a.classes + d.index);
+        e.prob_bits = x.x, e.alias = x.y, e.first = x.z, e.count = x.w;
+    } else {
+        const gvk_alias_entry t = a.table[d.index];
+        e.prob_bits = __float_as_uint(t.prob), e.alias = t.alias;
+    }
+    return e;
+}
+
+__device__ __forceinline__ uint32_t resolve(const TrainArgs &a, const Draw &d, const NegEntry &e) {
+    const bool self = d.u < __uint_as_float(e.prob_bits);
+    if (!a.classes) return self ? d.index : e.alias;
+    uint32_t first = e.first, count = e.count;
+    if (!self) {
+        const u32x2 other = *reinterpret_cast<const u32x2 *>(&a.classes[e.alias].first);
+        first = other.x, count = other.y;
+    }
+    return first + __umulhi(d.v, count);
 }
 
 // ---- rows in registers ---------------------------------------------------------------------------
@@ -226,13 +272,13 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_kernel(const TrainArgs a)
     const bool draw = DRAW < 0 ? a.negatives == nullptr : DRAW != 0;
 
     // round trip 1: the pair and the first negative's alias slot (independent of each other)
-    Draw d0 = {0, 0};
-    gvk_alias_entry e0 = {0, 0};
+    Draw d0 = {0, 0, 0};
+    NegEntry e0 = {0, 0, 0, 0};
     uint32_t neg0 = 0;
     if (k > 0) {
         if (draw) {
-            d0 = negative_slot(a.seed, a.batch_id, (uint32_t)s, 0, a.count);
-            e0 = a.table[d0.index];
+            d0 = negative_slot(a, (uint32_t)s, 0);
+            e0 = load_entry(a, d0);
         } else {
             neg0 = __builtin_nontemporal_load(a.negatives + (size_t)s * k);
         }
@@ -246,7 +292,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_kernel(const TrainArgs a)
     if constexpr (NM >= 1) load_row<DIM, G>(a.vm1, head, lane, reinterpret_cast<float(&)[V]>(vm1));
     if constexpr (NM >= 2) load_row<DIM, G>(a.vm2, head, lane, reinterpret_cast<float(&)[V]>(vm2));
 
-    uint32_t id_cur = k > 0 ? (draw ? resolve(d0, e0) : neg0) : tail;
+    uint32_t id_cur = k > 0 ? (draw ? resolve(a, d0, e0) : neg0) : tail;
     float cur[V], cur1[M1], cur2[M2];
     load_row<DIM, G>(a.context, id_cur, lane, cur);
     if constexpr (NM >= 1) load_row<DIM, G>(a.cm1, id_cur, lane, reinterpret_cast<float(&)[V]>(cur1));
@@ -260,8 +306,8 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_kernel(const TrainArgs a)
         if (j < k) {
             if (j + 1 < k) {
                 if (draw) {
-                    Draw d = negative_slot(a.seed, a.batch_id, (uint32_t)s, (uint32_t)(j + 1), a.count);
-                    id_nxt = resolve(d, a.table[d.index]);
+                    Draw d = negative_slot(a, (uint32_t)s, (uint32_t)(j + 1));
+                    id_nxt = resolve(a, d, load_entry(a, d));
                 } else {
                     id_nxt = __builtin_nontemporal_load(a.negatives + (size_t)s * k + j + 1);
                 }
@@ -370,13 +416,13 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_runs_kernel(const TrainAr
     const u32x2 *records = reinterpret_cast<const u32x2 *>(a.pairs);
 
     // round trip 1: the pair, its neighbours in the segment, and the first negative's alias slot
-    Draw d0 = {0, 0};
-    gvk_alias_entry e0 = {0, 0};
+    Draw d0 = {0, 0, 0};
+    NegEntry e0 = {0, 0, 0, 0};
     uint32_t neg0 = 0;
     if (k > 0) {
         if (draw) {
-            d0 = negative_slot(a.seed, a.batch_id, (uint32_t)s, 0, a.count);
-            e0 = a.table[d0.index];
+            d0 = negative_slot(a, (uint32_t)s, 0);
+            e0 = load_entry(a, d0);
         } else {
             neg0 = __builtin_nontemporal_load(a.negatives + (size_t)s * k);
         }
@@ -396,7 +442,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_runs_kernel(const TrainAr
     if constexpr (NM >= 1) load_row<DIM, G>(a.vm1, head, lane, reinterpret_cast<float(&)[V]>(vm1));
     if constexpr (NM >= 2) load_row<DIM, G>(a.vm2, head, lane, reinterpret_cast<float(&)[V]>(vm2));
 
-    uint32_t id_cur = k > 0 ? (draw ? resolve(d0, e0) : neg0) : tail;
+    uint32_t id_cur = k > 0 ? (draw ? resolve(a, d0, e0) : neg0) : tail;
     float cur[V], cur1[M1], cur2[M2];
     load_row<DIM, G>(a.context, id_cur, lane, cur);
     if constexpr (NM >= 1) load_row<DIM, G>(a.cm1, id_cur, lane, reinterpret_cast<float(&)[V]>(cur1));
@@ -407,15 +453,15 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_runs_kernel(const TrainAr
         // does the run go on with pair j + 1?  If so its first alias slot and the header of pair j + 2 are requested
         // now; both are back long before the positive step below needs them.
         const bool more = j + 1 < limit && next_pr.y == head;
-        Draw dn = {0, 0};
-        gvk_alias_entry en = {0, 0};
+        Draw dn = {0, 0, 0};
+        NegEntry en = {0, 0, 0, 0};
         uint32_t negn = 0;
         u32x2 after_pr = {0, 0};
         if (more) {
             if (k > 0) {
                 if (draw) {
-                    dn = negative_slot(a.seed, a.batch_id, (uint32_t)(j + 1), 0, a.count);
-                    en = a.table[dn.index];
+                    dn = negative_slot(a, (uint32_t)(j + 1), 0);
+                    en = load_entry(a, dn);
                 } else {
                     negn = __builtin_nontemporal_load(a.negatives + (size_t)(j + 1) * k);
                 }
@@ -433,15 +479,15 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_runs_kernel(const TrainAr
             if (has_next) {
                 if (t + 1 < k) {
                     if (draw) {
-                        Draw d = negative_slot(a.seed, a.batch_id, (uint32_t)j, (uint32_t)(t + 1), a.count);
-                        id_nxt = resolve(d, a.table[d.index]);
+                        Draw d = negative_slot(a, (uint32_t)j, (uint32_t)(t + 1));
+                        id_nxt = resolve(a, d, load_entry(a, d));
                     } else {
                         id_nxt = __builtin_nontemporal_load(a.negatives + (size_t)j * k + t + 1);
                     }
                 } else if (t < k) {
                     id_nxt = tail;
                 } else {
-                    id_nxt = k > 0 ? (draw ? resolve(dn, en) : negn) : next_pr.x;
+                    id_nxt = k > 0 ? (draw ? resolve(a, dn, en) : negn) : next_pr.x;
                 }
                 load_row<DIM, G>(a.context, id_nxt, lane, nxt);
                 if constexpr (NM >= 1) load_row<DIM, G>(a.cm1, id_nxt, lane, reinterpret_cast<float(&)[V]>(nxt1));
@@ -552,17 +598,17 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_segment_kernel(const Trai
     // phase 1: headers and alias slots
     uint32_t head[D], tail[D], neg[D];
     Draw dr[D];
-    gvk_alias_entry en[D];
+    NegEntry en[D];
 #pragma unroll
     for (int i = 0; i < D; i++) {
         const int s = base + i * NG + g;
         head[i] = kNone, tail[i] = 0, neg[i] = 0;
-        dr[i] = {0, 0};
-        en[i] = {0, 0};
+        dr[i] = {0, 0, 0};
+        en[i] = {0, 0, 0, 0};
         if (s < a.batch_size) {
             if (draw) {
-                dr[i] = negative_slot(a.seed, a.batch_id, (uint32_t)s, 0, a.count);
-                en[i] = a.table[dr[i].index];
+                dr[i] = negative_slot(a, (uint32_t)s, 0);
+                en[i] = load_entry(a, dr[i]);
             } else {
                 neg[i] = __builtin_nontemporal_load(a.negatives + s);
             }
@@ -589,7 +635,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_segment_kernel(const Trai
 #pragma unroll
     for (int i = 0; i < D; i++) {
         if (head[i] != kNone) {
-            if (draw) neg[i] = resolve(dr[i], en[i]);
+            if (draw) neg[i] = resolve(a, dr[i], en[i]);
             load_row<DIM, G>(a.context, neg[i], lane, cn_[i]);
             load_row<DIM, G>(a.context, tail[i], lane, cp_[i]);
             if (!cont[i]) load_row<DIM, G>(a.vertex, head[i], lane, vl_[i]);
@@ -698,8 +744,8 @@ __global__ void __launch_bounds__(512) train_kernel_reference_shape(const TrainA
                 if (a.negatives) {
                     id = a.negatives[(size_t)s * k + j];
                 } else {
-                    const Draw d = negative_slot(a.seed, a.batch_id, (uint32_t)s, (uint32_t)j, a.count);
-                    id = resolve(d, a.table[d.index]);
+                    const Draw d = negative_slot(a, (uint32_t)s, (uint32_t)j);
+                    id = resolve(a, d, load_entry(a, d));
                 }
             }
             float *context = a.context + (size_t)id * DIM;
@@ -791,6 +837,17 @@ __global__ void __launch_bounds__(kBlock) negative_draw_kernel(const gvk_alias_e
     const uint32_t s = i / k, j = i % k;
     const Draw d = negative_slot(seed, batch_id, s, j, count);
     out[i] = resolve(d, table[d.index]);
+}
+
+__global__ void __launch_bounds__(kBlock) negative_draw_classes_kernel(const gvk_class_entry *classes, uint32_t count,
+                                                                       uint64_t seed, uint32_t batch_id, uint32_t *out,
+                                                                       int batch_size, int k) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= batch_size * k) return;
+    TrainArgs a;  // the draw of the training kernels, verbatim
+    a.classes = classes, a.count = count, a.seed = seed, a.batch_id = batch_id;
+    const Draw d = negative_slot(a, (uint32_t)(i / k), (uint32_t)(i % k));
+    out[i] = resolve(a, d, load_entry(a, d));
 }
 
 constexpr uint32_t kTagPositive = 0x706f7321u;
@@ -1038,7 +1095,7 @@ int validate_train(int dim, const gvk_optimizer *o, const gvk_tables *t, const u
         return fail(GVK_EINVAL, "gvk_train: optimizer needs first-moment tables");
     if (o->type == GVK_ADAM && (!t->vertex_moment2 || !t->context_moment2))
         return fail(GVK_EINVAL, "gvk_train: Adam needs second-moment tables");
-    if (k > 0 && !neg->negatives && (!neg->table || neg->count == 0))
+    if (k > 0 && !neg->negatives && (!neg->table || neg->count == 0) && (!neg->classes || neg->class_count == 0))
         return fail(GVK_EINVAL, "gvk_train: num_negative > 0 but neither negatives nor an alias table given");
     if ((int64_t)batch_size * 64 > INT32_MAX) return fail(GVK_EINVAL, "gvk_train: batch_size too large");
     return 1;
@@ -1161,6 +1218,7 @@ int launch_train(hipStream_t stream, int dim, const gvk_optimizer *o, float lr, 
     a.vm2 = t->vertex_moment2; a.cm2 = t->context_moment2;
     a.pairs = pairs; a.negatives = neg->negatives; a.table = neg->table; a.loss = loss;
     a.seed = neg->seed; a.count = neg->count; a.batch_id = batch_id;
+    if (neg->classes) a.classes = neg->classes, a.count = neg->class_count;  // drawn by weight class
     a.batch_size = batch_size; a.k = k; a.run_cap = c.run_cap;
     a.lr = lr; a.wd = o->weight_decay; a.neg_weight = negative_weight;
     a.hp0 = o->hp0; a.hp1 = o->hp1; a.eps = o->epsilon;
@@ -1289,6 +1347,18 @@ int gvk_negative_draw(void *stream, const gvk_alias_entry *table, uint32_t count
     hipLaunchKernelGGL(negative_draw_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                        (hipStream_t)stream, table, count, seed, batch_id, negatives, batch_size, num_negative);
     return check_launch("gvk_negative_draw");
+}
+
+int gvk_negative_draw_classes(void *stream, const gvk_class_entry *classes, uint32_t class_count, uint64_t seed,
+                              uint32_t batch_id, uint32_t *negatives, int batch_size, int num_negative) {
+    if (batch_size < 0 || num_negative < 0) return fail(GVK_EINVAL, "gvk_negative_draw_classes: negative size");
+    const int64_t n = (int64_t)batch_size * num_negative;
+    if (n == 0) return GVK_OK;
+    if (n > INT32_MAX) return fail(GVK_EINVAL, "gvk_negative_draw_classes: too many draws for one call");
+    if (!classes || !class_count || !negatives) return fail(GVK_EINVAL, "gvk_negative_draw_classes: null pointer / empty table");
+    hipLaunchKernelGGL(negative_draw_classes_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, classes, class_count, seed, batch_id, negatives, batch_size, num_negative);
+    return check_launch("gvk_negative_draw_classes");
 }
 
 int gvk_sample_pairs(void *stream, const gvk_alias_entry *table, const uint32_t *block_pairs, uint32_t count,

@@ -119,7 +119,9 @@ struct Worker {
     float *head = nullptr;     // [P slots][1 + m][S][dim]: every head partition, vertex rows then moment tables
     float *context = nullptr;  // [T][1 + m][S][dim]: the tail partitions this worker owns
     std::vector<int> tails;
-    std::vector<gvk_alias_entry *> negative_tables;  // per owned tail
+    std::vector<gvk_alias_entry *> negative_tables;  // per owned tail: one alias slot per row, or null when ...
+    std::vector<gvk_class_entry *> negative_classes; // ... the sampler draws by weight class (gvk.h): an alias table over
+    std::vector<uint32_t> negative_class_counts;     // the classes of equal-degree rows, a few thousand entries
     float *loss = nullptr;
     uint32_t *pool[2] = {nullptr, nullptr}, *landing = nullptr;
     void *group_workspace = nullptr;
@@ -203,6 +205,7 @@ struct gvx_solver {
             hipFree(w.head), hipFree(w.context), hipFree(w.loss), hipFree(w.pool[0]), hipFree(w.pool[1]);
             hipFree(w.landing), hipFree(w.group_workspace);
             for (auto *t : w.negative_tables) hipFree(t);
+            for (auto *t : w.negative_classes) hipFree(t);
             hipFree(w.block_pools[0]), hipFree(w.block_pools[1]), hipFree(w.slices);
             for (auto &b : w.edge_blocks) hipFree(b.table);
             hipFree((void *)w.walk.flat_offsets), hipFree((void *)w.walk.edges_uv), hipFree((void *)w.walk.edge_table);
@@ -580,11 +583,25 @@ int gvx_solver::prepare_devices() {
             std::vector<gvk_alias_entry> packed(ids.size());
             GVK_TRY(gvs_negative_weights(gvs_graph_vertex_weights(graph), ids.data(), ids.size(),
                                          config.negative_sample_exponent, weights.data()));
-            GVK_TRY(gvk_alias_build(weights.data(), weights.size(), prob.data(), alias.data(), 4, packed.data()));
+            // rows of equal weight (= equal degree: the partition is sorted by it) form a class; when the classes are at
+            // least 8 times fewer than the rows (always, on an unweighted graph) the sampler draws class, then row
+            std::vector<gvk_class_entry> classes(ids.size());
+            uint32_t num_class = 0;
+            GVK_TRY(gvk_class_table_build(weights.data(), weights.size(), classes.data(), &num_class));
             gvk_alias_entry *table = nullptr;
-            HIP_TRY(hipMalloc(&table, packed.size() * sizeof(gvk_alias_entry)));
-            HIP_TRY(hipMemcpy(table, packed.data(), packed.size() * sizeof(gvk_alias_entry), hipMemcpyHostToDevice));
+            gvk_class_entry *class_table = nullptr;
+            if ((size_t)num_class * 8 <= ids.size()) {
+                HIP_TRY(hipMalloc(&class_table, num_class * sizeof(gvk_class_entry)));
+                HIP_TRY(hipMemcpy(class_table, classes.data(), num_class * sizeof(gvk_class_entry), hipMemcpyHostToDevice));
+            } else {
+                num_class = 0;
+                GVK_TRY(gvk_alias_build(weights.data(), weights.size(), prob.data(), alias.data(), 4, packed.data()));
+                HIP_TRY(hipMalloc(&table, packed.size() * sizeof(gvk_alias_entry)));
+                HIP_TRY(hipMemcpy(table, packed.data(), packed.size() * sizeof(gvk_alias_entry), hipMemcpyHostToDevice));
+            }
             w.negative_tables.push_back(table);
+            w.negative_classes.push_back(class_table);
+            w.negative_class_counts.push_back(num_class);
         }
         (void)nm;
     }
@@ -974,6 +991,7 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, uint32_t *pool) {
     t.n_vertex = t.n_context = part_rows;
     gvk_negative_source neg{};
     neg.table = w.negative_tables[ti], neg.count = (uint32_t)part_ids[tp].size();
+    neg.classes = w.negative_classes[ti], neg.class_count = w.negative_class_counts[ti];
     neg.seed = 0x100000001B3ull * 1 + (uint64_t)r;
     gvk_optimizer o{};
     o.type = optimizer.type, o.lr = optimizer.lr, o.weight_decay = optimizer.weight_decay;

@@ -44,6 +44,27 @@ def alias_build(weights, index_bytes=4):
     return prob, alias, packed
 
 
+CLASS_ENTRY = np.dtype([("prob", np.float32), ("alias", np.uint32), ("first", np.uint32), ("count", np.uint32)])
+
+
+def class_table_build(weights):
+    """gvk_class_entry[num_class] over maximal runs of consecutive equal weights (gvk_class_table_build): the negative
+    sampler's distribution in a table of a few thousand entries when the rows are sorted by degree."""
+    w = np.ascontiguousarray(weights, dtype=np.float32)
+    if w.ndim != 1 or w.size == 0:
+        raise ValueError("weights must be a non-empty one-dimensional array")
+    out = np.empty(w.size, CLASS_ENTRY)
+    num = C.c_uint32(0)
+    _lib.check(_lib.lib().gvk_class_table_build(w.ctypes.data, w.size, out.ctypes.data, C.byref(num)),
+               "gvk_class_table_build")
+    return out[:num.value].copy()
+
+
+def classes_to_device(classes, device):
+    """gvk_class_entry[n] -> int64 tensor [n, 2] on `device` (16-byte entries; the 2-D shape marks a class table)."""
+    return torch.from_numpy(classes.view(np.int64).reshape(-1, 2).copy()).to(device)
+
+
 def packed_to_device(packed, device):
     """gvk_alias_entry[n] -> int64 tensor [n] on `device` (8-byte entries, bit pattern preserved)."""
     return torch.from_numpy(packed.view(np.int64).copy()).to(device)
@@ -97,11 +118,14 @@ class HipKernels(object):
 
     @staticmethod
     def _negative(negatives, table, seed, dev):
+        """`table`: int64 [rows] = gvk_alias_entry per row, or int64 [classes, 2] = gvk_class_entry per weight class."""
         if negatives is not None:
             _need(negatives, torch.int32, "negatives", dev)
         if table is not None:
             _need(table, torch.int64, "alias table", dev)
-        return _lib.NegativeSource(_ptr(negatives), _ptr(table), 0 if table is None else table.numel(), seed)
+            if table.dim() == 2:
+                return _lib.NegativeSource(_ptr(negatives), None, 0, seed, _ptr(table), table.shape[0])
+        return _lib.NegativeSource(_ptr(negatives), _ptr(table), 0 if table is None else table.numel(), seed, None, 0)
 
     def train(self, vertex, context, pairs, loss, optimizer, num_negative, negative_weight, negatives=None,
               table=None, seed=0, batch_id=0, moments=None, lr=None):
@@ -174,8 +198,13 @@ class HipKernels(object):
         _lib.check(rc, "gvk_alias_sample")
 
     def negative_draw(self, table, seed, batch_id, out, batch_size, num_negative):
+        """The negatives of a batch as the training kernels draw them, from a row table [rows] or a class table [n, 2]."""
         _need(table, torch.int64, "alias table")
         _need(out, torch.int32, "negatives", table.device)
+        if table.dim() == 2:
+            rc = self.lib.gvk_negative_draw_classes(self._stream(table), _ptr(table), table.shape[0], seed, batch_id,
+                                                    _ptr(out), batch_size, num_negative)
+            return _lib.check(rc, "gvk_negative_draw_classes")
         rc = self.lib.gvk_negative_draw(self._stream(table), _ptr(table), table.numel(), seed, batch_id, _ptr(out),
                                         batch_size, num_negative)
         _lib.check(rc, "gvk_negative_draw")

@@ -200,6 +200,10 @@ class GraphSolver(object):
         self._upload_chunk_bytes = 256 << 20  # host <-> device table traffic goes through chunks of this size
         self.seed = seed
         self.node2vec_table_limit = 1 << 30  # entries (8 B each) of per-edge alias tables before switching to rejection
+        # the negative sampler's table: "rows" = one alias slot per row of the tail partition (the reference's), "classes"
+        # = an alias table over the classes of equal-weight rows (same distribution, cache-resident), "auto" = classes
+        # when they are at least 8 times fewer than the rows (unweighted graphs: always)
+        self.negative_table = "auto"
         # extension: draw LINE's positive edge samples on the GPU instead of CPU threads
         self.device_sampling = bool(device_sampling)
         if pair_order not in (auto, "sampled", "grouped"):
@@ -609,11 +613,17 @@ class GraphSolver(object):
                 scatter_in(head, mh["vertex"][j], range(P), 1 + nm, 1 + j)
                 scatter_in(state["context_m%d" % j], mh["context"][j], self._my_tails)
         # negative sampler per owned tail partition: deg^exponent in local order (solver.h:1264-1278)
-        from .kernels import alias_build, packed_to_device
+        from .kernels import alias_build, class_table_build, classes_to_device, packed_to_device
         weights = self.graph.vertex_weights
         state["negative_tables"] = {}
         for tp in self._my_tails:
             w = hostlib.negative_weights(weights, self._part_ids[tp], self.negative_sample_exponent)
+            # rows of equal weight (= equal degree: the partition is sorted by it) form a class; a few thousand classes
+            # instead of one slot per row keep the sampler's table in the caches (gvk.h)
+            classes = class_table_build(w) if self.negative_table != "rows" else None
+            if classes is not None and (self.negative_table == "classes" or classes.size * 8 <= w.size):
+                state["negative_tables"][tp] = classes_to_device(classes, self.device)
+                continue
             _, _, packed = alias_build(w)
             state["negative_tables"][tp] = packed_to_device(packed, self.device)
         state["loss"] = torch.zeros(self.batch_size, dtype=torch.float32, device=self.device)

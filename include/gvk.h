@@ -91,7 +91,32 @@ typedef struct {
     const gvk_alias_entry *table;  /* device, [count] */
     uint32_t count;
     uint64_t seed;
+    const struct gvk_class_entry *classes; /* device, [class_count], or NULL: the same distribution by weight classes */
+    uint32_t class_count;
 } gvk_negative_source;
+
+/* Negative sampling by weight classes.  The reference draws a negative from an alias table with one slot per row of
+ * the tail partition (solver.h:1264-1278, alias_table.cuh:148-152): 8 MB at 1M rows, one random memory request per draw —
+ * 1 in 7 of everything a dim-32 sample asks of the memory system, 1 in 25 at dim 128.  The weights are
+ * degree^0.75, and the rows of a partition are sorted by degree: rows of equal weight are contiguous and there are
+ * only a few thousand distinct weights.  A class = a maximal run of consecutive rows of equal weight; the class table
+ * is an alias table over the classes (class weight = rows * weight) whose entries also carry the run:
+ *     w = philox4x32_10(ctr = {sample, batch_id, j, 0x6e656743}, key = seed)
+ *     slot = (uint64(w[0]) * class_count) >> 32;  u = float(w[1] >> 8) * 2^-24
+ *     c = u < classes[slot].prob ? slot : classes[slot].alias
+ *     negative = classes[c].first + ((uint64(w[2]) * classes[c].count) >> 32)
+ * Every row is drawn with probability weight / sum of weights, exactly as from the row table; the table is 16 bytes
+ * per class and lives in the caches.  gvk_class_table_build (host) returns GVK_OK and *num_class; callers keep the row
+ * table when the classes are not much fewer than the rows (real-valued edge weights: every row its own class). */
+typedef struct gvk_class_entry {
+    float prob;
+    uint32_t alias;
+    uint32_t first, count;
+} gvk_class_entry;
+int gvk_class_table_build(const float *weights, size_t n, gvk_class_entry *out, uint32_t *num_class);
+/* negatives[s * num_negative + j] for a whole batch, as the training kernels draw them from a class table */
+int gvk_negative_draw_classes(void *stream, const gvk_class_entry *classes, uint32_t class_count, uint64_t seed,
+                              uint32_t batch_id, uint32_t *negatives, int batch_size, int num_negative);
 
 /* One batch of negative-sampling SGD: for every {tail, head} pair, num_negative negative steps then the
  * positive step on a progressively updated copy of vertex[head]; context rows are updated in place,

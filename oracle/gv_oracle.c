@@ -255,6 +255,47 @@ void gvo_negative_draw_batch(const float *prob, const uint32_t *alias, uint32_t 
             out[(size_t)s * k + j] = gvo_negative_draw(prob, alias, count, seed, batch_id, (uint32_t)s, (uint32_t)j);
 }
 
+/* Negatives by weight classes (include/gvk.h "Negative sampling by weight classes"; the reference has one slot per row,
+ * solver.h:1264-1278 — same distribution).  Classes: maximal runs of consecutive rows of equal weight; an alias table
+ * over the class masses (rows * weight) built exactly as alias_table.cuh:84-128 builds any table (gvo_alias_build). */
+#define GVO_TAG_NEG_CLASS 0x6e656743u /* "negC" */
+
+/* first / count / prob / alias: [n] capacity; returns the number of classes */
+uint32_t gvo_class_table_build(const float *weights, size_t n, uint32_t *first, uint32_t *count, float *prob, uint32_t *alias) {
+    float *mass = (float *)malloc(n * sizeof(float));
+    size_t classes = 0;
+    for (size_t i = 0; i < n;) {
+        size_t j = i + 1;
+        while (j < n && weights[j] == weights[i]) j++;
+        first[classes] = (uint32_t)i, count[classes] = (uint32_t)(j - i);
+        mass[classes++] = (float)((double)(j - i) * (double)weights[i]);
+        i = j;
+    }
+    gvo_alias_build(mass, classes, prob, alias, 4);
+    free(mass);
+    return (uint32_t)classes;
+}
+
+uint32_t gvo_negative_draw_class(const uint32_t *first, const uint32_t *count, const float *prob, const uint32_t *alias,
+                                 uint32_t num_class, uint64_t seed, uint32_t batch_id, uint32_t sample_id, uint32_t j) {
+    uint32_t ctr[4] = {sample_id, batch_id, j, GVO_TAG_NEG_CLASS}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t w[4];
+    gvo_philox4x32(ctr, key, w);
+    uint32_t slot = (uint32_t)(((uint64_t)w[0] * num_class) >> 32);
+    float u = (float)(w[1] >> 8) * (1.0f / 16777216.0f);
+    uint32_t c = u < prob[slot] ? slot : alias[slot];
+    return first[c] + (uint32_t)(((uint64_t)w[2] * count[c]) >> 32);
+}
+
+void gvo_negative_draw_class_batch(const uint32_t *first, const uint32_t *count, const float *prob, const uint32_t *alias,
+                                    uint32_t num_class, uint64_t seed, uint32_t batch_id, int batch_size, int k,
+                                    uint32_t *out) {
+    for (int s = 0; s < batch_size; s++)
+        for (int j = 0; j < k; j++)
+            out[(size_t)s * k + j] = gvo_negative_draw_class(first, count, prob, alias, num_class, seed, batch_id,
+                                                             (uint32_t)s, (uint32_t)j);
+}
+
 #define GVO_TAG_POS 0x706f7321u /* "pos!" */
 
 /* Device-side positive sampling of include/gvk.h (gvk_sample_pairs): out[t] = block_pairs[draw(first + t)] */

@@ -25,6 +25,10 @@ class OracleKernels(object):
         return None if t is None else t.numpy()
 
     def _negatives(self, table, seed, batch_id, B, k):
+        if table.dim() == 2:  # a class table (gvk_class_entry per weight class)
+            e = table.numpy().view(np.dtype([("prob", np.float32), ("alias", np.uint32), ("first", np.uint32),
+                                             ("count", np.uint32)])).reshape(-1)
+            return self.oracle.negatives_by_class((e["first"], e["count"], e["prob"], e["alias"]), seed, batch_id, B, k)
         packed = table.numpy().view(np.dtype([("prob", np.float32), ("alias", np.uint32)]))
         prob, alias = np.ascontiguousarray(packed["prob"]), np.ascontiguousarray(packed["alias"])
         return self.oracle.negatives(prob, alias, seed, batch_id, B, k)

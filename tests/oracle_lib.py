@@ -56,6 +56,11 @@ class Oracle(object):
         lib.gvo_negative_draw.argtypes = [_f32p, _u32p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
         lib.gvo_negative_draw_batch.restype = None
         lib.gvo_negative_draw_batch.argtypes = [_f32p, _u32p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.c_int, _u32p]
+        lib.gvo_class_table_build.restype = C.c_uint32
+        lib.gvo_class_table_build.argtypes = [_f32p, C.c_size_t, _u32p, _u32p, _f32p, _u32p]
+        lib.gvo_negative_draw_class_batch.restype = None
+        lib.gvo_negative_draw_class_batch.argtypes = [_u32p, _u32p, _f32p, _u32p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int,
+                                                       C.c_int, _u32p]
         lib.gvo_sample_pairs.restype = None
         lib.gvo_sample_pairs.argtypes = [_f32p, _u32p, _u32p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_size_t, _u32p]
         lib.gvo_sample_walks_device.restype = C.c_int
@@ -139,6 +144,21 @@ class Oracle(object):
     def negatives(self, prob, alias, seed, batch_id, batch_size, k):
         out = np.zeros((batch_size, k), np.uint32)
         self.lib.gvo_negative_draw_batch(prob, alias, prob.size, seed, batch_id, batch_size, k, out.reshape(-1))
+        return out
+
+    def class_table(self, weights):
+        """(first, count, prob, alias) of the weight classes of a partition (gvk_class_table_build restated)."""
+        w = np.ascontiguousarray(weights, np.float32)
+        first, count = np.zeros(w.size, np.uint32), np.zeros(w.size, np.uint32)
+        prob, alias = np.zeros(w.size, np.float32), np.zeros(w.size, np.uint32)
+        n = self.lib.gvo_class_table_build(w, w.size, first, count, prob, alias)
+        return first[:n].copy(), count[:n].copy(), prob[:n].copy(), alias[:n].copy()
+
+    def negatives_by_class(self, classes, seed, batch_id, batch_size, k):
+        first, count, prob, alias = (np.ascontiguousarray(a) for a in classes)
+        out = np.zeros((batch_size, k), np.uint32)
+        self.lib.gvo_negative_draw_class_batch(first, count, prob, alias, first.size, seed, batch_id, batch_size, k,
+                                               out.reshape(-1))
         return out
 
     def sample_pairs(self, prob, alias, block_pairs, seed, first, n):
