@@ -12,4 +12,7 @@ int gvk_sample_walks_blocks(void *, const gvk_walk_graph *, const int32_t *, int
 int gvk_describe_train(int, int, int, int, int, uint32_t, char *, size_t) { return GVK_EHIP; }
 int gvk_group_pairs(void *, const uint32_t *, uint32_t *, void *, size_t *, int, int, int) { return GVK_EHIP; }
 int gvk_set_tuning(int, int) { return GVK_OK; }
+int gvk_sample_edges(void *, const gvk_edge_entry *, uint32_t, uint64_t, uint64_t, uint32_t *, size_t) { return GVK_EHIP; }
+int gvk_negative_draw_classes(void *, const gvk_class_entry *, uint32_t, uint64_t, uint32_t, uint32_t *, int, int) { return GVK_EHIP; }
+int gvk_probe_row_traffic(void *, int, float *, float *, const uint32_t *, const uint32_t *, float, int) { return GVK_EHIP; }
 }
