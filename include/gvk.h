@@ -18,6 +18,17 @@
  *   gvk_alias_build      AliasTable::build (include/base/alias_table.cuh:84-128)
  *   gvk_alias_sample     AliasTable::device_sample / gpu::Sample (include/base/alias_table.cuh:155-158,174-182)
  *   gvk_negative_draw    the same draw as gvk_train's fused on-device draw, as a standalone kernel
+ *   gvk_class_table_build / gvk_negative_draw_classes
+ *                        WorkerMixin::build_negative_sampler (include/core/solver.h:1264-1278) in the form the
+ *                        solvers use by default: an alias table over the classes of equal-weight rows instead of
+ *                        one slot per row — same distribution ("Negative sampling by weight classes" below)
+ *   gvk_sample_pairs / gvk_sample_edges / gvk_sample_walks / gvk_sample_walks_blocks
+ *                        SamplerMixin::sample, GraphSampler::sample_random_walk / sample_biased_random_walk
+ *                        (include/core/solver.h:1012-1055, include/instance/graph.cuh:298-450) on the device (opt-in)
+ *   gvk_group_pairs      no counterpart: a per-batch pre-pass (same samples, shared rows adjacent)
+ *   gvk_probe_row_traffic, gvk_describe_train, gvk_set_tuning, gvk_range_push / _pop
+ *                        measurement aids (roofline.access_pattern, kernel label, A/B knobs, roctx ranges at the
+ *                        reference's Timer scopes, include/util/time.h:28-60)
  *
  * Data layout in HBM
  *   embedding tables  row-major float32 [rows][dim] (Vector<dim,float>, include/base/vector.h:31-69);
