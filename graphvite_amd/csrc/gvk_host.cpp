@@ -1,7 +1,12 @@
 // gvk_host.cpp — host-side entry points of include/gvk.h: error plumbing and the alias-table builder.
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
+#include <algorithm>
+#include <thread>
 #include <vector>
 
 #include <roctracer/roctx.h>
@@ -75,6 +80,20 @@ void alias_build(const float *w, size_t n, float *prob, Index *alias) {
 }
 
 }  // namespace
+
+int gvk_cpu_budget(void) {
+    unsigned n = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = (unsigned)CPU_COUNT(&set);
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[64];
+        double period = 0;
+        if (fscanf(f, "%63s %lf", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0)
+            n = std::min<unsigned>(n, (unsigned)std::max(1, (int)(atof(quota) / period)));
+        fclose(f);
+    }
+    return (int)std::max(1u, n);
+}
 
 extern "C" {
 

@@ -82,6 +82,31 @@ struct HugeAllocator {
 template <class T>
 using HugeVector = std::vector<T, HugeAllocator<T>>;
 
+// The same storage for arrays whose every element is written right after they are sized: resize(n) leaves the new
+// elements uninitialized instead of zeroing them on one thread, so the threads that fill the array are also the ones
+// that first touch (fault in) its pages.
+template <class T>
+struct RawHugeAllocator : HugeAllocator<T> {
+    typedef T value_type;
+    template <class U>
+    struct rebind {
+        typedef RawHugeAllocator<U> other;
+    };
+    RawHugeAllocator() = default;
+    template <class U>
+    RawHugeAllocator(const RawHugeAllocator<U> &) {}
+    template <class U>
+    void construct(U *p) {
+        ::new ((void *)p) U;
+    }
+    template <class U, class... Args>
+    void construct(U *p, Args &&...args) {
+        ::new ((void *)p) U(std::forward<Args>(args)...);
+    }
+};
+template <class T>
+using RawHugeVector = std::vector<T, RawHugeAllocator<T>>;
+
 // ---- graph ---------------------------------------------------------------------------------------------
 
 // name -> id for the text loaders.  A billion-edge list is two lookups per line into a table of up to 10^8 names, each
@@ -194,8 +219,8 @@ struct gvs_graph {
     std::vector<float> w;
     // flattened
     std::vector<float> vertex_weights;
-    HugeVector<uint32_t> edges_uv;
-    HugeVector<float> edge_weights;
+    RawHugeVector<uint32_t> edges_uv;   // both filled, every element, by finalize()
+    RawHugeVector<float> edge_weights;
     HugeVector<uint64_t> flat_offsets;
 
     void clear() {
@@ -271,21 +296,52 @@ struct gvs_graph {
         num_edge++;
     }
 
-    // GraphMixin::flatten (core/graph.h:87-101) + Graph::normalize (graph.cuh:103-121)
-    void finalize() {
+    // GraphMixin::flatten (core/graph.h:87-101) + Graph::normalize (graph.cuh:103-121).  The flattening is a stable
+    // counting sort of the directed edges by source; its scatter runs on `threads` host threads that each own a range
+    // of SOURCE VERTICES (equal shares of the edges): every thread scans the whole edge list in order and places the
+    // edges of its range, so a vertex's edges keep their insertion order, nobody shares a cursor, and a thread's
+    // random writes stay inside its own slice of the output.
+    void finalize(int threads = 0) {
         const size_t D = src.size();
+        const auto t_begin = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (getenv("GVS_TIMING"))
+                fprintf(stderr, "[gvs] finalize: %s at %.3f s\n", what,
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+        };
+        if (threads <= 0) threads = gvk_cpu_budget();
+        const size_t T = (size_t)std::max(1, std::min<int>(threads, (int)std::max<size_t>(D >> 18, 1)));
         flat_offsets.assign((size_t)num_vertex + 1, 0);
-        for (size_t e = 0; e < D; e++) flat_offsets[src[e] + 1]++;
+        for (size_t e = 0; e < D; e++) flat_offsets[src[e] + 1]++;  // (sequential reads: as fast on one thread as on many)
+        lap("histogram");
         for (uint32_t u = 0; u < num_vertex; u++) flat_offsets[u + 1] += flat_offsets[u];
         edges_uv.resize(2 * D);
         edge_weights.resize(D);
         std::vector<uint64_t> cursor(flat_offsets.begin(), flat_offsets.end() - 1);
-        for (size_t e = 0; e < D; e++) {
-            const uint64_t slot = cursor[src[e]]++;
-            edges_uv[2 * slot] = src[e];
-            edges_uv[2 * slot + 1] = dst[e];
-            edge_weights[slot] = w[e];
+        lap("allocation");
+        {  // scatter: vertex ranges holding equal shares of the edges
+            std::vector<uint32_t> bound(T + 1, num_vertex);
+            bound[0] = 0;
+            for (size_t t = 1; t < T; t++)
+                bound[t] = (uint32_t)(std::lower_bound(flat_offsets.begin(), flat_offsets.end() - 1, (uint64_t)(D / T * t)) -
+                                      flat_offsets.begin());
+            std::vector<std::thread> pool;
+            for (size_t t = 0; t < T; t++)
+                pool.emplace_back([&, t]() {
+                    const uint32_t lo = bound[t], hi = bound[t + 1];
+                    if (lo >= hi) return;
+                    for (size_t e = 0; e < D; e++) {
+                        const uint32_t u = src[e];
+                        if (u < lo || u >= hi) continue;
+                        const uint64_t slot = cursor[u]++;
+                        edges_uv[2 * slot] = u;
+                        edges_uv[2 * slot + 1] = dst[e];
+                        edge_weights[slot] = w[e];
+                    }
+                });
+            for (auto &th : pool) th.join();
         }
+        lap("scatter");
         decltype(src)().swap(src);
         decltype(dst)().swap(dst);
         decltype(w)().swap(w);

@@ -82,19 +82,7 @@ std::string header(const std::string &content) {  // util/io.h:86-103
     return std::string(pad / 2, '-') + " " + content + " " + std::string(pad - pad / 2, '-');
 }
 
-int cpu_budget() {
-    unsigned n = std::thread::hardware_concurrency();
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = (unsigned)CPU_COUNT(&set);
-    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // the container's quota, not the machine's threads
-        char quota[64];
-        double period = 0;
-        if (fscanf(f, "%63s %lf", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0)
-            n = std::min<unsigned>(n, std::max(1, (int)(atof(quota) / period)));
-        fclose(f);
-    }
-    return std::max(1u, n);
-}
+int cpu_budget() { return gvk_cpu_budget(); }
 
 struct Range {  // roctx range around a host phase (gvk_range_push / _pop): the reference's Timer scopes, time.h:28-60
     explicit Range(const char *name) { gvk_range_push(name); }
