@@ -41,6 +41,9 @@
  * sample_random_walk / sample_biased_random_walk record for record, the former is the same walk logic with the
  * i.i.d. uniforms taken in another order (and is what the product is pinned against, bit for bit).
  * gvo_sample_pairs / gvo_sample_walks_device restate device samplers the reference lacks.
+ * gvo_class_table_build / gvo_negative_draw_class restate the negative sampler by weight classes (include/gvk.h): the
+ * distribution of the reference's one-slot-per-row table (solver.h:1264-1278) drawn as class, then row; the tests
+ * reconstruct every row's probability from the class table and compare it with weight / sum of weights.
  */
 #include <math.h>
 #include <stdint.h>
