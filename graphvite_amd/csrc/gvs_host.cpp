@@ -407,60 +407,163 @@ int gvs_graph_load_file(gvs_graph *g, const char *file_name, int as_undirected, 
         g->clear();
         g->as_undirected = as_undirected != 0;
         g->normalization = normalization != 0;
-        // Two name lookups per line, each a cache miss into a table of up to 10^8 names: lines are tokenised and hashed
-        // kLookahead lines before their ids are resolved, with the table slots of both names prefetched meanwhile.
-        // Ids are still assigned in the order of the file.
-        constexpr int kLookahead = 16;
-        struct Parsed {
-            char *text = nullptr;
-            size_t cap = 0;
-            char *u_name, *v_name;
-            size_t u_len, v_len;
+        // Two stages on two threads.  A reader takes the file in chunks of whole lines, tokenises them in place and hashes
+        // the names (Graph::load_file's getline / strtok loop, graph.cuh:156-201, is all of that on one thread); this
+        // thread resolves the names in the order of the file — ids are first-seen order — with the table slots of the
+        // names 16 lines ahead being prefetched: two lookups per line into a table of up to 10^8 names are cache misses.
+        struct Record {
+            const char *u_name, *v_name;
+            uint32_t u_len, v_len;
             uint64_t u_hash, v_hash;
             float weight;
-        } ring[kLookahead];
-        int rc = GVK_OK;
-        size_t line_number = 0, head = 0, tail = 0;  // ring[head % k .. tail % k) are parsed and waiting
-        bool eof = false;
-        auto resolve = [&](const Parsed &p) {
-            const uint32_t u = g->id_of_name(p.u_name, p.u_len, p.u_hash);
-            const uint32_t v = g->id_of_name(p.v_name, p.v_len, p.v_hash);
-            g->add_edge(u, v, p.weight);
         };
-        while (rc == GVK_OK && (!eof || head < tail)) {
-            if (!eof && tail - head < (size_t)kLookahead) {
-                Parsed &p = ring[tail % kLookahead];
-                if (getline(&p.text, &p.cap, fin) < 0) {
-                    eof = true;
-                    continue;
+        struct Batch {
+            std::vector<char> text;       // whole lines; the tokens are terminated in place
+            std::vector<Record> records;
+            size_t bad_line = 0;          // first malformed line of the batch (1-based line number), 0 = none
+            bool last = false;
+        };
+        constexpr int kBatches = 3;
+        constexpr size_t kChunk = (size_t)4 << 20;
+        Batch batches[kBatches];
+        std::mutex lock;
+        std::condition_variable changed;
+        size_t produced = 0, consumed = 0;  // batches[produced % k] is being filled, batches[consumed % k] resolved
+        bool abandon = false, reader_failed = false;
+        std::thread reader([&]() {
+          try {
+            std::string carry;
+            size_t line_number = 0;
+            bool eof = false;
+            while (!eof) {
+                {
+                    std::unique_lock<std::mutex> hold(lock);
+                    changed.wait(hold, [&]() { return abandon || produced - consumed < (size_t)kBatches; });
+                    if (abandon) return;
                 }
-                line_number++;
-                if (*comment) {
-                    char *c = strstr(p.text, comment);
-                    if (c) *c = 0;
+                Batch &batch = batches[produced % kBatches];
+                batch.records.clear();
+                batch.bad_line = 0;
+                batch.text.assign(carry.begin(), carry.end());
+                carry.clear();
+                size_t complete = 0;  // bytes of whole lines in batch.text
+                while (true) {
+                    const size_t have = batch.text.size();
+                    batch.text.resize(have + kChunk);
+                    const size_t got = fread(batch.text.data() + have, 1, kChunk, fin);
+                    batch.text.resize(have + got);
+                    if (got < kChunk) eof = true;
+                    for (size_t i = batch.text.size(); i > have; i--)
+                        if (batch.text[i - 1] == '\n') {
+                            complete = i;
+                            break;
+                        }
+                    if (complete || eof) break;  // (a line longer than a chunk: keep reading)
                 }
-                char *cursor = p.text;
-                p.u_name = next_token(&cursor, delimiters);
-                if (!p.u_name) continue;
-                p.v_name = next_token(&cursor, delimiters);
-                char *w_str = next_token(&cursor, delimiters);
-                char *more = next_token(&cursor, delimiters);
-                if (!p.v_name || more) {
-                    rc = gvk_fail(GVK_EINVAL, "Invalid format at line %zu of `%s`", line_number, file_name);
-                    break;
+                if (eof) {
+                    complete = batch.text.size();  // the last line may lack its newline
+                } else {
+                    carry.assign(batch.text.begin() + complete, batch.text.end());
                 }
-                p.weight = w_str ? (float)atof(w_str) : 1.f;
-                p.u_len = strlen(p.u_name), p.v_len = strlen(p.v_name);
-                p.u_hash = NameTable::hash_of(p.u_name, p.u_len), p.v_hash = NameTable::hash_of(p.v_name, p.v_len);
-                g->name2id.prefetch(p.u_hash);
-                g->name2id.prefetch(p.v_hash);
-                tail++;
-                continue;
+                batch.text.resize(complete);
+                batch.text.push_back(0);
+                char *line = batch.text.data(), *const end = batch.text.data() + complete;
+                while (line < end && !batch.bad_line) {
+                    // getline keeps the newline in the line (it is a token byte unless it is a delimiter)
+                    char *stop = static_cast<char *>(memchr(line, '\n', end - line));
+                    stop = stop ? stop + 1 : end;
+                    const char saved = *stop;
+                    *stop = 0;
+                    line_number++;
+                    if (*comment) {
+                        char *c = strstr(line, comment);
+                        if (c) *c = 0;
+                    }
+                    char *cursor = line;
+                    Record r;
+                    char *u_name = next_token(&cursor, delimiters);
+                    if (u_name) {
+                        char *v_name = next_token(&cursor, delimiters);
+                        char *w_str = next_token(&cursor, delimiters);
+                        char *more = next_token(&cursor, delimiters);
+                        if (!v_name || more) {
+                            batch.bad_line = line_number;
+                        } else {
+                            r.u_name = u_name, r.v_name = v_name;
+                            r.weight = w_str ? (float)atof(w_str) : 1.f;
+                            r.u_len = (uint32_t)strlen(u_name), r.v_len = (uint32_t)strlen(v_name);
+                            r.u_hash = NameTable::hash_of(u_name, r.u_len), r.v_hash = NameTable::hash_of(v_name, r.v_len);
+                            batch.records.push_back(r);
+                        }
+                    }
+                    *stop = saved;
+                    line = stop;
+                }
+                batch.last = eof || batch.bad_line;
+                {
+                    std::lock_guard<std::mutex> hold(lock);
+                    produced++;
+                }
+                changed.notify_all();
+                if (batch.bad_line) return;
             }
-            resolve(ring[head++ % kLookahead]);
+          } catch (...) {  // out of memory while reading: hand the consumer a final, empty batch
+            std::lock_guard<std::mutex> hold(lock);
+            Batch &batch = batches[produced % kBatches];
+            batch.records.clear();
+            batch.bad_line = 0, batch.last = true;
+            reader_failed = true;
+            produced++;
+            changed.notify_all();
+          }
+        });
+        struct Joiner {  // whatever way this scope is left, the reader is told to stop and joined
+            std::thread &thread;
+            std::mutex &lock;
+            std::condition_variable &changed;
+            bool &abandon;
+            ~Joiner() {
+                {
+                    std::lock_guard<std::mutex> hold(lock);
+                    abandon = true;
+                }
+                changed.notify_all();
+                if (thread.joinable()) thread.join();
+            }
+        } joiner{reader, lock, changed, abandon};
+        int rc = GVK_OK;
+        constexpr size_t kLookahead = 16;
+        double waited = 0;  // seconds this thread waited for the reader (GVS_TIMING)
+        while (true) {
+            {
+                const auto w0 = std::chrono::steady_clock::now();
+                std::unique_lock<std::mutex> hold(lock);
+                changed.wait(hold, [&]() { return produced > consumed; });
+                waited += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+            }
+            Batch &batch = batches[consumed % kBatches];
+            const std::vector<Record> &rec = batch.records;
+            for (size_t i = 0; i < std::min(kLookahead, rec.size()); i++)
+                g->name2id.prefetch(rec[i].u_hash), g->name2id.prefetch(rec[i].v_hash);
+            for (size_t i = 0; i < rec.size(); i++) {
+                if (i + kLookahead < rec.size())
+                    g->name2id.prefetch(rec[i + kLookahead].u_hash), g->name2id.prefetch(rec[i + kLookahead].v_hash);
+                const uint32_t u = g->id_of_name(rec[i].u_name, rec[i].u_len, rec[i].u_hash);
+                const uint32_t v = g->id_of_name(rec[i].v_name, rec[i].v_len, rec[i].v_hash);
+                g->add_edge(u, v, rec[i].weight);
+            }
+            if (batch.bad_line) rc = gvk_fail(GVK_EINVAL, "Invalid format at line %zu of `%s`", batch.bad_line, file_name);
+            const bool last = batch.last;
+            {
+                std::lock_guard<std::mutex> hold(lock);
+                consumed++;
+            }
+            changed.notify_all();
+            if (last) break;
         }
-        for (Parsed &p : ring) free(p.text);
+        reader.join();
         fclose(fin);
+        if (reader_failed) rc = gvk_fail(GVK_ENOMEM, "gvs_graph_load_file: out of host memory");
         if (rc != GVK_OK) {
             g->clear();
             return rc;
@@ -468,8 +571,8 @@ int gvs_graph_load_file(gvs_graph *g, const char *file_name, int as_undirected, 
         const auto t_parsed = std::chrono::steady_clock::now();
         g->finalize();
         if (getenv("GVS_TIMING"))
-            fprintf(stderr, "[gvs] load_file: parse %.2f s, flatten %.2f s\n",
-                    std::chrono::duration<double>(t_parsed - t_start).count(),
+            fprintf(stderr, "[gvs] load_file: parse %.2f s (%.2f s of it waiting for the reader thread), flatten %.2f s\n",
+                    std::chrono::duration<double>(t_parsed - t_start).count(), waited,
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t_parsed).count());
         return GVK_OK;
     });
