@@ -1065,7 +1065,7 @@ public:
 private:
     // thread k -> the (offset + k)-th CPU of the process's affinity mask; done once per offset
     void pin(int offset) {
-        if (offset < 0 || offset == pinned_offset_ && pinned_count_ == threads_.size()) return;
+        if (offset < 0 || (offset == pinned_offset_ && pinned_count_ == threads_.size())) return;
         cpu_set_t allowed;
         if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
         std::vector<int> cpus;
