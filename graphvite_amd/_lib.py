@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgvk.so")
+# GVK_LIBRARY: measurements and tests of the A/B baselines load build/ab/libgvk_ab.so (make -C graphvite_amd/csrc ab) instead
+LIB_PATH = os.environ.get("GVK_LIBRARY") or os.path.join(_HERE, "libgvk.so")
 
 GVK_OK, GVK_EINVAL, GVK_EDIM, GVK_EHIP, GVK_ENOMEM = 0, -1, -2, -3, -4
 SGD, MOMENTUM, ADAGRAD, RMSPROP, ADAM = range(5)
@@ -16,6 +17,7 @@ TUNE_RUN_CAP = 3
 TUNE_GENERATION = 4
 TUNE_SEGMENT_STEPS = 5
 TUNE_SKIP_LOSS = 6
+TUNE_SPLIT_HITS = 7
 
 
 class AliasEntry(C.Structure):
@@ -109,6 +111,10 @@ def lib():
     l.gvk_alias_build.argtypes = [vp, C.c_size_t, vp, vp, i32, vp]
     l.gvk_set_tuning.restype = i32
     l.gvk_set_tuning.argtypes = [i32, i32]
+    l.gvk_train_launches.restype = i32
+    l.gvk_train_launches.argtypes = [i32, u32]
+    l.gvk_has_ab_builds.restype = i32
+    l.gvk_has_ab_builds.argtypes = []
     l.gvk_describe_train.restype = i32
     l.gvk_describe_train.argtypes = [i32, i32, i32, i32, i32, u32, C.c_char_p, C.c_size_t]
     l.gvk_range_push.restype = None

@@ -38,12 +38,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-int g_lanes_per_pair = 0;  // GVK_TUNE_LANES_PER_PAIR
 int g_variant = 0;         // GVK_TUNE_VARIANT
 int g_run_cap = 0;         // GVK_TUNE_RUN_CAP (0 = from the batch size, run_cap_for)
+int g_split_hits = 2;      // GVK_TUNE_SPLIT_HITS (samples per table row one launch may hold; 0 = never split a batch)
+#if defined(GVK_AB_BUILDS)  // knobs of the A/B library only (make ab -> build/ab/libgvk_ab.so)
+int g_lanes_per_pair = 0;  // GVK_TUNE_LANES_PER_PAIR
 int g_generation = 0;      // GVK_TUNE_GENERATION (0 = one launch per batch)
 int g_segment_steps = 0;   // GVK_TUNE_SEGMENT_STEPS (0 = off)
 int g_skip_loss = 1;       // GVK_TUNE_SKIP_LOSS (gvk_train_episode leaves out the loss of batches nobody can read)
+#else
+constexpr int g_lanes_per_pair = 0, g_generation = 0, g_segment_steps = 0, g_skip_loss = 1;
+#endif
 
 struct TrainArgs {
     float *vertex, *context, *vm1, *cm1, *vm2, *cm2;
@@ -56,7 +61,7 @@ struct TrainArgs {
     uint32_t count, batch_id;
     int batch_size, k;
     int run_cap;  // train_runs_kernel: longest run of adjacent same-head pairs one lane group trains in sequence
-    int first_sample;  // train_kernel: this launch trains samples [first_sample, batch_size) of the batch (GVK_TUNE_GENERATION)
+    int first_sample;  // this launch trains samples [first_sample, batch_size) of the batch (a batch split over several launches)
     float lr, wd, neg_weight, hp0, hp1, eps;
 };
 
@@ -181,7 +186,7 @@ __device__ __forceinline__ void load_row(const float *table, uint32_t id, int la
     for (int c = 0; c < L::NC; c++) {
         const float *p = row + c * G * L::CW;
         if (L::CW == 4) {
-#if defined(GVK_EXPERIMENT_NT_ROWS)  // A/B build only (scripts/experiments/gpu_r2_nt.sh): rows marked streaming in the caches
+#if defined(GVK_AB_BUILDS) && defined(GVK_EXPERIMENT_NT_ROWS)  // A/B build only (scripts/experiments/gpu_r2_nt.sh): rows marked streaming in the caches
             f32x4 x = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
 #else
             f32x4 x = *reinterpret_cast<const f32x4 *>(p);
@@ -205,7 +210,7 @@ __device__ __forceinline__ void store_row(float *table, uint32_t id, int lane, c
         float *p = row + c * G * L::CW;
         if (L::CW == 4) {
             f32x4 x = {r[c * 4 + 0], r[c * 4 + 1], r[c * 4 + 2], r[c * 4 + 3]};
-#if defined(GVK_EXPERIMENT_NT_ROWS) && GVK_EXPERIMENT_NT_ROWS >= 2
+#if defined(GVK_AB_BUILDS) && defined(GVK_EXPERIMENT_NT_ROWS) && GVK_EXPERIMENT_NT_ROWS >= 2
             __builtin_nontemporal_store(x, reinterpret_cast<f32x4 *>(p));
 #else
             *reinterpret_cast<f32x4 *>(p) = x;
@@ -271,7 +276,9 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_kernel(const TrainArgs a)
     const int k = KT > 0 ? KT : a.k;
     const bool draw = DRAW < 0 ? a.negatives == nullptr : DRAW != 0;
 
-    // round trip 1: the pair and the first negative's alias slot (independent of each other)
+    // round trip 1: the pair, requested before anything is computed, and the first negative's alias slot (Philox runs
+    // while the pair is on its way)
+    const u32x2 pr = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(a.pairs) + s);
     Draw d0 = {0, 0, 0};
     NegEntry e0 = {0, 0, 0, 0};
     uint32_t neg0 = 0;
@@ -283,14 +290,18 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_kernel(const TrainArgs a)
             neg0 = __builtin_nontemporal_load(a.negatives + (size_t)s * k);
         }
     }
-    const u32x2 pr = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(a.pairs) + s);
     const uint32_t tail = pr.x, head = pr.y;  // records are {tail, head}
 
-    // round trip 2: vertex row (+ moments) and the first target row
+    // round trip 2: vertex row (+ moments) and the first target row.  With one negative (KT == 1) the positive's row
+    // is requested here as well, ahead of the negative's: both ids of the pair are known, the negative's still waits
+    // for its alias entry.
     float v[V], vm1[M1], vm2[M2];
     load_row<DIM, G>(a.vertex, head, lane, v);
     if constexpr (NM >= 1) load_row<DIM, G>(a.vm1, head, lane, reinterpret_cast<float(&)[V]>(vm1));
     if constexpr (NM >= 2) load_row<DIM, G>(a.vm2, head, lane, reinterpret_cast<float(&)[V]>(vm2));
+    constexpr bool kTailEarly = KT == 1 && NM == 0;
+    float early[kTailEarly ? V : 1];
+    if constexpr (kTailEarly) load_row<DIM, G>(a.context, tail, lane, reinterpret_cast<float(&)[V]>(early));
 
     uint32_t id_cur = k > 0 ? (draw ? resolve(a, d0, e0) : neg0) : tail;
     float cur[V], cur1[M1], cur2[M2];
@@ -314,9 +325,13 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_kernel(const TrainArgs a)
             } else {
                 id_nxt = tail;
             }
-            load_row<DIM, G>(a.context, id_nxt, lane, nxt);
-            if constexpr (NM >= 1) load_row<DIM, G>(a.cm1, id_nxt, lane, reinterpret_cast<float(&)[V]>(nxt1));
-            if constexpr (NM >= 2) load_row<DIM, G>(a.cm2, id_nxt, lane, reinterpret_cast<float(&)[V]>(nxt2));
+            if constexpr (kTailEarly) {
+                copy_row(nxt, reinterpret_cast<float(&)[V]>(early));  // requested before the negative's row
+            } else {
+                load_row<DIM, G>(a.context, id_nxt, lane, nxt);
+                if constexpr (NM >= 1) load_row<DIM, G>(a.cm1, id_nxt, lane, reinterpret_cast<float(&)[V]>(nxt1));
+                if constexpr (NM >= 2) load_row<DIM, G>(a.cm2, id_nxt, lane, reinterpret_cast<float(&)[V]>(nxt2));
+            }
         }
 
         // forward: model/graph.h:40-45
@@ -407,7 +422,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_runs_kernel(const TrainAr
     constexpr int M1 = NM >= 1 ? V : 1, M2 = NM >= 2 ? V : 1;
 
     const int tid = blockIdx.x * kBlock + threadIdx.x;
-    const int s = tid / G, lane = tid % G;
+    const int s = a.first_sample + tid / G, lane = tid % G;
     if (s >= a.batch_size) return;  // whole groups leave together: G divides 64
 
     const int k = KT > 0 ? KT : a.k;
@@ -430,7 +445,8 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_runs_kernel(const TrainAr
     const u32x2 pr = records[s];
     uint32_t tail = pr.x;
     const uint32_t head = pr.y;  // records are {tail, head}
-    const int first_of_segment = s - s % R;
+    // runs stay inside their segment: run_cap samples, counted from the first sample of this launch
+    const int first_of_segment = s - (s - a.first_sample) % R;
     const int limit = first_of_segment + R < a.batch_size ? first_of_segment + R : a.batch_size;
     u32x2 next_pr = {0, 0};
     if (s + 1 < limit) next_pr = records[s + 1];
@@ -557,9 +573,11 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_runs_kernel(const TrainAr
     if constexpr (NM >= 2) store_row<DIM, G>(a.vm2, head, lane, reinterpret_cast<float(&)[V]>(vm2));
 }
 
-// ---- training kernel, SGD with one negative: a wavefront owns a segment of the batch --------------------------------
+#if defined(GVK_AB_BUILDS)  // A/B baselines: only in build/ab/libgvk_ab.so (make ab), never in the product library
+
+// ---- A/B: SGD with one negative, a wavefront owns a segment of the batch ----------------------------------------------
 //
-// The shipped kernel for the configuration every shipped setting of the reference uses (SGD, num_negative 1).  Lane
+// Measured alternative to train_runs_kernel (no faster on large tables, slower on cache-resident shards).  Lane
 // layout and arithmetic are those of train_kernel; the unit of work is a SEGMENT of S = (64 / G) * D consecutive pairs
 // per wavefront, trained in D steps of 64 / G pairs (one pair per lane group and step):
 //
@@ -774,6 +792,8 @@ __global__ void __launch_bounds__(512) train_kernel_reference_shape(const TrainA
         for (int i = lane; i < DIM; i += 64) vertex[i] = vertex_buffer[i];
     }
 }
+
+#endif  // GVK_AB_BUILDS
 
 // ---- predict / alias kernels ------------------------------------------------------------------------------
 
@@ -1039,13 +1059,14 @@ bool lanes_ok(int dim, int g) {
 
 typedef void (*TrainKernel)(const TrainArgs);
 
-// RUNS picks train_runs_kernel (shipped) or train_kernel (per-pair A/B build).  Non-default lane groups exist for A/B
-// measurement of the SGD kernel only.
+// RUNS picks train_runs_kernel or train_kernel.  Non-default lane groups exist in the A/B library only (SGD).
+#if defined(GVK_AB_BUILDS)
 template <int DIM, int G, bool RUNS>
 TrainKernel pick_sgd(int opt) {
     if (opt != GVK_SGD) return nullptr;
     return RUNS ? train_runs_kernel<DIM, G, GVK_SGD> : train_kernel<DIM, G, GVK_SGD>;
 }
+#endif
 
 template <int DIM, int G, bool RUNS>
 TrainKernel pick_any(int opt) {
@@ -1058,16 +1079,17 @@ TrainKernel pick_any(int opt) {
 
 template <bool RUNS>
 TrainKernel pick_train(int dim, int g, int opt) {
-    const bool def = g == default_lanes(dim);
-#define GVK_CASE(D, GG)                                                      \
-    if (dim == D && g == GG) return def ? pick_any<D, GG, RUNS>(opt) : pick_sgd<D, GG, RUNS>(opt);
-    GVK_CASE(32, 8) GVK_CASE(32, 16)
-    GVK_CASE(64, 8) GVK_CASE(64, 16)
-    GVK_CASE(96, 8) GVK_CASE(96, 16)
-    GVK_CASE(128, 8) GVK_CASE(128, 16) GVK_CASE(128, 32) GVK_CASE(128, 64)
-    GVK_CASE(256, 16) GVK_CASE(256, 32) GVK_CASE(256, 64)
-    GVK_CASE(512, 32) GVK_CASE(512, 64)
+#define GVK_CASE(D, GG) \
+    if (dim == D && g == GG) return pick_any<D, GG, RUNS>(opt);
+    GVK_CASE(32, 8) GVK_CASE(64, 16) GVK_CASE(96, 8) GVK_CASE(128, 16) GVK_CASE(256, 16) GVK_CASE(512, 32)
 #undef GVK_CASE
+#if defined(GVK_AB_BUILDS)
+#define GVK_CASE(D, GG) \
+    if (dim == D && g == GG) return pick_sgd<D, GG, RUNS>(opt);
+    GVK_CASE(32, 16) GVK_CASE(64, 8) GVK_CASE(96, 16) GVK_CASE(128, 8) GVK_CASE(128, 32) GVK_CASE(128, 64)
+    GVK_CASE(256, 32) GVK_CASE(256, 64) GVK_CASE(512, 64)
+#undef GVK_CASE
+#endif
     return nullptr;
 }
 
@@ -1105,6 +1127,7 @@ int validate_train(int dim, const gvk_optimizer *o, const gvk_tables *t, const u
 struct Choice {
     TrainKernel kernel = nullptr;
     int lanes = 0, run_cap = 1, steps = 0;  // steps > 0: train_segment_kernel, (64 / lanes) * steps pairs per wavefront
+    int launches = 1;                       // the batch is trained as this many consecutive launches (launches_for)
     bool runs = false, fixed_k = false, reference_shape = false;
 };
 
@@ -1121,6 +1144,7 @@ constexpr size_t kResidentTableBytes = (size_t)16 << 20;
 
 bool resident_table(int dim, uint32_t rows) { return (size_t)rows * dim * 4 < kResidentTableBytes; }
 
+#if defined(GVK_AB_BUILDS)
 // D pairs per lane group keep 3 * D rows of DIM / G floats in registers; past 128 VGPRs per lane the kernel is
 // built for 2 wavefronts per SIMD (256 VGPRs) instead of spilling, and D = 4 exists only where that suffices.
 template <int DIM, int G, int D>
@@ -1149,19 +1173,48 @@ TrainKernel pick_segment(int steps, bool draw, bool loss) {
     return nullptr;
 }
 
+#endif  // GVK_AB_BUILDS
+
 // want_loss = false: the caller promises that nobody can read this batch's loss (a later batch overwrites it)
+// A batch larger than a few samples per table row is trained as several launches.  Inside one launch
+// every sample may run at the same time, and of the updates that hold a row at the same time one survives (Hogwild, as
+// in the reference).  While a partition has about as many rows as a batch has samples that is rare; when a partition is
+// small (a 100k-node graph cut into 16 partitions trains 100 000 samples on 6 250 rows) every row is in flight dozens of
+// times per launch — a hub row thousands of times — and most of its updates are lost: link-prediction AUC 0.880 where the
+// reference's loop reaches 0.903 at the same partition count.  So a batch is cut into Q equal parts of at most
+// g_split_hits = 2 samples per row, each part regrouped on its own (gvk_group_pairs with batch_size / Q) and trained by
+// its own launch: same samples, same negatives (a sample keeps its index in the batch), same lr; a later launch sees
+// everything the earlier ones wrote.  Q = the smallest divisor of the batch size that is large enough; nothing changes
+// for partitions of batch_size / 2 rows or more.
+int launches_for(int batch_size, uint32_t rows) {
+    if (g_split_hits <= 0 || rows == 0 || batch_size <= 0) return 1;
+    const int64_t per_launch = (int64_t)rows * g_split_hits;
+    const int64_t want = ((int64_t)batch_size + per_launch - 1) / per_launch;
+    if (want <= 1) return 1;
+    for (int64_t q = want; q <= batch_size && q <= 8 * want; q++)
+        if (batch_size % q == 0) return (int)q;
+    for (int64_t q = want; q > 1; q--)  // no divisor just above: the nearest one below
+        if (batch_size % q == 0) return (int)q;
+    return 1;
+}
+
 Choice choose_train(int dim, int opt, int k, bool explicit_negatives, int batch_size, uint32_t rows,
                     bool want_loss = true) {
     Choice c;
+    (void)want_loss;
+#if defined(GVK_AB_BUILDS)
     if (g_variant == 3 && dim == 128 && opt == GVK_SGD) {  // the reference's launch shape, graph.cuh:487-490
         c.reference_shape = true;
         c.lanes = 64;
         return c;
     }
+#endif
     c.lanes = g_lanes_per_pair && lanes_ok(dim, g_lanes_per_pair) && opt == GVK_SGD ? g_lanes_per_pair
                                                                                     : default_lanes(dim);
     const bool shipped_shape = opt == GVK_SGD && k == 1 && c.lanes == default_lanes(dim);
     const bool draw = !explicit_negatives;
+    c.launches = g_generation > 0 ? 1 : launches_for(batch_size, rows);
+#if defined(GVK_AB_BUILDS)
     // GVK_TUNE_SEGMENT_STEPS: train_segment_kernel (a wavefront owns a segment), the A/B alternative to runs for SGD with
     // one negative on the default lane layout
     c.steps = g_variant == 0 && g_generation == 0 && shipped_shape ? g_segment_steps : 0;
@@ -1175,14 +1228,17 @@ Choice choose_train(int dim, int opt, int k, bool explicit_negatives, int batch_
 #undef GVK_SEGMENT
         if (c.kernel) {
             c.fixed_k = true;
+            c.launches = 1;
             return c;
         }
         c.steps = 0;
     }
+#endif
     // runs of same-head samples: cache-resident tables by default (resident_table), any table with GVK_TUNE_VARIANT 4
     c.runs = g_generation == 0 && (g_variant == 4 || (g_variant == 0 && resident_table(dim, rows)));
     c.run_cap = c.runs ? run_cap_for(batch_size) : 1;
     c.kernel = c.runs ? pick_train<true>(dim, c.lanes, opt) : pick_train<false>(dim, c.lanes, opt);
+#if defined(GVK_AB_BUILDS)
     // A/B: compile-time-k builds for a few non-default lane groups (GVK_TUNE_LANES_PER_PAIR), so that the comparison
     // with the shipped layout is like for like
     if (opt == GVK_SGD && k == 1 && !c.runs && g_variant != 1 && c.lanes != default_lanes(dim)) {
@@ -1191,7 +1247,8 @@ Choice choose_train(int dim, int opt, int k, bool explicit_negatives, int batch_
         GVK_ALT(64, 8) GVK_ALT(96, 16) GVK_ALT(128, 8)
 #undef GVK_ALT
     }
-    // compile-time k and negative source -> straight-line code.  GVK_TUNE_VARIANT 1 forces the generic build (A/B).
+#endif
+    // compile-time k and negative source -> straight-line code (the generic build only with GVK_TUNE_VARIANT 1, A/B library)
     if (shipped_shape && g_variant != 1) {
         c.fixed_k = true;
 #define GVK_K1(D, GG)                                                                                         \
@@ -1222,31 +1279,29 @@ int launch_train(hipStream_t stream, int dim, const gvk_optimizer *o, float lr, 
     a.batch_size = batch_size; a.k = k; a.run_cap = c.run_cap;
     a.lr = lr; a.wd = o->weight_decay; a.neg_weight = negative_weight;
     a.hp0 = o->hp0; a.hp1 = o->hp1; a.eps = o->epsilon;
+#if defined(GVK_AB_BUILDS)
     if (c.reference_shape) {
         hipLaunchKernelGGL(train_kernel_reference_shape<128>, dim3(8192), dim3(512), 0, stream, a);
         return check_launch("gvk_train (reference-shape variant)");
     }
+#endif
     if (!c.kernel) return fail(GVK_EINVAL, "gvk_train: no kernel for this (dim, lanes, optimizer)");
-    if (g_generation > 0) {
-        // Parity experiment: the batch as consecutive launches of at most g_generation samples each, per-pair kernel —
-        // every launch is small enough to be resident at once, so the samples of a launch run concurrently from the
-        // same table state and a later launch sees everything the earlier ones wrote: the concurrency structure of
-        // the reference's launch on a card that holds g_generation warps.  Same samples, same negatives.
-        for (int first = 0; first < batch_size; first += g_generation) {
-            a.first_sample = first;
-            a.batch_size = first + g_generation < batch_size ? first + g_generation : batch_size;
-            const unsigned grid = (unsigned)(((int64_t)(a.batch_size - first) * c.lanes + kBlock - 1) / kBlock);
-            hipLaunchKernelGGL(c.kernel, dim3(grid), dim3(kBlock), 0, stream, a);
-        }
-        return check_launch("gvk_train (generations)");
-    }
-    int64_t threads = (int64_t)batch_size * c.lanes;
-    if (c.steps > 0) {  // one wavefront per segment of (64 / lanes) * steps pairs
+    if (c.steps > 0) {  // A/B: one wavefront per segment of (64 / lanes) * steps pairs
         const int per_wave = 64 / c.lanes * c.steps;
-        threads = ((int64_t)batch_size + per_wave - 1) / per_wave * 64;
+        const int64_t threads = ((int64_t)batch_size + per_wave - 1) / per_wave * 64;
+        hipLaunchKernelGGL(c.kernel, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, a);
+        return check_launch("gvk_train");
     }
-    const unsigned grid = (unsigned)((threads + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(c.kernel, dim3(grid), dim3(kBlock), 0, stream, a);
+    // consecutive launches of `chunk` samples each: one for the whole batch unless the partition is small
+    // (launches_for: equal parts), or — A/B library, GVK_TUNE_GENERATION — launches of one generation of the reference's warps
+    int chunk = batch_size / c.launches;
+    if (g_generation > 0) chunk = g_generation;
+    for (int first = 0; first < batch_size; first += chunk) {
+        a.first_sample = first;
+        a.batch_size = first + chunk < batch_size ? first + chunk : batch_size;
+        const unsigned grid = (unsigned)(((int64_t)(a.batch_size - first) * c.lanes + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(c.kernel, dim3(grid), dim3(kBlock), 0, stream, a);
+    }
     return check_launch("gvk_train");
 }
 
@@ -1449,7 +1504,7 @@ int gvk_describe_train(int dim, int optimizer_type, int num_negative, int explic
         return fail(GVK_EINVAL, "gvk_describe_train: unknown optimizer type or no buffer");
     static const char *const kOptimizers[] = {"SGD", "Momentum", "AdaGrad", "RMSprop", "Adam"};
     const Choice c = choose_train(dim, optimizer_type, num_negative, explicit_negatives != 0, batch_size, n_vertex);
-    if (c.reference_shape)
+    if (c.reference_shape)  // A/B library only
         snprintf(name, capacity, "train_kernel_reference_shape<%d> grid 8192x512", dim);
     else if (!c.kernel)
         return fail(GVK_EINVAL, "gvk_describe_train: no kernel for this (dim, lanes, optimizer)");
@@ -1457,22 +1512,42 @@ int gvk_describe_train(int dim, int optimizer_type, int num_negative, int explic
         snprintf(name, capacity, "train_segment_kernel<%d,%d,SGD,k=1> %d pairs per wavefront", dim, c.lanes,
                  64 / c.lanes * c.steps);
     else
-        snprintf(name, capacity, "%s<%d,%d,%s%s> run_cap %d%s", c.runs ? "train_runs_kernel" : "train_kernel", dim, c.lanes,
-                 kOptimizers[optimizer_type], c.fixed_k ? ",k=1" : "", c.run_cap,
+    {
+        char split[48] = "";
+        if (c.launches > 1) snprintf(split, sizeof(split), " in %d launches per batch", c.launches);
+        snprintf(name, capacity, "%s<%d,%d,%s%s> run_cap %d%s%s", c.runs ? "train_runs_kernel" : "train_kernel", dim, c.lanes,
+                 kOptimizers[optimizer_type], c.fixed_k ? ",k=1" : "", c.run_cap, split,
                  g_generation > 0 ? " in launches of one generation" : "");
+    }
     return GVK_OK;
 }
 
 int gvk_set_tuning(int key, int value) {
+    if (key == GVK_TUNE_VARIANT) {
+#if defined(GVK_AB_BUILDS)
+        if (value < 0 || value > 4) return fail(GVK_EINVAL, "gvk_set_tuning: variant must be 0 ... 4");
+#else
+        if (value != 0 && value != 2 && value != 4)
+            return fail(GVK_EINVAL, "gvk_set_tuning: variant must be 0, 2 or 4 (1 and 3 exist in the A/B library only: make ab)");
+#endif
+        g_variant = value;
+        return GVK_OK;
+    }
+    if (key == GVK_TUNE_RUN_CAP) {
+        if (value < 0 || value > kMaxRunCap) return fail(GVK_EINVAL, "gvk_set_tuning: run cap must be in [0, 64]");
+        g_run_cap = value;
+        return GVK_OK;
+    }
+    if (key == GVK_TUNE_SPLIT_HITS) {
+        if (value < 0) return fail(GVK_EINVAL, "gvk_set_tuning: samples per row and launch must be >= 0");
+        g_split_hits = value;
+        return GVK_OK;
+    }
+#if defined(GVK_AB_BUILDS)
     if (key == GVK_TUNE_LANES_PER_PAIR) {
         if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64)
             return fail(GVK_EINVAL, "gvk_set_tuning: lanes per pair must be 0, 8, 16, 32 or 64");
         g_lanes_per_pair = value;
-        return GVK_OK;
-    }
-    if (key == GVK_TUNE_VARIANT) {
-        if (value < 0 || value > 4) return fail(GVK_EINVAL, "gvk_set_tuning: variant must be 0 ... 4");
-        g_variant = value;
         return GVK_OK;
     }
     if (key == GVK_TUNE_SEGMENT_STEPS) {
@@ -1491,12 +1566,24 @@ int gvk_set_tuning(int key, int value) {
         g_generation = value;
         return GVK_OK;
     }
-    if (key == GVK_TUNE_RUN_CAP) {
-        if (value < 0 || value > kMaxRunCap) return fail(GVK_EINVAL, "gvk_set_tuning: run cap must be in [0, 64]");
-        g_run_cap = value;
-        return GVK_OK;
+#else
+    if (key == GVK_TUNE_LANES_PER_PAIR || key == GVK_TUNE_SEGMENT_STEPS || key == GVK_TUNE_SKIP_LOSS ||
+        key == GVK_TUNE_GENERATION) {
+        if (value == (key == GVK_TUNE_SKIP_LOSS ? 1 : 0)) return GVK_OK;  // the default is all the product library has
+        return fail(GVK_EINVAL, "gvk_set_tuning: this knob exists in the A/B library only (make -C graphvite_amd/csrc ab)");
     }
+#endif
     return fail(GVK_EINVAL, "gvk_set_tuning: unknown key");
+}
+
+int gvk_train_launches(int batch_size, uint32_t n_vertex) { return launches_for(batch_size, n_vertex); }
+
+int gvk_has_ab_builds(void) {
+#if defined(GVK_AB_BUILDS)
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 }  // extern "C"

@@ -621,7 +621,9 @@ int gvx_solver::prepare_devices() {
     for (Worker &w : workers) {
         HIP_TRY(hipSetDevice(w.device));
         const int row_bits = std::max(32 - __builtin_clz(std::max(part_rows, 2u) - 1), 1);
-        GVK_TRY(gvk_group_pairs(nullptr, nullptr, nullptr, nullptr, &w.group_workspace_bytes, batch_size, episode_size, row_bits));
+        const int parts = gvk_train_launches(batch_size, part_rows);
+        GVK_TRY(gvk_group_pairs(nullptr, nullptr, nullptr, nullptr, &w.group_workspace_bytes, batch_size / parts,
+                                episode_size * parts, row_bits));
         HIP_TRY(hipMalloc(&w.group_workspace, std::max<size_t>(w.group_workspace_bytes, 16)));
     }
     return device_sampling ? prepare_device_sampling() : GVK_OK;
@@ -1044,6 +1046,7 @@ int gvx_solver::episode_loop() {
     const size_t table_bytes = (size_t)part_rows * dim * 4;
     const bool grouped = dim >= 64 && (table_bytes < ((size_t)16 << 20) || (table_bytes < ((size_t)256 << 20) && mode == GVS_MODE_EDGE));
     const int row_bits = std::max(32 - __builtin_clz(std::max(part_rows, 2u) - 1), 1);
+    const int parts = gvk_train_launches(batch_size, part_rows);
     const uint64_t per_episode = (uint64_t)num_step * episode_size * config.positive_reuse * W;
     auto produce = [&](int set) { return device_sampling ? device_fill(set) : fill(sets[set]); };
     int rc = produce(0);
@@ -1087,9 +1090,9 @@ int gvx_solver::episode_loop() {
                 w.copied.push_back(copied);
             }
             Range regroup("Regroup");
-            if (grouped)
-                GVK_TRY(gvk_group_pairs(w.copy, source, w.pool[b], w.group_workspace, &w.group_workspace_bytes, batch_size,
-                                        episode_size, row_bits));
+            if (grouped)  // per part of a batch: a part is what one launch trains (gvk_train_launches)
+                GVK_TRY(gvk_group_pairs(w.copy, source, w.pool[b], w.group_workspace, &w.group_workspace_bytes,
+                                        batch_size / parts, episode_size * parts, row_bits));
             HIP_TRY(hipEventRecord(w.uploaded[b], w.copy));
             return GVK_OK;
         };

@@ -353,6 +353,20 @@ class HipKernels(object):
         """Any GVK_TUNE_* knob of include/gvk.h by number (experiments)."""
         _lib.check(self.lib.gvk_set_tuning(int(key), int(value)), "gvk_set_tuning")
 
+    def train_launches(self, batch_size, num_row):
+        """Q: a batch on a head table of num_row rows is trained as Q launches of batch_size / Q samples (gvk_train_launches);
+        pools are regrouped per part."""
+        return int(self.lib.gvk_train_launches(int(batch_size), int(num_row)))
+
+    def set_split_hits(self, hits):
+        """GVK_TUNE_SPLIT_HITS: samples per table row one launch may hold (default 4; 0 = one launch per batch)."""
+        _lib.check(self.lib.gvk_set_tuning(_lib.TUNE_SPLIT_HITS, hits), "gvk_set_tuning")
+
+    @property
+    def has_ab_builds(self):
+        """True when the loaded library is the A/B library (GVK_LIBRARY=.../libgvk_ab.so)."""
+        return bool(self.lib.gvk_has_ab_builds())
+
     def set_generation(self, samples):
         """Parity experiment: train every batch as consecutive launches of at most `samples` samples (0 = off)."""
         _lib.check(self.lib.gvk_set_tuning(_lib.TUNE_GENERATION, samples), "gvk_set_tuning")

@@ -1021,8 +1021,12 @@ class GraphSolver(object):
             return
         if num_batches is None:
             num_batches = pool.numel() // 2 // self.batch_size
+        # a batch on a small partition is trained as Q launches of batch_size / Q samples (gvk_train_launches, DESIGN.md
+        # §7.8): what is made of runs is what runs concurrently, i.e. a part
+        launches = getattr(self.kernels, "train_launches", None)
+        parts = launches(self.batch_size, self._part_size) if launches else 1
         with profiler_range("Regroup"):
-            self.kernels.group_pairs(pool, out, self.batch_size, num_batches, self._part_size)
+            self.kernels.group_pairs(pool, out, self.batch_size // parts, num_batches * parts, self._part_size)
 
     def _tables(self, state, hp, tp):
         ti = self._my_tails.index(tp)

@@ -256,28 +256,42 @@ int gvk_alias_build(const float *weights, size_t n, float *prob, void *alias, in
 int gvk_probe_row_traffic(void *stream, int dim, float *vertex, float *context, const uint32_t *pairs,
                           const uint32_t *negatives, float bump, int batch_size);
 
-/* Tuning knobs for A/B measurement (bench.py --variant); they never change results beyond
- * floating-point summation order.  Returns GVK_EINVAL for an unknown key or unsupported value. */
-#define GVK_TUNE_LANES_PER_PAIR 1 /* 0 = per-dim default; else 8, 16, 32 or 64 */
+/* Tuning knobs.  The product library (libgvk.so) has three; the A/B library (make -C graphvite_amd/csrc ab ->
+ * build/ab/libgvk_ab.so, compiled with -DGVK_AB_BUILDS; bench.py / tests load it through GVK_LIBRARY) adds the measured
+ * alternatives that do not ship.  Returns GVK_EINVAL for an unknown key, an unsupported value, or an A/B-only knob set
+ * to anything but its default in the product library. */
 #define GVK_TUNE_VARIANT 2        /* 0 = default: the per-pair kernel; on a head table smaller than 16 MiB train_runs_kernel
                                      (one lane group trains a run of adjacent same-head samples in sequence);
-                                     1 = the per-pair kernel, generic build (run-time k); 2 = the per-pair kernel with
-                                     compile-time k at any table size; 3 = dim-128 SGD in the reference's kernel shape (one
-                                     wavefront per pair, vertex row in LDS, 8192 x 512 grid-stride launch); 4 =
-                                     train_runs_kernel at any table size.  1 - 4 are A/B baselines */
+                                     2 = the per-pair kernel at any table size; 4 = train_runs_kernel at any table size.
+                                     A/B library only: 1 = the per-pair kernel, generic build (run-time k); 3 = dim-128 SGD
+                                     in the reference's kernel shape (one wavefront per pair, vertex row in LDS, 8192 x 512
+                                     grid-stride launch) */
 #define GVK_TUNE_RUN_CAP 3        /* train_runs_kernel: longest run a lane group trains in sequence: 0 = from the batch size
                                      (batch_size / 5120 rounded up: the generations of the reference's launch on the card it
                                      was written for), 1 = every pair on its own, up to 64 */
+#define GVK_TUNE_SPLIT_HITS 7     /* a batch is trained as gvk_train_launches() equal parts, one launch each, so that a launch
+                                     holds at most `value` samples per row of the head table: default 2 (what keeps small
+                                     partitions at the reference's learning quality); 0 = always one launch
+                                     per batch */
+/* A/B library only: */
+#define GVK_TUNE_LANES_PER_PAIR 1 /* 0 = per-dim default; else 8, 16, 32 or 64 */
 #define GVK_TUNE_GENERATION 4     /* parity experiment: C > 0 trains a batch as consecutive launches of at most C samples
                                      (per-pair kernel), the concurrency structure of the reference's launch on a card
-                                     that keeps C warps resident; 0 = one launch per batch (default) */
-#define GVK_TUNE_SEGMENT_STEPS 5  /* A/B: 1, 2 or 4 = SGD with one negative runs train_segment_kernel (a wavefront owns 64 /
+                                     that keeps C warps resident; 0 = off (default) */
+#define GVK_TUNE_SEGMENT_STEPS 5  /* 1, 2 or 4 = SGD with one negative runs train_segment_kernel (a wavefront owns 64 /
                                      lanes * steps consecutive pairs and chains the same-head runs inside it through
                                      registers, all rows requested up front); 0 = off (default) */
 #define GVK_TUNE_SKIP_LOSS 6      /* train_segment_kernel only: 1 (default) = gvk_train_episode uses its loss-less build for
-                                     batches whose loss[] a later batch of the same call overwrites (nothing could read it);
-                                     0 = every batch computes it.  Measured gain: under 1 % */
+                                     batches whose loss[] a later batch of the same call overwrites; 0 = every batch
+                                     computes it */
 int gvk_set_tuning(int key, int value);
+/* Q: gvk_train / gvk_train_episode train a batch of batch_size samples on a head table of n_vertex rows as Q consecutive
+ * launches of batch_size / Q samples (Q divides batch_size; 1 unless the table has fewer than batch_size / 2 rows; see
+ * GVK_TUNE_SPLIT_HITS).  A solver that regroups its pools (gvk_group_pairs) regroups them per part: batch_size / Q samples,
+ * Q x the batches — a part is what runs concurrently, so a part is what is made of runs. */
+int gvk_train_launches(int batch_size, uint32_t n_vertex);
+/* 1 when this library was built with -DGVK_AB_BUILDS (the A/B baselines exist), 0 for the product library. */
+int gvk_has_ab_builds(void);
 
 /* The kernel gvk_train / gvk_train_episode launch for this configuration under the current tuning, as text
  * ("train_kernel<128,16,SGD,k=1> run_cap 1", "train_runs_kernel<128,16,SGD,k=1> run_cap 20") — what a benchmark should label

@@ -37,6 +37,8 @@ def main():
     tune.set_run_cap(int(extra.get("run_cap", 0)))
     tune.set_generation(int(extra.get("generation", 0)))
     tune.set_segment_steps(int(extra.get("steps", 0)))
+    if "split" in extra:
+        tune.set_split_hits(int(extra["split"]))
     tag = " ".join("%s=%s" % kv for kv in sorted(extra.items()))
     for order in orders:
         aucs = []

@@ -1,0 +1,58 @@
+"""Generates tests/golden/reference_c2.npz: link-prediction AUC of the REFERENCE's own training loop (GraphSolver::train
+as written, compiled for the host: oracle/ref_solver_harness.cpp, sequential kernel model) on the HEADLINE shape itself —
+BASELINE configs[1], the graph bench.py trains: synthetic power-law, 1M nodes / 10M edges (synthetic.power_law_edges,
+seed 1024), LINE, dim 128, batch 100 000, one partition, auto episode size, SGD 0.025 / 0.005 linear — for EPOCHS = 50
+epochs (5 000 batches).  ~15 minutes of host time per seed.
+
+    python tests/golden/make_c2_golden.py          # resumable
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [ROOT, os.path.dirname(HERE)]
+from graphvite_amd import synthetic  # noqa: E402  (graph generator only; nothing of the product trains here)
+from oracle_lib import Oracle, ReferenceSolver, link_prediction_auc, reference_train  # noqa: E402
+
+PATH = os.path.join(HERE, "reference_c2.npz")
+N, E, GRAPH_SEED, BATCH = 1000000, 10000000, 1024, 100000
+EPOCHS = int(os.environ.get("EPOCHS", "50"))
+SEEDS = (17, 18, 19)
+
+
+def main():
+    oracle = Oracle()
+    edges = synthetic.power_law_edges(N, E, seed=GRAPH_SEED)
+    train, (valid, test) = synthetic.link_prediction_split(edges, (100, 1, 1))
+    for i, seed in enumerate(SEEDS):
+        out = dict(np.load(PATH)) if os.path.exists(PATH) else {}
+        values = out.get("c2_line_sequential", np.full(len(SEEDS), np.nan))
+        if not np.isnan(values[i]):
+            continue
+        t0 = time.time()
+        rs = ReferenceSolver(oracle, seed, train.astype(np.uint32), None, True, 1, 4, 1, 1, BATCH, 0)  # episode auto
+        vertex, context, batch_id = reference_train(rs, "LINE", EPOCHS, augmentation_step=1)
+        labels = rs.partition()[0]
+        name2id = np.full(int(labels.max()) + 1, -1, np.int64)
+        name2id[labels] = np.arange(len(labels))
+        H, T, Y = (np.asarray(x) for x in test)
+        ok = (H <= labels.max()) & (T <= labels.max())
+        H, T, Y = H[ok], T[ok], Y[ok]
+        ok = (name2id[H] >= 0) & (name2id[T] >= 0)
+        values[i] = link_prediction_auc(vertex, context, name2id[H[ok]], name2id[T[ok]], Y[ok])
+        print("C2 LINE seed %d: episode %d, %d batches, AUC %.6f, %.0f s" % (seed, rs.episode_size, batch_id, values[i],
+                                                                            time.time() - t0), flush=True)
+        out = dict(np.load(PATH)) if os.path.exists(PATH) else {}
+        out["c2_line_sequential"] = values
+        out["c2_args"] = np.array([N, E, GRAPH_SEED, BATCH, rs.episode_size, EPOCHS], np.int64)
+        out["seeds"] = np.array(SEEDS, np.int64)
+        np.savez_compressed(PATH + ".tmp.npz", **out)
+        os.replace(PATH + ".tmp.npz", PATH)
+
+
+if __name__ == "__main__":
+    main()

@@ -165,26 +165,44 @@ def test_kernel_choice_by_table_size():
         _lib.check(lib.gvk_describe_train(dim, optimizer, k, int(explicit), batch, rows, name, len(name)), "describe")
         return name.value.decode()
 
-    assert describe(128, _lib.SGD, 1, 10312) == "train_runs_kernel<128,16,SGD,k=1> run_cap 20"     # BlogCatalog-sized: 5 MB
+    assert describe(128, _lib.SGD, 1, 10312) == "train_runs_kernel<128,16,SGD,k=1> run_cap 20 in 5 launches per batch"  # BlogCatalog-sized: 5 MB
     assert describe(128, _lib.SGD, 1, 10312, batch=5000) == "train_runs_kernel<128,16,SGD,k=1> run_cap 1"  # one generation
     assert describe(128, _lib.SGD, 1, 32767) .startswith("train_runs_kernel") and \
-        describe(128, _lib.SGD, 1, 32768) == "train_kernel<128,16,SGD,k=1> run_cap 1"              # 16 MiB is the border
+        describe(128, _lib.SGD, 1, 32768) == "train_kernel<128,16,SGD,k=1> run_cap 1 in 2 launches per batch"  # 16 MiB is the border
     assert describe(128, _lib.SGD, 1, 1000000) == "train_kernel<128,16,SGD,k=1> run_cap 1"          # configs[1]
     assert describe(96, _lib.SGD, 1, 8200000) == "train_kernel<96,8,SGD,k=1> run_cap 1"             # a Friendster shard
-    assert describe(128, _lib.ADAM, 5, 10312) == "train_runs_kernel<128,16,Adam> run_cap 20"
+    assert describe(128, _lib.ADAM, 5, 10312) == "train_runs_kernel<128,16,Adam> run_cap 20 in 5 launches per batch"
     assert describe(128, _lib.ADAM, 5, 1000000) == "train_kernel<128,16,Adam> run_cap 1"
     assert describe(32, _lib.SGD, 1, 100000).startswith("train_runs_kernel<32,8,SGD,k=1>")         # 12.8 MB at dim 32
+    # a partition with fewer than batch / 2 rows: the batch is cut into equal parts of at most 2 samples per row, one
+    # launch each (the number of parts divides the batch size)
+    assert describe(128, _lib.SGD, 1, 6250) == "train_runs_kernel<128,16,SGD,k=1> run_cap 20 in 8 launches per batch"
+    assert describe(128, _lib.SGD, 1, 50000) == "train_kernel<128,16,SGD,k=1> run_cap 1"
+    assert describe(128, _lib.SGD, 1, 49999).endswith("in 2 launches per batch")
+    assert lib.gvk_train_launches(100000, 6250) == 8 and lib.gvk_train_launches(100000, 1000000) == 1
+    assert lib.gvk_train_launches(100000, 7000) == 8 and lib.gvk_train_launches(99991, 7000) == 1  # 7.14 -> 8; a prime
     try:
-        _lib.check(lib.gvk_set_tuning(_lib.TUNE_SEGMENT_STEPS, 4))
-        assert describe(128, _lib.SGD, 1, 1000000) == "train_segment_kernel<128,16,SGD,k=1> 16 pairs per wavefront"
-        assert describe(512, _lib.SGD, 1, 1000000).startswith("train_kernel<512")  # no 4-step build at dim 512: falls back
-        _lib.check(lib.gvk_set_tuning(_lib.TUNE_SEGMENT_STEPS, 0))
-        _lib.check(lib.gvk_set_tuning(_lib.TUNE_VARIANT, 3))
-        assert "reference_shape" in describe(128, _lib.SGD, 1, 1000000)
+        _lib.check(lib.gvk_set_tuning(_lib.TUNE_SPLIT_HITS, 0))
+        assert describe(128, _lib.SGD, 1, 6250) == "train_runs_kernel<128,16,SGD,k=1> run_cap 20"
+        _lib.check(lib.gvk_set_tuning(_lib.TUNE_SPLIT_HITS, 2))
         _lib.check(lib.gvk_set_tuning(_lib.TUNE_VARIANT, 2))
-        assert describe(128, _lib.SGD, 1, 10312) == "train_kernel<128,16,SGD,k=1> run_cap 1"
+        assert describe(128, _lib.SGD, 1, 32768) == "train_kernel<128,16,SGD,k=1> run_cap 1 in 2 launches per batch"
+        _lib.check(lib.gvk_set_tuning(_lib.TUNE_VARIANT, 0))
+        if lib.gvk_has_ab_builds():  # GVK_LIBRARY=graphvite_amd/csrc/build/ab/libgvk_ab.so: the measured alternatives
+            _lib.check(lib.gvk_set_tuning(_lib.TUNE_SEGMENT_STEPS, 4))
+            assert describe(128, _lib.SGD, 1, 1000000) == "train_segment_kernel<128,16,SGD,k=1> 16 pairs per wavefront"
+            assert describe(512, _lib.SGD, 1, 1000000).startswith("train_kernel<512")  # no 4-step build at dim 512: falls back
+            _lib.check(lib.gvk_set_tuning(_lib.TUNE_SEGMENT_STEPS, 0))
+            _lib.check(lib.gvk_set_tuning(_lib.TUNE_VARIANT, 3))
+            assert "reference_shape" in describe(128, _lib.SGD, 1, 1000000)
+        else:  # the product library has none of them: the knobs refuse anything but their defaults
+            assert lib.gvk_set_tuning(_lib.TUNE_SEGMENT_STEPS, 4) == _lib.GVK_EINVAL
+            assert lib.gvk_set_tuning(_lib.TUNE_VARIANT, 3) == _lib.GVK_EINVAL
+            assert lib.gvk_set_tuning(_lib.TUNE_GENERATION, 5120) == _lib.GVK_EINVAL
+            assert lib.gvk_set_tuning(_lib.TUNE_SEGMENT_STEPS, 0) == _lib.GVK_OK
     finally:
         lib.gvk_set_tuning(_lib.TUNE_SEGMENT_STEPS, 0)
         lib.gvk_set_tuning(_lib.TUNE_VARIANT, 0)
+        lib.gvk_set_tuning(_lib.TUNE_SPLIT_HITS, 2)
     with pytest.raises(ValueError):
         describe(100, _lib.SGD, 1, 1000)

@@ -90,6 +90,8 @@ def test_moment_optimizers_match_oracle(hip, oracle, name, dim):
 
 @pytest.mark.parametrize("lanes", [8, 16, 32, 64])
 def test_lane_group_variants_agree(hip, oracle, lanes):
+    if not hip.has_ab_builds:
+        pytest.skip("non-default lane groups exist in the A/B library only (GVK_LIBRARY=.../libgvk_ab.so)")
     rng = np.random.default_rng(lanes)
     N, B, k, dim = 4096, 1000, 1, 128
     v, c = init_tables(rng, N, N, dim)
@@ -110,6 +112,8 @@ def test_lane_group_variants_agree(hip, oracle, lanes):
 
 def test_reference_shape_variant_is_also_correct(hip, oracle):
     """The A/B baseline kernel (the reference's launch shape on wave64) computes the same thing."""
+    if not hip.has_ab_builds:
+        pytest.skip("the reference-shape kernel exists in the A/B library only (GVK_LIBRARY=.../libgvk_ab.so)")
     rng = np.random.default_rng(41)
     N, B, k, dim = 4096, 1500, 1, 128
     v, c = init_tables(rng, N, N, dim)
@@ -189,6 +193,8 @@ def test_segment_kernel_trains_runs_in_sequence(hip, oracle, dim, steps, explici
     adjacent pairs that share a head row and lie in one wavefront's segment are one run, trained one after the other on one register copy of the row (the reference's warp does that with
     consecutive iterations of its loop, gpu/graph.cuh:54-94).  With distinct context rows the result equals the
     SEQUENTIAL oracle — no update of the head row is lost — and every sample keeps its own negative and loss slot."""
+    if steps and not hip.has_ab_builds:
+        pytest.skip("train_segment_kernel exists in the A/B library only (GVK_LIBRARY=.../libgvk_ab.so)")
     rng = np.random.default_rng(dim + steps)
     N, B, k = 8192, 1531, 1
     v, c = init_tables(rng, N, N, dim)
@@ -262,6 +268,46 @@ def test_runs_kernel_trains_runs_in_sequence(hip, oracle, dim, k):
     assert (~whole).sum() > 0
 
 
+@pytest.mark.parametrize("variant", [0, 2])
+def test_small_head_table_trains_in_several_launches(hip, oracle, variant):
+    """A head table with fewer than batch / 2 rows: the batch is trained as consecutive launches of at most 2 samples per
+    row (4 here; GVK_TUNE_SPLIT_HITS).  Launch boundaries add ordering and nothing else: with every head row's
+    samples adjacent (runs of 16 = the run cap) and distinct context rows the whole batch equals the SEQUENTIAL oracle,
+    and every sample keeps its own negative and loss slot.  variant 2: the per-pair kernel with every head row once per
+    launch — a row's four samples are trained by four launches, each starting from what the one before wrote."""
+    rng = np.random.default_rng(7 + variant)
+    dim, k = 128, 1
+    n_vertex, n_context = 96, 8192
+    B = 1536 if variant == 0 else 384       # 16 / 4 samples per head row -> 4 launches / 1 launch of 4 per row
+    v, c = init_tables(rng, n_vertex, n_context, dim)
+    v *= 20
+    c *= 20
+    ctx = rng.permutation(n_context)[:2 * B].astype(np.uint32)
+    if variant == 0:
+        heads = np.repeat(np.arange(n_vertex, dtype=np.uint32), B // n_vertex)   # runs of 16, in row order
+        hip.set_run_cap(16)
+        hip.set_split_hits(4)
+    else:   # a row at most once per launch of 96 * 4 / 4 = 96 ... here: 4 launches of 96 samples, each a permutation
+        heads = np.concatenate([rng.permutation(n_vertex) for _ in range(B // n_vertex)]).astype(np.uint32)
+        hip.set_split_hits(1)
+    pairs = np.stack([ctx[:B], heads], 1).astype(np.uint32)
+    negs = np.ascontiguousarray(ctx[B:].reshape(B, 1))
+    ov, oc = v.copy(), c.copy()
+    oloss = oracle.train(ov, oc, pairs, negs, 0.025, 0.005, 5.0)
+    hip.set_variant(variant)
+    try:
+        name = hip.describe_train(dim, "SGD", k, True, B, n_vertex)
+        assert name.endswith("in 4 launches per batch") and ("train_runs_kernel" in name) == (variant == 0), name
+        hv, hc, hloss, _ = run_hip(hip, v, c, pairs, negs, OPTS["SGD"][1], 5.0)
+    finally:
+        hip.set_variant(0)
+        hip.set_split_hits(2)
+        hip.set_run_cap(0)
+    np.testing.assert_allclose(hv, ov, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(hc, oc, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(hloss, oloss, rtol=RTOL, atol=1e-6)
+
+
 @pytest.mark.parametrize("name", ["Momentum", "Adam"])
 def test_runs_with_moment_optimizers(hip, oracle, name):
     opt_id, spec, hp = OPTS[name]
@@ -303,6 +349,8 @@ def test_run_cap_splits_long_runs(hip, oracle):
     pairs, negs = _run_batch(rng, N, B, k, [64])
     row = int(pairs[0, 1])
     for cap, variant in ((4, 4), (16, 4), (1, 4), (1, 2), (8, 0)):
+        if variant == 0 and not hip.has_ab_builds:
+            continue  # the segment kernel: A/B library only
         candidates = []
         for start in range(0, B, max(cap, 1)):
             ov, oc = v.copy(), c.copy()

@@ -161,6 +161,42 @@ def test_hub_heavy_shapes_match_the_reference_training_loop(shape):
     assert default.mean() >= floor
 
 
+PARTITIONS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_partitions.npz")
+
+
+@pytest.mark.parametrize("device_sampling", [False, True])
+@pytest.mark.parametrize("partitions", [4, 8, 16])
+def test_partitioned_training_matches_the_reference_training_loop(partitions, device_sampling):
+    """Learning quality once the tables are cut into the P = 4 / 8 / 16 partitions every multi-GPU configuration lives in,
+    against the reference's OWN training loop at the same P (tests/golden/make_partition_golden.py: GraphSolver::train as
+    written, sequential kernel model, "hub100k", batch 100 000, episode ~35 / P): the reference stays at 0.902 - 0.903 at
+    every P.  With 6 250-row partitions a 100 000-sample batch holds 16 samples per head row and 32 per context row; the
+    product trains such a batch as consecutive launches of at most 4 samples per row (gvk.h GVK_TUNE_SPLIT_HITS) — one
+    launch per batch loses most concurrent updates there (AUC 0.880 at P = 16).  Means over the golden's
+    three seeds, +-0.002; CPU samplers and positives drawn on the device."""
+    G = np.load(PARTITIONS)
+    n, e, communities, graph_seed, batch, epochs, aug = [int(x) for x in G["hub100k_args"]]
+    gamma, p_in = [float(x) for x in G["hub100k_gamma_p_in"]]
+    reference = G["hub100k_w1_p%d" % partitions]
+    episode = int(G["hub100k_w1_p%d_episode" % partitions])
+    edges = synthetic.hub_community_edges(n, e, gamma=gamma, num_community=communities, p_in=p_in, seed=graph_seed)
+    train, (valid, test) = synthetic.link_prediction_split(edges, (100, 1, 1))
+    gv.init_logging(logging.ERROR)
+    g = gv.graph.Graph()
+    g.load(train)
+    aucs = []
+    for seed in (17, 18, 19):
+        s = gv.solver.GraphSolver(128, num_sampler_per_worker=8, seed=seed, device_sampling=device_sampling)
+        s.build(g, batch_size=batch, episode_size=episode, num_partition=partitions)
+        s.train(model="LINE", num_epoch=epochs, augmentation_step=aug, log_frequency=1 << 30)
+        aucs.append(auc_of(g, s, test))
+    name = s.kernels.describe_train(128, "SGD", 1, False, batch, s._part_size)
+    print("hub100k, %d partitions (device_sampling=%s, %s): AUC here %s (mean %.6f) | reference training loop %s (mean %.6f)"
+          % (partitions, device_sampling, name, " ".join("%.6f" % a for a in aucs), np.mean(aucs),
+             " ".join("%.6f" % a for a in reference), reference.mean()))
+    assert abs(np.mean(aucs) - reference.mean()) <= 0.002
+
+
 def test_quick_start_pipeline():
     """BASELINE configs[0] end to end through GraphApplication — load, build, train, evaluate, predict — with
     config/demo/quick_start.yaml's hyper-parameters on the BlogCatalog-sized stand-in of the parity test above."""
