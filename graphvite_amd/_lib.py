@@ -32,7 +32,7 @@ class Optimizer(C.Structure):
 class Tables(C.Structure):
     _fields_ = [("vertex", C.c_void_p), ("context", C.c_void_p), ("vertex_moment1", C.c_void_p),
                 ("context_moment1", C.c_void_p), ("vertex_moment2", C.c_void_p), ("context_moment2", C.c_void_p),
-                ("n_vertex", C.c_uint32), ("n_context", C.c_uint32)]
+                ("n_vertex", C.c_uint32), ("n_context", C.c_uint32), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class NegativeSource(C.Structure):
@@ -54,6 +54,45 @@ class WalkGraph(C.Structure):
                 ("neighbor_table", C.c_void_p), ("sorted_neighbors", C.c_void_p), ("local", C.c_void_p),
                 ("num_vertex", C.c_uint32), ("num_edge_entries", C.c_uint32), ("biased", C.c_int32),
                 ("p", C.c_float), ("q", C.c_float)]
+
+
+# ---- include/gvx.h ---------------------------------------------------------------------------------------------------
+GVX_AUTO = 0
+GVX_DEVICE_SAMPLING, GVX_PAIR_ORDER, GVX_SEED, GVX_NEGATIVE_TABLE, GVX_NODE2VEC_TABLE_LIMIT = 1, 2, 3, 4, 5
+GVX_UNIQUE_ID_BYTES = 256
+SCHEDULE_FUNCTION = C.CFUNCTYPE(C.c_float, C.c_int, C.c_int, C.c_void_p)
+TRANSPORT_ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+TRANSPORT_ALL_TO_ALL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class SolverOptimizer(C.Structure):  # gvx_optimizer
+    _fields_ = [("type", C.c_int32), ("lr", C.c_float), ("weight_decay", C.c_float), ("hp0", C.c_float),
+                ("hp1", C.c_float), ("epsilon", C.c_float), ("schedule", C.c_int32),
+                ("schedule_function", SCHEDULE_FUNCTION), ("user", C.c_void_p)]
+
+
+class TrainConfig(C.Structure):  # gvx_train_config
+    _fields_ = [("model", C.c_char_p), ("num_epoch", C.c_int), ("resume", C.c_int), ("augmentation_step", C.c_int),
+                ("random_walk_length", C.c_int), ("random_walk_batch_size", C.c_int), ("shuffle_base", C.c_int),
+                ("p", C.c_float), ("q", C.c_float), ("positive_reuse", C.c_int), ("negative_sample_exponent", C.c_float),
+                ("negative_weight", C.c_float), ("log_frequency", C.c_int)]
+
+
+class SolverMembers(C.Structure):  # gvx_solver_members
+    _fields_ = [("dim", C.c_int), ("num_partition", C.c_int), ("num_negative", C.c_int), ("num_epoch", C.c_int),
+                ("resume", C.c_int), ("episode_size", C.c_int), ("batch_size", C.c_int), ("augmentation_step", C.c_int),
+                ("random_walk_length", C.c_int), ("random_walk_batch_size", C.c_int), ("shuffle_base", C.c_int),
+                ("positive_reuse", C.c_int), ("log_frequency", C.c_int), ("num_worker", C.c_int), ("num_sampler", C.c_int),
+                ("negative_sample_exponent", C.c_float), ("negative_weight", C.c_float), ("p", C.c_float), ("q", C.c_float),
+                ("gpu_memory_limit", C.c_size_t), ("gpu_memory_cost", C.c_size_t), ("model", C.c_char_p),
+                ("optimizer", SolverOptimizer), ("batch_id", C.c_uint64), ("num_batch", C.c_uint64),
+                ("train_seconds", C.c_double), ("rank", C.c_int), ("num_local_worker", C.c_int), ("pair_order", C.c_int),
+                ("sampler_mode", C.c_int), ("device_sampling", C.c_int), ("partition_rows", C.c_uint32),
+                ("transport", C.c_char_p)]
+
+
+class Transport(C.Structure):  # gvx_transport
+    _fields_ = [("all_gather", TRANSPORT_ALL_GATHER), ("all_to_all", TRANSPORT_ALL_TO_ALL), ("user", C.c_void_p)]
 
 
 class NativeLibraryError(RuntimeError):
@@ -186,6 +225,61 @@ def lib():
     l.gvs_sampler_column.argtypes = [vp, i32, P(u64), P(vp), P(vp), P(vp)]
     l.gvs_host_uniforms.restype = None
     l.gvs_host_uniforms.argtypes = [u64, u32, u64, sz, vp]
+    # the solver engine (include/gvx.h)
+    l.gvx_solver_create.restype = vp
+    l.gvx_solver_create.argtypes = [i32, P(i32), i32, i32, sz]
+    l.gvx_solver_create_distributed.restype = vp
+    l.gvx_solver_create_distributed.argtypes = [i32, i32, i32, i32, vp, sz, P(Transport), i32, sz]
+    l.gvx_unique_id.restype = i32
+    l.gvx_unique_id.argtypes = [vp, sz]
+    l.gvx_solver_destroy.restype = None
+    l.gvx_solver_destroy.argtypes = [vp]
+    l.gvx_solver_set.restype = i32
+    l.gvx_solver_set.argtypes = [vp, i32, C.c_int64]
+    l.gvx_solver_build.restype = i32
+    l.gvx_solver_build.argtypes = [vp, vp, P(SolverOptimizer), i32, i32, i32, i32]
+    l.gvx_solver_train.restype = i32
+    l.gvx_solver_train.argtypes = [vp, P(TrainConfig)]
+    l.gvx_solver_predict.restype = i32
+    l.gvx_solver_predict.argtypes = [vp, vp, sz, vp]
+    l.gvx_solver_clear.restype = i32
+    l.gvx_solver_clear.argtypes = [vp]
+    l.gvx_solver_embeddings.restype = vp
+    l.gvx_solver_embeddings.argtypes = [vp, i32, P(u64)]
+    l.gvx_solver_get.restype = i32
+    l.gvx_solver_get.argtypes = [vp, P(SolverMembers)]
+    l.gvx_solver_info.restype = sz
+    l.gvx_solver_info.argtypes = [vp, C.c_char_p, sz]
+    l.gvx_solver_save_embeddings.restype = i32
+    l.gvx_solver_save_embeddings.argtypes = [vp, C.c_char_p]
+    l.gvx_rccl_selftest.restype = i32
+    l.gvx_rccl_selftest.argtypes = [i32]
+    l.gvx_session_open.restype = i32
+    l.gvx_session_open.argtypes = [vp, P(TrainConfig), i32]
+    l.gvx_session_steps.restype = i32
+    l.gvx_session_steps.argtypes = [vp]
+    l.gvx_session_block.restype = i32
+    l.gvx_session_block.argtypes = [vp, i32, i32, P(i32), P(i32)]
+    l.gvx_session_fill.restype = i32
+    l.gvx_session_fill.argtypes = [vp, i32]
+    l.gvx_session_stage.restype = i32
+    l.gvx_session_stage.argtypes = [vp, i32, i32, i32]
+    l.gvx_session_train.restype = i32
+    l.gvx_session_train.argtypes = [vp, i32, i32, i32, i32, i32]
+    l.gvx_session_exchange.restype = i32
+    l.gvx_session_exchange.argtypes = [vp, i32]
+    for name in ("wait", "synchronize", "close"):
+        fn = getattr(l, "gvx_session_" + name)
+        fn.restype = i32
+        fn.argtypes = [vp]
+    l.gvx_session_stream.restype = vp
+    l.gvx_session_stream.argtypes = [vp, i32]
+    l.gvx_session_loss.restype = i32
+    l.gvx_session_loss.argtypes = [vp, i32, P(f32)]
+    l.gvx_session_probe.restype = i32
+    l.gvx_session_probe.argtypes = [vp, i32, i32, i32, i32, P(f32)]
+    l.gvx_session_exchange_stats.restype = i32
+    l.gvx_session_exchange_stats.argtypes = [vp, P(u64), P(u64)]
     _lib = l
     return l
 

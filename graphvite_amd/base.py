@@ -80,6 +80,32 @@ def init_logging(level=logging.INFO, dir="", verbose=False):
         fh = logging.FileHandler(os.path.join(dir, "graphvite_amd.log"))
         fh.setFormatter(logging.Formatter(fmt))
         logger.addHandler(fh)
+    _native_logging(level)
+
+
+_native_sink = None
+
+
+def _native_logging(level):
+    """The native runtime (include/gvx.h gvx_set_logging; glog in the reference, src/graphvite.cu:81-88) logs through this
+    package's logger: messages below `level` are dropped at the source."""
+    global _native_sink
+    import ctypes as C
+    from . import _lib
+    try:
+        lib = _lib.lib()
+    except _lib.NativeLibraryError:
+        return
+    levels = {0: logging.INFO, 1: logging.WARNING, 2: logging.ERROR, 3: logging.CRITICAL}
+
+    def sink(severity, message, user):
+        logger.log(levels.get(severity, logging.INFO), (message or b"").decode("utf-8", "replace"))
+    sink_type = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_void_p)
+    _native_sink = sink_type(sink)
+    lib.gvx_set_logging.restype = None
+    lib.gvx_set_logging.argtypes = [C.c_int, sink_type, C.c_void_p]
+    threshold = 0 if level <= logging.INFO else (1 if level <= logging.WARNING else (2 if level <= logging.ERROR else 3))
+    lib.gvx_set_logging(threshold, _native_sink, None)
 
 
 def cpu_budget():

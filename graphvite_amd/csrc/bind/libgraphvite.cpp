@@ -204,10 +204,11 @@ public:
     py::object graph_keepalive;
 
     GraphSolverBase(int dim, const std::vector<int> &device_ids, int num_sampler_per_worker, size_t gpu_memory_limit,
-                    bool device_sampling) {
+                    bool device_sampling, int64_t seed) {
         handle = gvx_solver_create(dim, device_ids.data(), (int)device_ids.size(), num_sampler_per_worker, gpu_memory_limit);
         if (!handle) raise(GVK_EINVAL, "GraphSolver");
         check(gvx_solver_set(handle, GVX_DEVICE_SAMPLING, device_sampling), "GraphSolver");
+        check(gvx_solver_set(handle, GVX_SEED, seed), "GraphSolver");
     }
     ~GraphSolverBase() { gvx_solver_destroy(handle); }
     GraphSolverBase(const GraphSolverBase &) = delete;
@@ -282,8 +283,9 @@ public:
 template <int dim>
 class GraphSolver : public GraphSolverBase {
 public:
-    GraphSolver(const std::vector<int> &device_ids, int num_sampler_per_worker, size_t gpu_memory_limit, bool device_sampling)
-        : GraphSolverBase(dim, device_ids, num_sampler_per_worker, gpu_memory_limit, device_sampling) {}
+    GraphSolver(const std::vector<int> &device_ids, int num_sampler_per_worker, size_t gpu_memory_limit, bool device_sampling,
+                int64_t seed)
+        : GraphSolverBase(dim, device_ids, num_sampler_per_worker, gpu_memory_limit, device_sampling, seed) {}
 };
 
 template <class T, class... Extra>
@@ -311,10 +313,12 @@ void bind_solver(py::module &solver) {
         "            num_sampler_per_worker (int, optional): number of sampler thread per GPU\n"
         "            gpu_memory_limit (int, optional): memory limit for each GPU in bytes\n"
         "            device_sampling (bool, optional): beyond the reference — draw the positive samples on the GPUs\n"
-        "                instead of the CPU sampler threads\n        ");
-    cls.def(py::init<std::vector<int>, int, size_t, bool>(), no_gil(), py::arg("device_ids") = std::vector<int>(),
+        "                instead of the CPU sampler threads\n"
+        "            seed (int, optional): beyond the reference — seeds the initial embeddings, the samplers and the\n"
+        "                negative draws (the reference seeds them from one process-wide generator)\n        ");
+    cls.def(py::init<std::vector<int>, int, size_t, bool, int64_t>(), no_gil(), py::arg("device_ids") = std::vector<int>(),
             py::arg("num_sampler_per_worker") = kAuto, py::arg("gpu_memory_limit") = kAuto,
-            py::arg("device_sampling") = false);
+            py::arg("device_sampling") = false, py::arg("seed") = 0);
 }
 
 }  // namespace

@@ -39,7 +39,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 int g_variant = 0;         // GVK_TUNE_VARIANT
-int g_run_cap = 0;         // GVK_TUNE_RUN_CAP (0 = from the batch size, run_cap_for)
+int g_run_cap = 0;         // GVK_TUNE_RUN_CAP (0 = the default of 20, run_cap_for)
 int g_split_hits = 2;      // GVK_TUNE_SPLIT_HITS (samples per table row one launch may hold; 0 = never split a batch)
 #if defined(GVK_AB_BUILDS)  // knobs of the A/B library only (make ab -> build/ab/libgvk_ab.so)
 int g_lanes_per_pair = 0;  // GVK_TUNE_LANES_PER_PAIR
@@ -408,9 +408,9 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_kernel(const TrainArgs a)
 // every head row of a batch is one or more runs: the row crosses HBM once per run instead of once per pair, and of
 // the m pairs of a batch that share a hub row, min(m, run_cap) consecutive updates survive instead of one (the
 // remaining ceil(m / run_cap) - 1 lane groups train the same row concurrently from the same start; the last store wins, as it
-// does between any two concurrent warps of the reference).  run_cap = batch_size / 5120, rounded up, is how many
-// times the reference's <<<8192, 512>>> launch refills a V100 (5120 resident warps) within one batch, i.e. how many
-// generations of updates to one row that launch can chain.
+// does between any two concurrent warps of the reference).  run_cap = 20 is how many times the reference's
+// <<<8192, 512>>> launch refills a V100 (5120 resident warps) within one default batch, i.e. how many generations of
+// updates to one row that launch can chain (run_cap_for).
 //
 // Pipelining inside a run: the header of pair j + 1 is loaded one pair ahead, its first alias slot as soon as the
 // header says the run continues, and its first target row while the positive target of pair j is computed — the
@@ -1093,16 +1093,17 @@ TrainKernel pick_train(int dim, int g, int opt) {
     return nullptr;
 }
 
-// Longest run one lane group trains in sequence (train_runs_kernel): how many times the reference's launch refills
-// the card it was written for within one batch — 8192 x 512 threads = one warp per sample (util/gpu.cuh:41-43), a
-// V100 holds 80 SMs x 2048 threads = 5120 of those warps at a time.
-constexpr int kReferenceResidentWarps = 5120;
+// Longest run one lane group trains in sequence (train_runs_kernel).  20 = how many times the reference's launch refills
+// the card it was written for within one default batch — 8192 x 512 threads = one warp per sample (util/gpu.cuh:41-43), a
+// V100 holds 80 SMs x 2048 threads = 5120 of those warps at a time, 100 000 / 5120 rounds up to 20 — i.e. how many
+// generations of updates to one row that launch can chain; the same cap at every batch size (round 2 scaled it with the
+// batch: a 500-sample batch then had runs of one, and walk-mode training fell 0.009 short of sequential).
+constexpr int kRunCap = 20;
 constexpr int kMaxRunCap = 64;
 
 int run_cap_for(int batch_size) {
-    if (g_run_cap > 0) return g_run_cap;
-    const int generations = (batch_size + kReferenceResidentWarps - 1) / kReferenceResidentWarps;
-    return generations < 1 ? 1 : (generations > kMaxRunCap ? kMaxRunCap : generations);
+    (void)batch_size;
+    return g_run_cap > 0 ? g_run_cap : kRunCap;
 }
 
 int validate_train(int dim, const gvk_optimizer *o, const gvk_tables *t, const uint32_t *pairs,
@@ -1199,7 +1200,7 @@ int launches_for(int batch_size, uint32_t rows) {
 }
 
 Choice choose_train(int dim, int opt, int k, bool explicit_negatives, int batch_size, uint32_t rows,
-                    bool want_loss = true) {
+                    bool want_loss = true, uint32_t flags = 0) {
     Choice c;
     (void)want_loss;
 #if defined(GVK_AB_BUILDS)
@@ -1235,7 +1236,8 @@ Choice choose_train(int dim, int opt, int k, bool explicit_negatives, int batch_
     }
 #endif
     // runs of same-head samples: cache-resident tables by default (resident_table), any table with GVK_TUNE_VARIANT 4
-    c.runs = g_generation == 0 && (g_variant == 4 || (g_variant == 0 && resident_table(dim, rows)));
+    // (never for the walk-ordered pools of DeepWalk / node2vec: GVK_PAIRS_OF_WALKS, gvk.h)
+    c.runs = g_generation == 0 && (g_variant == 4 || (g_variant == 0 && resident_table(dim, rows) && !(flags & GVK_PAIRS_OF_WALKS)));
     c.run_cap = c.runs ? run_cap_for(batch_size) : 1;
     c.kernel = c.runs ? pick_train<true>(dim, c.lanes, opt) : pick_train<false>(dim, c.lanes, opt);
 #if defined(GVK_AB_BUILDS)
@@ -1267,7 +1269,7 @@ Choice choose_train(int dim, int opt, int k, bool explicit_negatives, int batch_
 int launch_train(hipStream_t stream, int dim, const gvk_optimizer *o, float lr, const gvk_tables *t,
                  const uint32_t *pairs, const gvk_negative_source *neg, uint32_t batch_id, float *loss,
                  int batch_size, int k, float negative_weight, bool want_loss = true) {
-    const Choice c = choose_train(dim, o->type, k, neg->negatives != nullptr, batch_size, t->n_vertex, want_loss);
+    const Choice c = choose_train(dim, o->type, k, neg->negatives != nullptr, batch_size, t->n_vertex, want_loss, t->flags);
     TrainArgs a;
     memset(&a, 0, sizeof(a));
     a.vertex = t->vertex; a.context = t->context;

@@ -1,19 +1,24 @@
 // gvx_engine.cpp — the native solver engine behind include/gvx.h: the orchestration of the reference's GraphSolver /
 // SolverMixin / WorkerMixin (include/instance/graph.cuh:586-813, include/core/solver.h:87-888,1170-1623) as a C++ host
-// runtime for MI355X.  Not a translation of it:
+// runtime for MI355X, and the ONLY orchestrator of this repository: the pybind11 module (bind/libgraphvite.cpp), the
+// Python package (graphvite_amd/solver.py) and bench.py are bindings of it.  Not a translation of the reference's:
 //   * one HOST thread issues everything; a worker is a set of HIP streams on its GPU, not an OS thread.  Every block is
 //     one H2D copy + (optionally) one regrouping pass + episode_size back-to-back kernel launches, all asynchronous, so
 //     the host is never the bottleneck and the reference's thread-per-worker joins per schedule step disappear;
-//   * a worker keeps the WHOLE vertex table [P][1 + m][S][dim] and the context shards of the tail partitions it owns
-//     for good (288 GB of HBM per GPU); nothing is evicted, reloaded or rebuilt between schedule steps
-//     (WorkerMixin::load_partition / write_back, solver.h:1435-1504, have no counterpart);
-//   * after a schedule step every worker copies the head shard it trained straight into the replicas of the other
-//     workers (hipMemcpyPeerAsync over xGMI, on its exchange stream); consumers wait on events, the host does not;
-//   * CPU sampler threads (gvs_sampler_fill) fill the next episode's pinned pools while the GPUs train this one.
+//   * the W workers of a job live in one process (device_ids = [0, 1, ...], like the reference) or one per process
+//     (gvx_solver_create_distributed: torchrun / mpirun); the code below only ever iterates over the LOCAL workers;
+//   * a worker keeps the WHOLE vertex table — a slab [P slots][1 + m][S][dim] — and the context shards of the tail
+//     partitions it owns for good (288 GB of HBM per GPU); nothing is evicted, reloaded or rebuilt between schedule steps
+//     (WorkerMixin::load_partition / write_back, solver.h:1435-1504, only exist as the fallback for models that do not fit);
+//   * after a schedule step ONE in-place all-gather of a head group's slab (RCCL over xGMI; gvx_comm.h) hands every worker
+//     the shards the others trained; consumers wait on events, the host does not;
+//   * CPU sampler threads (gvs_sampler_fill) fill the next episode's pinned pools while the GPUs train this one — or the
+//     GPUs draw the positives themselves (GVX_DEVICE_SAMPLING).
 // The arithmetic lives in the kernels (gvk.h); this file moves no embedding through the CPU during training.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <time.h>
 
@@ -29,6 +34,7 @@
 
 #include "gvk_internal.h"
 #include "gvx.h"
+#include "gvx_comm.h"
 
 // Stream / event plumbing and clean-up calls are not checked one by one: a failure there is sticky in the HIP runtime
 // and surfaces at the next checked call (every allocation, copy and launch is checked).
@@ -102,9 +108,10 @@ struct Range {  // roctx range around a host phase (gvk_range_push / _pop): the 
     } while (0)
 
 struct Worker {
+    int rank = 0;    // among the W workers of the job (the schedule's worker index)
     int device = 0;
     hipStream_t compute = nullptr, copy = nullptr, exchange = nullptr;
-    float *head = nullptr;     // [P slots][1 + m][S][dim]: every head partition, vertex rows then moment tables
+    float *head = nullptr;     // the slab [P slots][1 + m][S][dim]: every head partition, vertex rows then moment tables
     float *context = nullptr;  // [T][1 + m][S][dim]: the tail partitions this worker owns
     std::vector<int> tails;
     std::vector<gvk_alias_entry *> negative_tables;  // per owned tail: one alias slot per row, or null when ...
@@ -117,11 +124,10 @@ struct Worker {
     hipEvent_t uploaded[2] = {nullptr, nullptr}, released[2] = {nullptr, nullptr}, trained = nullptr;
     bool released_valid[2] = {false, false};
     std::vector<hipEvent_t> copied;     // H2D copies of the current pool set still reading pinned memory
-    std::vector<hipEvent_t> incoming;   // peer copies into this worker's replica not yet fenced on its compute stream
-    hipEvent_t sent = nullptr;          // the peer copies of the head partition this worker trained last have left it
-    int sending = -1;                   // ... that partition (-1: nothing in flight)
+    std::vector<hipEvent_t> gathered;   // per head group: the all-gather of its slab has completed on this worker
+    std::vector<char> gathered_valid;
     uint64_t visits = 0;
-    // positive samples drawn on the device (GVX_DEVICE_SAMPLING)
+    // pools resident in HBM: positives drawn on the device (GVX_DEVICE_SAMPLING) or a session's resident pool sets
     struct EdgeBlock {
         gvk_edge_entry *table = nullptr;  // alias table over the weights of the block's edges + their {tail, head} records
         uint32_t count = 0;
@@ -129,8 +135,9 @@ struct Worker {
     hipStream_t sample = nullptr;
     hipEvent_t filled[2] = {nullptr, nullptr}, episode_end = nullptr;
     bool episode_end_valid = false;
-    uint32_t *block_pools[2] = {nullptr, nullptr};  // [tails][P][n] records: the pools of every block it trains, two episodes
-    uint32_t *slices = nullptr;                     // walks, several workers: [P * P][n / W], its slice of EVERY block
+    uint32_t *block_pools[2] = {nullptr, nullptr};  // [tails][P][n] records: the pools of every block it trains, two sets
+    uint32_t *route_send = nullptr, *route_recv = nullptr;  // walks, several workers: [W][T * P][n / W], its slice of EVERY block
+    uint32_t *route_host = nullptr;                 // ... sampled by this process's CPU samplers (pinned)
     std::vector<EdgeBlock> edge_blocks;             // edge mode: per block, index = tail index * P + head partition
     gvk_walk_graph walk{};                          // walk modes: the graph in HBM
     int32_t *walk_part = nullptr;
@@ -144,9 +151,18 @@ struct Worker {
 struct gvx_solver {
     // resources
     int dim = 0;
-    std::vector<int> device_ids;
-    int num_worker = 0, num_sampler_per_worker = 0, num_sampler = 0;
+    std::vector<int> device_ids;  // of the LOCAL workers
+    int num_worker = 0;           // W: workers of the whole job
+    int first_rank = 0;           // rank of the first local worker (0 in one process; the process's rank otherwise)
+    bool distributed = false;     // one process per GPU
+    std::vector<char> unique_id;
+    bool has_transport = false;
+    gvx_transport transport{};
+    int num_sampler_per_worker = 0, num_sampler = 0;
     size_t memory_request = 0, gpu_memory_limit = 0, gpu_memory_cost = 0;
+    uint64_t seed = 0;
+    int pair_order_request = 0, negative_table_request = 0;
+    uint64_t node2vec_table_limit = (uint64_t)1 << 30;
     // build
     const gvs_graph *graph = nullptr;
     gvx_optimizer optimizer{};
@@ -159,12 +175,13 @@ struct gvx_solver {
     // memory between blocks, the reference's load_partition / write_back scheme (solver.h:1435-1504)
     bool streamed = false;
     bool device_sampling = false;  // gvx_solver_set(GVX_DEVICE_SAMPLING)
-    std::vector<uint64_t> sample_positions;  // per worker: draws (edge mode) / walks consumed since build()
+    std::vector<uint64_t> sample_positions;  // per local worker: draws (edge mode) / walks consumed since build()
     std::vector<int32_t> part;
     std::vector<uint32_t> local, part_sizes;
     uint32_t part_rows = 0;  // S
     std::vector<std::vector<uint32_t>> part_ids;  // global ids of a partition in local order
-    std::vector<int32_t> schedule;                // [steps][W][2]
+    std::vector<int32_t> schedule;                // [steps][W][2], the reference's order (solver.h:519-575)
+    std::vector<int> order;                       // the episode's step order: head groups interleaved when P = m W, m > 1
     int num_step = 0;
     std::vector<float> vertex, context;           // host embeddings, global order (the numpy views)
     std::vector<std::vector<float>> vertex_moments, context_moments;  // kept across train(resume=True)
@@ -177,10 +194,27 @@ struct gvx_solver {
     gvs_sampler *sampler = nullptr;
     int sampler_mode = -1;
     float sampler_p = 0, sampler_q = 0;
-    std::vector<Worker> workers;
+    std::vector<Worker> workers;  // the LOCAL workers
+    gvx::Comm *comm = nullptr, *route = nullptr;  // exchange of head shards / routing of walk pools (own communicators)
+    std::string transport_name;
+    // where every head partition sits in the slab, the same on every worker of the job (claim_slots)
+    std::vector<int> slot_of, part_at;
+    std::vector<std::vector<int>> claimed;  // per head group: the heads (rank order) it was last arranged for
+    uint64_t exchanged_bytes = 0, exchanges = 0;
+    bool grouped = false;  // this training regroups its pools (pair order)
+    bool resident_pools = false, session_open = false;
+    std::vector<uint32_t *> host_sets[2];  // pinned host pools, two sets, one pool per block (index hp * P + tp)
     std::string info_text;
 
     ~gvx_solver() { release(); }
+
+    int num_local() const { return (int)device_ids.size(); }
+    bool walk_ordered() const {  // DeepWalk / node2vec pools: the pairs of a head node back to back (no pseudo shuffle)
+        return mode != GVS_MODE_EDGE && config.shuffle_base == 1;
+    }
+    bool routed() const {  // walk pools are sampled in slices by every worker and routed to the worker that trains them
+        return mode != GVS_MODE_EDGE && num_worker > 1 && (device_sampling || distributed);
+    }
 
     void release_device() {
         if (device_sampling && !workers.empty()) {  // the device samplers go on where they stopped at the next train()
@@ -190,11 +224,17 @@ struct gvx_solver {
         for (Worker &w : workers) {
             hipSetDevice(w.device);
             hipDeviceSynchronize();
+        }
+        delete comm, delete route;
+        comm = route = nullptr;
+        for (Worker &w : workers) {
+            hipSetDevice(w.device);
             hipFree(w.head), hipFree(w.context), hipFree(w.loss), hipFree(w.pool[0]), hipFree(w.pool[1]);
             hipFree(w.landing), hipFree(w.group_workspace);
             for (auto *t : w.negative_tables) hipFree(t);
             for (auto *t : w.negative_classes) hipFree(t);
-            hipFree(w.block_pools[0]), hipFree(w.block_pools[1]), hipFree(w.slices);
+            hipFree(w.block_pools[0]), hipFree(w.block_pools[1]), hipFree(w.route_send), hipFree(w.route_recv);
+            if (w.route_host) hipHostFree(w.route_host);
             for (auto &b : w.edge_blocks) hipFree(b.table);
             hipFree((void *)w.walk.flat_offsets), hipFree((void *)w.walk.edges_uv), hipFree((void *)w.walk.edge_table);
             hipFree((void *)w.walk.neighbor_table), hipFree((void *)w.walk.sorted_neighbors), hipFree((void *)w.walk.local);
@@ -208,14 +248,20 @@ struct gvx_solver {
                 if (w.released[b]) hipEventDestroy(w.released[b]);
             }
             if (w.trained) hipEventDestroy(w.trained);
-            if (w.sent) hipEventDestroy(w.sent);
             for (auto e : w.copied) hipEventDestroy(e);
-            for (auto e : w.incoming) hipEventDestroy(e);
+            for (auto e : w.gathered)
+                if (e) hipEventDestroy(e);
             if (w.compute) hipStreamDestroy(w.compute);
             if (w.copy) hipStreamDestroy(w.copy);
             if (w.exchange) hipStreamDestroy(w.exchange);
         }
         workers.clear();
+        for (auto &set : host_sets) {
+            for (uint32_t *p : set)
+                if (p) hipHostFree(p);
+            set.clear();
+        }
+        session_open = false;
     }
 
     void release() {
@@ -228,28 +274,42 @@ struct gvx_solver {
     size_t table_floats() const { return (size_t)part_rows * dim; }
     size_t slot_floats() const { return table_floats() * (1 + num_moment); }
     float *head_table(Worker &w, int hp, int table) {
-        return w.head + ((size_t)(streamed ? 0 : hp) * (1 + num_moment) + table) * table_floats();
+        return w.head + ((size_t)(streamed ? 0 : slot_of[hp]) * (1 + num_moment) + table) * table_floats();
     }
     float *context_table(Worker &w, int ti, int table) {
         return w.context + ((size_t)(streamed ? 0 : ti) * (1 + num_moment) + table) * table_floats();
     }
+    int block_of(int step, const Worker &w, int which) const { return schedule[((size_t)step * num_worker + w.rank) * 2 + which]; }
+    size_t tail_index(const Worker &w, int tp) const { return std::find(w.tails.begin(), w.tails.end(), tp) - w.tails.begin(); }
 
     size_t memory_demand(int P, int requested_episode, bool as_streamed = false) const;
     int load_block(Worker &w, int hp, int tp);
     int store_block(Worker &w, int hp, int tp);
     int configure(const gvx_train_config &c);
     int prepare_devices();
+    int prepare_comm();
+    int allocate_pools();
     int upload();
     int write_back();
     int move_table(bool to_device, Worker &w, float *device_table, std::vector<float> &host, int partition);
     int episode_loop();
-    int train_block(Worker &w, int hp, int tp, uint32_t *pool);
-    int fill(std::vector<uint32_t *> &pools);
+    int train_block(Worker &w, int hp, int tp, const uint32_t *pool, int first, int count);
+    int fill(int set);
+    int host_fill(int set);
     int prepare_device_sampling();
     int device_fill(int set);
+    int route_slices(int set);
+    int stage(Worker &w, int step, int set, int b);
+    int train_step(int step, int set, int first, int count, bool stage_next, int next_step, int next_set);
+    int claim_slots(int step);
+    int wait_exchange(Worker &w, int group);
+    int exchange(int step);
+    int allocate_host_sets();
     uint32_t *block_pool(Worker &w, int set, int hp, int tp) {
-        const size_t ti = std::find(w.tails.begin(), w.tails.end(), tp) - w.tails.begin();
-        return w.block_pools[set] + (ti * num_partition + hp) * (size_t)episode_size * batch_size * 2;
+        return w.block_pools[set] + (tail_index(w, tp) * num_partition + hp) * (size_t)episode_size * batch_size * 2;
+    }
+    const uint32_t *trained_pool(Worker &w, int set, int b, int hp, int tp) {
+        return w.block_pools[0] && !grouped ? block_pool(w, set, hp, tp) : w.pool[b];
     }
     void make_info();
 };
@@ -260,6 +320,28 @@ const char *optimizer_name(int type) {
     static const char *const names[] = {"SGD", "Momentum", "AdaGrad", "RMSprop", "Adam"};
     return type >= 0 && type <= GVK_ADAM ? names[type] : "Default";
 }
+
+// The extern "C" entry points promise "nothing aborts": a C++ exception (std::bad_alloc from a large vector, an error a
+// schedule callback threw) becomes an error code at the boundary.
+template <class F>
+int guarded(const char *what, F body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return gvk_fail(GVK_ENOMEM, "%s: out of host memory", what);
+    } catch (const std::exception &e) {
+        return gvk_fail(GVK_EINVAL, "%s: %s", what, e.what());
+    } catch (...) {
+        return gvk_fail(GVK_EINVAL, "%s: unknown exception", what);
+    }
+}
+
+struct JoinOnExit {  // a filler thread never outlives the scope that started it, whatever leaves the scope
+    std::thread &thread;
+    ~JoinOnExit() {
+        if (thread.joinable()) thread.join();
+    }
+};
 
 }  // namespace
 
@@ -273,9 +355,16 @@ size_t gvx_solver::memory_demand(int P, int requested_episode, bool as_streamed)
         episode = std::max<size_t>((size_t)((double)num_vertex * kSamplePerVertex / P / batch_size), 1);
         if (P == 1) episode = std::max<size_t>(episode, kMinEpisodeSample / batch_size);
     }
-    demand += 3 * episode * batch_size * 8;  // two pool buffers + the regrouping landing buffer
-    if (device_sampling && !as_streamed)  // the pools of every block a worker trains, two episodes, + its slices on their way to the owners
-        demand += 3 * tails * P * episode * batch_size * 8;
+    const size_t pool = episode * batch_size * 8;
+    demand += 3 * pool + pool;  // two pool buffers + the regrouping landing buffer + the regrouping workspace
+    if (device_sampling && !as_streamed) {
+        // the pools of every block a worker trains, two episodes, + its slices on their way to the owners (send + receive)
+        demand += 4 * tails * P * pool;
+        // what the device samplers draw from: ~16 B per directed edge (edge mode: packed block tables over the worker's
+        // columns) or ~44 B (walk modes: CSR, two alias tables, sorted neighbours, maps), on every worker
+        const uint64_t D = graph ? gvs_graph_num_directed_edge(graph) : 0;
+        demand += D * 44 + (size_t)num_vertex * 16;
+    }
     return demand;
 }
 
@@ -306,19 +395,34 @@ void gvx_solver::make_info() {  // GraphSolver::info, graph.cuh:739-768 over Sol
 
 // ---- build -------------------------------------------------------------------------------------------------------
 
-extern "C" gvx_solver *gvx_solver_create(int dim, const int *device_ids, int num_device, int num_sampler_per_worker,
-                                         size_t gpu_memory_limit) {
+namespace {
+
+gvx_solver *new_solver(int dim, int num_sampler_per_worker, size_t gpu_memory_limit) {
     if (dim != 32 && dim != 64 && dim != 96 && dim != 128 && dim != 256 && dim != 512) {
         gvk_fail(GVK_EDIM, "GraphSolver: dim must be one of 32, 64, 96, 128, 256, 512");
         return nullptr;
     }
+    std::unique_ptr<gvx_solver> s(new gvx_solver());
+    s->dim = dim;
+    s->num_sampler_per_worker = num_sampler_per_worker;
+    s->memory_request = gpu_memory_limit;
+    s->gpu_memory_limit = gpu_memory_limit;
+    s->config.random_walk_length = 40, s->config.random_walk_batch_size = 100, s->config.p = s->config.q = 1;
+    s->config.positive_reuse = 1, s->config.log_frequency = 1000;
+    return s.release();
+}
+
+}  // namespace
+
+extern "C" gvx_solver *gvx_solver_create(int dim, const int *device_ids, int num_device, int num_sampler_per_worker,
+                                         size_t gpu_memory_limit) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
         gvk_fail(GVK_EHIP, "No GPU devices found");  // solver.h:176
         return nullptr;
     }
-    std::unique_ptr<gvx_solver> s(new gvx_solver());
-    s->dim = dim;
+    std::unique_ptr<gvx_solver> s(new_solver(dim, num_sampler_per_worker, gpu_memory_limit));
+    if (!s) return nullptr;
     if (num_device <= 0)
         for (int i = 0; i < count; i++) s->device_ids.push_back(i);
     else
@@ -331,29 +435,114 @@ extern "C" gvx_solver *gvx_solver_create(int dim, const int *device_ids, int num
         }
     s->num_worker = (int)s->device_ids.size();
     if (num_sampler_per_worker == GVX_AUTO)  // solver.h:193-194, over the CPUs this process may really use
-        num_sampler_per_worker = std::max(cpu_budget() / s->num_worker - 1, 1);
-    s->num_sampler_per_worker = num_sampler_per_worker;
-    s->num_sampler = num_sampler_per_worker * s->num_worker;
-    s->memory_request = gpu_memory_limit;
-    s->gpu_memory_limit = gpu_memory_limit;
-    s->config.random_walk_length = 40, s->config.random_walk_batch_size = 100, s->config.p = s->config.q = 1;
-    s->config.positive_reuse = 1, s->config.log_frequency = 1000;
+        s->num_sampler_per_worker = std::max(cpu_budget() / s->num_worker - 1, 1);
+    s->num_sampler = s->num_sampler_per_worker * s->num_worker;
     return s.release();
+}
+
+extern "C" gvx_solver *gvx_solver_create_distributed(int dim, int rank, int world_size, int device_id, const void *unique_id,
+                                                     size_t unique_id_bytes, const gvx_transport *transport,
+                                                     int num_sampler_per_worker, size_t gpu_memory_limit) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+        gvk_fail(GVK_EHIP, "No GPU devices found");
+        return nullptr;
+    }
+    if (world_size < 1 || rank < 0 || rank >= world_size || device_id < 0 || device_id >= count) {
+        gvk_fail(GVK_EINVAL, "GraphSolver: rank %d of %d on GPU %d (%d device(s) visible)", rank, world_size, device_id, count);
+        return nullptr;
+    }
+    if (transport && (!transport->all_gather || !transport->all_to_all)) {
+        gvk_fail(GVK_EINVAL, "GraphSolver: a transport needs all_gather and all_to_all");
+        return nullptr;
+    }
+    std::unique_ptr<gvx_solver> s(new_solver(dim, num_sampler_per_worker, gpu_memory_limit));
+    if (!s) return nullptr;
+    s->device_ids.assign(1, device_id);
+    s->num_worker = world_size, s->first_rank = rank, s->distributed = world_size > 1;
+    if (transport) s->has_transport = true, s->transport = *transport;
+    if (unique_id && unique_id_bytes) s->unique_id.assign((const char *)unique_id, (const char *)unique_id + unique_id_bytes);
+    if (num_sampler_per_worker == GVX_AUTO) {
+        // the usable CPUs are shared by the processes of this node (LOCAL_WORLD_SIZE as torchrun / mpirun export it)
+        const char *local_world = getenv("LOCAL_WORLD_SIZE");
+        const int sharing = local_world && atoi(local_world) > 0 ? atoi(local_world) : world_size;
+        s->num_sampler_per_worker = std::max(cpu_budget() / sharing - 1, 1);
+    }
+    s->num_sampler = s->num_sampler_per_worker * world_size;
+    return s.release();
+}
+
+extern "C" int gvx_unique_id(void *out, size_t capacity) {
+    if (!out || capacity < GVX_UNIQUE_ID_BYTES) return gvk_fail(GVK_EINVAL, "gvx_unique_id: %d bytes needed", GVX_UNIQUE_ID_BYTES);
+    std::string why;
+    for (int i = 0; i < 2; i++) {
+        int rc = gvx::rccl_unique_id((char *)out + i * (GVX_UNIQUE_ID_BYTES / 2), GVX_UNIQUE_ID_BYTES / 2, &why);
+        if (rc != GVK_OK) return gvk_fail(rc, "gvx_unique_id: %s", why.c_str());
+    }
+    return GVK_OK;
+}
+
+extern "C" int gvx_rccl_selftest(int device) {
+    return guarded("gvx_rccl_selftest", [&]() -> int {
+        std::string why;
+        std::unique_ptr<gvx::Comm> comm(gvx::make_rccl_in_process({device}, &why));
+        if (!comm) return gvk_fail(GVK_EHIP, "gvx_rccl_selftest: %s", why.c_str());
+        HIP_TRY(hipSetDevice(device));
+        const size_t n = 1 << 20;
+        std::vector<uint32_t> host(n), back(n), other(n);
+        for (size_t i = 0; i < n; i++) host[i] = (uint32_t)(i * 2654435761u);
+        uint32_t *a = nullptr, *b = nullptr;
+        hipStream_t stream = nullptr;
+        HIP_TRY(hipMalloc(&a, n * 4));
+        HIP_TRY(hipMalloc(&b, n * 4));
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIP_TRY(hipMemcpy(a, host.data(), n * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(b, 0, n * 4));
+        int rc = comm->all_gather({{0, device, stream}}, {a}, n * 4);
+        if (rc == GVK_OK) rc = comm->all_to_all({{0, device, stream}}, {a}, {b}, n * 4);
+        if (rc == GVK_OK && hipStreamSynchronize(stream) != hipSuccess) rc = gvk_fail(GVK_EHIP, "gvx_rccl_selftest: stream failed");
+        if (rc == GVK_OK) {
+            hipMemcpy(back.data(), a, n * 4, hipMemcpyDeviceToHost);
+            hipMemcpy(other.data(), b, n * 4, hipMemcpyDeviceToHost);
+            if (back != host || other != host) rc = gvk_fail(GVK_EHIP, "gvx_rccl_selftest: a one-rank collective changed the data");
+        }
+        hipStreamDestroy(stream);
+        hipFree(a), hipFree(b);
+        return rc;
+    });
 }
 
 extern "C" void gvx_solver_destroy(gvx_solver *s) { delete s; }
 
 extern "C" int gvx_solver_set(gvx_solver *s, int option, int64_t value) {
     if (!s) return gvk_fail(GVK_EINVAL, "gvx_solver_set: null solver");
-    if (option != GVX_DEVICE_SAMPLING || (value != 0 && value != 1))
-        return gvk_fail(GVK_EINVAL, "gvx_solver_set: unknown option %d or unsupported value %lld", option, (long long)value);
-    s->device_sampling = value != 0;
-    return GVK_OK;
+    if (option == GVX_DEVICE_SAMPLING && (value == 0 || value == 1)) {
+        s->device_sampling = value != 0;
+        return GVK_OK;
+    }
+    if (option == GVX_PAIR_ORDER && value >= 0 && value <= 2) {
+        s->pair_order_request = (int)value;
+        return GVK_OK;
+    }
+    if (option == GVX_NEGATIVE_TABLE && value >= 0 && value <= 2) {
+        s->negative_table_request = (int)value;
+        return GVK_OK;
+    }
+    if (option == GVX_SEED) {
+        s->seed = (uint64_t)value;
+        return GVK_OK;
+    }
+    if (option == GVX_NODE2VEC_TABLE_LIMIT && value >= 0) {
+        s->node2vec_table_limit = (uint64_t)value;
+        return GVK_OK;
+    }
+    return gvk_fail(GVK_EINVAL, "gvx_solver_set: unknown option %d or unsupported value %lld", option, (long long)value);
 }
 
 extern "C" int gvx_solver_build(gvx_solver *s, const gvs_graph *graph, const gvx_optimizer *optimizer, int num_partition,
                                 int num_negative, int batch_size, int episode_size) {
     if (!s || !graph) return gvk_fail(GVK_EINVAL, "gvx_solver_build: null solver / graph");
+    return guarded("GraphSolver.build", [&]() -> int {
     if (gvs_graph_num_vertex(graph) == 0 || gvs_graph_num_directed_edge(graph) == 0)
         return gvk_fail(GVK_EINVAL, "The graph is empty");
     if (batch_size < 1 || num_negative < 0 || episode_size < 0 || num_partition < 0)
@@ -392,11 +581,15 @@ extern "C" int gvx_solver_build(gvx_solver *s, const gvs_graph *graph, const gvx
     }
     s->streamed = false;
     if (num_partition == GVX_AUTO) {
+        // resident, the design of this engine: N * dim * 4 * (1 + m) * (1 + 1 / W) bytes of tables whatever the partition
+        // count — more partitions only shrink the pools.  When even the most partitions do not fit, the reference's
+        // scheme: one head and one tail partition per worker in HBM, everything else in host memory (solver.h:365-384)
         num_partition = W;
         while (num_partition < kMaxPartition && s->memory_demand(num_partition, episode_size) >= limit) num_partition += W;
         if (s->memory_demand(num_partition, episode_size) >= limit) {
-            // the resident design does not fit even with the most partitions: fall back to the reference's scheme — one
-            // head and one tail partition per worker in HBM, everything else in host memory (solver.h:365-384)
+            if (s->distributed)
+                return gvk_fail(GVK_ENOMEM, "The tables do not fit the GPU memory limit; partitions that travel through host "
+                                            "memory need all workers in one process (device_ids=[...])");
             s->streamed = true;
             num_partition = W;
             while (num_partition < kMaxPartition && s->memory_demand(num_partition, episode_size, true) >= limit) num_partition += W;
@@ -404,7 +597,7 @@ extern "C" int gvx_solver_build(gvx_solver *s, const gvs_graph *graph, const gvx
                            "travel through host memory between blocks (%d partitions)", num_partition);
         }
     } else {
-        s->streamed = s->memory_demand(num_partition, episode_size) >= limit &&
+        s->streamed = !s->distributed && s->memory_demand(num_partition, episode_size) >= limit &&
                       s->memory_demand(num_partition, episode_size, true) < limit;
         if (num_partition < W) return gvk_fail(GVK_EINVAL, "#partition should be no less than %d", W);
         if (num_partition % W) return gvk_fail(GVK_EINVAL, "#partition (%d) must be a multiple of #worker (%d)", num_partition, W);
@@ -427,6 +620,19 @@ extern "C" int gvx_solver_build(gvx_solver *s, const gvs_graph *graph, const gvx
     s->schedule.assign((size_t)std::max((P / W) * (P / W) * W, 1) * W * 2 + 2, 0);
     s->num_step = gvs_schedule(P, W, s->schedule.data(), s->schedule.size());
     if (s->num_step < 0) return s->num_step;
+    // The reference walks the block groups x-major (solver.h:562-574): all steps that use head partitions x .. x + W - 1
+    // come back to back, and each needs the exchange of the one before.  An episode may visit its P^2 blocks in any
+    // order, so with P = m W (m > 1) the steps are interleaved across the m head groups: the all-gather of group x's
+    // slab then runs on the exchange streams while the next m - 1 steps train on the other groups.
+    s->order.clear();
+    const int m = P > 1 ? P / W : 1;
+    if (m > 1 && !s->streamed) {
+        for (int yi = 0; yi < m; yi++)
+            for (int o = 0; o < W; o++)
+                for (int xi = 0; xi < m; xi++) s->order.push_back((xi * m + yi) * W + o);
+    } else {
+        for (int step = 0; step < s->num_step; step++) s->order.push_back(step);
+    }
 
     if (episode_size == GVX_AUTO) {  // solver.h:426-436
         episode_size = std::max((int)((double)s->num_vertex * kSamplePerVertex / P / batch_size), 1);
@@ -438,6 +644,7 @@ extern "C" int gvx_solver_build(gvx_solver *s, const gvs_graph *graph, const gvx
     s->vertex_moments.clear(), s->context_moments.clear();
     s->make_info();
     return GVK_OK;
+    });
 }
 
 // ---- train: configuration ------------------------------------------------------------------------------------------
@@ -469,11 +676,12 @@ int gvx_solver::configure(const gvx_train_config &in) {
     config = c;
     config.model = model.c_str();
     make_info();
-    log_message(1, "\n<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<\n%s\n>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>", info_text.c_str());
-    if (!c.resume) {  // GraphSolver::init_embeddings, graph.cuh:724-731
-        std::mt19937 seed(5489u);
+    if (first_rank == 0)
+        log_message(1, "\n<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<\n%s\n>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>", info_text.c_str());
+    if (!c.resume) {  // GraphSolver::init_embeddings, graph.cuh:724-731 — the same table on every process
+        std::mt19937 generator(5489u + (uint32_t)seed);
         std::uniform_real_distribution<float> init(-0.5f / dim, 0.5f / dim);
-        for (float &x : vertex) x = init(seed);
+        for (float &x : vertex) x = init(generator);
         std::fill(context.begin(), context.end(), 0.0f);
         vertex_moments.clear(), context_moments.clear();
         batch_id = 0;
@@ -488,10 +696,28 @@ int gvx_solver::configure(const gvx_train_config &in) {
         const uint64_t D = gvs_graph_num_directed_edge(graph);
         uint64_t entries = 0;
         for (uint64_t e = 0; e < D; e++) entries += offsets[uv[2 * e + 1] + 1] - offsets[uv[2 * e + 1]];
-        if (entries > ((uint64_t)1 << 30)) {
-            log_message(1, "node2vec: %llu per-edge table entries exceed 2^30; sampling by rejection", (unsigned long long)entries);
+        if (entries > node2vec_table_limit) {
+            log_message(1, "node2vec: %llu per-edge table entries exceed the limit of %llu; sampling by rejection",
+                        (unsigned long long)entries, (unsigned long long)node2vec_table_limit);
             mode = GVS_MODE_BIASED_REJECT;
         }
+    }
+    // regroup by table size, at dim >= 64 (DESIGN.md §3.1.1): cache-resident tables (< 16 MiB) always — adjacent
+    // same-head samples are then trained as runs, which keeps training close to sequential (§7); shard-sized tables
+    // (< 256 MiB) for independent edge draws — a shared head row becomes one fetch; larger tables keep the sampler's order
+    const size_t table_bytes = (size_t)part_rows * dim * 4;
+    // — and never the walk-ordered pools of DeepWalk / node2vec, which are trained pair by pair in the sampler's order
+    // (gvk.h GVK_PAIRS_OF_WALKS)
+    grouped = pair_order_request == 2 ||
+              (pair_order_request == 0 && dim >= 64 && !walk_ordered() &&
+               (table_bytes < ((size_t)16 << 20) || (table_bytes < ((size_t)256 << 20) && mode == GVS_MODE_EDGE)));
+    if (routed()) {
+        if (pool_size % num_worker)
+            return gvk_fail(GVK_EINVAL, "episode_size * batch_size (%zu) must be a multiple of #worker (%d) for the "
+                            "random-walk models", pool_size, num_worker);
+        if (pool_size / num_worker % c.shuffle_base)
+            return gvk_fail(GVK_EINVAL, "Can't perform pseudo shuffle on %zu elements by a shuffle base of %d",
+                            pool_size / num_worker, c.shuffle_base);
     }
     if (device_sampling) {  // the GPUs draw the positives: no CPU sampler, none of its tables
         if (streamed)
@@ -499,22 +725,16 @@ int gvx_solver::configure(const gvx_train_config &in) {
                                         "or use the CPU samplers");
         if (gvs_graph_num_directed_edge(graph) >= ((uint64_t)1 << 32))
             return gvk_fail(GVK_EINVAL, "device sampling supports graphs with fewer than 2^32 directed edges");
-        if (mode != GVS_MODE_EDGE) {
-            if (pool_size % num_worker)
-                return gvk_fail(GVK_EINVAL, "episode_size * batch_size (%zu) must be a multiple of #worker (%d) for the "
-                                "random-walk models", pool_size, num_worker);
-            if (pool_size / num_worker % c.shuffle_base)
-                return gvk_fail(GVK_EINVAL, "Can't perform pseudo shuffle on %zu elements by a shuffle base of %d",
-                                pool_size / num_worker, c.shuffle_base);
-        }
         return GVK_OK;
     }
     if (!sampler) {
-        sampler = gvs_sampler_create(graph, part.data(), local.data(), num_partition, 0x9E3779B97F4A7C15ull);
+        sampler = gvs_sampler_create(graph, part.data(), local.data(), num_partition,
+                                     (seed + 0x9E3779B97F4A7C15ull * (uint64_t)(first_rank + 1)));
         if (!sampler) return GVK_EINVAL;
     }
+    const int threads = num_sampler_per_worker * num_local();
     if (sampler_mode != mode || sampler_p != c.p || sampler_q != c.q) {  // get_sample_function, graph.cuh:680-721
-        GVK_TRY(gvs_sampler_prepare(sampler, mode, c.p, c.q, num_sampler + 1));
+        GVK_TRY(gvs_sampler_prepare(sampler, mode, c.p, c.q, threads + 1));
         sampler_mode = mode, sampler_p = c.p, sampler_q = c.q;
     }
     return GVK_OK;
@@ -522,15 +742,51 @@ int gvx_solver::configure(const gvx_train_config &in) {
 
 // ---- device state --------------------------------------------------------------------------------------------------
 
+// The carriers of the exchange and of the walk-pool routing (gvx_comm.h): a caller-supplied transport; RCCL — one
+// communicator per GPU, a second set for the routing, whose all-to-all runs on its own stream and host thread beside the
+// all-gathers; or, when the workers of one process share GPUs, event-ordered device copies.
+int gvx_solver::prepare_comm() {
+    if (num_worker == 1 || streamed) return GVK_OK;
+    std::string why;
+    if (has_transport) {
+        comm = gvx::make_callbacks(transport, first_rank, num_worker);
+        route = gvx::make_callbacks(transport, first_rank, num_worker);
+    } else if (distributed) {
+        const size_t half = GVX_UNIQUE_ID_BYTES / 2;
+        if (unique_id.size() < GVX_UNIQUE_ID_BYTES)
+            return gvk_fail(GVK_EINVAL, "GraphSolver: %d processes need the %d bytes of gvx_unique_id() from rank 0", num_worker,
+                            GVX_UNIQUE_ID_BYTES);
+        comm = gvx::make_rccl_rank(first_rank, num_worker, device_ids[0], unique_id.data(), half, &why);
+        if (comm) route = gvx::make_rccl_rank(first_rank, num_worker, device_ids[0], unique_id.data() + half, half, &why);
+        if (!comm || !route) return gvk_fail(GVK_EHIP, "GraphSolver: no RCCL communicator: %s", why.c_str());
+    } else {
+        comm = gvx::make_rccl_in_process(device_ids, &why);
+        if (comm) route = gvx::make_rccl_in_process(device_ids, &why);
+        if (!comm || !route) {
+            delete comm, delete route;
+            log_message(0, "exchange by device copies (%s)", why.c_str());
+            comm = gvx::make_copies(num_worker);
+            route = gvx::make_copies(num_worker);
+        }
+    }
+    transport_name = comm->name();
+    return GVK_OK;
+}
+
 int gvx_solver::prepare_devices() {
     release_device();
-    const int P = num_partition, W = num_worker, nm = num_moment;
-    workers.assign(W, Worker());
-    for (int r = 0; r < W; r++) {
-        Worker &w = workers[r];
-        w.device = device_ids[r];
+    const int P = num_partition, W = num_worker;
+    workers.assign(num_local(), Worker());
+    slot_of.resize(P), part_at.resize(P);
+    for (int p = 0; p < P; p++) slot_of[p] = part_at[p] = p;
+    claimed.assign(std::max(P / W, 1), {});
+    exchanged_bytes = exchanges = 0;
+    for (int l = 0; l < num_local(); l++) {
+        Worker &w = workers[l];
+        w.rank = first_rank + l;
+        w.device = device_ids[l];
         for (int step = 0; step < num_step; step++) {
-            const int tp = schedule[((size_t)step * W + r) * 2 + 1];
+            const int tp = block_of(step, w, 1);
             if (std::find(w.tails.begin(), w.tails.end(), tp) == w.tails.end()) w.tails.push_back(tp);
         }
         std::sort(w.tails.begin(), w.tails.end());
@@ -539,7 +795,7 @@ int gvx_solver::prepare_devices() {
             for (int p = 0; p < P; p++) w.tails.push_back(p);
         }
         HIP_TRY(hipSetDevice(w.device));
-        for (int q = 0; q < W; q++)  // direct GPU-to-GPU copies for the exchange
+        for (int q = 0; q < num_local(); q++)  // direct GPU-to-GPU copies (the copies carrier)
             if (device_ids[q] != w.device) {
                 int can = 0;
                 if (hipDeviceCanAccessPeer(&can, w.device, device_ids[q]) == hipSuccess && can) {
@@ -562,7 +818,9 @@ int gvx_solver::prepare_devices() {
             HIP_TRY(hipEventCreateWithFlags(&w.released[b], hipEventDisableTiming));
         }
         HIP_TRY(hipEventCreateWithFlags(&w.trained, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&w.sent, hipEventDisableTiming));
+        w.gathered.assign(std::max(P / W, 1), nullptr);
+        w.gathered_valid.assign(w.gathered.size(), 0);
+        for (hipEvent_t &e : w.gathered) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         // negative sampler per owned tail partition: degree^exponent in local order (solver.h:1263-1278)
         for (int tp : w.tails) {
             const std::vector<uint32_t> &ids = part_ids[tp];
@@ -576,24 +834,44 @@ int gvx_solver::prepare_devices() {
             std::vector<gvk_class_entry> classes(ids.size());
             uint32_t num_class = 0;
             GVK_TRY(gvk_class_table_build(weights.data(), weights.size(), classes.data(), &num_class));
-            gvk_alias_entry *table = nullptr;
-            gvk_class_entry *class_table = nullptr;
-            if ((size_t)num_class * 8 <= ids.size()) {
-                HIP_TRY(hipMalloc(&class_table, num_class * sizeof(gvk_class_entry)));
-                HIP_TRY(hipMemcpy(class_table, classes.data(), num_class * sizeof(gvk_class_entry), hipMemcpyHostToDevice));
+            // the table joins the worker's lists BEFORE the copy that may fail, so that release_device() always frees it
+            w.negative_tables.push_back(nullptr);
+            w.negative_classes.push_back(nullptr);
+            w.negative_class_counts.push_back(0);
+            const bool by_class = negative_table_request == 2 || (negative_table_request == 0 && (size_t)num_class * 8 <= ids.size());
+            if (by_class) {
+                HIP_TRY(hipMalloc(&w.negative_classes.back(), num_class * sizeof(gvk_class_entry)));
+                HIP_TRY(hipMemcpy(w.negative_classes.back(), classes.data(), num_class * sizeof(gvk_class_entry), hipMemcpyHostToDevice));
+                w.negative_class_counts.back() = num_class;
             } else {
-                num_class = 0;
                 GVK_TRY(gvk_alias_build(weights.data(), weights.size(), prob.data(), alias.data(), 4, packed.data()));
-                HIP_TRY(hipMalloc(&table, packed.size() * sizeof(gvk_alias_entry)));
-                HIP_TRY(hipMemcpy(table, packed.data(), packed.size() * sizeof(gvk_alias_entry), hipMemcpyHostToDevice));
+                HIP_TRY(hipMalloc(&w.negative_tables.back(), packed.size() * sizeof(gvk_alias_entry)));
+                HIP_TRY(hipMemcpy(w.negative_tables.back(), packed.data(), packed.size() * sizeof(gvk_alias_entry), hipMemcpyHostToDevice));
             }
-            w.negative_tables.push_back(table);
-            w.negative_classes.push_back(class_table);
-            w.negative_class_counts.push_back(num_class);
         }
-        (void)nm;
     }
-    // the pools are the elastic part, as in the reference (solver.h:437-455): halve the episode until they fit
+    GVK_TRY(allocate_pools());
+    GVK_TRY(prepare_comm());
+    const size_t n = (size_t)episode_size * batch_size;
+    for (Worker &w : workers) {
+        if (!w.block_pools[0]) break;
+        HIP_TRY(hipSetDevice(w.device));
+        HIP_TRY(hipStreamCreateWithFlags(&w.sample, hipStreamNonBlocking));
+        for (hipEvent_t &e : w.filled) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&w.episode_end, hipEventDisableTiming));
+        if (!routed()) continue;  // its slice of every block pool: [owner rank][the owner's blocks][n / W] out, the same back
+        HIP_TRY(hipMalloc(&w.route_send, (size_t)P * P * (n / W) * 8));
+        HIP_TRY(hipMalloc(&w.route_recv, (size_t)P * P * (n / W) * 8));
+        if (!device_sampling) HIP_TRY(hipHostMalloc(&w.route_host, (size_t)P * P * (n / W) * 8, hipHostMallocDefault));
+    }
+    return device_sampling ? prepare_device_sampling() : GVK_OK;
+}
+
+// The pools are the elastic part, as in the reference (solver.h:437-455): halve the episode until they fit — the two
+// device buffers and the regrouping landing buffer, and the pool sets kept in HBM (device sampling, resident sessions).
+int gvx_solver::allocate_pools() {
+    const int W = num_worker;
+    const bool in_hbm = device_sampling || resident_pools || routed();
     while (true) {
         bool ok = true;
         const size_t bytes = (size_t)episode_size * batch_size * 8;
@@ -601,22 +879,30 @@ int gvx_solver::prepare_devices() {
             hipSetDevice(w.device);
             ok = ok && hipMalloc(&w.pool[0], bytes) == hipSuccess && hipMalloc(&w.pool[1], bytes) == hipSuccess &&
                  hipMalloc(&w.landing, bytes) == hipSuccess;
+            for (uint32_t *&pools : w.block_pools)
+                ok = ok && (!in_hbm || hipMalloc(&pools, w.tails.size() * num_partition * bytes) == hipSuccess);
             if (!ok) break;
         }
         if (ok) break;
         (void)hipGetLastError();
         for (Worker &w : workers) {
             hipSetDevice(w.device);
-            hipFree(w.pool[0]), hipFree(w.pool[1]), hipFree(w.landing);
-            w.pool[0] = w.pool[1] = w.landing = nullptr;
+            hipFree(w.pool[0]), hipFree(w.pool[1]), hipFree(w.landing), hipFree(w.block_pools[0]), hipFree(w.block_pools[1]);
+            w.pool[0] = w.pool[1] = w.landing = w.block_pools[0] = w.block_pools[1] = nullptr;
         }
         if (episode_size <= 1)
             return gvk_fail(GVK_ENOMEM, "Out of GPU memory. Try to reduce the size of your graph or the dimension of your embeddings.");
-        const int base = config.augmentation_step > 1 ? std::max(config.shuffle_base, 1) : 1;
+        // the halved episode keeps what configure() checked: a whole number of shuffle bases per pool — per slice, when
+        // every worker samples a slice of every pool
+        const size_t base = (size_t)(config.augmentation_step > 1 ? std::max(config.shuffle_base, 1) : 1) * (routed() ? W : 1);
         int half = episode_size / 2;
         while (half > 1 && ((size_t)half * batch_size) % base) half--;
+        if (((size_t)std::max(half, 1) * batch_size) % base)
+            return gvk_fail(GVK_ENOMEM, "Out of GPU memory for an episode of %d batches, and no smaller episode is a multiple of "
+                            "the shuffle base times the number of workers", episode_size);
         log_message(1, "Fail to allocate GPU memory for episode size of %d. Use %d instead.", episode_size, std::max(half, 1));
         episode_size = std::max(half, 1);
+        make_info();
     }
     for (Worker &w : workers) {
         HIP_TRY(hipSetDevice(w.device));
@@ -625,8 +911,10 @@ int gvx_solver::prepare_devices() {
         GVK_TRY(gvk_group_pairs(nullptr, nullptr, nullptr, nullptr, &w.group_workspace_bytes, batch_size / parts,
                                 episode_size * parts, row_bits));
         HIP_TRY(hipMalloc(&w.group_workspace, std::max<size_t>(w.group_workspace_bytes, 16)));
+        for (uint32_t *pools : w.block_pools)  // never train what nothing wrote
+            if (pools) HIP_TRY(hipMemsetAsync(pools, 0, w.tails.size() * num_partition * (size_t)episode_size * batch_size * 8, w.compute));
     }
-    return device_sampling ? prepare_device_sampling() : GVK_OK;
+    return GVK_OK;
 }
 
 // ---- positive samples drawn on the device (GVX_DEVICE_SAMPLING) ------------------------------------------------------
@@ -634,7 +922,7 @@ int gvx_solver::prepare_devices() {
 namespace {
 
 template <class T>
-int to_device(T **out, const T *host, size_t count) {  // on the current device
+int to_device(T **out, const T *host, size_t count) {  // on the current device; *out is owned by the caller's Worker
     HIP_TRY(hipMalloc((void **)out, std::max<size_t>(count, 1) * sizeof(T)));
     if (count) HIP_TRY(hipMemcpy(*out, host, count * sizeof(T), hipMemcpyHostToDevice));
     return GVK_OK;
@@ -661,6 +949,7 @@ int gvx_solver::prepare_device_sampling() {
     std::vector<gvk_alias_entry> edge_table, neighbor_table;
     std::vector<uint32_t> sorted_neighbors;
     const bool biased = mode == GVS_MODE_BIASED_WALK || mode == GVS_MODE_BIASED_REJECT;
+    const int threads = num_sampler_per_worker * num_local();
     if (mode == GVS_MODE_EDGE) {
         of_block.assign((size_t)P * P, {});
         for (uint64_t e = 0; e < D; e++) of_block[(size_t)part[uv[2 * e]] * P + part[uv[2 * e + 1]]].push_back((uint32_t)e);
@@ -669,7 +958,7 @@ int gvx_solver::prepare_device_sampling() {
         std::vector<uint32_t> alias(D);
         edge_table.resize(D), neighbor_table.resize(D);
         GVK_TRY(gvk_alias_build(weights, D, prob.data(), alias.data(), 4, edge_table.data()));
-        GVK_TRY(gvs_graph_neighbor_tables(graph, num_sampler + 1, neighbor_table.data()));
+        GVK_TRY(gvs_graph_neighbor_tables(graph, threads + 1, neighbor_table.data()));
         if (biased) {  // out-neighbours ascending inside each vertex's CSR segment (the acceptance test searches them)
             const uint64_t *offsets = gvs_graph_flat_offsets(graph);
             sorted_neighbors.resize(D);
@@ -678,16 +967,12 @@ int gvx_solver::prepare_device_sampling() {
                 std::sort(sorted_neighbors.begin() + offsets[v], sorted_neighbors.begin() + offsets[v + 1]);
         }
     }
-    for (int r = 0; r < W; r++) {
-        Worker &w = workers[r];
+    for (size_t l = 0; l < workers.size(); l++) {
+        Worker &w = workers[l];
         HIP_TRY(hipSetDevice(w.device));
-        HIP_TRY(hipStreamCreateWithFlags(&w.sample, hipStreamNonBlocking));
-        for (hipEvent_t &e : w.filled) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&w.episode_end, hipEventDisableTiming));
-        w.sample_seed = 0x9E3779B97F4A7C15ull * (uint64_t)(r + 1) + 0x706f73;
-        w.sample_index = (size_t)r < sample_positions.size() ? sample_positions[r] : 0;
+        w.sample_seed = seed * 0x9E3779B1ull + 0x9E3779B97F4A7C15ull * (uint64_t)(w.rank + 1) + 0x706f73;
+        w.sample_index = l < sample_positions.size() ? sample_positions[l] : 0;
         const size_t blocks = w.tails.size() * P;
-        for (uint32_t *&pools : w.block_pools) HIP_TRY(hipMalloc(&pools, blocks * n * 8));
         if (mode == GVS_MODE_EDGE) {
             w.edge_blocks.assign(blocks, Worker::EdgeBlock());
             for (size_t ti = 0; ti < w.tails.size(); ti++)
@@ -719,29 +1004,52 @@ int gvx_solver::prepare_device_sampling() {
         if (biased) GVK_TRY(to_device((uint32_t **)&g.sorted_neighbors, sorted_neighbors.data(), D));
         GVK_TRY(to_device((uint32_t **)&g.local, local.data(), num_vertex));
         GVK_TRY(to_device(&w.walk_part, part.data(), num_vertex));
-        // one worker: the walks land in the block pools themselves; several: in this worker's slice of every block
+        // one worker: the walks land in the block pools themselves; several: in this worker's slice of every block, laid
+        // out for the all-to-all — [owner rank][the owner's blocks, tail-major][n / W]
         std::vector<uint64_t> offsets((size_t)P * P);
-        const size_t n_slice = n / W;
+        const size_t n_slice = n / W, per_rank = (size_t)(P / W) * P;
         for (int hp = 0; hp < P; hp++)
             for (int tp = 0; tp < P; tp++) {
-                const size_t ti = std::find(w.tails.begin(), w.tails.end(), tp) - w.tails.begin();
-                offsets[(size_t)hp * P + tp] = W == 1 ? (ti * P + hp) * n : ((size_t)hp * P + tp) * n_slice;
+                const size_t owner = tp % W, ti = tp / W;  // worker i owns tails i, W + i, ... (gvs_schedule)
+                offsets[(size_t)hp * P + tp] = W == 1 ? (ti * P + hp) * n : ((owner * per_rank + ti * P + hp) * n_slice);
             }
         GVK_TRY(to_device(&w.walk_offsets, offsets.data(), offsets.size()));
-        if (W > 1) HIP_TRY(hipMalloc(&w.slices, (size_t)P * P * n_slice * 8));
         HIP_TRY(hipMalloc(&w.walk_counters, (size_t)P * P * largest_divisor(n_slice, 256) * 4));
     }
     return GVK_OK;
 }
 
-// The pools of one episode (set 0 / 1) for every worker, drawn by the GPUs on their sampling streams — what fill() does
-// with CPU threads.  Edge mode: one gvk_sample_edges per block, nothing to wait for.  Walk modes: rounds of
-// gvk_sample_walks_blocks until every stripe of every block is full (the host reads the counters between rounds —
-// a handful of round trips, on a thread of its own while the GPUs train the episode before), then each slice goes to
-// the worker that trains its block.
+// The slices every worker drew of every block pool go to the workers that train the blocks: one all-to-all per episode
+// on the sampling streams (its own communicator), then each block's W slices are laid side by side in the block's pool.
+int gvx_solver::route_slices(int set) {
+    const int P = num_partition, W = num_worker;
+    const size_t n = (size_t)episode_size * batch_size, n_slice = n / W, per_rank = (size_t)(P / W) * P;
+    std::vector<gvx::Peer> peers;
+    std::vector<const void *> send;
+    std::vector<void *> recv;
+    for (Worker &w : workers) {
+        peers.push_back({w.rank, w.device, w.sample});
+        send.push_back(w.route_send), recv.push_back(w.route_recv);
+    }
+    GVK_TRY(route->all_to_all(peers, send, recv, per_rank * n_slice * 8));
+    for (Worker &w : workers) {
+        HIP_TRY(hipSetDevice(w.device));
+        for (int q = 0; q < W; q++)  // rank q's slices of this worker's blocks: block i goes to pool i, W slices per pool
+            HIP_TRY(hipMemcpy2DAsync(w.block_pools[set] + (size_t)q * n_slice * 2, n * 8,
+                                     w.route_recv + (size_t)q * per_rank * n_slice * 2, n_slice * 8, n_slice * 8, per_rank,
+                                     hipMemcpyDeviceToDevice, w.sample));
+        HIP_TRY(hipEventRecord(w.filled[set], w.sample));
+    }
+    return GVK_OK;
+}
+
+// The pools of one episode (set 0 / 1) for every local worker, drawn by the GPUs on their sampling streams — what
+// host_fill() does with CPU threads.  Edge mode: one gvk_sample_edges per block, nothing to wait for.  Walk modes: rounds
+// of gvk_sample_walks_blocks until every stripe of every block is full (the host reads the counters between rounds — a
+// handful of round trips, on a thread of its own while the GPUs train the episode before), then the slices are routed.
 int gvx_solver::device_fill(int set) {
     Range range("Sample (device)");
-    const int P = num_partition, W = num_worker;
+    const int P = num_partition, W = num_worker, L = num_local();
     const size_t n = (size_t)episode_size * batch_size, n_slice = n / W;
     for (Worker &w : workers) {  // the pools of `set` were read by the episode before the one that trains now
         HIP_TRY(hipSetDevice(w.device));
@@ -761,11 +1069,11 @@ int gvx_solver::device_fill(int set) {
         }
         return GVK_OK;
     }
-    const int L = config.random_walk_length, aug = config.augmentation_step;
-    const uint64_t per_walk = (uint64_t)aug * L - (uint64_t)aug * (aug - 1) / 2;
+    const int length = config.random_walk_length, aug = config.augmentation_step;
+    const uint64_t per_walk = (uint64_t)aug * length - (uint64_t)aug * (aug - 1) / 2;
     if (P == 1) {  // one block: every walk owns its slots of the pool, no binning, no rounds
         Worker &w = workers[0];
-        GVK_TRY(gvk_sample_walks(w.sample, &w.walk, w.sample_seed, w.sample_index, w.block_pools[set], n, L, aug,
+        GVK_TRY(gvk_sample_walks(w.sample, &w.walk, w.sample_seed, w.sample_index, w.block_pools[set], n, length, aug,
                                  config.shuffle_base));
         w.sample_index += (n + per_walk - 1) / per_walk;
         HIP_TRY(hipEventRecord(w.filled[set], w.sample));
@@ -774,8 +1082,8 @@ int gvx_solver::device_fill(int set) {
     const int stripes = largest_divisor(n_slice, 256);
     const uint64_t stripe_capacity = n_slice / stripes, every = 64ull * stripes;  // the same number of wavefronts per stripe
     const size_t num_counter = (size_t)P * P * stripes;
-    std::vector<uint64_t> walks(W, ((n_slice * P * P + per_walk - 1) / per_walk / every + 1) * every), used(W, 0);
-    std::vector<char> full(W, 0);
+    std::vector<uint64_t> walks(L, ((n_slice * P * P + per_walk - 1) / per_walk / every + 1) * every), used(L, 0);
+    std::vector<char> full(L, 0);
     std::vector<uint32_t> counters(num_counter);
     for (Worker &w : workers) {
         HIP_TRY(hipSetDevice(w.device));
@@ -783,19 +1091,19 @@ int gvx_solver::device_fill(int set) {
     }
     for (int round = 0;; round++) {
         if (round == 64) return gvk_fail(GVK_EINVAL, "device sampling: the block pools are not full after 64 rounds of walks");
-        for (int r = 0; r < W; r++) {
-            Worker &w = workers[r];
-            if (full[r]) continue;
+        for (int l = 0; l < L; l++) {
+            Worker &w = workers[l];
+            if (full[l]) continue;
             HIP_TRY(hipSetDevice(w.device));
-            GVK_TRY(gvk_sample_walks_blocks(w.sample, &w.walk, w.walk_part, P, w.sample_seed, w.sample_index + used[r], walks[r],
-                                            W == 1 ? w.block_pools[set] : w.slices, w.walk_offsets, w.walk_counters,
-                                            (uint32_t)n_slice, stripes, L, aug, config.shuffle_base));
-            used[r] += walks[r];
+            GVK_TRY(gvk_sample_walks_blocks(w.sample, &w.walk, w.walk_part, P, w.sample_seed, w.sample_index + used[l], walks[l],
+                                            W == 1 ? w.block_pools[set] : w.route_send, w.walk_offsets, w.walk_counters,
+                                            (uint32_t)n_slice, stripes, length, aug, config.shuffle_base));
+            used[l] += walks[l];
         }
         bool all_full = true;
-        for (int r = 0; r < W; r++) {
-            Worker &w = workers[r];
-            if (full[r]) continue;
+        for (int l = 0; l < L; l++) {
+            Worker &w = workers[l];
+            if (full[l]) continue;
             HIP_TRY(hipSetDevice(w.device));
             HIP_TRY(hipMemcpyAsync(counters.data(), w.walk_counters, num_counter * 4, hipMemcpyDeviceToHost, w.sample));
             HIP_TRY(hipStreamSynchronize(w.sample));
@@ -803,37 +1111,22 @@ int gvx_solver::device_fill(int set) {
             double need = 0;
             for (size_t i = 0; i < num_counter; i++) {
                 if (counters[i] >= stripe_capacity) continue;
-                const double share = std::max((double)counters[i] / ((double)used[r] * per_walk), 1.0 / (64.0 * num_counter));
-                if (counters[i] == 0 && used[r] * per_walk > 64ull * n_slice * P * P)
+                const double share = std::max((double)counters[i] / ((double)used[l] * per_walk), 1.0 / (64.0 * num_counter));
+                if (counters[i] == 0 && used[l] * per_walk > 64ull * n_slice * P * P)
                     return gvk_fail(GVK_EINVAL, "block (%zu, %zu) of the partition grid receives no random-walk pairs; use "
                                     "fewer partitions", i / stripes / P, i / stripes % P);
                 need = std::max(need, (double)(stripe_capacity - counters[i]) / share / per_walk);
             }
-            full[r] = need == 0;
-            walks[r] = ((uint64_t)(need * 1.1) / every + 1) * every;
-            all_full = all_full && full[r];
+            full[l] = need == 0;
+            walks[l] = ((uint64_t)(need * 1.1) / every + 1) * every;
+            all_full = all_full && full[l];
         }
         if (all_full) break;
     }
-    for (int r = 0; r < W; r++) {
-        Worker &w = workers[r];
-        w.sample_index += used[r];
-        HIP_TRY(hipSetDevice(w.device));
-        for (int b = 0; b < P * P && W > 1; b++) {  // slice r of block b to the worker that trains b
-            const int hp = b / P, tp = b % P;
-            for (Worker &u : workers) {
-                const size_t ti = std::find(u.tails.begin(), u.tails.end(), tp) - u.tails.begin();
-                if (ti == u.tails.size()) continue;
-                uint32_t *to = u.block_pools[set] + ((ti * P + hp) * n + (size_t)r * n_slice) * 2;
-                const uint32_t *from = w.slices + (size_t)b * n_slice * 2;
-                hipError_t e = u.device == w.device
-                                   ? hipMemcpyAsync(to, from, n_slice * 8, hipMemcpyDeviceToDevice, w.sample)
-                                   : hipMemcpyPeerAsync(to, u.device, from, w.device, n_slice * 8, w.sample);
-                if (e != hipSuccess) return gvk_fail(GVK_EHIP, "routing of block (%d, %d): %s", hp, tp, hipGetErrorString(e));
-            }
-        }
-        HIP_TRY(hipEventRecord(w.filled[set], w.sample));
-    }
+    for (int l = 0; l < L; l++) workers[l].sample_index += used[l];
+    if (W > 1) return route_slices(set);
+    HIP_TRY(hipSetDevice(workers[0].device));
+    HIP_TRY(hipEventRecord(workers[0].filled[set], workers[0].sample));
     return GVK_OK;
 }
 
@@ -844,7 +1137,7 @@ int gvx_solver::move_table(bool to_device, Worker &w, float *device_table, std::
     const size_t row_bytes = (size_t)dim * 4, chunk_rows = std::max<size_t>(kChunkBytes / row_bytes, 1);
     float *staging = nullptr;
     HIP_TRY(hipHostMalloc(&staging, std::min(chunk_rows, std::max<size_t>(ids.size(), 1)) * row_bytes, hipHostMallocDefault));
-    const int threads = std::max(std::min(num_sampler, 16), 1);
+    const int threads = std::max(std::min(num_sampler_per_worker * num_local(), 16), 1);
     int rc = GVK_OK;
     for (size_t start = 0; start < ids.size() && rc == GVK_OK; start += chunk_rows) {
         const size_t n = std::min(chunk_rows, ids.size() - start);
@@ -900,7 +1193,10 @@ int gvx_solver::upload() {
     return GVK_OK;
 }
 
-int gvx_solver::write_back() {  // WorkerMixin::write_back, solver.h:1498-1504: every table once, from a worker that holds it
+// WorkerMixin::write_back, solver.h:1498-1504: every table once, from a worker that holds it.  One process per GPU: the
+// context shards of the other ranks arrive by all-gather (one per owned tail slot: shard i of every rank), so that every
+// rank's host arrays are complete.
+int gvx_solver::write_back() {
     for (Worker &w : workers) {
         HIP_TRY(hipSetDevice(w.device));
         HIP_TRY(hipDeviceSynchronize());
@@ -916,15 +1212,35 @@ int gvx_solver::write_back() {  // WorkerMixin::write_back, solver.h:1498-1504: 
         GVK_TRY(move_table(false, first, head_table(first, p, 0), vertex, p));
         for (int j = 0; j < num_moment; j++) GVK_TRY(move_table(false, first, head_table(first, p, 1 + j), vertex_moments[j], p));
     }
-    for (Worker &w : workers) {
-        HIP_TRY(hipSetDevice(w.device));
-        for (size_t ti = 0; ti < w.tails.size(); ti++) {
-            GVK_TRY(move_table(false, w, context_table(w, (int)ti, 0), context, w.tails[ti]));
-            for (int j = 0; j < num_moment; j++)
-                GVK_TRY(move_table(false, w, context_table(w, (int)ti, 1 + j), context_moments[j], w.tails[ti]));
+    if (!distributed) {
+        for (Worker &w : workers) {
+            HIP_TRY(hipSetDevice(w.device));
+            for (size_t ti = 0; ti < w.tails.size(); ti++) {
+                GVK_TRY(move_table(false, w, context_table(w, (int)ti, 0), context, w.tails[ti]));
+                for (int j = 0; j < num_moment; j++)
+                    GVK_TRY(move_table(false, w, context_table(w, (int)ti, 1 + j), context_moments[j], w.tails[ti]));
+            }
+        }
+        return GVK_OK;
+    }
+    const int W = num_worker;
+    float *all = nullptr;  // [W][1 + m][S][dim]: slot ti of every rank
+    HIP_TRY(hipMalloc(&all, (size_t)W * slot_floats() * 4));
+    int rc = GVK_OK;
+    for (size_t ti = 0; ti < first.tails.size() && rc == GVK_OK; ti++) {
+        hipMemcpyAsync(all + (size_t)first.rank * slot_floats(), context_table(first, (int)ti, 0), slot_floats() * 4,
+                       hipMemcpyDeviceToDevice, first.exchange);
+        rc = comm->all_gather({{first.rank, first.device, first.exchange}}, {all}, slot_floats() * 4);
+        if (rc == GVK_OK && hipStreamSynchronize(first.exchange) != hipSuccess) rc = gvk_fail(GVK_EHIP, "write back: all-gather failed");
+        for (int q = 0; q < W && rc == GVK_OK; q++) {
+            const int tp = (int)ti * W + q;  // worker q owns tails q, W + q, ... (gvs_schedule)
+            rc = move_table(false, first, all + ((size_t)q * (1 + num_moment)) * table_floats(), context, tp);
+            for (int j = 0; j < num_moment && rc == GVK_OK; j++)
+                rc = move_table(false, first, all + ((size_t)q * (1 + num_moment) + 1 + j) * table_floats(), context_moments[j], tp);
         }
     }
-    return GVK_OK;
+    hipFree(all);
+    return rc;
 }
 
 // Streamed mode (WorkerMixin::load_partition / write_back, solver.h:1435-1504): the head and tail partition of a block come
@@ -954,102 +1270,282 @@ int gvx_solver::store_block(Worker &w, int hp, int tp) {
     return GVK_OK;
 }
 
-// ---- episode loop ---------------------------------------------------------------------------------------------------
+// ---- pools -----------------------------------------------------------------------------------------------------------
 
-int gvx_solver::fill(std::vector<uint32_t *> &pools) {
+int gvx_solver::allocate_host_sets() {
+    if (device_sampling || !host_sets[0].empty()) return GVK_OK;
+    const int P = num_partition;
+    const size_t pool_bytes = (size_t)episode_size * batch_size * 8;
+    for (auto &set : host_sets) {
+        set.assign((size_t)P * P, nullptr);
+        if (routed()) continue;  // this process samples slices (Worker::route_host), not whole pools
+        for (Worker &w : workers)
+            for (int tp : w.tails)
+                for (int hp = 0; hp < P; hp++)
+                    if (hipHostMalloc(&set[(size_t)hp * P + tp], pool_bytes, hipHostMallocDefault) != hipSuccess)
+                        return gvk_fail(GVK_ENOMEM, "Out of host memory for the sample pools (%d x %d blocks of %s)", P, P,
+                                        size_string((double)pool_bytes).c_str());
+    }
+    return GVK_OK;
+}
+
+// The CPU samplers (SamplerMixin::sample, solver.h:1012-1055; GraphSampler::sample_random_walk, graph.cuh:298-450) fill the
+// pools of every block the LOCAL workers train.  Independent edge draws with several partitions: column by column, from
+// an alias table over exactly the edges that end in the column's tail partition (the exact conditional distribution,
+// nothing dropped; the reference draws from all edges and drops what does not fit).  Random walks yield pairs for every
+// block: one process fills all P x P pools at once; with one process per GPU each process fills its 1 / W slice of every
+// pool and the slices are routed (route_slices).
+int gvx_solver::host_fill(int set) {
     Range range("Sample threads");  // solver.h:622
+    const int P = num_partition, threads = num_sampler_per_worker * num_local();
     gvs_fill_config f{};
     f.mode = mode;
-    f.num_thread = 4 * num_sampler;  // 4 slices per OS thread: a descheduled thread delays a quarter-size slice
+    f.num_thread = 4 * threads;  // 4 slices per OS thread: a descheduled thread delays a quarter-size slice
     f.sample_batch_size = config.random_walk_length * config.random_walk_batch_size;  // graph.cuh:791
     f.walk_length = config.random_walk_length, f.walk_batch = config.random_walk_batch_size;
     f.augmentation_step = config.augmentation_step, f.shuffle_base = config.shuffle_base;
-    f.tail_partition = -1, f.os_threads = num_sampler, f.cpu_offset = -1;
-    return gvs_sampler_fill(sampler, pools.data(), (uint64_t)episode_size * batch_size, &f);
+    f.tail_partition = -1, f.os_threads = threads, f.cpu_offset = -1;
+    const uint64_t n = (uint64_t)episode_size * batch_size;
+    if (routed()) {  // this process's slice of every block pool, laid out for the all-to-all
+        Worker &w = workers[0];
+        const int W = num_worker;
+        const size_t n_slice = n / W, per_rank = (size_t)(P / W) * P;
+        std::vector<uint32_t *> slices((size_t)P * P);
+        for (int hp = 0; hp < P; hp++)
+            for (int tp = 0; tp < P; tp++)
+                slices[(size_t)hp * P + tp] = w.route_host + (((size_t)(tp % W) * per_rank + (size_t)(tp / W) * P + hp) * n_slice) * 2;
+        GVK_TRY(gvs_sampler_fill(sampler, slices.data(), n_slice, &f));
+        HIP_TRY(hipSetDevice(w.device));
+        for (Worker &u : workers)
+            if (u.episode_end_valid) HIP_TRY(hipStreamWaitEvent(w.sample, u.episode_end, 0));
+        HIP_TRY(hipMemcpyAsync(w.route_send, w.route_host, (size_t)P * P * n_slice * 8, hipMemcpyHostToDevice, w.sample));
+        GVK_TRY(route_slices(set));
+        HIP_TRY(hipStreamSynchronize(w.sample));  // the pinned slices may be refilled
+        return GVK_OK;
+    }
+    if (mode == GVS_MODE_EDGE && P > 1) {
+        for (Worker &w : workers)
+            for (int tp : w.tails) {
+                std::vector<uint32_t *> column((size_t)P * P, nullptr);
+                for (int hp = 0; hp < P; hp++) column[(size_t)hp * P + tp] = host_sets[set][(size_t)hp * P + tp];
+                f.tail_partition = tp;
+                GVK_TRY(gvs_sampler_fill(sampler, column.data(), n, &f));
+            }
+    } else {
+        GVK_TRY(gvs_sampler_fill(sampler, host_sets[set].data(), n, &f));
+    }
+    if (!resident_pools) return GVK_OK;
+    for (Worker &w : workers) {  // a session that keeps its pool sets in HBM: one H2D copy per block, now
+        HIP_TRY(hipSetDevice(w.device));
+        for (Worker &u : workers)
+            if (u.episode_end_valid) HIP_TRY(hipStreamWaitEvent(w.sample, u.episode_end, 0));
+        for (int tp : w.tails)
+            for (int hp = 0; hp < P; hp++)
+                HIP_TRY(hipMemcpyAsync(block_pool(w, set, hp, tp), host_sets[set][(size_t)hp * P + tp], n * 8, hipMemcpyHostToDevice,
+                                       w.sample));
+        HIP_TRY(hipEventRecord(w.filled[set], w.sample));
+    }
+    for (Worker &w : workers) HIP_TRY(hipStreamSynchronize(w.sample));
+    return GVK_OK;
 }
 
-// WorkerMixin::train (solver.h:1511-1522): positive_reuse x episode_size batches of one block on the worker's compute
-// stream; batch ids interleave over the workers as the reference's shared atomic counter hands them out (solver.h:1520)
-int gvx_solver::train_block(Worker &w, int hp, int tp, uint32_t *pool) {
+int gvx_solver::fill(int set) { return device_sampling ? device_fill(set) : host_fill(set); }
+
+// ---- one block -------------------------------------------------------------------------------------------------------
+
+// WorkerMixin::train (solver.h:1511-1522): batches [first, first + count) of one block's pool on the worker's compute
+// stream; batch ids interleave over the workers as the reference's shared atomic counter hands them out (solver.h:1520):
+// `base` is the id of the block visit's first batch on worker 0.
+int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int first_batch, int count) {
     Range range("Train Batch");  // solver.h:1526 (one range per block: its batches are back-to-back launches)
-    const int W = num_worker, r = (int)(&w - workers.data()), B = batch_size, nm = num_moment;
-    const int ti = (int)(std::find(w.tails.begin(), w.tails.end(), tp) - w.tails.begin());
+    const int W = num_worker, r = w.rank, B = batch_size, nm = num_moment;
+    const int ti = (int)tail_index(w, tp);
     gvk_tables t{};
     t.vertex = head_table(w, hp, 0), t.context = context_table(w, ti, 0);
     if (nm >= 1) t.vertex_moment1 = head_table(w, hp, 1), t.context_moment1 = context_table(w, ti, 1);
     if (nm >= 2) t.vertex_moment2 = head_table(w, hp, 2), t.context_moment2 = context_table(w, ti, 2);
     t.n_vertex = t.n_context = part_rows;
+    t.flags = walk_ordered() ? GVK_PAIRS_OF_WALKS : 0;
     gvk_negative_source neg{};
     neg.table = w.negative_tables[ti], neg.count = (uint32_t)part_ids[tp].size();
     neg.classes = w.negative_classes[ti], neg.class_count = w.negative_class_counts[ti];
-    neg.seed = 0x100000001B3ull * 1 + (uint64_t)r;
+    neg.seed = seed * 0x100000001B3ull + 0x100000001B3ull + (uint64_t)r;
     gvk_optimizer o{};
     o.type = optimizer.type, o.lr = optimizer.lr, o.weight_decay = optimizer.weight_decay;
     o.hp0 = optimizer.hp0, o.hp1 = optimizer.hp1, o.epsilon = optimizer.epsilon;
-    for (int reuse = 0; reuse < config.positive_reuse; reuse++) {
-        int done = 0;
-        while (done < episode_size) {
-            const uint64_t first = batch_id + ((uint64_t)reuse * episode_size + done) * W + r;
-            if (first % config.log_frequency == 0) {  // solver.h:1527-1549 (the loss is the previous batch's)
-                std::vector<float> host_loss(B);
-                HIP_TRY(hipMemcpyAsync(host_loss.data(), w.loss, (size_t)B * 4, hipMemcpyDeviceToHost, w.compute));
-                HIP_TRY(hipStreamSynchronize(w.compute));
-                double sum = 0;
-                for (float x : host_loss) sum += x;
-                log_message(0, "Batch id: %llu / %llu", (unsigned long long)first, (unsigned long long)num_batch);
-                log_message(0, "loss = %g", sum / B);
-            }
-            int n = 1;  // up to, not including, this worker's next logging batch
-            while (n < episode_size - done && (first + (uint64_t)n * W) % config.log_frequency) n++;
-            if (optimizer.schedule != 2) {
-                GVK_TRY(gvk_train_episode(w.compute, dim, &o, optimizer.schedule == 1, &t, pool + (size_t)done * B * 2, &neg,
-                                          (uint32_t)first, (uint32_t)W, (uint32_t)num_batch, n, w.loss, B, num_negative,
-                                          config.negative_weight));
-            } else {  // custom schedule: lr computed on the host per batch (optimizer.h:132-134)
-                for (int b = 0; b < n; b++) {
-                    const uint64_t id = first + (uint64_t)b * W;
-                    gvk_optimizer ob = o;
-                    ob.lr = optimizer.lr * optimizer.schedule_function((int)id, (int)num_batch, optimizer.user);
-                    GVK_TRY(gvk_train(w.compute, dim, &ob, &t, pool + (size_t)(done + b) * B * 2, &neg, (uint32_t)id, w.loss, B,
-                                      num_negative, config.negative_weight));
-                }
-            }
-            done += n;
+    int done = first_batch;
+    const int end = first_batch + count;
+    while (done < end) {
+        const uint64_t first = batch_id + (uint64_t)(done - first_batch) * W + r;
+        if (first % config.log_frequency == 0) {  // solver.h:1527-1549 (the loss is the previous batch's)
+            std::vector<float> host_loss(B);
+            HIP_TRY(hipMemcpyAsync(host_loss.data(), w.loss, (size_t)B * 4, hipMemcpyDeviceToHost, w.compute));
+            HIP_TRY(hipStreamSynchronize(w.compute));
+            double sum = 0;
+            for (float x : host_loss) sum += x;
+            log_message(0, "Batch id: %llu / %llu", (unsigned long long)first, (unsigned long long)num_batch);
+            log_message(0, "loss = %g", sum / B);
         }
+        int n = 1;  // up to, not including, this worker's next logging batch
+        while (n < end - done && (first + (uint64_t)n * W) % config.log_frequency) n++;
+        if (optimizer.schedule != 2) {
+            GVK_TRY(gvk_train_episode(w.compute, dim, &o, optimizer.schedule == 1, &t, pool + (size_t)done * B * 2, &neg,
+                                      (uint32_t)first, (uint32_t)W, (uint32_t)num_batch, n, w.loss, B, num_negative,
+                                      config.negative_weight));
+        } else {  // custom schedule: lr computed on the host per batch (optimizer.h:132-134)
+            for (int b = 0; b < n; b++) {
+                const uint64_t id = first + (uint64_t)b * W;
+                gvk_optimizer ob = o;
+                ob.lr = optimizer.lr * optimizer.schedule_function((int)id, (int)num_batch, optimizer.user);
+                GVK_TRY(gvk_train(w.compute, dim, &ob, &t, pool + (size_t)(done + b) * B * 2, &neg, (uint32_t)id, w.loss, B,
+                                  num_negative, config.negative_weight));
+            }
+        }
+        done += n;
     }
     return GVK_OK;
 }
 
-int gvx_solver::episode_loop() {
-    const int P = num_partition, W = num_worker;
+// The pool of the worker's block at `step`, from pool set `set`, into device buffer b on the copy stream: the H2D copy
+// (pools in pinned host memory) and / or the regrouping pass — per part of a batch, a part being what one launch trains
+// (gvk_train_launches).  Pools that live in HBM and are not regrouped are trained in place: nothing to do.
+int gvx_solver::stage(Worker &w, int step, int set, int b) {
+    Range upload_range("Upload");
+    const int P = num_partition;
     const size_t pool_elems = (size_t)episode_size * batch_size * 2;
-    // pinned host pools, two sets (the samplers fill one while the GPUs read the other), one pool per block;
-    // with device sampling the two sets are Worker::block_pools, in HBM
-    std::vector<uint32_t *> sets[2];
-    auto free_sets = [&]() {
-        for (auto &set : sets)
-            for (uint32_t *p : set) hipHostFree(p);
-    };
-    for (auto &set : sets) {
-        if (device_sampling) break;
-        set.assign((size_t)P * P, nullptr);
-        for (auto &p : set)
-            if (hipHostMalloc(&p, pool_elems * 4, hipHostMallocDefault) != hipSuccess) {
-                free_sets();
-                return gvk_fail(GVK_ENOMEM, "Out of host memory for the sample pools (%d x %d blocks of %s)", P, P,
-                                size_string((double)pool_elems * 4).c_str());
-            }
+    const int hp = block_of(step, w, 0), tp = block_of(step, w, 1);
+    HIP_TRY(hipSetDevice(w.device));
+    if (w.released_valid[b]) HIP_TRY(hipStreamWaitEvent(w.copy, w.released[b], 0));
+    const uint32_t *source = w.landing;
+    if (w.block_pools[0]) {  // already in HBM
+        HIP_TRY(hipStreamWaitEvent(w.copy, w.filled[set], 0));
+        source = block_pool(w, set, hp, tp);
+    } else {
+        uint32_t *target = grouped ? w.landing : w.pool[b];
+        HIP_TRY(hipMemcpyAsync(target, host_sets[set][(size_t)hp * P + tp], pool_elems * 4, hipMemcpyHostToDevice, w.copy));
+        hipEvent_t copied;
+        HIP_TRY(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(copied, w.copy));
+        w.copied.push_back(copied);
     }
-    // regroup by table size, at dim >= 64 (DESIGN.md §3.1.1): cache-resident tables (< 16 MiB) always — adjacent
-    // same-head samples are then trained as runs, which keeps training close to sequential (§7); shard-sized tables
-    // (< 256 MiB) for independent edge draws — a shared head row becomes one fetch; larger tables keep the sampler's order
-    const size_t table_bytes = (size_t)part_rows * dim * 4;
-    const bool grouped = dim >= 64 && (table_bytes < ((size_t)16 << 20) || (table_bytes < ((size_t)256 << 20) && mode == GVS_MODE_EDGE));
-    const int row_bits = std::max(32 - __builtin_clz(std::max(part_rows, 2u) - 1), 1);
-    const int parts = gvk_train_launches(batch_size, part_rows);
+    if (grouped) {
+        Range regroup("Regroup");
+        const int row_bits = std::max(32 - __builtin_clz(std::max(part_rows, 2u) - 1), 1);
+        const int parts = gvk_train_launches(batch_size, part_rows);
+        GVK_TRY(gvk_group_pairs(w.copy, source, w.pool[b], w.group_workspace, &w.group_workspace_bytes, batch_size / parts,
+                                episode_size * parts, row_bits));
+    }
+    HIP_TRY(hipEventRecord(w.uploaded[b], w.copy));
+    return GVK_OK;
+}
+
+// ---- the exchange ----------------------------------------------------------------------------------------------------
+
+int gvx_solver::wait_exchange(Worker &w, int group) {
+    if (num_worker == 1 || streamed || !w.gathered_valid[group]) return GVK_OK;
+    HIP_TRY(hipStreamWaitEvent(w.compute, w.gathered[group], 0));
+    return GVK_OK;
+}
+
+// Before worker r trains head partition hp it makes sure hp sits in ITS slot of hp's head group (slot x W + r): at most
+// one device-local copy of a shard — whatever partition sat in that slot is trained by another worker in this very step
+// and comes back with the gather.  After the step the group's slab is [what rank 0 trained][what rank 1 trained]..., so
+// the exchange is ONE in-place all-gather.  Every worker of the job keeps the same partition -> slot map.
+int gvx_solver::claim_slots(int step) {
+    const int W = num_worker;
+    if (W == 1 || streamed) return GVK_OK;
+    std::vector<int> heads(W);
+    for (int q = 0; q < W; q++) heads[q] = schedule[((size_t)step * W + q) * 2];
+    const int group = heads[0] / W;
+    if (claimed[group] == heads) return GVK_OK;
+    for (Worker &w : workers) {
+        const int hp = heads[w.rank], target = group * W + w.rank, source = slot_of[hp];
+        if (source == target) continue;
+        HIP_TRY(hipSetDevice(w.device));
+        HIP_TRY(hipMemcpyAsync(w.head + (size_t)target * slot_floats(), w.head + (size_t)source * slot_floats(), slot_floats() * 4,
+                               hipMemcpyDeviceToDevice, w.compute));
+    }
+    for (int q = 0; q < W; q++) {
+        slot_of[heads[q]] = group * W + q;
+        part_at[group * W + q] = heads[q];
+    }
+    claimed[group] = heads;
+    return GVK_OK;
+}
+
+// After a schedule step every worker has trained a different head partition of one head group, each in its own slot of
+// the group's slab: ONE in-place all-gather — vertex rows and moment tables together — gives every worker the whole,
+// current group again (RCCL over xGMI).  Asynchronous, on the exchange streams; the next block that reads the group
+// waits for it (wait_exchange), blocks of other groups train meanwhile.
+int gvx_solver::exchange(int step) {
+    const int W = num_worker;
+    if (W == 1 || streamed) return GVK_OK;
+    Range range("Exchange");
+    const int group = schedule[(size_t)step * W * 2] / W;
+    std::vector<gvx::Peer> peers;
+    std::vector<void *> slabs;
+    for (Worker &w : workers) {
+        HIP_TRY(hipSetDevice(w.device));
+        HIP_TRY(hipStreamWaitEvent(w.exchange, w.trained, 0));
+        peers.push_back({w.rank, w.device, w.exchange});
+        slabs.push_back(w.head + (size_t)group * W * slot_floats());
+    }
+    GVK_TRY(comm->all_gather(peers, slabs, slot_floats() * 4));
+    for (Worker &w : workers) {
+        HIP_TRY(hipSetDevice(w.device));
+        HIP_TRY(hipEventRecord(w.gathered[group], w.exchange));
+        w.gathered_valid[group] = 1;
+    }
+    exchanged_bytes += slot_floats() * 4 * (uint64_t)(W - 1);
+    exchanges++;
+    return GVK_OK;
+}
+
+// Batches [first, first + count) of every local worker's block at `step`: wait for the staged pool and for the exchange
+// the block depends on, bring the head partition to the worker's slot, stage the next visit's pool while this one trains.
+int gvx_solver::train_step(int step, int set, int first, int count, bool stage_next, int next_step, int next_set) {
+    const int W = num_worker;
+    const int group = schedule[(size_t)step * W * 2] / W;
+    for (Worker &w : workers) {
+        HIP_TRY(hipSetDevice(w.device));
+        GVK_TRY(wait_exchange(w, group));
+    }
+    GVK_TRY(claim_slots(step));
+    for (Worker &w : workers) {
+        const int hp = block_of(step, w, 0), tp = block_of(step, w, 1);
+        const int b = (int)(w.visits & 1);
+        HIP_TRY(hipSetDevice(w.device));
+        HIP_TRY(hipStreamWaitEvent(w.compute, w.uploaded[b], 0));
+        if (w.block_pools[0]) HIP_TRY(hipStreamWaitEvent(w.compute, w.filled[set], 0));
+        if (stage_next) {
+            w.visits++;
+            const int rc = stage(w, next_step, next_set, (int)(w.visits & 1));
+            w.visits--;
+            if (rc != GVK_OK) return rc;
+        }
+        if (streamed) GVK_TRY(load_block(w, hp, tp));
+        GVK_TRY(train_block(w, hp, tp, trained_pool(w, set, b, hp, tp), first, count));
+        HIP_TRY(hipEventRecord(w.released[b], w.compute));
+        w.released_valid[b] = true;
+        HIP_TRY(hipEventRecord(w.trained, w.compute));
+    }
+    // streamed: the blocks of this step go back to the host tables (distinct head and tail partitions per worker)
+    for (Worker &w : workers)
+        if (streamed) GVK_TRY(store_block(w, block_of(step, w, 0), block_of(step, w, 1)));
+    batch_id += (uint64_t)count * W;
+    return GVK_OK;
+}
+
+// ---- episode loop ---------------------------------------------------------------------------------------------------
+
+int gvx_solver::episode_loop() {
+    const int W = num_worker;
+    GVK_TRY(allocate_host_sets());
     const uint64_t per_episode = (uint64_t)num_step * episode_size * config.positive_reuse * W;
-    auto produce = [&](int set) { return device_sampling ? device_fill(set) : fill(sets[set]); };
-    int rc = produce(0);
+    // a transport of the embedding program is driven from this thread only (its collectives must be issued in the same
+    // order on every rank); RCCL's routing has a communicator of its own and overlaps the training
+    const bool overlap_fill = !(has_transport && routed());
+    int rc = fill(0);
     int current = 0;
     while (rc == GVK_OK && batch_id < num_batch) {
         // the samplers may overwrite the other set once every copy out of it has landed
@@ -1062,104 +1558,32 @@ int gvx_solver::episode_loop() {
         }
         int fill_rc = GVK_OK;
         std::thread filler;
-        if (batch_id + per_episode < num_batch)  // no pools for an episode that will not run
-            filler = std::thread([&, current]() { fill_rc = produce(current ^ 1); });
-        for (Worker &w : workers)  // device sampling: the pools of this episode, slices from every worker included
-            for (Worker &u : workers) {
-                if (!device_sampling) break;
-                hipSetDevice(w.device);
-                hipStreamWaitEvent(w.copy, u.filled[current], 0);
-                hipStreamWaitEvent(w.compute, u.filled[current], 0);
-            }
-        auto stage = [&](Worker &w, int step) -> int {  // H2D copy (+ regrouping) of the worker's block of `step`
-            Range upload_range("Upload");
-            const int r = (int)(&w - workers.data());
-            const int hp = schedule[((size_t)step * W + r) * 2], tp = schedule[((size_t)step * W + r) * 2 + 1];
-            const int b = (int)((w.visits + (uint64_t)step) & 1);
-            HIP_TRY(hipSetDevice(w.device));
-            if (w.released_valid[b]) HIP_TRY(hipStreamWaitEvent(w.copy, w.released[b], 0));
-            const uint32_t *source = w.landing;
-            if (device_sampling) {  // already in HBM: trained in place unless it is regrouped
-                source = block_pool(w, current, hp, tp);
-            } else {
-                uint32_t *target = grouped ? w.landing : w.pool[b];
-                HIP_TRY(hipMemcpyAsync(target, sets[current][(size_t)hp * P + tp], pool_elems * 4, hipMemcpyHostToDevice, w.copy));
-                hipEvent_t copied;
-                HIP_TRY(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
-                HIP_TRY(hipEventRecord(copied, w.copy));
-                w.copied.push_back(copied);
-            }
-            Range regroup("Regroup");
-            if (grouped)  // per part of a batch: a part is what one launch trains (gvk_train_launches)
-                GVK_TRY(gvk_group_pairs(w.copy, source, w.pool[b], w.group_workspace, &w.group_workspace_bytes,
-                                        batch_size / parts, episode_size * parts, row_bits));
-            HIP_TRY(hipEventRecord(w.uploaded[b], w.copy));
-            return GVK_OK;
-        };
-        for (Worker &w : workers)
-            if ((rc = stage(w, 0)) != GVK_OK) break;
-        for (int step = 0; step < num_step && rc == GVK_OK; step++) {
-            for (int r = 0; r < W && rc == GVK_OK; r++) {
-                Worker &w = workers[r];
-                const int hp = schedule[((size_t)step * W + r) * 2], tp = schedule[((size_t)step * W + r) * 2 + 1];
-                const int b = (int)((w.visits + (uint64_t)step) & 1);
-                if (hipSetDevice(w.device) != hipSuccess) rc = gvk_fail(GVK_EHIP, "hipSetDevice");
-                hipStreamWaitEvent(w.compute, w.uploaded[b], 0);
-                for (hipEvent_t e : w.incoming) {  // head shards other workers trained in earlier steps
-                    hipStreamWaitEvent(w.compute, e, 0);
-                    hipEventDestroy(e);
-                }
-                w.incoming.clear();
-                if (w.sending == hp) hipStreamWaitEvent(w.compute, w.sent, 0);  // its copies to the peers still read this slot
-                if (rc == GVK_OK && step + 1 < num_step) rc = stage(w, step + 1);  // next block's pool while this one trains
-                if (rc == GVK_OK && streamed) rc = load_block(w, hp, tp);
-                if (rc == GVK_OK)
-                    rc = train_block(w, hp, tp, device_sampling && !grouped ? block_pool(w, current, hp, tp) : w.pool[b]);
-                hipEventRecord(w.released[b], w.compute);
-                w.released_valid[b] = true;
-                hipEventRecord(w.trained, w.compute);
-            }
-            // streamed: the blocks of this step go back to the host tables (distinct head and tail partitions per worker)
-            for (int r = 0; r < W && rc == GVK_OK && streamed; r++)
-                rc = store_block(workers[r], schedule[((size_t)step * W + r) * 2], schedule[((size_t)step * W + r) * 2 + 1]);
-            // exchange: the head shard a worker just trained goes straight into every other worker's replica
-            Range exchange_range("Exchange");
-            for (int r = 0; r < W && rc == GVK_OK && W > 1 && !streamed; r++) {
-                Worker &w = workers[r];
-                const int hp = schedule[((size_t)step * W + r) * 2];
-                hipSetDevice(w.device);
-                hipStreamWaitEvent(w.exchange, w.trained, 0);
-                for (int q = 0; q < W; q++) {
-                    if (q == r) continue;
-                    Worker &u = workers[q];
-                    hipError_t e = u.device == w.device  // two workers sharing a GPU (tests): a plain device copy
-                                       ? hipMemcpyAsync(head_table(u, hp, 0), head_table(w, hp, 0), slot_floats() * 4,
-                                                        hipMemcpyDeviceToDevice, w.exchange)
-                                       : hipMemcpyPeerAsync(head_table(u, hp, 0), u.device, head_table(w, hp, 0), w.device,
-                                                            slot_floats() * 4, w.exchange);
-                    if (e != hipSuccess) rc = gvk_fail(GVK_EHIP, "exchange of head partition %d: %s", hp, hipGetErrorString(e));
-                    hipEvent_t arrived;
-                    hipEventCreateWithFlags(&arrived, hipEventDisableTiming);
-                    hipEventRecord(arrived, w.exchange);
-                    u.incoming.push_back(arrived);
-                }
-                hipEventRecord(w.sent, w.exchange);
-                w.sending = hp;
-            }
-            batch_id += (uint64_t)episode_size * config.positive_reuse * W;
+        JoinOnExit join{filler};
+        const bool more = batch_id + per_episode < num_batch;  // no pools for an episode that will not run
+        if (more && overlap_fill) filler = std::thread([&, current]() { fill_rc = guarded("sampling", [&]() { return fill(current ^ 1); }); });
+        for (Worker &w : workers) {
+            if ((rc = stage(w, order[0], current, (int)(w.visits & 1))) != GVK_OK) break;
         }
-        for (Worker &w : workers) w.visits += (uint64_t)num_step;
+        for (int k = 0; k < num_step && rc == GVK_OK; k++) {
+            const int step = order[k];
+            for (int reuse = 0; reuse < config.positive_reuse && rc == GVK_OK; reuse++)
+                rc = train_step(step, current, 0, episode_size, reuse == config.positive_reuse - 1 && k + 1 < num_step,
+                                k + 1 < num_step ? order[k + 1] : 0, current);
+            for (Worker &w : workers) w.visits++;
+            if (rc == GVK_OK) rc = exchange(step);
+        }
         {
             Range wait("Wait for sample threads");  // solver.h:645
             if (filler.joinable()) filler.join();
         }
         if (rc == GVK_OK) rc = fill_rc;
-        for (Worker &w : workers) {  // device sampling: the pools of this episode may be redrawn once it has trained
-            if (!device_sampling) break;
+        for (Worker &w : workers) {  // pool sets in HBM may be refilled once this episode has trained
+            if (!w.block_pools[0] || rc != GVK_OK) break;
             hipSetDevice(w.device);
             hipEventRecord(w.episode_end, w.compute);
             w.episode_end_valid = true;
         }
+        if (rc == GVK_OK && more && !overlap_fill) rc = fill(current ^ 1);
         current ^= 1;
     }
     for (Worker &w : workers) {
@@ -1168,26 +1592,196 @@ int gvx_solver::episode_loop() {
         for (hipEvent_t e : w.copied) hipEventDestroy(e);
         w.copied.clear();
     }
-    free_sets();
     return rc;
 }
 
 extern "C" int gvx_solver_train(gvx_solver *s, const gvx_train_config *config) {
     if (!s || !config) return gvk_fail(GVK_EINVAL, "gvx_solver_train: null solver / config");
-    GVK_TRY(s->configure(*config));
-    GVK_TRY(s->prepare_devices());
-    GVK_TRY(s->upload());
-    const auto t0 = std::chrono::steady_clock::now();
-    const uint64_t first = s->batch_id;
-    int rc = s->episode_loop();
-    s->train_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (rc == GVK_OK) {
-        log_message(0, "[time] %llu batches in %.2f s (%.1f M edge-samples/s)", (unsigned long long)(s->batch_id - first),
-                    s->train_seconds, (double)(s->batch_id - first) * s->batch_size / std::max(s->train_seconds, 1e-9) / 1e6);
-        rc = s->write_back();
+    return guarded("GraphSolver.train", [&]() -> int {
+        s->resident_pools = false;
+        GVK_TRY(s->configure(*config));
+        GVK_TRY(s->prepare_devices());
+        GVK_TRY(s->upload());
+        const auto t0 = std::chrono::steady_clock::now();
+        const uint64_t first = s->batch_id;
+        int rc = s->episode_loop();
+        s->train_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (rc == GVK_OK) {
+            log_message(0, "[time] %llu batches in %.2f s (%.1f M edge-samples/s)", (unsigned long long)(s->batch_id - first),
+                        s->train_seconds, (double)(s->batch_id - first) * s->batch_size / std::max(s->train_seconds, 1e-9) / 1e6);
+            rc = s->write_back();
+        }
+        s->release_device();
+        return rc;
+    });
+}
+
+// ---- a training run step by step (gvx.h "session") -------------------------------------------------------------------
+
+#define SESSION(s, what)                                                                            \
+    if (!(s) || !(s)->session_open) return gvk_fail(GVK_EINVAL, "%s: no open session (gvx_session_open)", what)
+
+extern "C" int gvx_session_open(gvx_solver *s, const gvx_train_config *config, int resident_pools) {
+    if (!s || !config) return gvk_fail(GVK_EINVAL, "gvx_session_open: null solver / config");
+    return guarded("gvx_session_open", [&]() -> int {
+        s->resident_pools = resident_pools != 0;
+        GVK_TRY(s->configure(*config));
+        if (s->streamed) return gvk_fail(GVK_EINVAL, "a session needs the tables resident in GPU memory");
+        GVK_TRY(s->prepare_devices());
+        GVK_TRY(s->upload());
+        GVK_TRY(s->allocate_host_sets());
+        s->session_open = true;
+        return GVK_OK;
+    });
+}
+
+extern "C" int gvx_session_steps(gvx_solver *s) { return s && s->session_open ? s->num_step : 0; }
+
+extern "C" int gvx_session_block(gvx_solver *s, int step, int worker, int *head_partition, int *tail_partition) {
+    SESSION(s, "gvx_session_block");
+    if (step < 0 || step >= s->num_step || worker < 0 || worker >= s->num_local())
+        return gvk_fail(GVK_EINVAL, "gvx_session_block: step %d / worker %d out of range", step, worker);
+    const Worker &w = s->workers[worker];
+    if (head_partition) *head_partition = s->block_of(s->order[step], w, 0);
+    if (tail_partition) *tail_partition = s->block_of(s->order[step], w, 1);
+    return GVK_OK;
+}
+
+extern "C" int gvx_session_fill(gvx_solver *s, int set) {
+    SESSION(s, "gvx_session_fill");
+    if (set != 0 && set != 1) return gvk_fail(GVK_EINVAL, "gvx_session_fill: set must be 0 or 1");
+    return guarded("gvx_session_fill", [&]() { return s->fill(set); });
+}
+
+extern "C" int gvx_session_stage(gvx_solver *s, int step, int set, int buffer) {
+    SESSION(s, "gvx_session_stage");
+    if (step < 0 || step >= s->num_step || (set | buffer) < 0 || set > 1 || buffer > 1)
+        return gvk_fail(GVK_EINVAL, "gvx_session_stage: step %d, set %d, buffer %d", step, set, buffer);
+    return guarded("gvx_session_stage", [&]() -> int {
+        for (Worker &w : s->workers) GVK_TRY(s->stage(w, s->order[step], set, buffer));
+        return GVK_OK;
+    });
+}
+
+extern "C" int gvx_session_train(gvx_solver *s, int step, int set, int buffer, int first, int count) {
+    SESSION(s, "gvx_session_train");
+    if (step < 0 || step >= s->num_step || (set | buffer) < 0 || set > 1 || buffer > 1 || first < 0 || count < 0 ||
+        first + count > s->episode_size)
+        return gvk_fail(GVK_EINVAL, "gvx_session_train: step %d, set %d, buffer %d, batches [%d, %d) of %d", step, set, buffer,
+                        first, first + count, s->episode_size);
+    return guarded("gvx_session_train", [&]() -> int {
+        for (Worker &w : s->workers) w.visits = (uint64_t)buffer;  // the buffer this visit reads
+        return s->train_step(s->order[step], set, first, count, false, 0, 0);
+    });
+}
+
+extern "C" int gvx_session_exchange(gvx_solver *s, int step) {
+    SESSION(s, "gvx_session_exchange");
+    if (step < 0 || step >= s->num_step) return gvk_fail(GVK_EINVAL, "gvx_session_exchange: step %d out of range", step);
+    return guarded("gvx_session_exchange", [&]() { return s->exchange(s->order[step]); });
+}
+
+extern "C" int gvx_session_wait(gvx_solver *s) {
+    SESSION(s, "gvx_session_wait");
+    for (Worker &w : s->workers) {
+        HIP_TRY(hipSetDevice(w.device));
+        for (size_t g = 0; g < w.gathered.size(); g++) GVK_TRY(s->wait_exchange(w, (int)g));
     }
-    s->release_device();
-    return rc;
+    return GVK_OK;
+}
+
+extern "C" int gvx_session_synchronize(gvx_solver *s) {
+    SESSION(s, "gvx_session_synchronize");
+    for (Worker &w : s->workers) {
+        HIP_TRY(hipSetDevice(w.device));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    return GVK_OK;
+}
+
+extern "C" void *gvx_session_stream(gvx_solver *s, int worker) {
+    if (!s || !s->session_open || worker < 0 || worker >= s->num_local()) return nullptr;
+    return s->workers[worker].compute;
+}
+
+extern "C" int gvx_session_loss(gvx_solver *s, int worker, float *mean_loss) {
+    SESSION(s, "gvx_session_loss");
+    if (worker < 0 || worker >= s->num_local() || !mean_loss) return gvk_fail(GVK_EINVAL, "gvx_session_loss: bad argument");
+    return guarded("gvx_session_loss", [&]() -> int {
+        Worker &w = s->workers[worker];
+        std::vector<float> host((size_t)s->batch_size);
+        HIP_TRY(hipSetDevice(w.device));
+        HIP_TRY(hipMemcpyAsync(host.data(), w.loss, host.size() * 4, hipMemcpyDeviceToHost, w.compute));
+        HIP_TRY(hipStreamSynchronize(w.compute));
+        double sum = 0;
+        for (float x : host) sum += x;
+        *mean_loss = (float)(sum / (double)host.size());
+        return GVK_OK;
+    });
+}
+
+extern "C" int gvx_session_probe(gvx_solver *s, int step, int set, int buffer, int launches, float *ms_per_launch) {
+    SESSION(s, "gvx_session_probe");
+    if (step < 0 || step >= s->num_step || launches < 1 || !ms_per_launch || s->num_negative != 1 || s->num_moment != 0)
+        return gvk_fail(GVK_EINVAL, "gvx_session_probe: needs SGD with one negative, a valid step and launches >= 1");
+    return guarded("gvx_session_probe", [&]() -> int {
+        Worker &w = s->workers[0];
+        const int hp = s->block_of(s->order[step], w, 0), tp = s->block_of(s->order[step], w, 1), B = s->batch_size;
+        const int ti = (int)s->tail_index(w, tp), batches = std::min(s->episode_size, launches);
+        HIP_TRY(hipSetDevice(w.device));
+        HIP_TRY(hipStreamWaitEvent(w.compute, w.uploaded[buffer], 0));
+        if (w.block_pools[0]) HIP_TRY(hipStreamWaitEvent(w.compute, w.filled[set], 0));
+        const uint32_t *pool = s->trained_pool(w, set, buffer, hp, tp);
+        uint32_t *negatives = nullptr;
+        HIP_TRY(hipMalloc(&negatives, (size_t)batches * B * 4));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        auto done = [&](int rc) {
+            hipFree(negatives);
+            if (e0) hipEventDestroy(e0);
+            if (e1) hipEventDestroy(e1);
+            return rc;
+        };
+        for (int b = 0; b < batches; b++) {  // fresh negatives per launch, drawn as the training kernel draws them
+            const int rc = w.negative_classes[ti]
+                               ? gvk_negative_draw_classes(w.compute, w.negative_classes[ti], w.negative_class_counts[ti], 0x51ed, b,
+                                                           negatives + (size_t)b * B, B, 1)
+                               : gvk_negative_draw(w.compute, w.negative_tables[ti], (uint32_t)s->part_ids[tp].size(), 0x51ed, b,
+                                                   negatives + (size_t)b * B, B, 1);
+            if (rc != GVK_OK) return done(rc);
+        }
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return done(gvk_fail(GVK_EHIP, "probe: events"));
+        for (int pass = 0; pass < 2; pass++) {  // an untimed sweep, then the timed one
+            if (pass == 1) hipEventRecord(e0, w.compute);
+            for (int i = 0; i < launches; i++) {
+                const int b = i % batches;
+                const int rc = gvk_probe_row_traffic(w.compute, s->dim, s->head_table(w, hp, 0), s->context_table(w, ti, 0),
+                                                     pool + (size_t)b * B * 2, negatives + (size_t)b * B, 0.0f, B);
+                if (rc != GVK_OK) return done(rc);
+            }
+        }
+        hipEventRecord(e1, w.compute);
+        if (hipEventSynchronize(e1) != hipSuccess) return done(gvk_fail(GVK_EHIP, "probe: synchronize"));
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        *ms_per_launch = ms / launches;
+        return done(GVK_OK);
+    });
+}
+
+extern "C" int gvx_session_exchange_stats(gvx_solver *s, uint64_t *bytes_sent_per_worker, uint64_t *exchanges) {
+    if (!s) return gvk_fail(GVK_EINVAL, "gvx_session_exchange_stats: null solver");
+    if (bytes_sent_per_worker) *bytes_sent_per_worker = s->exchanged_bytes;
+    if (exchanges) *exchanges = s->exchanges;
+    return GVK_OK;
+}
+
+extern "C" int gvx_session_close(gvx_solver *s) {
+    SESSION(s, "gvx_session_close");
+    return guarded("gvx_session_close", [&]() -> int {
+        const int rc = s->write_back();
+        s->release_device();
+        return rc;
+    });
 }
 
 extern "C" int gvx_solver_predict(gvx_solver *s, const int64_t *samples, size_t n, float *logits) {
@@ -1251,6 +1845,11 @@ extern "C" int gvx_solver_get(gvx_solver *s, gvx_solver_members *out) {
     out->model = s->model.c_str();
     out->optimizer = s->optimizer;
     out->batch_id = s->batch_id, out->num_batch = s->num_batch, out->train_seconds = s->train_seconds;
+    out->rank = s->first_rank, out->num_local_worker = s->num_local();
+    out->pair_order = s->grouped ? 2 : 1;
+    out->sampler_mode = s->mode, out->device_sampling = s->device_sampling;
+    out->partition_rows = s->part_rows;
+    out->transport = s->transport_name.c_str();
     return GVK_OK;
 }
 

@@ -114,7 +114,7 @@ class HipKernels(object):
                 if t.shape != (vertex if i % 2 == 0 else context).shape:
                     raise ValueError("moment table %d has the wrong shape" % i)
         return _lib.Tables(_ptr(vertex), _ptr(context), _ptr(m[0]), _ptr(m[1]), _ptr(m[2]), _ptr(m[3]),
-                           vertex.shape[0], context.shape[0])
+                           vertex.shape[0], context.shape[0], 0, 0)
 
     @staticmethod
     def _negative(negatives, table, seed, dev):

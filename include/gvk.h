@@ -93,7 +93,16 @@ typedef struct {
     float *vertex_moment2;  /* Adam */
     float *context_moment2;
     uint32_t n_vertex, n_context;
+    uint32_t flags;         /* GVK_PAIRS_* below; 0 = nothing known about the order of the pairs */
+    uint32_t reserved;
 } gvk_tables;
+
+/* gvk_tables.flags: adjacent pairs of the batch that share a head row come from ONE random walk (DeepWalk / node2vec pools
+ * in the sampler's order: a walk emits the pairs of a head node back to back, graph.cuh:357-373) — they are trained
+ * pair by pair like any others, never chained into runs on one copy of the row: chaining the head side while the context
+ * rows of the same walk are still updated concurrently shifts what is learned (link-prediction AUC +0.007 against the
+ * reference's loop on the BlogCatalog-sized shape; pair by pair: -0.001). */
+#define GVK_PAIRS_OF_WALKS 1u
 
 /* Where the negatives of a batch come from: an explicit array (the reference's negative_batch), or —
  * when `negatives` is NULL — the alias table, drawn inside the training kernel per the RNG contract. */
@@ -266,9 +275,9 @@ int gvk_probe_row_traffic(void *stream, int dim, float *vertex, float *context, 
                                      A/B library only: 1 = the per-pair kernel, generic build (run-time k); 3 = dim-128 SGD
                                      in the reference's kernel shape (one wavefront per pair, vertex row in LDS, 8192 x 512
                                      grid-stride launch) */
-#define GVK_TUNE_RUN_CAP 3        /* train_runs_kernel: longest run a lane group trains in sequence: 0 = from the batch size
-                                     (batch_size / 5120 rounded up: the generations of the reference's launch on the card it
-                                     was written for), 1 = every pair on its own, up to 64 */
+#define GVK_TUNE_RUN_CAP 3        /* train_runs_kernel: longest run a lane group trains in sequence: 0 = the default, 20 (the
+                                     generations of the reference's launch of a default batch on the card it was written
+                                     for), 1 = every pair on its own, up to 64 */
 #define GVK_TUNE_SPLIT_HITS 7     /* a batch is trained as gvk_train_launches() equal parts, one launch each, so that a launch
                                      holds at most `value` samples per row of the head table: default 2 (what keeps small
                                      partitions at the reference's learning quality); 0 = always one launch

@@ -2,13 +2,20 @@
  * SolverMixin / WorkerMixin orchestration (include/instance/graph.cuh:586-813, include/core/solver.h:87-888,
  * 1170-1623) as a C++ host runtime over the kernels (gvk.h) and the host samplers (gvs.h) — what the pybind11
  * module libgraphvite (graphvite_amd/csrc/bind/libgraphvite.cpp, the drop-in for src/graphvite.cu) is a thin
- * binding of.  One process drives every GPU it is given, like the reference: one worker per entry of device_ids,
- * each with its own HIP streams; a worker holds the whole vertex table and the context shards it owns for good,
- * and after a schedule step the workers copy the head shards they trained into each other's replicas directly,
- * GPU to GPU over xGMI (hipMemcpyPeerAsync) — no host staging, no collective library inside one process.
- * When that does not fit gpu_memory_limit, the engine falls back to the reference's scheme: one head and one tail
- * partition per worker in HBM, travelling through host memory between blocks (solver.h:1435-1504).
- * (Several processes, one GPU each, over RCCL: graphvite_amd.solver.GraphSolver.)
+ * binding of, and what graphvite_amd.solver.GraphSolver (the Python drop-in) and bench.py drive.  ONE orchestrator, two
+ * ways to place its W workers:
+ *   gvx_solver_create              one process drives every GPU it is given, like the reference: one worker per entry of
+ *                                  device_ids, each a set of HIP streams on its GPU;
+ *   gvx_solver_create_distributed  one process per GPU (torchrun / mpirun): the process is worker `rank` of `world_size`.
+ * Either way a worker holds the whole vertex table — a slab [P slots][1 + m][S][dim], the W slots of a head group
+ * contiguous — and the context shards it owns for good; before a worker trains head partition hp it brings hp to ITS slot
+ * of hp's group (at most one device-local copy), and after a schedule step ONE in-place all-gather of the group's slab
+ * hands every worker what the others trained: RCCL over xGMI (ncclCommInitAll in one process, ncclCommInitRank across
+ * processes; librccl is opened with dlopen at the first multi-GPU build).  Workers that share a GPU (device_ids = [0, 0],
+ * tests) exchange by event-ordered device copies instead, and a program may supply its own transport (gvx_transport).
+ * Random-walk pools drawn per worker are routed to the workers that train them by one all-to-all per episode.
+ * When the model does not fit gpu_memory_limit, the one-process engine falls back to the reference's scheme: one head and
+ * one tail partition per worker in HBM, travelling through host memory between blocks (solver.h:1435-1504).
  *
  * Reference interfaces replaced:
  *   gvx_solver_create   GraphSolver(device_ids, num_sampler_per_worker, gpu_memory_limit)   bind.h:438-441, solver.h:170-217
@@ -75,12 +82,40 @@ typedef struct {
     gvx_optimizer optimizer;
     uint64_t batch_id, num_batch;
     double train_seconds;        /* wall time of the episode loop of the last train() */
+    int rank, num_local_worker;  /* rank of the first local worker; how many workers this process drives */
+    int pair_order;              /* what the last train() did: 1 the sampler's order, 2 regrouped */
+    int sampler_mode;            /* GVS_MODE_* of the last train() */
+    int device_sampling;
+    uint32_t partition_rows;     /* S: rows of a partition's table */
+    const char *transport;       /* "RCCL", "device copies", "caller-supplied transport" or "" (one worker) */
 } gvx_solver_members;
 
 /* device_ids: num_device GPU ids (an id may repeat: its workers then share that GPU), or num_device == 0 for all
  * visible GPUs.  num_sampler_per_worker / gpu_memory_limit: GVX_AUTO = (usable CPUs / #worker) - 1 / free memory. */
 gvx_solver *gvx_solver_create(int dim, const int *device_ids, int num_device, int num_sampler_per_worker,
                               size_t gpu_memory_limit);
+
+/* A transport supplied by the embedding program instead of RCCL (the CPU tests run the engine over gloo this way).  Both
+ * calls are collective over the world_size processes, operate on memory of the engine's device, may be asynchronous on
+ * `stream` (the engine orders its own work behind that stream) and return GVK_OK or a negative code.
+ *   all_gather  in place: `slab` holds world_size parts of `bytes` bytes, this rank's part already at slab + rank * bytes;
+ *   all_to_all  part q of `send` arrives as part `rank` of rank q's `recv` (world_size parts of `bytes` bytes each). */
+typedef struct {
+    int (*all_gather)(void *user, void *slab, size_t bytes, void *stream);
+    int (*all_to_all)(void *user, const void *send, void *recv, size_t bytes, void *stream);
+    void *user;
+} gvx_transport;
+
+#define GVX_UNIQUE_ID_BYTES 256 /* two RCCL unique ids: the exchange communicator and the one that routes walk pools */
+/* Rank 0 calls this and broadcasts the bytes to every rank (torch.distributed, MPI, a file ...). */
+int gvx_unique_id(void *out, size_t capacity);
+
+/* One process per GPU: this process is worker `rank` of `world_size`, on GPU `device_id`.  unique_id: the bytes rank 0
+ * obtained from gvx_unique_id (ignored when `transport` is given).  Every rank must make the same build / train calls
+ * with the same arguments on the same graph; embeddings are complete on every rank after train(). */
+gvx_solver *gvx_solver_create_distributed(int dim, int rank, int world_size, int device_id, const void *unique_id,
+                                          size_t unique_id_bytes, const gvx_transport *transport,
+                                          int num_sampler_per_worker, size_t gpu_memory_limit);
 void gvx_solver_destroy(gvx_solver *s);
 
 /* Beyond the reference's arguments (off by default; takes effect at the next train()).
@@ -90,6 +125,19 @@ void gvx_solver_destroy(gvx_solver *s);
  * each slice to the worker that trains the block, GPU to GPU.  Resident (not streamed) mode only; graphs with fewer
  * than 2^32 directed edges. */
 #define GVX_DEVICE_SAMPLING 1
+/* GVX_PAIR_ORDER 0 (default): by table size — regrouped (gvk_group_pairs: the pairs of a part of a batch
+ * that share a head row made adjacent) for cache-resident tables and for shard-sized tables of independent edge draws,
+ * the sampler's order otherwise; 1: always the sampler's order; 2: always regrouped. */
+#define GVX_PAIR_ORDER 2
+/* GVX_SEED: seeds the embedding initialisation, the host samplers, the device samplers and the negative draws (default 0:
+ * the values the engine has always used). */
+#define GVX_SEED 3
+/* GVX_NEGATIVE_TABLE 0 (default): an alias table over the weight classes when they are at least 8 x fewer than the rows;
+ * 1: always one alias slot per row (the reference's); 2: always by class. */
+#define GVX_NEGATIVE_TABLE 4
+/* GVX_NODE2VEC_TABLE_LIMIT: entries of node2vec's per-edge alias tables (sum over edges of the head's degree, graph.cuh:
+ * 656-677) beyond which the CPU samplers switch to rejection over the per-vertex tables (default 2^30). */
+#define GVX_NODE2VEC_TABLE_LIMIT 5
 int gvx_solver_set(gvx_solver *s, int option, int64_t value);
 
 /* The graph is borrowed until the next build / destroy (solver.h:289).  num_partition / episode_size: GVX_AUTO. */
@@ -108,6 +156,48 @@ int gvx_solver_get(gvx_solver *s, gvx_solver_members *out);
 size_t gvx_solver_info(gvx_solver *s, char *buf, size_t capacity);
 /* word2vec binary format, GraphSolver::save_embeddings (graph.cuh:796-805) */
 int gvx_solver_save_embeddings(gvx_solver *s, const char *file_name);
+
+/* ---- a training run step by step (bench.py; custom loops) -------------------------------------------------------------
+ * gvx_solver_train is: open, then per episode { fill the next pool set while: for every schedule step { stage, train,
+ * exchange } }, then close.  The same pieces one at a time, for every LOCAL worker at once (all W in one process, one per
+ * process otherwise).  `set` is 0 / 1 (the two pool sets), `step` an index into the episode's step order
+ * (gvx_session_steps of them), a block visit trains batches [first, first + count) of the step's pool.
+ *   open      configure + device state + tables to HBM; resident_pools != 0: filled pool sets are kept in HBM, so that a
+ *             stage never crosses PCIe (what a benchmark of the GPU path wants; device sampling always is)
+ *   fill      the pools of every block the local workers train, by the CPU samplers (or on the device)
+ *   stage     the pool of `step` from `set` into device buffer `buffer` (0 / 1): H2D copy and / or regrouping pass, on the
+ *             copy stream; nothing when the pool is trained in place
+ *   train     wait for the stage and for the exchange this block depends on, bring the head partition to the worker's slot,
+ *             launch the batches; advances batch_id by count x W
+ *   exchange  the all-gather of the head group trained at `step` (asynchronous; W == 1: nothing)
+ *   wait      orders the compute streams behind every pending exchange (a fence for timed regions)
+ *   close     device tables -> host arrays (gvx_solver_embeddings), device state released. */
+int gvx_session_open(gvx_solver *s, const gvx_train_config *config, int resident_pools);
+int gvx_session_steps(gvx_solver *s);
+/* block (head partition, tail partition) local worker `worker` trains at `step` */
+int gvx_session_block(gvx_solver *s, int step, int worker, int *head_partition, int *tail_partition);
+int gvx_session_fill(gvx_solver *s, int set);
+int gvx_session_stage(gvx_solver *s, int step, int set, int buffer);
+int gvx_session_train(gvx_solver *s, int step, int set, int buffer, int first, int count);
+int gvx_session_exchange(gvx_solver *s, int step);
+int gvx_session_wait(gvx_solver *s);
+int gvx_session_synchronize(gvx_solver *s);
+int gvx_session_close(gvx_solver *s);
+/* the compute stream (hipStream_t) of a local worker: where HIP events around train calls belong */
+void *gvx_session_stream(gvx_solver *s, int worker);
+/* mean per-sample loss of the most recent batch of a local worker (synchronises its compute stream) */
+int gvx_session_loss(gvx_solver *s, int worker, float *mean_loss);
+/* The ceiling of the memory system for what the batches of a block touch (gvk_probe_row_traffic on the tables and the
+ * staged pool of local worker 0's block at `step`, negatives drawn as the training kernel draws them): `launches`
+ * back-to-back launches timed with HIP events after as many untimed ones; *ms_per_launch receives the average. */
+int gvx_session_probe(gvx_solver *s, int step, int set, int buffer, int launches, float *ms_per_launch);
+/* bytes every worker sent in exchanges since open, and their number */
+int gvx_session_exchange_stats(gvx_solver *s, uint64_t *bytes_sent_per_worker, uint64_t *exchanges);
+
+/* Opens librccl, creates a one-rank communicator on `device` and runs the engine's two collectives through it (an
+ * in-place all-gather and an all-to-all of one rank leave a buffer as it was): what a one-GPU box can check of the RCCL
+ * carrier — the library loads, the entry points exist, the call sequence is accepted. */
+int gvx_rccl_selftest(int device);
 
 /* Logging of the native runtime (glog in the reference, src/graphvite.cu:81-88): messages below `threshold`
  * (0 INFO, 1 WARNING, 2 ERROR, 3 FATAL) are dropped; the rest go to stderr, or to `sink` when one is installed. */

@@ -47,9 +47,10 @@ def main():
             s = gv.solver.GraphSolver(128, num_sampler_per_worker=int(extra.get("samplers", 8)), seed=seed, pair_order=gv.auto if order == "auto" else order,
                                       device_sampling=extra.get("device_sampling", "0") == "1")
             s.build(g, batch_size=batch, episode_size=int(extra.get("episode", episode)), num_partition=int(extra.get("partitions", 0)))
-            s.train(model="LINE", num_epoch=epochs, augmentation_step=train_kw["augmentation_step"],
+            s.train(model=extra.get("model", "LINE"), num_epoch=epochs,
+                    augmentation_step=int(extra.get("aug", train_kw["augmentation_step"])),
                     random_walk_length=train_kw.get("walk_length", 40), random_walk_batch_size=train_kw.get("walk_batch", 100),
-                    log_frequency=1 << 30)
+                    p=float(extra.get("p", 1)), q=float(extra.get("q", 1)), log_frequency=1 << 30)
             aucs.append(link_prediction_auc(s.vertex_embeddings, s.context_embeddings, [k[0] for k in keep],
                                             [k[1] for k in keep], [k[2] for k in keep]))
             print("%s epochs %d order %s seed %d: %d batches AUC %.6f (%.1f s)" % (shape, epochs, order, seed, s.batch_id,

@@ -4,6 +4,11 @@ user of the reference's Python package runs it â€” one process, device_ids=[0] â
 the device (GraphSolver(..., device_sampling=True)), one partition and the 4-partition per-GPU shape.
 
     python scripts/measure_engine.py [--epochs 100] > gpurun_out/engine_e2e.jsonl
+
+--bench (what bench.py's `end_to_end.module` leg runs in a process of its own): LINE on bench.py's own graph (synthetic
+power-law, written to an edge-list file and loaded with the module's Graph.load(file_name) like a user's dataset), one
+process, device_ids = [0 .. gpus - 1] â€” with several GPUs the engine creates its RCCL communicators with ncclCommInitAll â€”
+positives drawn on the device; prints one JSON line.
 """
 import argparse
 import json
@@ -35,12 +40,52 @@ def run(graph, name, model, epochs, threads, device_sampling, num_partition=lib.
     solver.clear()
 
 
+def bench(args):
+    import tempfile
+    edges = synthetic.power_law_edges(args.vertices, args.edges, seed=args.seed)
+    with tempfile.TemporaryDirectory() as directory:
+        path = os.path.join(directory, "edges.txt")
+        try:
+            import pandas
+            pandas.DataFrame(edges).to_csv(path, sep=" ", header=False, index=False)
+        except ImportError:
+            import numpy
+            numpy.savetxt(path, edges, fmt="%d")
+        graph = lib.graph.Graph_j()
+        t0 = time.perf_counter()
+        graph.load(path)
+        load_seconds = time.perf_counter() - t0
+    batch = 100000
+    solver = getattr(lib.solver, "GraphSolver_%d_f_j" % args.dim)(device_ids=list(range(args.gpus)), device_sampling=True,
+                                                                 seed=args.seed)
+    solver.build(graph, lib.optimizer.SGD(0.025, 0.005), num_negative=1, batch_size=batch)
+    epochs = max(args.batches * args.gpus * batch // graph.num_edge, 1)
+    t0 = time.perf_counter()
+    solver.train(model="LINE", num_epoch=epochs, augmentation_step=1, negative_weight=5, log_frequency=1 << 30)
+    wall = time.perf_counter() - t0
+    print(json.dumps({"value": solver.batch_id * batch / solver.train_seconds / 1e6, "unit": "million edge-samples/sec",
+                      "binding": "libgraphvite.solver.GraphSolver_%d_f_j(device_ids=%s, device_sampling=True)" % (
+                          args.dim, list(range(args.gpus))),
+                      "batches": solver.batch_id, "episode_seconds": solver.train_seconds, "train_seconds": wall,
+                      "num_worker": solver.num_worker, "num_partition": solver.num_partition,
+                      "episode_size": solver.episode_size, "graph_load_seconds": load_seconds}), flush=True)
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--epochs", type=int, default=100)
     p.add_argument("--quick", action="store_true", help="LINE on one partition only (profiling runs)")
+    p.add_argument("--bench", action="store_true", help="bench.py's `end_to_end.module` leg (see the docstring)")
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--vertices", type=int, default=1000000)
+    p.add_argument("--edges", type=int, default=10000000)
+    p.add_argument("--seed", type=int, default=1024)
+    p.add_argument("--dim", type=int, default=128)
+    p.add_argument("--batches", type=int, default=36000)
     args = p.parse_args()
     lib.init_logging(lib.ERROR)
+    if args.bench:
+        return bench(args)
     threads = max(cpu_budget() - 1, 1)
     graph = lib.graph.Graph_j()
     t0 = time.perf_counter()

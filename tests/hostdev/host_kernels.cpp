@@ -1,0 +1,301 @@
+// TEST INFRASTRUCTURE ONLY — never part of the product, never loaded by it.
+//
+// The device entry points of include/gvk.h implemented ON THE HOST by calling the CPU oracle (oracle/gv_oracle.c), plus the
+// allocator behind tests/hostdev/hip/hip_runtime.h.  Linked with the engine's own sources into
+// tests/hostdev/build/libgvk_host.so (tests/hostdev/Makefile), which the `-m "not gpu"` tests load through GVK_LIBRARY: the
+// solver engine's host logic then runs without a GPU, its "kernels" being the SEQUENTIAL oracle.  The GPU parity tests use
+// the same library (in a process of its own) as the sequential pipeline the HIP path is compared with.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "gvk.h"
+#include "gvk_internal.h"
+
+extern "C" {
+// oracle/gv_oracle.c
+float gvo_lr(float init_lr, int linear, int batch_id, int num_batch);
+int gvo_train(int dim, int type, float *vertex, float *context, float *vm1, float *cm1, float *vm2, float *cm2,
+              const uint32_t *batch, const uint32_t *negatives, float *loss, int batch_size, int k, float lr, float wd,
+              float negative_weight, const float *hp);
+void gvo_predict(int dim, const float *vertex, const float *context, const uint32_t *batch, float *logits, int batch_size);
+void gvo_negative_draw_batch(const float *prob, const uint32_t *alias, uint32_t count, uint64_t seed, uint32_t batch_id,
+                             int batch_size, int k, uint32_t *out);
+void gvo_negative_draw_class_batch(const uint32_t *first, const uint32_t *count, const float *prob, const uint32_t *alias,
+                                   uint32_t num_class, uint64_t seed, uint32_t batch_id, int batch_size, int k, uint32_t *out);
+void gvo_sample_pairs(const float *prob, const uint32_t *alias, const uint32_t *block_pairs, uint32_t count, uint64_t seed,
+                      uint64_t first, size_t n, uint32_t *out);
+int gvo_sample_walks_device(const uint64_t *flat, const uint32_t *edges_uv, const float *edge_prob, const uint32_t *edge_alias,
+                            uint32_t D, const float *nb_prob, const uint32_t *nb_alias, const uint32_t *sorted_nb,
+                            const uint32_t *local, int biased, float p, float q, uint64_t seed, uint64_t first_walk,
+                            uint32_t *pool, size_t pool_pairs, int L, int aug, int shuffle_base);
+}
+
+// ---- "device" memory ---------------------------------------------------------------------------------------------------
+
+extern "C" {
+size_t gvh_memory_limit = (size_t)64 << 30;
+size_t gvh_memory_used = 0;
+}
+
+namespace {
+std::mutex g_mutex;
+std::map<void *, size_t> g_blocks;
+}  // namespace
+
+hipError_t gvh_malloc(void **p, size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (gvh_memory_used + bytes > gvh_memory_limit) return hipErrorOutOfMemory;
+    *p = malloc(bytes ? bytes : 1);
+    if (!*p) return hipErrorOutOfMemory;
+    g_blocks[*p] = bytes;
+    gvh_memory_used += bytes;
+    return hipSuccess;
+}
+
+hipError_t gvh_free(void *p) {
+    if (!p) return hipSuccess;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    auto it = g_blocks.find(p);
+    if (it != g_blocks.end()) {
+        gvh_memory_used -= it->second;
+        g_blocks.erase(it);
+    }
+    free(p);
+    return hipSuccess;
+}
+
+// ---- what the tests can observe ---------------------------------------------------------------------------------------
+
+namespace {
+struct Launch {
+    uint32_t batch_id;
+    float lr;
+    int batch_size;
+    uint32_t n_vertex;
+};
+std::vector<Launch> g_launches;
+int g_split_hits = 2;
+
+void unpack(const gvk_alias_entry *table, size_t n, std::vector<float> &prob, std::vector<uint32_t> &alias) {
+    prob.resize(n), alias.resize(n);
+    for (size_t i = 0; i < n; i++) prob[i] = table[i].prob, alias[i] = table[i].alias;
+}
+}  // namespace
+
+extern "C" {
+
+int gvh_is_host_build(void) { return 1; }
+void gvh_set_memory_limit(size_t bytes) { gvh_memory_limit = bytes; }
+
+// every gvk_train / batch of gvk_train_episode since the last clear: (batch id, lr, batch size, rows of the head table)
+size_t gvh_launch_log(uint32_t *batch_ids, float *lrs, int32_t *batch_sizes, uint32_t *rows, size_t capacity) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    for (size_t i = 0; i < g_launches.size() && i < capacity; i++) {
+        if (batch_ids) batch_ids[i] = g_launches[i].batch_id;
+        if (lrs) lrs[i] = g_launches[i].lr;
+        if (batch_sizes) batch_sizes[i] = g_launches[i].batch_size;
+        if (rows) rows[i] = g_launches[i].n_vertex;
+    }
+    return g_launches.size();
+}
+void gvh_launch_log_clear(void) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    g_launches.clear();
+}
+
+// ---- include/gvk.h ---------------------------------------------------------------------------------------------------------
+
+int gvk_negative_draw(void *, const gvk_alias_entry *table, uint32_t count, uint64_t seed, uint32_t batch_id, uint32_t *negatives,
+                      int batch_size, int num_negative) {
+    std::vector<float> prob;
+    std::vector<uint32_t> alias;
+    unpack(table, count, prob, alias);
+    gvo_negative_draw_batch(prob.data(), alias.data(), count, seed, batch_id, batch_size, num_negative, negatives);
+    return GVK_OK;
+}
+
+int gvk_negative_draw_classes(void *, const gvk_class_entry *classes, uint32_t class_count, uint64_t seed, uint32_t batch_id,
+                              uint32_t *negatives, int batch_size, int num_negative) {
+    std::vector<float> prob(class_count);
+    std::vector<uint32_t> alias(class_count), first(class_count), count(class_count);
+    for (uint32_t i = 0; i < class_count; i++)
+        prob[i] = classes[i].prob, alias[i] = classes[i].alias, first[i] = classes[i].first, count[i] = classes[i].count;
+    gvo_negative_draw_class_batch(first.data(), count.data(), prob.data(), alias.data(), class_count, seed, batch_id, batch_size,
+                                  num_negative, negatives);
+    return GVK_OK;
+}
+
+static int train_batch(int dim, const gvk_optimizer *o, float lr, const gvk_tables *t, const uint32_t *pairs,
+                       const gvk_negative_source *neg, uint32_t batch_id, float *loss, int batch_size, int k, float negative_weight) {
+    std::vector<uint32_t> drawn;
+    const uint32_t *negatives = neg->negatives;
+    if (k > 0 && !negatives) {
+        drawn.resize((size_t)batch_size * k);
+        if (neg->classes)
+            gvk_negative_draw_classes(nullptr, neg->classes, neg->class_count, neg->seed, batch_id, drawn.data(), batch_size, k);
+        else if (neg->table)
+            gvk_negative_draw(nullptr, neg->table, neg->count, neg->seed, batch_id, drawn.data(), batch_size, k);
+        else
+            return gvk_fail(GVK_EINVAL, "gvk_train: num_negative > 0 but neither negatives nor an alias table given");
+        negatives = drawn.data();
+    }
+    const float hp[3] = {o->hp0, o->hp1, o->epsilon};
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        g_launches.push_back({batch_id, lr, batch_size, t->n_vertex});
+    }
+    return gvo_train(dim, o->type, t->vertex, t->context, t->vertex_moment1, t->context_moment1, t->vertex_moment2,
+                     t->context_moment2, pairs, negatives, loss, batch_size, k, lr, o->weight_decay, negative_weight, hp) == 0
+               ? GVK_OK
+               : gvk_fail(GVK_ENOMEM, "gvk_train: out of memory");
+}
+
+int gvk_train(void *, int dim, const gvk_optimizer *optimizer, const gvk_tables *tables, const uint32_t *pairs,
+              const gvk_negative_source *negative, uint32_t batch_id, float *loss, int batch_size, int num_negative,
+              float negative_weight) {
+    if (batch_size == 0) return GVK_OK;
+    return train_batch(dim, optimizer, optimizer->lr, tables, pairs, negative, batch_id, loss, batch_size, num_negative, negative_weight);
+}
+
+int gvk_train_episode(void *, int dim, const gvk_optimizer *optimizer, int linear_schedule, const gvk_tables *tables,
+                      const uint32_t *pairs, const gvk_negative_source *negative, uint32_t first_batch_id, uint32_t batch_id_stride,
+                      uint32_t total_batches, int num_batches, float *loss, int batch_size, int num_negative, float negative_weight) {
+    for (int i = 0; i < num_batches; i++) {
+        const uint32_t id = first_batch_id + (uint32_t)i * batch_id_stride;
+        const float lr = gvo_lr(optimizer->lr, linear_schedule, (int)id, (int)total_batches);
+        const int rc = train_batch(dim, optimizer, lr, tables, pairs + (size_t)i * batch_size * 2, negative, id, loss, batch_size,
+                                   num_negative, negative_weight);
+        if (rc != GVK_OK) return rc;
+    }
+    return GVK_OK;
+}
+
+int gvk_predict(void *, int dim, const float *vertex, const float *context, const uint32_t *pairs, float *logits, int batch_size) {
+    gvo_predict(dim, vertex, context, pairs, logits, batch_size);
+    return GVK_OK;
+}
+
+int gvk_alias_sample(void *, const gvk_alias_entry *, uint32_t, const double *, uint32_t *, int) {
+    return gvk_fail(GVK_EHIP, "gvk_alias_sample: not part of the host build");
+}
+
+int gvk_sample_pairs(void *, const gvk_alias_entry *table, const uint32_t *block_pairs, uint32_t count, uint64_t seed,
+                     uint64_t first_index, uint32_t *pool, size_t n) {
+    std::vector<float> prob;
+    std::vector<uint32_t> alias;
+    unpack(table, count, prob, alias);
+    gvo_sample_pairs(prob.data(), alias.data(), block_pairs, count, seed, first_index, n, pool);
+    return GVK_OK;
+}
+
+int gvk_sample_edges(void *, const gvk_edge_entry *table, uint32_t count, uint64_t seed, uint64_t first_index, uint32_t *pool, size_t n) {
+    std::vector<float> prob(count);
+    std::vector<uint32_t> alias(count), pairs((size_t)count * 2);
+    for (uint32_t i = 0; i < count; i++)
+        prob[i] = table[i].prob, alias[i] = table[i].alias, pairs[2 * (size_t)i] = table[i].tail, pairs[2 * (size_t)i + 1] = table[i].head;
+    gvo_sample_pairs(prob.data(), alias.data(), pairs.data(), count, seed, first_index, n, pool);
+    return GVK_OK;
+}
+
+int gvk_sample_walks(void *, const gvk_walk_graph *g, uint64_t seed, uint64_t first_walk, uint32_t *pool, size_t pool_pairs,
+                     int walk_length, int augmentation_step, int shuffle_base) {
+    std::vector<float> ep, np;
+    std::vector<uint32_t> ea, na;
+    unpack(g->edge_table, g->num_edge_entries, ep, ea);
+    unpack(g->neighbor_table, g->num_edge_entries, np, na);
+    return gvo_sample_walks_device(g->flat_offsets, g->edges_uv, ep.data(), ea.data(), g->num_edge_entries, np.data(), na.data(),
+                                   g->sorted_neighbors, g->local, g->biased, g->p, g->q, seed, first_walk, pool, pool_pairs,
+                                   walk_length, augmentation_step, shuffle_base) == 0
+               ? GVK_OK
+               : gvk_fail(GVK_EINVAL, "gvk_sample_walks: bad arguments");
+}
+
+// gvk_sample_walks_blocks restated: the walks of gvk_sample_walks (vertex ids instead of rows), every pair binned into the
+// pool of its (head partition, tail partition) block, stripe (walk / 64) % stripes, in walk order.
+int gvk_sample_walks_blocks(void *, const gvk_walk_graph *g, const int32_t *part, int P, uint64_t seed, uint64_t first_walk,
+                            uint64_t num_walks, uint32_t *pools, const uint64_t *offsets, uint32_t *counters, uint32_t capacity,
+                            int num_stripe, int walk_length, int aug, int shuffle_base) {
+    if (capacity % (uint32_t)num_stripe || capacity % (uint32_t)shuffle_base)
+        return gvk_fail(GVK_EINVAL, "gvk_sample_walks_blocks: stripes / shuffle base must divide the pool size");
+    std::vector<float> ep, np;
+    std::vector<uint32_t> ea, na, identity(g->num_vertex);
+    unpack(g->edge_table, g->num_edge_entries, ep, ea);
+    unpack(g->neighbor_table, g->num_edge_entries, np, na);
+    for (uint32_t v = 0; v < g->num_vertex; v++) identity[v] = v;
+    const uint64_t per_walk = (uint64_t)aug * walk_length - (uint64_t)aug * (aug - 1) / 2;
+    const uint32_t stripe_capacity = capacity / (uint32_t)num_stripe, stride = capacity / (uint32_t)shuffle_base;
+    std::vector<uint32_t> pairs(per_walk * 2);
+    for (uint64_t t = 0; t < num_walks; t++) {
+        if (gvo_sample_walks_device(g->flat_offsets, g->edges_uv, ep.data(), ea.data(), g->num_edge_entries, np.data(), na.data(),
+                                    g->sorted_neighbors, identity.data(), g->biased, g->p, g->q, seed, first_walk + t, pairs.data(),
+                                    per_walk, walk_length, aug, 1) != 0)
+            return gvk_fail(GVK_EINVAL, "gvk_sample_walks_blocks: bad arguments");
+        const uint32_t stripe = (uint32_t)((t / 64) % (uint64_t)num_stripe);
+        for (uint64_t i = 0; i < per_walk; i++) {
+            const uint32_t tail = pairs[2 * i], head = pairs[2 * i + 1];
+            const int block = part[head] * P + part[tail];
+            const uint64_t first = offsets[block];
+            if (first == ~(uint64_t)0) continue;
+            const uint32_t slot = counters[(size_t)block * num_stripe + stripe]++;
+            if (slot >= stripe_capacity) continue;
+            const uint32_t position = stripe * stripe_capacity + slot;
+            uint32_t *record = pools + 2 * (first + (position % (uint32_t)shuffle_base * stride + position / (uint32_t)shuffle_base));
+            record[0] = g->local[tail], record[1] = g->local[head];
+        }
+    }
+    return GVK_OK;
+}
+
+// per batch: a stable sort of the records by the low row bits of the head (what gvk_group_pairs promises)
+int gvk_group_pairs(void *, const uint32_t *pool_in, uint32_t *pool_out, void *workspace, size_t *workspace_bytes, int batch_size,
+                    int num_batch, int row_bits) {
+    if (!workspace_bytes) return gvk_fail(GVK_EINVAL, "gvk_group_pairs: workspace_bytes is null");
+    if (!workspace) {
+        *workspace_bytes = 16;
+        return GVK_OK;
+    }
+    const uint32_t mask = row_bits >= 32 ? 0xffffffffu : ((1u << row_bits) - 1);
+    std::vector<uint32_t> order((size_t)batch_size);
+    for (int b = 0; b < num_batch; b++) {
+        const uint32_t *in = pool_in + (size_t)b * batch_size * 2;
+        uint32_t *out = pool_out + (size_t)b * batch_size * 2;
+        for (int i = 0; i < batch_size; i++) order[i] = (uint32_t)i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return (in[2 * x + 1] & mask) < (in[2 * y + 1] & mask); });
+        std::vector<uint32_t> sorted((size_t)batch_size * 2);
+        for (int i = 0; i < batch_size; i++) sorted[2 * i] = in[2 * order[i]], sorted[2 * i + 1] = in[2 * order[i] + 1];
+        memcpy(out, sorted.data(), sorted.size() * 4);
+    }
+    return GVK_OK;
+}
+
+int gvk_probe_row_traffic(void *, int, float *, float *, const uint32_t *, const uint32_t *, float, int) { return GVK_OK; }
+
+int gvk_set_tuning(int key, int value) {
+    if (key == GVK_TUNE_SPLIT_HITS) g_split_hits = value;
+    return GVK_OK;
+}
+
+int gvk_train_launches(int batch_size, uint32_t rows) {  // the product's rule (gvk_kernels.hip launches_for)
+    if (g_split_hits <= 0 || rows == 0 || batch_size <= 0) return 1;
+    const int64_t per_launch = (int64_t)rows * g_split_hits, want = ((int64_t)batch_size + per_launch - 1) / per_launch;
+    if (want <= 1) return 1;
+    for (int64_t q = want; q <= batch_size && q <= 8 * want; q++)
+        if (batch_size % q == 0) return (int)q;
+    for (int64_t q = want; q > 1; q--)
+        if (batch_size % q == 0) return (int)q;
+    return 1;
+}
+
+int gvk_has_ab_builds(void) { return 0; }
+
+int gvk_describe_train(int dim, int, int num_negative, int, int, uint32_t, char *name, size_t capacity) {
+    snprintf(name, capacity, "host build: the sequential CPU oracle (dim %d, %d negative(s))", dim, num_negative);
+    return GVK_OK;
+}
+
+}  // extern "C"

@@ -166,7 +166,7 @@ def test_kernel_choice_by_table_size():
         return name.value.decode()
 
     assert describe(128, _lib.SGD, 1, 10312) == "train_runs_kernel<128,16,SGD,k=1> run_cap 20 in 5 launches per batch"  # BlogCatalog-sized: 5 MB
-    assert describe(128, _lib.SGD, 1, 10312, batch=5000) == "train_runs_kernel<128,16,SGD,k=1> run_cap 1"  # one generation
+    assert describe(128, _lib.SGD, 1, 10312, batch=5000) == "train_runs_kernel<128,16,SGD,k=1> run_cap 20"  # at any batch size
     assert describe(128, _lib.SGD, 1, 32767) .startswith("train_runs_kernel") and \
         describe(128, _lib.SGD, 1, 32768) == "train_kernel<128,16,SGD,k=1> run_cap 1 in 2 launches per batch"  # 16 MiB is the border
     assert describe(128, _lib.SGD, 1, 1000000) == "train_kernel<128,16,SGD,k=1> run_cap 1"          # configs[1]

@@ -138,6 +138,56 @@ def test_positive_samples_drawn_on_the_device(data, devices, partitions):
             small.train(model="LINE", num_epoch=1, augmentation_step=1)
 
 
+@pytest.mark.parametrize("workers,partitions", [(4, 4), (8, 8), (2, 8)])
+def test_several_workers_match_the_reference_training_loop(workers, partitions):
+    """Several workers, as many or more partitions, on the hub-heavy "hub100k" shape, against the reference's OWN training
+    loop (tests/golden/make_partition_golden.py).  One process, device_ids = [0] * W — the workers share the box's only
+    GPU, every schedule step ends with the slot claim and the in-place all-gather of the head group's slab (by device
+    copies; RCCL needs a GPU per rank) — means over three seeds.
+
+    The yardstick is the reference's loop at the same partition count with ONE worker, +-0.002.  With several worker
+    threads the reference itself trains 0.003 lower (0.8989 at (4, 4), 0.8994 at (8, 8) against 0.9020 / 0.9027): its
+    workers write a trained partition back to host memory at the START of their next block (WorkerMixin::load_partition,
+    solver.h:1459-1462) while the worker that trains that partition next is already loading it (solver.h:1493-1495) —
+    nothing orders the two threads (solver.h:637-643), so now and then a block trains on a stale partition and a whole
+    block of updates is lost.  Here a head shard reaches the next worker through the all-gather, ordered by events: that
+    race does not exist, and its loss must not appear — never below the reference's multi-worker figure."""
+    import os
+    lib = load_module()
+    lib.init_logging(lib.ERROR)
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_partitions.npz"))
+    n, e, communities, graph_seed, batch, epochs, aug = [int(x) for x in G["hub100k_args"]]
+    gamma, p_in = [float(x) for x in G["hub100k_gamma_p_in"]]
+    reference, episode = G["hub100k_w1_p%d" % partitions], int(G["hub100k_w1_p%d_episode" % partitions])
+    threaded = G["hub100k_w%d_p%d" % (workers, partitions)] if workers == partitions else reference
+    edges = synthetic.hub_community_edges(n, e, gamma=gamma, num_community=communities, p_in=p_in, seed=graph_seed)
+    train, (valid, test) = synthetic.link_prediction_split(edges, (100, 1, 1))
+    graph = lib.graph.Graph_j()
+    graph.load([(str(u), str(v)) for u, v in train.tolist()])
+    n2i = graph.name2id
+    keep = np.array([(n2i[str(h)], n2i[str(t)], y) for h, t, y in zip(*test) if str(h) in n2i and str(t) in n2i], np.int64)
+    aucs = []
+    for seed in (17, 18, 19):
+        solver = lib.solver.GraphSolver_128_f_j(device_ids=[0] * workers, num_sampler_per_worker=2, seed=seed)
+        solver.build(graph, num_partition=partitions, batch_size=batch, episode_size=episode)
+        solver.train(model="LINE", num_epoch=epochs, augmentation_step=aug, log_frequency=1 << 30)
+        aucs.append(auc_of(solver, keep))
+    print("hub100k, %d workers / %d partitions through the module: AUC %s (mean %.6f) | reference training loop, one worker %s "
+          "(mean %.6f), %d worker threads mean %.6f" % (workers, partitions, " ".join("%.6f" % a for a in aucs), np.mean(aucs),
+                                                        " ".join("%.6f" % a for a in reference), reference.mean(), workers,
+                                                        threaded.mean()))
+    assert abs(np.mean(aucs) - reference.mean()) <= 0.002
+    assert np.mean(aucs) >= threaded.mean() - 0.002
+
+
+def test_rccl_carrier_loads_and_runs():
+    """What a one-GPU box can check of the RCCL carrier (gvx_comm.cpp): librccl opens, a one-rank communicator is created,
+    the engine's in-place all-gather and all-to-all run through it and leave the data as it was."""
+    from graphvite_amd import _lib
+    lib = _lib.lib()
+    _lib.check(lib.gvx_rccl_selftest(0), "gvx_rccl_selftest")
+
+
 def test_custom_schedule_moments_and_resume(data):
     lib, graph, keep = data
     calls = []
