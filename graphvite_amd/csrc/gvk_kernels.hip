@@ -1099,7 +1099,7 @@ TrainKernel pick_train(int dim, int g, int opt) {
 // generations of updates to one row that launch can chain; the same cap at every batch size (round 2 scaled it with the
 // batch: a 500-sample batch then had runs of one, and walk-mode training fell 0.009 short of sequential).
 constexpr int kRunCap = 20;
-constexpr int kMaxRunCap = 64;
+constexpr int kMaxRunCap = 4096;
 
 int run_cap_for(int batch_size) {
     (void)batch_size;
@@ -1536,7 +1536,7 @@ int gvk_set_tuning(int key, int value) {
         return GVK_OK;
     }
     if (key == GVK_TUNE_RUN_CAP) {
-        if (value < 0 || value > kMaxRunCap) return fail(GVK_EINVAL, "gvk_set_tuning: run cap must be in [0, 64]");
+        if (value < 0 || value > kMaxRunCap) return fail(GVK_EINVAL, "gvk_set_tuning: run cap must be in [0, 4096]");
         g_run_cap = value;
         return GVK_OK;
     }

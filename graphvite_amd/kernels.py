@@ -2,7 +2,7 @@
 
 torch supplies device memory and streams only; every computation is a libgvk.so kernel.
 A `HipKernels` object is what `solver.GraphSolver` calls; tests for the host logic may inject an object
-with the same methods (tests/fake_kernels.py) to run the solver without a GPU.
+(the CPU tests run the engine over tests/hostdev instead: the same entry points served by the CPU oracle).
 """
 import ctypes as C
 

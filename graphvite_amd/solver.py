@@ -23,7 +23,7 @@ import numpy as np
 from . import _lib
 from .base import auto, dtype
 from .graph import Graph
-from .optimizer import LRSchedule, Optimizer
+from .optimizer import SGD, Optimizer
 
 _OPTIMIZER_TYPES = {"Default": -1, "SGD": _lib.SGD, "Momentum": _lib.MOMENTUM, "AdaGrad": _lib.ADAGRAD,
                     "RMSprop": _lib.RMSPROP, "Adam": _lib.ADAM}
@@ -305,9 +305,6 @@ class GraphSolver(object):
         self.transport = (m.transport or b"").decode()
         self.train_seconds = m.train_seconds
         self._mode = _MODES.get(m.sampler_mode, "edge")
-        if self.optimizer is not None and self.optimizer.type == "Default":  # what build() resolved `auto` to
-            self.optimizer.type, self.optimizer.init_lr, self.optimizer.lr = "SGD", m.optimizer.lr, m.optimizer.lr
-            self.optimizer.weight_decay, self.optimizer.schedule = m.optimizer.weight_decay, LRSchedule("linear")
 
     # names kept from the round-2 solver for callers that looked inside it
     _part_size = property(lambda self: self.partition_rows)
@@ -342,6 +339,9 @@ class GraphSolver(object):
         self._apply_options()
         self._check(self._lib.gvx_solver_build(self._handle, graph._handle, C.byref(o), int(num_partition), int(num_negative),
                                                int(batch_size), int(episode_size)), "GraphSolver.build")
+        if optimizer.type == "Default":  # what build() resolved `auto` to (solver.h:290-296; graph.cuh:634-636)
+            lr = optimizer.init_lr if optimizer.init_lr > 0 else 0.025
+            optimizer = SGD(lr, 5e-3, "linear")
         self.graph, self.optimizer = graph, optimizer
         self.num_vertex, self.num_edge = graph.num_vertex, graph.num_edge
         self.num_moment = optimizer.num_moment

@@ -277,7 +277,7 @@ int gvk_probe_row_traffic(void *stream, int dim, float *vertex, float *context, 
                                      grid-stride launch) */
 #define GVK_TUNE_RUN_CAP 3        /* train_runs_kernel: longest run a lane group trains in sequence: 0 = the default, 20 (the
                                      generations of the reference's launch of a default batch on the card it was written
-                                     for), 1 = every pair on its own, up to 64 */
+                                     for), 1 = every pair on its own, up to 4096 */
 #define GVK_TUNE_SPLIT_HITS 7     /* a batch is trained as gvk_train_launches() equal parts, one launch each, so that a launch
                                      holds at most `value` samples per row of the head table: default 2 (what keeps small
                                      partitions at the reference's learning quality); 0 = always one launch

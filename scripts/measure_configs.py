@@ -46,8 +46,7 @@ def run(graph, name, model, epochs, threads, **kw):
            "episode_size": s.episode_size, "device_sampling": s.device_sampling,
            "sampler_threads": 0 if s.device_sampling else threads, "batches": t["batches"],
            "million_edge_samples_per_sec": t["batches"] * 1e5 / t["episodes"] / 1e6, "episode_seconds": t["episodes"],
-           "train_seconds": wall, "configure_seconds": t["configure"], "upload_seconds": t["upload"],
-           "write_back_seconds": t["write_back"], "context_norm": float(np.abs(s.context_embeddings).mean())}
+           "train_seconds": wall, "context_norm": float(np.abs(s.context_embeddings).mean())}
     print(json.dumps(out), flush=True)
     s.clear()
 

@@ -10,7 +10,7 @@ import os
 import shutil
 import sys
 
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r2"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r3"
 SRC, DST = "gpurun_out", os.path.join("profiles", ROUND)
 os.makedirs(DST, exist_ok=True)
 
@@ -20,7 +20,7 @@ def find(directory, suffix):
     return hits[0] if hits else None
 
 
-for name in ("bench_n1.json", "bench_n1_steps20.json", "configs_2_4.jsonl", "engine_e2e.jsonl", "access_pattern_probe.jsonl", "dim_sweep.jsonl", "shard_sweep.jsonl", "parity_auc.log", "pytest_gpu_full.log", "smoke.log"):
+for name in ("bench_n1.json", "bench_n1_steps20.json", "configs_2_4.jsonl", "configs_4.jsonl", "friendster_shard.json", "engine_e2e.jsonl", "access_pattern_probe.jsonl", "dim_sweep.jsonl", "shard_sweep.jsonl", "parity_auc.log", "pytest_gpu_full.log", "smoke.log"):
     if os.path.exists(os.path.join(SRC, name)) and os.path.getsize(os.path.join(SRC, name)):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, name))
 
@@ -36,8 +36,8 @@ if trace:
     dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
     gap = sorted(int(rows[i + 1]["Start_Timestamp"]) - int(rows[i]["End_Timestamp"]) for i in range(len(rows) - 1))
     by_name = collections.Counter(r["Kernel_Name"] for r in rows)
-    summary = {"command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline "
-                          "--no-end-to-end", "kernels": dict(by_name), "launches": len(rows), "mean_ns": sum(dur) / len(dur),
+    summary = {"command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline "
+                          "--no-end-to-end (the driver's command, end-to-end legs off)", "kernels": dict(by_name), "launches": len(rows), "mean_ns": sum(dur) / len(dur),
                "min_ns": min(dur), "max_ns": max(dur), "median_gap_ns": gap[len(gap) // 2], "grid": rows[0]["Grid_Size_X"],
                "workgroup": rows[0]["Workgroup_Size_X"], "achieved_GBps": 308800000 / (sum(dur) / len(dur)),
                "fraction_of_hbm_peak": 308800000 / (sum(dur) / len(dur)) / 8000.0}
@@ -86,6 +86,16 @@ for dim in (32, 64, 96, 128, 256, 512):
         json.dump(out, open(os.path.join(DST, "pmc_summary_bench_n1.json"), "w"), indent=1)
     by_dim["dim_%d" % dim] = entry
     print("dim %d: traffic / algorithmic = %.3f" % (dim, entry["traffic_over_algorithmic"]))
+fetch, kernel = counters("pmc_FETCH_SIZE_shard96")
+write, _ = counters("pmc_WRITE_SIZE_shard96")
+if "FETCH_SIZE" in fetch and "WRITE_SIZE" in write:  # configs[4]'s kernel: dim 96 on one Friendster shard (8.2M rows)
+    f, w = fetch["FETCH_SIZE"]["mean"] * 1024, write["WRITE_SIZE"]["mean"] * 1024
+    algorithmic = (8 * 96 * 3 + 16) * 100000
+    by_dim["dim_96_friendster_shard_8200000_rows"] = {
+        "kernel": kernel, "FETCH_SIZE": fetch["FETCH_SIZE"], "WRITE_SIZE": write["WRITE_SIZE"],
+        "traffic_bytes_per_launch": 2 * f + w, "algorithmic_bytes_per_launch": algorithmic,
+        "traffic_over_algorithmic": (2 * f + w) / algorithmic}
+    print("dim 96, Friendster shard: traffic / algorithmic = %.3f" % ((2 * f + w) / algorithmic))
 if len(by_dim) > 2:
     json.dump(by_dim, open(os.path.join(DST, "pmc_summary_by_dim.json"), "w"), indent=1)
 

@@ -80,6 +80,8 @@ struct Launch {
 };
 std::vector<Launch> g_launches;
 int g_split_hits = 2;
+typedef void (*BatchObserver)(const uint32_t *pairs, int batch_size, uint32_t batch_id, const float *vertex, const float *context);
+BatchObserver g_observer = nullptr;
 
 void unpack(const gvk_alias_entry *table, size_t n, std::vector<float> &prob, std::vector<uint32_t> &alias) {
     prob.resize(n), alias.resize(n);
@@ -90,6 +92,8 @@ void unpack(const gvk_alias_entry *table, size_t n, std::vector<float> &prob, st
 extern "C" {
 
 int gvh_is_host_build(void) { return 1; }
+// called with every batch right before it is trained (tests look at the pairs a block is trained on)
+void gvh_set_batch_observer(BatchObserver observer) { g_observer = observer; }
 void gvh_set_memory_limit(size_t bytes) { gvh_memory_limit = bytes; }
 
 // every gvk_train / batch of gvk_train_episode since the last clear: (batch id, lr, batch size, rows of the head table)
@@ -149,6 +153,7 @@ static int train_batch(int dim, const gvk_optimizer *o, float lr, const gvk_tabl
         std::lock_guard<std::mutex> lock(g_mutex);
         g_launches.push_back({batch_id, lr, batch_size, t->n_vertex});
     }
+    if (g_observer) g_observer(pairs, batch_size, batch_id, t->vertex, t->context);
     return gvo_train(dim, o->type, t->vertex, t->context, t->vertex_moment1, t->context_moment1, t->vertex_moment2,
                      t->context_moment2, pairs, negatives, loss, batch_size, k, lr, o->weight_decay, negative_weight, hp) == 0
                ? GVK_OK

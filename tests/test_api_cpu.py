@@ -77,20 +77,17 @@ def test_kernel_wrappers_refuse_cpu_tensors():
         OptimizerSpec("Nadam")
 
 
-@pytest.mark.parametrize("world,order", [(1, "sampled"), (2, "grouped"), (2, "sampled"), (8, "grouped")])
-def test_bench_loop_dry_run(world, order):
-    """bench.py's own loop (block walk across warm-up / timed steps, staging pass, asynchronous exchange, max over
-    ranks, one JSON line from rank 0) executed on the CPU: gloo instead of RCCL, the oracle stand-in instead of the HIP
-    kernels.  The 8-GPU run belongs to the driver; this is the part of it that can be exercised without GPUs."""
+def _bench(world, *arguments):
+    """bench.py on the CPU: the host build of the engine (tests/hostdev, GVK_LIBRARY) instead of the HIP library, gloo
+    instead of RCCL; rank 0's JSON line."""
     import json
     import os
     import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    args = [os.path.join("tests", "bench_dry_run.py"), "--gpus", str(world), "--vertices", "400", "--edges", "4000", "--batch", "200",
-            "--dim", "32", "--steps", "23", "--warmup", "3", "--block-batches", "4", "--pair-order", order,
-            "--sampler-threads", "1"]
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "hostdev")])
+    args = ["bench.py", "--gpus", str(world)] + [str(a) for a in arguments]
     if world > 1:
         s = socket.socket()
         s.bind(("127.0.0.1", 0))
@@ -101,54 +98,49 @@ def test_bench_loop_dry_run(world, order):
     else:
         cmd = [sys.executable] + args
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    run = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=env)
-    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    env["GVK_LIBRARY"] = os.path.join(root, "tests", "hostdev", "build", "libgvk_host.so")
+    run = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900, env=env)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
     lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1  # rank 0 only
-    r = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world,partitions,order", [(1, 1, "sampled"), (2, 2, "grouped"), (2, 4, "sampled"), (8, 8, "grouped")])
+def test_bench_loop_dry_run(world, partitions, order):
+    """bench.py's own loop (block walk across warm-up / timed steps, staging pass, asynchronous exchange, max over ranks,
+    one JSON line from rank 0) executed on the CPU over the host build of the engine: one process per "GPU", the engine's
+    collectives carried by gloo.  The 8-GPU run belongs to the driver; this is the part of it that can be exercised
+    without GPUs."""
+    r = _bench(world, "--vertices", 400, "--edges", 4000, "--batch", 200, "--dim", 32, "--steps", 23, "--warmup", 3,
+               "--block-batches", 4, "--pair-order", order, "--sampler-threads", 1, "--partitions", partitions)
     assert r["n_gpus"] == world and r["steps"] == 23 and r["warmup"] == 3 and r["value"] > 0
     assert r["config"]["pair_order"].startswith(order) and "DRY RUN" in r["data"]
-    assert ("cpu_baseline" in r) == False
-    assert "%d vertex partition" % (1 if world == 1 else 2 * world) in r["config"]["parallelism"]
+    assert "cpu_baseline" not in r and "end_to_end" not in r
+    assert "%d vertex partition" % partitions in r["config"]["parallelism"]
+    assert r["config"]["shard"]["rows"] == -(-400 // partitions)
     if world > 1:
         # one collective per schedule step: every GPU sends its own head shard (ceil(400 / P) rows of dim 32, fp32) to
         # the W - 1 others, nothing else crosses the fabric in the data path of LINE
-        P = 2 * world
-        shard = -(-400 // P) * 32 * 4
+        shard = -(-400 // partitions) * 32 * 4
         assert r["exchange"]["bytes_sent_per_gpu_per_collective"] == shard * (world - 1)
-        # block visits that were completed: one per block in the residency pass, the warm-up's, the timed region's
-        # full ones (its last, partial visit has not reached its exchange when the run ends)
-        assert r["exchange"]["collectives_total"] == P * P // world + -(-3 // 4) + 23 // 4
+        assert r["exchange"]["collectives_timed"] == 23 // 4  # the region's last, partial visit has not reached its exchange
+        assert r["exchange"]["transport"] == "caller-supplied transport"
     else:
         assert r["exchange"] is None
-    assert r["config"]["block_visits_timed"] == 6 and r["roofline"]["kernel"] == "stand-in"
+    assert r["config"]["block_visits_timed"] == 6 and r["roofline"]["kernel"].startswith("host build")
 
 
 def test_bench_rounds_a_multi_gpu_run_up_to_whole_block_visits():
-    """`bench.py --gpus 2 --steps 20` as the driver launches it (no --block-batches): a block visit has the length the
-    reference's episode rule gives it (num_vertex * 175 / P / batch_size, solver.h:426-436) and the timed region is whole
-    visits, at least four — the line says how many steps that was, and every visit's exchange ran."""
-    import json
-    import os
-    import socket
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join("tests", "bench_dry_run.py"), "--gpus", "2", "--vertices", "400",
-           "--edges", "4000", "--batch", "2000", "--dim", "32", "--steps", "20", "--warmup", "5", "--sampler-threads", "1"]
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    run = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=env)
-    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
-    r = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][0])
-    block = 400 * 175 // 4 // 2000  # 8 batches per visit
+    """`bench.py --gpus 2 --steps 20` as the driver launches it (no --block-batches, P = #GPU): a block visit has the
+    length the reference's episode rule gives it (num_vertex * 175 / P / batch_size, solver.h:426-436) and the timed
+    region is whole visits, at least four — the line says how many steps that was, and every visit's exchange ran."""
+    r = _bench(2, "--vertices", 400, "--edges", 4000, "--batch", 2000, "--dim", 32, "--steps", 20, "--warmup", 5,
+               "--sampler-threads", 1)
+    block = 400 * 175 // 2 // 2000  # 17 batches per visit
     assert r["config"]["block_batches"] == block and r["steps_requested"] == 20
-    assert r["steps"] == 4 * block and r["config"]["block_visits_timed"] == 4  # 20 steps round up to 3 visits; at least 4
-    assert r["exchange"]["collectives_total"] == 4 * 4 // 2 + 1 + 4        # residency, warm-up, the four timed visits
+    assert r["steps"] == 4 * block and r["config"]["block_visits_timed"] == 4  # 20 steps round up to 2 visits; at least 4
+    assert r["exchange"]["collectives_timed"] == 4
     assert r["value"] == pytest.approx(2 * r["steps"] * 2000 / (r["ms_per_step"] * r["steps"] * 1e-3) / 1e6)
 
 

@@ -411,3 +411,59 @@ def test_auc_matches_the_reference_training_loop():
         " ".join("%.6f" % a for a in aucs), np.mean(aucs), " ".join("%.6f" % a for a in reference), reference.mean()))
     assert abs(np.mean(aucs) - reference.mean()) <= 0.002
     assert min(aucs) > reference.min() - 0.003 and max(aucs) < reference.max() + 0.003
+
+
+def test_node_classification_matches_a_restatement_of_the_reference_routine():
+    """f2: GraphApplication.node_classification's scoring — one-vs-rest logistic regression on frozen
+    embeddings, SGD(lr 1, weight decay 2e-5, momentum 0.9) until the loss has not improved for `patience` epochs, a test
+    node with n true labels assigned its n top-scoring classes, micro / macro F1 — against a numpy (float64) restatement
+    of the reference's linear_classification (python/graphvite/application/application.py:456-533) on the same fixed
+    embeddings, the same split (numpy seed) and the same initial weights (torch seed): the F1 values agree."""
+    from graphvite_amd.application.application import linear_classification
+    rng = np.random.default_rng(5)
+    n, dim, classes = 600, 32, 4
+    membership = rng.random((n, classes)) < 0.3
+    membership[np.arange(n), rng.integers(0, classes, n)] = True  # every node has at least one label
+    centres = rng.normal(0, 1, (classes, dim))
+    embeddings = (membership.astype(np.float64) @ centres + rng.normal(0, 2.5, (n, dim))).astype(np.float32)
+    labels = membership.astype(np.int64)
+    portion, patience = 0.2, 100
+
+    np.random.seed(7)
+    torch.manual_seed(3)
+    got = linear_classification(embeddings, labels, portion, normalization=False, times=1, patience=patience)
+
+    np.random.seed(7)
+    torch.manual_seed(3)
+    samples = np.random.permutation(n)
+    num_train = int(n * portion)
+    rows, cls = np.nonzero(labels[samples[:num_train]])  # one training example per (node, label) pair (application.py:463-473)
+    x = embeddings[samples[:num_train][rows]].astype(np.float64)
+    y = np.zeros((len(rows), classes))
+    y[np.arange(len(rows)), cls] = 1
+    first = torch.nn.Linear(dim, classes, bias=True)      # the initial weights the routine starts from under this seed
+    w, b = first.weight.detach().numpy().astype(np.float64).T.copy(), first.bias.detach().numpy().astype(np.float64).copy()
+    vw, vb = np.zeros_like(w), np.zeros_like(b)
+    best_loss, best_epoch = float("inf"), -1
+    for epoch in range(100000):
+        z = x @ w + b
+        loss = float(np.mean(np.maximum(z, 0) - z * y + np.log1p(np.exp(-np.abs(z)))))  # binary_cross_entropy_with_logits
+        g = (1 / (1 + np.exp(-z)) - y) / z.size
+        gw, gb = x.T @ g + 2e-5 * w, g.sum(0) + 2e-5 * b
+        vw, vb = 0.9 * vw + gw, 0.9 * vb + gb              # torch.optim.SGD: buffer = momentum * buffer + grad
+        w, b = w - vw, b - vb
+        if loss < best_loss:
+            best_epoch, best_loss = epoch, loss
+        if epoch == best_epoch + patience:
+            break
+    test = samples[num_train:]
+    logits, truth = embeddings[test].astype(np.float64) @ w + b, labels[test]
+    ordered = -np.sort(-logits, axis=1)
+    thresholds = ordered[np.arange(len(test)), truth.sum(1) - 1][:, None]
+    predictions = (logits >= thresholds).astype(np.int64)
+    tp = (predictions & truth).sum(0).astype(np.float64)
+    macro = float(np.mean(2 * tp / (truth.sum(0) + predictions.sum(0))))
+    micro = float(2 * tp.sum() / (truth.sum() + predictions.sum()))
+    print("node classification: here", got, "| restatement of the reference's routine: macro %.6f micro %.6f" % (macro, micro))
+    assert 0.5 < micro < 1.0
+    assert abs(got["macro-F1@20%"] - macro) <= 0.005 and abs(got["micro-F1@20%"] - micro) <= 0.005
