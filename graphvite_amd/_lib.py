@@ -18,6 +18,7 @@ TUNE_GENERATION = 4
 TUNE_SEGMENT_STEPS = 5
 TUNE_SKIP_LOSS = 6
 TUNE_SPLIT_HITS = 7
+TUNE_CHAIN_CAP = 8
 
 
 class AliasEntry(C.Structure):
@@ -58,7 +59,7 @@ class WalkGraph(C.Structure):
 
 # ---- include/gvx.h ---------------------------------------------------------------------------------------------------
 GVX_AUTO = 0
-GVX_DEVICE_SAMPLING, GVX_PAIR_ORDER, GVX_SEED, GVX_NEGATIVE_TABLE, GVX_NODE2VEC_TABLE_LIMIT = 1, 2, 3, 4, 5
+GVX_DEVICE_SAMPLING, GVX_PAIR_ORDER, GVX_SEED, GVX_NEGATIVE_TABLE, GVX_NODE2VEC_TABLE_LIMIT, GVX_HUB_ROWS = 1, 2, 3, 4, 5, 6
 GVX_UNIQUE_ID_BYTES = 256
 SCHEDULE_FUNCTION = C.CFUNCTYPE(C.c_float, C.c_int, C.c_int, C.c_void_p)
 TRANSPORT_ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -88,7 +89,7 @@ class SolverMembers(C.Structure):  # gvx_solver_members
                 ("optimizer", SolverOptimizer), ("batch_id", C.c_uint64), ("num_batch", C.c_uint64),
                 ("train_seconds", C.c_double), ("rank", C.c_int), ("num_local_worker", C.c_int), ("pair_order", C.c_int),
                 ("sampler_mode", C.c_int), ("device_sampling", C.c_int), ("partition_rows", C.c_uint32),
-                ("transport", C.c_char_p)]
+                ("transport", C.c_char_p), ("hub_rows", C.c_uint32)]
 
 
 class Transport(C.Structure):  # gvx_transport
@@ -124,6 +125,13 @@ def lib():
     l.gvk_train_episode.restype = i32
     l.gvk_train_episode.argtypes = [vp, i32, P(Optimizer), i32, P(Tables), vp, P(NegativeSource), u32, u32, u32,
                                     i32, vp, i32, i32, f32]
+    l.gvk_hot_plan.restype = i32
+    l.gvk_hot_plan.argtypes = [i32, i32, u32, u32, i32, P(C.c_size_t)]
+    l.gvk_hot_build.restype = i32
+    l.gvk_hot_build.argtypes = [vp, vp, C.c_size_t, vp, i32, i32, i32, P(NegativeSource), u32, u32, u32, u32]
+    l.gvk_train_episode_hot.restype = i32
+    l.gvk_train_episode_hot.argtypes = [vp, i32, P(Optimizer), i32, P(Tables), vp, P(NegativeSource), u32, u32, u32, i32, vp,
+                                        i32, i32, f32, vp, C.c_size_t, u32, u32, i32, i32]
     l.gvk_predict.restype = i32
     l.gvk_predict.argtypes = [vp, i32, vp, vp, vp, vp, i32]
     l.gvk_probe_row_traffic.restype = i32

@@ -41,6 +41,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 int g_variant = 0;         // GVK_TUNE_VARIANT
 int g_run_cap = 0;         // GVK_TUNE_RUN_CAP (0 = the default of 20, run_cap_for)
 int g_split_hits = 2;      // GVK_TUNE_SPLIT_HITS (samples per table row one launch may hold; 0 = never split a batch)
+int g_chain_cap = 0;       // GVK_TUNE_CHAIN_CAP (entries one chain task trains in sequence; 0 = the default of 256)
 #if defined(GVK_AB_BUILDS)  // knobs of the A/B library only (make ab -> build/ab/libgvk_ab.so)
 int g_lanes_per_pair = 0;  // GVK_TUNE_LANES_PER_PAIR
 int g_generation = 0;      // GVK_TUNE_GENERATION (0 = one launch per batch)
@@ -62,6 +63,7 @@ struct TrainArgs {
     int batch_size, k;
     int run_cap;  // train_runs_kernel: longest run of adjacent same-head pairs one lane group trains in sequence
     int first_sample;  // this launch trains samples [first_sample, batch_size) of the batch (a batch split over several launches)
+    uint32_t hot_vertex, hot_context;  // HOT builds: head / context rows below these local ids belong to chains (train_hot_kernel) and are not stored here
     float lr, wd, neg_weight, hp0, hp1, eps;
 };
 
@@ -263,13 +265,14 @@ __device__ __forceinline__ float update(const TrainArgs &a, float parameter, flo
 // KT > 0 fixes num_negative at compile time (the loop unrolls and every row request of the pair is issued
 // up front); DRAW fixes the negative source (-1: decided at run time).  WAVES is the occupancy the register
 // allocator is asked for (waves per SIMD).
-template <int DIM, int G, int OPT, int KT = 0, int DRAW = -1, int WAVES = 4>
-__global__ void __launch_bounds__(kBlock, WAVES) train_kernel(const TrainArgs a) {
+// HOT: the hub rows of both tables — local ids below a.hot_vertex / a.hot_context; partitions are ordered by falling
+// degree — belong to the chains of train_hot_kernel: this body reads them and never stores them.
+template <int DIM, int G, int OPT, int KT, int DRAW, int HOT>
+__device__ __forceinline__ void train_pair(const TrainArgs &a, const int tid) {
     constexpr int V = DIM / G;
     constexpr int NM = OPT == GVK_SGD ? 0 : (OPT == GVK_ADAM ? 2 : 1);  // moments per row
     constexpr int M1 = NM >= 1 ? V : 1, M2 = NM >= 2 ? V : 1;
 
-    const int tid = blockIdx.x * kBlock + threadIdx.x;
     const int s = a.first_sample + tid / G, lane = tid % G;
     if (s >= a.batch_size) return;  // whole groups leave together: G divides 64
 
@@ -358,7 +361,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_kernel(const TrainArgs a)
             v[i] -= update<OPT>(a, vi, gradient * ci, weight, vm1[NM >= 1 ? i : 0], vm2[NM >= 2 ? i : 0]);
             cur[i] -= update<OPT>(a, ci, gradient * vi, weight, cur1[NM >= 1 ? i : 0], cur2[NM >= 2 ? i : 0]);
         }
-        store_row<DIM, G>(a.context, id_cur, lane, cur);
+        if (HOT == 0 || id_cur >= a.hot_context) store_row<DIM, G>(a.context, id_cur, lane, cur);
         if constexpr (NM >= 1) store_row<DIM, G>(a.cm1, id_cur, lane, reinterpret_cast<float(&)[V]>(cur1));
         if constexpr (NM >= 2) store_row<DIM, G>(a.cm2, id_cur, lane, reinterpret_cast<float(&)[V]>(cur2));
 
@@ -388,9 +391,14 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_kernel(const TrainArgs a)
     }
 
     if (lane == 0) __builtin_nontemporal_store(sample_loss / (1 + k * a.neg_weight), a.loss + s);
-    store_row<DIM, G>(a.vertex, head, lane, v);
+    if (HOT == 0 || head >= a.hot_vertex) store_row<DIM, G>(a.vertex, head, lane, v);
     if constexpr (NM >= 1) store_row<DIM, G>(a.vm1, head, lane, reinterpret_cast<float(&)[V]>(vm1));
     if constexpr (NM >= 2) store_row<DIM, G>(a.vm2, head, lane, reinterpret_cast<float(&)[V]>(vm2));
+}
+
+template <int DIM, int G, int OPT, int KT = 0, int DRAW = -1, int WAVES = 4>
+__global__ void __launch_bounds__(kBlock, WAVES) train_kernel(const TrainArgs a) {
+    train_pair<DIM, G, OPT, KT, DRAW, 0>(a, blockIdx.x * kBlock + threadIdx.x);
 }
 
 // ---- training kernel, runs of same-head pairs ------------------------------------------------------------------
@@ -571,6 +579,227 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_runs_kernel(const TrainAr
     store_row<DIM, G>(a.vertex, head, lane, v);
     if constexpr (NM >= 1) store_row<DIM, G>(a.vm1, head, lane, reinterpret_cast<float(&)[V]>(vm1));
     if constexpr (NM >= 2) store_row<DIM, G>(a.vm2, head, lane, reinterpret_cast<float(&)[V]>(vm2));
+}
+
+// ---- hub rows: chains --------------------------------------------------------------------------------------------------
+//
+// The samples of a batch run concurrently, and of the updates that hold a row at the same time one survives (Hogwild, as
+// between two warps of the reference).  For most rows of a large table that never happens; a HUB row — the top hub of the
+// benchmark graph is the head of 1 in 100 samples and the tail of as many — is in flight hundreds of times per launch
+// and keeps a handful of its updates, where the reference's CPU solver (and its GPU kernel on the card it was written
+// for, far less concurrent) keeps them all: link-prediction AUC 0.650 against 0.668 on the headline shape.
+//
+// train_hot_kernel trains a batch as two kinds of work in ONE launch.  The hub rows of both tables — the first
+// hot_vertex / hot_context local ids; partitions are ordered by falling degree — are each owned by a CHAIN: one
+// wavefront holds the row in registers and applies every update the batch has for it one after the other (for a head
+// row the targets of its samples, negatives first; for a context row the heads it is the tail or the negative of),
+// reading the partner rows (D of them in flight) and writing nothing but its own row, once, at the end.  Everything else
+// is the per-pair body (train_pair<HOT>): every sample, all arithmetic, but hub rows are only read.  So a hub row has
+// ONE writer per launch and loses nothing; what remains of Hogwild is that a partner row may be read a few updates stale.
+// The chains' work lists (entries per hub row) are built per batch by hot_list_kernel.  A chain longer than `cap` entries
+// is cut into parts trained side by side from the row as the launch found it; their deltas add up (a few atomics).
+struct HotArgs {
+    const uint32_t *chain_start;  // [chains + 1] offsets of this batch into entries
+    const uint32_t *entries;      // partner row | label << 31 (label 1 = positive)
+    const uint32_t *extra;        // [0] = number of extra tasks, then {chain, part} records: parts 1.. of chains longer than cap
+    uint32_t chains;              // hot_vertex + hot_context
+    uint32_t extra_capacity;
+    uint32_t cap;                 // entries of one task
+    int task_blocks;              // blocks at the front of the grid that run chains
+    int what;                     // 0: chains + pairs; serialized form (tests): 1 = vertex chains, 2 = context chains, 3 = pairs
+};
+
+template <int DIM>
+struct ChainLayout {
+    static constexpr int G = DIM % 64 == 0 ? 64 : 32;  // lanes that hold the row (dims 32 and 96: half a wavefront)
+    static constexpr int V = DIM / G;
+    static constexpr int D = V <= 2 ? 16 : (V <= 4 ? 8 : 4);  // partner rows in flight
+};
+
+__device__ __forceinline__ float lane_value(float x, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+}
+
+// Sum over lanes 0 .. G - 1 (G = 32 or 64), the same value in every lane.
+template <int G>
+__device__ __forceinline__ float chain_sum(float x) {
+    x = group_sum<16>(x);  // every lane of a 16-lane row holds the row's sum
+    float s = lane_value(x, 0) + lane_value(x, 16);
+    if (G == 64) s += lane_value(x, 32) + lane_value(x, 48);
+    return s;
+}
+
+template <int DIM>
+__device__ __forceinline__ void train_chain(const TrainArgs &a, const HotArgs &h, const uint32_t task) {
+    typedef ChainLayout<DIM> L;
+    constexpr int G = L::G, V = L::V, D = L::D, EB = G;  // EB: entries per fetch of the work list
+    static_assert(EB % D == 0, "the entry window moves in steps of D");
+    const int lane = threadIdx.x & 63;
+    uint32_t chain = task, part = 0;
+    if (task >= h.chains) {
+        const uint32_t x = task - h.chains, n = h.extra[0] < h.extra_capacity ? h.extra[0] : h.extra_capacity;
+        if (x >= n) return;
+        chain = h.extra[1 + 2 * x], part = h.extra[2 + 2 * x];
+    }
+    const bool is_vertex = chain < a.hot_vertex;
+    if ((h.what == 1 && !is_vertex) || (h.what == 2 && is_vertex)) return;
+    const uint32_t first = h.chain_start[chain], last = h.chain_start[chain + 1];
+    const uint32_t begin = first + part * h.cap;
+    if (begin >= last) return;
+    const uint32_t end = last - begin > h.cap ? begin + h.cap : last;
+    const bool split = last - first > h.cap;  // several tasks train this row: their deltas add up
+    if (lane >= G) return;
+    float *own_table = is_vertex ? a.vertex : a.context;
+    const float *partner = is_vertex ? a.context : a.vertex;
+    const uint32_t row = is_vertex ? chain : chain - a.hot_vertex;
+
+    float own[V], own0[V];
+    load_row<DIM, G>(own_table, row, lane, own);
+    copy_row(own0, own);
+    // the work list, EB entries per fetch, two fetches resident: entries [blk, blk + 2 EB)
+    uint32_t blk = begin;
+    uint32_t e_cur = blk + lane < end ? h.entries[blk + lane] : 0;
+    uint32_t e_nxt = blk + EB + lane < end ? h.entries[blk + EB + lane] : 0;
+    auto entry = [&](const uint32_t p) -> uint32_t {
+        const uint32_t o = p - blk;
+        return (uint32_t)(o < EB ? __builtin_amdgcn_readlane((int)e_cur, (int)o) : __builtin_amdgcn_readlane((int)e_nxt, (int)(o - EB)));
+    };
+    float ring[D][V];
+#pragma unroll
+    for (int i = 0; i < D; i++)
+        if (begin + i < end) load_row<DIM, G>(partner, entry(begin + i) & 0x7fffffffu, lane, ring[i]);
+    float unused1 = 0, unused2 = 0;
+    for (uint32_t base = begin; base < end; base += D) {
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            const uint32_t p = base + i;
+            if (p < end) {
+                const uint32_t e = entry(p);
+                float c[V];
+                copy_row(c, ring[i]);
+                if (p + D < end) load_row<DIM, G>(partner, entry(p + D) & 0x7fffffffu, lane, ring[i]);
+                // forward / backward of one target: model/graph.h:40-58, gpu/graph.cuh:77-87 — on the own row only
+                float partial = 0;
+#pragma unroll
+                for (int x = 0; x < V; x++) partial += own[x] * c[x];
+                const float prob = sigmoidf(chain_sum<G>(partial));
+                const bool positive = (e >> 31) != 0;
+                const float gradient = positive ? prob - 1 : prob, weight = positive ? 1.0f : a.neg_weight;
+#pragma unroll
+                for (int x = 0; x < V; x++) own[x] -= update<GVK_SGD>(a, own[x], gradient * c[x], weight, unused1, unused2);
+            }
+        }
+        if (base + D >= blk + EB) {  // the next steps prefetch from beyond e_nxt: move the window
+            blk += EB;
+            e_cur = e_nxt;
+            e_nxt = blk + EB + lane < end ? h.entries[blk + EB + lane] : 0;
+        }
+    }
+    if (split) {
+        typedef Layout<DIM, G> R;
+        float *p = own_table + (size_t)row * DIM + lane * R::CW;
+#pragma unroll
+        for (int c = 0; c < R::NC; c++)
+#pragma unroll
+            for (int x = 0; x < R::CW; x++)
+                __hip_atomic_fetch_add(p + c * G * R::CW + x, own[c * R::CW + x] - own0[c * R::CW + x], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        store_row<DIM, G>(own_table, row, lane, own);
+    }
+}
+
+template <int DIM, int G, int KT>
+__global__ void __launch_bounds__(kBlock, 4) train_hot_kernel(const TrainArgs a, const HotArgs h) {
+    if ((int)blockIdx.x < h.task_blocks) {
+        train_chain<DIM>(a, h, blockIdx.x * (kBlock / 64) + threadIdx.x / 64);
+        return;
+    }
+    train_pair<DIM, G, GVK_SGD, KT, 1, 1>(a, (blockIdx.x - h.task_blocks) * kBlock + threadIdx.x);
+}
+
+// The chains' work lists, one workgroup per batch: counting sort of the batch's updates to hub rows by row.  Chain c <
+// hot_vertex is head row c: per sample with that head, the sample's k negatives (label 0) then its tail (label 1), in
+// that order.  Chain hot_vertex + r is context row r: the head of every sample r is the tail (label 1) or a negative
+// (label 0) of.  Negatives are drawn exactly as the training kernel draws them (same counters, same tables).  The order
+// of the samples inside a chain is the order the atomics retire in — any order is a valid sequential order.
+constexpr int kListThreads = 1024;
+
+__global__ void __launch_bounds__(kListThreads) hot_list_kernel(TrainArgs a, const uint32_t first_batch_id, const uint32_t stride,
+                                                                uint32_t *chain_start_all, uint32_t *entries_all, uint32_t *extra_all,
+                                                                const uint32_t entry_capacity, const uint32_t extra_capacity,
+                                                                const uint32_t cap) {
+    extern __shared__ uint32_t bins[];  // [chains]
+    __shared__ uint32_t wave_total[kListThreads / 64];
+    __shared__ uint32_t extra_count;
+    const uint32_t chains = a.hot_vertex + a.hot_context;
+    const int B = a.batch_size, k = a.k;
+    const u32x2 *records = reinterpret_cast<const u32x2 *>(a.pairs) + (size_t)blockIdx.x * B;
+    uint32_t *chain_start = chain_start_all + (size_t)blockIdx.x * (chains + 1);
+    uint32_t *entries = entries_all + (size_t)blockIdx.x * entry_capacity;
+    uint32_t *extra = extra_all + (size_t)blockIdx.x * (1 + 2 * (size_t)extra_capacity);
+    a.batch_id = first_batch_id + blockIdx.x * stride;
+
+    for (uint32_t i = threadIdx.x; i < chains; i += kListThreads) bins[i] = 0;
+    if (threadIdx.x == 0) extra_count = 0;
+    __syncthreads();
+    // A: how many entries every chain gets
+    for (int s = threadIdx.x; s < B; s += kListThreads) {
+        const u32x2 pr = records[s];
+        if (pr.y < a.hot_vertex) atomicAdd(&bins[pr.y], (uint32_t)(k + 1));
+        if (pr.x < a.hot_context) atomicAdd(&bins[a.hot_vertex + pr.x], 1u);
+        for (int j = 0; j < k; j++) {
+            const Draw d = negative_slot(a, (uint32_t)s, (uint32_t)j);
+            const uint32_t n = resolve(a, d, load_entry(a, d));
+            if (n < a.hot_context) atomicAdd(&bins[a.hot_vertex + n], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan over the chains: thread t owns the bins [t * per, (t + 1) * per)
+    {
+        const uint32_t per = (chains + kListThreads - 1) / kListThreads;
+        const uint32_t lo = threadIdx.x * per < chains ? threadIdx.x * per : chains;
+        const uint32_t hi = lo + per < chains ? lo + per : chains;
+        uint32_t sum = 0;
+        for (uint32_t i = lo; i < hi; i++) sum += bins[i];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        uint32_t inclusive = sum;
+        for (int step = 1; step < 64; step <<= 1) {
+            const uint32_t up = __shfl_up(inclusive, step);
+            if (lane >= step) inclusive += up;
+        }
+        if (lane == 63) wave_total[wave] = inclusive;
+        __syncthreads();
+        uint32_t running = inclusive - sum;
+        for (int w = 0; w < wave; w++) running += wave_total[w];
+        for (uint32_t i = lo; i < hi; i++) {
+            const uint32_t count = bins[i];
+            chain_start[i] = running;
+            bins[i] = running;  // the chain's cursor
+            for (uint32_t part = 1; part * cap < count; part++) {  // a long chain: parts 1.. are extra tasks
+                const uint32_t slot = atomicAdd(&extra_count, 1u);
+                if (slot < extra_capacity) extra[1 + 2 * slot] = i, extra[2 + 2 * slot] = part;
+            }
+            running += count;
+        }
+        if (threadIdx.x == kListThreads - 1) chain_start[chains] = running;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) extra[0] = extra_count;
+    // B: scatter
+    for (int s = threadIdx.x; s < B; s += kListThreads) {
+        const u32x2 pr = records[s];
+        const bool hot_head = pr.y < a.hot_vertex;
+        uint32_t at = hot_head ? atomicAdd(&bins[pr.y], (uint32_t)(k + 1)) : 0;
+        for (int j = 0; j < k; j++) {
+            const Draw d = negative_slot(a, (uint32_t)s, (uint32_t)j);
+            const uint32_t n = resolve(a, d, load_entry(a, d));
+            if (hot_head) entries[at + j] = n;
+            if (n < a.hot_context) entries[atomicAdd(&bins[a.hot_vertex + n], 1u)] = pr.y;
+        }
+        if (hot_head) entries[at + k] = pr.x | 0x80000000u;
+        if (pr.x < a.hot_context) entries[atomicAdd(&bins[a.hot_vertex + pr.x], 1u)] = pr.y | 0x80000000u;
+    }
 }
 
 #if defined(GVK_AB_BUILDS)  // A/B baselines: only in build/ab/libgvk_ab.so (make ab), never in the product library
@@ -1307,9 +1536,167 @@ int launch_train(hipStream_t stream, int dim, const gvk_optimizer *o, float lr, 
     return check_launch("gvk_train");
 }
 
+
+// ---- hub rows: work lists + launch (train_hot_kernel) -----------------------------------------------------------------
+
+struct HotLayout {
+    size_t chain_start = 0, entries = 0, extra = 0, bytes = 0;  // offsets into the workspace
+    uint32_t chains = 0, entry_capacity = 0, extra_capacity = 0, cap = 0;
+};
+
+constexpr uint32_t kMaxChains = 32768;  // one LDS counter per chain in hot_list_kernel (128 KB of the CU's 160 KB)
+
+// entries one chain task trains in sequence: whole samples for head chains
+uint32_t chain_cap_for(int k) {
+    const uint32_t want = g_chain_cap > 0 ? (uint32_t)g_chain_cap : 256u;
+    return (want + (uint32_t)k) / (uint32_t)(k + 1) * (uint32_t)(k + 1);
+}
+
+HotLayout hot_layout(int batch_size, int k, uint32_t hot_vertex, uint32_t hot_context, int num_batch) {
+    HotLayout l;
+    l.chains = hot_vertex + hot_context;
+    l.cap = chain_cap_for(k);
+    // a sample adds at most k + 1 entries to its head's chain and one to the chain of each of its k + 1 targets
+    l.entry_capacity = (uint32_t)(2 * (size_t)(k + 1) * (size_t)batch_size);
+    l.extra_capacity = l.entry_capacity / l.cap + 1;
+    auto align = [](size_t x) { return (x + 255) / 256 * 256; };
+    l.chain_start = 0;
+    l.entries = align((size_t)num_batch * (l.chains + 1) * 4);
+    l.extra = l.entries + align((size_t)num_batch * l.entry_capacity * 4);
+    l.bytes = l.extra + align((size_t)num_batch * (1 + 2 * (size_t)l.extra_capacity) * 4);
+    return l;
+}
+
+int validate_hot(const char *what, int batch_size, int k, uint32_t hot_vertex, uint32_t hot_context, int num_batch) {
+    if (batch_size <= 0 || k < 0 || num_batch < 0) return gvk_fail(GVK_EINVAL, "%s: bad sizes", what);
+    if ((uint64_t)hot_vertex + hot_context == 0) return gvk_fail(GVK_EINVAL, "%s: no hub rows given", what);
+    if ((uint64_t)hot_vertex + hot_context > kMaxChains)
+        return gvk_fail(GVK_EINVAL, "%s: at most %u hub rows in all (%u + %u given)", what, kMaxChains, hot_vertex, hot_context);
+    if (2 * (uint64_t)(k + 1) * (uint64_t)batch_size > 0x7fffffffull) return gvk_fail(GVK_EINVAL, "%s: batch too large", what);
+    return GVK_OK;
+}
+
+void fill_negative(TrainArgs &a, const gvk_negative_source *neg) {
+    a.negatives = nullptr; a.table = neg->table; a.seed = neg->seed; a.count = neg->count;
+    if (neg->classes) a.classes = neg->classes, a.count = neg->class_count;
+}
+
+typedef void (*HotKernel)(const TrainArgs, const HotArgs);
+
+HotKernel pick_hot(int dim, int k) {
+#define GVK_HOT(D, GG) case D: return k == 1 ? train_hot_kernel<D, GG, 1> : train_hot_kernel<D, GG, 0>;
+    switch (dim) {
+        GVK_HOT(32, 8) GVK_HOT(64, 16) GVK_HOT(96, 8) GVK_HOT(128, 16) GVK_HOT(256, 16) GVK_HOT(512, 32)
+    }
+#undef GVK_HOT
+    return nullptr;
+}
+
 }  // namespace
 
 extern "C" {
+
+int gvk_hot_plan(int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, size_t *bytes) {
+    if (!bytes) return fail(GVK_EINVAL, "gvk_hot_plan: bytes is null");
+    int rc = validate_hot("gvk_hot_plan", batch_size, num_negative, hot_vertex, hot_context, num_batch);
+    if (rc != GVK_OK) return rc;
+    *bytes = hot_layout(batch_size, num_negative, hot_vertex, hot_context, num_batch).bytes;
+    return GVK_OK;
+}
+
+int gvk_hot_build(void *stream, void *workspace, size_t workspace_bytes, const uint32_t *pool, int batch_size, int num_batch,
+                  int num_negative, const gvk_negative_source *negative, uint32_t first_batch_id, uint32_t batch_id_stride,
+                  uint32_t hot_vertex, uint32_t hot_context) {
+    int rc = validate_hot("gvk_hot_build", batch_size, num_negative, hot_vertex, hot_context, num_batch);
+    if (rc != GVK_OK) return rc;
+    if (num_batch == 0) return GVK_OK;
+    if (!workspace || !pool || !negative) return fail(GVK_EINVAL, "gvk_hot_build: null workspace / pool / negative source");
+    if (negative->negatives) return fail(GVK_EINVAL, "gvk_hot_build: the chains need negatives drawn on the device");
+    if (num_negative > 0 && (!negative->table || negative->count == 0) && (!negative->classes || negative->class_count == 0))
+        return fail(GVK_EINVAL, "gvk_hot_build: no alias table given");
+    const HotLayout l = hot_layout(batch_size, num_negative, hot_vertex, hot_context, num_batch);
+    if (workspace_bytes < l.bytes) return gvk_fail(GVK_EINVAL, "gvk_hot_build: workspace holds %zu bytes, %zu needed", workspace_bytes, l.bytes);
+    TrainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pairs = pool;
+    fill_negative(a, negative);
+    a.batch_size = batch_size; a.k = num_negative;
+    a.hot_vertex = hot_vertex; a.hot_context = hot_context;
+    char *base = static_cast<char *>(workspace);
+    const size_t lds = (size_t)l.chains * 4;
+    if (lds > 48 * 1024) {  // beyond the default limit of dynamic LDS the kernel needs the attribute (per device)
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(hot_list_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kMaxChains * 4));
+        if (e != hipSuccess) return gvk_fail(GVK_EHIP, "gvk_hot_build: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(hot_list_kernel, dim3((unsigned)num_batch), dim3(kListThreads), lds, (hipStream_t)stream, a, first_batch_id,
+                       batch_id_stride, reinterpret_cast<uint32_t *>(base + l.chain_start), reinterpret_cast<uint32_t *>(base + l.entries),
+                       reinterpret_cast<uint32_t *>(base + l.extra), l.entry_capacity, l.extra_capacity, l.cap);
+    return check_launch("gvk_hot_build");
+}
+
+int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer, int linear_schedule, const gvk_tables *tables,
+                          const uint32_t *pairs, const gvk_negative_source *negative, uint32_t first_batch_id,
+                          uint32_t batch_id_stride, uint32_t total_batches, int num_batches, float *loss, int batch_size,
+                          int num_negative, float negative_weight, const void *workspace, size_t workspace_bytes,
+                          uint32_t hot_vertex, uint32_t hot_context, int workspace_batches, int serialized) {
+    if (num_batches < 0 || num_batches > workspace_batches) return fail(GVK_EINVAL, "gvk_train_episode_hot: more batches than the work lists cover");
+    int rc = validate_train(dim, optimizer, tables, pairs, negative, loss, batch_size, num_negative);
+    if (rc <= 0) return rc;
+    rc = validate_hot("gvk_train_episode_hot", batch_size, num_negative, hot_vertex, hot_context, workspace_batches);
+    if (rc != GVK_OK) return rc;
+    if (optimizer->type != GVK_SGD) return fail(GVK_EINVAL, "gvk_train_episode_hot: chains exist for SGD only");
+    if (negative->negatives) return fail(GVK_EINVAL, "gvk_train_episode_hot draws negatives on device");
+    if (hot_vertex > tables->n_vertex || hot_context > tables->n_context)
+        return fail(GVK_EINVAL, "gvk_train_episode_hot: more hub rows than table rows");
+    const HotLayout l = hot_layout(batch_size, num_negative, hot_vertex, hot_context, workspace_batches);
+    if (!workspace || workspace_bytes < l.bytes) return fail(GVK_EINVAL, "gvk_train_episode_hot: workspace too small (gvk_hot_plan)");
+    const HotKernel kernel = pick_hot(dim, num_negative);
+    if (!kernel) return fail(GVK_EDIM, "gvk_train_episode_hot: no kernel for this dim");
+    const int lanes = default_lanes(dim);
+    const char *base = static_cast<const char *>(workspace);
+    TrainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.vertex = tables->vertex; a.context = tables->context;
+    a.loss = loss;
+    fill_negative(a, negative);
+    a.batch_size = batch_size; a.k = num_negative; a.run_cap = 1;
+    a.wd = optimizer->weight_decay; a.neg_weight = negative_weight;
+    a.hot_vertex = hot_vertex; a.hot_context = hot_context;
+    HotArgs h;
+    memset(&h, 0, sizeof(h));
+    h.chains = l.chains; h.extra_capacity = l.extra_capacity; h.cap = l.cap;
+    const int tasks = (int)(l.chains + l.extra_capacity);
+    const int task_blocks = (tasks + kBlock / 64 - 1) / (kBlock / 64);
+    const unsigned pair_blocks = (unsigned)(((int64_t)batch_size * lanes + kBlock - 1) / kBlock);
+    for (int i = 0; i < num_batches; i++) {
+        const uint32_t id = first_batch_id + (uint32_t)i * batch_id_stride;
+        float scale = 1;
+        if (linear_schedule) {  // optimizer.h:77-79
+            scale = 1 - float(int(id)) / int(total_batches);
+            if (scale < 1e-4f) scale = 1e-4f;
+        }
+        a.lr = optimizer->lr * scale;
+        a.batch_id = id;
+        a.pairs = pairs + (size_t)i * batch_size * 2;
+        h.chain_start = reinterpret_cast<const uint32_t *>(base + l.chain_start) + (size_t)i * (l.chains + 1);
+        h.entries = reinterpret_cast<const uint32_t *>(base + l.entries) + (size_t)i * l.entry_capacity;
+        h.extra = reinterpret_cast<const uint32_t *>(base + l.extra) + (size_t)i * (1 + 2 * (size_t)l.extra_capacity);
+        if (!serialized) {
+            h.what = 0, h.task_blocks = task_blocks;
+            hipLaunchKernelGGL(kernel, dim3((unsigned)task_blocks + pair_blocks), dim3(kBlock), 0, (hipStream_t)stream, a, h);
+        } else {  // the same work as three launches in a fixed order: vertex chains, context chains, pairs (what the oracle restates)
+            h.task_blocks = task_blocks;
+            h.what = 1;
+            hipLaunchKernelGGL(kernel, dim3((unsigned)task_blocks), dim3(kBlock), 0, (hipStream_t)stream, a, h);
+            h.what = 2;
+            hipLaunchKernelGGL(kernel, dim3((unsigned)task_blocks), dim3(kBlock), 0, (hipStream_t)stream, a, h);
+            h.what = 3, h.task_blocks = 0;
+            hipLaunchKernelGGL(kernel, dim3(pair_blocks), dim3(kBlock), 0, (hipStream_t)stream, a, h);
+        }
+    }
+    return check_launch("gvk_train_episode_hot");
+}
 
 int gvk_train(void *stream, int dim, const gvk_optimizer *optimizer, const gvk_tables *tables,
               const uint32_t *pairs, const gvk_negative_source *negative, uint32_t batch_id, float *loss,
@@ -1538,6 +1925,11 @@ int gvk_set_tuning(int key, int value) {
     if (key == GVK_TUNE_RUN_CAP) {
         if (value < 0 || value > kMaxRunCap) return fail(GVK_EINVAL, "gvk_set_tuning: run cap must be in [0, 4096]");
         g_run_cap = value;
+        return GVK_OK;
+    }
+    if (key == GVK_TUNE_CHAIN_CAP) {
+        if (value < 0 || value > (1 << 20)) return fail(GVK_EINVAL, "gvk_set_tuning: chain cap must be in [0, 2^20]");
+        g_chain_cap = value;
         return GVK_OK;
     }
     if (key == GVK_TUNE_SPLIT_HITS) {

@@ -46,6 +46,9 @@ namespace {
 constexpr int kMaxPartition = 16;  // solver.h:51-57
 constexpr int kMinBatchSize = 10000;
 constexpr int kSamplePerVertex = 175;
+constexpr double kHubHits = 2;          // GVX_HUB_ROWS -1: a row a batch is expected to hit this often is a hub row
+constexpr uint64_t kMaxHubRows = 16384;  // per table (gvk_hot_build counts the chains of both tables in LDS)
+constexpr int kHubChunk = 128;          // batches whose work lists are built at once
 constexpr int kMinEpisodeSample = 20000000;
 constexpr int kExpectedDegree = 1600;  // graph.cuh:55
 constexpr float kMaxNegativeWeight = 10;
@@ -121,6 +124,8 @@ struct Worker {
     uint32_t *pool[2] = {nullptr, nullptr}, *landing = nullptr;
     void *group_workspace = nullptr;
     size_t group_workspace_bytes = 0;
+    void *hub_workspace = nullptr;  // work lists of the hub rows' chains for kHubChunk batches (gvk_hot_build)
+    size_t hub_workspace_bytes = 0;
     hipEvent_t uploaded[2] = {nullptr, nullptr}, released[2] = {nullptr, nullptr}, trained = nullptr;
     bool released_valid[2] = {false, false};
     std::vector<hipEvent_t> copied;     // H2D copies of the current pool set still reading pinned memory
@@ -162,6 +167,7 @@ struct gvx_solver {
     size_t memory_request = 0, gpu_memory_limit = 0, gpu_memory_cost = 0;
     uint64_t seed = 0;
     int pair_order_request = 0, negative_table_request = 0;
+    int64_t hub_rows_request = 0;  // GVX_HUB_ROWS: 0 off, -1 by expected hits per batch, N > 0 the first N rows of every table
     uint64_t node2vec_table_limit = (uint64_t)1 << 30;
     // build
     const gvs_graph *graph = nullptr;
@@ -202,6 +208,10 @@ struct gvx_solver {
     std::vector<std::vector<int>> claimed;  // per head group: the heads (rank order) it was last arranged for
     uint64_t exchanged_bytes = 0, exchanges = 0;
     bool grouped = false;  // this training regroups its pools (pair order)
+    // hub rows trained by chains (gvk_train_episode_hot): per partition, how many of its first rows (they are
+    // ordered by falling degree) are owned by a chain when the partition is a block's head / tail table; 0 everywhere = off
+    std::vector<uint32_t> hub_rows;
+    bool hubs = false;
     bool resident_pools = false, session_open = false;
     std::vector<uint32_t *> host_sets[2];  // pinned host pools, two sets, one pool per block (index hp * P + tp)
     std::string info_text;
@@ -230,7 +240,7 @@ struct gvx_solver {
         for (Worker &w : workers) {
             hipSetDevice(w.device);
             hipFree(w.head), hipFree(w.context), hipFree(w.loss), hipFree(w.pool[0]), hipFree(w.pool[1]);
-            hipFree(w.landing), hipFree(w.group_workspace);
+            hipFree(w.landing), hipFree(w.group_workspace), hipFree(w.hub_workspace);
             for (auto *t : w.negative_tables) hipFree(t);
             for (auto *t : w.negative_classes) hipFree(t);
             hipFree(w.block_pools[0]), hipFree(w.block_pools[1]), hipFree(w.route_send), hipFree(w.route_recv);
@@ -532,6 +542,10 @@ extern "C" int gvx_solver_set(gvx_solver *s, int option, int64_t value) {
         s->seed = (uint64_t)value;
         return GVK_OK;
     }
+    if (option == GVX_HUB_ROWS && value >= -1) {
+        s->hub_rows_request = value;
+        return GVK_OK;
+    }
     if (option == GVX_NODE2VEC_TABLE_LIMIT && value >= 0) {
         s->node2vec_table_limit = (uint64_t)value;
         return GVK_OK;
@@ -711,6 +725,33 @@ int gvx_solver::configure(const gvx_train_config &in) {
     grouped = pair_order_request == 2 ||
               (pair_order_request == 0 && dim >= 64 && !walk_ordered() &&
                (table_bytes < ((size_t)16 << 20) || (table_bytes < ((size_t)256 << 20) && mode == GVS_MODE_EDGE)));
+    // hub rows (GVX_HUB_ROWS): the rows a batch is expected to hit kHubHits times or more — as a head / tail (degree share of
+    // the partition) or as a negative (share of degree^exponent) — are trained by chains; their batches keep the sampler's order
+    hub_rows.assign(num_partition, 0);
+    hubs = false;
+    if (hub_rows_request != 0 && optimizer.type == GVK_SGD && optimizer.schedule != 2) {
+        const float *vertex_weights = gvs_graph_vertex_weights(graph);
+        for (int p = 0; p < num_partition; p++) {
+            const std::vector<uint32_t> &ids = part_ids[p];
+            uint64_t rows = 0;
+            if (hub_rows_request > 0) {
+                rows = (uint64_t)hub_rows_request;
+            } else {
+                double total = 0, total_negative = 0;
+                for (uint32_t id : ids) total += vertex_weights[id], total_negative += std::pow((double)vertex_weights[id], (double)c.negative_sample_exponent);
+                for (uint32_t id : ids) {  // falling degree: stop at the first row below both thresholds
+                    const double w = vertex_weights[id];
+                    const bool often = batch_size * w >= kHubHits * total ||
+                                       (double)batch_size * num_negative * std::pow(w, (double)c.negative_sample_exponent) >= kHubHits * total_negative;
+                    if (!often) break;
+                    rows++;
+                }
+            }
+            hub_rows[p] = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(rows, ids.size()), kMaxHubRows);
+            hubs = hubs || hub_rows[p] > 0;
+        }
+        if (hubs) grouped = false;
+    }
     if (routed()) {
         if (pool_size % num_worker)
             return gvk_fail(GVK_EINVAL, "episode_size * batch_size (%zu) must be a multiple of #worker (%d) for the "
@@ -1388,7 +1429,25 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int
         }
         int n = 1;  // up to, not including, this worker's next logging batch
         while (n < end - done && (first + (uint64_t)n * W) % config.log_frequency) n++;
-        if (optimizer.schedule != 2) {
+        const uint32_t kv = hubs ? hub_rows[hp] : 0, kc = hubs ? hub_rows[tp] : 0;
+        if (kv + kc > 0 && optimizer.schedule != 2) {
+            // hub rows by chains: the work lists of up to kHubChunk batches, then their launches, on the same stream
+            if (!w.hub_workspace) {
+                const uint32_t most = *std::max_element(hub_rows.begin(), hub_rows.end());
+                GVK_TRY(gvk_hot_plan(B, num_negative, most, most, kHubChunk, &w.hub_workspace_bytes));
+                HIP_TRY(hipMalloc(&w.hub_workspace, w.hub_workspace_bytes));
+            }
+            for (int at = 0; at < n; at += kHubChunk) {
+                const int m = std::min(kHubChunk, n - at);
+                const uint32_t id = (uint32_t)(first + (uint64_t)at * W);
+                const uint32_t *batches = pool + (size_t)(done + at) * B * 2;
+                GVK_TRY(gvk_hot_build(w.compute, w.hub_workspace, w.hub_workspace_bytes, batches, B, m, num_negative, &neg, id,
+                                      (uint32_t)W, kv, kc));
+                GVK_TRY(gvk_train_episode_hot(w.compute, dim, &o, optimizer.schedule == 1, &t, batches, &neg, id, (uint32_t)W,
+                                              (uint32_t)num_batch, m, w.loss, B, num_negative, config.negative_weight,
+                                              w.hub_workspace, w.hub_workspace_bytes, kv, kc, m, 0));
+            }
+        } else if (optimizer.schedule != 2) {
             GVK_TRY(gvk_train_episode(w.compute, dim, &o, optimizer.schedule == 1, &t, pool + (size_t)done * B * 2, &neg,
                                       (uint32_t)first, (uint32_t)W, (uint32_t)num_batch, n, w.loss, B, num_negative,
                                       config.negative_weight));
@@ -1850,6 +1909,7 @@ extern "C" int gvx_solver_get(gvx_solver *s, gvx_solver_members *out) {
     out->sampler_mode = s->mode, out->device_sampling = s->device_sampling;
     out->partition_rows = s->part_rows;
     out->transport = s->transport_name.c_str();
+    out->hub_rows = s->hubs && !s->hub_rows.empty() ? *std::max_element(s->hub_rows.begin(), s->hub_rows.end()) : 0;
     return GVK_OK;
 }
 

@@ -202,7 +202,7 @@ class GraphSolver(object):
     available_models = ("DeepWalk", "LINE", "node2vec")
 
     def __init__(self, dim, float_type=dtype.float32, index_type=dtype.uint32, device_ids=(), num_sampler_per_worker=auto,
-                 gpu_memory_limit=auto, seed=0, device_sampling=False, pair_order=auto):
+                 gpu_memory_limit=auto, seed=0, device_sampling=False, pair_order=auto, hub_rows=0):
         if dim not in self.available_dims or float_type != dtype.float32 or index_type != dtype.uint32:
             raise AttributeError("Can't find an instantiation of GraphSolver with dim=%s, float_type=%s, "
                                  "index_type=%s" % (dim, float_type, index_type))
@@ -243,6 +243,7 @@ class GraphSolver(object):
         self.seed = int(seed)
         self.device_sampling = bool(device_sampling)
         self._pair_order_request = pair_order
+        self.hub_rows_request = -1 if hub_rows == "auto" else int(hub_rows)  # GVX_HUB_ROWS (gvx.h): 0 off, "auto", N rows
         self.negative_table = "auto"          # "rows": one alias slot per row (the reference's); "classes": by weight class
         self.node2vec_table_limit = 1 << 30   # per-edge table entries before node2vec samples by rejection
         self.graph = None
@@ -279,7 +280,8 @@ class GraphSolver(object):
         for option, value in ((_lib.GVX_SEED, self.seed), (_lib.GVX_DEVICE_SAMPLING, int(self.device_sampling)),
                               (_lib.GVX_PAIR_ORDER, _PAIR_ORDERS[self._pair_order_request]),
                               (_lib.GVX_NEGATIVE_TABLE, _NEGATIVE_TABLES[self.negative_table]),
-                              (_lib.GVX_NODE2VEC_TABLE_LIMIT, int(self.node2vec_table_limit))):
+                              (_lib.GVX_NODE2VEC_TABLE_LIMIT, int(self.node2vec_table_limit)),
+                              (_lib.GVX_HUB_ROWS, int(self.hub_rows_request))):
             self._check(self._lib.gvx_solver_set(self._handle, option, value), "GraphSolver")
 
     def _exchange_stats(self):
@@ -302,6 +304,7 @@ class GraphSolver(object):
         self.num_sampler_per_worker = m.num_sampler // max(m.num_worker, 1)
         self.pair_order = "grouped" if m.pair_order == 2 else "sampled"
         self.partition_rows = m.partition_rows
+        self.hub_rows = m.hub_rows
         self.transport = (m.transport or b"").decode()
         self.train_seconds = m.train_seconds
         self._mode = _MODES.get(m.sampler_mode, "edge")

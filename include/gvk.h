@@ -160,6 +160,32 @@ int gvk_train_episode(void *stream, int dim, const gvk_optimizer *optimizer, int
                       uint32_t first_batch_id, uint32_t batch_id_stride, uint32_t total_batches, int num_batches,
                       float *loss, int batch_size, int num_negative, float negative_weight);
 
+/* Hub rows trained by chains (SGD, negatives drawn on the device).  Inside one launch every sample runs at
+ * the same time, and of the updates that hold a row at the same time one survives.  For the rows of a large table that is
+ * rare; a hub row is in flight hundreds of times per launch and keeps a handful of its updates, where the reference's
+ * sequential loop keeps them all.  Here the first hot_vertex rows of the head table and the first hot_context rows of the
+ * tail table (partitions are ordered by falling degree: the hub rows) are each owned by a chain: one wavefront holds the row
+ * in registers and applies every update the batch has for it one after the other, partner rows read-only, and stores the
+ * row once; the per-pair work of the same launch trains every sample as gvk_train does but only READS hub rows.
+ *   gvk_hot_plan    bytes of device workspace the work lists of num_batch batches need
+ *   gvk_hot_build   the work lists of num_batch consecutive batches of a device pool (ids first_batch_id + i * stride): per
+ *                   batch and hub row the partner rows of its updates — for a head row the k negatives then the tail of every
+ *                   sample it heads, for a context row the head of every sample it is the tail or a negative of; negatives
+ *                   per the RNG contract, exactly as the training launch draws them
+ *   gvk_train_episode_hot   gvk_train_episode over batches whose work lists sit in `workspace` (built for workspace_batches
+ *                   batches starting with this call's first batch; same pool, ids, negative source, hot_vertex / hot_context).
+ *                   serialized != 0: the same work as three launches in a fixed order — head-row chains, context-row
+ *                   chains, pairs — which makes the result a pure function of the work lists (parity tests). */
+int gvk_hot_plan(int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, size_t *bytes);
+int gvk_hot_build(void *stream, void *workspace, size_t workspace_bytes, const uint32_t *pool, int batch_size, int num_batch,
+                  int num_negative, const gvk_negative_source *negative, uint32_t first_batch_id, uint32_t batch_id_stride,
+                  uint32_t hot_vertex, uint32_t hot_context);
+int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer, int linear_schedule, const gvk_tables *tables,
+                          const uint32_t *pairs, const gvk_negative_source *negative, uint32_t first_batch_id,
+                          uint32_t batch_id_stride, uint32_t total_batches, int num_batches, float *loss, int batch_size,
+                          int num_negative, float negative_weight, const void *workspace, size_t workspace_bytes,
+                          uint32_t hot_vertex, uint32_t hot_context, int workspace_batches, int serialized);
+
 /* logits[s] = dot(vertex[head_s], context[tail_s]) */
 int gvk_predict(void *stream, int dim, const float *vertex, const float *context, const uint32_t *pairs,
                 float *logits, int batch_size);
@@ -282,6 +308,8 @@ int gvk_probe_row_traffic(void *stream, int dim, float *vertex, float *context, 
                                      holds at most `value` samples per row of the head table: default 2 (what keeps small
                                      partitions at the reference's learning quality); 0 = always one launch
                                      per batch */
+#define GVK_TUNE_CHAIN_CAP 8      /* gvk_train_episode_hot: entries one chain task trains in sequence (a longer chain is cut into
+                                     parts trained side by side whose deltas add up): 0 = the default, 256 */
 /* A/B library only: */
 #define GVK_TUNE_LANES_PER_PAIR 1 /* 0 = per-dim default; else 8, 16, 32 or 64 */
 #define GVK_TUNE_GENERATION 4     /* parity experiment: C > 0 trains a batch as consecutive launches of at most C samples

@@ -88,6 +88,7 @@ typedef struct {
     int device_sampling;
     uint32_t partition_rows;     /* S: rows of a partition's table */
     const char *transport;       /* "RCCL", "device copies", "caller-supplied transport" or "" (one worker) */
+    uint32_t hub_rows;           /* rows per table the last train() trained by chains (the largest partition value; 0 = none) */
 } gvx_solver_members;
 
 /* device_ids: num_device GPU ids (an id may repeat: its workers then share that GPU), or num_device == 0 for all
@@ -138,6 +139,12 @@ void gvx_solver_destroy(gvx_solver *s);
 /* GVX_NODE2VEC_TABLE_LIMIT: entries of node2vec's per-edge alias tables (sum over edges of the head's degree, graph.cuh:
  * 656-677) beyond which the CPU samplers switch to rejection over the per-vertex tables (default 2^30). */
 #define GVX_NODE2VEC_TABLE_LIMIT 5
+/* GVX_HUB_ROWS (SGD): the hub rows of every partition are trained by chains (gvk_train_episode_hot): one
+ * wavefront per hub row applies all the updates a batch has for the row one after the other, so none of them is lost to a
+ * concurrent one — what keeps link-prediction AUC at the reference's sequential loop on hub-heavy graphs.  -1: the rows a
+ * batch is expected to hit twice or more (by degree share; at most 16384 per table); N > 0: the first N rows of every
+ * partition; 0: off.  Batches keep the sampler's order. */
+#define GVX_HUB_ROWS 6
 int gvx_solver_set(gvx_solver *s, int option, int64_t value);
 
 /* The graph is borrowed until the next build / destroy (solver.h:289).  num_partition / episode_size: GVX_AUTO. */

@@ -131,6 +131,128 @@ int gvo_train(int dim, int type, float *vertex, float *context, float *vm1, floa
     return 0;
 }
 
+/* ---- hub rows trained by chains (the product's gvk_hot_build / gvk_train_episode_hot, include/gvk.h; no counterpart in
+ * the reference — its kernel trains every sample the same way, gpu/graph.cuh:36-95) ----------------------------------------
+ * The work lists of one batch in sample order: chain c < kv is head row c — per sample with that head its k negatives
+ * (label 0) then its tail (label 1, bit 31); chain kv + r is context row r — the head of every sample r is the tail (label
+ * 1) or a negative (label 0) of.  chain_start [kv + kc + 1], entries [2 (k + 1) batch_size].  Returns the number of entries. */
+size_t gvo_hot_lists(const uint32_t *batch, const uint32_t *negatives, int batch_size, int k, uint32_t kv, uint32_t kc,
+                     uint32_t *chain_start, uint32_t *entries) {
+    const uint32_t chains = kv + kc;
+    uint32_t *cursor = (uint32_t *)calloc(chains + 1, sizeof(uint32_t));
+    if (!cursor) return 0;
+    for (int s = 0; s < batch_size; s++) {
+        const uint32_t tail = batch[2 * s], head = batch[2 * s + 1];
+        if (head < kv) cursor[head] += (uint32_t)(k + 1);
+        if (tail < kc) cursor[kv + tail]++;
+        for (int j = 0; j < k; j++)
+            if (negatives[(size_t)s * k + j] < kc) cursor[kv + negatives[(size_t)s * k + j]]++;
+    }
+    uint32_t running = 0;
+    for (uint32_t c = 0; c < chains; c++) {
+        const uint32_t n = cursor[c];
+        chain_start[c] = cursor[c] = running;
+        running += n;
+    }
+    chain_start[chains] = running;
+    for (int s = 0; s < batch_size; s++) {
+        const uint32_t tail = batch[2 * s], head = batch[2 * s + 1];
+        if (head < kv) {
+            for (int j = 0; j < k; j++) entries[cursor[head]++] = negatives[(size_t)s * k + j];
+            entries[cursor[head]++] = tail | 0x80000000u;
+        }
+        for (int j = 0; j < k; j++) {
+            const uint32_t n = negatives[(size_t)s * k + j];
+            if (n < kc) entries[cursor[kv + n]++] = head;
+        }
+        if (tail < kc) entries[cursor[kv + tail]++] = head | 0x80000000u;
+    }
+    free(cursor);
+    return running;
+}
+
+/* One chain task: entries [begin, end) applied one after the other to a copy of the own row; partner rows are only read. */
+static void gvo_chain(int dim, float *own, const float *partner, const uint32_t *entries, uint32_t begin, uint32_t end,
+                      float lr, float wd, float negative_weight) {
+    float dummy1 = 0, dummy2 = 0;
+    for (uint32_t p = begin; p < end; p++) {
+        const float *c = partner + (size_t)(entries[p] & 0x7fffffffu) * dim;
+        const int label = entries[p] >> 31;
+        float logit = 0;
+        for (int i = 0; i < dim; i++) logit += own[i] * c[i];
+        const float prob = gvo_sigmoid(logit);
+        const float gradient = label ? prob - 1 : prob, weight = label ? 1 : negative_weight;
+        for (int i = 0; i < dim; i++) own[i] -= gvo_update(0, lr, wd, NULL, own[i], gradient * c[i], weight, &dummy1, &dummy2);
+    }
+}
+
+/* One batch in the product's serialized form (SGD): (1) the chains of the kv hub head rows, each over its entries in list
+ * order on its own row, context rows read; (2) the chains of the kc hub context rows, vertex rows read; (3) every sample in
+ * order as gvo_train, except that hub rows are read and never written.  A chain longer than cap entries is trained as parts
+ * of cap entries, each from the row as the phase found it, and the row receives the sum of the parts' deltas. */
+int gvo_train_hot(int dim, float *vertex, float *context, const uint32_t *batch, const uint32_t *negatives, float *loss,
+                  int batch_size, int k, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
+                  const uint32_t *chain_start, const uint32_t *entries, uint32_t cap) {
+    float *own = (float *)malloc(sizeof(float) * dim), *sum = (float *)malloc(sizeof(float) * dim);
+    float *buf = (float *)malloc(sizeof(float) * dim);
+    float dummy1 = 0, dummy2 = 0;
+    if (!own || !sum || !buf) return -1;
+    for (uint32_t chain = 0; chain < kv + kc; chain++) {  /* chains kv.. read the vertex rows the first kv chains wrote */
+        float *row = chain < kv ? vertex + (size_t)chain * dim : context + (size_t)(chain - kv) * dim;
+        const float *partner = chain < kv ? context : vertex;
+        const uint32_t first = chain_start[chain], last = chain_start[chain + 1];
+        if (last - first <= cap) {
+            gvo_chain(dim, row, partner, entries, first, last, lr, wd, negative_weight);
+            continue;
+        }
+        memset(sum, 0, sizeof(float) * dim);
+        for (uint32_t begin = first; begin < last; begin += cap) {
+            memcpy(own, row, sizeof(float) * dim);
+            gvo_chain(dim, own, partner, entries, begin, last - begin > cap ? begin + cap : last, lr, wd, negative_weight);
+            for (int i = 0; i < dim; i++) sum[i] += own[i] - row[i];
+        }
+        for (int i = 0; i < dim; i++) row[i] += sum[i];
+    }
+    for (int s = 0; s < batch_size; s++) {
+        const size_t head = batch[2 * s + 1];
+        memcpy(buf, vertex + head * dim, sizeof(float) * dim);
+        float sample_loss = 0;
+        size_t last = 0;
+        int have = 0;
+        for (int j = 0; j <= k; j++) {
+            const size_t tail = j < k ? negatives[(size_t)s * k + j] : batch[2 * s];
+            const int label = j == k;
+            float *c = context + tail * dim;
+            /* a hub row is not written here, but a sample whose consecutive targets are the same row sees its own update
+             * (the kernel carries the updated registers over), as it does for any other row */
+            const float *from = (tail < kc && have && tail == last) ? own : c;
+            float logit = 0;
+            for (int i = 0; i < dim; i++) logit += buf[i] * from[i];
+            const float prob = gvo_sigmoid(logit);
+            float gradient, weight;
+            if (label) {
+                gradient = prob - 1, weight = 1;
+                sample_loss += weight * -logf(prob + GVO_EPS);
+            } else {
+                gradient = prob, weight = negative_weight;
+                sample_loss += weight * -logf(1 - prob + GVO_EPS);
+            }
+            for (int i = 0; i < dim; i++) {
+                const float vi = buf[i], ci = from[i];
+                buf[i] -= gvo_update(0, lr, wd, NULL, vi, gradient * ci, weight, &dummy1, &dummy2);
+                const float cn = ci - gvo_update(0, lr, wd, NULL, ci, gradient * vi, weight, &dummy1, &dummy2);
+                if (tail >= kc) c[i] = cn;
+                own[i] = cn;
+            }
+            last = tail, have = 1;
+        }
+        loss[s] = sample_loss / (1 + k * negative_weight);
+        if (head >= kv) memcpy(vertex + head * dim, buf, sizeof(float) * dim);
+    }
+    free(own), free(sum), free(buf);
+    return 0;
+}
+
 void gvo_predict(int dim, const float *vertex, const float *context, const uint32_t *batch, float *logits,
                  int batch_size) {
     for (int s = 0; s < batch_size; s++) {

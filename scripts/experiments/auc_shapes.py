@@ -39,13 +39,16 @@ def main():
     tune.set_segment_steps(int(extra.get("steps", 0)))
     if "split" in extra:
         tune.set_split_hits(int(extra["split"]))
+    tune.set_tuning(8, int(extra.get("chain_cap", 0)))  # GVK_TUNE_CHAIN_CAP
+    hub = extra.get("hub", "0")
     tag = " ".join("%s=%s" % kv for kv in sorted(extra.items()))
     for order in orders:
         aucs = []
         for seed in seeds:
             t0 = time.time()
             s = gv.solver.GraphSolver(128, num_sampler_per_worker=int(extra.get("samplers", 8)), seed=seed, pair_order=gv.auto if order == "auto" else order,
-                                      device_sampling=extra.get("device_sampling", "0") == "1")
+                                      device_sampling=extra.get("device_sampling", "0") == "1",
+                                      hub_rows=hub if hub == "auto" else int(hub))
             s.build(g, batch_size=batch, episode_size=int(extra.get("episode", episode)), num_partition=int(extra.get("partitions", 0)))
             s.train(model=extra.get("model", "LINE"), num_epoch=epochs,
                     augmentation_step=int(extra.get("aug", train_kw["augmentation_step"])),
@@ -55,8 +58,8 @@ def main():
                                             [k[1] for k in keep], [k[2] for k in keep]))
             print("%s epochs %d order %s seed %d: %d batches AUC %.6f (%.1f s)" % (shape, epochs, order, seed, s.batch_id,
                                                                                  aucs[-1], time.time() - t0), flush=True)
-        print("%s epochs %d order %s [%s] %s: mean %.6f sd %.6f" % (shape, epochs, order, tag, tune.describe_train(
-            128, "SGD", 1, False, batch, s._part_size), np.mean(aucs), np.std(aucs)), flush=True)
+        print("%s epochs %d order %s [%s] %s, %d hub rows: mean %.6f sd %.6f" % (shape, epochs, order, tag, tune.describe_train(
+            128, "SGD", 1, False, batch, s._part_size), s.hub_rows, np.mean(aucs), np.std(aucs)), flush=True)
 
 
 if __name__ == "__main__":

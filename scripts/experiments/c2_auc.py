@@ -35,15 +35,17 @@ for config in configs:
     tune.set_variant(int(kw.get("variant", 0)))
     tune.set_run_cap(int(kw.get("run_cap", 0)))
     tune.set_split_hits(int(kw.get("split", 2)))
+    tune.set_tuning(8, int(kw.get("chain_cap", 0)))  # GVK_TUNE_CHAIN_CAP
     order = kw.get("order", "auto")
     aucs = []
     for seed in [int(x) for x in extra.get("seeds", "1024").split(",")]:
         t0 = time.time()
         s = gv.solver.GraphSolver(128, num_sampler_per_worker=15, seed=seed, pair_order=gv.auto if order == "auto" else order,
-                                  device_sampling=kw.get("device", "0") == "1")
+                                  device_sampling=kw.get("device", "0") == "1",
+                                  hub_rows=kw.get("hub", "0") if kw.get("hub", "0") == "auto" else int(kw.get("hub", "0")))
         s.build(g, batch_size=int(kw.get("batch", 100000)), num_partition=int(kw.get("partitions", 0)))
         s.train(model="LINE", num_epoch=int(extra.get("epochs", 50)), augmentation_step=1, log_frequency=1 << 30)
         aucs.append(link_prediction_auc(s.vertex_embeddings, s.context_embeddings, name2id[H[keep]], name2id[T[keep]], Y[keep]))
         rate = s.timing["batches"] * s.batch_size / s.timing["episodes"] / 1e6
-    print("C2 [%s] %s %s: AUC %s mean %.6f | %.0f M edge-samples/s" % (config, s.pair_order, tune.describe_train(
-        128, "SGD", 1, False, s.batch_size, s.partition_rows), " ".join("%.6f" % a for a in aucs), np.mean(aucs), rate), flush=True)
+    print("C2 [%s] %s %s, %d hub rows: AUC %s mean %.6f | %.0f M edge-samples/s" % (config, s.pair_order, tune.describe_train(
+        128, "SGD", 1, False, s.batch_size, s.partition_rows), s.hub_rows, " ".join("%.6f" % a for a in aucs), np.mean(aucs), rate), flush=True)

@@ -42,6 +42,11 @@ class Oracle(object):
         lib.gvo_train.restype = C.c_int
         lib.gvo_train.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 6 + [_u32p, _u32p, _f32p, C.c_int, C.c_int,
                                                                          C.c_float, C.c_float, C.c_float, _f32p]
+        lib.gvo_hot_lists.restype = C.c_size_t
+        lib.gvo_hot_lists.argtypes = [_u32p, _u32p, C.c_int, C.c_int, C.c_uint32, C.c_uint32, _u32p, _u32p]
+        lib.gvo_train_hot.restype = C.c_int
+        lib.gvo_train_hot.argtypes = [C.c_int, _f32p, _f32p, _u32p, _u32p, _f32p, C.c_int, C.c_int, C.c_float, C.c_float,
+                                      C.c_float, C.c_uint32, C.c_uint32, _u32p, _u32p, C.c_uint32]
         lib.gvo_predict.restype = None
         lib.gvo_predict.argtypes = [C.c_int, _f32p, _f32p, _u32p, _f32p, C.c_int]
         lib.gvo_alias_build.restype = C.c_int
@@ -109,6 +114,31 @@ class Oracle(object):
         rc = self.lib.gvo_train(vertex.shape[1], optimizer, _opt(vertex), _opt(context), _opt(m[0]), _opt(m[1]),
                                 _opt(m[2]), _opt(m[3]), batch.reshape(-1), negatives.reshape(-1), loss, B, k, lr,
                                 wd, negative_weight, hp)
+        assert rc == 0
+        return loss
+
+    def hot_lists(self, batch, negatives, hot_vertex, hot_context):
+        """Work lists of the hub rows' chains in sample order: (chain_start [kv + kc + 1], entries [n])."""
+        B = batch.shape[0]
+        k = negatives.size // B if B else 0
+        start = np.zeros(hot_vertex + hot_context + 1, np.uint32)
+        entries = np.zeros(max(2 * (k + 1) * B, 1), np.uint32)
+        n = self.lib.gvo_hot_lists(np.ascontiguousarray(batch.reshape(-1)), np.ascontiguousarray(negatives.reshape(-1)), B, k,
+                                   hot_vertex, hot_context, start, entries)
+        return start, entries[:n].copy()
+
+    def train_hot(self, vertex, context, batch, negatives, lr, wd, negative_weight, hot_vertex, hot_context, chain_start,
+                  entries, cap):
+        """One batch in the product's serialized hub-chain form (gvk_train_episode_hot(serialized=1)); in place."""
+        B = batch.shape[0]
+        k = negatives.size // B if B else 0
+        loss = np.zeros(B, np.float32)
+        entries = np.ascontiguousarray(entries, np.uint32)
+        if entries.size == 0:
+            entries = np.zeros(1, np.uint32)
+        rc = self.lib.gvo_train_hot(vertex.shape[1], vertex, context, np.ascontiguousarray(batch.reshape(-1)),
+                                    np.ascontiguousarray(negatives.reshape(-1)), loss, B, k, lr, wd, negative_weight, hot_vertex,
+                                    hot_context, np.ascontiguousarray(chain_start, np.uint32), entries, cap)
         assert rc == 0
         return loss
 
