@@ -89,9 +89,10 @@ def parse(argv=None):
     p.add_argument("--pair-order", choices=["auto", "sampled", "grouped"], default="auto",
                    help="GraphSolver(pair_order=...): auto (the product default) regroups the pairs of a batch by head "
                         "row on the device by table size (DESIGN.md §3.1.1)")
-    p.add_argument("--hub-rows", default="0",
-                   help="GraphSolver(hub_rows=...): 0 = every row trained pair by pair, `auto` / N = the hub rows of each partition "
-                        "(auto: expected hits per batch >= 2) trained by chains (gvk_train_episode_hot, DESIGN.md §3.1.2)")
+    p.add_argument("--hub-rows", default="default",
+                   help="GraphSolver(hub_rows=...): default = the product's rule (off for LINE), 0 = every row trained pair by pair, "
+                        "`auto` / N = the hub rows of each partition (auto: expected hits per batch >= 2) trained by chains "
+                        "(gvk_train_episode_hot, DESIGN.md §3.1.2)")
     p.add_argument("--optimizer", choices=["SGD", "Momentum", "AdaGrad", "RMSprop", "Adam"], default="SGD",
                    help="experiment: moment optimizers move (1 + m) x the row bytes (m = 1, Adam 2)")
     p.add_argument("--graph", choices=["power-law", "community"], default="power-law",
@@ -185,7 +186,7 @@ def train_timed(args, gv, graph, threads, partitions, device_sampling, epochs):
     import torch
     solver = gv.solver.GraphSolver(args.dim, num_sampler_per_worker=threads, seed=args.seed, device_sampling=device_sampling,
                                    pair_order=gv.auto if args.pair_order == "auto" else args.pair_order,
-                                   hub_rows=args.hub_rows if args.hub_rows == "auto" else int(args.hub_rows))
+                                   hub_rows=None if args.hub_rows == "default" else (args.hub_rows if args.hub_rows == "auto" else int(args.hub_rows)))
     solver.negative_table = args.negative_table
     solver.build(graph, optimizer=gv.optimizer.SGD(0.025, 0.005, "linear"), num_partition=partitions,
                  num_negative=args.negatives, batch_size=args.batch)
@@ -330,7 +331,7 @@ def main(argv=None):
         graph.load(synthetic.power_law_edges(N, E, seed=args.seed))
     solver = gv.solver.GraphSolver(dim, num_sampler_per_worker=threads, seed=args.seed,
                                    pair_order=gv.auto if args.pair_order == "auto" else args.pair_order,
-                                   hub_rows=args.hub_rows if args.hub_rows == "auto" else int(args.hub_rows))
+                                   hub_rows=None if args.hub_rows == "default" else (args.hub_rows if args.hub_rows == "auto" else int(args.hub_rows)))
     solver.negative_table = args.negative_table
     for item in args.tune:
         key, value = item.split("=")

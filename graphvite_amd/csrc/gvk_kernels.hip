@@ -42,6 +42,7 @@ int g_variant = 0;         // GVK_TUNE_VARIANT
 int g_run_cap = 0;         // GVK_TUNE_RUN_CAP (0 = the default of 20, run_cap_for)
 int g_split_hits = 2;      // GVK_TUNE_SPLIT_HITS (samples per table row one launch may hold; 0 = never split a batch)
 int g_chain_cap = 0;       // GVK_TUNE_CHAIN_CAP (entries one chain task trains in sequence; 0 = the default of 256)
+int g_hot_serialized = 0;  // GVK_TUNE_HOT_SERIALIZED (bring-up: every gvk_train_episode_hot runs its three-launch form)
 #if defined(GVK_AB_BUILDS)  // knobs of the A/B library only (make ab -> build/ab/libgvk_ab.so)
 int g_lanes_per_pair = 0;  // GVK_TUNE_LANES_PER_PAIR
 int g_generation = 0;      // GVK_TUNE_GENERATION (0 = one launch per batch)
@@ -234,8 +235,11 @@ __device__ __forceinline__ void copy_row(float (&dst)[N], const float (&src)[N])
 
 // ---- arithmetic (include/util/math.h:30-33, include/core/optimizer.h:161-210) -------------------
 
+// x > 0 ? 1 / (1 + expf(-x)) : expf(x) / (expf(x) + 1), the same bits with one exponential and one division: both branches
+// evaluate expf(-|x|)
 __device__ __forceinline__ float sigmoidf(float x) {
-    return x > 0 ? 1 / (1 + expf(-x)) : expf(x) / (expf(x) + 1);
+    const float t = expf(-fabsf(x));
+    return (x > 0 ? 1.0f : t) / (1 + t);
 }
 
 template <int OPT>
@@ -605,8 +609,9 @@ struct HotArgs {
     uint32_t chains;              // hot_vertex + hot_context
     uint32_t extra_capacity;
     uint32_t cap;                 // entries of one task
+    float lr;                     // learning rate of the chains' batch (the pairs of the same launch may belong to another batch)
     int task_blocks;              // blocks at the front of the grid that run chains
-    int what;                     // 0: chains + pairs; serialized form (tests): 1 = vertex chains, 2 = context chains, 3 = pairs
+    int what;                     // work of this launch: bit 0 = chains of head rows, bit 1 = chains of context rows, bit 2 = pairs
 };
 
 template <int DIM>
@@ -642,7 +647,7 @@ __device__ __forceinline__ void train_chain(const TrainArgs &a, const HotArgs &h
         chain = h.extra[1 + 2 * x], part = h.extra[2 + 2 * x];
     }
     const bool is_vertex = chain < a.hot_vertex;
-    if ((h.what == 1 && !is_vertex) || (h.what == 2 && is_vertex)) return;
+    if (!(h.what & (is_vertex ? 1 : 2))) return;
     const uint32_t first = h.chain_start[chain], last = h.chain_start[chain + 1];
     const uint32_t begin = first + part * h.cap;
     if (begin >= last) return;
@@ -656,6 +661,32 @@ __device__ __forceinline__ void train_chain(const TrainArgs &a, const HotArgs &h
     float own[V], own0[V];
     load_row<DIM, G>(own_table, row, lane, own);
     copy_row(own0, own);
+    // A chain cut into parts.  An update is own <- a own - lr w g c with a = 1 - lr w wd: weight decay is a factor that
+    // depends on the entry's label only, so the decay of the entries BEFORE this part (before_), of the part itself and of the
+    // entries AFTER it (after_) are known in closed form from label counts.  The part starts from the row as the earlier
+    // parts' decay leaves it, and what it adds to the row is its end state carried through the later parts' decay:
+    //     row <- total row + sum over parts (after_p end_p - total row),         total = before_ x part x after_
+    // which composes the parts' decay exactly (a hub row of the benchmark graph decays to 0.48 of itself within ONE batch —
+    // summing plain deltas of 8 parts would take it to 0.30) and leaves only the gradients' dependence on the other parts'
+    // steps to first order.
+    float before_ = 1, after_ = 1, total = 1;
+    if (split) {
+        uint32_t positives_before = 0, positives_inside = 0, positives_after = 0;
+        for (uint32_t at = first; at < last; at += G) {
+            const uint32_t p = at + lane;
+            const bool positive = p < last && (h.entries[p] >> 31) != 0;
+            positives_before += (uint32_t)__popcll(__ballot(positive && p < begin));
+            positives_inside += (uint32_t)__popcll(__ballot(positive && p >= begin && p < end));
+            positives_after += (uint32_t)__popcll(__ballot(positive && p >= end));
+        }
+        const float decay_positive = 1 - h.lr * a.wd, decay_negative = 1 - h.lr * a.neg_weight * a.wd;
+        before_ = powf(decay_positive, (float)positives_before) * powf(decay_negative, (float)(begin - first - positives_before));
+        after_ = powf(decay_positive, (float)positives_after) * powf(decay_negative, (float)(last - end - positives_after));
+        total = before_ * after_ * powf(decay_positive, (float)positives_inside) *
+                powf(decay_negative, (float)(end - begin - positives_inside));
+#pragma unroll
+        for (int x = 0; x < V; x++) own[x] *= before_;
+    }
     // the work list, EB entries per fetch, two fetches resident: entries [blk, blk + 2 EB)
     uint32_t blk = begin;
     uint32_t e_cur = blk + lane < end ? h.entries[blk + lane] : 0;
@@ -664,35 +695,43 @@ __device__ __forceinline__ void train_chain(const TrainArgs &a, const HotArgs &h
         const uint32_t o = p - blk;
         return (uint32_t)(o < EB ? __builtin_amdgcn_readlane((int)e_cur, (int)o) : __builtin_amdgcn_readlane((int)e_nxt, (int)(o - EB)));
     };
+    // Every step of the loop below issues exactly one row request and consumes the one issued D steps earlier, with no
+    // branch around either: the number of requests in flight is a compile-time fact, so the wait before a step is "all but
+    // the D - 1 youngest" and not "all".  Steps beyond the end of the chain request the last entry again and train with
+    // weight 0 (the row is unchanged); the window of entries moves by register copies only.
+    const uint32_t last_entry = end - 1;
     float ring[D][V];
 #pragma unroll
-    for (int i = 0; i < D; i++)
-        if (begin + i < end) load_row<DIM, G>(partner, entry(begin + i) & 0x7fffffffu, lane, ring[i]);
-    float unused1 = 0, unused2 = 0;
+    for (int i = 0; i < D; i++) {
+        const uint32_t q = begin + i < end ? begin + i : last_entry;
+        load_row<DIM, G>(partner, entry(q) & 0x7fffffffu, lane, ring[i]);
+    }
     for (uint32_t base = begin; base < end; base += D) {
+        const uint32_t f = blk + 2 * EB + lane;
+        const uint32_t e_fut = h.entries[f < end ? f : last_entry];  // the window after e_nxt, asked for ahead of its use
 #pragma unroll
         for (int i = 0; i < D; i++) {
             const uint32_t p = base + i;
-            if (p < end) {
-                const uint32_t e = entry(p);
-                float c[V];
-                copy_row(c, ring[i]);
-                if (p + D < end) load_row<DIM, G>(partner, entry(p + D) & 0x7fffffffu, lane, ring[i]);
-                // forward / backward of one target: model/graph.h:40-58, gpu/graph.cuh:77-87 — on the own row only
-                float partial = 0;
+            const uint32_t e = entry(p < end ? p : last_entry);
+            float c[V];
+            copy_row(c, ring[i]);
+            const uint32_t q = p + D < end ? p + D : last_entry;
+            load_row<DIM, G>(partner, entry(q) & 0x7fffffffu, lane, ring[i]);
+            // forward / backward of one target: model/graph.h:40-58, gpu/graph.cuh:77-87 — on the own row only
+            float partial = 0;
 #pragma unroll
-                for (int x = 0; x < V; x++) partial += own[x] * c[x];
-                const float prob = sigmoidf(chain_sum<G>(partial));
-                const bool positive = (e >> 31) != 0;
-                const float gradient = positive ? prob - 1 : prob, weight = positive ? 1.0f : a.neg_weight;
+            for (int x = 0; x < V; x++) partial += own[x] * c[x];
+            const float prob = sigmoidf(chain_sum<G>(partial));
+            const bool positive = (e >> 31) != 0;
+            const float gradient = positive ? prob - 1 : prob;
+            const float weight = p < end ? (positive ? 1.0f : a.neg_weight) : 0.0f;
 #pragma unroll
-                for (int x = 0; x < V; x++) own[x] -= update<GVK_SGD>(a, own[x], gradient * c[x], weight, unused1, unused2);
-            }
+            for (int x = 0; x < V; x++) own[x] -= h.lr * weight * (gradient * c[x] + a.wd * own[x]);  // optimizer.h:161-164
         }
-        if (base + D >= blk + EB) {  // the next steps prefetch from beyond e_nxt: move the window
+        if (base + D >= blk + EB) {  // the next steps look beyond e_nxt: move the window
             blk += EB;
             e_cur = e_nxt;
-            e_nxt = blk + EB + lane < end ? h.entries[blk + EB + lane] : 0;
+            e_nxt = e_fut;
         }
     }
     if (split) {
@@ -702,8 +741,9 @@ __device__ __forceinline__ void train_chain(const TrainArgs &a, const HotArgs &h
         for (int c = 0; c < R::NC; c++)
 #pragma unroll
             for (int x = 0; x < R::CW; x++)
-                __hip_atomic_fetch_add(p + c * G * R::CW + x, own[c * R::CW + x] - own0[c * R::CW + x], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(p + c * G * R::CW + x,
+                                       after_ * own[c * R::CW + x] - (part == 0 ? 1.0f : total) * own0[c * R::CW + x],
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         store_row<DIM, G>(own_table, row, lane, own);
     }
@@ -1669,30 +1709,51 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     const int tasks = (int)(l.chains + l.extra_capacity);
     const int task_blocks = (tasks + kBlock / 64 - 1) / (kBlock / 64);
     const unsigned pair_blocks = (unsigned)(((int64_t)batch_size * lanes + kBlock - 1) / kBlock);
-    for (int i = 0; i < num_batches; i++) {
+    if (num_batches == 0) return GVK_OK;
+    auto lr_of = [&](int i) {
         const uint32_t id = first_batch_id + (uint32_t)i * batch_id_stride;
         float scale = 1;
         if (linear_schedule) {  // optimizer.h:77-79
             scale = 1 - float(int(id)) / int(total_batches);
             if (scale < 1e-4f) scale = 1e-4f;
         }
-        a.lr = optimizer->lr * scale;
-        a.batch_id = id;
-        a.pairs = pairs + (size_t)i * batch_size * 2;
+        return optimizer->lr * scale;
+    };
+    auto chains_of = [&](int i) {  // the chain blocks of a launch work on batch i
         h.chain_start = reinterpret_cast<const uint32_t *>(base + l.chain_start) + (size_t)i * (l.chains + 1);
         h.entries = reinterpret_cast<const uint32_t *>(base + l.entries) + (size_t)i * l.entry_capacity;
         h.extra = reinterpret_cast<const uint32_t *>(base + l.extra) + (size_t)i * (1 + 2 * (size_t)l.extra_capacity);
-        if (!serialized) {
-            h.what = 0, h.task_blocks = task_blocks;
-            hipLaunchKernelGGL(kernel, dim3((unsigned)task_blocks + pair_blocks), dim3(kBlock), 0, (hipStream_t)stream, a, h);
-        } else {  // the same work as three launches in a fixed order: vertex chains, context chains, pairs (what the oracle restates)
-            h.task_blocks = task_blocks;
-            h.what = 1;
-            hipLaunchKernelGGL(kernel, dim3((unsigned)task_blocks), dim3(kBlock), 0, (hipStream_t)stream, a, h);
-            h.what = 2;
-            hipLaunchKernelGGL(kernel, dim3((unsigned)task_blocks), dim3(kBlock), 0, (hipStream_t)stream, a, h);
-            h.what = 3, h.task_blocks = 0;
-            hipLaunchKernelGGL(kernel, dim3(pair_blocks), dim3(kBlock), 0, (hipStream_t)stream, a, h);
+        h.lr = lr_of(i);
+    };
+    auto pairs_of = [&](int i) {  // the pair blocks of a launch work on batch i
+        a.lr = lr_of(i);
+        a.batch_id = first_batch_id + (uint32_t)i * batch_id_stride;
+        a.pairs = pairs + (size_t)i * batch_size * 2;
+    };
+    auto launch = [&](int what) {
+        h.what = what;
+        h.task_blocks = (what & 3) ? task_blocks : 0;
+        hipLaunchKernelGGL(kernel, dim3((unsigned)h.task_blocks + ((what & 4) ? pair_blocks : 0u)), dim3(kBlock), 0,
+                           (hipStream_t)stream, a, h);
+    };
+    // A sample's updates to its rows are all computed from the rows as the sample found them (model/graph.h:47-58).  The
+    // chains of a batch therefore run BEFORE its pairs: a chain reads the partner rows before the batch's pairs move them
+    // towards the hub row (a chain that read them afterwards would compound the step it is about to take — every sample of a
+    // hub row, thousands per epoch: the row's norm explodes), and the pairs train against the hub rows the chains left.
+    // Pipelined: launch i trains the pairs of batch i and, in its first blocks, the chains of batch i + 1 — different samples,
+    // so neither waits for the other — which hides the chains (a few long sequential tasks) behind the pairs (the bulk).
+    if (serialized || g_hot_serialized) {  // tests / bring-up: per batch three launches, what the oracle restates
+        for (int i = 0; i < num_batches; i++) {
+            chains_of(i), pairs_of(i);
+            launch(1), launch(2), launch(4);
+        }
+    } else {
+        chains_of(0);
+        launch(3);
+        for (int i = 0; i < num_batches; i++) {
+            pairs_of(i);
+            if (i + 1 < num_batches) chains_of(i + 1);
+            launch(i + 1 < num_batches ? 7 : 4);
         }
     }
     return check_launch("gvk_train_episode_hot");
@@ -1925,6 +1986,10 @@ int gvk_set_tuning(int key, int value) {
     if (key == GVK_TUNE_RUN_CAP) {
         if (value < 0 || value > kMaxRunCap) return fail(GVK_EINVAL, "gvk_set_tuning: run cap must be in [0, 4096]");
         g_run_cap = value;
+        return GVK_OK;
+    }
+    if (key == GVK_TUNE_HOT_SERIALIZED) {
+        g_hot_serialized = value != 0;
         return GVK_OK;
     }
     if (key == GVK_TUNE_CHAIN_CAP) {

@@ -167,7 +167,7 @@ struct gvx_solver {
     size_t memory_request = 0, gpu_memory_limit = 0, gpu_memory_cost = 0;
     uint64_t seed = 0;
     int pair_order_request = 0, negative_table_request = 0;
-    int64_t hub_rows_request = 0;  // GVX_HUB_ROWS: 0 off, -1 by expected hits per batch, N > 0 the first N rows of every table
+    int64_t hub_rows_request = -2;  // GVX_HUB_ROWS: -2 the default rule, -1 by expected hits per batch, 0 off, N > 0 the first N rows
     uint64_t node2vec_table_limit = (uint64_t)1 << 30;
     // build
     const gvs_graph *graph = nullptr;
@@ -542,7 +542,7 @@ extern "C" int gvx_solver_set(gvx_solver *s, int option, int64_t value) {
         s->seed = (uint64_t)value;
         return GVK_OK;
     }
-    if (option == GVX_HUB_ROWS && value >= -1) {
+    if (option == GVX_HUB_ROWS && value >= -2) {
         s->hub_rows_request = value;
         return GVK_OK;
     }
@@ -729,13 +729,17 @@ int gvx_solver::configure(const gvx_train_config &in) {
     // the partition) or as a negative (share of degree^exponent) — are trained by chains; their batches keep the sampler's order
     hub_rows.assign(num_partition, 0);
     hubs = false;
-    if (hub_rows_request != 0 && optimizer.type == GVK_SGD && optimizer.schedule != 2) {
+    // the default rule (-2): where chains are pinned against the reference's training loop — the walk-ordered
+    // pools of DeepWalk / node2vec on one partition small enough that EVERY row is a hub row; everything else pair by pair
+    int64_t request = hub_rows_request;
+    if (request == -2) request = walk_ordered() && num_partition == 1 && part_rows <= kMaxHubRows ? (int64_t)part_rows : 0;
+    if (request != 0 && optimizer.type == GVK_SGD && optimizer.schedule != 2) {
         const float *vertex_weights = gvs_graph_vertex_weights(graph);
         for (int p = 0; p < num_partition; p++) {
             const std::vector<uint32_t> &ids = part_ids[p];
             uint64_t rows = 0;
-            if (hub_rows_request > 0) {
-                rows = (uint64_t)hub_rows_request;
+            if (request > 0) {
+                rows = (uint64_t)request;
             } else {
                 double total = 0, total_negative = 0;
                 for (uint32_t id : ids) total += vertex_weights[id], total_negative += std::pow((double)vertex_weights[id], (double)c.negative_sample_exponent);

@@ -202,7 +202,7 @@ class GraphSolver(object):
     available_models = ("DeepWalk", "LINE", "node2vec")
 
     def __init__(self, dim, float_type=dtype.float32, index_type=dtype.uint32, device_ids=(), num_sampler_per_worker=auto,
-                 gpu_memory_limit=auto, seed=0, device_sampling=False, pair_order=auto, hub_rows=0):
+                 gpu_memory_limit=auto, seed=0, device_sampling=False, pair_order=auto, hub_rows=None):
         if dim not in self.available_dims or float_type != dtype.float32 or index_type != dtype.uint32:
             raise AttributeError("Can't find an instantiation of GraphSolver with dim=%s, float_type=%s, "
                                  "index_type=%s" % (dim, float_type, index_type))
@@ -243,7 +243,8 @@ class GraphSolver(object):
         self.seed = int(seed)
         self.device_sampling = bool(device_sampling)
         self._pair_order_request = pair_order
-        self.hub_rows_request = -1 if hub_rows == "auto" else int(hub_rows)  # GVX_HUB_ROWS (gvx.h): 0 off, "auto", N rows
+        # GVX_HUB_ROWS (gvx.h): None = the default rule, "auto" = by expected hits per batch, 0 = off, N = the first N rows
+        self.hub_rows_request = -2 if hub_rows is None else (-1 if hub_rows == "auto" else int(hub_rows))
         self.negative_table = "auto"          # "rows": one alias slot per row (the reference's); "classes": by weight class
         self.node2vec_table_limit = 1 << 30   # per-edge table entries before node2vec samples by rejection
         self.graph = None

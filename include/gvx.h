@@ -141,9 +141,10 @@ void gvx_solver_destroy(gvx_solver *s);
 #define GVX_NODE2VEC_TABLE_LIMIT 5
 /* GVX_HUB_ROWS (SGD): the hub rows of every partition are trained by chains (gvk_train_episode_hot): one
  * wavefront per hub row applies all the updates a batch has for the row one after the other, so none of them is lost to a
- * concurrent one — what keeps link-prediction AUC at the reference's sequential loop on hub-heavy graphs.  -1: the rows a
- * batch is expected to hit twice or more (by degree share; at most 16384 per table); N > 0: the first N rows of every
- * partition; 0: off.  Batches keep the sampler's order. */
+ * concurrent one.  -2 (default): where that is pinned against the reference's training loop — DeepWalk /
+ * node2vec on one partition of at most 16384 rows: every row is a hub row —, off otherwise; -1: the rows a batch is expected
+ * to hit twice or more (by degree share; at most 16384 per table); N > 0: the first N rows of every partition; 0: off.
+ * Batches keep the sampler's order. */
 #define GVX_HUB_ROWS 6
 int gvx_solver_set(gvx_solver *s, int option, int64_t value);
 

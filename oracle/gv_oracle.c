@@ -189,7 +189,7 @@ static void gvo_chain(int dim, float *own, const float *partner, const uint32_t 
 /* One batch in the product's serialized form (SGD): (1) the chains of the kv hub head rows, each over its entries in list
  * order on its own row, context rows read; (2) the chains of the kc hub context rows, vertex rows read; (3) every sample in
  * order as gvo_train, except that hub rows are read and never written.  A chain longer than cap entries is trained as parts
- * of cap entries, each from the row as the phase found it, and the row receives the sum of the parts' deltas. */
+ * of cap entries side by side and the parts are composed (below). */
 int gvo_train_hot(int dim, float *vertex, float *context, const uint32_t *batch, const uint32_t *negatives, float *loss,
                   int batch_size, int k, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
                   const uint32_t *chain_start, const uint32_t *entries, uint32_t cap) {
@@ -205,13 +205,28 @@ int gvo_train_hot(int dim, float *vertex, float *context, const uint32_t *batch,
             gvo_chain(dim, row, partner, entries, first, last, lr, wd, negative_weight);
             continue;
         }
+        /* parts: weight decay composes in closed form (a factor per entry that depends on its label only), so every part
+         * starts from the row as the decay of the entries before it leaves it, and its end state is carried through the
+         * decay of the entries after it: row <- total row + sum over parts (after end - total row) */
+        const float decay_positive = 1 - lr * wd, decay_negative = 1 - lr * negative_weight * wd;
+        uint32_t positives_all = 0;
+        for (uint32_t p = first; p < last; p++) positives_all += entries[p] >> 31;
+        const float total = powf(decay_positive, (float)positives_all) * powf(decay_negative, (float)(last - first - positives_all));
         memset(sum, 0, sizeof(float) * dim);
+        uint32_t positives_before = 0;
         for (uint32_t begin = first; begin < last; begin += cap) {
-            memcpy(own, row, sizeof(float) * dim);
-            gvo_chain(dim, own, partner, entries, begin, last - begin > cap ? begin + cap : last, lr, wd, negative_weight);
-            for (int i = 0; i < dim; i++) sum[i] += own[i] - row[i];
+            const uint32_t end = last - begin > cap ? begin + cap : last;
+            uint32_t positives_inside = 0;
+            for (uint32_t p = begin; p < end; p++) positives_inside += entries[p] >> 31;
+            const uint32_t positives_after = positives_all - positives_before - positives_inside;
+            const float before = powf(decay_positive, (float)positives_before) * powf(decay_negative, (float)(begin - first - positives_before));
+            const float after = powf(decay_positive, (float)positives_after) * powf(decay_negative, (float)(last - end - positives_after));
+            for (int i = 0; i < dim; i++) own[i] = before * row[i];
+            gvo_chain(dim, own, partner, entries, begin, end, lr, wd, negative_weight);
+            for (int i = 0; i < dim; i++) sum[i] += after * own[i] - total * row[i];
+            positives_before += positives_inside;
         }
-        for (int i = 0; i < dim; i++) row[i] += sum[i];
+        for (int i = 0; i < dim; i++) row[i] = total * row[i] + sum[i];
     }
     for (int s = 0; s < batch_size; s++) {
         const size_t head = batch[2 * s + 1];

@@ -1,0 +1,53 @@
+"""Experiment: a small stand-in for the headline shape — power-law 200k nodes / 2M edges, batch 100 000 (the top hub heads
+1 400 samples of a batch, as hub-heavy per launch as configs[1]), LINE, 50 epochs — link-prediction AUC per executor.
+With GVK_LIBRARY = the host build (tests/hostdev) the kernels are the sequential oracle: the value to match.
+
+    python scripts/experiments/c2mini.py seeds=3,4 configs="hub=0;hub=auto;hub=auto,chain_cap=64" [epochs=50]
+"""
+import logging
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import graphvite_amd as gv  # noqa: E402
+from graphvite_amd import synthetic  # noqa: E402
+from oracle_lib import link_prediction_auc  # noqa: E402
+
+extra = dict(kv.split("=", 1) for kv in sys.argv[1:])
+gv.init_logging(logging.ERROR)
+N, E, B = int(extra.get("nodes", 200000)), int(extra.get("edges", 2000000)), int(extra.get("batch", 100000))
+edges = synthetic.power_law_edges(N, E, seed=5)
+train, (valid, test) = synthetic.link_prediction_split(edges, (100, 1, 1))
+g = gv.graph.Graph()
+g.load(train)
+H, T, Y = (np.asarray(x) for x in test)
+name2id = np.full(N, -1, np.int64)
+names = np.array([int(x) for x in g.id2name], np.int64)
+name2id[names] = np.arange(len(names))
+keep = (name2id[H] >= 0) & (name2id[T] >= 0)
+host = "host" in os.environ.get("GVK_LIBRARY", "")
+if not host:
+    from graphvite_amd.kernels import HipKernels
+    tune = HipKernels()
+for config in extra.get("configs", "hub=0").split(";"):
+    kw = dict(kv.split("=") for kv in config.split(",") if kv)
+    if not host:
+        tune.set_tuning(8, int(kw.get("chain_cap", 0)))
+        tune.set_tuning(9, int(kw.get("serialized", 0)))
+        tune.set_variant(int(kw.get("variant", 0)))
+    aucs = []
+    for seed in [int(x) for x in extra.get("seeds", "3").split(",")]:
+        t0 = time.time()
+        hub = kw.get("hub", "0")
+        s = gv.solver.GraphSolver(128, num_sampler_per_worker=6, seed=seed, hub_rows=hub if hub == "auto" else int(hub),
+                                  pair_order=kw.get("order", "sampled") if kw.get("order", "sampled") != "auto" else gv.auto)
+        s.build(g, batch_size=B, episode_size=int(kw.get("episode", 20)))
+        s.train(model="LINE", num_epoch=int(extra.get("epochs", 50)), augmentation_step=1, log_frequency=1 << 30)
+        aucs.append(link_prediction_auc(s.vertex_embeddings, s.context_embeddings, name2id[H[keep]], name2id[T[keep]], Y[keep]))
+        print("    seed %d: AUC %.6f (%d batches, %.0f s)" % (seed, aucs[-1], s.batch_id, time.time() - t0), flush=True)
+    print("c2mini [%s]%s, %d hub rows: AUC %s mean %.6f" % (config, " sequential host build" if host else "", s.hub_rows,
+                                                           " ".join("%.6f" % a for a in aucs), np.mean(aucs)), flush=True)

@@ -1,0 +1,178 @@
+"""-m gpu: hub rows trained by chains (gvk_hot_build / gvk_train_episode_hot, include/gvk.h) against the oracle's restatement
+(oracle/gv_oracle.c gvo_hot_lists / gvo_train_hot).  The reference has no counterpart — its kernel trains every sample the
+same way (gpu/graph.cuh:36-95) — so what is pinned here is (1) that the work lists hold exactly the updates the batch has for
+every hub row, (2) that the three-launch form computes what the oracle computes from the same lists, and (3) that the
+pipelined product form stays with it; what the chains are FOR — the reference's learning quality on hub-heavy shapes — is
+pinned end to end in tests/test_solver_gpu.py."""
+import numpy as np
+import pytest
+import torch
+
+from graphvite_amd import kernels as K
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SEED, FIRST_ID, TOTAL = 5, 7, 100
+
+
+def layout(batch_size, k, chains, num_batch, cap):
+    """Offsets of gvk_hot_plan's workspace (hot_layout, graphvite_amd/csrc/gvk_kernels.hip)."""
+    cap = (cap or 256)
+    cap = (cap + k) // (k + 1) * (k + 1)
+    entry_capacity = 2 * (k + 1) * batch_size
+    align = lambda x: (x + 255) // 256 * 256  # noqa: E731
+    return cap, entry_capacity, align(num_batch * (chains + 1) * 4)
+
+
+def hub_case(rng, N, B, batches, kv, kc):
+    """Heads / tails: 40 % hub rows (skewed), the rest distinct other rows; the negative sampler: 30 % hub rows."""
+    def column(hot, lo):
+        ids = lo + rng.permutation(N // 4)[:batches * B]
+        pick = rng.random(batches * B) < 0.4
+        ids[pick] = np.minimum((rng.pareto(1.0, pick.sum()) * 2).astype(np.int64), hot - 1)
+        return ids
+    pool = np.stack([column(kc, N // 2), column(kv, N // 4)], 1).astype(np.uint32)
+    w = np.ones(N, np.float32)
+    w[:kc] = N * 0.3 / kc
+    w[kc:3 * N // 4] = 1e-3
+    return pool, w
+
+
+def negative_table(w, by_class):
+    if by_class:
+        return K.classes_to_device(K.class_table_build(w), DEV)
+    return K.packed_to_device(K.alias_build(w)[2], DEV)
+
+
+@pytest.mark.parametrize("by_class", [False, True])
+@pytest.mark.parametrize("dim,k,cap", [(128, 1, 0), (128, 1, 16), (128, 3, 10), (32, 1, 0), (64, 1, 8), (96, 2, 12), (256, 1, 0), (512, 1, 32)])
+def test_chains_match_the_oracle(hip, oracle, dim, k, cap, by_class):
+    if by_class and (dim, k, cap) not in ((128, 1, 0), (128, 3, 10)):
+        pytest.skip("the class table is exercised at dim 128")
+    rng = np.random.default_rng(dim * 10 + k)
+    # one batch: from the second batch on the chains would read rows that the first batch's pair launch trained Hogwild
+    N, B, batches, kv, kc = 1 << 15, 1500, 1, 24, 40
+    hip.set_tuning(8, cap)  # GVK_TUNE_CHAIN_CAP
+    try:
+        v = (rng.uniform(-0.5, 0.5, (N, dim)) * 0.05).astype(np.float32)
+        c = (rng.uniform(-0.5, 0.5, (N, dim)) * 0.05).astype(np.float32)
+        pool, w = hub_case(rng, N, B, batches, kv, kc)
+        table = negative_table(w, by_class)
+        opt = K.OptimizerSpec("SGD", 0.025, 0.005)
+        dpool = torch.from_numpy(pool.view(np.int32)).to(DEV)
+        ws = torch.zeros(hip.hot_plan(B, k, kv, kc, batches), dtype=torch.uint8, device=DEV)
+        hip.hot_build(ws, dpool, B, batches, k, table, SEED, FIRST_ID, kv, kc)
+        torch.cuda.synchronize()
+        chains = kv + kc
+        cap_entries, entry_capacity, off = layout(B, k, chains, batches, cap)
+        raw = ws.cpu().numpy()
+        starts = raw[:batches * (chains + 1) * 4].view(np.uint32).reshape(batches, chains + 1)
+        entries = raw[off:off + batches * entry_capacity * 4].view(np.uint32).reshape(batches, entry_capacity)
+        negs = torch.zeros(batches, B * k, dtype=torch.int32, device=DEV)
+        ov, oc = v.copy(), c.copy()
+        longest = 0
+        for b in range(batches):
+            hip.negative_draw(table, SEED, FIRST_ID + b, negs[b], B, k)
+            nb = negs[b].cpu().numpy().view(np.uint32).reshape(B, k)
+            pb = pool[b * B:(b + 1) * B]
+            # (1) the work lists: the oracle's, chain by chain, as multisets (the order inside a chain is the order the atomics retired in)
+            st, en = oracle.hot_lists(pb, nb, kv, kc)
+            assert (st == starts[b]).all()
+            for ch in range(chains):
+                assert (np.sort(en[st[ch]:st[ch + 1]]) == np.sort(entries[b, st[ch]:st[ch + 1]])).all(), ch
+            longest = max(longest, int(np.diff(st.astype(np.int64)).max()))
+            oracle.train_hot(ov, oc, pb, nb, oracle.lr(0.025, True, FIRST_ID + b, TOTAL), 0.005, 5.0, kv, kc, starts[b],
+                             entries[b, :st[-1]], cap_entries)
+        assert longest > cap_entries or cap == 0  # the small caps cut chains into parts
+        out = {}
+        for name, serialized in (("three launches", True), ("pipelined", False)):
+            tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
+            loss = torch.zeros(B, device=DEV)
+            hip.train_episode_hot(tv, tc, dpool, loss, opt, k, 5.0, table, SEED, FIRST_ID, TOTAL, batches, B, ws, kv, kc,
+                                  serialized=serialized)
+            torch.cuda.synchronize()
+            out[name] = (tv.cpu().numpy(), tc.cpu().numpy())
+            assert np.isfinite(out[name][0]).all() and np.isfinite(out[name][1]).all()
+        # (2) three launches per batch = the oracle on the same lists.  Rows of samples that share a NON-hub row with another
+        # sample are Hogwild in the pair launch and are left out; hub rows all count.
+        allneg = negs.cpu().numpy().view(np.uint32).reshape(batches * B, k)
+        ctx = np.concatenate([pool[:, 0][pool[:, 0] >= kc], allneg[allneg >= kc]])
+        ids, counts = np.unique(ctx, return_counts=True)
+        dirty_ctx = np.zeros(N, bool)
+        dirty_ctx[ids[counts > 1]] = True
+        hid, hcount = np.unique(pool[:, 1][pool[:, 1] >= kv], return_counts=True)
+        dirty_head = np.zeros(N, bool)
+        dirty_head[hid[hcount > 1]] = True
+        bad = dirty_ctx[pool[:, 0]] | dirty_head[pool[:, 1]] | dirty_ctx[allneg].any(1)
+        keep_v, keep_c = np.ones(N, bool), np.ones(N, bool)
+        keep_v[pool[bad, 1]] = False
+        keep_c[pool[bad, 0]] = False
+        keep_c[allneg[bad].reshape(-1)] = False
+        keep_v[:kv] = True
+        keep_c[:kc] = True
+        sv, sc = out["three launches"]
+        # fp32 tolerance: a chain is hundreds of dependent steps, each within 1e-7 of the oracle's (summation order of the dot
+        # product, expf / powf of the device library)
+        for got, want, keep in ((sv, ov, keep_v), (sc, oc, keep_c)):
+            np.testing.assert_allclose(got[keep], want[keep], rtol=1e-4, atol=1e-6)
+        moved_v, moved_c = np.linalg.norm(sv[:kv] - v[:kv]), np.linalg.norm(sc[:kc] - c[:kc])
+        assert moved_v > 0 and moved_c > 0
+        # (3) the product form (head-row and context-row chains in one launch, the pairs in the next): hub rows end where the
+        # three-launch form leaves them up to what the chains of the other table changed meanwhile (here 4 in 10 partners of a
+        # hub row are hub rows themselves: a coarse bound)
+        fv, fc = out["pipelined"]
+        assert np.linalg.norm(fv[:kv] - sv[:kv]) < moved_v and np.linalg.norm(fc[:kc] - sc[:kc]) < moved_c
+        # ... and over several batches (launch i: the pairs of batch i and the chains of batch i + 1)
+        pool3, _ = hub_case(rng, N, B, 3, kv, kc)
+        dpool3 = torch.from_numpy(pool3.view(np.int32)).to(DEV)
+        ws3 = torch.zeros(hip.hot_plan(B, k, kv, kc, 3), dtype=torch.uint8, device=DEV)
+        hip.hot_build(ws3, dpool3, B, 3, k, table, SEED, FIRST_ID, kv, kc)
+        ends = []
+        for serialized in (True, False):
+            tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
+            loss = torch.zeros(B, device=DEV)
+            hip.train_episode_hot(tv, tc, dpool3, loss, opt, k, 5.0, table, SEED, FIRST_ID, TOTAL, 3, B, ws3, kv, kc, serialized=serialized)
+            torch.cuda.synchronize()
+            ends.append((tv.cpu().numpy()[:kv], tc.cpu().numpy()[:kc]))
+        for (a, b), start in zip(zip(*ends), (v[:kv], c[:kc])):
+            assert np.isfinite(b).all() and np.linalg.norm(a - b) < np.linalg.norm(a - start)
+    finally:
+        hip.set_tuning(8, 0)
+
+
+def test_hub_rows_keep_their_updates(hip, oracle):
+    """What the chains are for: a head row that heads 400 samples of a batch.  Pair by pair one launch keeps a handful of the
+    400 updates; with the row owned by a chain it ends where 400 sequential updates take it."""
+    rng = np.random.default_rng(1)
+    N, m, dim = 1 << 14, 400, 128
+    B = m + 1000
+    v = (rng.uniform(-0.5, 0.5, (N, dim)) / dim).astype(np.float32)
+    c = (rng.uniform(-0.5, 0.5, (N, dim)) * 0.2).astype(np.float32)
+    heads = np.concatenate([np.zeros(m, np.int64), 100 + np.arange(1000)])
+    tails = 2000 + rng.permutation(4000)[:B]
+    pool = np.stack([tails, heads], 1).astype(np.uint32)
+    w = np.zeros(N, np.float32)
+    w[8000:] = 1
+    table = K.packed_to_device(K.alias_build(w)[2], DEV)
+    opt = K.OptimizerSpec("SGD", 0.025, 0.005)
+    dpool = torch.from_numpy(pool.view(np.int32)).to(DEV)
+    negs = torch.zeros(B, dtype=torch.int32, device=DEV)
+    hip.negative_draw(table, SEED, FIRST_ID, negs, B, 1)
+    nb = negs.cpu().numpy().view(np.uint32).reshape(B, 1)
+    sv, sc = v.copy(), c.copy()
+    oracle.train(sv, sc, pool, nb, oracle.lr(0.025, True, FIRST_ID, TOTAL), 0.005, 5.0)  # sequential
+    results = {}
+    for name, hub in (("pair by pair", 0), ("chain", 1)):
+        tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
+        loss = torch.zeros(B, device=DEV)
+        if hub:
+            ws = torch.zeros(hip.hot_plan(B, 1, 1, 1, 1), dtype=torch.uint8, device=DEV)
+            hip.hot_build(ws, dpool, B, 1, 1, table, SEED, FIRST_ID, 1, 1)
+            hip.train_episode_hot(tv, tc, dpool, loss, opt, 1, 5.0, table, SEED, FIRST_ID, TOTAL, 1, B, ws, 1, 1)
+        else:
+            hip.train_episode(tv, tc, dpool, loss, opt, 1, 5.0, table, SEED, FIRST_ID, TOTAL, 1, B)
+        torch.cuda.synchronize()
+        results[name] = tv.cpu().numpy()[0]
+    want = np.linalg.norm(sv[0] - v[0])
+    assert np.linalg.norm(results["chain"] - sv[0]) < 0.15 * want        # the chain: the sequential row (its partners read as the batch found them)
+    assert np.linalg.norm(results["pair by pair"] - v[0]) < 0.2 * want   # one launch of concurrent pairs: most updates lost

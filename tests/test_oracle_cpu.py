@@ -243,3 +243,78 @@ def test_solver_golden_equals_live_reference_solver(oracle):
     assert (part == G["cfg_w_p4_part"]).all() and (local == G["cfg_w_p4_local"]).all()
     assert (rs.schedule() == G["cfg_w_p4_schedule"]).all()
     assert (rs.sample("LINE", 1) == G["cfg_w_p4_edge_pools"]).all()
+
+
+# ---- hub rows trained by chains (the oracle's restatement of gvk_hot_build / gvk_train_episode_hot) -------------------------
+
+def _hub_batch(rng, N, B, k, kv, kc):
+    """Heads / tails: 40 % hub rows (skewed), the rest distinct non-hub rows; negatives: 30 % hub rows, the rest distinct."""
+    def column(hot, lo):
+        ids = lo + rng.permutation(N // 4)[:B]
+        pick = rng.random(B) < 0.4
+        ids[pick] = np.minimum((rng.pareto(1.0, pick.sum()) * 2).astype(np.int64), hot - 1)
+        return ids
+    batch = np.stack([column(kc, N // 2), column(kv, N // 4)], 1).astype(np.uint32)
+    negs = (3 * N // 4 + rng.permutation(N // 4)[:B * k]).reshape(B, k)
+    pick = rng.random((B, k)) < 0.3
+    negs[pick] = rng.integers(0, kc, pick.sum())
+    return batch, negs.astype(np.uint32)
+
+
+def test_hub_work_lists_hold_every_update_of_a_hub_row_once(oracle):
+    rng = np.random.default_rng(3)
+    N, B, k, kv, kc = 16384, 1500, 2, 20, 30
+    batch, negs = _hub_batch(rng, N, B, k, kv, kc)
+    start, entries = oracle.hot_lists(batch, negs, kv, kc)
+    assert start[0] == 0 and (np.diff(start.astype(np.int64)) >= 0).all() and start[-1] == len(entries)
+    for row in range(kv):  # a head row's chain: the targets of its samples, sample by sample, negatives first
+        mine = np.nonzero(batch[:, 1] == row)[0]
+        want = np.concatenate([np.concatenate([negs[s], [batch[s, 0] | 0x80000000]]) for s in mine]) if len(mine) else []
+        assert (entries[start[row]:start[row + 1]] == np.asarray(want, np.uint32)).all()
+    for row in range(kc):  # a context row's chain: the head of every sample the row is a target of, with the label
+        got = np.sort(entries[start[kv + row]:start[kv + row + 1]])
+        want = np.sort(np.concatenate([batch[batch[:, 0] == row, 1] | 0x80000000] +
+                                      [batch[negs[:, j] == row, 1] for j in range(k)]).astype(np.uint32))
+        assert (got == want).all()
+
+
+def test_hub_chains_without_hub_rows_are_the_plain_batch(oracle):
+    rng = np.random.default_rng(4)
+    N, B, k, dim = 512, 300, 2, 32
+    batch = rng.integers(0, N, (B, 2)).astype(np.uint32)
+    negs = rng.integers(0, N, (B, k)).astype(np.uint32)
+    v, c = init_tables(rng, N, N, dim)
+    v1, c1, v2, c2 = v.copy(), c.copy(), v.copy(), c.copy()
+    loss1 = oracle.train(v1, c1, batch, negs, 0.025, 0.005, 5.0)
+    loss2 = oracle.train_hot(v2, c2, batch, negs, 0.025, 0.005, 5.0, 0, 0, np.zeros(1, np.uint32), np.zeros(0, np.uint32), 256)
+    assert (v1 == v2).all() and (c1 == c2).all() and (loss1 == loss2).all()
+
+
+def test_hub_chains_keep_every_update_of_a_hub_row(oracle):
+    """A hub row that is the head of m samples moves as m sequential updates move it (the chain), the rows of the other
+    samples as in the plain batch; a chain cut into parts receives the sum of the parts' deltas."""
+    rng = np.random.default_rng(5)
+    N, m, dim = 256, 40, 32
+    v, c = init_tables(rng, N, N, dim)
+    v *= 30
+    c *= 30
+    batch = np.stack([100 + np.arange(m), np.zeros(m, np.int64)], 1).astype(np.uint32)  # head row 0, distinct tails
+    negs = (200 + np.arange(m)).astype(np.uint32).reshape(m, 1)
+    start, entries = oracle.hot_lists(batch, negs, 1, 0)
+    assert len(entries) == 2 * m
+    want_v, want_c = v.copy(), c.copy()
+    oracle.train(want_v, want_c, batch, negs, 0.025, 0.005, 5.0)           # sequential: what the reference's loop does
+    got_v, got_c = v.copy(), c.copy()
+    oracle.train_hot(got_v, got_c, batch, negs, 0.025, 0.005, 5.0, 1, 0, start, entries, 256)
+    # the chain reads the context rows as the batch found them, the sequential loop updates them as it goes: the head row
+    # agrees to first order in the learning rate, and it moved far beyond what one update moves it
+    one_v, one_c = v.copy(), c.copy()
+    oracle.train(one_v, one_c, batch[:1], negs[:1], 0.025, 0.005, 5.0)
+    moved, single = np.linalg.norm(got_v[0] - v[0]), np.linalg.norm(one_v[0] - v[0])
+    assert moved > 3 * single  # m random directions: about sqrt(m) single steps
+    assert np.linalg.norm(got_v[0] - want_v[0]) < 0.05 * moved
+    # the partner rows were trained against the hub row as the batch found it: the same step to first order
+    assert np.linalg.norm(got_c[100:100 + m] - want_c[100:100 + m]) < 0.5 * np.linalg.norm(want_c[100:100 + m] - c[100:100 + m])
+    parts_v, parts_c = v.copy(), c.copy()
+    oracle.train_hot(parts_v, parts_c, batch, negs, 0.025, 0.005, 5.0, 1, 0, start, entries, 20)  # 4 parts of 10 samples
+    assert np.linalg.norm(parts_v[0] - got_v[0]) < 0.1 * moved
