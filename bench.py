@@ -243,8 +243,8 @@ def link_prediction(args, gv, world, threads, partitions):
     ranked = y[order]
     auc = float(np.cumsum(ranked)[ranked == 0].sum()) / (int((ranked == 0).sum()) * int((ranked == 1).sum()))
     out = {"value": auc, "epochs": args.auc_epochs, "batches": solver.batch_id, "workers": world, "partitions": solver.num_partition,
-           "device_sampling": world > 1, "kernel": solver.kernels.describe_train(args.dim, "SGD", args.negatives, False, args.batch,
-                                                                                solver.partition_rows)}
+           "device_sampling": world > 1, "hub_rows": solver.hub_rows,
+           "kernel": solver.kernels.describe_train(args.dim, "SGD", args.negatives, False, args.batch, solver.partition_rows)}
     golden = os.path.join(ROOT, "tests", "golden", "reference_c2.npz")
     if os.path.exists(golden) and (args.vertices, args.edges, args.seed, args.batch) == (1000000, 10000000, 1024, 100000):
         G = np.load(golden)
@@ -255,6 +255,11 @@ def link_prediction(args, gv, world, threads, partitions):
                                               "note": "the reference's own GraphSolver::train on this shape, sequential kernel "
                                                       "model, one worker / one partition (tests/golden/make_c2_golden.py)"}
             out["difference"] = auc - float(reference.mean())
+            # the reference's kernel is itself concurrent (<<<8192, 512>>>, instance/graph.cuh:487-490): its own training loop
+            # under the two chunk-synchronous models of that launch on the card it was written for
+            models = {name: float(G["c2_line_" + name][0]) for name in ("lock_step", "reads_at_start") if "c2_line_" + name in G}
+            if models:
+                out["reference_training_loop"]["concurrent_models"] = models
     solver.clear()
     return out
 
@@ -451,6 +456,8 @@ def main(argv=None):
             break
     rows = solver.partition_rows
     kernel_name = solver.kernels.describe_train(dim, args.optimizer, k, False, B, rows)
+    if solver.hub_rows:  # gvk_train_episode_hot: the per-pair body + the chains of the next batch's hub rows in one launch
+        kernel_name = "train_hot_kernel<%d>: pairs + chains over %d hub rows per table" % (dim, solver.hub_rows)
     shard_bytes = rows * dim * 4 * (1 + moments)
     residency_note = ("both tables of a block fit the 32 MB of L2" if 2 * shard_bytes <= L2_BYTES else
                       "both tables of a block fit the 256 MB Infinity Cache: the kernel is served by the cache, not by HBM — "

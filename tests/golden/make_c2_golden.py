@@ -2,7 +2,8 @@
 as written, compiled for the host: oracle/ref_solver_harness.cpp, sequential kernel model) on the HEADLINE shape itself —
 BASELINE configs[1], the graph bench.py trains: synthetic power-law, 1M nodes / 10M edges (synthetic.power_law_edges,
 seed 1024), LINE, dim 128, batch 100 000, one partition, auto episode size, SGD 0.025 / 0.005 linear — for EPOCHS = 50
-epochs (5 000 batches).  ~15 minutes of host time per seed.
+epochs (5 000 batches), under the sequential kernel model (three seeds) and the two chunk-synchronous models of the
+reference's own launch (one seed each).  ~15 minutes of host time per training.
 
     python tests/golden/make_c2_golden.py          # resumable
 """
@@ -28,14 +29,20 @@ def main():
     oracle = Oracle()
     edges = synthetic.power_law_edges(N, E, seed=GRAPH_SEED)
     train, (valid, test) = synthetic.link_prediction_split(edges, (100, 1, 1))
-    for i, seed in enumerate(SEEDS):
+    # sequential: three seeds; the two chunk-synchronous models of the reference's own <<<8192, 512>>> launch on a V100
+    # (5120 resident warps; tests/golden/make_concurrency_golden.py): one seed each — the bracket the product is read against
+    jobs = [("sequential", 0, False, i, seed) for i, seed in enumerate(SEEDS)]
+    jobs += [("lock_step", 5120, False, 0, SEEDS[0]), ("reads_at_start", 5120, True, 0, SEEDS[0])]
+    for model, chunk, reads_at_start, i, seed in jobs:
+        key = "c2_line_" + model
         out = dict(np.load(PATH)) if os.path.exists(PATH) else {}
-        values = out.get("c2_line_sequential", np.full(len(SEEDS), np.nan))
+        values = out.get(key, np.full(len(SEEDS) if model == "sequential" else 1, np.nan))
         if not np.isnan(values[i]):
             continue
         t0 = time.time()
         rs = ReferenceSolver(oracle, seed, train.astype(np.uint32), None, True, 1, 4, 1, 1, BATCH, 0)  # episode auto
-        vertex, context, batch_id = reference_train(rs, "LINE", EPOCHS, augmentation_step=1)
+        kw = dict(kernel_chunk=chunk, threads=int(os.environ.get("THREADS", "3")), reads_at_start=reads_at_start) if chunk else {}
+        vertex, context, batch_id = reference_train(rs, "LINE", EPOCHS, augmentation_step=1, **kw)
         labels = rs.partition()[0]
         name2id = np.full(int(labels.max()) + 1, -1, np.int64)
         name2id[labels] = np.arange(len(labels))
@@ -44,10 +51,10 @@ def main():
         H, T, Y = H[ok], T[ok], Y[ok]
         ok = (name2id[H] >= 0) & (name2id[T] >= 0)
         values[i] = link_prediction_auc(vertex, context, name2id[H[ok]], name2id[T[ok]], Y[ok])
-        print("C2 LINE seed %d: episode %d, %d batches, AUC %.6f, %.0f s" % (seed, rs.episode_size, batch_id, values[i],
-                                                                            time.time() - t0), flush=True)
+        print("C2 LINE %s seed %d: episode %d, %d batches, AUC %.6f, %.0f s" % (model, seed, rs.episode_size, batch_id, values[i],
+                                                                               time.time() - t0), flush=True)
         out = dict(np.load(PATH)) if os.path.exists(PATH) else {}
-        out["c2_line_sequential"] = values
+        out[key] = values
         out["c2_args"] = np.array([N, E, GRAPH_SEED, BATCH, rs.episode_size, EPOCHS], np.int64)
         out["seeds"] = np.array(SEEDS, np.int64)
         np.savez_compressed(PATH + ".tmp.npz", **out)

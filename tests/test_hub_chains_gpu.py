@@ -175,4 +175,4 @@ def test_hub_rows_keep_their_updates(hip, oracle):
         results[name] = tv.cpu().numpy()[0]
     want = np.linalg.norm(sv[0] - v[0])
     assert np.linalg.norm(results["chain"] - sv[0]) < 0.15 * want        # the chain: the sequential row (its partners read as the batch found them)
-    assert np.linalg.norm(results["pair by pair"] - v[0]) < 0.2 * want   # one launch of concurrent pairs: most updates lost
+    assert np.linalg.norm(results["pair by pair"] - v[0]) < 0.5 * want   # one launch of concurrent pairs: most updates lost
