@@ -159,6 +159,7 @@ def test_several_workers_match_the_reference_training_loop(workers, partitions):
     n, e, communities, graph_seed, batch, epochs, aug = [int(x) for x in G["hub100k_args"]]
     gamma, p_in = [float(x) for x in G["hub100k_gamma_p_in"]]
     reference, episode = G["hub100k_w1_p%d" % partitions], int(G["hub100k_w1_p%d_episode" % partitions])
+    reference = reference[~np.isnan(reference)]
     threaded = G["hub100k_w%d_p%d" % (workers, partitions)] if workers == partitions else reference
     edges = synthetic.hub_community_edges(n, e, gamma=gamma, num_community=communities, p_in=p_in, seed=graph_seed)
     train, (valid, test) = synthetic.link_prediction_split(edges, (100, 1, 1))
