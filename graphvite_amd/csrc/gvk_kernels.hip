@@ -768,23 +768,25 @@ constexpr int kListThreads = 1024;
 __global__ void __launch_bounds__(kListThreads) hot_list_kernel(TrainArgs a, const uint32_t first_batch_id, const uint32_t stride,
                                                                 uint32_t *chain_start_all, uint32_t *entries_all, uint32_t *extra_all,
                                                                 const uint32_t entry_capacity, const uint32_t extra_capacity,
-                                                                const uint32_t cap) {
+                                                                const uint32_t cap, const int parts) {
     extern __shared__ uint32_t bins[];  // [chains]
     __shared__ uint32_t wave_total[kListThreads / 64];
     __shared__ uint32_t extra_count;
     const uint32_t chains = a.hot_vertex + a.hot_context;
+    // list blockIdx.x = part (blockIdx.x % parts) of batch (blockIdx.x / parts): samples [lo, hi) of the batch
     const int B = a.batch_size, k = a.k;
-    const u32x2 *records = reinterpret_cast<const u32x2 *>(a.pairs) + (size_t)blockIdx.x * B;
+    const int batch = blockIdx.x / parts, lo = (int)(blockIdx.x % parts) * (B / parts), hi = lo + B / parts;
+    const u32x2 *records = reinterpret_cast<const u32x2 *>(a.pairs) + (size_t)batch * B;
     uint32_t *chain_start = chain_start_all + (size_t)blockIdx.x * (chains + 1);
     uint32_t *entries = entries_all + (size_t)blockIdx.x * entry_capacity;
     uint32_t *extra = extra_all + (size_t)blockIdx.x * (1 + 2 * (size_t)extra_capacity);
-    a.batch_id = first_batch_id + blockIdx.x * stride;
+    a.batch_id = first_batch_id + (uint32_t)batch * stride;
 
     for (uint32_t i = threadIdx.x; i < chains; i += kListThreads) bins[i] = 0;
     if (threadIdx.x == 0) extra_count = 0;
     __syncthreads();
     // A: how many entries every chain gets
-    for (int s = threadIdx.x; s < B; s += kListThreads) {
+    for (int s = lo + threadIdx.x; s < hi; s += kListThreads) {
         const u32x2 pr = records[s];
         if (pr.y < a.hot_vertex) atomicAdd(&bins[pr.y], (uint32_t)(k + 1));
         if (pr.x < a.hot_context) atomicAdd(&bins[a.hot_vertex + pr.x], 1u);
@@ -827,7 +829,7 @@ __global__ void __launch_bounds__(kListThreads) hot_list_kernel(TrainArgs a, con
     __syncthreads();
     if (threadIdx.x == 0) extra[0] = extra_count;
     // B: scatter
-    for (int s = threadIdx.x; s < B; s += kListThreads) {
+    for (int s = lo + threadIdx.x; s < hi; s += kListThreads) {
         const u32x2 pr = records[s];
         const bool hot_head = pr.y < a.hot_vertex;
         uint32_t at = hot_head ? atomicAdd(&bins[pr.y], (uint32_t)(k + 1)) : 0;
@@ -1592,10 +1594,13 @@ uint32_t chain_cap_for(int k) {
     return (want + (uint32_t)k) / (uint32_t)(k + 1) * (uint32_t)(k + 1);
 }
 
-HotLayout hot_layout(int batch_size, int k, uint32_t hot_vertex, uint32_t hot_context, int num_batch) {
+// One work list per part of a batch (parts divides batch_size: gvk_train_launches): num_batch * parts lists.
+HotLayout hot_layout(int batch_size, int k, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts) {
     HotLayout l;
     l.chains = hot_vertex + hot_context;
     l.cap = chain_cap_for(k);
+    num_batch *= parts;
+    batch_size /= parts;
     // a sample adds at most k + 1 entries to its head's chain and one to the chain of each of its k + 1 targets
     l.entry_capacity = (uint32_t)(2 * (size_t)(k + 1) * (size_t)batch_size);
     l.extra_capacity = l.entry_capacity / l.cap + 1;
@@ -1607,8 +1612,9 @@ HotLayout hot_layout(int batch_size, int k, uint32_t hot_vertex, uint32_t hot_co
     return l;
 }
 
-int validate_hot(const char *what, int batch_size, int k, uint32_t hot_vertex, uint32_t hot_context, int num_batch) {
+int validate_hot(const char *what, int batch_size, int k, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts) {
     if (batch_size <= 0 || k < 0 || num_batch < 0) return gvk_fail(GVK_EINVAL, "%s: bad sizes", what);
+    if (parts < 1 || batch_size % parts) return gvk_fail(GVK_EINVAL, "%s: parts (%d) must divide the batch size", what, parts);
     if ((uint64_t)hot_vertex + hot_context == 0) return gvk_fail(GVK_EINVAL, "%s: no hub rows given", what);
     if ((uint64_t)hot_vertex + hot_context > kMaxChains)
         return gvk_fail(GVK_EINVAL, "%s: at most %u hub rows in all (%u + %u given)", what, kMaxChains, hot_vertex, hot_context);
@@ -1636,25 +1642,26 @@ HotKernel pick_hot(int dim, int k) {
 
 extern "C" {
 
-int gvk_hot_plan(int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, size_t *bytes) {
+int gvk_hot_plan(int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts,
+                 size_t *bytes) {
     if (!bytes) return fail(GVK_EINVAL, "gvk_hot_plan: bytes is null");
-    int rc = validate_hot("gvk_hot_plan", batch_size, num_negative, hot_vertex, hot_context, num_batch);
+    int rc = validate_hot("gvk_hot_plan", batch_size, num_negative, hot_vertex, hot_context, num_batch, parts);
     if (rc != GVK_OK) return rc;
-    *bytes = hot_layout(batch_size, num_negative, hot_vertex, hot_context, num_batch).bytes;
+    *bytes = hot_layout(batch_size, num_negative, hot_vertex, hot_context, num_batch, parts).bytes;
     return GVK_OK;
 }
 
 int gvk_hot_build(void *stream, void *workspace, size_t workspace_bytes, const uint32_t *pool, int batch_size, int num_batch,
                   int num_negative, const gvk_negative_source *negative, uint32_t first_batch_id, uint32_t batch_id_stride,
-                  uint32_t hot_vertex, uint32_t hot_context) {
-    int rc = validate_hot("gvk_hot_build", batch_size, num_negative, hot_vertex, hot_context, num_batch);
+                  uint32_t hot_vertex, uint32_t hot_context, int parts) {
+    int rc = validate_hot("gvk_hot_build", batch_size, num_negative, hot_vertex, hot_context, num_batch, parts);
     if (rc != GVK_OK) return rc;
     if (num_batch == 0) return GVK_OK;
     if (!workspace || !pool || !negative) return fail(GVK_EINVAL, "gvk_hot_build: null workspace / pool / negative source");
     if (negative->negatives) return fail(GVK_EINVAL, "gvk_hot_build: the chains need negatives drawn on the device");
     if (num_negative > 0 && (!negative->table || negative->count == 0) && (!negative->classes || negative->class_count == 0))
         return fail(GVK_EINVAL, "gvk_hot_build: no alias table given");
-    const HotLayout l = hot_layout(batch_size, num_negative, hot_vertex, hot_context, num_batch);
+    const HotLayout l = hot_layout(batch_size, num_negative, hot_vertex, hot_context, num_batch, parts);
     if (workspace_bytes < l.bytes) return gvk_fail(GVK_EINVAL, "gvk_hot_build: workspace holds %zu bytes, %zu needed", workspace_bytes, l.bytes);
     TrainArgs a;
     memset(&a, 0, sizeof(a));
@@ -1669,9 +1676,10 @@ int gvk_hot_build(void *stream, void *workspace, size_t workspace_bytes, const u
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kMaxChains * 4));
         if (e != hipSuccess) return gvk_fail(GVK_EHIP, "gvk_hot_build: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(hot_list_kernel, dim3((unsigned)num_batch), dim3(kListThreads), lds, (hipStream_t)stream, a, first_batch_id,
-                       batch_id_stride, reinterpret_cast<uint32_t *>(base + l.chain_start), reinterpret_cast<uint32_t *>(base + l.entries),
-                       reinterpret_cast<uint32_t *>(base + l.extra), l.entry_capacity, l.extra_capacity, l.cap);
+    hipLaunchKernelGGL(hot_list_kernel, dim3((unsigned)(num_batch * parts)), dim3(kListThreads), lds, (hipStream_t)stream, a,
+                       first_batch_id, batch_id_stride, reinterpret_cast<uint32_t *>(base + l.chain_start),
+                       reinterpret_cast<uint32_t *>(base + l.entries), reinterpret_cast<uint32_t *>(base + l.extra), l.entry_capacity,
+                       l.extra_capacity, l.cap, parts);
     return check_launch("gvk_hot_build");
 }
 
@@ -1679,17 +1687,17 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
                           const uint32_t *pairs, const gvk_negative_source *negative, uint32_t first_batch_id,
                           uint32_t batch_id_stride, uint32_t total_batches, int num_batches, float *loss, int batch_size,
                           int num_negative, float negative_weight, const void *workspace, size_t workspace_bytes,
-                          uint32_t hot_vertex, uint32_t hot_context, int workspace_batches, int serialized) {
+                          uint32_t hot_vertex, uint32_t hot_context, int workspace_batches, int parts, int serialized) {
     if (num_batches < 0 || num_batches > workspace_batches) return fail(GVK_EINVAL, "gvk_train_episode_hot: more batches than the work lists cover");
     int rc = validate_train(dim, optimizer, tables, pairs, negative, loss, batch_size, num_negative);
     if (rc <= 0) return rc;
-    rc = validate_hot("gvk_train_episode_hot", batch_size, num_negative, hot_vertex, hot_context, workspace_batches);
+    rc = validate_hot("gvk_train_episode_hot", batch_size, num_negative, hot_vertex, hot_context, workspace_batches, parts);
     if (rc != GVK_OK) return rc;
     if (optimizer->type != GVK_SGD) return fail(GVK_EINVAL, "gvk_train_episode_hot: chains exist for SGD only");
     if (negative->negatives) return fail(GVK_EINVAL, "gvk_train_episode_hot draws negatives on device");
     if (hot_vertex > tables->n_vertex || hot_context > tables->n_context)
         return fail(GVK_EINVAL, "gvk_train_episode_hot: more hub rows than table rows");
-    const HotLayout l = hot_layout(batch_size, num_negative, hot_vertex, hot_context, workspace_batches);
+    const HotLayout l = hot_layout(batch_size, num_negative, hot_vertex, hot_context, workspace_batches, parts);
     if (!workspace || workspace_bytes < l.bytes) return fail(GVK_EINVAL, "gvk_train_episode_hot: workspace too small (gvk_hot_plan)");
     const HotKernel kernel = pick_hot(dim, num_negative);
     if (!kernel) return fail(GVK_EDIM, "gvk_train_episode_hot: no kernel for this dim");
@@ -1708,8 +1716,13 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     h.chains = l.chains; h.extra_capacity = l.extra_capacity; h.cap = l.cap;
     const int tasks = (int)(l.chains + l.extra_capacity);
     const int task_blocks = (tasks + kBlock / 64 - 1) / (kBlock / 64);
-    const unsigned pair_blocks = (unsigned)(((int64_t)batch_size * lanes + kBlock - 1) / kBlock);
+    // the unit of work is a PART of a batch (parts = 1: the batch): unit u = part u % parts of batch u / parts
+    const int part_size = batch_size / parts, units = num_batches * parts;
+    const unsigned pair_blocks = (unsigned)(((int64_t)part_size * lanes + kBlock - 1) / kBlock);
     if (num_batches == 0) return GVK_OK;
+    // when every row of both tables is a hub row the pairs have nothing to store: they run for the last batch only, whose
+    // per-sample loss a caller may read
+    const bool chains_only = hot_vertex == tables->n_vertex && hot_context == tables->n_context;
     auto lr_of = [&](int i) {
         const uint32_t id = first_batch_id + (uint32_t)i * batch_id_stride;
         float scale = 1;
@@ -1719,41 +1732,47 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
         }
         return optimizer->lr * scale;
     };
-    auto chains_of = [&](int i) {  // the chain blocks of a launch work on batch i
-        h.chain_start = reinterpret_cast<const uint32_t *>(base + l.chain_start) + (size_t)i * (l.chains + 1);
-        h.entries = reinterpret_cast<const uint32_t *>(base + l.entries) + (size_t)i * l.entry_capacity;
-        h.extra = reinterpret_cast<const uint32_t *>(base + l.extra) + (size_t)i * (1 + 2 * (size_t)l.extra_capacity);
-        h.lr = lr_of(i);
+    auto chains_of = [&](int u) {  // the chain blocks of a launch work on unit u
+        h.chain_start = reinterpret_cast<const uint32_t *>(base + l.chain_start) + (size_t)u * (l.chains + 1);
+        h.entries = reinterpret_cast<const uint32_t *>(base + l.entries) + (size_t)u * l.entry_capacity;
+        h.extra = reinterpret_cast<const uint32_t *>(base + l.extra) + (size_t)u * (1 + 2 * (size_t)l.extra_capacity);
+        h.lr = lr_of(u / parts);
     };
-    auto pairs_of = [&](int i) {  // the pair blocks of a launch work on batch i
+    auto pairs_of = [&](int u) {  // the pair blocks of a launch work on unit u; false: nothing to do
+        const int i = u / parts;
         a.lr = lr_of(i);
         a.batch_id = first_batch_id + (uint32_t)i * batch_id_stride;
         a.pairs = pairs + (size_t)i * batch_size * 2;
+        a.first_sample = (u % parts) * part_size;
+        a.batch_size = a.first_sample + part_size;
+        return !chains_only || i == num_batches - 1;
     };
     auto launch = [&](int what) {
         h.what = what;
         h.task_blocks = (what & 3) ? task_blocks : 0;
+        if (!what) return;
         hipLaunchKernelGGL(kernel, dim3((unsigned)h.task_blocks + ((what & 4) ? pair_blocks : 0u)), dim3(kBlock), 0,
                            (hipStream_t)stream, a, h);
     };
     // A sample's updates to its rows are all computed from the rows as the sample found them (model/graph.h:47-58).  The
-    // chains of a batch therefore run BEFORE its pairs: a chain reads the partner rows before the batch's pairs move them
+    // chains of a unit therefore run BEFORE its pairs: a chain reads the partner rows before the unit's pairs move them
     // towards the hub row (a chain that read them afterwards would compound the step it is about to take — every sample of a
     // hub row, thousands per epoch: the row's norm explodes), and the pairs train against the hub rows the chains left.
-    // Pipelined: launch i trains the pairs of batch i and, in its first blocks, the chains of batch i + 1 — different samples,
+    // Pipelined: launch u trains the pairs of unit u and, in its first blocks, the chains of unit u + 1 — different samples,
     // so neither waits for the other — which hides the chains (a few long sequential tasks) behind the pairs (the bulk).
-    if (serialized || g_hot_serialized) {  // tests / bring-up: per batch three launches, what the oracle restates
-        for (int i = 0; i < num_batches; i++) {
-            chains_of(i), pairs_of(i);
-            launch(1), launch(2), launch(4);
+    if (serialized || g_hot_serialized) {  // tests / bring-up: per unit three launches, what the oracle restates
+        for (int u = 0; u < units; u++) {
+            chains_of(u);
+            const bool with_pairs = pairs_of(u);
+            launch(1), launch(2), launch(with_pairs ? 4 : 0);
         }
     } else {
         chains_of(0);
         launch(3);
-        for (int i = 0; i < num_batches; i++) {
-            pairs_of(i);
-            if (i + 1 < num_batches) chains_of(i + 1);
-            launch(i + 1 < num_batches ? 7 : 4);
+        for (int u = 0; u < units; u++) {
+            const bool with_pairs = pairs_of(u);
+            if (u + 1 < units) chains_of(u + 1);
+            launch((u + 1 < units ? 3 : 0) | (with_pairs ? 4 : 0));
         }
     }
     return check_launch("gvk_train_episode_hot");

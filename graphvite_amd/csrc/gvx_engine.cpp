@@ -1436,9 +1436,15 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int
         const uint32_t kv = hubs ? hub_rows[hp] : 0, kc = hubs ? hub_rows[tp] : 0;
         if (kv + kc > 0 && optimizer.schedule != 2) {
             // hub rows by chains: the work lists of up to kHubChunk batches, then their launches, on the same stream
+            // a small table — every row a hub row, many samples per row and batch — is trained as the parts gvk_train_launches
+            // prescribes for it (§7.8): a chain then sees its partners at most a part old
+            const int parts = kv == part_rows && kc == part_rows ? gvk_train_launches(B, part_rows) : 1;
             if (!w.hub_workspace) {
                 const uint32_t most = *std::max_element(hub_rows.begin(), hub_rows.end());
-                GVK_TRY(gvk_hot_plan(B, num_negative, most, most, kHubChunk, &w.hub_workspace_bytes));
+                size_t whole = 0;
+                GVK_TRY(gvk_hot_plan(B, num_negative, most, most, kHubChunk, 1, &whole));
+                GVK_TRY(gvk_hot_plan(B, num_negative, most, most, kHubChunk, gvk_train_launches(B, part_rows), &w.hub_workspace_bytes));
+                w.hub_workspace_bytes = std::max(w.hub_workspace_bytes, whole);
                 HIP_TRY(hipMalloc(&w.hub_workspace, w.hub_workspace_bytes));
             }
             for (int at = 0; at < n; at += kHubChunk) {
@@ -1446,10 +1452,10 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int
                 const uint32_t id = (uint32_t)(first + (uint64_t)at * W);
                 const uint32_t *batches = pool + (size_t)(done + at) * B * 2;
                 GVK_TRY(gvk_hot_build(w.compute, w.hub_workspace, w.hub_workspace_bytes, batches, B, m, num_negative, &neg, id,
-                                      (uint32_t)W, kv, kc));
+                                      (uint32_t)W, kv, kc, parts));
                 GVK_TRY(gvk_train_episode_hot(w.compute, dim, &o, optimizer.schedule == 1, &t, batches, &neg, id, (uint32_t)W,
                                               (uint32_t)num_batch, m, w.loss, B, num_negative, config.negative_weight,
-                                              w.hub_workspace, w.hub_workspace_bytes, kv, kc, m, 0));
+                                              w.hub_workspace, w.hub_workspace_bytes, kv, kc, m, parts, 0));
             }
         } else if (optimizer.schedule != 2) {
             GVK_TRY(gvk_train_episode(w.compute, dim, &o, optimizer.schedule == 1, &t, pool + (size_t)done * B * 2, &neg,

@@ -175,16 +175,21 @@ int gvk_train_episode(void *stream, int dim, const gvk_optimizer *optimizer, int
  *   gvk_train_episode_hot   gvk_train_episode over batches whose work lists sit in `workspace` (built for workspace_batches
  *                   batches starting with this call's first batch; same pool, ids, negative source, hot_vertex / hot_context).
  *                   serialized != 0: the same work as three launches in a fixed order — head-row chains, context-row
- *                   chains, pairs — which makes the result a pure function of the work lists (parity tests). */
-int gvk_hot_plan(int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, size_t *bytes);
+ *                   chains, pairs — which makes the result a pure function of the work lists (parity tests).
+ * parts (a divisor of batch_size, the same in all three calls; 1 = none): a batch is trained as `parts` equal parts one after
+ * the other, each with its own work lists — chains, then pairs, of samples [q, q + 1) * batch_size / parts — so that a chain
+ * sees its partner rows at most a part old; what gvk_train_launches() prescribes for small tables.  When
+ * every row of both tables is a hub row the pairs have nothing to store and only run for the last batch (its loss). */
+int gvk_hot_plan(int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts,
+                 size_t *bytes);
 int gvk_hot_build(void *stream, void *workspace, size_t workspace_bytes, const uint32_t *pool, int batch_size, int num_batch,
                   int num_negative, const gvk_negative_source *negative, uint32_t first_batch_id, uint32_t batch_id_stride,
-                  uint32_t hot_vertex, uint32_t hot_context);
+                  uint32_t hot_vertex, uint32_t hot_context, int parts);
 int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer, int linear_schedule, const gvk_tables *tables,
                           const uint32_t *pairs, const gvk_negative_source *negative, uint32_t first_batch_id,
                           uint32_t batch_id_stride, uint32_t total_batches, int num_batches, float *loss, int batch_size,
                           int num_negative, float negative_weight, const void *workspace, size_t workspace_bytes,
-                          uint32_t hot_vertex, uint32_t hot_context, int workspace_batches, int serialized);
+                          uint32_t hot_vertex, uint32_t hot_context, int workspace_batches, int parts, int serialized);
 
 /* logits[s] = dot(vertex[head_s], context[tail_s]) */
 int gvk_predict(void *stream, int dim, const float *vertex, const float *context, const uint32_t *pairs,

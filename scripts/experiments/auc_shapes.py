@@ -40,6 +40,7 @@ def main():
     if "split" in extra:
         tune.set_split_hits(int(extra["split"]))
     tune.set_tuning(8, int(extra.get("chain_cap", 0)))  # GVK_TUNE_CHAIN_CAP
+    tune.set_tuning(9, int(extra.get("serialized", 0)))  # GVK_TUNE_HOT_SERIALIZED
     hub = extra.get("hub", "0")
     tag = " ".join("%s=%s" % kv for kv in sorted(extra.items()))
     for order in orders:

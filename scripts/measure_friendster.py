@@ -30,6 +30,10 @@ def main():
     p.add_argument("--edges", type=int, default=200000000)
     p.add_argument("--partitions", type=int, default=8)
     p.add_argument("--episodes", type=int, default=2)
+    p.add_argument("--episode-size", type=int, default=250,
+                   help="batches per block pool; the reference's automatic size for this graph (65M * 175 / 8 / 100 000 = 14 218 "
+                        "batches = 11 GB per block pool) does not fit any GPU and is halved until it does (solver.h:437-455); with the "
+                        "positives drawn on the device every block pool of an episode is resident twice, so the size is given")
     p.add_argument("--dim", type=int, default=96)
     p.add_argument("--cpu-samplers", action="store_true", help="CPU sampler threads instead of device-side sampling")
     args = p.parse_args()
@@ -42,7 +46,8 @@ def main():
     del edges
     t2 = time.perf_counter()
     solver = gv.solver.GraphSolver(args.dim, device_sampling=not args.cpu_samplers, seed=1)
-    solver.build(graph, optimizer=gv.optimizer.SGD(0.025, 0.005), num_partition=args.partitions, num_negative=1, batch_size=100000)
+    solver.build(graph, optimizer=gv.optimizer.SGD(0.025, 0.005), num_partition=args.partitions, num_negative=1, batch_size=100000,
+                 episode_size=args.episode_size)
     per_episode = solver.num_partition ** 2 * solver.episode_size
     epochs = max(args.episodes * per_episode * solver.batch_size // graph.num_edge, 1)
     t3 = time.perf_counter()

@@ -15,10 +15,11 @@ DEV = "cuda:0"
 SEED, FIRST_ID, TOTAL = 5, 7, 100
 
 
-def layout(batch_size, k, chains, num_batch, cap):
-    """Offsets of gvk_hot_plan's workspace (hot_layout, graphvite_amd/csrc/gvk_kernels.hip)."""
+def layout(batch_size, k, chains, num_batch, cap, parts=1):
+    """Offsets of gvk_hot_plan's workspace (hot_layout, graphvite_amd/csrc/gvk_kernels.hip): one list per part of a batch."""
     cap = (cap or 256)
     cap = (cap + k) // (k + 1) * (k + 1)
+    num_batch, batch_size = num_batch * parts, batch_size // parts
     entry_capacity = 2 * (k + 1) * batch_size
     align = lambda x: (x + 255) // 256 * 256  # noqa: E731
     return cap, entry_capacity, align(num_batch * (chains + 1) * 4)
@@ -176,3 +177,55 @@ def test_hub_rows_keep_their_updates(hip, oracle):
     want = np.linalg.norm(sv[0] - v[0])
     assert np.linalg.norm(results["chain"] - sv[0]) < 0.15 * want        # the chain: the sequential row (its partners read as the batch found them)
     assert np.linalg.norm(results["pair by pair"] - v[0]) < 0.5 * want   # one launch of concurrent pairs: most updates lost
+
+
+def test_a_batch_trained_as_parts(hip, oracle):
+    """parts = 3: the batch's samples [0, 500), [500, 1000), [1000, 1500) one after the other, each with its own work lists
+    (negatives keep their sample's index in the batch) — the oracle's three-launch form applied part by part."""
+    rng = np.random.default_rng(9)
+    N, B, kv, kc, dim, k, parts = 1 << 15, 1500, 24, 40, 128, 1, 3
+    v = (rng.uniform(-0.5, 0.5, (N, dim)) * 0.05).astype(np.float32)
+    c = (rng.uniform(-0.5, 0.5, (N, dim)) * 0.05).astype(np.float32)
+    pool, w = hub_case(rng, N, B, 1, kv, kc)
+    table = negative_table(w, False)
+    opt = K.OptimizerSpec("SGD", 0.025, 0.005)
+    dpool = torch.from_numpy(pool.view(np.int32)).to(DEV)
+    ws = torch.zeros(hip.hot_plan(B, k, kv, kc, 1, parts), dtype=torch.uint8, device=DEV)
+    hip.hot_build(ws, dpool, B, 1, k, table, SEED, FIRST_ID, kv, kc, parts=parts)
+    torch.cuda.synchronize()
+    chains = kv + kc
+    cap_entries, entry_capacity, off = layout(B, k, chains, 1, 0, parts)
+    raw = ws.cpu().numpy()
+    starts = raw[:parts * (chains + 1) * 4].view(np.uint32).reshape(parts, chains + 1)
+    entries = raw[off:off + parts * entry_capacity * 4].view(np.uint32).reshape(parts, entry_capacity)
+    negs = torch.zeros(B * k, dtype=torch.int32, device=DEV)
+    hip.negative_draw(table, SEED, FIRST_ID, negs, B, k)
+    nb = negs.cpu().numpy().view(np.uint32).reshape(B, k)
+    ov, oc = v.copy(), c.copy()
+    lr = oracle.lr(0.025, True, FIRST_ID, TOTAL)
+    for q in range(parts):
+        lo, hi = q * B // parts, (q + 1) * B // parts
+        st, en = oracle.hot_lists(pool[lo:hi], nb[lo:hi], kv, kc)
+        assert (st == starts[q]).all()
+        for ch in range(chains):
+            assert (np.sort(en[st[ch]:st[ch + 1]]) == np.sort(entries[q, st[ch]:st[ch + 1]])).all()
+        oracle.train_hot(ov, oc, pool[lo:hi], nb[lo:hi], lr, 0.005, 5.0, kv, kc, starts[q], entries[q, :st[-1]], cap_entries)
+    tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
+    loss = torch.zeros(B, device=DEV)
+    hip.train_episode_hot(tv, tc, dpool, loss, opt, k, 5.0, table, SEED, FIRST_ID, TOTAL, 1, B, ws, kv, kc, serialized=True, parts=parts)
+    torch.cuda.synchronize()
+    # hub rows: exact; other rows are trained Hogwild inside a part and may have been read by a later part's chains
+    np.testing.assert_allclose(tv.cpu().numpy()[:kv], ov[:kv], rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(tc.cpu().numpy()[:kc], oc[:kc], rtol=2e-3, atol=2e-5)
+    # every row a hub row: the pairs have nothing to store (they only run for the last batch: its loss)
+    small_v, small_c = v[:64].copy(), c[:64].copy()
+    small = np.stack([rng.integers(0, 64, 600), rng.integers(0, 64, 600)], 1).astype(np.uint32)
+    dsmall = torch.from_numpy(small.view(np.int32)).to(DEV)
+    t2 = negative_table(np.ones(64, np.float32), False)
+    ws2 = torch.zeros(hip.hot_plan(300, 1, 64, 64, 2, 3), dtype=torch.uint8, device=DEV)
+    hip.hot_build(ws2, dsmall, 300, 2, 1, t2, SEED, FIRST_ID, 64, 64, parts=3)
+    tv, tc = torch.from_numpy(small_v).to(DEV), torch.from_numpy(small_c).to(DEV)
+    hip.train_episode_hot(tv, tc, dsmall, loss, opt, 1, 5.0, t2, SEED, FIRST_ID, TOTAL, 2, 300, ws2, 64, 64, parts=3)
+    torch.cuda.synchronize()
+    assert np.isfinite(tv.cpu().numpy()).all() and np.abs(tv.cpu().numpy() - small_v).max() > 0
+    assert np.isfinite(loss[:300].cpu().numpy()).all() and loss[:300].abs().sum() > 0

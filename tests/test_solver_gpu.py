@@ -105,8 +105,8 @@ def test_walk_models_match_the_reference_training_loop(name, sampling):
     GraphSolver::train as written — its sample_random_walk / sample_biased_random_walk with the per-edge alias tables of
     build_edge_edge, graph.cuh:298-450,656-721 — sequential kernel model) on the "blog" shape with the walk settings the
     reference ships for these models (augmentation_step 5, walks of 40, batch 100 000, episode 500) — p = q = 0.25 is
-    BASELINE configs[3], p = 4 / q = 2 config/graph/node2vec_youtube.yaml.  Means over the golden's six seeds (the two pipelines
-    share no random stream: the comparison is between means), +-0.002:
+    BASELINE configs[3], p = 4 / q = 2 config/graph/node2vec_youtube.yaml.  Means — the reference's over the golden's six seeds, this repo's over four (the two
+    pipelines share no random stream: the comparison is between means) — within +-0.002:
     the CPU samplers with the reference's tables, node2vec by rejection over the per-vertex tables (what configs[3] runs
     at Youtube's size, where the per-edge tables exceed 2^30 entries) and the walks drawn on the device."""
     G, train, test, build, fit = _walk_shape()
@@ -120,7 +120,7 @@ def test_walk_models_match_the_reference_training_loop(name, sampling):
     g = gv.graph.Graph()
     g.load(train)
     aucs = []
-    for seed in [int(x) for x in G["seeds"]]:
+    for seed in [int(x) for x in G["seeds"]][:4]:
         s = gv.solver.GraphSolver(128, num_sampler_per_worker=8, seed=seed, device_sampling=sampling == "device")
         if sampling == "rejection":
             s.node2vec_table_limit = 0
