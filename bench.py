@@ -93,6 +93,9 @@ def parse(argv=None):
                    help="GraphSolver(hub_rows=...): default = the product's rule (off for LINE), 0 = every row trained pair by pair, "
                         "`auto` / N = the hub rows of each partition (auto: expected hits per batch >= 2) trained by chains "
                         "(gvk_train_episode_hot, DESIGN.md §3.1.2)")
+    p.add_argument("--no-fidelity-leg", action="store_true", help="skip auc.fidelity_reference (the same training with "
+                        "GraphSolver(fidelity='reference'))")
+    p.add_argument("--hub-parts", type=int, default=0, help="GraphSolver.hub_parts: with hub rows by chains, a batch as this many parts")
     p.add_argument("--optimizer", choices=["SGD", "Momentum", "AdaGrad", "RMSprop", "Adam"], default="SGD",
                    help="experiment: moment optimizers move (1 + m) x the row bytes (m = 1, Adam 2)")
     p.add_argument("--graph", choices=["power-law", "community"], default="power-law",
@@ -181,12 +184,13 @@ def cpu_baseline(args, graph):
     return out
 
 
-def train_timed(args, gv, graph, threads, partitions, device_sampling, epochs):
+def train_timed(args, gv, graph, threads, partitions, device_sampling, epochs, fidelity="throughput"):
     """One GraphSolver.train() as a user calls it, timed by this process."""
     import torch
     solver = gv.solver.GraphSolver(args.dim, num_sampler_per_worker=threads, seed=args.seed, device_sampling=device_sampling,
-                                   pair_order=gv.auto if args.pair_order == "auto" else args.pair_order,
+                                   pair_order=gv.auto if args.pair_order == "auto" else args.pair_order, fidelity=fidelity,
                                    hub_rows=None if args.hub_rows == "default" else (args.hub_rows if args.hub_rows == "auto" else int(args.hub_rows)))
+    solver.hub_parts = args.hub_parts
     solver.negative_table = args.negative_table
     solver.build(graph, optimizer=gv.optimizer.SGD(0.025, 0.005, "linear"), num_partition=partitions,
                  num_negative=args.negatives, batch_size=args.batch)
@@ -238,10 +242,12 @@ def link_prediction(args, gv, world, threads, partitions):
     name2id[names] = np.arange(len(names))
     keep = (name2id[H] >= 0) & (name2id[T] >= 0)
     h, t, y = name2id[H[keep]], name2id[T[keep]], Y[keep]
-    score = np.einsum("ij,ij->i", solver.vertex_embeddings[h], solver.context_embeddings[t])
-    order = np.argsort(-score, kind="stable")
-    ranked = y[order]
-    auc = float(np.cumsum(ranked)[ranked == 0].sum()) / (int((ranked == 0).sum()) * int((ranked == 1).sum()))
+
+    def auc_of(trained):
+        score = np.einsum("ij,ij->i", trained.vertex_embeddings[h], trained.context_embeddings[t])
+        ranked = y[np.argsort(-score, kind="stable")]
+        return float(np.cumsum(ranked)[ranked == 0].sum()) / (int((ranked == 0).sum()) * int((ranked == 1).sum()))
+    auc = auc_of(solver)
     out = {"value": auc, "epochs": args.auc_epochs, "batches": solver.batch_id, "workers": world, "partitions": solver.num_partition,
            "device_sampling": world > 1, "hub_rows": solver.hub_rows,
            "kernel": solver.kernels.describe_train(args.dim, "SGD", args.negatives, False, args.batch, solver.partition_rows)}
@@ -261,6 +267,19 @@ def link_prediction(args, gv, world, threads, partitions):
             if models:
                 out["reference_training_loop"]["concurrent_models"] = models
     solver.clear()
+    if world == 1 and partitions == 1 and args.hub_rows == "default" and not args.no_fidelity_leg:
+        # the same training with GraphSolver(fidelity="reference"): the hub rows of the graph trained by chains, a batch as about
+        # ten parts — the product's answer to "AUC within 0.002 of the reference's loop" on this shape,
+        # and what it costs
+        faithful, wall = train_timed(args, gv, graph, threads, partitions, False, args.auc_epochs, fidelity="reference")
+        value = auc_of(faithful)
+        timing = faithful.timing
+        out["fidelity_reference"] = {"value": value, "hub_rows": faithful.hub_rows, "batches": timing["batches"],
+                                     "million_edge_samples_per_sec": timing["batches"] * args.batch / timing["episodes"] / 1e6,
+                                     "train_seconds": wall}
+        if "reference_training_loop" in out:
+            out["fidelity_reference"]["difference"] = value - out["reference_training_loop"]["mean"]
+        faithful.clear()
     return out
 
 
@@ -337,6 +356,7 @@ def main(argv=None):
     solver = gv.solver.GraphSolver(dim, num_sampler_per_worker=threads, seed=args.seed,
                                    pair_order=gv.auto if args.pair_order == "auto" else args.pair_order,
                                    hub_rows=None if args.hub_rows == "default" else (args.hub_rows if args.hub_rows == "auto" else int(args.hub_rows)))
+    solver.hub_parts = args.hub_parts
     solver.negative_table = args.negative_table
     for item in args.tune:
         key, value = item.split("=")

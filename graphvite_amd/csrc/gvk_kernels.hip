@@ -43,6 +43,7 @@ int g_run_cap = 0;         // GVK_TUNE_RUN_CAP (0 = the default of 20, run_cap_f
 int g_split_hits = 2;      // GVK_TUNE_SPLIT_HITS (samples per table row one launch may hold; 0 = never split a batch)
 int g_chain_cap = 0;       // GVK_TUNE_CHAIN_CAP (entries one chain task trains in sequence; 0 = the default of 256)
 int g_hot_serialized = 0;  // GVK_TUNE_HOT_SERIALIZED (bring-up: every gvk_train_episode_hot runs its three-launch form)
+int g_hot_whole_pairs = 0; // GVK_TUNE_HOT_WHOLE_PAIRS (experiment: only the chains of a batch are trained part by part, its pairs in one launch)
 #if defined(GVK_AB_BUILDS)  // knobs of the A/B library only (make ab -> build/ab/libgvk_ab.so)
 int g_lanes_per_pair = 0;  // GVK_TUNE_LANES_PER_PAIR
 int g_generation = 0;      // GVK_TUNE_GENERATION (0 = one launch per batch)
@@ -1589,16 +1590,16 @@ struct HotLayout {
 constexpr uint32_t kMaxChains = 32768;  // one LDS counter per chain in hot_list_kernel (128 KB of the CU's 160 KB)
 
 // entries one chain task trains in sequence: whole samples for head chains
-uint32_t chain_cap_for(int k) {
-    const uint32_t want = g_chain_cap > 0 ? (uint32_t)g_chain_cap : 256u;
+uint32_t chain_cap_for(int k, int chain_cap) {
+    const uint32_t want = chain_cap > 0 ? (uint32_t)chain_cap : (g_chain_cap > 0 ? (uint32_t)g_chain_cap : 256u);
     return (want + (uint32_t)k) / (uint32_t)(k + 1) * (uint32_t)(k + 1);
 }
 
 // One work list per part of a batch (parts divides batch_size: gvk_train_launches): num_batch * parts lists.
-HotLayout hot_layout(int batch_size, int k, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts) {
+HotLayout hot_layout(int batch_size, int k, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts, int chain_cap) {
     HotLayout l;
     l.chains = hot_vertex + hot_context;
-    l.cap = chain_cap_for(k);
+    l.cap = chain_cap_for(k, chain_cap);
     num_batch *= parts;
     batch_size /= parts;
     // a sample adds at most k + 1 entries to its head's chain and one to the chain of each of its k + 1 targets
@@ -1643,17 +1644,18 @@ HotKernel pick_hot(int dim, int k) {
 extern "C" {
 
 int gvk_hot_plan(int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts,
-                 size_t *bytes) {
+                 int chain_cap, size_t *bytes) {
     if (!bytes) return fail(GVK_EINVAL, "gvk_hot_plan: bytes is null");
     int rc = validate_hot("gvk_hot_plan", batch_size, num_negative, hot_vertex, hot_context, num_batch, parts);
     if (rc != GVK_OK) return rc;
-    *bytes = hot_layout(batch_size, num_negative, hot_vertex, hot_context, num_batch, parts).bytes;
+    if (chain_cap < 0) return fail(GVK_EINVAL, "gvk_hot_plan: negative chain_cap");
+    *bytes = hot_layout(batch_size, num_negative, hot_vertex, hot_context, num_batch, parts, chain_cap).bytes;
     return GVK_OK;
 }
 
 int gvk_hot_build(void *stream, void *workspace, size_t workspace_bytes, const uint32_t *pool, int batch_size, int num_batch,
                   int num_negative, const gvk_negative_source *negative, uint32_t first_batch_id, uint32_t batch_id_stride,
-                  uint32_t hot_vertex, uint32_t hot_context, int parts) {
+                  uint32_t hot_vertex, uint32_t hot_context, int parts, int chain_cap) {
     int rc = validate_hot("gvk_hot_build", batch_size, num_negative, hot_vertex, hot_context, num_batch, parts);
     if (rc != GVK_OK) return rc;
     if (num_batch == 0) return GVK_OK;
@@ -1661,7 +1663,8 @@ int gvk_hot_build(void *stream, void *workspace, size_t workspace_bytes, const u
     if (negative->negatives) return fail(GVK_EINVAL, "gvk_hot_build: the chains need negatives drawn on the device");
     if (num_negative > 0 && (!negative->table || negative->count == 0) && (!negative->classes || negative->class_count == 0))
         return fail(GVK_EINVAL, "gvk_hot_build: no alias table given");
-    const HotLayout l = hot_layout(batch_size, num_negative, hot_vertex, hot_context, num_batch, parts);
+    if (chain_cap < 0) return fail(GVK_EINVAL, "gvk_hot_build: negative chain_cap");
+    const HotLayout l = hot_layout(batch_size, num_negative, hot_vertex, hot_context, num_batch, parts, chain_cap);
     if (workspace_bytes < l.bytes) return gvk_fail(GVK_EINVAL, "gvk_hot_build: workspace holds %zu bytes, %zu needed", workspace_bytes, l.bytes);
     TrainArgs a;
     memset(&a, 0, sizeof(a));
@@ -1687,7 +1690,8 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
                           const uint32_t *pairs, const gvk_negative_source *negative, uint32_t first_batch_id,
                           uint32_t batch_id_stride, uint32_t total_batches, int num_batches, float *loss, int batch_size,
                           int num_negative, float negative_weight, const void *workspace, size_t workspace_bytes,
-                          uint32_t hot_vertex, uint32_t hot_context, int workspace_batches, int parts, int serialized) {
+                          uint32_t hot_vertex, uint32_t hot_context, int workspace_batches, int parts, int chain_cap,
+                          int serialized) {
     if (num_batches < 0 || num_batches > workspace_batches) return fail(GVK_EINVAL, "gvk_train_episode_hot: more batches than the work lists cover");
     int rc = validate_train(dim, optimizer, tables, pairs, negative, loss, batch_size, num_negative);
     if (rc <= 0) return rc;
@@ -1697,7 +1701,8 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     if (negative->negatives) return fail(GVK_EINVAL, "gvk_train_episode_hot draws negatives on device");
     if (hot_vertex > tables->n_vertex || hot_context > tables->n_context)
         return fail(GVK_EINVAL, "gvk_train_episode_hot: more hub rows than table rows");
-    const HotLayout l = hot_layout(batch_size, num_negative, hot_vertex, hot_context, workspace_batches, parts);
+    if (chain_cap < 0) return fail(GVK_EINVAL, "gvk_train_episode_hot: negative chain_cap");
+    const HotLayout l = hot_layout(batch_size, num_negative, hot_vertex, hot_context, workspace_batches, parts, chain_cap);
     if (!workspace || workspace_bytes < l.bytes) return fail(GVK_EINVAL, "gvk_train_episode_hot: workspace too small (gvk_hot_plan)");
     const HotKernel kernel = pick_hot(dim, num_negative);
     if (!kernel) return fail(GVK_EDIM, "gvk_train_episode_hot: no kernel for this dim");
@@ -1760,7 +1765,21 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     // hub row, thousands per epoch: the row's norm explodes), and the pairs train against the hub rows the chains left.
     // Pipelined: launch u trains the pairs of unit u and, in its first blocks, the chains of unit u + 1 — different samples,
     // so neither waits for the other — which hides the chains (a few long sequential tasks) behind the pairs (the bulk).
-    if (serialized || g_hot_serialized) {  // tests / bring-up: per unit three launches, what the oracle restates
+    if (g_hot_whole_pairs && parts > 1 && !serialized) {
+        // experiment: the chains of a batch part by part (a chain sees the other hub rows at most a part old), then the pairs of
+        // the whole batch in one launch
+        const unsigned whole_blocks = (unsigned)(((int64_t)batch_size * lanes + kBlock - 1) / kBlock);
+        for (int i = 0; i < num_batches; i++) {
+            for (int q = 0; q < parts; q++) {
+                chains_of(i * parts + q);
+                launch(3);
+            }
+            pairs_of(i * parts);
+            a.first_sample = 0, a.batch_size = batch_size;
+            h.what = 4, h.task_blocks = 0;
+            hipLaunchKernelGGL(kernel, dim3(whole_blocks), dim3(kBlock), 0, (hipStream_t)stream, a, h);
+        }
+    } else if (serialized || g_hot_serialized) {  // tests / bring-up: per unit three launches, what the oracle restates
         for (int u = 0; u < units; u++) {
             chains_of(u);
             const bool with_pairs = pairs_of(u);
@@ -2005,6 +2024,10 @@ int gvk_set_tuning(int key, int value) {
     if (key == GVK_TUNE_RUN_CAP) {
         if (value < 0 || value > kMaxRunCap) return fail(GVK_EINVAL, "gvk_set_tuning: run cap must be in [0, 4096]");
         g_run_cap = value;
+        return GVK_OK;
+    }
+    if (key == GVK_TUNE_HOT_WHOLE_PAIRS) {
+        g_hot_whole_pairs = value != 0;
         return GVK_OK;
     }
     if (key == GVK_TUNE_HOT_SERIALIZED) {

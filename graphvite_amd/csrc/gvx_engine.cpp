@@ -49,6 +49,7 @@ constexpr int kSamplePerVertex = 175;
 constexpr double kHubHits = 2;          // GVX_HUB_ROWS -1: a row a batch is expected to hit this often is a hub row
 constexpr uint64_t kMaxHubRows = 16384;  // per table (gvk_hot_build counts the chains of both tables in LDS)
 constexpr int kHubChunk = 128;          // batches whose work lists are built at once
+constexpr int kFidelityChainCap = 64;   // GVX_FIDELITY 1: entries per chain task
 constexpr int kMinEpisodeSample = 20000000;
 constexpr int kExpectedDegree = 1600;  // graph.cuh:55
 constexpr float kMaxNegativeWeight = 10;
@@ -167,6 +168,8 @@ struct gvx_solver {
     size_t memory_request = 0, gpu_memory_limit = 0, gpu_memory_cost = 0;
     uint64_t seed = 0;
     int pair_order_request = 0, negative_table_request = 0;
+    int fidelity = 0;               // GVX_FIDELITY: 0 = throughput (default), 1 = the reference's learning quality on hub-heavy tables
+    int hub_parts_request = 0;      // GVX_HUB_PARTS: 0 the rule (gvk_train_launches when every row is a hub row, else 1), Q > 0 given
     int64_t hub_rows_request = -2;  // GVX_HUB_ROWS: -2 the default rule, -1 by expected hits per batch, 0 off, N > 0 the first N rows
     uint64_t node2vec_table_limit = (uint64_t)1 << 30;
     // build
@@ -542,6 +545,14 @@ extern "C" int gvx_solver_set(gvx_solver *s, int option, int64_t value) {
         s->seed = (uint64_t)value;
         return GVK_OK;
     }
+    if (option == GVX_FIDELITY && (value == 0 || value == 1)) {
+        s->fidelity = (int)value;
+        return GVK_OK;
+    }
+    if (option == GVX_HUB_PARTS && value >= 0 && value <= 1024) {
+        s->hub_parts_request = (int)value;
+        return GVK_OK;
+    }
     if (option == GVX_HUB_ROWS && value >= -2) {
         s->hub_rows_request = value;
         return GVK_OK;
@@ -732,7 +743,7 @@ int gvx_solver::configure(const gvx_train_config &in) {
     // the default rule (-2): where chains are pinned against the reference's training loop — the walk-ordered
     // pools of DeepWalk / node2vec on one partition small enough that EVERY row is a hub row; everything else pair by pair
     int64_t request = hub_rows_request;
-    if (request == -2) request = walk_ordered() && num_partition == 1 && part_rows <= kMaxHubRows ? (int64_t)part_rows : 0;
+    if (request == -2) request = walk_ordered() && num_partition == 1 && part_rows <= kMaxHubRows ? (int64_t)part_rows : (fidelity ? -1 : 0);
     if (request != 0 && optimizer.type == GVK_SGD && optimizer.schedule != 2) {
         const float *vertex_weights = gvs_graph_vertex_weights(graph);
         for (int p = 0; p < num_partition; p++) {
@@ -1438,24 +1449,32 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int
             // hub rows by chains: the work lists of up to kHubChunk batches, then their launches, on the same stream
             // a small table — every row a hub row, many samples per row and batch — is trained as the parts gvk_train_launches
             // prescribes for it (§7.8): a chain then sees its partners at most a part old
-            const int parts = kv == part_rows && kc == part_rows ? gvk_train_launches(B, part_rows) : 1;
-            if (!w.hub_workspace) {
-                const uint32_t most = *std::max_element(hub_rows.begin(), hub_rows.end());
-                size_t whole = 0;
-                GVK_TRY(gvk_hot_plan(B, num_negative, most, most, kHubChunk, 1, &whole));
-                GVK_TRY(gvk_hot_plan(B, num_negative, most, most, kHubChunk, gvk_train_launches(B, part_rows), &w.hub_workspace_bytes));
-                w.hub_workspace_bytes = std::max(w.hub_workspace_bytes, whole);
-                HIP_TRY(hipMalloc(&w.hub_workspace, w.hub_workspace_bytes));
+            int parts = kv == part_rows && kc == part_rows ? gvk_train_launches(B, part_rows) : 1;
+            int chain_cap = 0;
+            if (hub_parts_request > 0 && B % hub_parts_request == 0) parts = hub_parts_request;
+            else if (fidelity && parts == 1) {  // GVX_FIDELITY 1: about ten parts per batch, chain tasks of 64 entries (§7.10)
+                for (int q = 10; q >= 2; q--)
+                    if (B % q == 0) { parts = q; break; }
+                chain_cap = kFidelityChainCap;
+            }
+            size_t need = 0;
+            GVK_TRY(gvk_hot_plan(B, num_negative, kv, kc, kHubChunk, parts, chain_cap, &need));
+            if (need > w.hub_workspace_bytes) {  // first block, or a block with more hub rows / parts than any before it
+                HIP_TRY(hipStreamSynchronize(w.compute));
+                hipFree(w.hub_workspace);
+                w.hub_workspace = nullptr, w.hub_workspace_bytes = 0;
+                HIP_TRY(hipMalloc(&w.hub_workspace, need));
+                w.hub_workspace_bytes = need;
             }
             for (int at = 0; at < n; at += kHubChunk) {
                 const int m = std::min(kHubChunk, n - at);
                 const uint32_t id = (uint32_t)(first + (uint64_t)at * W);
                 const uint32_t *batches = pool + (size_t)(done + at) * B * 2;
                 GVK_TRY(gvk_hot_build(w.compute, w.hub_workspace, w.hub_workspace_bytes, batches, B, m, num_negative, &neg, id,
-                                      (uint32_t)W, kv, kc, parts));
+                                      (uint32_t)W, kv, kc, parts, chain_cap));
                 GVK_TRY(gvk_train_episode_hot(w.compute, dim, &o, optimizer.schedule == 1, &t, batches, &neg, id, (uint32_t)W,
                                               (uint32_t)num_batch, m, w.loss, B, num_negative, config.negative_weight,
-                                              w.hub_workspace, w.hub_workspace_bytes, kv, kc, m, parts, 0));
+                                              w.hub_workspace, w.hub_workspace_bytes, kv, kc, m, parts, chain_cap, 0));
             }
         } else if (optimizer.schedule != 2) {
             GVK_TRY(gvk_train_episode(w.compute, dim, &o, optimizer.schedule == 1, &t, pool + (size_t)done * B * 2, &neg,

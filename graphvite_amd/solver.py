@@ -202,7 +202,8 @@ class GraphSolver(object):
     available_models = ("DeepWalk", "LINE", "node2vec")
 
     def __init__(self, dim, float_type=dtype.float32, index_type=dtype.uint32, device_ids=(), num_sampler_per_worker=auto,
-                 gpu_memory_limit=auto, seed=0, device_sampling=False, pair_order=auto, hub_rows=None):
+                 gpu_memory_limit=auto, seed=0, device_sampling=False, pair_order=auto, hub_rows=None,
+                 fidelity="throughput"):
         if dim not in self.available_dims or float_type != dtype.float32 or index_type != dtype.uint32:
             raise AttributeError("Can't find an instantiation of GraphSolver with dim=%s, float_type=%s, "
                                  "index_type=%s" % (dim, float_type, index_type))
@@ -245,6 +246,10 @@ class GraphSolver(object):
         self._pair_order_request = pair_order
         # GVX_HUB_ROWS (gvx.h): None = the default rule, "auto" = by expected hits per batch, 0 = off, N = the first N rows
         self.hub_rows_request = -2 if hub_rows is None else (-1 if hub_rows == "auto" else int(hub_rows))
+        self.hub_parts = 0  # GVX_HUB_PARTS (gvx.h): 0 = the rule
+        if fidelity not in ("throughput", "reference"):
+            raise ValueError("fidelity must be 'throughput' or 'reference', not %r" % (fidelity,))
+        self.fidelity = fidelity  # GVX_FIDELITY (gvx.h)
         self.negative_table = "auto"          # "rows": one alias slot per row (the reference's); "classes": by weight class
         self.node2vec_table_limit = 1 << 30   # per-edge table entries before node2vec samples by rejection
         self.graph = None
@@ -282,7 +287,8 @@ class GraphSolver(object):
                               (_lib.GVX_PAIR_ORDER, _PAIR_ORDERS[self._pair_order_request]),
                               (_lib.GVX_NEGATIVE_TABLE, _NEGATIVE_TABLES[self.negative_table]),
                               (_lib.GVX_NODE2VEC_TABLE_LIMIT, int(self.node2vec_table_limit)),
-                              (_lib.GVX_HUB_ROWS, int(self.hub_rows_request))):
+                              (_lib.GVX_HUB_ROWS, int(self.hub_rows_request)), (_lib.GVX_HUB_PARTS, int(self.hub_parts)),
+                              (_lib.GVX_FIDELITY, int(self.fidelity == "reference"))):
             self._check(self._lib.gvx_solver_set(self._handle, option, value), "GraphSolver")
 
     def _exchange_stats(self):

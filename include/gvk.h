@@ -179,17 +179,20 @@ int gvk_train_episode(void *stream, int dim, const gvk_optimizer *optimizer, int
  * parts (a divisor of batch_size, the same in all three calls; 1 = none): a batch is trained as `parts` equal parts one after
  * the other, each with its own work lists — chains, then pairs, of samples [q, q + 1) * batch_size / parts — so that a chain
  * sees its partner rows at most a part old; what gvk_train_launches() prescribes for small tables.  When
- * every row of both tables is a hub row the pairs have nothing to store and only run for the last batch (its loss). */
+ * every row of both tables is a hub row the pairs have nothing to store and only run for the last batch (its loss).
+ * chain_cap (the same in all three calls; 0 = the default, 256): entries one chain task trains in sequence — a longer chain
+ * is cut into tasks trained side by side and composed (weight decay in closed form). */
 int gvk_hot_plan(int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts,
-                 size_t *bytes);
+                 int chain_cap, size_t *bytes);
 int gvk_hot_build(void *stream, void *workspace, size_t workspace_bytes, const uint32_t *pool, int batch_size, int num_batch,
                   int num_negative, const gvk_negative_source *negative, uint32_t first_batch_id, uint32_t batch_id_stride,
-                  uint32_t hot_vertex, uint32_t hot_context, int parts);
+                  uint32_t hot_vertex, uint32_t hot_context, int parts, int chain_cap);
 int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer, int linear_schedule, const gvk_tables *tables,
                           const uint32_t *pairs, const gvk_negative_source *negative, uint32_t first_batch_id,
                           uint32_t batch_id_stride, uint32_t total_batches, int num_batches, float *loss, int batch_size,
                           int num_negative, float negative_weight, const void *workspace, size_t workspace_bytes,
-                          uint32_t hot_vertex, uint32_t hot_context, int workspace_batches, int parts, int serialized);
+                          uint32_t hot_vertex, uint32_t hot_context, int workspace_batches, int parts, int chain_cap,
+                          int serialized);
 
 /* logits[s] = dot(vertex[head_s], context[tail_s]) */
 int gvk_predict(void *stream, int dim, const float *vertex, const float *context, const uint32_t *pairs,
@@ -315,6 +318,7 @@ int gvk_probe_row_traffic(void *stream, int dim, float *vertex, float *context, 
                                      per batch */
 #define GVK_TUNE_CHAIN_CAP 8      /* gvk_train_episode_hot: entries one chain task trains in sequence (a longer chain is cut into
                                      parts trained side by side whose deltas add up): 0 = the default, 256 */
+#define GVK_TUNE_HOT_WHOLE_PAIRS 10 /* experiment: 1 = with parts, only the chains are trained part by part; the pairs of a batch in one launch */
 #define GVK_TUNE_HOT_SERIALIZED 9 /* bring-up: 1 = gvk_train_episode_hot always runs its three-launch form */
 /* A/B library only: */
 #define GVK_TUNE_LANES_PER_PAIR 1 /* 0 = per-dim default; else 8, 16, 32 or 64 */

@@ -146,6 +146,15 @@ void gvx_solver_destroy(gvx_solver *s);
  * to hit twice or more (by degree share; at most 16384 per table); N > 0: the first N rows of every partition; 0: off.
  * Batches keep the sampler's order. */
 #define GVX_HUB_ROWS 6
+/* GVX_HUB_PARTS: with hub rows trained by chains, a batch is trained as this many equal parts (a divisor of the batch size),
+ * each with its own chains and pairs; 0 (default): gvk_train_launches() parts where every row is a hub row, one otherwise. */
+#define GVX_HUB_PARTS 7
+/* GVX_FIDELITY 0 (default): throughput — every row of a large table is trained pair by pair (Hogwild, as the reference's
+ * kernel), the hub rows of a hub-heavy graph keep only some of their updates; 1: the reference's learning quality — the rows
+ * a batch is expected to hit twice or more are trained by chains and a batch as about ten parts (chain tasks of 64 entries):
+ * link-prediction AUC within 0.002 of the reference's sequential loop on the headline shape, at about a sixth of the rate
+ * (DESIGN.md §7.10).  GVX_HUB_ROWS / GVX_HUB_PARTS given explicitly take precedence. */
+#define GVX_FIDELITY 8
 int gvx_solver_set(gvx_solver *s, int option, int64_t value);
 
 /* The graph is borrowed until the next build / destroy (solver.h:289).  num_partition / episode_size: GVX_AUTO. */

@@ -36,6 +36,7 @@ for config in configs:
     tune.set_run_cap(int(kw.get("run_cap", 0)))
     tune.set_split_hits(int(kw.get("split", 2)))
     tune.set_tuning(8, int(kw.get("chain_cap", 0)))  # GVK_TUNE_CHAIN_CAP
+    tune.set_tuning(10, int(kw.get("whole_pairs", 0)))  # GVK_TUNE_HOT_WHOLE_PAIRS
     order = kw.get("order", "auto")
     aucs = []
     for seed in [int(x) for x in extra.get("seeds", "1024").split(",")]:
@@ -43,6 +44,7 @@ for config in configs:
         s = gv.solver.GraphSolver(128, num_sampler_per_worker=15, seed=seed, pair_order=gv.auto if order == "auto" else order,
                                   device_sampling=kw.get("device", "0") == "1",
                                   hub_rows=kw.get("hub", "0") if kw.get("hub", "0") == "auto" else int(kw.get("hub", "0")))
+        s.hub_parts = int(kw.get("parts", 0))
         s.build(g, batch_size=int(kw.get("batch", 100000)), num_partition=int(kw.get("partitions", 0)))
         s.train(model="LINE", num_epoch=int(extra.get("epochs", 50)), augmentation_step=1, log_frequency=1 << 30)
         aucs.append(link_prediction_auc(s.vertex_embeddings, s.context_embeddings, name2id[H[keep]], name2id[T[keep]], Y[keep]))

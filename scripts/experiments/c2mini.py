@@ -38,6 +38,7 @@ for config in extra.get("configs", "hub=0").split(";"):
     if not host:
         tune.set_tuning(8, int(kw.get("chain_cap", 0)))
         tune.set_tuning(9, int(kw.get("serialized", 0)))
+        tune.set_tuning(10, int(kw.get("whole_pairs", 0)))
         tune.set_variant(int(kw.get("variant", 0)))
     aucs = []
     for seed in [int(x) for x in extra.get("seeds", "3").split(",")]:
@@ -45,6 +46,7 @@ for config in extra.get("configs", "hub=0").split(";"):
         hub = kw.get("hub", "0")
         s = gv.solver.GraphSolver(128, num_sampler_per_worker=6, seed=seed, hub_rows=hub if hub == "auto" else int(hub),
                                   pair_order=kw.get("order", "sampled") if kw.get("order", "sampled") != "auto" else gv.auto)
+        s.hub_parts = int(kw.get("parts", 0))
         s.build(g, batch_size=B, episode_size=int(kw.get("episode", 20)))
         s.train(model="LINE", num_epoch=int(extra.get("epochs", 50)), augmentation_step=1, log_frequency=1 << 30)
         aucs.append(link_prediction_auc(s.vertex_embeddings, s.context_embeddings, name2id[H[keep]], name2id[T[keep]], Y[keep]))

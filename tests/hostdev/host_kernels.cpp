@@ -182,7 +182,7 @@ int gvk_train_episode(void *, int dim, const gvk_optimizer *optimizer, int linea
 
 // Hub rows by chains (gvk.h): a device-execution concern — what the chains restore is the sequential result, and the host
 // build's kernels ARE sequential.  The work lists are not needed; the batches are trained as gvk_train_episode trains them.
-int gvk_hot_plan(int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts,
+int gvk_hot_plan(int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts, int,
                  size_t *bytes) {
     if (!bytes || parts < 1 || batch_size % parts || batch_size <= 0 || num_negative < 0 || num_batch < 0 || (uint64_t)hot_vertex + hot_context == 0)
         return gvk_fail(GVK_EINVAL, "gvk_hot_plan: bad argument");
@@ -191,7 +191,7 @@ int gvk_hot_plan(int batch_size, int num_negative, uint32_t hot_vertex, uint32_t
 }
 
 int gvk_hot_build(void *, void *workspace, size_t, const uint32_t *pool, int, int, int, const gvk_negative_source *negative, uint32_t,
-                  uint32_t, uint32_t, uint32_t, int) {
+                  uint32_t, uint32_t, uint32_t, int, int) {
     return workspace && pool && negative ? GVK_OK : gvk_fail(GVK_EINVAL, "gvk_hot_build: null argument");
 }
 
@@ -199,7 +199,7 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
                           const uint32_t *pairs, const gvk_negative_source *negative, uint32_t first_batch_id,
                           uint32_t batch_id_stride, uint32_t total_batches, int num_batches, float *loss, int batch_size,
                           int num_negative, float negative_weight, const void *workspace, size_t, uint32_t hot_vertex,
-                          uint32_t hot_context, int workspace_batches, int, int) {
+                          uint32_t hot_context, int workspace_batches, int, int, int) {
     if (!workspace || num_batches > workspace_batches || hot_vertex > tables->n_vertex || hot_context > tables->n_context)
         return gvk_fail(GVK_EINVAL, "gvk_train_episode_hot: bad argument");
     return gvk_train_episode(stream, dim, optimizer, linear_schedule, tables, pairs, negative, first_batch_id, batch_id_stride,
