@@ -4,6 +4,9 @@ extern "C" {
 int gvk_train(void *, int, const gvk_optimizer *, const gvk_tables *, const uint32_t *, const gvk_negative_source *, uint32_t, float *, int, int, float) { return GVK_EHIP; }
 int gvk_train_episode(void *, int, const gvk_optimizer *, int, const gvk_tables *, const uint32_t *, const gvk_negative_source *, uint32_t, uint32_t, uint32_t, int, float *, int, int, float) { return GVK_EHIP; }
 int gvk_predict(void *, int, const float *, const float *, const uint32_t *, float *, int) { return GVK_EHIP; }
+int gvk_hot_plan(int, int, uint32_t, uint32_t, int, int, int, size_t *) { return GVK_EHIP; }
+int gvk_hot_build(void *, void *, size_t, const uint32_t *, int, int, int, const gvk_negative_source *, uint32_t, uint32_t, uint32_t, uint32_t, int, int) { return GVK_EHIP; }
+int gvk_train_episode_hot(void *, int, const gvk_optimizer *, int, const gvk_tables *, const uint32_t *, const gvk_negative_source *, uint32_t, uint32_t, uint32_t, int, float *, int, int, float, const void *, size_t, uint32_t, uint32_t, int, int, int, int) { return GVK_EHIP; }
 int gvk_alias_sample(void *, const gvk_alias_entry *, uint32_t, const double *, uint32_t *, int) { return GVK_EHIP; }
 int gvk_negative_draw(void *, const gvk_alias_entry *, uint32_t, uint64_t, uint32_t, uint32_t *, int, int) { return GVK_EHIP; }
 int gvk_sample_pairs(void *, const gvk_alias_entry *, const uint32_t *, uint32_t, uint64_t, uint64_t, uint32_t *, size_t) { return GVK_EHIP; }

@@ -108,6 +108,47 @@ def build_defaults():
         raise AssertionError("an instantiation that does not exist was accepted")
 
 
+def hub_row_rules():
+    """Which rows the engine hands to chains (GVX_HUB_ROWS / GVX_HUB_PARTS / GVX_FIDELITY).  The host build's
+    kernels are sequential — what chains restore — so the trained tables must not depend on the choice."""
+    g = make_graph(n=2000, e=30000)
+    trained = {}
+    for name, kw, model, want in (("default, LINE", {}, "LINE", 0), ("off", dict(hub_rows=0), "DeepWalk", 0),
+                                  ("default, DeepWalk: every row", {}, "DeepWalk", g.num_vertex),
+                                  ("by expected hits", dict(hub_rows="auto"), "LINE", None), ("given", dict(hub_rows=100), "LINE", 100),
+                                  ("more than there are", dict(hub_rows=10 ** 6), "LINE", g.num_vertex),
+                                  ("fidelity", dict(fidelity="reference"), "LINE", None)):
+        s = gv.solver.GraphSolver(32, num_sampler_per_worker=2, seed=1, **kw)
+        s.build(g, batch_size=1000, episode_size=4)
+        s.train(model=model, num_epoch=2, augmentation_step=1 if model == "LINE" else 2, log_frequency=1 << 30)
+        if want is None:  # rows a 1000-sample batch is expected to hit twice: a few dozen of 2000, the same for both requests
+            assert 0 < s.hub_rows < g.num_vertex // 4, (name, s.hub_rows)
+            trained.setdefault("expected hits", s.hub_rows)
+            assert trained["expected hits"] == s.hub_rows
+        else:
+            assert s.hub_rows == want, (name, s.hub_rows, want)
+        trained.setdefault(model, s.vertex_embeddings.copy())
+        assert (trained[model] == s.vertex_embeddings).all(), name
+    # partitions: the default rule is for one partition; a custom schedule and moment optimizers keep the pair-by-pair path
+    s = gv.solver.GraphSolver(32, num_sampler_per_worker=2, seed=1)
+    s.build(g, batch_size=1000, episode_size=4, num_partition=2)
+    s.train(model="DeepWalk", num_epoch=1, augmentation_step=2, log_frequency=1 << 30)
+    assert s.hub_rows == 0
+    s = gv.solver.GraphSolver(32, num_sampler_per_worker=2, seed=1, hub_rows=50)
+    s.build(g, optimizer=gv.optimizer.Adam(1e-3), batch_size=1000, episode_size=4)
+    s.train(model="LINE", num_epoch=1, log_frequency=1 << 30)
+    assert s.hub_rows == 0
+    s.hub_parts = 7  # not a divisor of the batch size: the rule's parts stay
+    s.build(g, batch_size=1000, episode_size=4)
+    s.train(model="LINE", num_epoch=1, log_frequency=1 << 30)
+    for bad in (lambda: gv.solver.GraphSolver(32, fidelity="exact"), lambda: gv.solver.GraphSolver(32, hub_rows=-5).build(g)):
+        try:
+            bad()
+        except ValueError:
+            continue
+        raise AssertionError("an invalid argument was accepted")
+
+
 def accounting_and_determinism():
     g = make_graph()
     log = Launches()

@@ -50,6 +50,10 @@ def test_build_defaults_follow_the_reference(host_build):
     scenario(host_build, "build_defaults")
 
 
+def test_hub_row_rules(host_build):
+    scenario(host_build, "hub_row_rules")
+
+
 def test_train_accounting_and_determinism(host_build):
     scenario(host_build, "accounting_and_determinism")
 
