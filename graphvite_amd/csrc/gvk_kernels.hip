@@ -42,15 +42,15 @@ int g_variant = 0;         // GVK_TUNE_VARIANT
 int g_run_cap = 0;         // GVK_TUNE_RUN_CAP (0 = the default of 20, run_cap_for)
 int g_split_hits = 2;      // GVK_TUNE_SPLIT_HITS (samples per table row one launch may hold; 0 = never split a batch)
 int g_chain_cap = 0;       // GVK_TUNE_CHAIN_CAP (entries one chain task trains in sequence; 0 = the default of 256)
-int g_hot_serialized = 0;  // GVK_TUNE_HOT_SERIALIZED (bring-up: every gvk_train_episode_hot runs its three-launch form)
-int g_hot_whole_pairs = 0; // GVK_TUNE_HOT_WHOLE_PAIRS (experiment: only the chains of a batch are trained part by part, its pairs in one launch)
 #if defined(GVK_AB_BUILDS)  // knobs of the A/B library only (make ab -> build/ab/libgvk_ab.so)
 int g_lanes_per_pair = 0;  // GVK_TUNE_LANES_PER_PAIR
 int g_generation = 0;      // GVK_TUNE_GENERATION (0 = one launch per batch)
 int g_segment_steps = 0;   // GVK_TUNE_SEGMENT_STEPS (0 = off)
 int g_skip_loss = 1;       // GVK_TUNE_SKIP_LOSS (gvk_train_episode leaves out the loss of batches nobody can read)
+int g_hot_serialized = 0;  // GVK_TUNE_HOT_SERIALIZED (bring-up: every gvk_train_episode_hot runs its three-launch form)
+int g_hot_whole_pairs = 0; // GVK_TUNE_HOT_WHOLE_PAIRS (experiment: only the chains of a batch are trained part by part, its pairs in one launch)
 #else
-constexpr int g_lanes_per_pair = 0, g_generation = 0, g_segment_steps = 0, g_skip_loss = 1;
+constexpr int g_lanes_per_pair = 0, g_generation = 0, g_segment_steps = 0, g_skip_loss = 1, g_hot_serialized = 0, g_hot_whole_pairs = 0;
 #endif
 
 struct TrainArgs {
@@ -1765,7 +1765,7 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     // hub row, thousands per epoch: the row's norm explodes), and the pairs train against the hub rows the chains left.
     // Pipelined: launch u trains the pairs of unit u and, in its first blocks, the chains of unit u + 1 — different samples,
     // so neither waits for the other — which hides the chains (a few long sequential tasks) behind the pairs (the bulk).
-    if (g_hot_whole_pairs && parts > 1 && !serialized) {
+    if (g_hot_whole_pairs != 0 && parts > 1 && !serialized) {
         // experiment: the chains of a batch part by part (a chain sees the other hub rows at most a part old), then the pairs of
         // the whole batch in one launch
         const unsigned whole_blocks = (unsigned)(((int64_t)batch_size * lanes + kBlock - 1) / kBlock);
@@ -1779,7 +1779,7 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
             h.what = 4, h.task_blocks = 0;
             hipLaunchKernelGGL(kernel, dim3(whole_blocks), dim3(kBlock), 0, (hipStream_t)stream, a, h);
         }
-    } else if (serialized || g_hot_serialized) {  // tests / bring-up: per unit three launches, what the oracle restates
+    } else if (serialized != 0 || g_hot_serialized != 0) {  // tests / bring-up: per unit three launches, what the oracle restates
         for (int u = 0; u < units; u++) {
             chains_of(u);
             const bool with_pairs = pairs_of(u);
@@ -2026,14 +2026,6 @@ int gvk_set_tuning(int key, int value) {
         g_run_cap = value;
         return GVK_OK;
     }
-    if (key == GVK_TUNE_HOT_WHOLE_PAIRS) {
-        g_hot_whole_pairs = value != 0;
-        return GVK_OK;
-    }
-    if (key == GVK_TUNE_HOT_SERIALIZED) {
-        g_hot_serialized = value != 0;
-        return GVK_OK;
-    }
     if (key == GVK_TUNE_CHAIN_CAP) {
         if (value < 0 || value > (1 << 20)) return fail(GVK_EINVAL, "gvk_set_tuning: chain cap must be in [0, 2^20]");
         g_chain_cap = value;
@@ -2067,9 +2059,13 @@ int gvk_set_tuning(int key, int value) {
         g_generation = value;
         return GVK_OK;
     }
+    if (key == GVK_TUNE_HOT_WHOLE_PAIRS || key == GVK_TUNE_HOT_SERIALIZED) {
+        (key == GVK_TUNE_HOT_WHOLE_PAIRS ? g_hot_whole_pairs : g_hot_serialized) = value != 0;
+        return GVK_OK;
+    }
 #else
     if (key == GVK_TUNE_LANES_PER_PAIR || key == GVK_TUNE_SEGMENT_STEPS || key == GVK_TUNE_SKIP_LOSS ||
-        key == GVK_TUNE_GENERATION) {
+        key == GVK_TUNE_GENERATION || key == GVK_TUNE_HOT_WHOLE_PAIRS || key == GVK_TUNE_HOT_SERIALIZED) {
         if (value == (key == GVK_TUNE_SKIP_LOSS ? 1 : 0)) return GVK_OK;  // the default is all the product library has
         return fail(GVK_EINVAL, "gvk_set_tuning: this knob exists in the A/B library only (make -C graphvite_amd/csrc ab)");
     }

@@ -318,10 +318,11 @@ int gvk_probe_row_traffic(void *stream, int dim, float *vertex, float *context, 
                                      per batch */
 #define GVK_TUNE_CHAIN_CAP 8      /* gvk_train_episode_hot: entries one chain task trains in sequence (a longer chain is cut into
                                      parts trained side by side whose deltas add up): 0 = the default, 256 */
-#define GVK_TUNE_HOT_WHOLE_PAIRS 10 /* experiment: 1 = with parts, only the chains are trained part by part; the pairs of a batch in one launch */
-#define GVK_TUNE_HOT_SERIALIZED 9 /* bring-up: 1 = gvk_train_episode_hot always runs its three-launch form */
 /* A/B library only: */
 #define GVK_TUNE_LANES_PER_PAIR 1 /* 0 = per-dim default; else 8, 16, 32 or 64 */
+#define GVK_TUNE_HOT_SERIALIZED 9   /* bring-up: 1 = gvk_train_episode_hot always runs its three-launch form */
+#define GVK_TUNE_HOT_WHOLE_PAIRS 10 /* experiment: 1 = with parts, only the chains are trained part by part; the pairs of a batch in one
+                                       launch (not enough: DESIGN.md §7.10) */
 #define GVK_TUNE_GENERATION 4     /* parity experiment: C > 0 trains a batch as consecutive launches of at most C samples
                                      (per-pair kernel), the concurrency structure of the reference's launch on a card
                                      that keeps C warps resident; 0 = off (default) */

@@ -213,7 +213,7 @@ def test_partitioned_training_matches_the_reference_training_loop(partitions, de
     every P.  With 6 250-row partitions a 100 000-sample batch holds 16 samples per head row and 32 per context row; the
     product trains such a batch as consecutive launches of at most 4 samples per row (gvk.h GVK_TUNE_SPLIT_HITS) — one
     launch per batch loses most concurrent updates there (AUC 0.880 at P = 16).  Means over the golden's
-    three seeds, +-0.002; CPU samplers and positives drawn on the device."""
+    seeds (six at P = 4, three otherwise), +-0.002; CPU samplers and positives drawn on the device."""
     G = np.load(PARTITIONS)
     n, e, communities, graph_seed, batch, epochs, aug = [int(x) for x in G["hub100k_args"]]
     gamma, p_in = [float(x) for x in G["hub100k_gamma_p_in"]]
@@ -226,7 +226,7 @@ def test_partitioned_training_matches_the_reference_training_loop(partitions, de
     g = gv.graph.Graph()
     g.load(train)
     aucs = []
-    for seed in (17, 18, 19):
+    for seed in [int(x) for x in G["seeds"]][:len(reference)]:  # as many seeds as the golden holds for this P (6 at P = 4, 3 otherwise)
         s = gv.solver.GraphSolver(128, num_sampler_per_worker=8, seed=seed, device_sampling=device_sampling)
         s.build(g, batch_size=batch, episode_size=episode, num_partition=partitions)
         s.train(model="LINE", num_epoch=epochs, augmentation_step=aug, log_frequency=1 << 30)
