@@ -49,7 +49,7 @@ constexpr int kSamplePerVertex = 175;
 constexpr double kHubHits = 2;          // GVX_HUB_ROWS -1: a row a batch is expected to hit this often is a hub row
 constexpr uint64_t kMaxHubRows = 16384;  // per table (gvk_hot_build counts the chains of both tables in LDS)
 constexpr int kHubChunk = 128;          // batches whose work lists are built at once
-constexpr int kFidelityChainCap = 64;   // GVX_FIDELITY 1: entries per chain task
+constexpr int kFidelityChainCap = 32;   // GVX_FIDELITY 1: entries per chain task
 constexpr int kMinEpisodeSample = 20000000;
 constexpr int kExpectedDegree = 1600;  // graph.cuh:55
 constexpr float kMaxNegativeWeight = 10;
@@ -1452,8 +1452,8 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int
             int parts = kv == part_rows && kc == part_rows ? gvk_train_launches(B, part_rows) : 1;
             int chain_cap = 0;
             if (hub_parts_request > 0 && B % hub_parts_request == 0) parts = hub_parts_request;
-            else if (fidelity && parts == 1) {  // GVX_FIDELITY 1: about ten parts per batch, chain tasks of 64 entries (§7.10)
-                for (int q = 10; q >= 2; q--)
+            else if (fidelity && parts == 1) {  // GVX_FIDELITY 1: about twenty parts per batch, chain tasks of 32 entries (§7.10)
+                for (int q = 20; q >= 2; q--)
                     if (B % q == 0) { parts = q; break; }
                 chain_cap = kFidelityChainCap;
             }
