@@ -269,7 +269,7 @@ def link_prediction(args, gv, world, threads, partitions):
     solver.clear()
     if world == 1 and partitions == 1 and args.hub_rows == "default" and not args.no_fidelity_leg:
         # the same training with GraphSolver(fidelity="reference"): the hub rows of the graph trained by chains, a batch as about
-        # ten parts — the product's answer to "AUC within 0.002 of the reference's loop" on this shape,
+        # twenty parts — the product's answer to "AUC within 0.002 of the reference's loop" on this shape,
         # and what it costs
         faithful, wall = train_timed(args, gv, graph, threads, partitions, False, args.auc_epochs, fidelity="reference")
         value = auc_of(faithful)

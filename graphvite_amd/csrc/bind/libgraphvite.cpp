@@ -320,8 +320,8 @@ void bind_solver(py::module &solver) {
         "            seed (int, optional): beyond the reference — seeds the initial embeddings, the samplers and the\n"
         "                negative draws (the reference seeds them from one process-wide generator)\n"
         "            fidelity (str, optional): beyond the reference — 'throughput' (default) or 'reference': train the hub rows\n"
-        "                of a hub-heavy graph by chains, a batch as ten parts (the reference's sequential learning quality at a\n"
-        "                seventh of the rate; gvx.h GVX_FIDELITY)\n        ");
+        "                of a hub-heavy graph by chains, a batch as twenty parts (the reference's sequential learning quality at a\n"
+        "                ninth of the rate; gvx.h GVX_FIDELITY)\n        ");
     cls.def(py::init<std::vector<int>, int, size_t, bool, int64_t, std::string>(), no_gil(),
             py::arg("device_ids") = std::vector<int>(), py::arg("num_sampler_per_worker") = kAuto,
             py::arg("gpu_memory_limit") = kAuto, py::arg("device_sampling") = false, py::arg("seed") = 0,

@@ -481,7 +481,7 @@ def test_headline_shape_matches_the_reference_training_loop_with_reference_fidel
     as written, sequential kernel model, three seeds: 0.6677).  The top hub of this graph heads a thousand samples of every
     batch: trained pair by pair (the throughput default, what bench.py times) the hub rows keep a handful of their updates
     and the AUC ends 0.018 below the reference's — below even the harsher of the two models of the reference's own
-    concurrent launch; GraphSolver(fidelity="reference") (hub rows by chains, a batch as ten parts)
+    concurrent launch; GraphSolver(fidelity="reference") (hub rows by chains, a batch as twenty parts)
     is held to +-0.002 here.  The default's figure is printed and bounded from below by the reference's lock-step model
     less 0.01 so that a regression of the fast path shows."""
     G = np.load(C2)
