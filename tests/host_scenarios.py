@@ -533,10 +533,31 @@ def node_classification_and_cli(tmp):
     assert rest.startswith(name0 + b" ")
     first = np.frombuffer(rest[len(name0) + 1:len(name0) + 1 + 32 * 4], np.float32)
     assert (first == app.solver.vertex_embeddings[0]).all()
+    # `baseline` / `list` (cmd.py:193-260): a configuration directory laid out as the reference's, a dataset placeholder that
+    # resolves to the file the reference's downloader would have left (dataset.py:183) — and to an error when it is not there
+    configs, datasets = os.path.join(tmp, "config"), os.path.join(tmp, "dataset")
+    os.makedirs(os.path.join(configs, "graph"))
+    os.makedirs(os.path.join(configs, "template"))
+    os.makedirs(os.path.join(datasets, "toy"))
+    np.savetxt(os.path.join(datasets, "toy", "toy_train.txt"), edges, fmt="%d")
+    baseline = dict(config, graph={"file_name": "<toy.train>", "as_undirected": True}, evaluate=[], save={"file_name": os.path.join(tmp, "b.pkl")})
+    baseline["train"] = dict(config["train"], num_epoch=1000)
+    for name in ("line_toy.yaml", "deepwalk_toy.yaml"):
+        open(os.path.join(configs, "graph", name), "w").write(yaml.safe_dump(baseline))
+    assert cmd.main(["baseline", "line", "toy", "--config-path", configs, "--dataset-path", datasets, "--epoch", "2", "--no-eval"]) == 0
+    assert os.path.exists(os.path.join(tmp, "b.pkl"))
+    assert cmd.list_main(argparse.Namespace(config_path=configs)) == 2
+    for keywords, message in ((["toy"], "Ambiguous"), (["node2vec"], "Can't find")):
+        try:
+            cmd.find_baseline(keywords, configs)
+        except ValueError as error:
+            assert message in str(error)
+            continue
+        raise AssertionError("baseline lookup accepted %s" % keywords)
     bad = os.path.join(tmp, "bad.yaml")
     open(bad, "w").write("graph:\n  file_name: <blogcatalog.train>\n")
     try:
-        cmd.load_config(bad)  # placeholder datasets are rejected
+        cmd.load_config(bad, datasets)  # a dataset that is not there: nothing is downloaded
     except ValueError:
         return
     raise AssertionError("a dataset placeholder was accepted")
