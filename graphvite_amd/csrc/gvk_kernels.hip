@@ -594,15 +594,17 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_runs_kernel(const TrainAr
 // and keeps a handful of its updates, where the reference's CPU solver (and its GPU kernel on the card it was written
 // for, far less concurrent) keeps them all: link-prediction AUC 0.650 against 0.668 on the headline shape.
 //
-// train_hot_kernel trains a batch as two kinds of work in ONE launch.  The hub rows of both tables — the first
+// With hub rows, a batch (or each of its parts) is two kinds of work.  The hub rows of both tables — the first
 // hot_vertex / hot_context local ids; partitions are ordered by falling degree — are each owned by a CHAIN: one
-// wavefront holds the row in registers and applies every update the batch has for it one after the other (for a head
+// wavefront holds the row in registers and applies every update the unit has for it one after the other (for a head
 // row the targets of its samples, negatives first; for a context row the heads it is the tail or the negative of),
 // reading the partner rows (D of them in flight) and writing nothing but its own row, once, at the end.  Everything else
 // is the per-pair body (train_pair<HOT>): every sample, all arithmetic, but hub rows are only read.  So a hub row has
-// ONE writer per launch and loses nothing; what remains of Hogwild is that a partner row may be read a few updates stale.
-// The chains' work lists (entries per hub row) are built per batch by hot_list_kernel.  A chain longer than `cap` entries
-// is cut into parts trained side by side from the row as the launch found it; their deltas add up (a few atomics).
+// ONE writer per unit and loses nothing.  The chains of a unit run BEFORE its pairs (gvk_train_episode_hot says why), and
+// train_hot_kernel is both in one launch for two DIFFERENT units: its first blocks run the chains of unit u + 1, the rest
+// the pairs of unit u.  The chains' work lists (entries per hub row) are built by hot_list_kernel.  A chain longer than
+// `cap` entries is cut into tasks trained side by side and composed: weight decay in closed form, the rest summed (a few
+// float atomics).
 struct HotArgs {
     const uint32_t *chain_start;  // [chains + 1] offsets of this batch into entries
     const uint32_t *entries;      // partner row | label << 31 (label 1 = positive)
