@@ -129,6 +129,17 @@ def hub_row_rules():
             assert s.hub_rows == want, (name, s.hub_rows, want)
         trained.setdefault(model, s.vertex_embeddings.copy())
         assert (trained[model] == s.vertex_embeddings).all(), name
+    # several workers / partitions with hub rows: the engine's bookkeeping (work lists per block visit, per-worker workspaces,
+    # partitions with different numbers of hub rows) — the tables must still be those of the plain run
+    plain = None
+    for hub, parts, fidelity in ((0, 0, "throughput"), (40, 0, "throughput"), ("auto", 4, "throughput"), (None, 0, "reference")):
+        s = gv.solver.GraphSolver(32, device_ids=[0, 0], num_sampler_per_worker=1, seed=4, hub_rows=hub, fidelity=fidelity)
+        s.hub_parts = parts
+        s.build(g, batch_size=1000, episode_size=3, num_partition=4)
+        s.train(model="LINE", num_epoch=2, augmentation_step=1, log_frequency=1 << 30)
+        assert (s.hub_rows > 0) == (hub != 0)
+        plain = s.vertex_embeddings.copy() if plain is None else plain
+        assert (plain == s.vertex_embeddings).all(), (hub, parts, fidelity)
     # partitions: the default rule is for one partition; a custom schedule and moment optimizers keep the pair-by-pair path
     s = gv.solver.GraphSolver(32, num_sampler_per_worker=2, seed=1)
     s.build(g, batch_size=1000, episode_size=4, num_partition=2)
