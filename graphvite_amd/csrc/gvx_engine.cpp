@@ -214,6 +214,7 @@ struct gvx_solver {
     // hub rows trained by chains (gvk_train_episode_hot): per partition, how many of its first rows (they are
     // ordered by falling degree) are owned by a chain when the partition is a block's head / tail table; 0 everywhere = off
     std::vector<uint32_t> hub_rows;
+    std::vector<int> hub_top_entries;  // per partition: updates a batch is expected to hold for its largest hub row (head role)
     bool hubs = false;
     bool resident_pools = false, session_open = false;
     std::vector<uint32_t *> host_sets[2];  // pinned host pools, two sets, one pool per block (index hp * P + tp)
@@ -739,6 +740,7 @@ int gvx_solver::configure(const gvx_train_config &in) {
     // hub rows (GVX_HUB_ROWS): the rows a batch is expected to hit kHubHits times or more — as a head / tail (degree share of
     // the partition) or as a negative (share of degree^exponent) — are trained by chains; their batches keep the sampler's order
     hub_rows.assign(num_partition, 0);
+    hub_top_entries.assign(num_partition, 0);
     hubs = false;
     // the default rule (-2): where chains are pinned against the reference's training loop — the walk-ordered
     // pools of DeepWalk / node2vec on one partition small enough that EVERY row is a hub row; everything else pair by pair
@@ -763,6 +765,11 @@ int gvx_solver::configure(const gvx_train_config &in) {
                 }
             }
             hub_rows[p] = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(rows, ids.size()), kMaxHubRows);
+            if (!ids.empty()) {  // the head of batch_size * share samples, (num_negative + 1) chain entries each
+                double total = 0;
+                for (uint32_t id : ids) total += vertex_weights[id];
+                hub_top_entries[p] = (int)std::min(1e9, (double)batch_size * (num_negative + 1) * vertex_weights[ids[0]] / std::max(total, 1e-30));
+            }
             hubs = hubs || hub_rows[p] > 0;
         }
         if (hubs) grouped = false;
@@ -1452,9 +1459,15 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int
             int parts = kv == part_rows && kc == part_rows ? gvk_train_launches(B, part_rows) : 1;
             int chain_cap = 0;
             if (hub_parts_request > 0 && B % hub_parts_request == 0) parts = hub_parts_request;
-            else if (fidelity && parts == 1) {  // GVX_FIDELITY 1: about twenty parts per batch, chain tasks of 32 entries (§7.10)
-                for (int q = 20; q >= 2; q--)
-                    if (B % q == 0) { parts = q; break; }
+            else if (fidelity && parts == 1) {
+                // GVX_FIDELITY 1: so many parts that the largest hub row meets about a hundred of its updates per part — twenty
+                // on the headline shape, where 20 parts with chain tasks of 32 entries are within 0.002 of the reference's loop and
+                // 10 parts are not safely (§7.10) —, a divisor of the batch size, at most 50
+                const int want = std::min(std::max((std::max(hub_top_entries[hp], hub_top_entries[tp]) + 50) / 100, 2), 50);
+                for (int q = want; q <= 4 * want && parts == 1; q++)
+                    if (B % q == 0) parts = q;
+                for (int q = want; q >= 2 && parts == 1; q--)
+                    if (B % q == 0) parts = q;
                 chain_cap = kFidelityChainCap;
             }
             size_t need = 0;

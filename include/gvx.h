@@ -151,8 +151,9 @@ void gvx_solver_destroy(gvx_solver *s);
 #define GVX_HUB_PARTS 7
 /* GVX_FIDELITY 0 (default): throughput — every row of a large table is trained pair by pair (Hogwild, as the reference's
  * kernel), the hub rows of a hub-heavy graph keep only some of their updates; 1: the reference's learning quality — the rows
- * a batch is expected to hit twice or more are trained by chains and a batch as about twenty parts (chain tasks of 32
- * entries): link-prediction AUC within 0.002 of the reference's sequential loop on the headline shape, at about an eighth of the rate
+ * a batch is expected to hit twice or more are trained by chains and a batch as so many parts that the largest hub row meets
+ * about a hundred of its updates per part (twenty on the headline shape; chain tasks of 32 entries): link-prediction AUC
+ * within 0.002 of the reference's sequential loop there, at about a ninth of the rate
  * (DESIGN.md §7.10).  GVX_HUB_ROWS / GVX_HUB_PARTS given explicitly take precedence. */
 #define GVX_FIDELITY 8
 int gvx_solver_set(gvx_solver *s, int option, int64_t value);
