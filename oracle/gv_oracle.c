@@ -190,14 +190,12 @@ static void gvo_chain(int dim, float *own, const float *partner, const uint32_t 
  * order on its own row, context rows read; (2) the chains of the kc hub context rows, vertex rows read; (3) every sample in
  * order as gvo_train, except that hub rows are read and never written.  A chain longer than cap entries is trained as parts
  * of cap entries side by side and the parts are composed (below). */
-int gvo_train_hot(int dim, float *vertex, float *context, const uint32_t *batch, const uint32_t *negatives, float *loss,
-                  int batch_size, int k, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
-                  const uint32_t *chain_start, const uint32_t *entries, uint32_t cap) {
+static int gvo_hot_chains(int dim, float *vertex, float *context, float lr, float wd, float negative_weight, uint32_t kv,
+                          const uint32_t *chain_start, const uint32_t *entries, uint32_t cap, uint32_t first_chain,
+                          uint32_t last_chain) {
     float *own = (float *)malloc(sizeof(float) * dim), *sum = (float *)malloc(sizeof(float) * dim);
-    float *buf = (float *)malloc(sizeof(float) * dim);
-    float dummy1 = 0, dummy2 = 0;
-    if (!own || !sum || !buf) return -1;
-    for (uint32_t chain = 0; chain < kv + kc; chain++) {  /* chains kv.. read the vertex rows the first kv chains wrote */
+    if (!own || !sum) return -1;
+    for (uint32_t chain = first_chain; chain < last_chain; chain++) {  /* chains kv.. read the vertex rows as they are */
         float *row = chain < kv ? vertex + (size_t)chain * dim : context + (size_t)(chain - kv) * dim;
         const float *partner = chain < kv ? context : vertex;
         const uint32_t first = chain_start[chain], last = chain_start[chain + 1];
@@ -228,6 +226,18 @@ int gvo_train_hot(int dim, float *vertex, float *context, const uint32_t *batch,
         }
         for (int i = 0; i < dim; i++) row[i] = total * row[i] + sum[i];
     }
+    free(own), free(sum);
+    return 0;
+}
+
+int gvo_train_hot(int dim, float *vertex, float *context, const uint32_t *batch, const uint32_t *negatives, float *loss,
+                  int batch_size, int k, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
+                  const uint32_t *chain_start, const uint32_t *entries, uint32_t cap) {
+    float *own = (float *)malloc(sizeof(float) * dim), *buf = (float *)malloc(sizeof(float) * dim);
+    float dummy1 = 0, dummy2 = 0;
+    if (!own || !buf) return -1;
+    /* the chains of the head rows, then those of the context rows (which read the head rows the first kv chains wrote) */
+    if (gvo_hot_chains(dim, vertex, context, lr, wd, negative_weight, kv, chain_start, entries, cap, 0, kv + kc)) return -1;
     for (int s = 0; s < batch_size; s++) {
         const size_t head = batch[2 * s + 1];
         memcpy(buf, vertex + head * dim, sizeof(float) * dim);
@@ -264,7 +274,89 @@ int gvo_train_hot(int dim, float *vertex, float *context, const uint32_t *batch,
         loss[s] = sample_loss / (1 + k * negative_weight);
         if (head >= kv) memcpy(vertex + head * dim, buf, sizeof(float) * dim);
     }
-    free(own), free(sum), free(buf);
+    free(own), free(buf);
+    return 0;
+}
+
+/* EXPERIMENT (scripts/experiments/executor_sim.py; no product counterpart yet): gvo_train_hot with one change in its third
+ * phase — a sample reads a hub row not as the chains left it but where the chain was when it met the sample, approximated by
+ * the straight line from the row before the chains to the row after them: sample s of n reads start + (s + 1/2) / n (end -
+ * start).  `lerp` = 0 gives gvo_train_hot.  Asks: how much of the staleness that sub-batching removes is the pairs reading
+ * end-of-batch hub rows? */
+int gvo_train_hot_lerp(int dim, float *vertex, float *context, const uint32_t *batch, const uint32_t *negatives, float *loss,
+                       int batch_size, int k, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
+                       const uint32_t *chain_start, const uint32_t *entries, uint32_t cap, int lerp) {
+    float *v0 = (float *)malloc(sizeof(float) * dim * (kv ? kv : 1)), *c0 = (float *)malloc(sizeof(float) * dim * (kc ? kc : 1));
+    float *buf = (float *)malloc(sizeof(float) * dim), *hub = (float *)malloc(sizeof(float) * dim);
+    float *own = (float *)malloc(sizeof(float) * dim);
+    float dummy1 = 0, dummy2 = 0;
+    if (!v0 || !c0 || !buf || !hub || !own) return -1;
+    memcpy(v0, vertex, sizeof(float) * dim * kv);
+    memcpy(c0, context, sizeof(float) * dim * kc);
+    /* phases 1 and 2: the chains.  lerp & 2: the two families side by side, each reading the OTHER table's hub rows as the
+     * unit found them (what one launch of concurrent chains does: a sample between two hub rows updates both from their old
+     * values, as the reference does, model/graph.h:47-58); otherwise head rows first, context rows against the new head rows */
+    int rc;
+    if (lerp & 2) {
+        float *c_end = (float *)malloc(sizeof(float) * dim * (kc ? kc : 1));
+        if (!c_end) return -1;
+        rc = gvo_hot_chains(dim, vertex, context, lr, wd, negative_weight, kv, chain_start, entries, cap, kv, kv + kc);
+        memcpy(c_end, context, sizeof(float) * dim * kc);
+        memcpy(context, c0, sizeof(float) * dim * kc);
+        if (!rc) rc = gvo_hot_chains(dim, vertex, context, lr, wd, negative_weight, kv, chain_start, entries, cap, 0, kv);
+        memcpy(context, c_end, sizeof(float) * dim * kc);
+        free(c_end);
+    } else {
+        rc = gvo_hot_chains(dim, vertex, context, lr, wd, negative_weight, kv, chain_start, entries, cap, 0, kv + kc);
+    }
+    if (rc) return rc;
+    for (int s = 0; s < batch_size; s++) {
+        const float at = (lerp & 1) ? (s + 0.5f) / batch_size : 1.0f;
+        const size_t head = batch[2 * s + 1];
+        if (head < kv)
+            for (int i = 0; i < dim; i++) buf[i] = v0[head * dim + i] + at * (vertex[head * dim + i] - v0[head * dim + i]);
+        else
+            memcpy(buf, vertex + head * dim, sizeof(float) * dim);
+        float sample_loss = 0;
+        size_t last = 0;
+        int have = 0;
+        for (int j = 0; j <= k; j++) {
+            const size_t tail = j < k ? negatives[(size_t)s * k + j] : batch[2 * s];
+            const int label = j == k;
+            float *c = context + tail * dim;
+            const float *from = c;
+            if (tail < kc) {
+                if (have && tail == last) {
+                    from = own;
+                } else {
+                    for (int i = 0; i < dim; i++) hub[i] = c0[tail * dim + i] + at * (c[i] - c0[tail * dim + i]);
+                    from = hub;
+                }
+            }
+            float logit = 0;
+            for (int i = 0; i < dim; i++) logit += buf[i] * from[i];
+            const float prob = gvo_sigmoid(logit);
+            float gradient, weight;
+            if (label) {
+                gradient = prob - 1, weight = 1;
+                sample_loss += weight * -logf(prob + GVO_EPS);
+            } else {
+                gradient = prob, weight = negative_weight;
+                sample_loss += weight * -logf(1 - prob + GVO_EPS);
+            }
+            for (int i = 0; i < dim; i++) {
+                const float vi = buf[i], ci = from[i];
+                buf[i] -= gvo_update(0, lr, wd, NULL, vi, gradient * ci, weight, &dummy1, &dummy2);
+                const float cn = ci - gvo_update(0, lr, wd, NULL, ci, gradient * vi, weight, &dummy1, &dummy2);
+                if (tail >= kc) c[i] = cn;
+                own[i] = cn;
+            }
+            last = tail, have = 1;
+        }
+        loss[s] = sample_loss / (1 + k * negative_weight);
+        if (head >= kv) memcpy(vertex + head * dim, buf, sizeof(float) * dim);
+    }
+    free(v0), free(c0), free(buf), free(hub), free(own);
     return 0;
 }
 

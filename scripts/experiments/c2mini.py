@@ -1,6 +1,11 @@
 """Experiment: a small stand-in for the headline shape — power-law 200k nodes / 2M edges, batch 100 000 (the top hub heads
 1 400 samples of a batch, as hub-heavy per launch as configs[1]), LINE, 50 epochs — link-prediction AUC per executor.
-With GVK_LIBRARY = the host build (tests/hostdev) the kernels are the sequential oracle: the value to match.
+With GVK_LIBRARY = the host build (tests/hostdev) the kernels are the sequential oracle: the value to match.  The host build
+is also an executor SIMULATOR: with hub rows requested (hub=…, parts=…) and GVH_EXECUTOR=chains it trains every part in the
+product's three-launch form (head-row chains, context-row chains, pairs: oracle/gv_oracle.c gvo_train_hot; GVH_CHAIN_CAP =
+entries per chain task), with GVH_EXECUTOR=lerp the pairs read a hub row where its chain was when it met the sample
+(gvo_train_hot_lerp) — what a change of the device path would do to learning, measured without a GPU (the Hogwild losses of
+the other rows are not simulated).
 
     python scripts/experiments/c2mini.py seeds=3,4 configs="hub=0;hub=auto;hub=auto,chain_cap=64" [epochs=50]
 """
