@@ -175,7 +175,10 @@ int gvk_train_episode(void *stream, int dim, const gvk_optimizer *optimizer, int
  *   gvk_train_episode_hot   gvk_train_episode over batches whose work lists sit in `workspace` (built for workspace_batches
  *                   batches starting with this call's first batch; same pool, ids, negative source, hot_vertex / hot_context).
  *                   serialized != 0: the same work as three launches in a fixed order — head-row chains, context-row
- *                   chains, pairs — which makes the result a pure function of the work lists (parity tests).
+ *                   chains, pairs — which makes the result a pure function of the work lists.  A form for parity tests of the
+ *                   kernels only: the product form runs the two chain families side by side, so that a sample between two
+ *                   hub rows updates both from their old values as the reference does; one after the other they compound
+ *                   (DESIGN.md §3.1.2).
  * parts (a divisor of batch_size, the same in all three calls; 1 = none): a batch is trained as `parts` equal parts one after
  * the other, each with its own work lists — chains, then pairs, of samples [q, q + 1) * batch_size / parts — so that a chain
  * sees its partner rows at most a part old; what gvk_train_launches() prescribes for small tables.  When
