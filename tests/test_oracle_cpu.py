@@ -318,3 +318,33 @@ def test_hub_chains_keep_every_update_of_a_hub_row(oracle):
     parts_v, parts_c = v.copy(), c.copy()
     oracle.train_hot(parts_v, parts_c, batch, negs, 0.025, 0.005, 5.0, 1, 0, start, entries, 20)  # 4 parts of 10 samples
     assert np.linalg.norm(parts_v[0] - got_v[0]) < 0.1 * moved
+
+
+def test_chain_families_side_by_side_update_a_hub_pair_from_its_old_values(oracle):
+    """A sample between two hub rows belongs to two chains.  The reference updates both rows from their old values
+    (model/graph.h:47-58): with the two chain families side by side — what the product's launch does — a positive sample
+    between two hub rows is exactly the reference's step; head rows first and context rows against the NEW head rows (the
+    three-launch test form) gives the context row a step that already contains the sample's own (the second
+    ordering fact)."""
+    rng = np.random.default_rng(11)
+    N, dim = 8, 32
+    v, c = init_tables(rng, N, N, dim)
+    v *= 40
+    c *= 40
+    batch = np.array([[1, 0]], np.uint32)      # {tail 1, head 0}: both hub rows (kv = kc = 2); no negatives
+    negs = np.zeros((1, 0), np.uint32)
+    start, entries = oracle.hot_lists(batch, negs, 2, 2)
+    assert start.tolist() == [0, 1, 1, 1, 2] and entries.tolist() == [1 | 0x80000000, 0 | 0x80000000]
+    want_v, want_c = v.copy(), c.copy()
+    oracle.train(want_v, want_c, batch, negs, 0.025, 0.005, 5.0)
+    side_v, side_c = v.copy(), c.copy()
+    oracle.train_hot_forms(side_v, side_c, batch, negs, 0.025, 0.005, 5.0, 2, 2, start, entries, 256, simultaneous=True)
+    after_v, after_c = v.copy(), c.copy()
+    oracle.train_hot_forms(after_v, after_c, batch, negs, 0.025, 0.005, 5.0, 2, 2, start, entries, 256, simultaneous=False)
+    assert (side_v == want_v).all() and (side_c == want_c).all()          # side by side: the reference's step, bit for bit
+    assert (after_v == want_v).all() and not (after_c == want_c).all()    # one after the other: the context row saw the new head row
+    step = np.linalg.norm(want_c[1] - c[1])
+    assert 0 < np.linalg.norm(after_c[1] - want_c[1]) < 0.2 * step         # ... a second-order difference per sample, but every sample
+    plain_v, plain_c = v.copy(), c.copy()                                 # the same call without flags is gvo_train_hot
+    oracle.train_hot(plain_v, plain_c, batch, negs, 0.025, 0.005, 5.0, 2, 2, start, entries, 256)
+    assert (plain_v == after_v).all() and (plain_c == after_c).all()
