@@ -621,7 +621,7 @@ def _rank(rank, world, port, out_dir, model, aug, partitions, order, device_samp
         log = Launches()
         log.clear()
         s = gv.solver.GraphSolver(dim, num_sampler_per_worker=2, seed=train_kw.pop("seed", 9), device_sampling=device_sampling,
-                                  pair_order=gv.auto if order == "auto" else order)
+                                  pair_order=gv.auto if order == "auto" else order, **train_kw.pop("solver", {}))
         s.build(g, num_partition=partitions, **train_kw.pop("build"))
         assert s.num_worker == world and s.num_local_worker == 1 and s.rank == rank
         assert s.num_partition == (partitions or world)
@@ -698,6 +698,18 @@ def processes_over_gloo(tmp, world, model, aug, partitions, order, device_sampli
     for w, x in enumerate(r):
         assert (x["ids"] % world == w).all() and int(x["batch_id"]) == len(ids) >= int(x["num_batch"])
         np.testing.assert_allclose(x["lrs"], np.float32(0.025) * np.maximum(1 - x["ids"] / float(x["num_batch"]), 1e-4), rtol=1e-6)
+
+
+def hub_rows_over_gloo(tmp):
+    """Two processes, four partitions, hub rows requested: every rank builds the work lists of its own blocks; with the
+    host build's sequential kernels the tables are those of the plain run, and both ranks end with the same tables."""
+    kw = lambda **solver: dict(seed=9, solver=solver, check_pairs=False, build=dict(batch_size=400, episode_size=3), num_epoch=4,  # noqa: E731
+                               log_frequency=100000)
+    plain = _spawn(2, tmp, "LINE", 1, 4, "sampled", False, None, kw())
+    for solver in (dict(hub_rows=20), dict(fidelity="reference")):
+        hub = _spawn(2, tmp, "LINE", 1, 4, "sampled", False, None, kw(**solver))
+        assert (hub[0]["v"] == hub[1]["v"]).all() and (hub[0]["c"] == hub[1]["c"]).all()
+        assert (hub[0]["v"] == plain[0]["v"]).all() and (hub[0]["c"] == plain[0]["c"]).all()
 
 
 def learning_quality_over_gloo(tmp):

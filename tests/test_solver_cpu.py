@@ -122,5 +122,9 @@ def test_processes_over_gloo(host_build, tmp_path, world, model, aug, partitions
     scenario(host_build, "processes_over_gloo", str(tmp_path), world, model, aug, partitions, order, device_sampling)
 
 
+def test_hub_rows_over_gloo(host_build, tmp_path):
+    scenario(host_build, "hub_rows_over_gloo", str(tmp_path))
+
+
 def test_two_processes_learn_what_the_reference_learns(host_build, tmp_path):
     scenario(host_build, "learning_quality_over_gloo", str(tmp_path), timeout=3000)
