@@ -96,6 +96,8 @@ def parse(argv=None):
     p.add_argument("--no-fidelity-leg", action="store_true", help="skip auc.fidelity_reference (the same training with "
                         "GraphSolver(fidelity='reference'))")
     p.add_argument("--hub-parts", type=int, default=0, help="GraphSolver.hub_parts: with hub rows by chains, a batch as this many parts")
+    p.add_argument("--hub-lerp", type=int, default=-1, help="GraphSolver.hub_lerp: -1 the rule, 0 / 1 (the pairs read hub rows along their chains' way)")
+    p.add_argument("--hub-cap", type=int, default=0, help="GraphSolver.hub_chain_cap: entries one chain task trains in sequence (0 = default)")
     p.add_argument("--optimizer", choices=["SGD", "Momentum", "AdaGrad", "RMSprop", "Adam"], default="SGD",
                    help="experiment: moment optimizers move (1 + m) x the row bytes (m = 1, Adam 2)")
     p.add_argument("--graph", choices=["power-law", "community"], default="power-law",
@@ -191,6 +193,8 @@ def train_timed(args, gv, graph, threads, partitions, device_sampling, epochs, f
                                    pair_order=gv.auto if args.pair_order == "auto" else args.pair_order, fidelity=fidelity,
                                    hub_rows=None if args.hub_rows == "default" else (args.hub_rows if args.hub_rows == "auto" else int(args.hub_rows)))
     solver.hub_parts = args.hub_parts
+    solver.hub_lerp = None if args.hub_lerp < 0 else bool(args.hub_lerp)
+    solver.hub_chain_cap = args.hub_cap
     solver.negative_table = args.negative_table
     solver.build(graph, optimizer=gv.optimizer.SGD(0.025, 0.005, "linear"), num_partition=partitions,
                  num_negative=args.negatives, batch_size=args.batch)
@@ -357,6 +361,8 @@ def main(argv=None):
                                    pair_order=gv.auto if args.pair_order == "auto" else args.pair_order,
                                    hub_rows=None if args.hub_rows == "default" else (args.hub_rows if args.hub_rows == "auto" else int(args.hub_rows)))
     solver.hub_parts = args.hub_parts
+    solver.hub_lerp = None if args.hub_lerp < 0 else bool(args.hub_lerp)
+    solver.hub_chain_cap = args.hub_cap
     solver.negative_table = args.negative_table
     for item in args.tune:
         key, value = item.split("=")

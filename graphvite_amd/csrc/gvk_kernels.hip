@@ -25,6 +25,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+#include <cmath>
+
 #include "gvk.h"
 #include "gvk_internal.h"
 
@@ -41,16 +44,14 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 int g_variant = 0;         // GVK_TUNE_VARIANT
 int g_run_cap = 0;         // GVK_TUNE_RUN_CAP (0 = the default of 20, run_cap_for)
 int g_split_hits = 2;      // GVK_TUNE_SPLIT_HITS (samples per table row one launch may hold; 0 = never split a batch)
-int g_chain_cap = 0;       // GVK_TUNE_CHAIN_CAP (entries one chain task trains in sequence; 0 = the default of 256)
+int g_chain_cap = 0;       // GVK_TUNE_CHAIN_CAP (entries one chain task trains in sequence; 0 = the default of 16)
 #if defined(GVK_AB_BUILDS)  // knobs of the A/B library only (make ab -> build/ab/libgvk_ab.so)
 int g_lanes_per_pair = 0;  // GVK_TUNE_LANES_PER_PAIR
 int g_generation = 0;      // GVK_TUNE_GENERATION (0 = one launch per batch)
 int g_segment_steps = 0;   // GVK_TUNE_SEGMENT_STEPS (0 = off)
 int g_skip_loss = 1;       // GVK_TUNE_SKIP_LOSS (gvk_train_episode leaves out the loss of batches nobody can read)
-int g_hot_serialized = 0;  // GVK_TUNE_HOT_SERIALIZED (bring-up: every gvk_train_episode_hot runs its three-launch form)
-int g_hot_whole_pairs = 0; // GVK_TUNE_HOT_WHOLE_PAIRS (experiment: only the chains of a batch are trained part by part, its pairs in one launch)
 #else
-constexpr int g_lanes_per_pair = 0, g_generation = 0, g_segment_steps = 0, g_skip_loss = 1, g_hot_serialized = 0, g_hot_whole_pairs = 0;
+constexpr int g_lanes_per_pair = 0, g_generation = 0, g_segment_steps = 0, g_skip_loss = 1;
 #endif
 
 struct TrainArgs {
@@ -66,6 +67,9 @@ struct TrainArgs {
     int run_cap;  // train_runs_kernel: longest run of adjacent same-head pairs one lane group trains in sequence
     int first_sample;  // this launch trains samples [first_sample, batch_size) of the batch (a batch split over several launches)
     uint32_t hot_vertex, hot_context;  // HOT builds: head / context rows below these local ids belong to chains (train_hot_kernel) and are not stored here
+    const float *hub_now;     // HOT builds: the hub rows [hot_vertex + hot_context][dim] (head rows first) as the chains of the pairs' unit left them
+    const float *hub_before;  // HOT == 2: ... and as those chains found them (a sample reads a hub row on the straight line between the two)
+    float hub_step;           // HOT == 2: 1 / samples of the unit
     float lr, wd, neg_weight, hp0, hp1, eps;
 };
 
@@ -182,10 +186,11 @@ struct Layout {
     static_assert(DIM % G == 0, "dim must split over the lane group");
 };
 
+// the row that starts at `base`
 template <int DIM, int G>
-__device__ __forceinline__ void load_row(const float *table, uint32_t id, int lane, float (&r)[DIM / G]) {
+__device__ __forceinline__ void load_row_at(const float *base, int lane, float (&r)[DIM / G]) {
     typedef Layout<DIM, G> L;
-    const float *row = table + (size_t)id * DIM + lane * L::CW;
+    const float *row = base + lane * L::CW;
 #pragma unroll
     for (int c = 0; c < L::NC; c++) {
         const float *p = row + c * G * L::CW;
@@ -206,9 +211,14 @@ __device__ __forceinline__ void load_row(const float *table, uint32_t id, int la
 }
 
 template <int DIM, int G>
-__device__ __forceinline__ void store_row(float *table, uint32_t id, int lane, const float (&r)[DIM / G]) {
+__device__ __forceinline__ void load_row(const float *table, uint32_t id, int lane, float (&r)[DIM / G]) {
+    load_row_at<DIM, G>(table + (size_t)id * DIM, lane, r);
+}
+
+template <int DIM, int G>
+__device__ __forceinline__ void store_row_at(float *base, int lane, const float (&r)[DIM / G]) {
     typedef Layout<DIM, G> L;
-    float *row = table + (size_t)id * DIM + lane * L::CW;
+    float *row = base + lane * L::CW;
 #pragma unroll
     for (int c = 0; c < L::NC; c++) {
         float *p = row + c * G * L::CW;
@@ -226,6 +236,11 @@ __device__ __forceinline__ void store_row(float *table, uint32_t id, int lane, c
             *p = r[c];
         }
     }
+}
+
+template <int DIM, int G>
+__device__ __forceinline__ void store_row(float *table, uint32_t id, int lane, const float (&r)[DIM / G]) {
+    store_row_at<DIM, G>(table + (size_t)id * DIM, lane, r);
 }
 
 template <int N>
@@ -300,20 +315,57 @@ __device__ __forceinline__ void train_pair(const TrainArgs &a, const int tid) {
     }
     const uint32_t tail = pr.x, head = pr.y;  // records are {tail, head}
 
+    // HOT: a hub row is read from the mirror the chains of the unit stored it to (the table's copy is written once, when
+    // the call ends), every other row from its table
+    auto vertex_row = [&](const uint32_t id) __attribute__((always_inline)) -> const float * {
+        if (HOT != 0 && id < a.hot_vertex) return a.hub_now + (size_t)id * DIM;
+        return a.vertex + (size_t)id * DIM;
+    };
+    auto context_row = [&](const uint32_t id) __attribute__((always_inline)) -> const float * {
+        if (HOT != 0 && id < a.hot_context) return a.hub_now + ((size_t)a.hot_vertex + id) * DIM;
+        return a.context + (size_t)id * DIM;
+    };
+
     // round trip 2: vertex row (+ moments) and the first target row.  With one negative (KT == 1) the positive's row
     // is requested here as well, ahead of the negative's: both ids of the pair are known, the negative's still waits
     // for its alias entry.
-    float v[V], vm1[M1], vm2[M2];
-    load_row<DIM, G>(a.vertex, head, lane, v);
+    // HOT == 2 (lerp): a hub row is read where its chain was when it met the sample — on the straight line from the row as
+    // the unit's chains found it (hub_before) to the row as they left it (hub_now), at the sample's place in the unit.  The
+    // second row is requested together with the first and the two are combined when the row is first used.
+    constexpr int VB = HOT == 2 ? V : 1;
+    const float at = HOT == 2 ? ((float)(s - a.first_sample) + 0.5f) * a.hub_step : 0.0f;
+    auto before_row = [&](const bool is_hub, const size_t slot, float (&b)[VB]) __attribute__((always_inline)) {
+        if constexpr (HOT == 2) {
+            if (is_hub) load_row_at<DIM, G>(a.hub_before + slot * DIM, lane, reinterpret_cast<float(&)[V]>(b));
+        }
+    };
+    auto on_the_way = [&](const bool is_hub, float (&r)[V], const float (&b)[VB]) __attribute__((always_inline)) {
+        if constexpr (HOT == 2) {
+            if (is_hub) {
+#pragma unroll
+                for (int i = 0; i < V; i++) r[i] = b[i] + at * (r[i] - b[i]);
+            }
+        }
+    };
+    float v[V], vm1[M1], vm2[M2], v_before[VB];
+    const bool v_hub = HOT == 2 && head < a.hot_vertex;
+    load_row_at<DIM, G>(vertex_row(head), lane, v);
+    before_row(v_hub, head, v_before);
     if constexpr (NM >= 1) load_row<DIM, G>(a.vm1, head, lane, reinterpret_cast<float(&)[V]>(vm1));
     if constexpr (NM >= 2) load_row<DIM, G>(a.vm2, head, lane, reinterpret_cast<float(&)[V]>(vm2));
     constexpr bool kTailEarly = KT == 1 && NM == 0;
-    float early[kTailEarly ? V : 1];
-    if constexpr (kTailEarly) load_row<DIM, G>(a.context, tail, lane, reinterpret_cast<float(&)[V]>(early));
+    float early[kTailEarly ? V : 1], early_before[kTailEarly ? VB : 1];
+    const bool early_hub = HOT == 2 && kTailEarly && tail < a.hot_context;
+    if constexpr (kTailEarly) {
+        load_row_at<DIM, G>(context_row(tail), lane, reinterpret_cast<float(&)[V]>(early));
+        before_row(early_hub, (size_t)a.hot_vertex + tail, reinterpret_cast<float(&)[VB]>(early_before));
+    }
 
     uint32_t id_cur = k > 0 ? (draw ? resolve(a, d0, e0) : neg0) : tail;
-    float cur[V], cur1[M1], cur2[M2];
-    load_row<DIM, G>(a.context, id_cur, lane, cur);
+    float cur[V], cur1[M1], cur2[M2], cur_before[VB];
+    bool cur_hub = HOT == 2 && id_cur < a.hot_context;
+    load_row_at<DIM, G>(context_row(id_cur), lane, cur);
+    before_row(cur_hub, (size_t)a.hot_vertex + id_cur, cur_before);
     if constexpr (NM >= 1) load_row<DIM, G>(a.cm1, id_cur, lane, reinterpret_cast<float(&)[V]>(cur1));
     if constexpr (NM >= 2) load_row<DIM, G>(a.cm2, id_cur, lane, reinterpret_cast<float(&)[V]>(cur2));
 
@@ -321,7 +373,8 @@ __device__ __forceinline__ void train_pair(const TrainArgs &a, const int tid) {
     auto target_step = [&](const int j) __attribute__((always_inline)) {
         // request the next target row before touching the current one
         uint32_t id_nxt = 0;
-        float nxt[V], nxt1[M1], nxt2[M2];
+        float nxt[V], nxt1[M1], nxt2[M2], nxt_before[VB];
+        bool nxt_hub = false;
         if (j < k) {
             if (j + 1 < k) {
                 if (draw) {
@@ -335,12 +388,18 @@ __device__ __forceinline__ void train_pair(const TrainArgs &a, const int tid) {
             }
             if constexpr (kTailEarly) {
                 copy_row(nxt, reinterpret_cast<float(&)[V]>(early));  // requested before the negative's row
+                copy_row(nxt_before, reinterpret_cast<float(&)[VB]>(early_before));
+                nxt_hub = early_hub;
             } else {
-                load_row<DIM, G>(a.context, id_nxt, lane, nxt);
+                nxt_hub = HOT == 2 && id_nxt < a.hot_context;
+                load_row_at<DIM, G>(context_row(id_nxt), lane, nxt);
+                before_row(nxt_hub, (size_t)a.hot_vertex + id_nxt, nxt_before);
                 if constexpr (NM >= 1) load_row<DIM, G>(a.cm1, id_nxt, lane, reinterpret_cast<float(&)[V]>(nxt1));
                 if constexpr (NM >= 2) load_row<DIM, G>(a.cm2, id_nxt, lane, reinterpret_cast<float(&)[V]>(nxt2));
             }
         }
+        if (j == 0) on_the_way(v_hub, v, v_before);
+        on_the_way(cur_hub, cur, cur_before);
 
         // forward: model/graph.h:40-45
         float partial = 0;
@@ -377,6 +436,10 @@ __device__ __forceinline__ void train_pair(const TrainArgs &a, const int tid) {
             const bool same = id_nxt == id_cur;
 #pragma unroll
             for (int i = 0; i < V; i++) cur[i] = same ? cur[i] : nxt[i];
+            if constexpr (HOT == 2) {
+                copy_row(cur_before, nxt_before);
+                cur_hub = !same && nxt_hub;  // the same row again: the registers already hold the row on its way, updated
+            }
             if constexpr (NM >= 1) {
 #pragma unroll
                 for (int i = 0; i < V; i++) cur1[i] = same ? cur1[i] : nxt1[i];
@@ -588,193 +651,254 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_runs_kernel(const TrainAr
 
 // ---- hub rows: chains --------------------------------------------------------------------------------------------------
 //
-// The samples of a batch run concurrently, and of the updates that hold a row at the same time one survives (Hogwild, as
+// The samples of a launch run concurrently, and of the updates that hold a row at the same time one survives (Hogwild, as
 // between two warps of the reference).  For most rows of a large table that never happens; a HUB row — the top hub of the
 // benchmark graph is the head of 1 in 100 samples and the tail of as many — is in flight hundreds of times per launch
 // and keeps a handful of its updates, where the reference's CPU solver (and its GPU kernel on the card it was written
 // for, far less concurrent) keeps them all: link-prediction AUC 0.650 against 0.668 on the headline shape.
 //
-// With hub rows, a batch (or each of its parts) is two kinds of work.  The hub rows of both tables — the first
-// hot_vertex / hot_context local ids; partitions are ordered by falling degree — are each owned by a CHAIN: one
-// wavefront holds the row in registers and applies every update the unit has for it one after the other (for a head
-// row the targets of its samples, negatives first; for a context row the heads it is the tail or the negative of),
-// reading the partner rows (D of them in flight) and writing nothing but its own row, once, at the end.  Everything else
-// is the per-pair body (train_pair<HOT>): every sample, all arithmetic, but hub rows are only read.  So a hub row has
-// ONE writer per unit and loses nothing.  The chains of a unit run BEFORE its pairs (gvk_train_episode_hot says why), and
-// train_hot_kernel is both in one launch for two DIFFERENT units: its first blocks run the chains of unit u + 1, the rest
-// the pairs of unit u.  The chains' work lists (entries per hub row) are built by hot_list_kernel.  A chain longer than
-// `cap` entries is cut into tasks trained side by side and composed: weight decay in closed form, the rest summed (a few
-// float atomics).
+// With hub rows, a batch is trained as UNITS (its `parts`), and a unit is two kinds of work.  The hub rows of both tables —
+// the first hot_vertex / hot_context local ids; partitions are ordered by falling degree — are each owned by a CHAIN: a
+// lane group holds the row in registers and applies every update the unit has for it one after the other (for a head row
+// the targets of its samples, negatives first; for a context row the heads it is the tail or the negative of), reading
+// the partner rows (D of them in flight) and writing nothing but its own row, once, at the end.  Everything else is the
+// per-pair body (train_pair<HOT>): every sample, all arithmetic, but hub rows are only read.  So a hub row has ONE writer
+// per unit and loses nothing.
+//
+// Where hub rows live.  During a call they live in three MIRRORS M[0..2] ([hot_vertex + hot_context][dim], head rows
+// first) in the workspace, not in the tables: the chains of unit u read M[(u - 1) % 3] — their own row AND every partner
+// that is a hub row itself, so that a sample between two hub rows updates both from the values the unit started with, as
+// the reference does (model/graph.h:47-58); two chains that read each other's fresh stores would compound the step they
+// share, DESIGN.md §3.1.2 — and store to M[u % 3]; the pairs of unit u read M[u % 3] (and, lerp, M[(u - 1) % 3]).  One
+// launch runs the pairs of unit u and, in its first blocks, the chains of unit u + 1: nothing it reads is written by it.
+// The tables' hub rows are written once, when the call ends (hub_rows_kernel).
+//
+// A chain longer than `cap` entries is a LONG chain: a whole workgroup trains it, up to kBlock / G tasks of consecutive
+// entries side by side, composed through LDS in task order — deterministic given the work lists, no atomics.  The chains'
+// work lists are built by hot_list_kernel.
 struct HotArgs {
-    const uint32_t *chain_start;  // [chains + 1] offsets of this batch into entries
+    const uint32_t *chain_start;  // [chains + 1] offsets of this unit into entries
     const uint32_t *entries;      // partner row | label << 31 (label 1 = positive)
-    const uint32_t *extra;        // [0] = number of extra tasks, then {chain, part} records: parts 1.. of chains longer than cap
+    const uint32_t *long_list;    // [0] = number of long chains (more than cap entries), then their chain ids
+    const float *from;            // mirror the chains read: own rows and hub partners as the unit finds them
+    float *to;                    // mirror the chains store to
     uint32_t chains;              // hot_vertex + hot_context
-    uint32_t extra_capacity;
+    uint32_t long_capacity;
     uint32_t cap;                 // entries of one task
+    int k;                        // negatives per sample: tasks of head chains are cut at whole samples
     float lr;                     // learning rate of the chains' batch (the pairs of the same launch may belong to another batch)
-    int task_blocks;              // blocks at the front of the grid that run chains
-    int what;                     // work of this launch: bit 0 = chains of head rows, bit 1 = chains of context rows, bit 2 = pairs
+    float log2_decay_positive, log2_decay_negative;  // log2(1 - lr wd), log2(1 - lr negative_weight wd): decay of an entry by label
+    int long_blocks, short_blocks;  // grid: [long chains | chains of at most cap entries, kBlock / G per block | pairs]
 };
 
-template <int DIM>
-struct ChainLayout {
-    static constexpr int G = DIM % 64 == 0 ? 64 : 32;  // lanes that hold the row (dims 32 and 96: half a wavefront)
+template <int DIM, int G>
+struct ChainShape {
     static constexpr int V = DIM / G;
-    static constexpr int D = V <= 2 ? 16 : (V <= 4 ? 8 : 4);  // partner rows in flight
+    static constexpr int D = V <= 8 ? 8 : (V <= 12 ? 4 : 2);  // partner rows in flight per lane group (V * D <= 64 registers)
+    static constexpr int NG = kBlock / G;     // lane groups of a block = most tasks of a long chain
+    static_assert(D <= G, "the entry window is two fetches of G entries");
 };
 
-__device__ __forceinline__ float lane_value(float x, int lane) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
-}
-
-// Sum over lanes 0 .. G - 1 (G = 32 or 64), the same value in every lane.
-template <int G>
-__device__ __forceinline__ float chain_sum(float x) {
-    x = group_sum<16>(x);  // every lane of a 16-lane row holds the row's sum
-    float s = lane_value(x, 0) + lane_value(x, 16);
-    if (G == 64) s += lane_value(x, 32) + lane_value(x, 48);
-    return s;
-}
-
-template <int DIM>
-__device__ __forceinline__ void train_chain(const TrainArgs &a, const HotArgs &h, const uint32_t task) {
-    typedef ChainLayout<DIM> L;
-    constexpr int G = L::G, V = L::V, D = L::D, EB = G;  // EB: entries per fetch of the work list
-    static_assert(EB % D == 0, "the entry window moves in steps of D");
-    const int lane = threadIdx.x & 63;
-    uint32_t chain = task, part = 0;
-    if (task >= h.chains) {
-        const uint32_t x = task - h.chains, n = h.extra[0] < h.extra_capacity ? h.extra[0] : h.extra_capacity;
-        if (x >= n) return;
-        chain = h.extra[1 + 2 * x], part = h.extra[2 + 2 * x];
-    }
+// Entries [begin, end) of one chain applied one after the other to `own` (the row of `chain`, in the registers of a lane
+// group).  Every lane group of the wavefront comes here together, each with its own chain and range (an empty range: a
+// group without work) — the loop runs as long as any group has entries left; a group past its end keeps requesting its own
+// mirror row and trains with weight 0.  Every step issues exactly one row request and consumes the one issued D steps
+// earlier, with no branch around either, so the wait before a step is "all but the D - 1 youngest" and not "all".
+template <int DIM, int G>
+__device__ __forceinline__ void chain_steps(const TrainArgs &a, const HotArgs &h, const uint32_t chain, const uint32_t begin,
+                                            const uint32_t end, const int lane, float (&own)[DIM / G]) {
+    typedef ChainShape<DIM, G> S;
+    constexpr int V = S::V, D = S::D;
     const bool is_vertex = chain < a.hot_vertex;
-    if (!(h.what & (is_vertex ? 1 : 2))) return;
-    const uint32_t first = h.chain_start[chain], last = h.chain_start[chain + 1];
-    const uint32_t begin = first + part * h.cap;
-    if (begin >= last) return;
-    const uint32_t end = last - begin > h.cap ? begin + h.cap : last;
-    const bool split = last - first > h.cap;  // several tasks train this row: their deltas add up
-    if (lane >= G) return;
-    float *own_table = is_vertex ? a.vertex : a.context;
-    const float *partner = is_vertex ? a.context : a.vertex;
-    const uint32_t row = is_vertex ? chain : chain - a.hot_vertex;
-
-    float own[V], own0[V];
-    load_row<DIM, G>(own_table, row, lane, own);
-    copy_row(own0, own);
-    // A chain cut into parts.  An update is own <- a own - lr w g c with a = 1 - lr w wd: weight decay is a factor that
-    // depends on the entry's label only, so the decay of the entries BEFORE this part (before_), of the part itself and of the
-    // entries AFTER it (after_) are known in closed form from label counts.  The part starts from the row as the earlier
-    // parts' decay leaves it, and what it adds to the row is its end state carried through the later parts' decay:
-    //     row <- total row + sum over parts (after_p end_p - total row),         total = before_ x part x after_
-    // which composes the parts' decay exactly (a hub row of the benchmark graph decays to 0.48 of itself within ONE batch —
-    // summing plain deltas of 8 parts would take it to 0.30) and leaves only the gradients' dependence on the other parts'
-    // steps to first order.
-    float before_ = 1, after_ = 1, total = 1;
-    if (split) {
-        uint32_t positives_before = 0, positives_inside = 0, positives_after = 0;
-        for (uint32_t at = first; at < last; at += G) {
-            const uint32_t p = at + lane;
-            const bool positive = p < last && (h.entries[p] >> 31) != 0;
-            positives_before += (uint32_t)__popcll(__ballot(positive && p < begin));
-            positives_inside += (uint32_t)__popcll(__ballot(positive && p >= begin && p < end));
-            positives_after += (uint32_t)__popcll(__ballot(positive && p >= end));
-        }
-        const float decay_positive = 1 - h.lr * a.wd, decay_negative = 1 - h.lr * a.neg_weight * a.wd;
-        before_ = powf(decay_positive, (float)positives_before) * powf(decay_negative, (float)(begin - first - positives_before));
-        after_ = powf(decay_positive, (float)positives_after) * powf(decay_negative, (float)(last - end - positives_after));
-        total = before_ * after_ * powf(decay_positive, (float)positives_inside) *
-                powf(decay_negative, (float)(end - begin - positives_inside));
-#pragma unroll
-        for (int x = 0; x < V; x++) own[x] *= before_;
-    }
-    // the work list, EB entries per fetch, two fetches resident: entries [blk, blk + 2 EB)
+    const float *partner_table = is_vertex ? a.context : a.vertex;
+    const uint32_t partner_hot = is_vertex ? a.hot_context : a.hot_vertex;  // partners below this id are hub rows: read from the mirror
+    const float *partner_mirror = h.from + (is_vertex ? (size_t)a.hot_vertex * DIM : (size_t)0);
+    const float *idle = h.from + (size_t)chain * DIM;
+    // the work list, G entries per fetch, two fetches resident: entries [blk, blk + 2 G)
     uint32_t blk = begin;
     uint32_t e_cur = blk + lane < end ? h.entries[blk + lane] : 0;
-    uint32_t e_nxt = blk + EB + lane < end ? h.entries[blk + EB + lane] : 0;
-    auto entry = [&](const uint32_t p) -> uint32_t {
+    uint32_t e_nxt = blk + G + lane < end ? h.entries[blk + G + lane] : 0;
+    // entry p of the list (through the window): the row it names (past the end: the group's own mirror row) and its label
+    auto row_of = [&](const uint32_t p, uint32_t &label) __attribute__((always_inline)) -> const float * {
         const uint32_t o = p - blk;
-        return (uint32_t)(o < EB ? __builtin_amdgcn_readlane((int)e_cur, (int)o) : __builtin_amdgcn_readlane((int)e_nxt, (int)(o - EB)));
+        const uint32_t e = (uint32_t)__shfl((int)(o < (uint32_t)G ? e_cur : e_nxt), (int)(o & (G - 1)), G);
+        label = e >> 31;
+        const uint32_t id = e & 0x7fffffffu;
+        const float *row = id < partner_hot ? partner_mirror + (size_t)id * DIM : partner_table + (size_t)id * DIM;
+        return p < end ? row : idle;
     };
-    // Every step of the loop below issues exactly one row request and consumes the one issued D steps earlier, with no
-    // branch around either: the number of requests in flight is a compile-time fact, so the wait before a step is "all but
-    // the D - 1 youngest" and not "all".  Steps beyond the end of the chain request the last entry again and train with
-    // weight 0 (the row is unchanged); the window of entries moves by register copies only.
-    const uint32_t last_entry = end - 1;
     float ring[D][V];
+    uint32_t labels = 0;  // bit i: the label of the entry whose row sits in ring[i]
 #pragma unroll
     for (int i = 0; i < D; i++) {
-        const uint32_t q = begin + i < end ? begin + i : last_entry;
-        load_row<DIM, G>(partner, entry(q) & 0x7fffffffu, lane, ring[i]);
+        uint32_t label;
+        load_row_at<DIM, G>(row_of(begin + i, label), lane, ring[i]);
+        labels |= label << i;
     }
-    for (uint32_t base = begin; base < end; base += D) {
-        const uint32_t f = blk + 2 * EB + lane;
-        const uint32_t e_fut = h.entries[f < end ? f : last_entry];  // the window after e_nxt, asked for ahead of its use
+    for (uint32_t base = begin; __builtin_amdgcn_ballot_w64(base < end) != 0; base += D) {
+        const uint32_t f = blk + 2 * G + lane;
+        const uint32_t e_fut = h.entries[f < end ? f : (begin < end ? end - 1 : 0)];  // the window after e_nxt, asked for ahead of its use
 #pragma unroll
         for (int i = 0; i < D; i++) {
             const uint32_t p = base + i;
-            const uint32_t e = entry(p < end ? p : last_entry);
-            float c[V];
-            copy_row(c, ring[i]);
-            const uint32_t q = p + D < end ? p + D : last_entry;
-            load_row<DIM, G>(partner, entry(q) & 0x7fffffffu, lane, ring[i]);
+            const bool positive = (labels >> i & 1u) != 0;
+            const float(&c)[V] = ring[i];
             // forward / backward of one target: model/graph.h:40-58, gpu/graph.cuh:77-87 — on the own row only
             float partial = 0;
 #pragma unroll
             for (int x = 0; x < V; x++) partial += own[x] * c[x];
-            const float prob = sigmoidf(chain_sum<G>(partial));
-            const bool positive = (e >> 31) != 0;
+            const float prob = sigmoidf(group_sum<G>(partial));
             const float gradient = positive ? prob - 1 : prob;
             const float weight = p < end ? (positive ? 1.0f : a.neg_weight) : 0.0f;
 #pragma unroll
             for (int x = 0; x < V; x++) own[x] -= h.lr * weight * (gradient * c[x] + a.wd * own[x]);  // optimizer.h:161-164
+            // the slot is free: the row of entry p + D takes it (D - 1 requests stay in flight while a step computes)
+            uint32_t label;
+            load_row_at<DIM, G>(row_of(p + D, label), lane, ring[i]);
+            labels = (labels & ~(1u << i)) | label << i;
         }
-        if (base + D >= blk + EB) {  // the next steps look beyond e_nxt: move the window
-            blk += EB;
+        if (base + D >= blk + G) {  // the next steps look beyond e_nxt: move the window
+            blk += G;
             e_cur = e_nxt;
             e_nxt = e_fut;
         }
     }
-    if (split) {
-        typedef Layout<DIM, G> R;
-        float *p = own_table + (size_t)row * DIM + lane * R::CW;
+}
+
+// Sum over the lanes of a group of a small count (exact in fp32).
+template <int G>
+__device__ __forceinline__ float group_count(const uint32_t x) {
+    return group_sum<G>((float)x);
+}
+
+// Chains of at most cap entries, one lane group each: block b trains chains [b NG, (b + 1) NG).  A chain without entries
+// copies its row to the next mirror; a long chain is left to its workgroup (train_long_chains).
+template <int DIM, int G>
+__device__ __forceinline__ void train_short_chains(const TrainArgs &a, const HotArgs &h, const uint32_t block) {
+    typedef ChainShape<DIM, G> S;
+    const int lane = threadIdx.x % G;
+    uint32_t chain = block * S::NG + threadIdx.x / G;
+    const bool exists = chain < h.chains;
+    if (!exists) chain = h.chains - 1;  // whole wavefronts walk chain_steps together: a group without a chain idles on the last one
+    const uint32_t first = h.chain_start[chain], last = h.chain_start[chain + 1];
+    const bool mine = exists && last - first <= h.cap;
+    float own[S::V];
+    load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, own);
+    chain_steps<DIM, G>(a, h, chain, first, mine ? last : first, lane, own);
+    if (mine) store_row_at<DIM, G>(h.to + (size_t)chain * DIM, lane, own);
+}
+
+// Long chains, one workgroup each (block b takes long chains b, b + long_blocks, ...): T <= NG tasks of consecutive
+// entries (whole samples for a head chain) trained side by side by the block's lane groups and composed.  An update is
+// own <- d own - lr w g c with d = 1 - lr w wd: weight decay is a factor that depends on the entry's label only, so the
+// decay of the entries BEFORE a task (before_), of the task itself and of the entries AFTER it (after_) are known in closed
+// form from label counts.  A task starts from the row as the earlier tasks' decay leaves it, and what it adds to the row is
+// its end state carried through the later tasks' decay:
+//     row <- total row + sum over tasks (after_t end_t - total row),         total = before_ x task x after_
+// which composes the tasks' decay exactly (a hub row of the benchmark graph decays to 0.48 of itself within ONE batch —
+// summing plain deltas of 8 tasks would take it to 0.30) and leaves only the gradients' dependence on the other tasks'
+// steps to first order.  The sum runs in task order in one lane group: the same bits on every run.
+template <int DIM, int G>
+__device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotArgs &h, const uint32_t block) {
+    typedef ChainShape<DIM, G> S;
+    constexpr int V = S::V, NG = S::NG;
+    __shared__ float ends[NG][DIM];
+    const int lane = threadIdx.x % G, group = threadIdx.x / G;
+    const uint32_t count = h.long_list[0] < h.long_capacity ? h.long_list[0] : h.long_capacity;
+    for (uint32_t j = block; j < count; j += (uint32_t)h.long_blocks) {
+        const uint32_t chain = h.long_list[1 + j];
+        const uint32_t first = h.chain_start[chain], last = h.chain_start[chain + 1], n = last - first;
+        // NG tasks at most: a longer chain gets longer tasks (whole samples: k + 1 entries)
+        uint32_t per = h.cap;
+        if ((uint64_t)per * NG < n) per = ((n + NG - 1) / NG + (uint32_t)h.k) / (uint32_t)(h.k + 1) * (uint32_t)(h.k + 1);
+        const uint32_t tasks = (n + per - 1) / per;
+        const bool mine = (uint32_t)group < tasks;
+        const uint32_t begin = mine ? first + (uint32_t)group * per : last;
+        const uint32_t end = last - begin > per ? begin + per : last;
+        float own[V];
+        load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, own);
+        uint32_t positives_before = 0, positives_inside = 0, positives_after = 0;
+        for (uint32_t at = first; at < last; at += G) {
+            const uint32_t p = at + lane;
+            const bool positive = p < last && (h.entries[p] >> 31) != 0;
+            positives_before += positive && p < begin;
+            positives_inside += positive && p >= begin && p < end;
+            positives_after += positive && p >= end;
+        }
+        const float pb = group_count<G>(positives_before), pi = group_count<G>(positives_inside), pa = group_count<G>(positives_after);
+        const float before_ = exp2f(pb * h.log2_decay_positive + ((float)(begin - first) - pb) * h.log2_decay_negative);
+        const float after_ = exp2f(pa * h.log2_decay_positive + ((float)(last - end) - pa) * h.log2_decay_negative);
+        const float total = exp2f((pb + pi + pa) * h.log2_decay_positive + ((float)n - (pb + pi + pa)) * h.log2_decay_negative);
 #pragma unroll
-        for (int c = 0; c < R::NC; c++)
+        for (int x = 0; x < V; x++) own[x] *= before_;
+        chain_steps<DIM, G>(a, h, chain, begin, end, lane, own);
+        if (mine) {
 #pragma unroll
-            for (int x = 0; x < R::CW; x++)
-                __hip_atomic_fetch_add(p + c * G * R::CW + x,
-                                       after_ * own[c * R::CW + x] - (part == 0 ? 1.0f : total) * own0[c * R::CW + x],
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int x = 0; x < V; x++) own[x] *= after_;
+            store_row_at<DIM, G>(&ends[group][0], lane, own);
+        }
+        __syncthreads();
+        if (group == 0) {
+            float sum[V], row0[V];
+            load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, row0);
+#pragma unroll
+            for (int x = 0; x < V; x++) sum[x] = (1.0f - (float)tasks) * total * row0[x];
+            for (uint32_t t = 0; t < tasks; t++) {
+                float part[V];
+                load_row_at<DIM, G>(&ends[t][0], lane, part);
+#pragma unroll
+                for (int x = 0; x < V; x++) sum[x] += part[x];
+            }
+            store_row_at<DIM, G>(h.to + (size_t)chain * DIM, lane, sum);
+        }
+        __syncthreads();
+    }
+}
+
+// HOT: 1 = the pairs read a hub row as the chains of their unit left it, 2 = on the straight line from where those chains
+// found it to where they left it, at the sample's place in the unit (lerp)
+// Built for three wavefronts per SIMD (170 registers): the chain loop keeps D partner rows per lane group in flight; a unit
+// of the sizes this kernel trains (a part of a batch) is resident at once at that occupancy.
+template <int DIM, int G, int KT, int HOT>
+__global__ void __launch_bounds__(kBlock, 3) train_hot_kernel(const TrainArgs a, const HotArgs h) {
+    const int chain_blocks = h.long_blocks + h.short_blocks;
+    if ((int)blockIdx.x < h.long_blocks) {
+        train_long_chains<DIM, G>(a, h, blockIdx.x);
+    } else if ((int)blockIdx.x < chain_blocks) {
+        train_short_chains<DIM, G>(a, h, blockIdx.x - h.long_blocks);
     } else {
-        store_row<DIM, G>(own_table, row, lane, own);
+        train_pair<DIM, G, GVK_SGD, KT, 1, HOT>(a, (blockIdx.x - chain_blocks) * kBlock + threadIdx.x);
     }
 }
 
-template <int DIM, int G, int KT>
-__global__ void __launch_bounds__(kBlock, 4) train_hot_kernel(const TrainArgs a, const HotArgs h) {
-    if ((int)blockIdx.x < h.task_blocks) {
-        train_chain<DIM>(a, h, blockIdx.x * (kBlock / 64) + threadIdx.x / 64);
-        return;
-    }
-    train_pair<DIM, G, GVK_SGD, KT, 1, 1>(a, (blockIdx.x - h.task_blocks) * kBlock + threadIdx.x);
+// Hub rows between the tables and a mirror: to_mirror != 0 copies the first hot_vertex rows of the head table and the first
+// hot_context rows of the tail table into the mirror (a call's first step), else the mirror into the tables (its last).
+__global__ void __launch_bounds__(kBlock) hub_rows_kernel(float *vertex, float *context, float *mirror, const uint32_t hot_vertex,
+                                                          const uint32_t hot_context, const int dim, const int to_mirror) {
+    const size_t quads = (size_t)dim / 4, head_quads = (size_t)hot_vertex * quads, all = head_quads + (size_t)hot_context * quads;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= all) return;
+    f32x4 *in_table = i < head_quads ? reinterpret_cast<f32x4 *>(vertex) + i : reinterpret_cast<f32x4 *>(context) + (i - head_quads);
+    f32x4 *in_mirror = reinterpret_cast<f32x4 *>(mirror) + i;
+    if (to_mirror) *in_mirror = *in_table;
+    else *in_table = *in_mirror;
 }
 
-// The chains' work lists, one workgroup per batch: counting sort of the batch's updates to hub rows by row.  Chain c <
+// The chains' work lists, one workgroup per unit: counting sort of the unit's updates to hub rows by row.  Chain c <
 // hot_vertex is head row c: per sample with that head, the sample's k negatives (label 0) then its tail (label 1), in
 // that order.  Chain hot_vertex + r is context row r: the head of every sample r is the tail (label 1) or a negative
 // (label 0) of.  Negatives are drawn exactly as the training kernel draws them (same counters, same tables).  The order
-// of the samples inside a chain is the order the atomics retire in — any order is a valid sequential order.
+// of the samples inside a chain is the order the atomics retire in — any order is a valid sequential order.  Chains of
+// more than cap entries are listed in long_list (train_long_chains).
 constexpr int kListThreads = 1024;
 
 __global__ void __launch_bounds__(kListThreads) hot_list_kernel(TrainArgs a, const uint32_t first_batch_id, const uint32_t stride,
-                                                                uint32_t *chain_start_all, uint32_t *entries_all, uint32_t *extra_all,
-                                                                const uint32_t entry_capacity, const uint32_t extra_capacity,
+                                                                uint32_t *chain_start_all, uint32_t *entries_all, uint32_t *long_all,
+                                                                const uint32_t entry_capacity, const uint32_t long_capacity,
                                                                 const uint32_t cap, const int parts) {
     extern __shared__ uint32_t bins[];  // [chains]
     __shared__ uint32_t wave_total[kListThreads / 64];
-    __shared__ uint32_t extra_count;
+    __shared__ uint32_t long_count;
     const uint32_t chains = a.hot_vertex + a.hot_context;
     // list blockIdx.x = part (blockIdx.x % parts) of batch (blockIdx.x / parts): samples [lo, hi) of the batch
     const int B = a.batch_size, k = a.k;
@@ -782,11 +906,11 @@ __global__ void __launch_bounds__(kListThreads) hot_list_kernel(TrainArgs a, con
     const u32x2 *records = reinterpret_cast<const u32x2 *>(a.pairs) + (size_t)batch * B;
     uint32_t *chain_start = chain_start_all + (size_t)blockIdx.x * (chains + 1);
     uint32_t *entries = entries_all + (size_t)blockIdx.x * entry_capacity;
-    uint32_t *extra = extra_all + (size_t)blockIdx.x * (1 + 2 * (size_t)extra_capacity);
+    uint32_t *long_list = long_all + (size_t)blockIdx.x * (1 + (size_t)long_capacity);
     a.batch_id = first_batch_id + (uint32_t)batch * stride;
 
     for (uint32_t i = threadIdx.x; i < chains; i += kListThreads) bins[i] = 0;
-    if (threadIdx.x == 0) extra_count = 0;
+    if (threadIdx.x == 0) long_count = 0;
     __syncthreads();
     // A: how many entries every chain gets
     for (int s = lo + threadIdx.x; s < hi; s += kListThreads) {
@@ -821,16 +945,16 @@ __global__ void __launch_bounds__(kListThreads) hot_list_kernel(TrainArgs a, con
             const uint32_t count = bins[i];
             chain_start[i] = running;
             bins[i] = running;  // the chain's cursor
-            for (uint32_t part = 1; part * cap < count; part++) {  // a long chain: parts 1.. are extra tasks
-                const uint32_t slot = atomicAdd(&extra_count, 1u);
-                if (slot < extra_capacity) extra[1 + 2 * slot] = i, extra[2 + 2 * slot] = part;
+            if (count > cap) {
+                const uint32_t slot = atomicAdd(&long_count, 1u);
+                if (slot < long_capacity) long_list[1 + slot] = i;
             }
             running += count;
         }
         if (threadIdx.x == kListThreads - 1) chain_start[chains] = running;
     }
     __syncthreads();
-    if (threadIdx.x == 0) extra[0] = extra_count;
+    if (threadIdx.x == 0) long_list[0] = long_count;
     // B: scatter
     for (int s = lo + threadIdx.x; s < hi; s += kListThreads) {
         const u32x2 pr = records[s];
@@ -1585,20 +1709,22 @@ int launch_train(hipStream_t stream, int dim, const gvk_optimizer *o, float lr, 
 // ---- hub rows: work lists + launch (train_hot_kernel) -----------------------------------------------------------------
 
 struct HotLayout {
-    size_t chain_start = 0, entries = 0, extra = 0, bytes = 0;  // offsets into the workspace
-    uint32_t chains = 0, entry_capacity = 0, extra_capacity = 0, cap = 0;
+    size_t chain_start = 0, entries = 0, long_list = 0, mirrors = 0, mirror_bytes = 0, bytes = 0;  // offsets into the workspace
+    uint32_t chains = 0, entry_capacity = 0, long_capacity = 0, cap = 0;
 };
 
 constexpr uint32_t kMaxChains = 32768;  // one LDS counter per chain in hot_list_kernel (128 KB of the CU's 160 KB)
+constexpr int kLongBlocks = 256;        // workgroups that walk the long chains of a unit (one per CU)
 
 // entries one chain task trains in sequence: whole samples for head chains
 uint32_t chain_cap_for(int k, int chain_cap) {
-    const uint32_t want = chain_cap > 0 ? (uint32_t)chain_cap : (g_chain_cap > 0 ? (uint32_t)g_chain_cap : 256u);
+    const uint32_t want = chain_cap > 0 ? (uint32_t)chain_cap : (g_chain_cap > 0 ? (uint32_t)g_chain_cap : 16u);
     return (want + (uint32_t)k) / (uint32_t)(k + 1) * (uint32_t)(k + 1);
 }
 
-// One work list per part of a batch (parts divides batch_size: gvk_train_launches): num_batch * parts lists.
-HotLayout hot_layout(int batch_size, int k, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts, int chain_cap) {
+// One work list per part of a batch (parts divides batch_size: gvk_train_launches): num_batch * parts lists; behind them
+// the three mirrors of the hub rows (train_hot_kernel).
+HotLayout hot_layout(int dim, int batch_size, int k, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts, int chain_cap) {
     HotLayout l;
     l.chains = hot_vertex + hot_context;
     l.cap = chain_cap_for(k, chain_cap);
@@ -1606,16 +1732,19 @@ HotLayout hot_layout(int batch_size, int k, uint32_t hot_vertex, uint32_t hot_co
     batch_size /= parts;
     // a sample adds at most k + 1 entries to its head's chain and one to the chain of each of its k + 1 targets
     l.entry_capacity = (uint32_t)(2 * (size_t)(k + 1) * (size_t)batch_size);
-    l.extra_capacity = l.entry_capacity / l.cap + 1;
+    l.long_capacity = std::min(l.chains, l.entry_capacity / (l.cap + 1) + 1);  // a long chain holds more than cap entries
     auto align = [](size_t x) { return (x + 255) / 256 * 256; };
     l.chain_start = 0;
     l.entries = align((size_t)num_batch * (l.chains + 1) * 4);
-    l.extra = l.entries + align((size_t)num_batch * l.entry_capacity * 4);
-    l.bytes = l.extra + align((size_t)num_batch * (1 + 2 * (size_t)l.extra_capacity) * 4);
+    l.long_list = l.entries + align((size_t)num_batch * l.entry_capacity * 4);
+    l.mirrors = l.long_list + align((size_t)num_batch * (1 + (size_t)l.long_capacity) * 4);
+    l.mirror_bytes = align((size_t)l.chains * dim * 4);
+    l.bytes = l.mirrors + 3 * l.mirror_bytes;
     return l;
 }
 
-int validate_hot(const char *what, int batch_size, int k, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts) {
+int validate_hot(const char *what, int dim, int batch_size, int k, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts) {
+    if (!default_lanes(dim)) return gvk_fail(GVK_EDIM, "%s: dim must be one of 32, 64, 96, 128, 256, 512", what);
     if (batch_size <= 0 || k < 0 || num_batch < 0) return gvk_fail(GVK_EINVAL, "%s: bad sizes", what);
     if (parts < 1 || batch_size % parts) return gvk_fail(GVK_EINVAL, "%s: parts (%d) must divide the batch size", what, parts);
     if ((uint64_t)hot_vertex + hot_context == 0) return gvk_fail(GVK_EINVAL, "%s: no hub rows given", what);
@@ -1632,8 +1761,11 @@ void fill_negative(TrainArgs &a, const gvk_negative_source *neg) {
 
 typedef void (*HotKernel)(const TrainArgs, const HotArgs);
 
-HotKernel pick_hot(int dim, int k) {
-#define GVK_HOT(D, GG) case D: return k == 1 ? train_hot_kernel<D, GG, 1> : train_hot_kernel<D, GG, 0>;
+HotKernel pick_hot(int dim, int k, int lerp) {
+#define GVK_HOT(D, GG)                                                                                              \
+    case D:                                                                                                         \
+        return k == 1 ? (lerp ? train_hot_kernel<D, GG, 1, 2> : train_hot_kernel<D, GG, 1, 1>)                      \
+                      : (lerp ? train_hot_kernel<D, GG, 0, 2> : train_hot_kernel<D, GG, 0, 1>);
     switch (dim) {
         GVK_HOT(32, 8) GVK_HOT(64, 16) GVK_HOT(96, 8) GVK_HOT(128, 16) GVK_HOT(256, 16) GVK_HOT(512, 32)
     }
@@ -1645,20 +1777,20 @@ HotKernel pick_hot(int dim, int k) {
 
 extern "C" {
 
-int gvk_hot_plan(int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts,
+int gvk_hot_plan(int dim, int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts,
                  int chain_cap, size_t *bytes) {
     if (!bytes) return fail(GVK_EINVAL, "gvk_hot_plan: bytes is null");
-    int rc = validate_hot("gvk_hot_plan", batch_size, num_negative, hot_vertex, hot_context, num_batch, parts);
+    int rc = validate_hot("gvk_hot_plan", dim, batch_size, num_negative, hot_vertex, hot_context, num_batch, parts);
     if (rc != GVK_OK) return rc;
     if (chain_cap < 0) return fail(GVK_EINVAL, "gvk_hot_plan: negative chain_cap");
-    *bytes = hot_layout(batch_size, num_negative, hot_vertex, hot_context, num_batch, parts, chain_cap).bytes;
+    *bytes = hot_layout(dim, batch_size, num_negative, hot_vertex, hot_context, num_batch, parts, chain_cap).bytes;
     return GVK_OK;
 }
 
-int gvk_hot_build(void *stream, void *workspace, size_t workspace_bytes, const uint32_t *pool, int batch_size, int num_batch,
+int gvk_hot_build(void *stream, int dim, void *workspace, size_t workspace_bytes, const uint32_t *pool, int batch_size, int num_batch,
                   int num_negative, const gvk_negative_source *negative, uint32_t first_batch_id, uint32_t batch_id_stride,
                   uint32_t hot_vertex, uint32_t hot_context, int parts, int chain_cap) {
-    int rc = validate_hot("gvk_hot_build", batch_size, num_negative, hot_vertex, hot_context, num_batch, parts);
+    int rc = validate_hot("gvk_hot_build", dim, batch_size, num_negative, hot_vertex, hot_context, num_batch, parts);
     if (rc != GVK_OK) return rc;
     if (num_batch == 0) return GVK_OK;
     if (!workspace || !pool || !negative) return fail(GVK_EINVAL, "gvk_hot_build: null workspace / pool / negative source");
@@ -1666,7 +1798,7 @@ int gvk_hot_build(void *stream, void *workspace, size_t workspace_bytes, const u
     if (num_negative > 0 && (!negative->table || negative->count == 0) && (!negative->classes || negative->class_count == 0))
         return fail(GVK_EINVAL, "gvk_hot_build: no alias table given");
     if (chain_cap < 0) return fail(GVK_EINVAL, "gvk_hot_build: negative chain_cap");
-    const HotLayout l = hot_layout(batch_size, num_negative, hot_vertex, hot_context, num_batch, parts, chain_cap);
+    const HotLayout l = hot_layout(dim, batch_size, num_negative, hot_vertex, hot_context, num_batch, parts, chain_cap);
     if (workspace_bytes < l.bytes) return gvk_fail(GVK_EINVAL, "gvk_hot_build: workspace holds %zu bytes, %zu needed", workspace_bytes, l.bytes);
     TrainArgs a;
     memset(&a, 0, sizeof(a));
@@ -1683,33 +1815,35 @@ int gvk_hot_build(void *stream, void *workspace, size_t workspace_bytes, const u
     }
     hipLaunchKernelGGL(hot_list_kernel, dim3((unsigned)(num_batch * parts)), dim3(kListThreads), lds, (hipStream_t)stream, a,
                        first_batch_id, batch_id_stride, reinterpret_cast<uint32_t *>(base + l.chain_start),
-                       reinterpret_cast<uint32_t *>(base + l.entries), reinterpret_cast<uint32_t *>(base + l.extra), l.entry_capacity,
-                       l.extra_capacity, l.cap, parts);
+                       reinterpret_cast<uint32_t *>(base + l.entries), reinterpret_cast<uint32_t *>(base + l.long_list), l.entry_capacity,
+                       l.long_capacity, l.cap, parts);
     return check_launch("gvk_hot_build");
 }
 
 int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer, int linear_schedule, const gvk_tables *tables,
                           const uint32_t *pairs, const gvk_negative_source *negative, uint32_t first_batch_id,
                           uint32_t batch_id_stride, uint32_t total_batches, int num_batches, float *loss, int batch_size,
-                          int num_negative, float negative_weight, const void *workspace, size_t workspace_bytes,
+                          int num_negative, float negative_weight, void *workspace, size_t workspace_bytes,
                           uint32_t hot_vertex, uint32_t hot_context, int workspace_batches, int parts, int chain_cap,
-                          int serialized) {
+                          int form) {
     if (num_batches < 0 || num_batches > workspace_batches) return fail(GVK_EINVAL, "gvk_train_episode_hot: more batches than the work lists cover");
     int rc = validate_train(dim, optimizer, tables, pairs, negative, loss, batch_size, num_negative);
     if (rc <= 0) return rc;
-    rc = validate_hot("gvk_train_episode_hot", batch_size, num_negative, hot_vertex, hot_context, workspace_batches, parts);
+    rc = validate_hot("gvk_train_episode_hot", dim, batch_size, num_negative, hot_vertex, hot_context, workspace_batches, parts);
     if (rc != GVK_OK) return rc;
     if (optimizer->type != GVK_SGD) return fail(GVK_EINVAL, "gvk_train_episode_hot: chains exist for SGD only");
     if (negative->negatives) return fail(GVK_EINVAL, "gvk_train_episode_hot draws negatives on device");
     if (hot_vertex > tables->n_vertex || hot_context > tables->n_context)
         return fail(GVK_EINVAL, "gvk_train_episode_hot: more hub rows than table rows");
     if (chain_cap < 0) return fail(GVK_EINVAL, "gvk_train_episode_hot: negative chain_cap");
-    const HotLayout l = hot_layout(batch_size, num_negative, hot_vertex, hot_context, workspace_batches, parts, chain_cap);
+    if (form & ~(GVK_HOT_SERIALIZED | GVK_HOT_LERP)) return fail(GVK_EINVAL, "gvk_train_episode_hot: unknown form bits");
+    const HotLayout l = hot_layout(dim, batch_size, num_negative, hot_vertex, hot_context, workspace_batches, parts, chain_cap);
     if (!workspace || workspace_bytes < l.bytes) return fail(GVK_EINVAL, "gvk_train_episode_hot: workspace too small (gvk_hot_plan)");
-    const HotKernel kernel = pick_hot(dim, num_negative);
+    const bool lerp = (form & GVK_HOT_LERP) != 0, serialized = (form & GVK_HOT_SERIALIZED) != 0;
+    const HotKernel kernel = pick_hot(dim, num_negative, lerp);
     if (!kernel) return fail(GVK_EDIM, "gvk_train_episode_hot: no kernel for this dim");
     const int lanes = default_lanes(dim);
-    const char *base = static_cast<const char *>(workspace);
+    char *base = static_cast<char *>(workspace);
     TrainArgs a;
     memset(&a, 0, sizeof(a));
     a.vertex = tables->vertex; a.context = tables->context;
@@ -1720,9 +1854,10 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     a.hot_vertex = hot_vertex; a.hot_context = hot_context;
     HotArgs h;
     memset(&h, 0, sizeof(h));
-    h.chains = l.chains; h.extra_capacity = l.extra_capacity; h.cap = l.cap;
-    const int tasks = (int)(l.chains + l.extra_capacity);
-    const int task_blocks = (tasks + kBlock / 64 - 1) / (kBlock / 64);
+    h.chains = l.chains; h.long_capacity = l.long_capacity; h.cap = l.cap; h.k = num_negative;
+    const int groups = kBlock / lanes;
+    const int short_blocks = (int)((l.chains + groups - 1) / groups);
+    const int long_blocks = (int)std::min<uint32_t>(l.long_capacity, (uint32_t)kLongBlocks);
     // the unit of work is a PART of a batch (parts = 1: the batch): unit u = part u % parts of batch u / parts
     const int part_size = batch_size / parts, units = num_batches * parts;
     const unsigned pair_blocks = (unsigned)(((int64_t)part_size * lanes + kBlock - 1) / kBlock);
@@ -1730,6 +1865,7 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     // when every row of both tables is a hub row the pairs have nothing to store: they run for the last batch only, whose
     // per-sample loss a caller may read
     const bool chains_only = hot_vertex == tables->n_vertex && hot_context == tables->n_context;
+    auto mirror = [&](int u) { return reinterpret_cast<float *>(base + l.mirrors + (size_t)((u + 3) % 3) * l.mirror_bytes); };
     auto lr_of = [&](int i) {
         const uint32_t id = first_batch_id + (uint32_t)i * batch_id_stride;
         float scale = 1;
@@ -1739,11 +1875,14 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
         }
         return optimizer->lr * scale;
     };
-    auto chains_of = [&](int u) {  // the chain blocks of a launch work on unit u
+    auto chains_of = [&](int u) {  // the chain blocks of a launch work on unit u: from mirror u - 1 to mirror u
         h.chain_start = reinterpret_cast<const uint32_t *>(base + l.chain_start) + (size_t)u * (l.chains + 1);
         h.entries = reinterpret_cast<const uint32_t *>(base + l.entries) + (size_t)u * l.entry_capacity;
-        h.extra = reinterpret_cast<const uint32_t *>(base + l.extra) + (size_t)u * (1 + 2 * (size_t)l.extra_capacity);
+        h.long_list = reinterpret_cast<const uint32_t *>(base + l.long_list) + (size_t)u * (1 + (size_t)l.long_capacity);
+        h.from = mirror(u - 1), h.to = mirror(u);
         h.lr = lr_of(u / parts);
+        h.log2_decay_positive = (float)std::log2(1.0 - (double)h.lr * a.wd);
+        h.log2_decay_negative = (float)std::log2(1.0 - (double)h.lr * a.neg_weight * a.wd);
     };
     auto pairs_of = [&](int u) {  // the pair blocks of a launch work on unit u; false: nothing to do
         const int i = u / parts;
@@ -1752,50 +1891,45 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
         a.pairs = pairs + (size_t)i * batch_size * 2;
         a.first_sample = (u % parts) * part_size;
         a.batch_size = a.first_sample + part_size;
+        a.hub_now = mirror(u), a.hub_before = mirror(u - 1);
+        a.hub_step = 1.0f / (float)part_size;
         return !chains_only || i == num_batches - 1;
     };
-    auto launch = [&](int what) {
-        h.what = what;
-        h.task_blocks = (what & 3) ? task_blocks : 0;
-        if (!what) return;
-        hipLaunchKernelGGL(kernel, dim3((unsigned)h.task_blocks + ((what & 4) ? pair_blocks : 0u)), dim3(kBlock), 0,
-                           (hipStream_t)stream, a, h);
+    auto launch = [&](bool with_chains, bool with_pairs) {
+        h.long_blocks = with_chains ? long_blocks : 0;
+        h.short_blocks = with_chains ? short_blocks : 0;
+        const unsigned grid = (unsigned)(h.long_blocks + h.short_blocks) + (with_pairs ? pair_blocks : 0u);
+        if (grid) hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, h);
     };
+    const unsigned copy_blocks = (unsigned)(((size_t)l.chains * (size_t)(dim / 4) + kBlock - 1) / kBlock);
+    // the hub rows enter the mirrors: M[-1] = the tables' rows
+    hipLaunchKernelGGL(hub_rows_kernel, dim3(copy_blocks), dim3(kBlock), 0, (hipStream_t)stream, a.vertex, a.context, mirror(-1),
+                       hot_vertex, hot_context, dim, 1);
     // A sample's updates to its rows are all computed from the rows as the sample found them (model/graph.h:47-58).  The
     // chains of a unit therefore run BEFORE its pairs: a chain reads the partner rows before the unit's pairs move them
     // towards the hub row (a chain that read them afterwards would compound the step it is about to take — every sample of a
     // hub row, thousands per epoch: the row's norm explodes), and the pairs train against the hub rows the chains left.
     // Pipelined: launch u trains the pairs of unit u and, in its first blocks, the chains of unit u + 1 — different samples,
-    // so neither waits for the other — which hides the chains (a few long sequential tasks) behind the pairs (the bulk).
-    if (g_hot_whole_pairs != 0 && parts > 1 && !serialized) {
-        // experiment: the chains of a batch part by part (a chain sees the other hub rows at most a part old), then the pairs of
-        // the whole batch in one launch
-        const unsigned whole_blocks = (unsigned)(((int64_t)batch_size * lanes + kBlock - 1) / kBlock);
-        for (int i = 0; i < num_batches; i++) {
-            for (int q = 0; q < parts; q++) {
-                chains_of(i * parts + q);
-                launch(3);
-            }
-            pairs_of(i * parts);
-            a.first_sample = 0, a.batch_size = batch_size;
-            h.what = 4, h.task_blocks = 0;
-            hipLaunchKernelGGL(kernel, dim3(whole_blocks), dim3(kBlock), 0, (hipStream_t)stream, a, h);
-        }
-    } else if (serialized != 0 || g_hot_serialized != 0) {  // tests / bring-up: per unit three launches, what the oracle restates
+    // different mirrors, so neither waits for the other — which hides the chains (few, sequential) behind the pairs (the bulk).
+    if (serialized) {  // tests: per unit the chains, then the pairs, as two launches — a pure function of the work lists
         for (int u = 0; u < units; u++) {
             chains_of(u);
             const bool with_pairs = pairs_of(u);
-            launch(1), launch(2), launch(with_pairs ? 4 : 0);
+            launch(true, false);
+            launch(false, with_pairs);
         }
     } else {
         chains_of(0);
-        launch(3);
+        launch(true, false);
         for (int u = 0; u < units; u++) {
             const bool with_pairs = pairs_of(u);
             if (u + 1 < units) chains_of(u + 1);
-            launch((u + 1 < units ? 3 : 0) | (with_pairs ? 4 : 0));
+            launch(u + 1 < units, with_pairs);
         }
     }
+    // ... and leave them: the tables' hub rows = M[last unit]
+    hipLaunchKernelGGL(hub_rows_kernel, dim3(copy_blocks), dim3(kBlock), 0, (hipStream_t)stream, a.vertex, a.context, mirror(units - 1),
+                       hot_vertex, hot_context, dim, 0);
     return check_launch("gvk_train_episode_hot");
 }
 
@@ -2061,13 +2195,9 @@ int gvk_set_tuning(int key, int value) {
         g_generation = value;
         return GVK_OK;
     }
-    if (key == GVK_TUNE_HOT_WHOLE_PAIRS || key == GVK_TUNE_HOT_SERIALIZED) {
-        (key == GVK_TUNE_HOT_WHOLE_PAIRS ? g_hot_whole_pairs : g_hot_serialized) = value != 0;
-        return GVK_OK;
-    }
 #else
     if (key == GVK_TUNE_LANES_PER_PAIR || key == GVK_TUNE_SEGMENT_STEPS || key == GVK_TUNE_SKIP_LOSS ||
-        key == GVK_TUNE_GENERATION || key == GVK_TUNE_HOT_WHOLE_PAIRS || key == GVK_TUNE_HOT_SERIALIZED) {
+        key == GVK_TUNE_GENERATION) {
         if (value == (key == GVK_TUNE_SKIP_LOSS ? 1 : 0)) return GVK_OK;  // the default is all the product library has
         return fail(GVK_EINVAL, "gvk_set_tuning: this knob exists in the A/B library only (make -C graphvite_amd/csrc ab)");
     }

@@ -49,7 +49,8 @@ constexpr int kSamplePerVertex = 175;
 constexpr double kHubHits = 2;          // GVX_HUB_ROWS -1: a row a batch is expected to hit this often is a hub row
 constexpr uint64_t kMaxHubRows = 16384;  // per table (gvk_hot_build counts the chains of both tables in LDS)
 constexpr int kHubChunk = 128;          // batches whose work lists are built at once
-constexpr int kFidelityChainCap = 32;   // GVX_FIDELITY 1: entries per chain task
+constexpr int kHubEntriesPerPart = 250;  // with hub rows by chains a batch is trained as so many parts that its largest hub row meets about this many of its updates per part
+constexpr int kHubLerp = 0;              // GVX_HUB_LERP -1: the pairs read hub rows as their part's chains left them
 constexpr int kMinEpisodeSample = 20000000;
 constexpr int kExpectedDegree = 1600;  // graph.cuh:55
 constexpr float kMaxNegativeWeight = 10;
@@ -171,6 +172,8 @@ struct gvx_solver {
     int fidelity = 0;               // GVX_FIDELITY: 0 = throughput (default), 1 = the reference's learning quality on hub-heavy tables
     int hub_parts_request = 0;      // GVX_HUB_PARTS: 0 the rule (gvk_train_launches when every row is a hub row, else 1), Q > 0 given
     int64_t hub_rows_request = -2;  // GVX_HUB_ROWS: -2 the default rule, -1 by expected hits per batch, 0 off, N > 0 the first N rows
+    int hub_lerp_request = -1;      // GVX_HUB_LERP: -1 the rule, 0 / 1: the pairs read hub rows as their unit's chains left them / along the chains' way
+    int hub_chain_cap_request = 0;  // GVX_HUB_CHAIN_CAP: entries one chain task trains in sequence (0 = the kernels' default)
     uint64_t node2vec_table_limit = (uint64_t)1 << 30;
     // build
     const gvs_graph *graph = nullptr;
@@ -556,6 +559,14 @@ extern "C" int gvx_solver_set(gvx_solver *s, int option, int64_t value) {
     }
     if (option == GVX_HUB_ROWS && value >= -2) {
         s->hub_rows_request = value;
+        return GVK_OK;
+    }
+    if (option == GVX_HUB_LERP && value >= -1 && value <= 1) {
+        s->hub_lerp_request = (int)value;
+        return GVK_OK;
+    }
+    if (option == GVX_HUB_CHAIN_CAP && value >= 0 && value <= (1 << 20)) {
+        s->hub_chain_cap_request = (int)value;
         return GVK_OK;
     }
     if (option == GVX_NODE2VEC_TABLE_LIMIT && value >= 0) {
@@ -1457,21 +1468,20 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int
             // a small table — every row a hub row, many samples per row and batch — is trained as the parts gvk_train_launches
             // prescribes for it (§7.8): a chain then sees its partners at most a part old
             int parts = kv == part_rows && kc == part_rows ? gvk_train_launches(B, part_rows) : 1;
-            int chain_cap = 0;
+            int chain_cap = hub_chain_cap_request;
             if (hub_parts_request > 0 && B % hub_parts_request == 0) parts = hub_parts_request;
-            else if (fidelity && parts == 1) {
-                // GVX_FIDELITY 1: so many parts that the largest hub row meets about a hundred of its updates per part — twenty
-                // on the headline shape, where 20 parts with chain tasks of 32 entries are within 0.002 of the reference's loop and
-                // 10 parts are not safely (§7.10) —, a divisor of the batch size, at most 50
-                const int want = std::min(std::max((std::max(hub_top_entries[hp], hub_top_entries[tp]) + 50) / 100, 2), 50);
-                for (int q = want; q <= 4 * want && parts == 1; q++)
+            else if (parts == 1) {
+                // so many parts that the largest hub row meets about kHubEntriesPerPart of its updates per part (DESIGN.md §3.1.2,
+                // §7.10), a divisor of the batch size, at most 50
+                const int want = std::min(std::max((std::max(hub_top_entries[hp], hub_top_entries[tp]) + kHubEntriesPerPart / 2) / kHubEntriesPerPart, 1), 50);
+                for (int q = want; q <= 4 * want && (parts == 1 && want > 1); q++)
                     if (B % q == 0) parts = q;
                 for (int q = want; q >= 2 && parts == 1; q--)
                     if (B % q == 0) parts = q;
-                chain_cap = kFidelityChainCap;
             }
+            const int form = (hub_lerp_request < 0 ? kHubLerp : hub_lerp_request) ? GVK_HOT_LERP : 0;
             size_t need = 0;
-            GVK_TRY(gvk_hot_plan(B, num_negative, kv, kc, kHubChunk, parts, chain_cap, &need));
+            GVK_TRY(gvk_hot_plan(dim, B, num_negative, kv, kc, kHubChunk, parts, chain_cap, &need));
             if (need > w.hub_workspace_bytes) {  // first block, or a block with more hub rows / parts than any before it
                 HIP_TRY(hipStreamSynchronize(w.compute));
                 hipFree(w.hub_workspace);
@@ -1483,11 +1493,11 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int
                 const int m = std::min(kHubChunk, n - at);
                 const uint32_t id = (uint32_t)(first + (uint64_t)at * W);
                 const uint32_t *batches = pool + (size_t)(done + at) * B * 2;
-                GVK_TRY(gvk_hot_build(w.compute, w.hub_workspace, w.hub_workspace_bytes, batches, B, m, num_negative, &neg, id,
+                GVK_TRY(gvk_hot_build(w.compute, dim, w.hub_workspace, w.hub_workspace_bytes, batches, B, m, num_negative, &neg, id,
                                       (uint32_t)W, kv, kc, parts, chain_cap));
                 GVK_TRY(gvk_train_episode_hot(w.compute, dim, &o, optimizer.schedule == 1, &t, batches, &neg, id, (uint32_t)W,
                                               (uint32_t)num_batch, m, w.loss, B, num_negative, config.negative_weight,
-                                              w.hub_workspace, w.hub_workspace_bytes, kv, kc, m, parts, chain_cap, 0));
+                                              w.hub_workspace, w.hub_workspace_bytes, kv, kc, m, parts, chain_cap, form));
             }
         } else if (optimizer.schedule != 2) {
             GVK_TRY(gvk_train_episode(w.compute, dim, &o, optimizer.schedule == 1, &t, pool + (size_t)done * B * 2, &neg,

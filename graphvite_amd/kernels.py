@@ -162,28 +162,31 @@ class HipKernels(object):
                                         batch_size, num_negative, negative_weight)
         _lib.check(rc, "gvk_train_episode")
 
-    def hot_plan(self, batch_size, num_negative, hot_vertex, hot_context, num_batch, parts=1, chain_cap=0):
-        """Bytes of device workspace the chains' work lists of num_batch batches (each trained as `parts` parts) need."""
+    def hot_plan(self, dim, batch_size, num_negative, hot_vertex, hot_context, num_batch, parts=1, chain_cap=0):
+        """Bytes of device workspace the chains' work lists of num_batch batches (each trained as `parts` parts) and the
+        mirrors of the hub rows need."""
         n = C.c_size_t(0)
-        _lib.check(self.lib.gvk_hot_plan(batch_size, num_negative, hot_vertex, hot_context, num_batch, parts, chain_cap, C.byref(n)),
-                   "gvk_hot_plan")
+        _lib.check(self.lib.gvk_hot_plan(dim, batch_size, num_negative, hot_vertex, hot_context, num_batch, parts, chain_cap,
+                                         C.byref(n)), "gvk_hot_plan")
         return n.value
 
-    def hot_build(self, workspace, pool, batch_size, num_batch, num_negative, table, seed, first_batch_id, hot_vertex,
+    def hot_build(self, dim, workspace, pool, batch_size, num_batch, num_negative, table, seed, first_batch_id, hot_vertex,
                   hot_context, batch_id_stride=1, parts=1, chain_cap=0):
         """The work lists of the hub rows' chains for num_batch batches of a device pool (gvk_hot_build); workspace: uint8
         device tensor of hot_plan() bytes."""
         dev = pool.device
         _need(pool, torch.int32, "pool", dev)
         neg = self._negative(None, table, seed, dev)
-        rc = self.lib.gvk_hot_build(self._stream(pool), _ptr(workspace), workspace.numel(), _ptr(pool), batch_size, num_batch,
+        rc = self.lib.gvk_hot_build(self._stream(pool), dim, _ptr(workspace), workspace.numel(), _ptr(pool), batch_size, num_batch,
                                     num_negative, C.byref(neg), first_batch_id, batch_id_stride, hot_vertex, hot_context, parts,
                                     chain_cap)
         _lib.check(rc, "gvk_hot_build")
 
+    HOT_SERIALIZED, HOT_LERP = 1, 2  # gvk.h GVK_HOT_SERIALIZED, GVK_HOT_LERP
+
     def train_episode_hot(self, vertex, context, pool, loss, optimizer, num_negative, negative_weight, table, seed,
                           first_batch_id, total_batches, num_batches, batch_size, workspace, hot_vertex, hot_context,
-                          workspace_batches=None, batch_id_stride=1, serialized=False, parts=1, chain_cap=0):
+                          workspace_batches=None, batch_id_stride=1, serialized=False, parts=1, chain_cap=0, lerp=False):
         """gvk_train_episode_hot: batches whose hub rows are trained by chains (work lists from hot_build in `workspace`)."""
         dev = vertex.device
         tables = self._tables(vertex, context, None)
@@ -196,7 +199,7 @@ class HipKernels(object):
                                             first_batch_id, batch_id_stride, total_batches, num_batches, _ptr(loss), batch_size,
                                             num_negative, negative_weight, _ptr(workspace), workspace.numel(), hot_vertex,
                                             hot_context, num_batches if workspace_batches is None else workspace_batches,
-                                            parts, chain_cap, int(serialized))
+                                            parts, chain_cap, (self.HOT_SERIALIZED if serialized else 0) | (self.HOT_LERP if lerp else 0))
         _lib.check(rc, "gvk_train_episode_hot")
 
     def predict(self, vertex, context, pairs, logits):

@@ -247,6 +247,8 @@ class GraphSolver(object):
         # GVX_HUB_ROWS (gvx.h): None = the default rule, "auto" = by expected hits per batch, 0 = off, N = the first N rows
         self.hub_rows_request = -2 if hub_rows is None else (-1 if hub_rows == "auto" else int(hub_rows))
         self.hub_parts = 0  # GVX_HUB_PARTS (gvx.h): 0 = the rule
+        self.hub_lerp = None  # GVX_HUB_LERP (gvx.h): None = the rule, False / True
+        self.hub_chain_cap = 0  # GVX_HUB_CHAIN_CAP (gvx.h): 0 = the kernels' default
         if fidelity not in ("throughput", "reference"):
             raise ValueError("fidelity must be 'throughput' or 'reference', not %r" % (fidelity,))
         self.fidelity = fidelity  # GVX_FIDELITY (gvx.h)
@@ -288,6 +290,8 @@ class GraphSolver(object):
                               (_lib.GVX_NEGATIVE_TABLE, _NEGATIVE_TABLES[self.negative_table]),
                               (_lib.GVX_NODE2VEC_TABLE_LIMIT, int(self.node2vec_table_limit)),
                               (_lib.GVX_HUB_ROWS, int(self.hub_rows_request)), (_lib.GVX_HUB_PARTS, int(self.hub_parts)),
+                              (_lib.GVX_HUB_LERP, -1 if self.hub_lerp is None else int(bool(self.hub_lerp))),
+                              (_lib.GVX_HUB_CHAIN_CAP, int(self.hub_chain_cap)),
                               (_lib.GVX_FIDELITY, int(self.fidelity == "reference"))):
             self._check(self._lib.gvx_solver_set(self._handle, option, value), "GraphSolver")
 

@@ -163,39 +163,45 @@ int gvk_train_episode(void *stream, int dim, const gvk_optimizer *optimizer, int
 /* Hub rows trained by chains (SGD, negatives drawn on the device).  Inside one launch every sample runs at
  * the same time, and of the updates that hold a row at the same time one survives.  For the rows of a large table that is
  * rare; a hub row is in flight hundreds of times per launch and keeps a handful of its updates, where the reference's
- * sequential loop keeps them all.  Here the first hot_vertex rows of the head table and the first hot_context rows of the
- * tail table (partitions are ordered by falling degree: the hub rows) are each owned by a chain: one wavefront holds the row
- * in registers and applies every update the batch has for it one after the other, partner rows read-only, and stores the
- * row once; the per-pair work of the same launch trains every sample as gvk_train does but only READS hub rows.
- *   gvk_hot_plan    bytes of device workspace the work lists of num_batch batches need
+ * sequential loop (gpu/graph.cuh:54-94 in sample order) keeps them all.  Here the first hot_vertex rows of the head table and
+ * the first hot_context rows of the tail table (partitions are ordered by falling degree: the hub rows) are each owned by a
+ * chain: one lane group holds the row in registers and applies every update the unit has for it one after the other, partner
+ * rows read-only, and stores the row once; the per-pair work trains every sample as gvk_train does but only READS hub rows.
+ * A unit is a batch or one of its `parts`.  The chains of a unit start from the hub rows as the unit found them — their own
+ * row and every partner that is a hub row, so a sample between two hub rows updates both from their old values, as the
+ * reference does (model/graph.h:47-58) — and the unit's pairs read the hub rows those chains left; during a call the hub
+ * rows live in mirrors inside the workspace and are written to the tables when the call returns its last launch.
+ *   gvk_hot_plan    bytes of device workspace the work lists of num_batch batches (and the mirrors of the hub rows) need
  *   gvk_hot_build   the work lists of num_batch consecutive batches of a device pool (ids first_batch_id + i * stride): per
- *                   batch and hub row the partner rows of its updates — for a head row the k negatives then the tail of every
+ *                   unit and hub row the partner rows of its updates — for a head row the k negatives then the tail of every
  *                   sample it heads, for a context row the head of every sample it is the tail or a negative of; negatives
  *                   per the RNG contract, exactly as the training launch draws them
  *   gvk_train_episode_hot   gvk_train_episode over batches whose work lists sit in `workspace` (built for workspace_batches
- *                   batches starting with this call's first batch; same pool, ids, negative source, hot_vertex / hot_context).
- *                   serialized != 0: the same work as three launches in a fixed order — head-row chains, context-row
- *                   chains, pairs — which makes the result a pure function of the work lists.  A form for parity tests of the
- *                   kernels only: the product form runs the two chain families side by side, so that a sample between two
- *                   hub rows updates both from their old values as the reference does; one after the other they compound
- *                   (DESIGN.md §3.1.2).
- * parts (a divisor of batch_size, the same in all three calls; 1 = none): a batch is trained as `parts` equal parts one after
- * the other, each with its own work lists — chains, then pairs, of samples [q, q + 1) * batch_size / parts — so that a chain
- * sees its partner rows at most a part old; what gvk_train_launches() prescribes for small tables.  When
- * every row of both tables is a hub row the pairs have nothing to store and only run for the last batch (its loss).
- * chain_cap (the same in all three calls; 0 = the default, 256): entries one chain task trains in sequence — a longer chain
- * is cut into tasks trained side by side and composed (weight decay in closed form). */
-int gvk_hot_plan(int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts,
+ *                   batches starting with this call's first batch; same dim, pool, ids, negative source, hot_vertex /
+ *                   hot_context).  One launch per unit: the pairs of unit u and, in its first blocks, the chains of unit
+ *                   u + 1.  form: GVK_HOT_SERIALIZED = per unit two launches, chains then pairs — the result is then a pure
+ *                   function of the work lists, what the oracle restates (parity tests of the kernels); GVK_HOT_LERP = a
+ *                   sample reads a hub row not as its unit's chains left it but on the straight line from where they found it
+ *                   to where they left it, at the sample's place in the unit (fewer parts for the same staleness).
+ * parts (a divisor of batch_size, the same in all three calls; 1 = none): a batch is trained as `parts` equal units one after
+ * the other, each with its own work lists, so that nothing reads a hub row that is more than a unit old.  When every row of
+ * both tables is a hub row the pairs have nothing to store and only run for the last batch (its loss).
+ * chain_cap (the same in all three calls; 0 = the default, 16): entries one chain task trains in sequence — a longer chain is
+ * cut into up to 256 / lanes tasks trained side by side by one workgroup and composed in task order (weight decay in closed
+ * form; deterministic given the work lists). */
+#define GVK_HOT_SERIALIZED 1
+#define GVK_HOT_LERP 2
+int gvk_hot_plan(int dim, int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts,
                  int chain_cap, size_t *bytes);
-int gvk_hot_build(void *stream, void *workspace, size_t workspace_bytes, const uint32_t *pool, int batch_size, int num_batch,
-                  int num_negative, const gvk_negative_source *negative, uint32_t first_batch_id, uint32_t batch_id_stride,
-                  uint32_t hot_vertex, uint32_t hot_context, int parts, int chain_cap);
+int gvk_hot_build(void *stream, int dim, void *workspace, size_t workspace_bytes, const uint32_t *pool, int batch_size,
+                  int num_batch, int num_negative, const gvk_negative_source *negative, uint32_t first_batch_id,
+                  uint32_t batch_id_stride, uint32_t hot_vertex, uint32_t hot_context, int parts, int chain_cap);
 int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer, int linear_schedule, const gvk_tables *tables,
                           const uint32_t *pairs, const gvk_negative_source *negative, uint32_t first_batch_id,
                           uint32_t batch_id_stride, uint32_t total_batches, int num_batches, float *loss, int batch_size,
-                          int num_negative, float negative_weight, const void *workspace, size_t workspace_bytes,
+                          int num_negative, float negative_weight, void *workspace, size_t workspace_bytes,
                           uint32_t hot_vertex, uint32_t hot_context, int workspace_batches, int parts, int chain_cap,
-                          int serialized);
+                          int form);
 
 /* logits[s] = dot(vertex[head_s], context[tail_s]) */
 int gvk_predict(void *stream, int dim, const float *vertex, const float *context, const uint32_t *pairs,
@@ -320,12 +326,9 @@ int gvk_probe_row_traffic(void *stream, int dim, float *vertex, float *context, 
                                      partitions at the reference's learning quality); 0 = always one launch
                                      per batch */
 #define GVK_TUNE_CHAIN_CAP 8      /* gvk_train_episode_hot: entries one chain task trains in sequence (a longer chain is cut into
-                                     parts trained side by side whose deltas add up): 0 = the default, 256 */
+                                     tasks trained side by side and composed): 0 = the default, 16 */
 /* A/B library only: */
 #define GVK_TUNE_LANES_PER_PAIR 1 /* 0 = per-dim default; else 8, 16, 32 or 64 */
-#define GVK_TUNE_HOT_SERIALIZED 9   /* bring-up: 1 = gvk_train_episode_hot always runs its three-launch form */
-#define GVK_TUNE_HOT_WHOLE_PAIRS 10 /* experiment: 1 = with parts, only the chains are trained part by part; the pairs of a batch in one
-                                       launch (not enough: DESIGN.md §7.10) */
 #define GVK_TUNE_GENERATION 4     /* parity experiment: C > 0 trains a batch as consecutive launches of at most C samples
                                      (per-pair kernel), the concurrency structure of the reference's launch on a card
                                      that keeps C warps resident; 0 = off (default) */

@@ -156,6 +156,11 @@ void gvx_solver_destroy(gvx_solver *s);
  * within 0.002 of the reference's sequential loop there, at about a ninth of the rate
  * (DESIGN.md §7.10).  GVX_HUB_ROWS / GVX_HUB_PARTS given explicitly take precedence. */
 #define GVX_FIDELITY 8
+/* GVX_HUB_LERP -1 (default): the rule; 0 / 1: with hub rows trained by chains, a sample reads a hub row as the chains of its
+ * part left it / on the straight line from where they found it to where they left it, at the sample's place in the part
+ * (gvk.h GVK_HOT_LERP).  GVX_HUB_CHAIN_CAP: entries one chain task trains in sequence (gvk.h chain_cap; 0 = the default). */
+#define GVX_HUB_LERP 9
+#define GVX_HUB_CHAIN_CAP 10
 int gvx_solver_set(gvx_solver *s, int option, int64_t value);
 
 /* The graph is borrowed until the next build / destroy (solver.h:289).  num_partition / episode_size: GVX_AUTO. */

@@ -186,34 +186,39 @@ static void gvo_chain(int dim, float *own, const float *partner, const uint32_t 
     }
 }
 
-/* One batch in the product's serialized form (SGD): (1) the chains of the kv hub head rows, each over its entries in list
- * order on its own row, context rows read; (2) the chains of the kc hub context rows, vertex rows read; (3) every sample in
- * order as gvo_train, except that hub rows are read and never written.  A chain longer than cap entries is trained as parts
- * of cap entries side by side and the parts are composed (below). */
-static int gvo_hot_chains(int dim, float *vertex, float *context, float lr, float wd, float negative_weight, uint32_t kv,
-                          const uint32_t *chain_start, const uint32_t *entries, uint32_t cap, uint32_t first_chain,
+/* The chains [first_chain, last_chain) of one unit (SGD): each over its entries in list order on its own row, which it reads
+ * from `own_table` and leaves there; partner rows are read from `partner_vertex` / `partner_context` (the caller passes the
+ * tables as the unit found them).  A chain longer than cap entries is trained as tasks of consecutive entries side by side
+ * and the tasks are composed (below): tasks of cap entries, or — past max_tasks of them (0 = no limit) — of
+ * ceil(n / max_tasks) entries rounded up to whole samples (k + 1 entries), what one workgroup of the product trains
+ * (train_long_chains, graphvite_amd/csrc/gvk_kernels.hip). */
+static int gvo_hot_chains(int dim, float *vertex, float *context, const float *partner_vertex, const float *partner_context,
+                          float lr, float wd, float negative_weight, uint32_t kv, const uint32_t *chain_start,
+                          const uint32_t *entries, uint32_t cap, uint32_t max_tasks, int k, uint32_t first_chain,
                           uint32_t last_chain) {
     float *own = (float *)malloc(sizeof(float) * dim), *sum = (float *)malloc(sizeof(float) * dim);
     if (!own || !sum) return -1;
-    for (uint32_t chain = first_chain; chain < last_chain; chain++) {  /* chains kv.. read the vertex rows as they are */
+    for (uint32_t chain = first_chain; chain < last_chain; chain++) {
         float *row = chain < kv ? vertex + (size_t)chain * dim : context + (size_t)(chain - kv) * dim;
-        const float *partner = chain < kv ? context : vertex;
-        const uint32_t first = chain_start[chain], last = chain_start[chain + 1];
-        if (last - first <= cap) {
+        const float *partner = chain < kv ? partner_context : partner_vertex;
+        const uint32_t first = chain_start[chain], last = chain_start[chain + 1], n = last - first;
+        if (n <= cap) {
             gvo_chain(dim, row, partner, entries, first, last, lr, wd, negative_weight);
             continue;
         }
-        /* parts: weight decay composes in closed form (a factor per entry that depends on its label only), so every part
+        uint32_t per = cap;
+        if (max_tasks && (uint64_t)per * max_tasks < n) per = ((n + max_tasks - 1) / max_tasks + (uint32_t)k) / (uint32_t)(k + 1) * (uint32_t)(k + 1);
+        /* tasks: weight decay composes in closed form (a factor per entry that depends on its label only), so every task
          * starts from the row as the decay of the entries before it leaves it, and its end state is carried through the
-         * decay of the entries after it: row <- total row + sum over parts (after end - total row) */
+         * decay of the entries after it: row <- total row + sum over tasks (after end - total row) */
         const float decay_positive = 1 - lr * wd, decay_negative = 1 - lr * negative_weight * wd;
         uint32_t positives_all = 0;
         for (uint32_t p = first; p < last; p++) positives_all += entries[p] >> 31;
-        const float total = powf(decay_positive, (float)positives_all) * powf(decay_negative, (float)(last - first - positives_all));
+        const float total = powf(decay_positive, (float)positives_all) * powf(decay_negative, (float)(n - positives_all));
         memset(sum, 0, sizeof(float) * dim);
         uint32_t positives_before = 0;
-        for (uint32_t begin = first; begin < last; begin += cap) {
-            const uint32_t end = last - begin > cap ? begin + cap : last;
+        for (uint32_t begin = first; begin < last; begin += per) {
+            const uint32_t end = last - begin > per ? begin + per : last;
             uint32_t positives_inside = 0;
             for (uint32_t p = begin; p < end; p++) positives_inside += entries[p] >> 31;
             const uint32_t positives_after = positives_all - positives_before - positives_inside;
@@ -230,91 +235,43 @@ static int gvo_hot_chains(int dim, float *vertex, float *context, float lr, floa
     return 0;
 }
 
-int gvo_train_hot(int dim, float *vertex, float *context, const uint32_t *batch, const uint32_t *negatives, float *loss,
-                  int batch_size, int k, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
-                  const uint32_t *chain_start, const uint32_t *entries, uint32_t cap) {
-    float *own = (float *)malloc(sizeof(float) * dim), *buf = (float *)malloc(sizeof(float) * dim);
-    float dummy1 = 0, dummy2 = 0;
-    if (!own || !buf) return -1;
-    /* the chains of the head rows, then those of the context rows (which read the head rows the first kv chains wrote) */
-    if (gvo_hot_chains(dim, vertex, context, lr, wd, negative_weight, kv, chain_start, entries, cap, 0, kv + kc)) return -1;
-    for (int s = 0; s < batch_size; s++) {
-        const size_t head = batch[2 * s + 1];
-        memcpy(buf, vertex + head * dim, sizeof(float) * dim);
-        float sample_loss = 0;
-        size_t last = 0;
-        int have = 0;
-        for (int j = 0; j <= k; j++) {
-            const size_t tail = j < k ? negatives[(size_t)s * k + j] : batch[2 * s];
-            const int label = j == k;
-            float *c = context + tail * dim;
-            /* a hub row is not written here, but a sample whose consecutive targets are the same row sees its own update
-             * (the kernel carries the updated registers over), as it does for any other row */
-            const float *from = (tail < kc && have && tail == last) ? own : c;
-            float logit = 0;
-            for (int i = 0; i < dim; i++) logit += buf[i] * from[i];
-            const float prob = gvo_sigmoid(logit);
-            float gradient, weight;
-            if (label) {
-                gradient = prob - 1, weight = 1;
-                sample_loss += weight * -logf(prob + GVO_EPS);
-            } else {
-                gradient = prob, weight = negative_weight;
-                sample_loss += weight * -logf(1 - prob + GVO_EPS);
-            }
-            for (int i = 0; i < dim; i++) {
-                const float vi = buf[i], ci = from[i];
-                buf[i] -= gvo_update(0, lr, wd, NULL, vi, gradient * ci, weight, &dummy1, &dummy2);
-                const float cn = ci - gvo_update(0, lr, wd, NULL, ci, gradient * vi, weight, &dummy1, &dummy2);
-                if (tail >= kc) c[i] = cn;
-                own[i] = cn;
-            }
-            last = tail, have = 1;
-        }
-        loss[s] = sample_loss / (1 + k * negative_weight);
-        if (head >= kv) memcpy(vertex + head * dim, buf, sizeof(float) * dim);
+/* The chains of one unit, BOTH families from the tables as the unit finds them: a chain reads its own row and its partners,
+ * hub rows included, from that state, so a sample between two hub rows updates both from their old values, as the reference
+ * does (model/graph.h:47-58).  In place: the hub rows of both tables end as the chains leave them. */
+int gvo_hot_unit_chains(int dim, float *vertex, float *context, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
+                        const uint32_t *chain_start, const uint32_t *entries, uint32_t cap, uint32_t max_tasks, int k) {
+    /* the context-row chains read the head table, whose hub rows are still untouched; the head-row chains then read the hub
+     * rows of the context table from a copy taken before.  Rows that are not hub rows are the same in both. */
+    float *c0 = (float *)malloc(sizeof(float) * dim * (kc ? kc : 1)), *seen = (float *)malloc(sizeof(float) * dim * (kc ? kc : 1));
+    if (!c0 || !seen) return -1;
+    memcpy(c0, context, sizeof(float) * dim * kc);
+    int rc = gvo_hot_chains(dim, vertex, context, vertex, context, lr, wd, negative_weight, kv, chain_start, entries, cap, max_tasks, k, kv, kv + kc);
+    if (!rc && kv) {
+        memcpy(seen, context, sizeof(float) * dim * kc);
+        memcpy(context, c0, sizeof(float) * dim * kc);
+        rc = gvo_hot_chains(dim, vertex, context, vertex, context, lr, wd, negative_weight, kv, chain_start, entries, cap, max_tasks, k, 0, kv);
+        memcpy(context, seen, sizeof(float) * dim * kc);
     }
-    free(own), free(buf);
-    return 0;
+    free(c0), free(seen);
+    return rc;
 }
 
-/* EXPERIMENT (scripts/experiments/executor_sim.py; no product counterpart yet): gvo_train_hot with one change in its third
- * phase — a sample reads a hub row not as the chains left it but where the chain was when it met the sample, approximated by
- * the straight line from the row before the chains to the row after them: sample s of n reads start + (s + 1/2) / n (end -
- * start).  `lerp` = 0 gives gvo_train_hot.  Asks: how much of the staleness that sub-batching removes is the pairs reading
- * end-of-batch hub rows? */
-int gvo_train_hot_lerp(int dim, float *vertex, float *context, const uint32_t *batch, const uint32_t *negatives, float *loss,
-                       int batch_size, int k, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
-                       const uint32_t *chain_start, const uint32_t *entries, uint32_t cap, int lerp) {
-    float *v0 = (float *)malloc(sizeof(float) * dim * (kv ? kv : 1)), *c0 = (float *)malloc(sizeof(float) * dim * (kc ? kc : 1));
+/* The pairs of one unit: every sample in order as gvo_train, except that hub rows (the first kv / kc rows: in the tables as
+ * the unit's chains left them) are read and never written.  before_vertex / before_context non-NULL (lerp): the hub rows as
+ * those chains FOUND them — a sample then reads a hub row where its chain was when it met the sample, approximated by the
+ * straight line from the row before the chains to the row after them: sample s of n reads before + (s + 1/2) / n (now - before). */
+int gvo_train_pairs_hot(int dim, float *vertex, float *context, const uint32_t *batch, const uint32_t *negatives, float *loss,
+                        int batch_size, int k, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
+                        const float *before_vertex, const float *before_context) {
     float *buf = (float *)malloc(sizeof(float) * dim), *hub = (float *)malloc(sizeof(float) * dim);
     float *own = (float *)malloc(sizeof(float) * dim);
     float dummy1 = 0, dummy2 = 0;
-    if (!v0 || !c0 || !buf || !hub || !own) return -1;
-    memcpy(v0, vertex, sizeof(float) * dim * kv);
-    memcpy(c0, context, sizeof(float) * dim * kc);
-    /* phases 1 and 2: the chains.  lerp & 2: the two families side by side, each reading the OTHER table's hub rows as the
-     * unit found them (what one launch of concurrent chains does: a sample between two hub rows updates both from their old
-     * values, as the reference does, model/graph.h:47-58); otherwise head rows first, context rows against the new head rows */
-    int rc;
-    if (lerp & 2) {
-        float *c_end = (float *)malloc(sizeof(float) * dim * (kc ? kc : 1));
-        if (!c_end) return -1;
-        rc = gvo_hot_chains(dim, vertex, context, lr, wd, negative_weight, kv, chain_start, entries, cap, kv, kv + kc);
-        memcpy(c_end, context, sizeof(float) * dim * kc);
-        memcpy(context, c0, sizeof(float) * dim * kc);
-        if (!rc) rc = gvo_hot_chains(dim, vertex, context, lr, wd, negative_weight, kv, chain_start, entries, cap, 0, kv);
-        memcpy(context, c_end, sizeof(float) * dim * kc);
-        free(c_end);
-    } else {
-        rc = gvo_hot_chains(dim, vertex, context, lr, wd, negative_weight, kv, chain_start, entries, cap, 0, kv + kc);
-    }
-    if (rc) return rc;
+    if (!buf || !hub || !own) return -1;
     for (int s = 0; s < batch_size; s++) {
-        const float at = (lerp & 1) ? (s + 0.5f) / batch_size : 1.0f;
+        const float at = (s + 0.5f) / batch_size;
         const size_t head = batch[2 * s + 1];
-        if (head < kv)
-            for (int i = 0; i < dim; i++) buf[i] = v0[head * dim + i] + at * (vertex[head * dim + i] - v0[head * dim + i]);
+        if (head < kv && before_vertex)
+            for (int i = 0; i < dim; i++) buf[i] = before_vertex[head * dim + i] + at * (vertex[head * dim + i] - before_vertex[head * dim + i]);
         else
             memcpy(buf, vertex + head * dim, sizeof(float) * dim);
         float sample_loss = 0;
@@ -326,10 +283,12 @@ int gvo_train_hot_lerp(int dim, float *vertex, float *context, const uint32_t *b
             float *c = context + tail * dim;
             const float *from = c;
             if (tail < kc) {
+                /* a hub row is not written here, but a sample whose consecutive targets are the same row sees its own
+                 * update (the kernel carries the updated registers over), as it does for any other row */
                 if (have && tail == last) {
                     from = own;
-                } else {
-                    for (int i = 0; i < dim; i++) hub[i] = c0[tail * dim + i] + at * (c[i] - c0[tail * dim + i]);
+                } else if (before_context) {
+                    for (int i = 0; i < dim; i++) hub[i] = before_context[tail * dim + i] + at * (c[i] - before_context[tail * dim + i]);
                     from = hub;
                 }
             }
@@ -356,8 +315,27 @@ int gvo_train_hot_lerp(int dim, float *vertex, float *context, const uint32_t *b
         loss[s] = sample_loss / (1 + k * negative_weight);
         if (head >= kv) memcpy(vertex + head * dim, buf, sizeof(float) * dim);
     }
-    free(v0), free(c0), free(buf), free(hub), free(own);
+    free(buf), free(hub), free(own);
     return 0;
+}
+
+/* One unit (a batch or a part of one) in the product's serialized form (gvk_train_episode_hot with GVK_HOT_SERIALIZED): the
+ * unit's chains (gvo_hot_unit_chains), then its pairs (gvo_train_pairs_hot; `lerp`: hub rows read along the chains' way). */
+int gvo_train_hot(int dim, float *vertex, float *context, const uint32_t *batch, const uint32_t *negatives, float *loss,
+                  int batch_size, int k, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
+                  const uint32_t *chain_start, const uint32_t *entries, uint32_t cap, uint32_t max_tasks, int lerp) {
+    float *v0 = NULL, *c0 = NULL;
+    if (lerp) {
+        v0 = (float *)malloc(sizeof(float) * dim * (kv ? kv : 1)), c0 = (float *)malloc(sizeof(float) * dim * (kc ? kc : 1));
+        if (!v0 || !c0) return -1;
+        memcpy(v0, vertex, sizeof(float) * dim * kv);
+        memcpy(c0, context, sizeof(float) * dim * kc);
+    }
+    int rc = gvo_hot_unit_chains(dim, vertex, context, lr, wd, negative_weight, kv, kc, chain_start, entries, cap, max_tasks, k);
+    if (!rc)
+        rc = gvo_train_pairs_hot(dim, vertex, context, batch, negatives, loss, batch_size, k, lr, wd, negative_weight, kv, kc, v0, c0);
+    free(v0), free(c0);
+    return rc;
 }
 
 void gvo_predict(int dim, const float *vertex, const float *context, const uint32_t *batch, float *logits,

@@ -23,9 +23,14 @@ extern "C" {
 float gvo_lr(float init_lr, int linear, int batch_id, int num_batch);
 size_t gvo_hot_lists(const uint32_t *batch, const uint32_t *negatives, int batch_size, int k, uint32_t kv, uint32_t kc,
                      uint32_t *chain_start, uint32_t *entries);
-int gvo_train_hot_lerp(int dim, float *vertex, float *context, const uint32_t *batch, const uint32_t *negatives, float *loss,
-                       int batch_size, int k, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
-                       const uint32_t *chain_start, const uint32_t *entries, uint32_t cap, int lerp);
+int gvo_train_hot(int dim, float *vertex, float *context, const uint32_t *batch, const uint32_t *negatives, float *loss,
+                  int batch_size, int k, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
+                  const uint32_t *chain_start, const uint32_t *entries, uint32_t cap, uint32_t max_tasks, int lerp);
+int gvo_hot_unit_chains(int dim, float *vertex, float *context, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
+                        const uint32_t *chain_start, const uint32_t *entries, uint32_t cap, uint32_t max_tasks, int k);
+int gvo_train_pairs_hot(int dim, float *vertex, float *context, const uint32_t *batch, const uint32_t *negatives, float *loss,
+                        int batch_size, int k, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
+                        const float *before_vertex, const float *before_context);
 int gvo_train(int dim, int type, float *vertex, float *context, float *vm1, float *cm1, float *vm2, float *cm2,
               const uint32_t *batch, const uint32_t *negatives, float *loss, int batch_size, int k, float lr, float wd,
               float negative_weight, const float *hp);
@@ -189,15 +194,15 @@ int gvk_train_episode(void *, int dim, const gvk_optimizer *optimizer, int linea
 
 // Hub rows by chains (gvk.h): a device-execution concern — what the chains restore is the sequential result, and the host
 // build's kernels ARE sequential.  The work lists are not needed; the batches are trained as gvk_train_episode trains them.
-int gvk_hot_plan(int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts, int,
+int gvk_hot_plan(int dim, int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts, int,
                  size_t *bytes) {
-    if (!bytes || parts < 1 || batch_size % parts || batch_size <= 0 || num_negative < 0 || num_batch < 0 || (uint64_t)hot_vertex + hot_context == 0)
+    if (!bytes || dim <= 0 || parts < 1 || batch_size % parts || batch_size <= 0 || num_negative < 0 || num_batch < 0 || (uint64_t)hot_vertex + hot_context == 0)
         return gvk_fail(GVK_EINVAL, "gvk_hot_plan: bad argument");
     *bytes = 256;
     return GVK_OK;
 }
 
-int gvk_hot_build(void *, void *workspace, size_t, const uint32_t *pool, int, int, int, const gvk_negative_source *negative, uint32_t,
+int gvk_hot_build(void *, int, void *workspace, size_t, const uint32_t *pool, int, int, int, const gvk_negative_source *negative, uint32_t,
                   uint32_t, uint32_t, uint32_t, int, int) {
     return workspace && pool && negative ? GVK_OK : gvk_fail(GVK_EINVAL, "gvk_hot_build: null argument");
 }
@@ -205,80 +210,76 @@ int gvk_hot_build(void *, void *workspace, size_t, const uint32_t *pool, int, in
 int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer, int linear_schedule, const gvk_tables *tables,
                           const uint32_t *pairs, const gvk_negative_source *negative, uint32_t first_batch_id,
                           uint32_t batch_id_stride, uint32_t total_batches, int num_batches, float *loss, int batch_size,
-                          int num_negative, float negative_weight, const void *workspace, size_t, uint32_t hot_vertex,
-                          uint32_t hot_context, int workspace_batches, int parts, int chain_cap, int) {
+                          int num_negative, float negative_weight, void *workspace, size_t, uint32_t hot_vertex,
+                          uint32_t hot_context, int workspace_batches, int parts, int chain_cap, int form) {
     if (!workspace || num_batches > workspace_batches || hot_vertex > tables->n_vertex || hot_context > tables->n_context)
         return gvk_fail(GVK_EINVAL, "gvk_train_episode_hot: bad argument");
-    // GVH_EXECUTOR (scripts/experiments/executor_sim.py): instead of the sequential batch, the product's three-launch form part
-    // by part ("chains"), or the same with the pairs reading hub rows along the chains' way ("lerp") — an executor simulator
-    // for what a change of the device path would do to learning, no GPU needed
+    // GVH_EXECUTOR: instead of the sequential batch, the device path's execution model unit by unit (oracle/gv_oracle.c
+    // gvo_train_hot: chains of both families from the unit's start state, then its pairs; `form` & GVK_HOT_LERP or GVH_LERP=1:
+    // the pairs read hub rows along the chains' way) — an executor simulator for what a change of the device path does to
+    // learning, no GPU needed.  "units": unit after unit; "pipelined": the chains of unit u + 1 are computed before the pairs of
+    // unit u have written anything, as one launch of the product does.  (The Hogwild losses of rows that are not hub rows are
+    // not simulated: the pairs run in sample order.)
     const char *executor = getenv("GVH_EXECUTOR");
     if (!executor || !*executor || !strcmp(executor, "sequential"))
         return gvk_train_episode(stream, dim, optimizer, linear_schedule, tables, pairs, negative, first_batch_id, batch_id_stride,
                                  total_batches, num_batches, loss, batch_size, num_negative, negative_weight);
-    // names: chains | lerp | simultaneous | simultaneous-lerp, each also as pipelined-...
-    const int lerp = (strstr(executor, "lerp") ? 1 : 0) | (strstr(executor, "simultaneous") ? 2 : 0);
+    const int lerp = (form & GVK_HOT_LERP) || (getenv("GVH_LERP") && atoi(getenv("GVH_LERP")));
     const int pipelined = strstr(executor, "pipelined") != nullptr, n = batch_size / parts, k = num_negative;
     if (getenv("GVH_CHAIN_CAP")) chain_cap = atoi(getenv("GVH_CHAIN_CAP"));
-    const uint32_t cap = ((chain_cap > 0 ? chain_cap : 256) + k) / (k + 1) * (k + 1);
-    std::vector<uint32_t> drawn((size_t)batch_size * std::max(k, 1)), start(hot_vertex + hot_context + 1), entries(2 * (size_t)(k + 1) * n + 1);
-    if (pipelined) {
-        // the product form: launch u = the pairs of unit u + the chains of unit u + 1, which start before those pairs have
-        // written anything and store their rows at the end — the chains of unit u + 1 are computed from the tables as the pairs of
-        // unit u - 1 left them, the pairs of unit u read the hub rows the chains of unit u left
-        const int units = num_batches * parts;
-        const size_t hv = (size_t)hot_vertex * dim, hc = (size_t)hot_context * dim;
-        std::vector<float> now_v(hv), now_c(hc), next_v(hv), next_c(hc);
-        std::vector<uint32_t> none(hot_vertex + hot_context + 1, 0), all((size_t)num_batches * batch_size * std::max(k, 1));
-        for (int i = 0; i < num_batches; i++) {
-            const uint32_t id = first_batch_id + (uint32_t)i * batch_id_stride;
-            uint32_t *out = all.data() + (size_t)i * batch_size * k;
-            if (negative->classes)
-                gvk_negative_draw_classes(nullptr, negative->classes, negative->class_count, negative->seed, id, out, batch_size, k);
-            else
-                gvk_negative_draw(nullptr, negative->table, negative->count, negative->seed, id, out, batch_size, k);
-        }
-        auto chains = [&](int u) {
-            const int i = u / parts, q = u % parts;
-            const uint32_t *part = pairs + ((size_t)i * batch_size + (size_t)q * n) * 2, *negatives = all.data() + ((size_t)i * batch_size + (size_t)q * n) * k;
-            const float lr = gvo_lr(optimizer->lr, linear_schedule, (int)(first_batch_id + (uint32_t)i * batch_id_stride), (int)total_batches);
-            gvo_hot_lists(part, negatives, n, k, hot_vertex, hot_context, start.data(), entries.data());
-            return gvo_train_hot_lerp(dim, tables->vertex, tables->context, part, negatives, loss, 0, k, lr, optimizer->weight_decay,
-                                      negative_weight, hot_vertex, hot_context, start.data(), entries.data(), cap, lerp & 2);
-        };
-        if (chains(0)) return gvk_fail(GVK_ENOMEM, "gvk_train_episode_hot: out of memory");
-        for (int u = 0; u < units; u++) {
-            const int i = u / parts, q = u % parts;
-            if (u + 1 < units) {  // the chains of the next unit, from the tables as they are now; their rows land after this unit's pairs
-                memcpy(now_v.data(), tables->vertex, hv * 4), memcpy(now_c.data(), tables->context, hc * 4);
-                if (chains(u + 1)) return gvk_fail(GVK_ENOMEM, "gvk_train_episode_hot: out of memory");
-                memcpy(next_v.data(), tables->vertex, hv * 4), memcpy(next_c.data(), tables->context, hc * 4);
-                memcpy(tables->vertex, now_v.data(), hv * 4), memcpy(tables->context, now_c.data(), hc * 4);
-            }
-            const uint32_t *part = pairs + ((size_t)i * batch_size + (size_t)q * n) * 2, *negatives = all.data() + ((size_t)i * batch_size + (size_t)q * n) * k;
-            const float lr = gvo_lr(optimizer->lr, linear_schedule, (int)(first_batch_id + (uint32_t)i * batch_id_stride), (int)total_batches);
-            if (gvo_train_hot_lerp(dim, tables->vertex, tables->context, part, negatives, loss + (size_t)q * n, n, k, lr, optimizer->weight_decay,
-                                   negative_weight, hot_vertex, hot_context, none.data(), entries.data(), cap, lerp & 1))
-                return gvk_fail(GVK_ENOMEM, "gvk_train_episode_hot: out of memory");
-            if (u + 1 < units) memcpy(tables->vertex, next_v.data(), hv * 4), memcpy(tables->context, next_c.data(), hc * 4);
-        }
-        return GVK_OK;
-    }
+    const uint32_t cap = ((chain_cap > 0 ? chain_cap : 16) + k) / (k + 1) * (k + 1);
+    const uint32_t max_tasks = getenv("GVH_MAX_TASKS") ? (uint32_t)atoi(getenv("GVH_MAX_TASKS")) : (dim == 512 ? 8u : (dim == 32 || dim == 96 ? 32u : 16u));
+    std::vector<uint32_t> start(hot_vertex + hot_context + 1), entries(2 * (size_t)(k + 1) * n + 1);
+    std::vector<uint32_t> all((size_t)num_batches * batch_size * std::max(k, 1));
     for (int i = 0; i < num_batches; i++) {
         const uint32_t id = first_batch_id + (uint32_t)i * batch_id_stride;
-        const float lr = gvo_lr(optimizer->lr, linear_schedule, (int)id, (int)total_batches);
-        const uint32_t *batch = pairs + (size_t)i * batch_size * 2;
+        uint32_t *out = all.data() + (size_t)i * batch_size * k;
         if (negative->classes)
-            gvk_negative_draw_classes(nullptr, negative->classes, negative->class_count, negative->seed, id, drawn.data(), batch_size, k);
+            gvk_negative_draw_classes(nullptr, negative->classes, negative->class_count, negative->seed, id, out, batch_size, k);
         else
-            gvk_negative_draw(nullptr, negative->table, negative->count, negative->seed, id, drawn.data(), batch_size, k);
-        for (int q = 0; q < parts; q++) {
-            const uint32_t *part = batch + (size_t)q * n * 2, *negatives = drawn.data() + (size_t)q * n * k;
-            gvo_hot_lists(part, negatives, n, k, hot_vertex, hot_context, start.data(), entries.data());
-            if (gvo_train_hot_lerp(dim, tables->vertex, tables->context, part, negatives, loss + (size_t)q * n, n, k, lr,
-                                   optimizer->weight_decay, negative_weight, hot_vertex, hot_context, start.data(), entries.data(), cap, lerp))
-                return gvk_fail(GVK_ENOMEM, "gvk_train_episode_hot: out of memory");
+            gvk_negative_draw(nullptr, negative->table, negative->count, negative->seed, id, out, batch_size, k);
+    }
+    const int units = num_batches * parts;
+    const size_t hv = (size_t)hot_vertex * dim, hc = (size_t)hot_context * dim;
+    std::vector<uint32_t> none(hot_vertex + hot_context + 1, 0);
+    // with_chains / with_pairs of unit u on the tables as they are
+    auto unit = [&](int u, bool with_chains, bool with_pairs, const float *before_v, const float *before_c) {
+        const int i = u / parts, q = u % parts;
+        const uint32_t *part = pairs + ((size_t)i * batch_size + (size_t)q * n) * 2, *negatives = all.data() + ((size_t)i * batch_size + (size_t)q * n) * k;
+        const float lr = gvo_lr(optimizer->lr, linear_schedule, (int)(first_batch_id + (uint32_t)i * batch_id_stride), (int)total_batches);
+        if (with_chains) gvo_hot_lists(part, negatives, n, k, hot_vertex, hot_context, start.data(), entries.data());
+        if (with_chains && with_pairs)
+            return gvo_train_hot(dim, tables->vertex, tables->context, part, negatives, loss + (size_t)q * n, n, k, lr, optimizer->weight_decay,
+                                 negative_weight, hot_vertex, hot_context, start.data(), entries.data(), cap, max_tasks, lerp);
+        if (with_chains)
+            return gvo_hot_unit_chains(dim, tables->vertex, tables->context, lr, optimizer->weight_decay, negative_weight, hot_vertex,
+                                       hot_context, start.data(), entries.data(), cap, max_tasks, k);
+        // pairs only: the hub rows in the tables are the rows after the unit's chains; with lerp they are read on the way from
+        // (before_v, before_c)
+        return gvo_train_pairs_hot(dim, tables->vertex, tables->context, part, negatives, loss + (size_t)q * n, n, k, lr, optimizer->weight_decay,
+                                   negative_weight, hot_vertex, hot_context, lerp ? before_v : nullptr, lerp ? before_c : nullptr);
+    };
+    if (!pipelined) {
+        for (int u = 0; u < units; u++)
+            if (unit(u, true, true, nullptr, nullptr)) return gvk_fail(GVK_ENOMEM, "gvk_train_episode_hot: out of memory");
+        return GVK_OK;
+    }
+    // the product form: launch u = the pairs of unit u + the chains of unit u + 1, which start before those pairs have written
+    // anything and leave their rows in another mirror — the chains of unit u + 1 are computed from the tables as the pairs of
+    // unit u - 1 left them, the pairs of unit u read the hub rows the chains of unit u left
+    std::vector<float> before_v(hv), before_c(hc), now_v(hv), now_c(hc), next_v(hv), next_c(hc);
+    memcpy(before_v.data(), tables->vertex, hv * 4), memcpy(before_c.data(), tables->context, hc * 4);
+    if (unit(0, true, false, nullptr, nullptr)) return gvk_fail(GVK_ENOMEM, "gvk_train_episode_hot: out of memory");
+    for (int u = 0; u < units; u++) {
+        memcpy(now_v.data(), tables->vertex, hv * 4), memcpy(now_c.data(), tables->context, hc * 4);
+        if (u + 1 < units) {  // the chains of the next unit, from the tables as they are now; their rows land after this unit's pairs
+            if (unit(u + 1, true, false, nullptr, nullptr)) return gvk_fail(GVK_ENOMEM, "gvk_train_episode_hot: out of memory");
+            memcpy(next_v.data(), tables->vertex, hv * 4), memcpy(next_c.data(), tables->context, hc * 4);
+            memcpy(tables->vertex, now_v.data(), hv * 4), memcpy(tables->context, now_c.data(), hc * 4);
         }
+        if (unit(u, false, true, before_v.data(), before_c.data())) return gvk_fail(GVK_ENOMEM, "gvk_train_episode_hot: out of memory");
+        before_v.swap(now_v), before_c.swap(now_c);
+        if (u + 1 < units) memcpy(tables->vertex, next_v.data(), hv * 4), memcpy(tables->context, next_c.data(), hc * 4);
     }
     return GVK_OK;
 }

@@ -46,10 +46,7 @@ class Oracle(object):
         lib.gvo_hot_lists.argtypes = [_u32p, _u32p, C.c_int, C.c_int, C.c_uint32, C.c_uint32, _u32p, _u32p]
         lib.gvo_train_hot.restype = C.c_int
         lib.gvo_train_hot.argtypes = [C.c_int, _f32p, _f32p, _u32p, _u32p, _f32p, C.c_int, C.c_int, C.c_float, C.c_float,
-                                      C.c_float, C.c_uint32, C.c_uint32, _u32p, _u32p, C.c_uint32]
-        lib.gvo_train_hot_lerp.restype = C.c_int
-        lib.gvo_train_hot_lerp.argtypes = [C.c_int, _f32p, _f32p, _u32p, _u32p, _f32p, C.c_int, C.c_int, C.c_float, C.c_float,
-                                           C.c_float, C.c_uint32, C.c_uint32, _u32p, _u32p, C.c_uint32, C.c_int]
+                                      C.c_float, C.c_uint32, C.c_uint32, _u32p, _u32p, C.c_uint32, C.c_uint32, C.c_int]
         lib.gvo_predict.restype = None
         lib.gvo_predict.argtypes = [C.c_int, _f32p, _f32p, _u32p, _f32p, C.c_int]
         lib.gvo_alias_build.restype = C.c_int
@@ -131,34 +128,19 @@ class Oracle(object):
         return start, entries[:n].copy()
 
     def train_hot(self, vertex, context, batch, negatives, lr, wd, negative_weight, hot_vertex, hot_context, chain_start,
-                  entries, cap):
-        """One batch in the product's serialized hub-chain form (gvk_train_episode_hot(serialized=1)); in place."""
-        B = batch.shape[0]
-        k = negatives.size // B if B else 0
-        loss = np.zeros(B, np.float32)
-        entries = np.ascontiguousarray(entries, np.uint32)
-        if entries.size == 0:
-            entries = np.zeros(1, np.uint32)
-        rc = self.lib.gvo_train_hot(vertex.shape[1], vertex, context, np.ascontiguousarray(batch.reshape(-1)),
-                                    np.ascontiguousarray(negatives.reshape(-1)), loss, B, k, lr, wd, negative_weight, hot_vertex,
-                                    hot_context, np.ascontiguousarray(chain_start, np.uint32), entries, cap)
-        assert rc == 0
-        return loss
-
-    def train_hot_forms(self, vertex, context, batch, negatives, lr, wd, negative_weight, hot_vertex, hot_context, chain_start,
-                        entries, cap, simultaneous=False, lerp=False):
-        """gvo_train_hot_lerp (experiment, oracle/gv_oracle.c): gvo_train_hot with the two chain families side by side
-        (`simultaneous`) and / or the pairs reading hub rows on the chains' way (`lerp`); in place."""
+                  entries, cap, max_tasks=0, lerp=False):
+        """One unit in the product's serialized hub-chain form (gvk_train_episode_hot(serialized=1)): the chains of both
+        families from the unit's start state, then its pairs (`lerp`: hub rows read along the chains' way); in place.
+        max_tasks: tasks one workgroup of the product trains side by side (256 / lanes per pair; 0 = no limit)."""
         B = batch.shape[0]
         k = negatives.size // B if B else 0
         loss = np.zeros(max(B, 1), np.float32)
         entries = np.ascontiguousarray(entries, np.uint32)
         if entries.size == 0:
             entries = np.zeros(1, np.uint32)
-        rc = self.lib.gvo_train_hot_lerp(vertex.shape[1], vertex, context, np.ascontiguousarray(batch.reshape(-1)),
-                                         np.ascontiguousarray(negatives.reshape(-1)), loss, B, k, lr, wd, negative_weight,
-                                         hot_vertex, hot_context, np.ascontiguousarray(chain_start, np.uint32), entries, cap,
-                                         int(lerp) | 2 * int(simultaneous))
+        rc = self.lib.gvo_train_hot(vertex.shape[1], vertex, context, np.ascontiguousarray(batch.reshape(-1)),
+                                    np.ascontiguousarray(negatives.reshape(-1)), loss, B, k, lr, wd, negative_weight, hot_vertex,
+                                    hot_context, np.ascontiguousarray(chain_start, np.uint32), entries, cap, max_tasks, int(lerp))
         assert rc == 0
         return loss[:B]
 

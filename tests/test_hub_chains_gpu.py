@@ -1,9 +1,10 @@
 """-m gpu: hub rows trained by chains (gvk_hot_build / gvk_train_episode_hot, include/gvk.h) against the oracle's restatement
 (oracle/gv_oracle.c gvo_hot_lists / gvo_train_hot).  The reference has no counterpart — its kernel trains every sample the
-same way (gpu/graph.cuh:36-95) — so what is pinned here is (1) that the work lists hold exactly the updates the batch has for
-every hub row, (2) that the three-launch form computes what the oracle computes from the same lists, and (3) that the
-pipelined product form stays with it; what the chains are FOR — the reference's learning quality on hub-heavy shapes — is
-pinned end to end in tests/test_solver_gpu.py."""
+same way (gpu/graph.cuh:36-95) — so what is pinned here is (1) that the work lists hold exactly the updates the unit has for
+every hub row, (2) that the serialized form (per unit: chains, then pairs) computes what the oracle computes from the same
+lists — chains of both families from the unit's start state, long chains as tasks composed in order, pairs reading hub rows as
+the chains left them or along their way (lerp) —, and (3) that the pipelined product form stays with it; what the chains are
+FOR — the reference's learning quality on hub-heavy shapes — is pinned end to end in tests/test_solver_gpu.py."""
 import numpy as np
 import pytest
 import torch
@@ -13,11 +14,12 @@ from graphvite_amd import kernels as K
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 SEED, FIRST_ID, TOTAL = 5, 7, 100
+LANES = {32: 8, 64: 16, 96: 8, 128: 16, 256: 16, 512: 32}  # lanes per pair = per chain (default_lanes, gvk_kernels.hip)
 
 
 def layout(batch_size, k, chains, num_batch, cap, parts=1):
     """Offsets of gvk_hot_plan's workspace (hot_layout, graphvite_amd/csrc/gvk_kernels.hip): one list per part of a batch."""
-    cap = (cap or 256)
+    cap = (cap or 16)
     cap = (cap + k) // (k + 1) * (k + 1)
     num_batch, batch_size = num_batch * parts, batch_size // parts
     entry_capacity = 2 * (k + 1) * batch_size
@@ -45,100 +47,98 @@ def negative_table(w, by_class):
     return K.packed_to_device(K.alias_build(w)[2], DEV)
 
 
+def clean_rows(pool, allneg, N, kv, kc):
+    """Rows the pair launch trains without a conflict (plus every hub row): samples that share a NON-hub row with another
+    sample are Hogwild inside a launch and are left out of elementwise comparisons."""
+    ctx = np.concatenate([pool[:, 0][pool[:, 0] >= kc], allneg[allneg >= kc]])
+    ids, counts = np.unique(ctx, return_counts=True)
+    dirty_ctx = np.zeros(N, bool)
+    dirty_ctx[ids[counts > 1]] = True
+    hid, hcount = np.unique(pool[:, 1][pool[:, 1] >= kv], return_counts=True)
+    dirty_head = np.zeros(N, bool)
+    dirty_head[hid[hcount > 1]] = True
+    bad = dirty_ctx[pool[:, 0]] | dirty_head[pool[:, 1]] | dirty_ctx[allneg].any(1)
+    keep_v, keep_c = np.ones(N, bool), np.ones(N, bool)
+    keep_v[pool[bad, 1]] = False
+    keep_c[pool[bad, 0]] = False
+    keep_c[allneg[bad].reshape(-1)] = False
+    keep_v[:kv] = True
+    keep_c[:kc] = True
+    return keep_v, keep_c
+
+
 @pytest.mark.parametrize("by_class", [False, True])
-@pytest.mark.parametrize("dim,k,cap", [(128, 1, 0), (128, 1, 16), (128, 3, 10), (32, 1, 0), (64, 1, 8), (96, 2, 12), (256, 1, 0), (512, 1, 32)])
+@pytest.mark.parametrize("dim,k,cap", [(128, 1, 0), (128, 1, 64), (128, 3, 10), (32, 1, 0), (64, 1, 8), (96, 2, 12), (256, 1, 0), (512, 1, 32)])
 def test_chains_match_the_oracle(hip, oracle, dim, k, cap, by_class):
     if by_class and (dim, k, cap) not in ((128, 1, 0), (128, 3, 10)):
         pytest.skip("the class table is exercised at dim 128")
     rng = np.random.default_rng(dim * 10 + k)
     # one batch: from the second batch on the chains would read rows that the first batch's pair launch trained Hogwild
     N, B, batches, kv, kc = 1 << 15, 1500, 1, 24, 40
-    hip.set_tuning(8, cap)  # GVK_TUNE_CHAIN_CAP
-    try:
-        v = (rng.uniform(-0.5, 0.5, (N, dim)) * 0.05).astype(np.float32)
-        c = (rng.uniform(-0.5, 0.5, (N, dim)) * 0.05).astype(np.float32)
-        pool, w = hub_case(rng, N, B, batches, kv, kc)
-        table = negative_table(w, by_class)
-        opt = K.OptimizerSpec("SGD", 0.025, 0.005)
-        dpool = torch.from_numpy(pool.view(np.int32)).to(DEV)
-        ws = torch.zeros(hip.hot_plan(B, k, kv, kc, batches), dtype=torch.uint8, device=DEV)
-        hip.hot_build(ws, dpool, B, batches, k, table, SEED, FIRST_ID, kv, kc)
-        torch.cuda.synchronize()
-        chains = kv + kc
-        cap_entries, entry_capacity, off = layout(B, k, chains, batches, cap)
-        raw = ws.cpu().numpy()
-        starts = raw[:batches * (chains + 1) * 4].view(np.uint32).reshape(batches, chains + 1)
-        entries = raw[off:off + batches * entry_capacity * 4].view(np.uint32).reshape(batches, entry_capacity)
-        negs = torch.zeros(batches, B * k, dtype=torch.int32, device=DEV)
+    v = (rng.uniform(-0.5, 0.5, (N, dim)) * 0.05).astype(np.float32)
+    c = (rng.uniform(-0.5, 0.5, (N, dim)) * 0.05).astype(np.float32)
+    pool, w = hub_case(rng, N, B, batches, kv, kc)
+    table = negative_table(w, by_class)
+    opt = K.OptimizerSpec("SGD", 0.025, 0.005)
+    dpool = torch.from_numpy(pool.view(np.int32)).to(DEV)
+    ws = torch.zeros(hip.hot_plan(dim, B, k, kv, kc, batches, chain_cap=cap), dtype=torch.uint8, device=DEV)
+    hip.hot_build(dim, ws, dpool, B, batches, k, table, SEED, FIRST_ID, kv, kc, chain_cap=cap)
+    torch.cuda.synchronize()
+    chains = kv + kc
+    cap_entries, entry_capacity, off = layout(B, k, chains, batches, cap)
+    raw = ws.cpu().numpy()
+    starts = raw[:batches * (chains + 1) * 4].view(np.uint32).reshape(batches, chains + 1)
+    entries = raw[off:off + batches * entry_capacity * 4].view(np.uint32).reshape(batches, entry_capacity)
+    negs = torch.zeros(B * k, dtype=torch.int32, device=DEV)
+    hip.negative_draw(table, SEED, FIRST_ID, negs, B, k)
+    nb = negs.cpu().numpy().view(np.uint32).reshape(B, k)
+    # (1) the work lists: the oracle's, chain by chain, as multisets (the order inside a chain is the order the atomics retired in)
+    st, en = oracle.hot_lists(pool, nb, kv, kc)
+    assert (st == starts[0]).all()
+    for ch in range(chains):
+        assert (np.sort(en[st[ch]:st[ch + 1]]) == np.sort(entries[0, st[ch]:st[ch + 1]])).all(), ch
+    longest = int(np.diff(st.astype(np.int64)).max())
+    assert longest > cap_entries  # the hub rows of this case have long chains: tasks side by side, composed
+    keep_v, keep_c = clean_rows(pool, nb, N, kv, kc)
+    lr = oracle.lr(0.025, True, FIRST_ID, TOTAL)
+    hub = {}
+    for lerp in (False, True):
+        # (2) chains, then pairs = the oracle on the same lists.  fp32 tolerance: a chain is dozens of dependent steps, each
+        # within 1e-7 of the oracle's (summation order of the dot product, expf / exp2f of the device library)
         ov, oc = v.copy(), c.copy()
-        longest = 0
-        for b in range(batches):
-            hip.negative_draw(table, SEED, FIRST_ID + b, negs[b], B, k)
-            nb = negs[b].cpu().numpy().view(np.uint32).reshape(B, k)
-            pb = pool[b * B:(b + 1) * B]
-            # (1) the work lists: the oracle's, chain by chain, as multisets (the order inside a chain is the order the atomics retired in)
-            st, en = oracle.hot_lists(pb, nb, kv, kc)
-            assert (st == starts[b]).all()
-            for ch in range(chains):
-                assert (np.sort(en[st[ch]:st[ch + 1]]) == np.sort(entries[b, st[ch]:st[ch + 1]])).all(), ch
-            longest = max(longest, int(np.diff(st.astype(np.int64)).max()))
-            oracle.train_hot(ov, oc, pb, nb, oracle.lr(0.025, True, FIRST_ID + b, TOTAL), 0.005, 5.0, kv, kc, starts[b],
-                             entries[b, :st[-1]], cap_entries)
-        assert longest > cap_entries or cap == 0  # the small caps cut chains into parts
-        out = {}
-        for name, serialized in (("three launches", True), ("pipelined", False)):
-            tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
-            loss = torch.zeros(B, device=DEV)
-            hip.train_episode_hot(tv, tc, dpool, loss, opt, k, 5.0, table, SEED, FIRST_ID, TOTAL, batches, B, ws, kv, kc,
-                                  serialized=serialized)
-            torch.cuda.synchronize()
-            out[name] = (tv.cpu().numpy(), tc.cpu().numpy())
-            assert np.isfinite(out[name][0]).all() and np.isfinite(out[name][1]).all()
-        # (2) three launches per batch = the oracle on the same lists.  Rows of samples that share a NON-hub row with another
-        # sample are Hogwild in the pair launch and are left out; hub rows all count.
-        allneg = negs.cpu().numpy().view(np.uint32).reshape(batches * B, k)
-        ctx = np.concatenate([pool[:, 0][pool[:, 0] >= kc], allneg[allneg >= kc]])
-        ids, counts = np.unique(ctx, return_counts=True)
-        dirty_ctx = np.zeros(N, bool)
-        dirty_ctx[ids[counts > 1]] = True
-        hid, hcount = np.unique(pool[:, 1][pool[:, 1] >= kv], return_counts=True)
-        dirty_head = np.zeros(N, bool)
-        dirty_head[hid[hcount > 1]] = True
-        bad = dirty_ctx[pool[:, 0]] | dirty_head[pool[:, 1]] | dirty_ctx[allneg].any(1)
-        keep_v, keep_c = np.ones(N, bool), np.ones(N, bool)
-        keep_v[pool[bad, 1]] = False
-        keep_c[pool[bad, 0]] = False
-        keep_c[allneg[bad].reshape(-1)] = False
-        keep_v[:kv] = True
-        keep_c[:kc] = True
-        sv, sc = out["three launches"]
-        # fp32 tolerance: a chain is hundreds of dependent steps, each within 1e-7 of the oracle's (summation order of the dot
-        # product, expf / powf of the device library)
-        for got, want, keep in ((sv, ov, keep_v), (sc, oc, keep_c)):
-            np.testing.assert_allclose(got[keep], want[keep], rtol=1e-4, atol=1e-6)
-        moved_v, moved_c = np.linalg.norm(sv[:kv] - v[:kv]), np.linalg.norm(sc[:kc] - c[:kc])
-        assert moved_v > 0 and moved_c > 0
-        # (3) the product form (head-row and context-row chains in one launch, the pairs in the next): hub rows end where the
-        # three-launch form leaves them up to what the chains of the other table changed meanwhile (here 4 in 10 partners of a
-        # hub row are hub rows themselves: a coarse bound)
-        fv, fc = out["pipelined"]
-        assert np.linalg.norm(fv[:kv] - sv[:kv]) < moved_v and np.linalg.norm(fc[:kc] - sc[:kc]) < moved_c
-        # ... and over several batches (launch i: the pairs of batch i and the chains of batch i + 1)
-        pool3, _ = hub_case(rng, N, B, 3, kv, kc)
-        dpool3 = torch.from_numpy(pool3.view(np.int32)).to(DEV)
-        ws3 = torch.zeros(hip.hot_plan(B, k, kv, kc, 3), dtype=torch.uint8, device=DEV)
-        hip.hot_build(ws3, dpool3, B, 3, k, table, SEED, FIRST_ID, kv, kc)
-        ends = []
+        oracle.train_hot(ov, oc, pool, nb, lr, 0.005, 5.0, kv, kc, starts[0], entries[0, :st[-1]], cap_entries,
+                         max_tasks=256 // LANES[dim], lerp=lerp)
         for serialized in (True, False):
             tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
             loss = torch.zeros(B, device=DEV)
-            hip.train_episode_hot(tv, tc, dpool3, loss, opt, k, 5.0, table, SEED, FIRST_ID, TOTAL, 3, B, ws3, kv, kc, serialized=serialized)
+            hip.train_episode_hot(tv, tc, dpool, loss, opt, k, 5.0, table, SEED, FIRST_ID, TOTAL, batches, B, ws, kv, kc,
+                                  serialized=serialized, chain_cap=cap, lerp=lerp)
             torch.cuda.synchronize()
-            ends.append((tv.cpu().numpy()[:kv], tc.cpu().numpy()[:kc]))
-        for (a, b), start in zip(zip(*ends), (v[:kv], c[:kc])):
-            assert np.isfinite(b).all() and np.linalg.norm(a - b) < np.linalg.norm(a - start)
-    finally:
-        hip.set_tuning(8, 0)
+            sv, sc = tv.cpu().numpy(), tc.cpu().numpy()
+            for got, want, keep in ((sv, ov, keep_v), (sc, oc, keep_c)):
+                np.testing.assert_allclose(got[keep], want[keep], rtol=1e-4, atol=1e-6)
+            # a single unit: the pipelined form is the same two launches; the chains are deterministic given the lists
+            if (lerp, "hub") in hub:
+                assert (hub[lerp, "hub"][0] == sv[:kv]).all() and (hub[lerp, "hub"][1] == sc[:kc]).all()
+            hub[lerp, "hub"] = (sv[:kv].copy(), sc[:kc].copy())
+        assert np.linalg.norm(sv[:kv] - v[:kv]) > 0 and np.linalg.norm(sc[:kc] - c[:kc]) > 0
+    assert (hub[False, "hub"][0] == hub[True, "hub"][0]).all()  # lerp changes what the pairs read, not the chains
+    # (3) several batches, the product form (launch u: the pairs of unit u and the chains of unit u + 1, which read the other
+    # rows before those pairs have moved them): hub rows end near where the serialized form leaves them
+    pool3, _ = hub_case(rng, N, B, 3, kv, kc)
+    dpool3 = torch.from_numpy(pool3.view(np.int32)).to(DEV)
+    ws3 = torch.zeros(hip.hot_plan(dim, B, k, kv, kc, 3, chain_cap=cap), dtype=torch.uint8, device=DEV)
+    hip.hot_build(dim, ws3, dpool3, B, 3, k, table, SEED, FIRST_ID, kv, kc, chain_cap=cap)
+    ends = []
+    for serialized in (True, False):
+        tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
+        loss = torch.zeros(B, device=DEV)
+        hip.train_episode_hot(tv, tc, dpool3, loss, opt, k, 5.0, table, SEED, FIRST_ID, TOTAL, 3, B, ws3, kv, kc,
+                              serialized=serialized, chain_cap=cap)
+        torch.cuda.synchronize()
+        ends.append((tv.cpu().numpy()[:kv], tc.cpu().numpy()[:kc]))
+    for (a, b), start in zip(zip(*ends), (v[:kv], c[:kc])):
+        assert np.isfinite(b).all() and np.linalg.norm(a - b) < 0.5 * np.linalg.norm(a - start)
 
 
 def test_hub_rows_keep_their_updates(hip, oracle):
@@ -167,8 +167,8 @@ def test_hub_rows_keep_their_updates(hip, oracle):
         tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
         loss = torch.zeros(B, device=DEV)
         if hub:
-            ws = torch.zeros(hip.hot_plan(B, 1, 1, 1, 1), dtype=torch.uint8, device=DEV)
-            hip.hot_build(ws, dpool, B, 1, 1, table, SEED, FIRST_ID, 1, 1)
+            ws = torch.zeros(hip.hot_plan(dim, B, 1, 1, 1, 1), dtype=torch.uint8, device=DEV)
+            hip.hot_build(dim, ws, dpool, B, 1, 1, table, SEED, FIRST_ID, 1, 1)
             hip.train_episode_hot(tv, tc, dpool, loss, opt, 1, 5.0, table, SEED, FIRST_ID, TOTAL, 1, B, ws, 1, 1)
         else:
             hip.train_episode(tv, tc, dpool, loss, opt, 1, 5.0, table, SEED, FIRST_ID, TOTAL, 1, B)
@@ -180,8 +180,8 @@ def test_hub_rows_keep_their_updates(hip, oracle):
 
 
 def test_a_batch_trained_as_parts(hip, oracle):
-    """parts = 3: the batch's samples [0, 500), [500, 1000), [1000, 1500) one after the other, each with its own work lists
-    (negatives keep their sample's index in the batch) — the oracle's three-launch form applied part by part."""
+    """parts = 3: the batch's samples [0, 500), [500, 1000), [1000, 1500) one after the other, each a unit with its own work
+    lists (negatives keep their sample's index in the batch) — the oracle's unit form applied part by part."""
     rng = np.random.default_rng(9)
     N, B, kv, kc, dim, k, parts = 1 << 15, 1500, 24, 40, 128, 1, 3
     v = (rng.uniform(-0.5, 0.5, (N, dim)) * 0.05).astype(np.float32)
@@ -190,8 +190,8 @@ def test_a_batch_trained_as_parts(hip, oracle):
     table = negative_table(w, False)
     opt = K.OptimizerSpec("SGD", 0.025, 0.005)
     dpool = torch.from_numpy(pool.view(np.int32)).to(DEV)
-    ws = torch.zeros(hip.hot_plan(B, k, kv, kc, 1, parts), dtype=torch.uint8, device=DEV)
-    hip.hot_build(ws, dpool, B, 1, k, table, SEED, FIRST_ID, kv, kc, parts=parts)
+    ws = torch.zeros(hip.hot_plan(dim, B, k, kv, kc, 1, parts), dtype=torch.uint8, device=DEV)
+    hip.hot_build(dim, ws, dpool, B, 1, k, table, SEED, FIRST_ID, kv, kc, parts=parts)
     torch.cuda.synchronize()
     chains = kv + kc
     cap_entries, entry_capacity, off = layout(B, k, chains, 1, 0, parts)
@@ -201,31 +201,51 @@ def test_a_batch_trained_as_parts(hip, oracle):
     negs = torch.zeros(B * k, dtype=torch.int32, device=DEV)
     hip.negative_draw(table, SEED, FIRST_ID, negs, B, k)
     nb = negs.cpu().numpy().view(np.uint32).reshape(B, k)
-    ov, oc = v.copy(), c.copy()
     lr = oracle.lr(0.025, True, FIRST_ID, TOTAL)
-    for q in range(parts):
-        lo, hi = q * B // parts, (q + 1) * B // parts
-        st, en = oracle.hot_lists(pool[lo:hi], nb[lo:hi], kv, kc)
-        assert (st == starts[q]).all()
-        for ch in range(chains):
-            assert (np.sort(en[st[ch]:st[ch + 1]]) == np.sort(entries[q, st[ch]:st[ch + 1]])).all()
-        oracle.train_hot(ov, oc, pool[lo:hi], nb[lo:hi], lr, 0.005, 5.0, kv, kc, starts[q], entries[q, :st[-1]], cap_entries)
-    tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
-    loss = torch.zeros(B, device=DEV)
-    hip.train_episode_hot(tv, tc, dpool, loss, opt, k, 5.0, table, SEED, FIRST_ID, TOTAL, 1, B, ws, kv, kc, serialized=True, parts=parts)
-    torch.cuda.synchronize()
-    # hub rows: exact; other rows are trained Hogwild inside a part and may have been read by a later part's chains
-    np.testing.assert_allclose(tv.cpu().numpy()[:kv], ov[:kv], rtol=2e-3, atol=2e-5)
-    np.testing.assert_allclose(tc.cpu().numpy()[:kc], oc[:kc], rtol=2e-3, atol=2e-5)
+    for lerp in (False, True):
+        ov, oc = v.copy(), c.copy()
+        for q in range(parts):
+            lo, hi = q * B // parts, (q + 1) * B // parts
+            st, en = oracle.hot_lists(pool[lo:hi], nb[lo:hi], kv, kc)
+            assert (st == starts[q]).all()
+            for ch in range(chains):
+                assert (np.sort(en[st[ch]:st[ch + 1]]) == np.sort(entries[q, st[ch]:st[ch + 1]])).all()
+            oracle.train_hot(ov, oc, pool[lo:hi], nb[lo:hi], lr, 0.005, 5.0, kv, kc, starts[q], entries[q, :st[-1]], cap_entries,
+                             max_tasks=16, lerp=lerp)
+        tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
+        loss = torch.zeros(B, device=DEV)
+        hip.train_episode_hot(tv, tc, dpool, loss, opt, k, 5.0, table, SEED, FIRST_ID, TOTAL, 1, B, ws, kv, kc, serialized=True,
+                              parts=parts, lerp=lerp)
+        torch.cuda.synchronize()
+        # hub rows: exact; other rows are trained Hogwild inside a part and may have been read by a later part's chains
+        np.testing.assert_allclose(tv.cpu().numpy()[:kv], ov[:kv], rtol=2e-3, atol=2e-5)
+        np.testing.assert_allclose(tc.cpu().numpy()[:kc], oc[:kc], rtol=2e-3, atol=2e-5)
     # every row a hub row: the pairs have nothing to store (they only run for the last batch: its loss)
     small_v, small_c = v[:64].copy(), c[:64].copy()
     small = np.stack([rng.integers(0, 64, 600), rng.integers(0, 64, 600)], 1).astype(np.uint32)
     dsmall = torch.from_numpy(small.view(np.int32)).to(DEV)
     t2 = negative_table(np.ones(64, np.float32), False)
-    ws2 = torch.zeros(hip.hot_plan(300, 1, 64, 64, 2, 3), dtype=torch.uint8, device=DEV)
-    hip.hot_build(ws2, dsmall, 300, 2, 1, t2, SEED, FIRST_ID, 64, 64, parts=3)
-    tv, tc = torch.from_numpy(small_v).to(DEV), torch.from_numpy(small_c).to(DEV)
-    hip.train_episode_hot(tv, tc, dsmall, loss, opt, 1, 5.0, t2, SEED, FIRST_ID, TOTAL, 2, 300, ws2, 64, 64, parts=3)
-    torch.cuda.synchronize()
-    assert np.isfinite(tv.cpu().numpy()).all() and np.abs(tv.cpu().numpy() - small_v).max() > 0
+    ws2 = torch.zeros(hip.hot_plan(dim, 300, 1, 64, 64, 2, 3), dtype=torch.uint8, device=DEV)
+    hip.hot_build(dim, ws2, dsmall, 300, 2, 1, t2, SEED, FIRST_ID, 64, 64, parts=3)
+    nb2 = torch.zeros(2, 300, dtype=torch.int32, device=DEV)
+    for b in range(2):
+        hip.negative_draw(t2, SEED, FIRST_ID + b, nb2[b], 300, 1)
+    nb2 = nb2.cpu().numpy().view(np.uint32)
+    raw2 = ws2.cpu().numpy()
+    cap2, capacity2, off2 = layout(300, 1, 128, 2, 0, 3)
+    starts2 = raw2[:6 * 129 * 4].view(np.uint32).reshape(6, 129)
+    entries2 = raw2[off2:off2 + 6 * capacity2 * 4].view(np.uint32).reshape(6, capacity2)
+    ov, oc = small_v.copy(), small_c.copy()
+    for u in range(6):  # every sample between two hub rows: the whole training is the chains', deterministic given the lists
+        b, lo = u // 3, (u % 3) * 100
+        oracle.train_hot(ov, oc, small[b * 300 + lo:b * 300 + lo + 100], nb2[b, lo:lo + 100].reshape(100, 1),
+                         oracle.lr(0.025, True, FIRST_ID + b, TOTAL), 0.005, 5.0, 64, 64, starts2[u], entries2[u, :starts2[u, -1]],
+                         cap2, max_tasks=16)
+    for serialized in (True, False):  # nothing but hub rows: the pipelined form reads and writes the same mirrors
+        tv, tc = torch.from_numpy(small_v).to(DEV), torch.from_numpy(small_c).to(DEV)
+        hip.train_episode_hot(tv, tc, dsmall, loss, opt, 1, 5.0, t2, SEED, FIRST_ID, TOTAL, 2, 300, ws2, 64, 64, parts=3,
+                              serialized=serialized)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(tv.cpu().numpy(), ov, rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(tc.cpu().numpy(), oc, rtol=1e-4, atol=1e-6)
     assert np.isfinite(loss[:300].cpu().numpy()).all() and loss[:300].abs().sum() > 0

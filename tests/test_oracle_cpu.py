@@ -322,10 +322,9 @@ def test_hub_chains_keep_every_update_of_a_hub_row(oracle):
 
 def test_chain_families_side_by_side_update_a_hub_pair_from_its_old_values(oracle):
     """A sample between two hub rows belongs to two chains.  The reference updates both rows from their old values
-    (model/graph.h:47-58): with the two chain families side by side — what the product's launch does — a positive sample
-    between two hub rows is exactly the reference's step; head rows first and context rows against the NEW head rows (the
-    three-launch test form) gives the context row a step that already contains the sample's own (the second
-    ordering fact)."""
+    (model/graph.h:47-58): the chains of a unit — both families — start from the hub rows as the unit found them, so a
+    positive sample between two hub rows is exactly the reference's step (one family after the other would give the second
+    row a step that already contains the sample's own, DESIGN.md §3.1.2: the second ordering fact)."""
     rng = np.random.default_rng(11)
     N, dim = 8, 32
     v, c = init_tables(rng, N, N, dim)
@@ -337,14 +336,26 @@ def test_chain_families_side_by_side_update_a_hub_pair_from_its_old_values(oracl
     assert start.tolist() == [0, 1, 1, 1, 2] and entries.tolist() == [1 | 0x80000000, 0 | 0x80000000]
     want_v, want_c = v.copy(), c.copy()
     oracle.train(want_v, want_c, batch, negs, 0.025, 0.005, 5.0)
-    side_v, side_c = v.copy(), c.copy()
-    oracle.train_hot_forms(side_v, side_c, batch, negs, 0.025, 0.005, 5.0, 2, 2, start, entries, 256, simultaneous=True)
-    after_v, after_c = v.copy(), c.copy()
-    oracle.train_hot_forms(after_v, after_c, batch, negs, 0.025, 0.005, 5.0, 2, 2, start, entries, 256, simultaneous=False)
-    assert (side_v == want_v).all() and (side_c == want_c).all()          # side by side: the reference's step, bit for bit
-    assert (after_v == want_v).all() and not (after_c == want_c).all()    # one after the other: the context row saw the new head row
-    step = np.linalg.norm(want_c[1] - c[1])
-    assert 0 < np.linalg.norm(after_c[1] - want_c[1]) < 0.2 * step         # ... a second-order difference per sample, but every sample
-    plain_v, plain_c = v.copy(), c.copy()                                 # the same call without flags is gvo_train_hot
-    oracle.train_hot(plain_v, plain_c, batch, negs, 0.025, 0.005, 5.0, 2, 2, start, entries, 256)
-    assert (plain_v == after_v).all() and (plain_c == after_c).all()
+    for lerp in (False, True):  # one sample: the chains' way has one point
+        side_v, side_c = v.copy(), c.copy()
+        oracle.train_hot(side_v, side_c, batch, negs, 0.025, 0.005, 5.0, 2, 2, start, entries, 256, lerp=lerp)
+        assert (side_v == want_v).all() and (side_c == want_c).all()      # the reference's step, bit for bit
+
+
+def test_long_chains_are_cut_into_at_most_max_tasks(oracle):
+    """A chain of 64 entries with cap 4 is 16 tasks of 4; with max_tasks = 8 it is 8 tasks of 8 = cap 8 without a limit."""
+    rng = np.random.default_rng(12)
+    N, dim, m = 256, 32, 64
+    v, c = init_tables(rng, N, N, dim)
+    v *= 20
+    c *= 20
+    batch = np.stack([100 + np.arange(m), np.zeros(m, np.int64)], 1).astype(np.uint32)
+    negs = np.zeros((m, 0), np.uint32)
+    start, entries = oracle.hot_lists(batch, negs, 1, 0)
+    out = {}
+    for name, cap, max_tasks in (("cap 4", 4, 0), ("cap 4, 8 tasks", 4, 8), ("cap 8", 8, 0), ("cap 8, 16 tasks", 8, 16)):
+        tv, tc = v.copy(), c.copy()
+        oracle.train_hot(tv, tc, batch, negs, 0.025, 0.005, 5.0, 1, 0, start, entries, cap, max_tasks)
+        out[name] = tv[0].copy()
+    assert (out["cap 4, 8 tasks"] == out["cap 8"]).all() and (out["cap 8, 16 tasks"] == out["cap 8"]).all()
+    assert not (out["cap 4"] == out["cap 8"]).all()
