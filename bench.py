@@ -93,8 +93,11 @@ def parse(argv=None):
                    help="GraphSolver(hub_rows=...): default = the product's rule (off for LINE), 0 = every row trained pair by pair, "
                         "`auto` / N = the hub rows of each partition (auto: expected hits per batch >= 2) trained by chains "
                         "(gvk_train_episode_hot, DESIGN.md §3.1.2)")
-    p.add_argument("--no-fidelity-leg", action="store_true", help="skip auc.fidelity_reference (the same training with "
-                        "GraphSolver(fidelity='reference'))")
+    p.add_argument("--fidelity", choices=["auto", "reference", "throughput"], default="auto",
+                   help="GraphSolver(fidelity=...): auto (the product's default: hub rows by chains where chains exist), "
+                        "throughput = every row pair by pair")
+    p.add_argument("--no-fidelity-leg", action="store_true", help="skip auc.fidelity_throughput (the same training with "
+                        "GraphSolver(fidelity='throughput'))")
     p.add_argument("--hub-parts", type=int, default=0, help="GraphSolver.hub_parts: with hub rows by chains, a batch as this many parts")
     p.add_argument("--hub-lerp", type=int, default=-1, help="GraphSolver.hub_lerp: -1 the rule, 0 / 1 (the pairs read hub rows along their chains' way)")
     p.add_argument("--hub-cap", type=int, default=0, help="GraphSolver.hub_chain_cap: entries one chain task trains in sequence (0 = default)")
@@ -186,11 +189,11 @@ def cpu_baseline(args, graph):
     return out
 
 
-def train_timed(args, gv, graph, threads, partitions, device_sampling, epochs, fidelity="throughput"):
+def train_timed(args, gv, graph, threads, partitions, device_sampling, epochs, fidelity=None):
     """One GraphSolver.train() as a user calls it, timed by this process."""
     import torch
     solver = gv.solver.GraphSolver(args.dim, num_sampler_per_worker=threads, seed=args.seed, device_sampling=device_sampling,
-                                   pair_order=gv.auto if args.pair_order == "auto" else args.pair_order, fidelity=fidelity,
+                                   pair_order=gv.auto if args.pair_order == "auto" else args.pair_order, fidelity=fidelity or args.fidelity,
                                    hub_rows=None if args.hub_rows == "default" else (args.hub_rows if args.hub_rows == "auto" else int(args.hub_rows)))
     solver.hub_parts = args.hub_parts
     solver.hub_lerp = None if args.hub_lerp < 0 else bool(args.hub_lerp)
@@ -253,37 +256,38 @@ def link_prediction(args, gv, world, threads, partitions):
         return float(np.cumsum(ranked)[ranked == 0].sum()) / (int((ranked == 0).sum()) * int((ranked == 1).sum()))
     auc = auc_of(solver)
     out = {"value": auc, "epochs": args.auc_epochs, "batches": solver.batch_id, "workers": world, "partitions": solver.num_partition,
-           "device_sampling": world > 1, "hub_rows": solver.hub_rows,
-           "kernel": solver.kernels.describe_train(args.dim, "SGD", args.negatives, False, args.batch, solver.partition_rows)}
+           "device_sampling": world > 1, "hub_rows": solver.hub_rows, "hub_parts": solver.hub_parts_used, "fidelity": solver.fidelity,
+           "kernel": ("train_hot_kernel: hub rows by chains, a batch as %d parts" % solver.hub_parts_used) if solver.hub_rows else
+                     solver.kernels.describe_train(args.dim, "SGD", args.negatives, False, args.batch, solver.partition_rows)}
     golden = os.path.join(ROOT, "tests", "golden", "reference_c2.npz")
     if os.path.exists(golden) and (args.vertices, args.edges, args.seed, args.batch) == (1000000, 10000000, 1024, 100000):
         G = np.load(golden)
-        reference = G["c2_line_sequential"]
+        key = "c2_line_sequential" if solver.num_partition == 1 else "c2_line_p%d" % solver.num_partition
+        reference = G[key] if key in G else np.zeros(0)
         reference = reference[~np.isnan(reference)]
         if len(reference) and int(G["c2_args"][5]) == args.auc_epochs:
             out["reference_training_loop"] = {"mean": float(reference.mean()), "seeds": len(reference),
                                               "note": "the reference's own GraphSolver::train on this shape, sequential kernel "
-                                                      "model, one worker / one partition (tests/golden/make_c2_golden.py)"}
+                                                      "model, one worker / %d partition(s) (tests/golden/make_c2_golden.py)" % solver.num_partition}
             out["difference"] = auc - float(reference.mean())
             # the reference's kernel is itself concurrent (<<<8192, 512>>>, instance/graph.cuh:487-490): its own training loop
             # under the two chunk-synchronous models of that launch on the card it was written for
             models = {name: float(G["c2_line_" + name][0]) for name in ("lock_step", "reads_at_start") if "c2_line_" + name in G}
-            if models:
+            if models and solver.num_partition == 1:
                 out["reference_training_loop"]["concurrent_models"] = models
     solver.clear()
-    if world == 1 and partitions == 1 and args.hub_rows == "default" and not args.no_fidelity_leg:
-        # the same training with GraphSolver(fidelity="reference"): the hub rows of the graph trained by chains, a batch as about
-        # twenty parts — the product's answer to "AUC within 0.002 of the reference's loop" on this shape,
-        # and what it costs
-        faithful, wall = train_timed(args, gv, graph, threads, partitions, False, args.auc_epochs, fidelity="reference")
-        value = auc_of(faithful)
-        timing = faithful.timing
-        out["fidelity_reference"] = {"value": value, "hub_rows": faithful.hub_rows, "batches": timing["batches"],
-                                     "million_edge_samples_per_sec": timing["batches"] * args.batch / timing["episodes"] / 1e6,
-                                     "train_seconds": wall}
+    if world == 1 and partitions == 1 and args.hub_rows == "default" and args.fidelity != "throughput" and not args.no_fidelity_leg:
+        # the same training pair by pair (GraphSolver(fidelity="throughput"): no chains, every row Hogwild as in the reference's
+        # kernel): what the hub rows' lost updates cost on this shape
+        plain, wall = train_timed(args, gv, graph, threads, partitions, False, args.auc_epochs, fidelity="throughput")
+        value = auc_of(plain)
+        timing = plain.timing
+        out["fidelity_throughput"] = {"value": value, "hub_rows": plain.hub_rows, "batches": timing["batches"],
+                                      "million_edge_samples_per_sec": timing["batches"] * args.batch / timing["episodes"] / 1e6,
+                                      "train_seconds": wall}
         if "reference_training_loop" in out:
-            out["fidelity_reference"]["difference"] = value - out["reference_training_loop"]["mean"]
-        faithful.clear()
+            out["fidelity_throughput"]["difference"] = value - out["reference_training_loop"]["mean"]
+        plain.clear()
     return out
 
 
@@ -357,7 +361,7 @@ def main(argv=None):
         graph.load(synthetic.community_edges(N, E, num_community=max(N // 1000, 1), seed=args.seed))
     else:
         graph.load(synthetic.power_law_edges(N, E, seed=args.seed))
-    solver = gv.solver.GraphSolver(dim, num_sampler_per_worker=threads, seed=args.seed,
+    solver = gv.solver.GraphSolver(dim, num_sampler_per_worker=threads, seed=args.seed, fidelity=args.fidelity,
                                    pair_order=gv.auto if args.pair_order == "auto" else args.pair_order,
                                    hub_rows=None if args.hub_rows == "default" else (args.hub_rows if args.hub_rows == "auto" else int(args.hub_rows)))
     solver.hub_parts = args.hub_parts
@@ -470,7 +474,11 @@ def main(argv=None):
     visits = -(-args.steps // args.block_batches)
     collectives = after["exchanges"] - before["exchanges"]
     moments = optimizer.num_moment
-    bytes_per_launch = (8 * dim * (k + 2) * (1 + moments) + 16) * B  # moment tables are rows read + written too
+    # With hub rows trained by chains a batch is `launches` launches of train_hot_kernel, each the pairs of one part of the
+    # batch (and the chains of the next part): the roofline is stated per launch, as for the one-launch-per-batch kernels
+    launches = max(solver.hub_parts_used, 1) if solver.hub_rows else 1
+    kernel_ms /= launches
+    bytes_per_launch = (8 * dim * (k + 2) * (1 + moments) + 16) * B // launches  # moment tables are rows read + written too
     achieved = bytes_per_launch / (kernel_ms * 1e-3)
     # HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM); bench.py cannot read PMCs itself
@@ -482,8 +490,9 @@ def main(argv=None):
             break
     rows = solver.partition_rows
     kernel_name = solver.kernels.describe_train(dim, args.optimizer, k, False, B, rows)
-    if solver.hub_rows:  # gvk_train_episode_hot: the per-pair body + the chains of the next batch's hub rows in one launch
-        kernel_name = "train_hot_kernel<%d>: pairs + chains over %d hub rows per table" % (dim, solver.hub_rows)
+    if solver.hub_rows:  # gvk_train_episode_hot: the pairs of a part of a batch + the chains of the next part's hub rows in one launch
+        kernel_name = "train_hot_kernel<%d>: the pairs of %d samples (a batch as %d parts) + the chains of the next part over %d hub rows per table%s" % (
+            dim, B // launches, launches, solver.hub_rows, ", hub rows read along the chains' way (lerp)" if solver.hub_lerp_used else "")
     shard_bytes = rows * dim * 4 * (1 + moments)
     residency_note = ("both tables of a block fit the 32 MB of L2" if 2 * shard_bytes <= L2_BYTES else
                       "both tables of a block fit the 256 MB Infinity Cache: the kernel is served by the cache, not by HBM — "
@@ -520,7 +529,7 @@ def main(argv=None):
         if world > 1 else None,
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": pmc_path,
-                     "kernel": kernel_name, "kernel_ms": kernel_ms,
+                     "kernel": kernel_name, "kernel_ms": kernel_ms, "launches_per_step": launches,
                      "algorithmic_bytes_per_launch": bytes_per_launch},
         "sampler": {"value": sampled / fill_s / 1e6, "unit": "million edge-samples/sec per GPU", "threads": threads,
                     "note": "CPU edge sampler filling this GPU's block pools (+ their upload) before the timed region"},
@@ -528,7 +537,7 @@ def main(argv=None):
     }
     if probe is not None:  # how close the training kernel is to what the memory system sustains for ITS access pattern
         result["roofline"]["access_pattern"] = probe
-        probe["train_kernel_vs_probe"] = probe["kernel_ms"] / kernel_ms
+        probe["train_kernel_vs_probe"] = probe["kernel_ms"] / (kernel_ms * launches)  # per batch, both
     session.close()
     solver.clear()
     del session, solver

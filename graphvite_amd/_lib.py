@@ -90,7 +90,7 @@ class SolverMembers(C.Structure):  # gvx_solver_members
                 ("optimizer", SolverOptimizer), ("batch_id", C.c_uint64), ("num_batch", C.c_uint64),
                 ("train_seconds", C.c_double), ("rank", C.c_int), ("num_local_worker", C.c_int), ("pair_order", C.c_int),
                 ("sampler_mode", C.c_int), ("device_sampling", C.c_int), ("partition_rows", C.c_uint32),
-                ("transport", C.c_char_p), ("hub_rows", C.c_uint32)]
+                ("transport", C.c_char_p), ("hub_rows", C.c_uint32), ("hub_parts_used", C.c_int32), ("hub_lerp_used", C.c_int32)]
 
 
 class Transport(C.Structure):  # gvx_transport

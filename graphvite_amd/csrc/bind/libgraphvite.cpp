@@ -205,11 +205,11 @@ public:
 
     GraphSolverBase(int dim, const std::vector<int> &device_ids, int num_sampler_per_worker, size_t gpu_memory_limit,
                     bool device_sampling, int64_t seed, const std::string &fidelity) {
-        if (fidelity != "throughput" && fidelity != "reference")
-            throw py::value_error("fidelity must be 'throughput' or 'reference', not '" + fidelity + "'");
+        if (fidelity != "auto" && fidelity != "throughput" && fidelity != "reference")
+            throw py::value_error("fidelity must be 'auto', 'throughput' or 'reference', not '" + fidelity + "'");
         handle = gvx_solver_create(dim, device_ids.data(), (int)device_ids.size(), num_sampler_per_worker, gpu_memory_limit);
         if (!handle) raise(GVK_EINVAL, "GraphSolver");
-        check(gvx_solver_set(handle, GVX_FIDELITY, fidelity == "reference"), "GraphSolver");
+        check(gvx_solver_set(handle, GVX_FIDELITY, fidelity == "auto" ? -1 : (fidelity == "reference" ? 1 : 0)), "GraphSolver");
         check(gvx_solver_set(handle, GVX_DEVICE_SAMPLING, device_sampling), "GraphSolver");
         check(gvx_solver_set(handle, GVX_SEED, seed), "GraphSolver");
     }
@@ -319,13 +319,14 @@ void bind_solver(py::module &solver) {
         "                instead of the CPU sampler threads\n"
         "            seed (int, optional): beyond the reference — seeds the initial embeddings, the samplers and the\n"
         "                negative draws (the reference seeds them from one process-wide generator)\n"
-        "            fidelity (str, optional): beyond the reference — 'throughput' (default) or 'reference': train the hub rows\n"
-        "                of a hub-heavy graph by chains, a batch as twenty parts (the reference's sequential learning quality at a\n"
-        "                ninth of the rate; gvx.h GVX_FIDELITY)\n        ");
+        "            fidelity (str, optional): beyond the reference — 'auto' (default): the hub rows of a hub-heavy graph are\n"
+        "                trained by chains wherever chains exist (SGD; the reference's sequential learning quality);\n"
+        "                'reference': the same, an error where they do not; 'throughput': every row pair by pair\n"
+        "                (gvx.h GVX_FIDELITY)\n        ");
     cls.def(py::init<std::vector<int>, int, size_t, bool, int64_t, std::string>(), no_gil(),
             py::arg("device_ids") = std::vector<int>(), py::arg("num_sampler_per_worker") = kAuto,
             py::arg("gpu_memory_limit") = kAuto, py::arg("device_sampling") = false, py::arg("seed") = 0,
-            py::arg("fidelity") = "throughput");
+            py::arg("fidelity") = "auto");
 }
 
 }  // namespace

@@ -44,6 +44,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 int g_variant = 0;         // GVK_TUNE_VARIANT
 int g_run_cap = 0;         // GVK_TUNE_RUN_CAP (0 = the default of 20, run_cap_for)
 int g_split_hits = 2;      // GVK_TUNE_SPLIT_HITS (samples per table row one launch may hold; 0 = never split a batch)
+int g_hot_wide = 0;        // GVK_TUNE_HOT_WIDE (samples per lane group of train_hot_kernel's pair body; 0 = the default)
 int g_chain_cap = 0;       // GVK_TUNE_CHAIN_CAP (entries one chain task trains in sequence; 0 = the default of 16)
 #if defined(GVK_AB_BUILDS)  // knobs of the A/B library only (make ab -> build/ab/libgvk_ab.so)
 int g_lanes_per_pair = 0;  // GVK_TUNE_LANES_PER_PAIR
@@ -464,6 +465,109 @@ __device__ __forceinline__ void train_pair(const TrainArgs &a, const int tid) {
     if constexpr (NM >= 2) store_row<DIM, G>(a.vm2, head, lane, reinterpret_cast<float(&)[V]>(vm2));
 }
 
+// The per-pair body for few wavefronts per SIMD (train_hot_kernel is built for the registers of the chains: three
+// wavefronts per SIMD, where train_kernel runs eight): a lane group trains N samples — SGD, one negative drawn in the kernel —
+// and requests every row of all of them before it uses the first, so that the bytes in flight per SIMD, which is what the
+// memory system sees, stay what eight narrow wavefronts put there.  Sample i of lane group g of wavefront w is
+// first_sample + w (64 / G) N + i (64 / G) + g (a step of the wavefront covers adjacent samples).  Arithmetic, negative
+// draw, loss and the HOT rules (hub rows read from the mirrors and never stored) are those of train_pair; the N samples of a
+// lane group are as concurrent as the samples of different lane groups are.
+template <int DIM, int G, int N, int HOT>
+__device__ __forceinline__ void train_pairs_wide(const TrainArgs &a, const int tid) {
+    constexpr int V = DIM / G, NG = 64 / G;
+    constexpr int VB = HOT == 2 ? V : 1;
+    const int wave = tid / 64, g = (tid % 64) / G, lane = tid % G;
+    const int base = a.first_sample + wave * (NG * N);
+    if (base >= a.batch_size) return;  // whole wavefronts leave together
+    const u32x2 *records = reinterpret_cast<const u32x2 *>(a.pairs);
+
+    // round trip 1: the pairs and the alias slots of their negatives (samples past the end of the unit train nothing: they
+    // follow the last sample's loads and store nothing)
+    uint32_t head[N], tail[N];
+    Draw dr[N];
+    NegEntry en[N];
+    bool valid[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int s = base + i * NG + g;
+        valid[i] = s < a.batch_size;
+        const int at = valid[i] ? s : a.batch_size - 1;
+        dr[i] = negative_slot(a, (uint32_t)at, 0);
+        en[i] = load_entry(a, dr[i]);
+        const u32x2 pr = __builtin_nontemporal_load(records + at);
+        tail[i] = pr.x, head[i] = pr.y;
+    }
+    // round trip 2: every row
+    float v[N][V], cn[N][V], cp[N][V], v_before[N][VB], cn_before[N][VB], cp_before[N][VB];
+    uint32_t neg[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        neg[i] = resolve(a, dr[i], en[i]);
+        const bool hub_v = HOT != 0 && head[i] < a.hot_vertex, hub_p = HOT != 0 && tail[i] < a.hot_context, hub_n = HOT != 0 && neg[i] < a.hot_context;
+        load_row_at<DIM, G>(hub_v ? a.hub_now + (size_t)head[i] * DIM : a.vertex + (size_t)head[i] * DIM, lane, v[i]);
+        load_row_at<DIM, G>(hub_p ? a.hub_now + ((size_t)a.hot_vertex + tail[i]) * DIM : a.context + (size_t)tail[i] * DIM, lane, cp[i]);
+        load_row_at<DIM, G>(hub_n ? a.hub_now + ((size_t)a.hot_vertex + neg[i]) * DIM : a.context + (size_t)neg[i] * DIM, lane, cn[i]);
+        if constexpr (HOT == 2) {
+            if (hub_v) load_row_at<DIM, G>(a.hub_before + (size_t)head[i] * DIM, lane, v_before[i]);
+            if (hub_p) load_row_at<DIM, G>(a.hub_before + ((size_t)a.hot_vertex + tail[i]) * DIM, lane, cp_before[i]);
+            if (hub_n) load_row_at<DIM, G>(a.hub_before + ((size_t)a.hot_vertex + neg[i]) * DIM, lane, cn_before[i]);
+        }
+    }
+    // arithmetic: the negative target, then the positive one (gpu/graph.cuh:63-88; model/graph.h:40-58)
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int s = base + i * NG + g;
+        const bool hub_v = HOT != 0 && head[i] < a.hot_vertex, hub_p = HOT != 0 && tail[i] < a.hot_context, hub_n = HOT != 0 && neg[i] < a.hot_context;
+        if constexpr (HOT == 2) {  // hub rows where their chains were when they met the sample
+            const float at = ((float)(s - a.first_sample) + 0.5f) * a.hub_step;
+            if (hub_v) {
+#pragma unroll
+                for (int x = 0; x < V; x++) v[i][x] = v_before[i][x] + at * (v[i][x] - v_before[i][x]);
+            }
+            if (hub_p) {
+#pragma unroll
+                for (int x = 0; x < V; x++) cp[i][x] = cp_before[i][x] + at * (cp[i][x] - cp_before[i][x]);
+            }
+            if (hub_n) {
+#pragma unroll
+                for (int x = 0; x < V; x++) cn[i][x] = cn_before[i][x] + at * (cn[i][x] - cn_before[i][x]);
+            }
+        }
+        float sample_loss = 0, m1 = 0, m2 = 0;
+        {
+            float partial = 0;
+#pragma unroll
+            for (int x = 0; x < V; x++) partial += v[i][x] * cn[i][x];
+            const float prob = sigmoidf(group_sum<G>(partial));
+            sample_loss += a.neg_weight * -logf(1 - prob + kEpsilon);
+#pragma unroll
+            for (int x = 0; x < V; x++) {
+                const float vi = v[i][x], ci = cn[i][x];
+                v[i][x] -= update<GVK_SGD>(a, vi, prob * ci, a.neg_weight, m1, m2);
+                cn[i][x] -= update<GVK_SGD>(a, ci, prob * vi, a.neg_weight, m1, m2);
+            }
+            if (valid[i] && !hub_n) store_row<DIM, G>(a.context, neg[i], lane, cn[i]);
+            if (neg[i] == tail[i]) copy_row(cp[i], cn[i]);  // the sample sees its own update
+        }
+        {
+            float partial = 0;
+#pragma unroll
+            for (int x = 0; x < V; x++) partial += v[i][x] * cp[i][x];
+            const float prob = sigmoidf(group_sum<G>(partial));
+            sample_loss += -logf(prob + kEpsilon);
+#pragma unroll
+            for (int x = 0; x < V; x++) {
+                const float vi = v[i][x], ci = cp[i][x];
+                v[i][x] -= update<GVK_SGD>(a, vi, (prob - 1) * ci, 1.0f, m1, m2);
+                cp[i][x] -= update<GVK_SGD>(a, ci, (prob - 1) * vi, 1.0f, m1, m2);
+            }
+            if (valid[i] && !hub_p) store_row<DIM, G>(a.context, tail[i], lane, cp[i]);
+        }
+        if (valid[i] && lane == 0) __builtin_nontemporal_store(sample_loss / (1 + a.neg_weight), a.loss + s);
+        if (valid[i] && !hub_v) store_row<DIM, G>(a.vertex, head[i], lane, v[i]);
+    }
+}
+
 template <int DIM, int G, int OPT, int KT = 0, int DRAW = -1, int WAVES = 4>
 __global__ void __launch_bounds__(kBlock, WAVES) train_kernel(const TrainArgs a) {
     train_pair<DIM, G, OPT, KT, DRAW, 0>(a, blockIdx.x * kBlock + threadIdx.x);
@@ -679,7 +783,8 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_runs_kernel(const TrainAr
 struct HotArgs {
     const uint32_t *chain_start;  // [chains + 1] offsets of this unit into entries
     const uint32_t *entries;      // partner row | label << 31 (label 1 = positive)
-    const uint32_t *long_list;    // [0] = number of long chains (more than cap entries), then their chain ids
+    const uint32_t *long_list;    // [0] = number of long chains (more than cap entries), then from [4] on a record {chain, first entry, entries, -} each
+    const uint32_t *short_list;   // the same for the chains of 1 .. cap entries
     const float *from;            // mirror the chains read: own rows and hub partners as the unit finds them
     float *to;                    // mirror the chains store to
     uint32_t chains;              // hot_vertex + hot_context
@@ -688,13 +793,13 @@ struct HotArgs {
     int k;                        // negatives per sample: tasks of head chains are cut at whole samples
     float lr;                     // learning rate of the chains' batch (the pairs of the same launch may belong to another batch)
     float log2_decay_positive, log2_decay_negative;  // log2(1 - lr wd), log2(1 - lr negative_weight wd): decay of an entry by label
-    int long_blocks, short_blocks;  // grid: [long chains | chains of at most cap entries, kBlock / G per block | pairs]
+    int long_blocks, short_blocks, copy_blocks;  // grid: [long chains | chains of 1 .. cap entries, kBlock / G per block | rows without entries | pairs]
 };
 
 template <int DIM, int G>
 struct ChainShape {
     static constexpr int V = DIM / G;
-    static constexpr int D = V <= 8 ? 8 : (V <= 12 ? 4 : 2);  // partner rows in flight per lane group (V * D <= 64 registers)
+    static constexpr int D = V <= 4 ? 8 : (V <= 8 ? 7 : (V <= 12 ? 4 : 2));  // partner rows in flight per lane group: what 168 registers (three wavefronts per SIMD) hold without spilling
     static constexpr int NG = kBlock / G;     // lane groups of a block = most tasks of a long chain
     static_assert(D <= G, "the entry window is two fetches of G entries");
 };
@@ -771,29 +876,55 @@ __device__ __forceinline__ float group_count(const uint32_t x) {
     return group_sum<G>((float)x);
 }
 
-// Chains of at most cap entries, one lane group each: block b trains chains [b NG, (b + 1) NG).  A chain without entries
-// copies its row to the next mirror; a long chain is left to its workgroup (train_long_chains).
+// Chains of 1 .. cap entries, one lane group each: block b trains records [b NG, (b + 1) NG) of the unit's short list.
 template <int DIM, int G>
 __device__ __forceinline__ void train_short_chains(const TrainArgs &a, const HotArgs &h, const uint32_t block) {
     typedef ChainShape<DIM, G> S;
     const int lane = threadIdx.x % G;
-    uint32_t chain = block * S::NG + threadIdx.x / G;
-    const bool exists = chain < h.chains;
-    if (!exists) chain = h.chains - 1;  // whole wavefronts walk chain_steps together: a group without a chain idles on the last one
-    const uint32_t first = h.chain_start[chain], last = h.chain_start[chain + 1];
-    const bool mine = exists && last - first <= h.cap;
+    const uint32_t at = block * S::NG + threadIdx.x / G;
+    const uint32_t count = h.short_list[0] < h.chains ? h.short_list[0] : h.chains;
+    if (block * S::NG >= count) return;  // the whole block at once
+    const bool mine = at < count;
+    const u32x4 record = *reinterpret_cast<const u32x4 *>(h.short_list + 4 + 4 * (size_t)(mine ? at : count - 1));
+    const uint32_t chain = record.x, first = record.y, n = mine ? record.z : 0;
     float own[S::V];
     load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, own);
-    chain_steps<DIM, G>(a, h, chain, first, mine ? last : first, lane, own);
+    chain_steps<DIM, G>(a, h, chain, first, first + n, lane, own);
     if (mine) store_row_at<DIM, G>(h.to + (size_t)chain * DIM, lane, own);
+}
+
+// Hub rows the unit has no entry for pass from mirror to mirror unchanged: block b looks at chains [64 b, 64 b + 64), each
+// lane group at four of them (all four rows requested before the first is stored).
+template <int DIM, int G>
+__device__ __forceinline__ void copy_idle_rows(const HotArgs &h, const uint32_t block) {
+    typedef ChainShape<DIM, G> S;
+    constexpr int R = 4;
+    const int lane = threadIdx.x % G, group = threadIdx.x / G;
+    float row[R][S::V];
+    bool idle[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const uint32_t chain = (block * R + i) * S::NG + group;
+        idle[i] = chain < h.chains && h.chain_start[chain] == h.chain_start[chain + 1];
+    }
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const uint32_t chain = (block * R + i) * S::NG + group;
+        if (idle[i]) load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, row[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const uint32_t chain = (block * R + i) * S::NG + group;
+        if (idle[i]) store_row_at<DIM, G>(h.to + (size_t)chain * DIM, lane, row[i]);
+    }
 }
 
 // Long chains, one workgroup each (block b takes long chains b, b + long_blocks, ...): T <= NG tasks of consecutive
 // entries (whole samples for a head chain) trained side by side by the block's lane groups and composed.  An update is
 // own <- d own - lr w g c with d = 1 - lr w wd: weight decay is a factor that depends on the entry's label only, so the
 // decay of the entries BEFORE a task (before_), of the task itself and of the entries AFTER it (after_) are known in closed
-// form from label counts.  A task starts from the row as the earlier tasks' decay leaves it, and what it adds to the row is
-// its end state carried through the later tasks' decay:
+// form from label counts (every task counts its own positives; the counts meet in LDS).  A task starts from the row as the
+// earlier tasks' decay leaves it, and what it adds to the row is its end state carried through the later tasks' decay:
 //     row <- total row + sum over tasks (after_t end_t - total row),         total = before_ x task x after_
 // which composes the tasks' decay exactly (a hub row of the benchmark graph decays to 0.48 of itself within ONE batch —
 // summing plain deltas of 8 tasks would take it to 0.30) and leaves only the gradients' dependence on the other tasks'
@@ -803,11 +934,12 @@ __device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotA
     typedef ChainShape<DIM, G> S;
     constexpr int V = S::V, NG = S::NG;
     __shared__ float ends[NG][DIM];
+    __shared__ float positives[NG];
     const int lane = threadIdx.x % G, group = threadIdx.x / G;
     const uint32_t count = h.long_list[0] < h.long_capacity ? h.long_list[0] : h.long_capacity;
     for (uint32_t j = block; j < count; j += (uint32_t)h.long_blocks) {
-        const uint32_t chain = h.long_list[1 + j];
-        const uint32_t first = h.chain_start[chain], last = h.chain_start[chain + 1], n = last - first;
+        const u32x4 record = *reinterpret_cast<const u32x4 *>(h.long_list + 4 + 4 * (size_t)j);
+        const uint32_t chain = record.x, first = record.y, n = record.z, last = first + n;
         // NG tasks at most: a longer chain gets longer tasks (whole samples: k + 1 entries)
         uint32_t per = h.cap;
         if ((uint64_t)per * NG < n) per = ((n + NG - 1) / NG + (uint32_t)h.k) / (uint32_t)(h.k + 1) * (uint32_t)(h.k + 1);
@@ -817,15 +949,17 @@ __device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotA
         const uint32_t end = last - begin > per ? begin + per : last;
         float own[V];
         load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, own);
-        uint32_t positives_before = 0, positives_inside = 0, positives_after = 0;
-        for (uint32_t at = first; at < last; at += G) {
-            const uint32_t p = at + lane;
-            const bool positive = p < last && (h.entries[p] >> 31) != 0;
-            positives_before += positive && p < begin;
-            positives_inside += positive && p >= begin && p < end;
-            positives_after += positive && p >= end;
+        uint32_t inside = 0;
+        for (uint32_t p = begin + lane; p < end; p += G) inside += h.entries[p] >> 31;
+        const float pi = group_count<G>(inside);
+        if (lane == 0) positives[group] = pi;
+        __syncthreads();
+        float pb = 0, pa = 0;
+        for (uint32_t t = 0; t < tasks; t++) {
+            const float x = positives[t];
+            pb += t < (uint32_t)group ? x : 0.0f;
+            pa += t > (uint32_t)group ? x : 0.0f;
         }
-        const float pb = group_count<G>(positives_before), pi = group_count<G>(positives_inside), pa = group_count<G>(positives_after);
         const float before_ = exp2f(pb * h.log2_decay_positive + ((float)(begin - first) - pb) * h.log2_decay_negative);
         const float after_ = exp2f(pa * h.log2_decay_positive + ((float)(last - end) - pa) * h.log2_decay_negative);
         const float total = exp2f((pb + pi + pa) * h.log2_decay_positive + ((float)n - (pb + pi + pa)) * h.log2_decay_negative);
@@ -859,15 +993,20 @@ __device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotA
 // found it to where they left it, at the sample's place in the unit (lerp)
 // Built for three wavefronts per SIMD (170 registers): the chain loop keeps D partner rows per lane group in flight; a unit
 // of the sizes this kernel trains (a part of a batch) is resident at once at that occupancy.
-template <int DIM, int G, int KT, int HOT>
+// WIDE > 1 (SGD with one negative): the pairs as train_pairs_wide, WIDE samples per lane group.
+template <int DIM, int G, int KT, int HOT, int WIDE>
 __global__ void __launch_bounds__(kBlock, 3) train_hot_kernel(const TrainArgs a, const HotArgs h) {
-    const int chain_blocks = h.long_blocks + h.short_blocks;
+    const int chain_blocks = h.long_blocks + h.short_blocks + h.copy_blocks;
     if ((int)blockIdx.x < h.long_blocks) {
         train_long_chains<DIM, G>(a, h, blockIdx.x);
-    } else if ((int)blockIdx.x < chain_blocks) {
+    } else if ((int)blockIdx.x < h.long_blocks + h.short_blocks) {
         train_short_chains<DIM, G>(a, h, blockIdx.x - h.long_blocks);
+    } else if ((int)blockIdx.x < chain_blocks) {
+        copy_idle_rows<DIM, G>(h, blockIdx.x - h.long_blocks - h.short_blocks);
     } else {
-        train_pair<DIM, G, GVK_SGD, KT, 1, HOT>(a, (blockIdx.x - chain_blocks) * kBlock + threadIdx.x);
+        const int tid = (blockIdx.x - chain_blocks) * kBlock + threadIdx.x;
+        if constexpr (WIDE > 1) train_pairs_wide<DIM, G, WIDE, HOT>(a, tid);
+        else train_pair<DIM, G, GVK_SGD, KT, 1, HOT>(a, tid);
     }
 }
 
@@ -889,16 +1028,17 @@ __global__ void __launch_bounds__(kBlock) hub_rows_kernel(float *vertex, float *
 // that order.  Chain hot_vertex + r is context row r: the head of every sample r is the tail (label 1) or a negative
 // (label 0) of.  Negatives are drawn exactly as the training kernel draws them (same counters, same tables).  The order
 // of the samples inside a chain is the order the atomics retire in — any order is a valid sequential order.  Chains of
-// more than cap entries are listed in long_list (train_long_chains).
+// more than cap entries are listed in long_list (train_long_chains), those of 1 .. cap entries in short_list
+// (train_short_chains): records {chain, first entry, entries, -} behind the count.
 constexpr int kListThreads = 1024;
 
 __global__ void __launch_bounds__(kListThreads) hot_list_kernel(TrainArgs a, const uint32_t first_batch_id, const uint32_t stride,
                                                                 uint32_t *chain_start_all, uint32_t *entries_all, uint32_t *long_all,
-                                                                const uint32_t entry_capacity, const uint32_t long_capacity,
+                                                                uint32_t *short_all, const uint32_t entry_capacity, const uint32_t long_capacity,
                                                                 const uint32_t cap, const int parts) {
     extern __shared__ uint32_t bins[];  // [chains]
     __shared__ uint32_t wave_total[kListThreads / 64];
-    __shared__ uint32_t long_count;
+    __shared__ uint32_t long_count, short_count;
     const uint32_t chains = a.hot_vertex + a.hot_context;
     // list blockIdx.x = part (blockIdx.x % parts) of batch (blockIdx.x / parts): samples [lo, hi) of the batch
     const int B = a.batch_size, k = a.k;
@@ -906,11 +1046,12 @@ __global__ void __launch_bounds__(kListThreads) hot_list_kernel(TrainArgs a, con
     const u32x2 *records = reinterpret_cast<const u32x2 *>(a.pairs) + (size_t)batch * B;
     uint32_t *chain_start = chain_start_all + (size_t)blockIdx.x * (chains + 1);
     uint32_t *entries = entries_all + (size_t)blockIdx.x * entry_capacity;
-    uint32_t *long_list = long_all + (size_t)blockIdx.x * (1 + (size_t)long_capacity);
+    uint32_t *long_list = long_all + (size_t)blockIdx.x * 4 * (1 + (size_t)long_capacity);
+    uint32_t *short_list = short_all + (size_t)blockIdx.x * 4 * (1 + (size_t)chains);
     a.batch_id = first_batch_id + (uint32_t)batch * stride;
 
     for (uint32_t i = threadIdx.x; i < chains; i += kListThreads) bins[i] = 0;
-    if (threadIdx.x == 0) long_count = 0;
+    if (threadIdx.x == 0) long_count = 0, short_count = 0;
     __syncthreads();
     // A: how many entries every chain gets
     for (int s = lo + threadIdx.x; s < hi; s += kListThreads) {
@@ -947,14 +1088,17 @@ __global__ void __launch_bounds__(kListThreads) hot_list_kernel(TrainArgs a, con
             bins[i] = running;  // the chain's cursor
             if (count > cap) {
                 const uint32_t slot = atomicAdd(&long_count, 1u);
-                if (slot < long_capacity) long_list[1 + slot] = i;
+                if (slot < long_capacity) *reinterpret_cast<u32x4 *>(long_list + 4 + 4 * (size_t)slot) = u32x4{i, running, count, 0u};
+            } else if (count > 0) {
+                const uint32_t slot = atomicAdd(&short_count, 1u);
+                *reinterpret_cast<u32x4 *>(short_list + 4 + 4 * (size_t)slot) = u32x4{i, running, count, 0u};
             }
             running += count;
         }
         if (threadIdx.x == kListThreads - 1) chain_start[chains] = running;
     }
     __syncthreads();
-    if (threadIdx.x == 0) long_list[0] = long_count;
+    if (threadIdx.x == 0) long_list[0] = long_count, short_list[0] = short_count;
     // B: scatter
     for (int s = lo + threadIdx.x; s < hi; s += kListThreads) {
         const u32x2 pr = records[s];
@@ -1709,7 +1853,7 @@ int launch_train(hipStream_t stream, int dim, const gvk_optimizer *o, float lr, 
 // ---- hub rows: work lists + launch (train_hot_kernel) -----------------------------------------------------------------
 
 struct HotLayout {
-    size_t chain_start = 0, entries = 0, long_list = 0, mirrors = 0, mirror_bytes = 0, bytes = 0;  // offsets into the workspace
+    size_t chain_start = 0, entries = 0, long_list = 0, short_list = 0, mirrors = 0, mirror_bytes = 0, bytes = 0;  // offsets into the workspace
     uint32_t chains = 0, entry_capacity = 0, long_capacity = 0, cap = 0;
 };
 
@@ -1737,7 +1881,8 @@ HotLayout hot_layout(int dim, int batch_size, int k, uint32_t hot_vertex, uint32
     l.chain_start = 0;
     l.entries = align((size_t)num_batch * (l.chains + 1) * 4);
     l.long_list = l.entries + align((size_t)num_batch * l.entry_capacity * 4);
-    l.mirrors = l.long_list + align((size_t)num_batch * (1 + (size_t)l.long_capacity) * 4);
+    l.short_list = l.long_list + align((size_t)num_batch * (1 + (size_t)l.long_capacity) * 16);
+    l.mirrors = l.short_list + align((size_t)num_batch * (1 + (size_t)l.chains) * 16);
     l.mirror_bytes = align((size_t)l.chains * dim * 4);
     l.bytes = l.mirrors + 3 * l.mirror_bytes;
     return l;
@@ -1761,11 +1906,24 @@ void fill_negative(TrainArgs &a, const gvk_negative_source *neg) {
 
 typedef void (*HotKernel)(const TrainArgs, const HotArgs);
 
+// Samples per lane group of the pair body (train_pairs_wide; SGD with one negative): what the registers left by the chains
+// hold — three at dims up to 128 (two with lerp: six rows per sample), one (train_pair) beyond and for other k.
+int hot_wide(int dim, int k, int lerp) {
+    if (g_hot_wide > 0) return k == 1 && dim <= 128 ? std::min(g_hot_wide, lerp ? 2 : 3) : 1;
+    if (k != 1 || dim > 128) return 1;
+    return lerp ? 2 : 3;
+}
+
 HotKernel pick_hot(int dim, int k, int lerp) {
-#define GVK_HOT(D, GG)                                                                                              \
-    case D:                                                                                                         \
-        return k == 1 ? (lerp ? train_hot_kernel<D, GG, 1, 2> : train_hot_kernel<D, GG, 1, 1>)                      \
-                      : (lerp ? train_hot_kernel<D, GG, 0, 2> : train_hot_kernel<D, GG, 0, 1>);
+    const int wide = hot_wide(dim, k, lerp);
+#define GVK_HOT(D, GG)                                                                                                   \
+    case D:                                                                                                              \
+        if (k != 1) return lerp ? train_hot_kernel<D, GG, 0, 2, 1> : train_hot_kernel<D, GG, 0, 1, 1>;                   \
+        if constexpr (D <= 128) {                                                                                        \
+            if (wide == 3) return train_hot_kernel<D, GG, 1, 1, 3>;                                                      \
+            if (wide == 2) return lerp ? train_hot_kernel<D, GG, 1, 2, 2> : train_hot_kernel<D, GG, 1, 1, 2>;            \
+        }                                                                                                                \
+        return lerp ? train_hot_kernel<D, GG, 1, 2, 1> : train_hot_kernel<D, GG, 1, 1, 1>;
     switch (dim) {
         GVK_HOT(32, 8) GVK_HOT(64, 16) GVK_HOT(96, 8) GVK_HOT(128, 16) GVK_HOT(256, 16) GVK_HOT(512, 32)
     }
@@ -1815,8 +1973,8 @@ int gvk_hot_build(void *stream, int dim, void *workspace, size_t workspace_bytes
     }
     hipLaunchKernelGGL(hot_list_kernel, dim3((unsigned)(num_batch * parts)), dim3(kListThreads), lds, (hipStream_t)stream, a,
                        first_batch_id, batch_id_stride, reinterpret_cast<uint32_t *>(base + l.chain_start),
-                       reinterpret_cast<uint32_t *>(base + l.entries), reinterpret_cast<uint32_t *>(base + l.long_list), l.entry_capacity,
-                       l.long_capacity, l.cap, parts);
+                       reinterpret_cast<uint32_t *>(base + l.entries), reinterpret_cast<uint32_t *>(base + l.long_list),
+                       reinterpret_cast<uint32_t *>(base + l.short_list), l.entry_capacity, l.long_capacity, l.cap, parts);
     return check_launch("gvk_hot_build");
 }
 
@@ -1858,9 +2016,12 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     const int groups = kBlock / lanes;
     const int short_blocks = (int)((l.chains + groups - 1) / groups);
     const int long_blocks = (int)std::min<uint32_t>(l.long_capacity, (uint32_t)kLongBlocks);
+    const int copy_blocks = (int)((l.chains + 4 * groups - 1) / (4 * groups));
     // the unit of work is a PART of a batch (parts = 1: the batch): unit u = part u % parts of batch u / parts
     const int part_size = batch_size / parts, units = num_batches * parts;
-    const unsigned pair_blocks = (unsigned)(((int64_t)part_size * lanes + kBlock - 1) / kBlock);
+    const int wide = hot_wide(dim, num_negative, lerp);
+    const int per_block = kBlock / lanes * wide;  // samples a block of the pair body trains
+    const unsigned pair_blocks = (unsigned)((part_size + per_block - 1) / per_block);
     if (num_batches == 0) return GVK_OK;
     // when every row of both tables is a hub row the pairs have nothing to store: they run for the last batch only, whose
     // per-sample loss a caller may read
@@ -1878,7 +2039,8 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     auto chains_of = [&](int u) {  // the chain blocks of a launch work on unit u: from mirror u - 1 to mirror u
         h.chain_start = reinterpret_cast<const uint32_t *>(base + l.chain_start) + (size_t)u * (l.chains + 1);
         h.entries = reinterpret_cast<const uint32_t *>(base + l.entries) + (size_t)u * l.entry_capacity;
-        h.long_list = reinterpret_cast<const uint32_t *>(base + l.long_list) + (size_t)u * (1 + (size_t)l.long_capacity);
+        h.long_list = reinterpret_cast<const uint32_t *>(base + l.long_list) + (size_t)u * 4 * (1 + (size_t)l.long_capacity);
+        h.short_list = reinterpret_cast<const uint32_t *>(base + l.short_list) + (size_t)u * 4 * (1 + (size_t)l.chains);
         h.from = mirror(u - 1), h.to = mirror(u);
         h.lr = lr_of(u / parts);
         h.log2_decay_positive = (float)std::log2(1.0 - (double)h.lr * a.wd);
@@ -1898,12 +2060,13 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     auto launch = [&](bool with_chains, bool with_pairs) {
         h.long_blocks = with_chains ? long_blocks : 0;
         h.short_blocks = with_chains ? short_blocks : 0;
-        const unsigned grid = (unsigned)(h.long_blocks + h.short_blocks) + (with_pairs ? pair_blocks : 0u);
+        h.copy_blocks = with_chains ? copy_blocks : 0;
+        const unsigned grid = (unsigned)(h.long_blocks + h.short_blocks + h.copy_blocks) + (with_pairs ? pair_blocks : 0u);
         if (grid) hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, h);
     };
-    const unsigned copy_blocks = (unsigned)(((size_t)l.chains * (size_t)(dim / 4) + kBlock - 1) / kBlock);
+    const unsigned mirror_blocks = (unsigned)(((size_t)l.chains * (size_t)(dim / 4) + kBlock - 1) / kBlock);
     // the hub rows enter the mirrors: M[-1] = the tables' rows
-    hipLaunchKernelGGL(hub_rows_kernel, dim3(copy_blocks), dim3(kBlock), 0, (hipStream_t)stream, a.vertex, a.context, mirror(-1),
+    hipLaunchKernelGGL(hub_rows_kernel, dim3(mirror_blocks), dim3(kBlock), 0, (hipStream_t)stream, a.vertex, a.context, mirror(-1),
                        hot_vertex, hot_context, dim, 1);
     // A sample's updates to its rows are all computed from the rows as the sample found them (model/graph.h:47-58).  The
     // chains of a unit therefore run BEFORE its pairs: a chain reads the partner rows before the unit's pairs move them
@@ -1928,7 +2091,7 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
         }
     }
     // ... and leave them: the tables' hub rows = M[last unit]
-    hipLaunchKernelGGL(hub_rows_kernel, dim3(copy_blocks), dim3(kBlock), 0, (hipStream_t)stream, a.vertex, a.context, mirror(units - 1),
+    hipLaunchKernelGGL(hub_rows_kernel, dim3(mirror_blocks), dim3(kBlock), 0, (hipStream_t)stream, a.vertex, a.context, mirror(units - 1),
                        hot_vertex, hot_context, dim, 0);
     return check_launch("gvk_train_episode_hot");
 }
@@ -2165,6 +2328,11 @@ int gvk_set_tuning(int key, int value) {
     if (key == GVK_TUNE_CHAIN_CAP) {
         if (value < 0 || value > (1 << 20)) return fail(GVK_EINVAL, "gvk_set_tuning: chain cap must be in [0, 2^20]");
         g_chain_cap = value;
+        return GVK_OK;
+    }
+    if (key == GVK_TUNE_HOT_WIDE) {
+        if (value < 0 || value > 3) return fail(GVK_EINVAL, "gvk_set_tuning: samples per lane group must be 0 .. 3");
+        g_hot_wide = value;
         return GVK_OK;
     }
     if (key == GVK_TUNE_SPLIT_HITS) {

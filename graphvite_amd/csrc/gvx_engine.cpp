@@ -50,6 +50,7 @@ constexpr double kHubHits = 2;          // GVX_HUB_ROWS -1: a row a batch is exp
 constexpr uint64_t kMaxHubRows = 16384;  // per table (gvk_hot_build counts the chains of both tables in LDS)
 constexpr int kHubChunk = 128;          // batches whose work lists are built at once
 constexpr int kHubEntriesPerPart = 250;  // with hub rows by chains a batch is trained as so many parts that its largest hub row meets about this many of its updates per part
+constexpr int kHubMaxParts = 50;
 constexpr int kHubLerp = 0;              // GVX_HUB_LERP -1: the pairs read hub rows as their part's chains left them
 constexpr int kMinEpisodeSample = 20000000;
 constexpr int kExpectedDegree = 1600;  // graph.cuh:55
@@ -169,7 +170,7 @@ struct gvx_solver {
     size_t memory_request = 0, gpu_memory_limit = 0, gpu_memory_cost = 0;
     uint64_t seed = 0;
     int pair_order_request = 0, negative_table_request = 0;
-    int fidelity = 0;               // GVX_FIDELITY: 0 = throughput (default), 1 = the reference's learning quality on hub-heavy tables
+    int fidelity = -1;              // GVX_FIDELITY: -1 = the default rule (hub rows by chains where chains exist), 0 = throughput (no chains), 1 = chains or an error
     int hub_parts_request = 0;      // GVX_HUB_PARTS: 0 the rule (gvk_train_launches when every row is a hub row, else 1), Q > 0 given
     int64_t hub_rows_request = -2;  // GVX_HUB_ROWS: -2 the default rule, -1 by expected hits per batch, 0 off, N > 0 the first N rows
     int hub_lerp_request = -1;      // GVX_HUB_LERP: -1 the rule, 0 / 1: the pairs read hub rows as their unit's chains left them / along the chains' way
@@ -316,6 +317,7 @@ struct gvx_solver {
     int prepare_device_sampling();
     int device_fill(int set);
     int route_slices(int set);
+    int hub_parts_of(int hp, int tp) const;
     int stage(Worker &w, int step, int set, int b);
     int train_step(int step, int set, int first, int count, bool stage_next, int next_step, int next_set);
     int claim_slots(int step);
@@ -374,6 +376,9 @@ size_t gvx_solver::memory_demand(int P, int requested_episode, bool as_streamed)
     }
     const size_t pool = episode * batch_size * 8;
     demand += 3 * pool + pool;  // two pool buffers + the regrouping landing buffer + the regrouping workspace
+    // hub rows by chains: the work lists of kHubChunk batches (8 bytes per list entry, 2 (k + 1) entries per sample at most,
+    // as much again for the chains' records) and the mirrors of the hub rows
+    demand += (size_t)kHubChunk * batch_size * (num_negative + 1) * 32 + 3 * 2 * (size_t)kMaxHubRows * dim * 4;
     if (device_sampling && !as_streamed) {
         // the pools of every block a worker trains, two episodes, + its slices on their way to the owners (send + receive)
         demand += 4 * tails * P * pool;
@@ -549,7 +554,7 @@ extern "C" int gvx_solver_set(gvx_solver *s, int option, int64_t value) {
         s->seed = (uint64_t)value;
         return GVK_OK;
     }
-    if (option == GVX_FIDELITY && (value == 0 || value == 1)) {
+    if (option == GVX_FIDELITY && value >= -1 && value <= 1) {
         s->fidelity = (int)value;
         return GVK_OK;
     }
@@ -753,11 +758,29 @@ int gvx_solver::configure(const gvx_train_config &in) {
     hub_rows.assign(num_partition, 0);
     hub_top_entries.assign(num_partition, 0);
     hubs = false;
-    // the default rule (-2): where chains are pinned against the reference's training loop — the walk-ordered
-    // pools of DeepWalk / node2vec on one partition small enough that EVERY row is a hub row; everything else pair by pair
+    // the default rule (-2): every row of the walk-ordered pools of DeepWalk / node2vec on one partition of at most kMaxHubRows
+    // rows; else the rows a batch is expected to hit kHubHits times — on tables that do not live in the caches
+    // (smaller ones are regrouped and trained as runs of same-head samples, §3.1.1, pinned against the reference's loop the
+    // same way); GVX_FIDELITY 0: none, every row pair by pair (Hogwild)
     int64_t request = hub_rows_request;
-    if (request == -2) request = walk_ordered() && num_partition == 1 && part_rows <= kMaxHubRows ? (int64_t)part_rows : (fidelity ? -1 : 0);
-    if (request != 0 && optimizer.type == GVK_SGD && optimizer.schedule != 2) {
+    if (request == -2) {
+        if (fidelity == 0) request = 0;
+        else if (walk_ordered() && num_partition == 1 && part_rows <= kMaxHubRows) request = (int64_t)part_rows;
+        else request = walk_ordered() || table_bytes >= ((size_t)16 << 20) || fidelity == 1 ? -1 : 0;
+    }
+    // chains apply SGD updates (a row's update composes in closed form); the other optimizers and schedules computed by a
+    // callback per batch have none: asked for explicitly that is an error, by default it is said once
+    const bool chains_exist = optimizer.type == GVK_SGD && optimizer.schedule != 2;
+    if (request != 0 && !chains_exist) {
+        if (fidelity == 1 || hub_rows_request > -2)
+            return gvk_fail(GVK_EINVAL, "hub rows are trained by chains for SGD with a constant or linear schedule only: "
+                            "fidelity='reference' / hub_rows cannot be honoured for this optimizer (use fidelity='throughput')");
+        if (first_rank == 0)
+            log_message(1, "WARNING: this optimizer / schedule has no chains for hub rows: every row is trained pair by pair "
+                        "(Hogwild); on hub-heavy graphs the hub rows then keep a few of their updates per batch");
+        request = 0;
+    }
+    if (request != 0) {
         const float *vertex_weights = gvs_graph_vertex_weights(graph);
         for (int p = 0; p < num_partition; p++) {
             const std::vector<uint32_t> &ids = part_ids[p];
@@ -987,6 +1010,23 @@ int gvx_solver::allocate_pools() {
         HIP_TRY(hipMalloc(&w.group_workspace, std::max<size_t>(w.group_workspace_bytes, 16)));
         for (uint32_t *pools : w.block_pools)  // never train what nothing wrote
             if (pools) HIP_TRY(hipMemsetAsync(pools, 0, w.tails.size() * num_partition * (size_t)episode_size * batch_size * 8, w.compute));
+        if (hubs) {  // the chains' work lists and mirrors, sized for the largest block
+            size_t need = 0;
+            for (int hp = 0; hp < num_partition; hp++)
+                for (int tp = 0; tp < num_partition; tp++) {
+                    if (hub_rows[hp] + hub_rows[tp] == 0) continue;
+                    size_t bytes = 0;
+                    GVK_TRY(gvk_hot_plan(dim, batch_size, num_negative, hub_rows[hp], hub_rows[tp], kHubChunk, hub_parts_of(hp, tp),
+                                         hub_chain_cap_request, &bytes));
+                    need = std::max(need, bytes);
+                }
+            if (need > w.hub_workspace_bytes) {
+                hipFree(w.hub_workspace);
+                w.hub_workspace = nullptr, w.hub_workspace_bytes = 0;
+                HIP_TRY(hipMalloc(&w.hub_workspace, need));
+                w.hub_workspace_bytes = need;
+            }
+        }
     }
     return GVK_OK;
 }
@@ -1430,6 +1470,27 @@ int gvx_solver::fill(int set) { return device_sampling ? device_fill(set) : host
 // WorkerMixin::train (solver.h:1511-1522): batches [first, first + count) of one block's pool on the worker's compute
 // stream; batch ids interleave over the workers as the reference's shared atomic counter hands them out (solver.h:1520):
 // `base` is the id of the block visit's first batch on worker 0.
+// With hub rows trained by chains, the parts a batch of block (hp, tp) is trained as (GVX_HUB_PARTS; gvk.h `parts`).
+int gvx_solver::hub_parts_of(int hp, int tp) const {
+    const int B = batch_size;
+    const uint32_t kv = hubs ? hub_rows[hp] : 0, kc = hubs ? hub_rows[tp] : 0;
+    if (kv + kc == 0) return 1;
+    if (hub_parts_request > 0 && B % hub_parts_request == 0) return hub_parts_request;
+    // a small table — every row a hub row, many samples per row and batch — is trained as the parts gvk_train_launches
+    // prescribes for it (§7.8): a chain then sees its partners at most a part old
+    int parts = kv == part_rows && kc == part_rows ? gvk_train_launches(B, part_rows) : 1;
+    if (parts == 1) {
+        // so many parts that the largest hub row meets about kHubEntriesPerPart of its updates per part (DESIGN.md §3.1.2,
+        // §7.10), a divisor of the batch size, at most kHubMaxParts
+        const int want = std::min(std::max((std::max(hub_top_entries[hp], hub_top_entries[tp]) + kHubEntriesPerPart / 2) / kHubEntriesPerPart, 1), kHubMaxParts);
+        for (int q = want; q <= 2 * want && parts == 1 && want > 1; q++)
+            if (B % q == 0) parts = q;
+        for (int q = want; q >= 2 && parts == 1; q--)
+            if (B % q == 0) parts = q;
+    }
+    return parts;
+}
+
 int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int first_batch, int count) {
     Range range("Train Batch");  // solver.h:1526 (one range per block: its batches are back-to-back launches)
     const int W = num_worker, r = w.rank, B = batch_size, nm = num_moment;
@@ -1467,18 +1528,8 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int
             // hub rows by chains: the work lists of up to kHubChunk batches, then their launches, on the same stream
             // a small table — every row a hub row, many samples per row and batch — is trained as the parts gvk_train_launches
             // prescribes for it (§7.8): a chain then sees its partners at most a part old
-            int parts = kv == part_rows && kc == part_rows ? gvk_train_launches(B, part_rows) : 1;
-            int chain_cap = hub_chain_cap_request;
-            if (hub_parts_request > 0 && B % hub_parts_request == 0) parts = hub_parts_request;
-            else if (parts == 1) {
-                // so many parts that the largest hub row meets about kHubEntriesPerPart of its updates per part (DESIGN.md §3.1.2,
-                // §7.10), a divisor of the batch size, at most 50
-                const int want = std::min(std::max((std::max(hub_top_entries[hp], hub_top_entries[tp]) + kHubEntriesPerPart / 2) / kHubEntriesPerPart, 1), 50);
-                for (int q = want; q <= 4 * want && (parts == 1 && want > 1); q++)
-                    if (B % q == 0) parts = q;
-                for (int q = want; q >= 2 && parts == 1; q--)
-                    if (B % q == 0) parts = q;
-            }
+            const int parts = hub_parts_of(hp, tp);
+            const int chain_cap = hub_chain_cap_request;
             const int form = (hub_lerp_request < 0 ? kHubLerp : hub_lerp_request) ? GVK_HOT_LERP : 0;
             size_t need = 0;
             GVK_TRY(gvk_hot_plan(dim, B, num_negative, kv, kc, kHubChunk, parts, chain_cap, &need));
@@ -1653,9 +1704,12 @@ int gvx_solver::episode_loop() {
     const int W = num_worker;
     GVK_TRY(allocate_host_sets());
     const uint64_t per_episode = (uint64_t)num_step * episode_size * config.positive_reuse * W;
-    // a transport of the embedding program is driven from this thread only (its collectives must be issued in the same
-    // order on every rank); RCCL's routing has a communicator of its own and overlaps the training
-    const bool overlap_fill = !(has_transport && routed());
+    // Routed walk pools end their fill with an all-to-all (route_slices).  Every collective of a rank — the exchange's
+    // all-gathers and that all-to-all, whatever carries them (RCCL communicators, the embedding program's transport) — is
+    // issued from THIS thread, in the same order on every rank: two communicators driven from two host threads may enqueue
+    // their collectives in different orders on different ranks and deadlock.  Such a fill therefore runs here, after the
+    // episode's last step has been enqueued (the GPUs train that episode meanwhile); every other fill has a thread of its own.
+    const bool overlap_fill = !routed();
     int rc = fill(0);
     int current = 0;
     while (rc == GVK_OK && batch_id < num_batch) {
@@ -1962,6 +2016,11 @@ extern "C" int gvx_solver_get(gvx_solver *s, gvx_solver_members *out) {
     out->partition_rows = s->part_rows;
     out->transport = s->transport_name.c_str();
     out->hub_rows = s->hubs && !s->hub_rows.empty() ? *std::max_element(s->hub_rows.begin(), s->hub_rows.end()) : 0;
+    out->hub_parts = 0;
+    if (out->hub_rows)
+        for (int hp = 0; hp < s->num_partition; hp++)
+            for (int tp = 0; tp < s->num_partition; tp++) out->hub_parts = std::max(out->hub_parts, s->hub_parts_of(hp, tp));
+    out->hub_lerp = out->hub_rows ? (s->hub_lerp_request < 0 ? kHubLerp : s->hub_lerp_request) : 0;
     return GVK_OK;
 }
 

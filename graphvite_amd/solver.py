@@ -203,7 +203,7 @@ class GraphSolver(object):
 
     def __init__(self, dim, float_type=dtype.float32, index_type=dtype.uint32, device_ids=(), num_sampler_per_worker=auto,
                  gpu_memory_limit=auto, seed=0, device_sampling=False, pair_order=auto, hub_rows=None,
-                 fidelity="throughput"):
+                 fidelity=auto):
         if dim not in self.available_dims or float_type != dtype.float32 or index_type != dtype.uint32:
             raise AttributeError("Can't find an instantiation of GraphSolver with dim=%s, float_type=%s, "
                                  "index_type=%s" % (dim, float_type, index_type))
@@ -249,9 +249,9 @@ class GraphSolver(object):
         self.hub_parts = 0  # GVX_HUB_PARTS (gvx.h): 0 = the rule
         self.hub_lerp = None  # GVX_HUB_LERP (gvx.h): None = the rule, False / True
         self.hub_chain_cap = 0  # GVX_HUB_CHAIN_CAP (gvx.h): 0 = the kernels' default
-        if fidelity not in ("throughput", "reference"):
-            raise ValueError("fidelity must be 'throughput' or 'reference', not %r" % (fidelity,))
-        self.fidelity = fidelity  # GVX_FIDELITY (gvx.h)
+        if fidelity is not auto and fidelity not in ("auto", "throughput", "reference"):
+            raise ValueError("fidelity must be auto, 'throughput' or 'reference', not %r" % (fidelity,))
+        self.fidelity = "auto" if fidelity is auto else fidelity  # GVX_FIDELITY (gvx.h)
         self.negative_table = "auto"          # "rows": one alias slot per row (the reference's); "classes": by weight class
         self.node2vec_table_limit = 1 << 30   # per-edge table entries before node2vec samples by rejection
         self.graph = None
@@ -292,7 +292,7 @@ class GraphSolver(object):
                               (_lib.GVX_HUB_ROWS, int(self.hub_rows_request)), (_lib.GVX_HUB_PARTS, int(self.hub_parts)),
                               (_lib.GVX_HUB_LERP, -1 if self.hub_lerp is None else int(bool(self.hub_lerp))),
                               (_lib.GVX_HUB_CHAIN_CAP, int(self.hub_chain_cap)),
-                              (_lib.GVX_FIDELITY, int(self.fidelity == "reference"))):
+                              (_lib.GVX_FIDELITY, {"auto": -1, "throughput": 0, "reference": 1}[self.fidelity])):
             self._check(self._lib.gvx_solver_set(self._handle, option, value), "GraphSolver")
 
     def _exchange_stats(self):
@@ -316,6 +316,7 @@ class GraphSolver(object):
         self.pair_order = "grouped" if m.pair_order == 2 else "sampled"
         self.partition_rows = m.partition_rows
         self.hub_rows = m.hub_rows
+        self.hub_parts_used, self.hub_lerp_used = m.hub_parts_used, bool(m.hub_lerp_used)
         self.transport = (m.transport or b"").decode()
         self.train_seconds = m.train_seconds
         self._mode = _MODES.get(m.sampler_mode, "edge")
@@ -366,7 +367,11 @@ class GraphSolver(object):
         data = self._lib.gvx_solver_embeddings(self._handle, which, C.byref(rows))
         if not data or self.graph is None:
             return None
+        # the array's base chain ends at this ctypes buffer, which keeps the solver — the owner of the memory — alive for as long
+        # as any view of it exists (the reference's binding ties the array's lifetime to the solver the same way, bind.h:90-106).
+        # A later build() re-allocates the tables: views taken before it must not be used afterwards.
         buffer = (C.c_float * (rows.value * self.dim)).from_address(data)
+        buffer._owner = self
         return np.frombuffer(buffer, dtype=np.float32).reshape(rows.value, self.dim)
 
     @property

@@ -325,6 +325,9 @@ int gvk_probe_row_traffic(void *stream, int dim, float *vertex, float *context, 
                                      holds at most `value` samples per row of the head table: default 2 (what keeps small
                                      partitions at the reference's learning quality); 0 = always one launch
                                      per batch */
+#define GVK_TUNE_HOT_WIDE 9       /* gvk_train_episode_hot, SGD with one negative, dim <= 128: samples a lane group of the pair body
+                                     trains with all their rows in flight (train_pairs_wide): 0 = the default (3; 2 with lerp), 1 =
+                                     the per-pair body */
 #define GVK_TUNE_CHAIN_CAP 8      /* gvk_train_episode_hot: entries one chain task trains in sequence (a longer chain is cut into
                                      tasks trained side by side and composed): 0 = the default, 16 */
 /* A/B library only: */

@@ -89,6 +89,8 @@ typedef struct {
     uint32_t partition_rows;     /* S: rows of a partition's table */
     const char *transport;       /* "RCCL", "device copies", "caller-supplied transport" or "" (one worker) */
     uint32_t hub_rows;           /* rows per table the last train() trained by chains (the largest partition value; 0 = none) */
+    int32_t hub_parts;           /* ... the parts it trained a batch as (the largest block value; 0 = no hub rows) */
+    int32_t hub_lerp;            /* ... 1 = its pairs read hub rows along the chains' way (gvk.h GVK_HOT_LERP) */
 } gvx_solver_members;
 
 /* device_ids: num_device GPU ids (an id may repeat: its workers then share that GPU), or num_device == 0 for all
@@ -149,12 +151,14 @@ void gvx_solver_destroy(gvx_solver *s);
 /* GVX_HUB_PARTS: with hub rows trained by chains, a batch is trained as this many equal parts (a divisor of the batch size),
  * each with its own chains and pairs; 0 (default): gvk_train_launches() parts where every row is a hub row, one otherwise. */
 #define GVX_HUB_PARTS 7
-/* GVX_FIDELITY 0 (default): throughput — every row of a large table is trained pair by pair (Hogwild, as the reference's
- * kernel), the hub rows of a hub-heavy graph keep only some of their updates; 1: the reference's learning quality — the rows
- * a batch is expected to hit twice or more are trained by chains and a batch as so many parts that the largest hub row meets
- * about a hundred of its updates per part (twenty on the headline shape; chain tasks of 32 entries): link-prediction AUC
- * within 0.002 of the reference's sequential loop there, at about a ninth of the rate
- * (DESIGN.md §7.10).  GVX_HUB_ROWS / GVX_HUB_PARTS given explicitly take precedence. */
+/* GVX_FIDELITY -1 (default, `auto`): the reference's learning quality wherever chains exist — on tables that do not live in
+ * the caches, the rows a batch is expected to hit twice or more are trained by chains (GVX_HUB_ROWS -1) and a batch as so many
+ * parts that the largest hub row meets about 250 of its updates per part (eight on the headline shape): link-prediction AUC
+ * within 0.002 of the reference's sequential loop there; optimizers and schedules without chains (anything
+ * but SGD with a constant or linear schedule) train every row pair by pair and say so once.  1 (`reference`): the same, but a
+ * configuration without chains is an error.  0 (`throughput`): every row is trained pair by pair (Hogwild, as the reference's
+ * kernel); the hub rows of a hub-heavy graph then keep only some of their updates.  GVX_HUB_ROWS / GVX_HUB_PARTS given
+ * explicitly take precedence. */
 #define GVX_FIDELITY 8
 /* GVX_HUB_LERP -1 (default): the rule; 0 / 1: with hub rows trained by chains, a sample reads a hub row as the chains of its
  * part left it / on the straight line from where they found it to where they left it, at the sample's place in the part

@@ -132,7 +132,7 @@ def hub_row_rules():
     # several workers / partitions with hub rows: the engine's bookkeeping (work lists per block visit, per-worker workspaces,
     # partitions with different numbers of hub rows) — the tables must still be those of the plain run
     plain = None
-    for hub, parts, fidelity in ((0, 0, "throughput"), (40, 0, "throughput"), ("auto", 4, "throughput"), (None, 0, "reference")):
+    for hub, parts, fidelity in ((0, 0, "throughput"), (40, 0, "throughput"), ("auto", 4, gv.auto), (None, 0, "reference")):
         s = gv.solver.GraphSolver(32, device_ids=[0, 0], num_sampler_per_worker=1, seed=4, hub_rows=hub, fidelity=fidelity)
         s.hub_parts = parts
         s.build(g, batch_size=1000, episode_size=3, num_partition=4)
@@ -140,15 +140,27 @@ def hub_row_rules():
         assert (s.hub_rows > 0) == (hub != 0)
         plain = s.vertex_embeddings.copy() if plain is None else plain
         assert (plain == s.vertex_embeddings).all(), (hub, parts, fidelity)
-    # partitions: the default rule is for one partition; a custom schedule and moment optimizers keep the pair-by-pair path
+    # several partitions of walk-ordered pools: hub rows by expected hits
     s = gv.solver.GraphSolver(32, num_sampler_per_worker=2, seed=1)
     s.build(g, batch_size=1000, episode_size=4, num_partition=2)
     s.train(model="DeepWalk", num_epoch=1, augmentation_step=2, log_frequency=1 << 30)
-    assert s.hub_rows == 0
-    s = gv.solver.GraphSolver(32, num_sampler_per_worker=2, seed=1, hub_rows=50)
+    assert 0 < s.hub_rows < g.num_vertex // 2
+    # moment optimizers have no chains: by default every row is trained pair by pair (and the log says so), asked for
+    # explicitly — hub_rows / fidelity="reference" — it is an error
+    s = gv.solver.GraphSolver(32, num_sampler_per_worker=2, seed=1)
     s.build(g, optimizer=gv.optimizer.Adam(1e-3), batch_size=1000, episode_size=4)
-    s.train(model="LINE", num_epoch=1, log_frequency=1 << 30)
+    s.train(model="DeepWalk", num_epoch=1, augmentation_step=2, log_frequency=1 << 30)
     assert s.hub_rows == 0
+    for kw in (dict(hub_rows=50), dict(fidelity="reference")):
+        s = gv.solver.GraphSolver(32, num_sampler_per_worker=2, seed=1, **kw)
+        s.build(g, optimizer=gv.optimizer.Adam(1e-3), batch_size=1000, episode_size=4)
+        try:
+            s.train(model="LINE", num_epoch=1, log_frequency=1 << 30)
+        except ValueError as e:
+            assert "chains" in str(e)
+        else:
+            raise AssertionError("chains were promised for Adam")
+    s = gv.solver.GraphSolver(32, num_sampler_per_worker=2, seed=1, hub_rows=50)
     s.hub_parts = 7  # not a divisor of the batch size: the rule's parts stay
     s.build(g, batch_size=1000, episode_size=4)
     s.train(model="LINE", num_epoch=1, log_frequency=1 << 30)
