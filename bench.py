@@ -310,6 +310,11 @@ def module_leg(args, world, timeout=240):
     return json.loads(lines[-1])
 
 
+# True only inside tests/bench_dry_run.py (the loop's logic on the CPU over the host build of the engine; no command line
+# and no environment variable of bench.py sets it)
+DRY_RUN = False
+
+
 def main(argv=None):
     args = parse(argv)
     import torch
@@ -324,8 +329,7 @@ def main(argv=None):
     import graphvite_amd as gv
     from graphvite_amd import _lib, synthetic
     gv.init_logging(logging.ERROR)
-    host_build = bool(getattr(_lib.lib(), "gvh_is_host_build", None))  # tests/hostdev: the engine's logic on the CPU
-    cuda = not host_build
+    cuda = not DRY_RUN
     if cuda:
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)

@@ -6,8 +6,17 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# GVK_LIBRARY: measurements and tests of the A/B baselines load build/ab/libgvk_ab.so (make -C graphvite_amd/csrc ab) instead
-LIB_PATH = os.environ.get("GVK_LIBRARY") or os.path.join(_HERE, "libgvk.so")
+# GVK_LIBRARY is a TEST switch: tests/ and scripts/experiments/ load the A/B baselines (build/ab/libgvk_ab.so, make -C
+# graphvite_amd/csrc ab) or the host build of the engine over the oracle's kernels (tests/hostdev) through it.  It is honoured
+# only together with GVK_ALLOW_TEST_LIBRARY=1, which those set themselves; on its own it is an error, so that nothing can point
+# the product at an oracle-backed build by accident.
+PRODUCT_LIBRARY = os.path.join(_HERE, "libgvk.so")
+LIB_PATH = PRODUCT_LIBRARY
+if os.environ.get("GVK_LIBRARY"):
+    if os.environ.get("GVK_ALLOW_TEST_LIBRARY") != "1":
+        raise ImportError("GVK_LIBRARY=%s: another kernel library is a test switch (tests/, scripts/experiments/); it needs "
+                          "GVK_ALLOW_TEST_LIBRARY=1 as well" % os.environ["GVK_LIBRARY"])
+    LIB_PATH = os.environ["GVK_LIBRARY"]
 
 GVK_OK, GVK_EINVAL, GVK_EDIM, GVK_EHIP, GVK_ENOMEM = 0, -1, -2, -3, -4
 SGD, MOMENTUM, ADAGRAD, RMSPROP, ADAM = range(5)
@@ -119,6 +128,8 @@ def lib():
         l = C.CDLL(LIB_PATH)
     except OSError as e:
         raise NativeLibraryError("cannot load %s: %s" % (LIB_PATH, e))
+    if LIB_PATH == PRODUCT_LIBRARY and hasattr(l, "gvh_is_host_build"):
+        raise NativeLibraryError("%s is a host build of the engine (oracle kernels): not a product library" % LIB_PATH)
     vp, i32, u32, u64, f32 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_float
     P = C.POINTER
     l.gvk_train.restype = i32

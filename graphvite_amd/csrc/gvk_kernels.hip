@@ -44,8 +44,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 int g_variant = 0;         // GVK_TUNE_VARIANT
 int g_run_cap = 0;         // GVK_TUNE_RUN_CAP (0 = the default of 20, run_cap_for)
 int g_split_hits = 2;      // GVK_TUNE_SPLIT_HITS (samples per table row one launch may hold; 0 = never split a batch)
-int g_hot_wide = 0;        // GVK_TUNE_HOT_WIDE (samples per lane group of train_hot_kernel's pair body; 0 = the default)
-int g_chain_cap = 0;       // GVK_TUNE_CHAIN_CAP (entries one chain task trains in sequence; 0 = the default of 16)
+int g_hot_serialized = 0;  // GVK_TUNE_HOT_SERIALIZED (measurement: gvk_train_episode_hot launches the chains and the pairs of a unit one after the other)
+int g_chain_cap = 0;       // GVK_TUNE_CHAIN_CAP (entries one chain task trains in sequence; 0 = the default of 7)
 #if defined(GVK_AB_BUILDS)  // knobs of the A/B library only (make ab -> build/ab/libgvk_ab.so)
 int g_lanes_per_pair = 0;  // GVK_TUNE_LANES_PER_PAIR
 int g_generation = 0;      // GVK_TUNE_GENERATION (0 = one launch per batch)
@@ -465,109 +465,6 @@ __device__ __forceinline__ void train_pair(const TrainArgs &a, const int tid) {
     if constexpr (NM >= 2) store_row<DIM, G>(a.vm2, head, lane, reinterpret_cast<float(&)[V]>(vm2));
 }
 
-// The per-pair body for few wavefronts per SIMD (train_hot_kernel is built for the registers of the chains: three
-// wavefronts per SIMD, where train_kernel runs eight): a lane group trains N samples — SGD, one negative drawn in the kernel —
-// and requests every row of all of them before it uses the first, so that the bytes in flight per SIMD, which is what the
-// memory system sees, stay what eight narrow wavefronts put there.  Sample i of lane group g of wavefront w is
-// first_sample + w (64 / G) N + i (64 / G) + g (a step of the wavefront covers adjacent samples).  Arithmetic, negative
-// draw, loss and the HOT rules (hub rows read from the mirrors and never stored) are those of train_pair; the N samples of a
-// lane group are as concurrent as the samples of different lane groups are.
-template <int DIM, int G, int N, int HOT>
-__device__ __forceinline__ void train_pairs_wide(const TrainArgs &a, const int tid) {
-    constexpr int V = DIM / G, NG = 64 / G;
-    constexpr int VB = HOT == 2 ? V : 1;
-    const int wave = tid / 64, g = (tid % 64) / G, lane = tid % G;
-    const int base = a.first_sample + wave * (NG * N);
-    if (base >= a.batch_size) return;  // whole wavefronts leave together
-    const u32x2 *records = reinterpret_cast<const u32x2 *>(a.pairs);
-
-    // round trip 1: the pairs and the alias slots of their negatives (samples past the end of the unit train nothing: they
-    // follow the last sample's loads and store nothing)
-    uint32_t head[N], tail[N];
-    Draw dr[N];
-    NegEntry en[N];
-    bool valid[N];
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        const int s = base + i * NG + g;
-        valid[i] = s < a.batch_size;
-        const int at = valid[i] ? s : a.batch_size - 1;
-        dr[i] = negative_slot(a, (uint32_t)at, 0);
-        en[i] = load_entry(a, dr[i]);
-        const u32x2 pr = __builtin_nontemporal_load(records + at);
-        tail[i] = pr.x, head[i] = pr.y;
-    }
-    // round trip 2: every row
-    float v[N][V], cn[N][V], cp[N][V], v_before[N][VB], cn_before[N][VB], cp_before[N][VB];
-    uint32_t neg[N];
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        neg[i] = resolve(a, dr[i], en[i]);
-        const bool hub_v = HOT != 0 && head[i] < a.hot_vertex, hub_p = HOT != 0 && tail[i] < a.hot_context, hub_n = HOT != 0 && neg[i] < a.hot_context;
-        load_row_at<DIM, G>(hub_v ? a.hub_now + (size_t)head[i] * DIM : a.vertex + (size_t)head[i] * DIM, lane, v[i]);
-        load_row_at<DIM, G>(hub_p ? a.hub_now + ((size_t)a.hot_vertex + tail[i]) * DIM : a.context + (size_t)tail[i] * DIM, lane, cp[i]);
-        load_row_at<DIM, G>(hub_n ? a.hub_now + ((size_t)a.hot_vertex + neg[i]) * DIM : a.context + (size_t)neg[i] * DIM, lane, cn[i]);
-        if constexpr (HOT == 2) {
-            if (hub_v) load_row_at<DIM, G>(a.hub_before + (size_t)head[i] * DIM, lane, v_before[i]);
-            if (hub_p) load_row_at<DIM, G>(a.hub_before + ((size_t)a.hot_vertex + tail[i]) * DIM, lane, cp_before[i]);
-            if (hub_n) load_row_at<DIM, G>(a.hub_before + ((size_t)a.hot_vertex + neg[i]) * DIM, lane, cn_before[i]);
-        }
-    }
-    // arithmetic: the negative target, then the positive one (gpu/graph.cuh:63-88; model/graph.h:40-58)
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        const int s = base + i * NG + g;
-        const bool hub_v = HOT != 0 && head[i] < a.hot_vertex, hub_p = HOT != 0 && tail[i] < a.hot_context, hub_n = HOT != 0 && neg[i] < a.hot_context;
-        if constexpr (HOT == 2) {  // hub rows where their chains were when they met the sample
-            const float at = ((float)(s - a.first_sample) + 0.5f) * a.hub_step;
-            if (hub_v) {
-#pragma unroll
-                for (int x = 0; x < V; x++) v[i][x] = v_before[i][x] + at * (v[i][x] - v_before[i][x]);
-            }
-            if (hub_p) {
-#pragma unroll
-                for (int x = 0; x < V; x++) cp[i][x] = cp_before[i][x] + at * (cp[i][x] - cp_before[i][x]);
-            }
-            if (hub_n) {
-#pragma unroll
-                for (int x = 0; x < V; x++) cn[i][x] = cn_before[i][x] + at * (cn[i][x] - cn_before[i][x]);
-            }
-        }
-        float sample_loss = 0, m1 = 0, m2 = 0;
-        {
-            float partial = 0;
-#pragma unroll
-            for (int x = 0; x < V; x++) partial += v[i][x] * cn[i][x];
-            const float prob = sigmoidf(group_sum<G>(partial));
-            sample_loss += a.neg_weight * -logf(1 - prob + kEpsilon);
-#pragma unroll
-            for (int x = 0; x < V; x++) {
-                const float vi = v[i][x], ci = cn[i][x];
-                v[i][x] -= update<GVK_SGD>(a, vi, prob * ci, a.neg_weight, m1, m2);
-                cn[i][x] -= update<GVK_SGD>(a, ci, prob * vi, a.neg_weight, m1, m2);
-            }
-            if (valid[i] && !hub_n) store_row<DIM, G>(a.context, neg[i], lane, cn[i]);
-            if (neg[i] == tail[i]) copy_row(cp[i], cn[i]);  // the sample sees its own update
-        }
-        {
-            float partial = 0;
-#pragma unroll
-            for (int x = 0; x < V; x++) partial += v[i][x] * cp[i][x];
-            const float prob = sigmoidf(group_sum<G>(partial));
-            sample_loss += -logf(prob + kEpsilon);
-#pragma unroll
-            for (int x = 0; x < V; x++) {
-                const float vi = v[i][x], ci = cp[i][x];
-                v[i][x] -= update<GVK_SGD>(a, vi, (prob - 1) * ci, 1.0f, m1, m2);
-                cp[i][x] -= update<GVK_SGD>(a, ci, (prob - 1) * vi, 1.0f, m1, m2);
-            }
-            if (valid[i] && !hub_p) store_row<DIM, G>(a.context, tail[i], lane, cp[i]);
-        }
-        if (valid[i] && lane == 0) __builtin_nontemporal_store(sample_loss / (1 + a.neg_weight), a.loss + s);
-        if (valid[i] && !hub_v) store_row<DIM, G>(a.vertex, head[i], lane, v[i]);
-    }
-}
-
 template <int DIM, int G, int OPT, int KT = 0, int DRAW = -1, int WAVES = 4>
 __global__ void __launch_bounds__(kBlock, WAVES) train_kernel(const TrainArgs a) {
     train_pair<DIM, G, OPT, KT, DRAW, 0>(a, blockIdx.x * kBlock + threadIdx.x);
@@ -784,13 +681,12 @@ struct HotArgs {
     const uint32_t *chain_start;  // [chains + 1] offsets of this unit into entries
     const uint32_t *entries;      // partner row | label << 31 (label 1 = positive)
     const uint32_t *long_list;    // [0] = number of long chains (more than cap entries), then from [4] on a record {chain, first entry, entries, -} each
-    const uint32_t *short_list;   // the same for the chains of 1 .. cap entries
+    const uint32_t *short_list;   // [0] = number of chains of 1 .. cap entries, then from [16] on a record of 16 words each: {chain, entries, -, -, the entries themselves}
     const float *from;            // mirror the chains read: own rows and hub partners as the unit finds them
     float *to;                    // mirror the chains store to
     uint32_t chains;              // hot_vertex + hot_context
     uint32_t long_capacity;
-    uint32_t cap;                 // entries of one task
-    int k;                        // negatives per sample: tasks of head chains are cut at whole samples
+    uint32_t cap;                 // entries of one task (at most kShortEntries)
     float lr;                     // learning rate of the chains' batch (the pairs of the same launch may belong to another batch)
     float log2_decay_positive, log2_decay_negative;  // log2(1 - lr wd), log2(1 - lr negative_weight wd): decay of an entry by label
     int long_blocks, short_blocks, copy_blocks;  // grid: [long chains | chains of 1 .. cap entries, kBlock / G per block | rows without entries | pairs]
@@ -876,20 +772,60 @@ __device__ __forceinline__ float group_count(const uint32_t x) {
     return group_sum<G>((float)x);
 }
 
-// Chains of 1 .. cap entries, one lane group each: block b trains records [b NG, (b + 1) NG) of the unit's short list.
+// Chains of 1 .. cap entries (cap <= kShortEntries = 7), one lane group each: block b trains records [b NG, (b + 1) NG) of the
+// unit's short list.  A record carries the chain's entries, so a chain costs two dependent round trips: its record (asked for
+// together with the list's length), then its own row and every partner row at once; then at most seven steps.
+constexpr int kShortEntries = 7;
+
 template <int DIM, int G>
 __device__ __forceinline__ void train_short_chains(const TrainArgs &a, const HotArgs &h, const uint32_t block) {
     typedef ChainShape<DIM, G> S;
-    const int lane = threadIdx.x % G;
-    const uint32_t at = block * S::NG + threadIdx.x / G;
+    constexpr int V = S::V, N = kShortEntries;
+    constexpr int D = V <= 8 ? N : (V <= 12 ? 4 : 3);  // partner rows in flight: all of them where the registers hold them
+    constexpr int LW = G < 16 ? G : 16;                // lanes that hold the record's sixteen words
+    const int lane = threadIdx.x % G, group = threadIdx.x / G;
+    const uint32_t at = block * S::NG + group;
+    // the record's sixteen words across the lanes of the group; the list's length arrives with them
+    const uint32_t *record = h.short_list + 16 + 16 * (size_t)(at < h.chains ? at : h.chains - 1);
+    const uint32_t word0 = record[lane % LW], word1 = LW < 16 ? record[8 + lane % LW] : 0;
     const uint32_t count = h.short_list[0] < h.chains ? h.short_list[0] : h.chains;
     if (block * S::NG >= count) return;  // the whole block at once
+    auto word = [&](const int i) __attribute__((always_inline)) -> uint32_t {
+        return (uint32_t)(i < LW ? __shfl((int)word0, i, G) : __shfl((int)word1, i - LW, G));
+    };
     const bool mine = at < count;
-    const u32x4 record = *reinterpret_cast<const u32x4 *>(h.short_list + 4 + 4 * (size_t)(mine ? at : count - 1));
-    const uint32_t chain = record.x, first = record.y, n = mine ? record.z : 0;
-    float own[S::V];
-    load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, own);
-    chain_steps<DIM, G>(a, h, chain, first, first + n, lane, own);
+    const uint32_t chain = mine ? word(0) : 0, n = mine ? word(1) : 0;
+    const bool is_vertex = chain < a.hot_vertex;
+    const float *partner_table = is_vertex ? a.context : a.vertex;
+    const uint32_t partner_hot = is_vertex ? a.hot_context : a.hot_vertex;
+    const float *partner_mirror = h.from + (is_vertex ? (size_t)a.hot_vertex * DIM : (size_t)0);
+    const float *idle = h.from + (size_t)chain * DIM;
+    float own[V], ring[D][V];
+    load_row_at<DIM, G>(idle, lane, own);
+    uint32_t labels = 0;
+    auto request = [&](const int i) __attribute__((always_inline)) {  // the row of entry i into its slot of the ring
+        const uint32_t e = word(4 + i);
+        const uint32_t id = e & 0x7fffffffu;
+        const float *row = id < partner_hot ? partner_mirror + (size_t)id * DIM : partner_table + (size_t)id * DIM;
+        load_row_at<DIM, G>((uint32_t)i < n ? row : idle, lane, ring[i % D]);
+        labels |= (e >> 31) << i;
+    };
+#pragma unroll
+    for (int i = 0; i < D; i++) request(i);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const bool positive = (labels >> i & 1u) != 0;
+        const float(&c)[V] = ring[i % D];
+        float partial = 0;
+#pragma unroll
+        for (int x = 0; x < V; x++) partial += own[x] * c[x];
+        const float prob = sigmoidf(group_sum<G>(partial));
+        const float gradient = positive ? prob - 1 : prob;
+        const float weight = (uint32_t)i < n ? (positive ? 1.0f : a.neg_weight) : 0.0f;
+#pragma unroll
+        for (int x = 0; x < V; x++) own[x] -= h.lr * weight * (gradient * c[x] + a.wd * own[x]);  // optimizer.h:161-164
+        if (i + D < N) request(i + D);
+    }
     if (mine) store_row_at<DIM, G>(h.to + (size_t)chain * DIM, lane, own);
 }
 
@@ -936,13 +872,15 @@ __device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotA
     __shared__ float ends[NG][DIM];
     __shared__ float positives[NG];
     const int lane = threadIdx.x % G, group = threadIdx.x / G;
+    // the block's first record is asked for together with the list's length (one round trip)
+    u32x4 record = *reinterpret_cast<const u32x4 *>(h.long_list + 4 + 4 * (size_t)(block < h.long_capacity ? block : 0));
     const uint32_t count = h.long_list[0] < h.long_capacity ? h.long_list[0] : h.long_capacity;
     for (uint32_t j = block; j < count; j += (uint32_t)h.long_blocks) {
-        const u32x4 record = *reinterpret_cast<const u32x4 *>(h.long_list + 4 + 4 * (size_t)j);
+        if (j != block) record = *reinterpret_cast<const u32x4 *>(h.long_list + 4 + 4 * (size_t)j);
         const uint32_t chain = record.x, first = record.y, n = record.z, last = first + n;
-        // NG tasks at most: a longer chain gets longer tasks (whole samples: k + 1 entries)
+        // NG tasks at most: a longer chain gets longer tasks
         uint32_t per = h.cap;
-        if ((uint64_t)per * NG < n) per = ((n + NG - 1) / NG + (uint32_t)h.k) / (uint32_t)(h.k + 1) * (uint32_t)(h.k + 1);
+        if ((uint64_t)per * NG < n) per = (n + NG - 1) / NG;
         const uint32_t tasks = (n + per - 1) / per;
         const bool mine = (uint32_t)group < tasks;
         const uint32_t begin = mine ? first + (uint32_t)group * per : last;
@@ -993,8 +931,7 @@ __device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotA
 // found it to where they left it, at the sample's place in the unit (lerp)
 // Built for three wavefronts per SIMD (170 registers): the chain loop keeps D partner rows per lane group in flight; a unit
 // of the sizes this kernel trains (a part of a batch) is resident at once at that occupancy.
-// WIDE > 1 (SGD with one negative): the pairs as train_pairs_wide, WIDE samples per lane group.
-template <int DIM, int G, int KT, int HOT, int WIDE>
+template <int DIM, int G, int KT, int HOT>
 __global__ void __launch_bounds__(kBlock, 3) train_hot_kernel(const TrainArgs a, const HotArgs h) {
     const int chain_blocks = h.long_blocks + h.short_blocks + h.copy_blocks;
     if ((int)blockIdx.x < h.long_blocks) {
@@ -1004,9 +941,7 @@ __global__ void __launch_bounds__(kBlock, 3) train_hot_kernel(const TrainArgs a,
     } else if ((int)blockIdx.x < chain_blocks) {
         copy_idle_rows<DIM, G>(h, blockIdx.x - h.long_blocks - h.short_blocks);
     } else {
-        const int tid = (blockIdx.x - chain_blocks) * kBlock + threadIdx.x;
-        if constexpr (WIDE > 1) train_pairs_wide<DIM, G, WIDE, HOT>(a, tid);
-        else train_pair<DIM, G, GVK_SGD, KT, 1, HOT>(a, tid);
+        train_pair<DIM, G, GVK_SGD, KT, 1, HOT>(a, (blockIdx.x - chain_blocks) * kBlock + threadIdx.x);
     }
 }
 
@@ -1028,8 +963,9 @@ __global__ void __launch_bounds__(kBlock) hub_rows_kernel(float *vertex, float *
 // that order.  Chain hot_vertex + r is context row r: the head of every sample r is the tail (label 1) or a negative
 // (label 0) of.  Negatives are drawn exactly as the training kernel draws them (same counters, same tables).  The order
 // of the samples inside a chain is the order the atomics retire in — any order is a valid sequential order.  Chains of
-// more than cap entries are listed in long_list (train_long_chains), those of 1 .. cap entries in short_list
-// (train_short_chains): records {chain, first entry, entries, -} behind the count.
+// more than cap entries are listed in long_list (train_long_chains: records {chain, first entry, entries, -} from word 4 on),
+// those of 1 .. cap entries in short_list (train_short_chains: records of 16 words from word 16 on — {chain, entries, first
+// entry, -} and, from word 4, the entries themselves).
 constexpr int kListThreads = 1024;
 
 __global__ void __launch_bounds__(kListThreads) hot_list_kernel(TrainArgs a, const uint32_t first_batch_id, const uint32_t stride,
@@ -1047,7 +983,7 @@ __global__ void __launch_bounds__(kListThreads) hot_list_kernel(TrainArgs a, con
     uint32_t *chain_start = chain_start_all + (size_t)blockIdx.x * (chains + 1);
     uint32_t *entries = entries_all + (size_t)blockIdx.x * entry_capacity;
     uint32_t *long_list = long_all + (size_t)blockIdx.x * 4 * (1 + (size_t)long_capacity);
-    uint32_t *short_list = short_all + (size_t)blockIdx.x * 4 * (1 + (size_t)chains);
+    uint32_t *short_list = short_all + (size_t)blockIdx.x * 16 * (1 + (size_t)chains);
     a.batch_id = first_batch_id + (uint32_t)batch * stride;
 
     for (uint32_t i = threadIdx.x; i < chains; i += kListThreads) bins[i] = 0;
@@ -1091,7 +1027,7 @@ __global__ void __launch_bounds__(kListThreads) hot_list_kernel(TrainArgs a, con
                 if (slot < long_capacity) *reinterpret_cast<u32x4 *>(long_list + 4 + 4 * (size_t)slot) = u32x4{i, running, count, 0u};
             } else if (count > 0) {
                 const uint32_t slot = atomicAdd(&short_count, 1u);
-                *reinterpret_cast<u32x4 *>(short_list + 4 + 4 * (size_t)slot) = u32x4{i, running, count, 0u};
+                *reinterpret_cast<u32x4 *>(short_list + 16 + 16 * (size_t)slot) = u32x4{i, count, running, 0u};
             }
             running += count;
         }
@@ -1112,6 +1048,15 @@ __global__ void __launch_bounds__(kListThreads) hot_list_kernel(TrainArgs a, con
         }
         if (hot_head) entries[at + k] = pr.x | 0x80000000u;
         if (pr.x < a.hot_context) entries[atomicAdd(&bins[a.hot_vertex + pr.x], 1u)] = pr.y | 0x80000000u;
+    }
+    __syncthreads();
+    // C: the short chains' entries into their records (written by this workgroup above: its own stores are visible to it
+    // after the barrier)
+    __threadfence_block();
+    for (uint32_t r = threadIdx.x / 8; r < short_count; r += kListThreads / 8) {
+        uint32_t *record = short_list + 16 + 16 * (size_t)r;
+        const uint32_t n = record[1], first = record[2], i = threadIdx.x % 8;
+        if (i < n) record[4 + i] = entries[first + i];
     }
 }
 
@@ -1860,10 +1805,12 @@ struct HotLayout {
 constexpr uint32_t kMaxChains = 32768;  // one LDS counter per chain in hot_list_kernel (128 KB of the CU's 160 KB)
 constexpr int kLongBlocks = 256;        // workgroups that walk the long chains of a unit (one per CU)
 
-// entries one chain task trains in sequence: whole samples for head chains
-uint32_t chain_cap_for(int k, int chain_cap) {
-    const uint32_t want = chain_cap > 0 ? (uint32_t)chain_cap : (g_chain_cap > 0 ? (uint32_t)g_chain_cap : 16u);
-    return (want + (uint32_t)k) / (uint32_t)(k + 1) * (uint32_t)(k + 1);
+// entries one chain task trains in sequence: at most what a short record holds (train_short_chains)
+constexpr uint32_t kDefaultChainCap = 7, kMaxChainCap = 7;
+
+uint32_t chain_cap_for(int chain_cap) {
+    const uint32_t want = chain_cap > 0 ? (uint32_t)chain_cap : (g_chain_cap > 0 ? (uint32_t)g_chain_cap : kDefaultChainCap);
+    return std::min(want, kMaxChainCap);
 }
 
 // One work list per part of a batch (parts divides batch_size: gvk_train_launches): num_batch * parts lists; behind them
@@ -1871,7 +1818,7 @@ uint32_t chain_cap_for(int k, int chain_cap) {
 HotLayout hot_layout(int dim, int batch_size, int k, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts, int chain_cap) {
     HotLayout l;
     l.chains = hot_vertex + hot_context;
-    l.cap = chain_cap_for(k, chain_cap);
+    l.cap = chain_cap_for(chain_cap);
     num_batch *= parts;
     batch_size /= parts;
     // a sample adds at most k + 1 entries to its head's chain and one to the chain of each of its k + 1 targets
@@ -1882,7 +1829,7 @@ HotLayout hot_layout(int dim, int batch_size, int k, uint32_t hot_vertex, uint32
     l.entries = align((size_t)num_batch * (l.chains + 1) * 4);
     l.long_list = l.entries + align((size_t)num_batch * l.entry_capacity * 4);
     l.short_list = l.long_list + align((size_t)num_batch * (1 + (size_t)l.long_capacity) * 16);
-    l.mirrors = l.short_list + align((size_t)num_batch * (1 + (size_t)l.chains) * 16);
+    l.mirrors = l.short_list + align((size_t)num_batch * (1 + (size_t)l.chains) * 64);
     l.mirror_bytes = align((size_t)l.chains * dim * 4);
     l.bytes = l.mirrors + 3 * l.mirror_bytes;
     return l;
@@ -1906,24 +1853,11 @@ void fill_negative(TrainArgs &a, const gvk_negative_source *neg) {
 
 typedef void (*HotKernel)(const TrainArgs, const HotArgs);
 
-// Samples per lane group of the pair body (train_pairs_wide; SGD with one negative): what the registers left by the chains
-// hold — three at dims up to 128 (two with lerp: six rows per sample), one (train_pair) beyond and for other k.
-int hot_wide(int dim, int k, int lerp) {
-    if (g_hot_wide > 0) return k == 1 && dim <= 128 ? std::min(g_hot_wide, lerp ? 2 : 3) : 1;
-    if (k != 1 || dim > 128) return 1;
-    return lerp ? 2 : 3;
-}
-
 HotKernel pick_hot(int dim, int k, int lerp) {
-    const int wide = hot_wide(dim, k, lerp);
-#define GVK_HOT(D, GG)                                                                                                   \
-    case D:                                                                                                              \
-        if (k != 1) return lerp ? train_hot_kernel<D, GG, 0, 2, 1> : train_hot_kernel<D, GG, 0, 1, 1>;                   \
-        if constexpr (D <= 128) {                                                                                        \
-            if (wide == 3) return train_hot_kernel<D, GG, 1, 1, 3>;                                                      \
-            if (wide == 2) return lerp ? train_hot_kernel<D, GG, 1, 2, 2> : train_hot_kernel<D, GG, 1, 1, 2>;            \
-        }                                                                                                                \
-        return lerp ? train_hot_kernel<D, GG, 1, 2, 1> : train_hot_kernel<D, GG, 1, 1, 1>;
+#define GVK_HOT(D, GG)                                                                                              \
+    case D:                                                                                                         \
+        return k == 1 ? (lerp ? train_hot_kernel<D, GG, 1, 2> : train_hot_kernel<D, GG, 1, 1>)                      \
+                      : (lerp ? train_hot_kernel<D, GG, 0, 2> : train_hot_kernel<D, GG, 0, 1>);
     switch (dim) {
         GVK_HOT(32, 8) GVK_HOT(64, 16) GVK_HOT(96, 8) GVK_HOT(128, 16) GVK_HOT(256, 16) GVK_HOT(512, 32)
     }
@@ -1997,7 +1931,7 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     if (form & ~(GVK_HOT_SERIALIZED | GVK_HOT_LERP)) return fail(GVK_EINVAL, "gvk_train_episode_hot: unknown form bits");
     const HotLayout l = hot_layout(dim, batch_size, num_negative, hot_vertex, hot_context, workspace_batches, parts, chain_cap);
     if (!workspace || workspace_bytes < l.bytes) return fail(GVK_EINVAL, "gvk_train_episode_hot: workspace too small (gvk_hot_plan)");
-    const bool lerp = (form & GVK_HOT_LERP) != 0, serialized = (form & GVK_HOT_SERIALIZED) != 0;
+    const bool lerp = (form & GVK_HOT_LERP) != 0, serialized = (form & GVK_HOT_SERIALIZED) != 0 || g_hot_serialized != 0;
     const HotKernel kernel = pick_hot(dim, num_negative, lerp);
     if (!kernel) return fail(GVK_EDIM, "gvk_train_episode_hot: no kernel for this dim");
     const int lanes = default_lanes(dim);
@@ -2012,16 +1946,14 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     a.hot_vertex = hot_vertex; a.hot_context = hot_context;
     HotArgs h;
     memset(&h, 0, sizeof(h));
-    h.chains = l.chains; h.long_capacity = l.long_capacity; h.cap = l.cap; h.k = num_negative;
+    h.chains = l.chains; h.long_capacity = l.long_capacity; h.cap = l.cap;
     const int groups = kBlock / lanes;
     const int short_blocks = (int)((l.chains + groups - 1) / groups);
     const int long_blocks = (int)std::min<uint32_t>(l.long_capacity, (uint32_t)kLongBlocks);
     const int copy_blocks = (int)((l.chains + 4 * groups - 1) / (4 * groups));
     // the unit of work is a PART of a batch (parts = 1: the batch): unit u = part u % parts of batch u / parts
     const int part_size = batch_size / parts, units = num_batches * parts;
-    const int wide = hot_wide(dim, num_negative, lerp);
-    const int per_block = kBlock / lanes * wide;  // samples a block of the pair body trains
-    const unsigned pair_blocks = (unsigned)((part_size + per_block - 1) / per_block);
+    const unsigned pair_blocks = (unsigned)(((int64_t)part_size * lanes + kBlock - 1) / kBlock);
     if (num_batches == 0) return GVK_OK;
     // when every row of both tables is a hub row the pairs have nothing to store: they run for the last batch only, whose
     // per-sample loss a caller may read
@@ -2040,7 +1972,7 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
         h.chain_start = reinterpret_cast<const uint32_t *>(base + l.chain_start) + (size_t)u * (l.chains + 1);
         h.entries = reinterpret_cast<const uint32_t *>(base + l.entries) + (size_t)u * l.entry_capacity;
         h.long_list = reinterpret_cast<const uint32_t *>(base + l.long_list) + (size_t)u * 4 * (1 + (size_t)l.long_capacity);
-        h.short_list = reinterpret_cast<const uint32_t *>(base + l.short_list) + (size_t)u * 4 * (1 + (size_t)l.chains);
+        h.short_list = reinterpret_cast<const uint32_t *>(base + l.short_list) + (size_t)u * 16 * (1 + (size_t)l.chains);
         h.from = mirror(u - 1), h.to = mirror(u);
         h.lr = lr_of(u / parts);
         h.log2_decay_positive = (float)std::log2(1.0 - (double)h.lr * a.wd);
@@ -2330,9 +2262,8 @@ int gvk_set_tuning(int key, int value) {
         g_chain_cap = value;
         return GVK_OK;
     }
-    if (key == GVK_TUNE_HOT_WIDE) {
-        if (value < 0 || value > 3) return fail(GVK_EINVAL, "gvk_set_tuning: samples per lane group must be 0 .. 3");
-        g_hot_wide = value;
+    if (key == GVK_TUNE_HOT_SERIALIZED) {
+        g_hot_serialized = value != 0;
         return GVK_OK;
     }
     if (key == GVK_TUNE_SPLIT_HITS) {

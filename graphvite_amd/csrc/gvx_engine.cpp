@@ -174,6 +174,7 @@ struct gvx_solver {
     int hub_parts_request = 0;      // GVX_HUB_PARTS: 0 the rule (gvk_train_launches when every row is a hub row, else 1), Q > 0 given
     int64_t hub_rows_request = -2;  // GVX_HUB_ROWS: -2 the default rule, -1 by expected hits per batch, 0 off, N > 0 the first N rows
     int hub_lerp_request = -1;      // GVX_HUB_LERP: -1 the rule, 0 / 1: the pairs read hub rows as their unit's chains left them / along the chains' way
+    int hub_chunk = kHubChunk;      // batches whose work lists are built at once (fewer where memory is short)
     int hub_chain_cap_request = 0;  // GVX_HUB_CHAIN_CAP: entries one chain task trains in sequence (0 = the kernels' default)
     uint64_t node2vec_table_limit = (uint64_t)1 << 30;
     // build
@@ -376,9 +377,11 @@ size_t gvx_solver::memory_demand(int P, int requested_episode, bool as_streamed)
     }
     const size_t pool = episode * batch_size * 8;
     demand += 3 * pool + pool;  // two pool buffers + the regrouping landing buffer + the regrouping workspace
-    // hub rows by chains: the work lists of kHubChunk batches (8 bytes per list entry, 2 (k + 1) entries per sample at most,
-    // as much again for the chains' records) and the mirrors of the hub rows
-    demand += (size_t)kHubChunk * batch_size * (num_negative + 1) * 32 + 3 * 2 * (size_t)kMaxHubRows * dim * 4;
+    // hub rows by chains: the work lists of up to kHubChunk batches (8 bytes per list entry, 2 (k + 1) entries per sample at
+    // most, as much again for the chains' records) — of fewer batches where that would be more than an eighth of the memory
+    // (prepare_devices) — and the three mirrors of the hub rows of both tables
+    demand += std::min((size_t)kHubChunk * batch_size * (num_negative + 1) * 32, gpu_memory_limit / 8) +
+              3 * 2 * std::min<size_t>(kMaxHubRows, S) * dim * 4;
     if (device_sampling && !as_streamed) {
         // the pools of every block a worker trains, two episodes, + its slices on their way to the owners (send + receive)
         demand += 4 * tails * P * pool;
@@ -664,11 +667,14 @@ extern "C" int gvx_solver_build(gvx_solver *s, const gvs_graph *graph, const gvx
     if (s->num_step < 0) return s->num_step;
     // The reference walks the block groups x-major (solver.h:562-574): all steps that use head partitions x .. x + W - 1
     // come back to back, and each needs the exchange of the one before.  An episode may visit its P^2 blocks in any
-    // order, so with P = m W (m > 1) the steps are interleaved across the m head groups: the all-gather of group x's
-    // slab then runs on the exchange streams while the next m - 1 steps train on the other groups.
+    // order, so with several workers and P = m W (m > 1) the steps are interleaved across the m head groups: the all-gather
+    // of group x's slab then runs on the exchange streams while the next m - 1 steps train on the other groups.  One worker
+    // has no exchange to hide and keeps the reference's order (when a training is shorter than an episode — the automatic
+    // episode size at P = 4 on the benchmark graph is 436 batches per block, 6 976 per episode — the order decides which
+    // blocks meet the large learning rates).
     s->order.clear();
     const int m = P > 1 ? P / W : 1;
-    if (m > 1 && !s->streamed) {
+    if (m > 1 && W > 1 && !s->streamed) {
         for (int yi = 0; yi < m; yi++)
             for (int o = 0; o < W; o++)
                 for (int xi = 0; xi < m; xi++) s->order.push_back((xi * m + yi) * W + o);
@@ -1010,16 +1016,20 @@ int gvx_solver::allocate_pools() {
         HIP_TRY(hipMalloc(&w.group_workspace, std::max<size_t>(w.group_workspace_bytes, 16)));
         for (uint32_t *pools : w.block_pools)  // never train what nothing wrote
             if (pools) HIP_TRY(hipMemsetAsync(pools, 0, w.tails.size() * num_partition * (size_t)episode_size * batch_size * 8, w.compute));
-        if (hubs) {  // the chains' work lists and mirrors, sized for the largest block
+        if (hubs) {  // the chains' work lists and mirrors, sized for the largest block: hub_chunk batches at a time
             size_t need = 0;
-            for (int hp = 0; hp < num_partition; hp++)
-                for (int tp = 0; tp < num_partition; tp++) {
-                    if (hub_rows[hp] + hub_rows[tp] == 0) continue;
-                    size_t bytes = 0;
-                    GVK_TRY(gvk_hot_plan(dim, batch_size, num_negative, hub_rows[hp], hub_rows[tp], kHubChunk, hub_parts_of(hp, tp),
-                                         hub_chain_cap_request, &bytes));
-                    need = std::max(need, bytes);
-                }
+            for (hub_chunk = kHubChunk;; hub_chunk /= 2) {
+                need = 0;
+                for (int hp = 0; hp < num_partition; hp++)
+                    for (int tp = 0; tp < num_partition; tp++) {
+                        if (hub_rows[hp] + hub_rows[tp] == 0) continue;
+                        size_t bytes = 0;
+                        GVK_TRY(gvk_hot_plan(dim, batch_size, num_negative, hub_rows[hp], hub_rows[tp], hub_chunk, hub_parts_of(hp, tp),
+                                             hub_chain_cap_request, &bytes));
+                        need = std::max(need, bytes);
+                    }
+                if (need <= gpu_memory_limit / 8 || hub_chunk == 1) break;
+            }
             if (need > w.hub_workspace_bytes) {
                 hipFree(w.hub_workspace);
                 w.hub_workspace = nullptr, w.hub_workspace_bytes = 0;
@@ -1532,7 +1542,7 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int
             const int chain_cap = hub_chain_cap_request;
             const int form = (hub_lerp_request < 0 ? kHubLerp : hub_lerp_request) ? GVK_HOT_LERP : 0;
             size_t need = 0;
-            GVK_TRY(gvk_hot_plan(dim, B, num_negative, kv, kc, kHubChunk, parts, chain_cap, &need));
+            GVK_TRY(gvk_hot_plan(dim, B, num_negative, kv, kc, hub_chunk, parts, chain_cap, &need));
             if (need > w.hub_workspace_bytes) {  // first block, or a block with more hub rows / parts than any before it
                 HIP_TRY(hipStreamSynchronize(w.compute));
                 hipFree(w.hub_workspace);
@@ -1540,8 +1550,8 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int
                 HIP_TRY(hipMalloc(&w.hub_workspace, need));
                 w.hub_workspace_bytes = need;
             }
-            for (int at = 0; at < n; at += kHubChunk) {
-                const int m = std::min(kHubChunk, n - at);
+            for (int at = 0; at < n; at += hub_chunk) {
+                const int m = std::min(hub_chunk, n - at);
                 const uint32_t id = (uint32_t)(first + (uint64_t)at * W);
                 const uint32_t *batches = pool + (size_t)(done + at) * B * 2;
                 GVK_TRY(gvk_hot_build(w.compute, dim, w.hub_workspace, w.hub_workspace_bytes, batches, B, m, num_negative, &neg, id,

@@ -186,9 +186,11 @@ int gvk_train_episode(void *stream, int dim, const gvk_optimizer *optimizer, int
  * parts (a divisor of batch_size, the same in all three calls; 1 = none): a batch is trained as `parts` equal units one after
  * the other, each with its own work lists, so that nothing reads a hub row that is more than a unit old.  When every row of
  * both tables is a hub row the pairs have nothing to store and only run for the last batch (its loss).
- * chain_cap (the same in all three calls; 0 = the default, 16): entries one chain task trains in sequence — a longer chain is
- * cut into up to 256 / lanes tasks trained side by side by one workgroup and composed in task order (weight decay in closed
- * form; deterministic given the work lists). */
+ * chain_cap (the same in all three calls; 0 = the default and the most, 7): entries one chain task trains in sequence — what a
+ * chain's record carries, so that a chain of up to chain_cap entries costs two dependent round trips (its record; its own row
+ * and all partner rows at once).  A longer chain is cut into up to 256 / lanes tasks trained side by side by one workgroup and
+ * composed in task order (weight decay in closed form; deterministic given the work lists); beyond that many tasks of chain_cap
+ * entries the tasks grow. */
 #define GVK_HOT_SERIALIZED 1
 #define GVK_HOT_LERP 2
 int gvk_hot_plan(int dim, int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts,
@@ -325,11 +327,10 @@ int gvk_probe_row_traffic(void *stream, int dim, float *vertex, float *context, 
                                      holds at most `value` samples per row of the head table: default 2 (what keeps small
                                      partitions at the reference's learning quality); 0 = always one launch
                                      per batch */
-#define GVK_TUNE_HOT_WIDE 9       /* gvk_train_episode_hot, SGD with one negative, dim <= 128: samples a lane group of the pair body
-                                     trains with all their rows in flight (train_pairs_wide): 0 = the default (3; 2 with lerp), 1 =
-                                     the per-pair body */
+#define GVK_TUNE_HOT_SERIALIZED 9 /* measurement: 1 = gvk_train_episode_hot always launches the chains and the pairs of a unit one after the
+                                     other (GVK_HOT_SERIALIZED): their durations apart in a kernel trace */
 #define GVK_TUNE_CHAIN_CAP 8      /* gvk_train_episode_hot: entries one chain task trains in sequence (a longer chain is cut into
-                                     tasks trained side by side and composed): 0 = the default, 16 */
+                                     tasks trained side by side and composed): 0 = the default, 7 (also the most) */
 /* A/B library only: */
 #define GVK_TUNE_LANES_PER_PAIR 1 /* 0 = per-dim default; else 8, 16, 32 or 64 */
 #define GVK_TUNE_GENERATION 4     /* parity experiment: C > 0 trains a batch as consecutive launches of at most C samples

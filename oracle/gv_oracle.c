@@ -190,7 +190,7 @@ static void gvo_chain(int dim, float *own, const float *partner, const uint32_t 
  * from `own_table` and leaves there; partner rows are read from `partner_vertex` / `partner_context` (the caller passes the
  * tables as the unit found them).  A chain longer than cap entries is trained as tasks of consecutive entries side by side
  * and the tasks are composed (below): tasks of cap entries, or — past max_tasks of them (0 = no limit) — of
- * ceil(n / max_tasks) entries rounded up to whole samples (k + 1 entries), what one workgroup of the product trains
+ * ceil(n / max_tasks) entries, what one workgroup of the product trains
  * (train_long_chains, graphvite_amd/csrc/gvk_kernels.hip). */
 static int gvo_hot_chains(int dim, float *vertex, float *context, const float *partner_vertex, const float *partner_context,
                           float lr, float wd, float negative_weight, uint32_t kv, const uint32_t *chain_start,
@@ -207,7 +207,8 @@ static int gvo_hot_chains(int dim, float *vertex, float *context, const float *p
             continue;
         }
         uint32_t per = cap;
-        if (max_tasks && (uint64_t)per * max_tasks < n) per = ((n + max_tasks - 1) / max_tasks + (uint32_t)k) / (uint32_t)(k + 1) * (uint32_t)(k + 1);
+        if (max_tasks && (uint64_t)per * max_tasks < n) per = (n + max_tasks - 1) / max_tasks;
+        (void)k;
         /* tasks: weight decay composes in closed form (a factor per entry that depends on its label only), so every task
          * starts from the row as the decay of the entries before it leaves it, and its end state is carried through the
          * decay of the entries after it: row <- total row + sum over tasks (after end - total row) */

@@ -39,9 +39,7 @@ def main():
     tune.set_segment_steps(int(extra.get("steps", 0)))
     if "split" in extra:
         tune.set_split_hits(int(extra["split"]))
-    tune.set_tuning(8, int(extra.get("chain_cap", 0)))  # GVK_TUNE_CHAIN_CAP
-    tune.set_tuning(9, int(extra.get("serialized", 0)))  # GVK_TUNE_HOT_SERIALIZED
-    hub = extra.get("hub", "0")
+    hub = extra.get("hub", "default")
     tag = " ".join("%s=%s" % kv for kv in sorted(extra.items()))
     for order in orders:
         aucs = []
@@ -49,7 +47,10 @@ def main():
             t0 = time.time()
             s = gv.solver.GraphSolver(128, num_sampler_per_worker=int(extra.get("samplers", 8)), seed=seed, pair_order=gv.auto if order == "auto" else order,
                                       device_sampling=extra.get("device_sampling", "0") == "1",
-                                      hub_rows=hub if hub == "auto" else int(hub))
+                                      hub_rows=None if hub == "default" else (hub if hub == "auto" else int(hub)),
+                                      fidelity=extra.get("fidelity", "auto"))
+            s.hub_parts, s.hub_chain_cap = int(extra.get("parts", 0)), int(extra.get("cap", 0))
+            s.hub_lerp = None if "lerp" not in extra else bool(int(extra["lerp"]))
             s.build(g, batch_size=batch, episode_size=int(extra.get("episode", episode)), num_partition=int(extra.get("partitions", 0)))
             s.train(model=extra.get("model", "LINE"), num_epoch=epochs,
                     augmentation_step=int(extra.get("aug", train_kw["augmentation_step"])),
@@ -60,7 +61,7 @@ def main():
             print("%s epochs %d order %s seed %d: %d batches AUC %.6f (%.1f s)" % (shape, epochs, order, seed, s.batch_id,
                                                                                  aucs[-1], time.time() - t0), flush=True)
         print("%s epochs %d order %s [%s] %s, %d hub rows: mean %.6f sd %.6f" % (shape, epochs, order, tag, tune.describe_train(
-            128, "SGD", 1, False, batch, s._part_size), s.hub_rows, np.mean(aucs), np.std(aucs)), flush=True)
+            128, "SGD", 1, False, batch, s.partition_rows), s.hub_rows, np.mean(aucs), np.std(aucs)), flush=True)
 
 
 if __name__ == "__main__":

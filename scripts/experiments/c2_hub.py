@@ -37,7 +37,7 @@ for config in extra.get("configs", "hub=auto").split(";"):
         hub = kw.get("hub", "default")
         s = gv.solver.GraphSolver(128, num_sampler_per_worker=15, seed=seed, device_sampling=kw.get("device", "0") == "1",
                                   hub_rows=None if hub == "default" else (hub if hub == "auto" else int(hub)),
-                                  fidelity=kw.get("fidelity", "throughput"))
+                                  fidelity=kw.get("fidelity", "auto"))
         s.hub_parts = int(kw.get("parts", 0))
         s.hub_lerp = None if "lerp" not in kw else bool(int(kw["lerp"]))
         s.hub_chain_cap = int(kw.get("cap", 0))

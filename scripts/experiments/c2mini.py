@@ -1,13 +1,14 @@
 """Experiment: a small stand-in for the headline shape — power-law 200k nodes / 2M edges, batch 100 000 (the top hub heads
 1 400 samples of a batch, as hub-heavy per launch as configs[1]), LINE, 50 epochs — link-prediction AUC per executor.
 With GVK_LIBRARY = the host build (tests/hostdev) the kernels are the sequential oracle: the value to match.  The host build
-is also an executor SIMULATOR: with hub rows requested (hub=…, parts=…) and GVH_EXECUTOR=chains it trains every part in the
-product's three-launch form (head-row chains, context-row chains, pairs: oracle/gv_oracle.c gvo_train_hot; GVH_CHAIN_CAP =
-entries per chain task), with GVH_EXECUTOR=lerp the pairs read a hub row where its chain was when it met the sample
-(gvo_train_hot_lerp) — what a change of the device path would do to learning, measured without a GPU (the Hogwild losses of
-the other rows are not simulated).
+is also an executor SIMULATOR: with hub rows (hub=…, parts=…, cap=…, lerp=…) and GVH_EXECUTOR=units it trains every part the
+way the device path does (oracle/gv_oracle.c gvo_train_hot: chains of both families from the part's start state, long chains
+as tasks composed in order, then the pairs — hub rows as the chains left them or along their way), with
+GVH_EXECUTOR=pipelined the chains of part u + 1 are computed before the pairs of part u write — what a change of the device
+path would do to learning, measured without a GPU (the Hogwild losses of the other rows are not simulated).
 
-    python scripts/experiments/c2mini.py seeds=3,4 configs="hub=0;hub=auto;hub=auto,chain_cap=64" [epochs=50]
+    GVK_ALLOW_TEST_LIBRARY=1 GVK_LIBRARY=tests/hostdev/build/libgvk_host.so GVH_EXECUTOR=units \
+        python scripts/experiments/c2mini.py seeds=3,4 configs="hub=0;hub=auto,parts=8;hub=auto,parts=5,lerp=1" [epochs=50]
 """
 import logging
 import os
@@ -41,9 +42,6 @@ if not host:
 for config in extra.get("configs", "hub=0").split(";"):
     kw = dict(kv.split("=") for kv in config.split(",") if kv)
     if not host:
-        tune.set_tuning(8, int(kw.get("chain_cap", 0)))
-        tune.set_tuning(9, int(kw.get("serialized", 0)))
-        tune.set_tuning(10, int(kw.get("whole_pairs", 0)))
         tune.set_variant(int(kw.get("variant", 0)))
     aucs = []
     for seed in [int(x) for x in extra.get("seeds", "3").split(",")]:
@@ -51,7 +49,8 @@ for config in extra.get("configs", "hub=0").split(";"):
         hub = kw.get("hub", "0")
         s = gv.solver.GraphSolver(128, num_sampler_per_worker=6, seed=seed, hub_rows=hub if hub == "auto" else int(hub),
                                   pair_order=kw.get("order", "sampled") if kw.get("order", "sampled") != "auto" else gv.auto)
-        s.hub_parts = int(kw.get("parts", 0))
+        s.hub_parts, s.hub_chain_cap = int(kw.get("parts", 0)), int(kw.get("cap", 0))
+        s.hub_lerp = None if "lerp" not in kw else bool(int(kw["lerp"]))
         s.build(g, batch_size=B, episode_size=int(kw.get("episode", 20)))
         s.train(model="LINE", num_epoch=int(extra.get("epochs", 50)), augmentation_step=1, log_frequency=1 << 30)
         aucs.append(link_prediction_auc(s.vertex_embeddings, s.context_embeddings, name2id[H[keep]], name2id[T[keep]], Y[keep]))

@@ -20,6 +20,10 @@ SHAPES = {
              dict(augmentation_step=2, walk_length=40, walk_batch=100, shuffle_base=2)),
     "hub100k": (dict(num_vertex=100000, num_edge=2000000, gamma=2.3, num_community=100, p_in=0.7, seed=1024), 100000, 35,
                 dict(augmentation_step=1)),
+    # Youtube-like (BASELINE configs[2] / [3]: 1.1M nodes / 4.9M edges, maximum degree 28 754): a fifth of the nodes and edges, the
+    # largest hub 7 % of the nodes, sum of squared degrees 8.9e8 — node2vec's per-edge tables still fit (2^30 entries)
+    "tube": (dict(num_vertex=200000, num_edge=1000000, gamma=2.3, num_community=200, p_in=0.7, seed=1024), 100000, 200,
+             dict(augmentation_step=5, walk_length=40, walk_batch=100, shuffle_base=1)),
 }
 
 

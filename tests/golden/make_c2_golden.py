@@ -4,7 +4,8 @@ BASELINE configs[1], the graph bench.py trains: synthetic power-law, 1M nodes / 
 seed 1024), LINE, dim 128, batch 100 000, one partition, auto episode size, SGD 0.025 / 0.005 linear — for EPOCHS = 50
 epochs (5 000 batches), under the sequential kernel model (three seeds) and the two chunk-synchronous models of the
 reference's own launch (one seed each); and, sequential model, one worker, with the tables split into P = 2 / 4 / 8
-partitions (keys c2_line_p2 / _p4 / _p8, two seeds each: the configurations `bench.py --gpus N` trains — the reference fills
+partitions (keys c2_line_p2 / _p4 with the automatic episode size, c2_line_p<P>_e<E> with episodes of E batches per block;
+two seeds each: the configurations `bench.py --gpus N` trains — the reference fills
 every block pool with the same number of samples, solver.h:1045-1052, and walks the blocks by get_schedule, solver.h:519-575).
 ~15 minutes of host time per training.
 
@@ -36,18 +37,23 @@ def main():
     # (5120 resident warps; tests/golden/make_concurrency_golden.py): one seed each — the bracket the product is read against
     jobs = [("sequential", 0, False, i, seed) for i, seed in enumerate(SEEDS)]
     jobs += [("lock_step", 5120, False, 0, SEEDS[0]), ("reads_at_start", 5120, True, 0, SEEDS[0])]
-    jobs += [("p%d" % P, 0, False, i, SEEDS[i]) for P in (4, 2, 8) for i in range(2)]
+    jobs += [("p%d" % P, 0, False, i, SEEDS[i]) for P in (4, 2) for i in range(2)]
+    # ... and with episodes of about 512 batches (episode_size 128 / 32 / 8 per block at P = 2 / 4 / 8) instead of the automatic
+    # size, which at P >= 4 makes this 5 000-batch training shorter than ONE episode (every block visited once, under a
+    # learning rate that has decayed by the time the last blocks are met): keys c2_line_p<P>_e<E>
+    jobs += [("p%d_e%d" % (P, E), 0, False, i, SEEDS[i]) for P, E in ((4, 32), (8, 8), (2, 128)) for i in range(2)]
     if len(sys.argv) > 1:
         jobs = [j for j in jobs if j[0] in sys.argv[1:]]
     for model, chunk, reads_at_start, i, seed in jobs:
         key = "c2_line_" + model
-        partitions = int(model[1:]) if model[0] == "p" and model[1:].isdigit() else 1
+        partitions = int(model[1:].split("_e")[0]) if model[0] == "p" and model[1:].split("_e")[0].isdigit() else 1
+        episode = int(model.split("_e")[1]) if "_e" in model else 0  # 0: automatic
         out = dict(np.load(PATH)) if os.path.exists(PATH) else {}
         values = out.get(key, np.full(len(SEEDS) if model == "sequential" else (2 if partitions > 1 else 1), np.nan))
         if not np.isnan(values[i]):
             continue
         t0 = time.time()
-        rs = ReferenceSolver(oracle, seed, train.astype(np.uint32), None, True, 1, 4, partitions, 1, BATCH, 0)  # episode auto
+        rs = ReferenceSolver(oracle, seed, train.astype(np.uint32), None, True, 1, 4, partitions, 1, BATCH, episode)
         kw = dict(kernel_chunk=chunk, threads=int(os.environ.get("THREADS", "3")), reads_at_start=reads_at_start) if chunk else {}
         vertex, context, batch_id = reference_train(rs, "LINE", EPOCHS, augmentation_step=1, **kw)
         labels = rs.partition()[0]

@@ -5,9 +5,12 @@ per-edge alias tables of build_edge_edge (include/instance/graph.cuh:298-450,656
 (BASELINE configs[0]: 10 312 nodes / 333 983 edges, hub-heavy with communities; small enough for node2vec's per-edge
 tables: 135M entries) with the walk hyper-parameters the reference ships for these models
 (config/graph/deepwalk_youtube.yaml, node2vec_youtube.yaml: augmentation_step 5, random_walk_length 40,
-random_walk_batch_size 100, batch 100 000, episode 500) and the quick start's 2000 epochs.
+random_walk_batch_size 100, batch 100 000, episode 500) and the quick start's 2000 epochs; and — SHAPE=tube EPOCHS=300 — on
+a Youtube-like graph (scripts/experiments/reference_concurrency.py SHAPES: 200k nodes / 1M edges, the largest hub 7 % of the
+nodes; 3 000 batches in episodes of 200), the scale BASELINE configs[2] / [3] run at.
 
     python tests/golden/make_walk_golden.py deepwalk node2vec_p0.25_q0.25 node2vec_p4_q2     # any subset; resumable
+    SHAPE=tube EPOCHS=300 SEEDS=2 python tests/golden/make_walk_golden.py deepwalk node2vec_p0.25_q0.25
 """
 import fcntl
 import os
@@ -24,7 +27,7 @@ from oracle_lib import Oracle, ReferenceSolver, link_prediction_auc, reference_t
 from reference_concurrency import SHAPES  # noqa: E402
 
 PATH = os.path.join(HERE, "reference_walks.npz")
-SHAPE = "blog"
+SHAPE = os.environ.get("SHAPE", "blog")
 EPOCHS = int(os.environ.get("EPOCHS", "2000"))
 WALK = dict(augmentation_step=5, walk_length=40, walk_batch=100, shuffle_base=1)
 MODELS = {
@@ -32,7 +35,7 @@ MODELS = {
     "node2vec_p0.25_q0.25": ("node2vec", 0.25, 0.25),   # BASELINE configs[3]
     "node2vec_p4_q2": ("node2vec", 4.0, 2.0),           # config/graph/node2vec_youtube.yaml:30-31
 }
-SEEDS = (17, 18, 19, 20, 21, 22)  # 3 at first; 6 since the comparison is between means of different random streams
+SEEDS = (17, 18, 19, 20, 21, 22)[:int(os.environ.get("SEEDS", "6"))]  # 3 at first; 6 since the comparison is between means of different random streams
 
 
 def update(key, index, value, extra):
@@ -76,7 +79,7 @@ def main():
                                            EPOCHS, WALK["augmentation_step"], WALK["walk_length"], WALK["walk_batch"]], np.int64),
                 SHAPE + "_gamma_p_in": np.array([kw["gamma"], kw["p_in"]], np.float64),
                 key + "_p_q": np.array([p, q], np.float64),
-                "seeds": np.array(SEEDS, np.int64)})
+                ("seeds" if SHAPE == "blog" else SHAPE + "_seeds"): np.array(SEEDS, np.int64)})
 
 
 if __name__ == "__main__":

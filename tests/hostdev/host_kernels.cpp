@@ -227,7 +227,7 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     const int lerp = (form & GVK_HOT_LERP) || (getenv("GVH_LERP") && atoi(getenv("GVH_LERP")));
     const int pipelined = strstr(executor, "pipelined") != nullptr, n = batch_size / parts, k = num_negative;
     if (getenv("GVH_CHAIN_CAP")) chain_cap = atoi(getenv("GVH_CHAIN_CAP"));
-    const uint32_t cap = ((chain_cap > 0 ? chain_cap : 16) + k) / (k + 1) * (k + 1);
+    const uint32_t cap = (uint32_t)std::min(chain_cap > 0 ? chain_cap : 7, 7);  // chain_cap_for, gvk_kernels.hip
     const uint32_t max_tasks = getenv("GVH_MAX_TASKS") ? (uint32_t)atoi(getenv("GVH_MAX_TASKS")) : (dim == 512 ? 8u : (dim == 32 || dim == 96 ? 32u : 16u));
     std::vector<uint32_t> start(hot_vertex + hot_context + 1), entries(2 * (size_t)(k + 1) * n + 1);
     std::vector<uint32_t> all((size_t)num_batches * batch_size * std::max(k, 1));

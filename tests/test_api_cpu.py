@@ -78,8 +78,8 @@ def test_kernel_wrappers_refuse_cpu_tensors():
 
 
 def _bench(world, *arguments):
-    """bench.py on the CPU: the host build of the engine (tests/hostdev, GVK_LIBRARY) instead of the HIP library, gloo
-    instead of RCCL; rank 0's JSON line."""
+    """bench.py's loop on the CPU (tests/bench_dry_run.py: the host build of the engine instead of the HIP library, gloo
+    instead of RCCL); rank 0's JSON line."""
     import json
     import os
     import socket
@@ -87,7 +87,7 @@ def _bench(world, *arguments):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "hostdev")])
-    args = ["bench.py", "--gpus", str(world)] + [str(a) for a in arguments]
+    args = [os.path.join("tests", "bench_dry_run.py"), "--gpus", str(world)] + [str(a) for a in arguments]
     if world > 1:
         s = socket.socket()
         s.bind(("127.0.0.1", 0))
@@ -98,7 +98,7 @@ def _bench(world, *arguments):
     else:
         cmd = [sys.executable] + args
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    env["GVK_LIBRARY"] = os.path.join(root, "tests", "hostdev", "build", "libgvk_host.so")
+    env.pop("GVK_LIBRARY", None)
     run = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900, env=env)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
     lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
@@ -198,3 +198,21 @@ def test_kernel_choice_by_table_size():
         lib.gvk_set_tuning(_lib.TUNE_SPLIT_HITS, 2)
     with pytest.raises(ValueError):
         describe(100, _lib.SGD, 1, 1000)
+
+
+def test_another_kernel_library_is_a_test_switch():
+    """GVK_LIBRARY alone must not point the product at another kernel library (the host build of the engine runs the oracle's
+    kernels): it is honoured only together with GVK_ALLOW_TEST_LIBRARY=1, which tests/ and scripts/experiments/ set themselves."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "tests", "hostdev", "build", "libgvk_host.so")
+    env = {k: v for k, v in os.environ.items() if k != "GVK_ALLOW_TEST_LIBRARY"}
+    env["GVK_LIBRARY"] = host
+    run = subprocess.run([sys.executable, "-c", "import graphvite_amd"], cwd=root, capture_output=True, text=True, env=env)
+    assert run.returncode != 0 and "GVK_ALLOW_TEST_LIBRARY" in run.stderr
+    env["GVK_ALLOW_TEST_LIBRARY"] = "1"
+    run = subprocess.run([sys.executable, "-c", "import graphvite_amd; from graphvite_amd import _lib; print(_lib.LIB_PATH)"],
+                         cwd=root, capture_output=True, text=True, env=env)
+    assert run.returncode == 0 and run.stdout.strip() == host, run.stderr[-2000:]

@@ -19,8 +19,7 @@ LANES = {32: 8, 64: 16, 96: 8, 128: 16, 256: 16, 512: 32}  # lanes per pair = pe
 
 def layout(batch_size, k, chains, num_batch, cap, parts=1):
     """Offsets of gvk_hot_plan's workspace (hot_layout, graphvite_amd/csrc/gvk_kernels.hip): one list per part of a batch."""
-    cap = (cap or 16)
-    cap = (cap + k) // (k + 1) * (k + 1)
+    cap = min(cap or 7, 7)  # chain_cap_for, gvk_kernels.hip
     num_batch, batch_size = num_batch * parts, batch_size // parts
     entry_capacity = 2 * (k + 1) * batch_size
     align = lambda x: (x + 255) // 256 * 256  # noqa: E731
@@ -68,9 +67,9 @@ def clean_rows(pool, allneg, N, kv, kc):
 
 
 @pytest.mark.parametrize("by_class", [False, True])
-@pytest.mark.parametrize("dim,k,cap", [(128, 1, 0), (128, 1, 64), (128, 3, 10), (32, 1, 0), (64, 1, 8), (96, 2, 12), (256, 1, 0), (512, 1, 32)])
+@pytest.mark.parametrize("dim,k,cap", [(128, 1, 0), (128, 1, 4), (128, 3, 5), (32, 1, 0), (64, 1, 3), (96, 2, 6), (256, 1, 0), (512, 1, 2)])
 def test_chains_match_the_oracle(hip, oracle, dim, k, cap, by_class):
-    if by_class and (dim, k, cap) not in ((128, 1, 0), (128, 3, 10)):
+    if by_class and (dim, k, cap) not in ((128, 1, 0), (128, 3, 5)):
         pytest.skip("the class table is exercised at dim 128")
     rng = np.random.default_rng(dim * 10 + k)
     # one batch: from the second batch on the chains would read rows that the first batch's pair launch trained Hogwild

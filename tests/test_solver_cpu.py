@@ -26,6 +26,7 @@ def host_build():
 def scenario(host_build, name, *arguments, timeout=1200):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env["GVK_LIBRARY"] = host_build
+    env["GVK_ALLOW_TEST_LIBRARY"] = "1"
     run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host_scenarios.py"), name, json.dumps(list(arguments))],
                          cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
     print(run.stdout[-3000:])
