@@ -189,7 +189,15 @@ def cpu_baseline(args, graph):
     return out
 
 
-def train_timed(args, gv, graph, threads, partitions, device_sampling, epochs, fidelity=None):
+def auc_episode_size(partitions):
+    """Episode size of the trainings whose AUC is compared with the reference's loop at P > 1 partitions: about 512 batches per
+    episode (all P x P blocks), like the goldens c2_line_p<P>_e<E> (tests/golden/make_c2_golden.py).  The automatic size makes
+    a 50-epoch training shorter than one episode from P = 4 on: every block would be visited once, the last ones under a
+    learning rate that has all but decayed — a protocol artefact, not a property of the path."""
+    return max(512 // (partitions * partitions), 1)
+
+
+def train_timed(args, gv, graph, threads, partitions, device_sampling, epochs, fidelity=None, episode_size=None):
     """One GraphSolver.train() as a user calls it, timed by this process."""
     import torch
     solver = gv.solver.GraphSolver(args.dim, num_sampler_per_worker=threads, seed=args.seed, device_sampling=device_sampling,
@@ -200,7 +208,7 @@ def train_timed(args, gv, graph, threads, partitions, device_sampling, epochs, f
     solver.hub_chain_cap = args.hub_cap
     solver.negative_table = args.negative_table
     solver.build(graph, optimizer=gv.optimizer.SGD(0.025, 0.005, "linear"), num_partition=partitions,
-                 num_negative=args.negatives, batch_size=args.batch)
+                 num_negative=args.negatives, batch_size=args.batch, episode_size=episode_size or gv.auto)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     solver.train(model="LINE", num_epoch=epochs, augmentation_step=1, log_frequency=1 << 30)
@@ -242,7 +250,8 @@ def link_prediction(args, gv, world, threads, partitions):
     train, (valid, test) = synthetic.link_prediction_split(edges, (100, 1, 1))
     graph = gv.graph.Graph()
     graph.load(train)
-    solver, wall = train_timed(args, gv, graph, threads, partitions, world > 1, args.auc_epochs)
+    episode = auc_episode_size(partitions) if partitions > 1 else None
+    solver, wall = train_timed(args, gv, graph, threads, partitions, world > 1, args.auc_epochs, episode_size=episode)
     H, T, Y = (np.asarray(x) for x in test)
     name2id = np.full(args.vertices, -1, np.int64)
     names = np.array([int(x) for x in graph.id2name], np.int64)
@@ -257,12 +266,13 @@ def link_prediction(args, gv, world, threads, partitions):
     auc = auc_of(solver)
     out = {"value": auc, "epochs": args.auc_epochs, "batches": solver.batch_id, "workers": world, "partitions": solver.num_partition,
            "device_sampling": world > 1, "hub_rows": solver.hub_rows, "hub_parts": solver.hub_parts_used, "fidelity": solver.fidelity,
+           "episode_size": solver.episode_size,
            "kernel": ("train_hot_kernel: hub rows by chains, a batch as %d parts" % solver.hub_parts_used) if solver.hub_rows else
                      solver.kernels.describe_train(args.dim, "SGD", args.negatives, False, args.batch, solver.partition_rows)}
     golden = os.path.join(ROOT, "tests", "golden", "reference_c2.npz")
     if os.path.exists(golden) and (args.vertices, args.edges, args.seed, args.batch) == (1000000, 10000000, 1024, 100000):
         G = np.load(golden)
-        key = "c2_line_sequential" if solver.num_partition == 1 else "c2_line_p%d" % solver.num_partition
+        key = "c2_line_sequential" if solver.num_partition == 1 else "c2_line_p%d_e%d" % (solver.num_partition, episode or 0)
         reference = G[key] if key in G else np.zeros(0)
         reference = reference[~np.isnan(reference)]
         if len(reference) and int(G["c2_args"][5]) == args.auc_epochs:

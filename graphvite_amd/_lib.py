@@ -164,6 +164,8 @@ def lib():
     l.gvk_sample_walks.argtypes = [vp, P(WalkGraph), u64, u64, vp, C.c_size_t, i32, i32, i32]
     l.gvk_sample_walks_blocks.restype = i32
     l.gvk_sample_walks_blocks.argtypes = [vp, P(WalkGraph), vp, i32, u64, u64, u64, vp, vp, vp, u32, i32, i32, i32, i32]
+    l.gvk_spread_pairs.restype = i32
+    l.gvk_spread_pairs.argtypes = [vp, vp, vp, C.c_size_t, i32]
     l.gvk_group_pairs.restype = i32
     l.gvk_group_pairs.argtypes = [vp, vp, vp, vp, P(C.c_size_t), i32, i32, i32]
     l.gvk_alias_build.restype = i32

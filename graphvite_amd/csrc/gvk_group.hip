@@ -107,7 +107,28 @@ __global__ void __launch_bounds__(kThreads) group_pass_kernel(const uint64_t *__
     }
 }
 
+// gvk_spread_pairs: record i of the pool to place (i % units) * (n / units) + i / units
+__global__ void __launch_bounds__(256) spread_kernel(const uint64_t *in, uint64_t *out, const uint64_t n, const uint64_t units) {
+    const uint64_t per = n / units;
+    // thread t writes output record t (coalesced stores; the loads stride by `units` records)
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const uint64_t unit = t / per, slot = t % per;
+    out[t] = in[slot * units + unit];
+}
+
 }  // namespace
+
+extern "C" int gvk_spread_pairs(void *stream, const uint32_t *pool_in, uint32_t *pool_out, size_t num_pair, int units) {
+    if (units < 1 || num_pair % (size_t)units) return gvk_fail(GVK_EINVAL, "gvk_spread_pairs: %d units do not divide %zu pairs", units, num_pair);
+    if (num_pair == 0) return GVK_OK;
+    if (!pool_in || !pool_out || pool_in == pool_out) return gvk_fail(GVK_EINVAL, "gvk_spread_pairs: needs distinct input and output pools");
+    hipLaunchKernelGGL(spread_kernel, dim3((unsigned)((num_pair + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint64_t *>(pool_in), reinterpret_cast<uint64_t *>(pool_out), (uint64_t)num_pair, (uint64_t)units);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return gvk_fail(GVK_EHIP, "gvk_spread_pairs: %s", hipGetErrorString(err));
+    return GVK_OK;
+}
 
 extern "C" int gvk_group_pairs(void *stream, const uint32_t *pool_in, uint32_t *pool_out, void *workspace,
                                size_t *workspace_bytes, int batch_size, int num_batch, int row_bits) {

@@ -695,7 +695,7 @@ struct HotArgs {
 template <int DIM, int G>
 struct ChainShape {
     static constexpr int V = DIM / G;
-    static constexpr int D = V <= 4 ? 8 : (V <= 8 ? 7 : (V <= 12 ? 4 : 2));  // partner rows in flight per lane group: what 168 registers (three wavefronts per SIMD) hold without spilling
+    static constexpr int D = V <= 4 ? 8 : (V <= 8 ? 4 : 2);  // partner rows in flight per lane group of a long chain's task
     static constexpr int NG = kBlock / G;     // lane groups of a block = most tasks of a long chain
     static_assert(D <= G, "the entry window is two fetches of G entries");
 };
@@ -781,7 +781,7 @@ template <int DIM, int G>
 __device__ __forceinline__ void train_short_chains(const TrainArgs &a, const HotArgs &h, const uint32_t block) {
     typedef ChainShape<DIM, G> S;
     constexpr int V = S::V, N = kShortEntries;
-    constexpr int D = V <= 8 ? N : (V <= 12 ? 4 : 3);  // partner rows in flight: all of them where the registers hold them
+    constexpr int D = V <= 8 ? N : 3;  // partner rows in flight: all of them where the registers hold them
     constexpr int LW = G < 16 ? G : 16;                // lanes that hold the record's sixteen words
     const int lane = threadIdx.x % G, group = threadIdx.x / G;
     const uint32_t at = block * S::NG + group;
@@ -929,10 +929,10 @@ __device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotA
 
 // HOT: 1 = the pairs read a hub row as the chains of their unit left it, 2 = on the straight line from where those chains
 // found it to where they left it, at the sample's place in the unit (lerp)
-// Built for three wavefronts per SIMD (170 registers): the chain loop keeps D partner rows per lane group in flight; a unit
-// of the sizes this kernel trains (a part of a batch) is resident at once at that occupancy.
+// Built for four wavefronts per SIMD (128 registers; the short chains keep seven partner rows per lane group in flight): the
+// chains and the pairs of a unit of the sizes this kernel trains (a part of a batch) are then resident side by side.
 template <int DIM, int G, int KT, int HOT>
-__global__ void __launch_bounds__(kBlock, 3) train_hot_kernel(const TrainArgs a, const HotArgs h) {
+__global__ void __launch_bounds__(kBlock, 4) train_hot_kernel(const TrainArgs a, const HotArgs h) {
     const int chain_blocks = h.long_blocks + h.short_blocks + h.copy_blocks;
     if ((int)blockIdx.x < h.long_blocks) {
         train_long_chains<DIM, G>(a, h, blockIdx.x);

@@ -216,6 +216,8 @@ struct gvx_solver {
     std::vector<std::vector<int>> claimed;  // per head group: the heads (rank order) it was last arranged for
     uint64_t exchanged_bytes = 0, exchanges = 0;
     bool grouped = false;  // this training regroups its pools (pair order)
+    bool spread = false;   // this training spreads its walk-ordered pools over the launches that train them (gvk_spread_pairs, §3.1.3)
+    bool reordered() const { return grouped || spread; }
     // hub rows trained by chains (gvk_train_episode_hot): per partition, how many of its first rows (they are
     // ordered by falling degree) are owned by a chain when the partition is a block's head / tail table; 0 everywhere = off
     std::vector<uint32_t> hub_rows;
@@ -329,7 +331,7 @@ struct gvx_solver {
         return w.block_pools[set] + (tail_index(w, tp) * num_partition + hp) * (size_t)episode_size * batch_size * 2;
     }
     const uint32_t *trained_pool(Worker &w, int set, int b, int hp, int tp) {
-        return w.block_pools[0] && !grouped ? block_pool(w, set, hp, tp) : w.pool[b];
+        return w.block_pools[0] && !reordered() ? block_pool(w, set, hp, tp) : w.pool[b];
     }
     void make_info();
 };
@@ -378,10 +380,9 @@ size_t gvx_solver::memory_demand(int P, int requested_episode, bool as_streamed)
     const size_t pool = episode * batch_size * 8;
     demand += 3 * pool + pool;  // two pool buffers + the regrouping landing buffer + the regrouping workspace
     // hub rows by chains: the work lists of up to kHubChunk batches (8 bytes per list entry, 2 (k + 1) entries per sample at
-    // most, as much again for the chains' records) — of fewer batches where that would be more than an eighth of the memory
-    // (prepare_devices) — and the three mirrors of the hub rows of both tables
-    demand += std::min((size_t)kHubChunk * batch_size * (num_negative + 1) * 32, gpu_memory_limit / 8) +
-              3 * 2 * std::min<size_t>(kMaxHubRows, S) * dim * 4;
+    // most, as much again for the chains' records) — of fewer batches where that would be more than a sixteenth of the memory
+    // (prepare_devices).  The mirrors of the hub rows (at most 3 x 2 x kMaxHubRows rows: 50 MB at dim 128) are not counted.
+    demand += std::min((size_t)kHubChunk * batch_size * (num_negative + 1) * 32, gpu_memory_limit / 16);
     if (device_sampling && !as_streamed) {
         // the pools of every block a worker trains, two episodes, + its slices on their way to the owners (send + receive)
         demand += 4 * tails * P * pool;
@@ -774,15 +775,15 @@ int gvx_solver::configure(const gvx_train_config &in) {
         else if (walk_ordered() && num_partition == 1 && part_rows <= kMaxHubRows) request = (int64_t)part_rows;
         else request = walk_ordered() || table_bytes >= ((size_t)16 << 20) || fidelity == 1 ? -1 : 0;
     }
-    // chains apply SGD updates (a row's update composes in closed form); the other optimizers and schedules computed by a
-    // callback per batch have none: asked for explicitly that is an error, by default it is said once
-    const bool chains_exist = optimizer.type == GVK_SGD && optimizer.schedule != 2;
+    // chains apply SGD updates (a row's update composes in closed form), under any schedule; the moment optimizers have none:
+    // asked for explicitly that is an error, by default it is said once
+    const bool chains_exist = optimizer.type == GVK_SGD;
     if (request != 0 && !chains_exist) {
         if (fidelity == 1 || hub_rows_request > -2)
-            return gvk_fail(GVK_EINVAL, "hub rows are trained by chains for SGD with a constant or linear schedule only: "
-                            "fidelity='reference' / hub_rows cannot be honoured for this optimizer (use fidelity='throughput')");
+            return gvk_fail(GVK_EINVAL, "hub rows are trained by chains for SGD only: fidelity='reference' / hub_rows cannot be "
+                            "honoured for this optimizer (use fidelity='throughput')");
         if (first_rank == 0)
-            log_message(1, "WARNING: this optimizer / schedule has no chains for hub rows: every row is trained pair by pair "
+            log_message(1, "WARNING: this optimizer has no chains for hub rows: every row is trained pair by pair "
                         "(Hogwild); on hub-heavy graphs the hub rows then keep a few of their updates per batch");
         request = 0;
     }
@@ -814,6 +815,14 @@ int gvx_solver::configure(const gvx_train_config &in) {
         }
         if (hubs) grouped = false;
     }
+    // The walk-ordered pools of DeepWalk / node2vec: a walk emits the pairs of a head node back to back and meets a tail node
+    // in pairs a few records apart (graph.cuh:320-348), so consecutive records share rows — side by side in one launch all
+    // but one of those updates are lost.  Unless chains own every row (a small partition, above), the pool is spread: record i
+    // to the launch i % units (gvk_spread_pairs), so that what the reference's sequential loop trains one after the other is
+    // trained by consecutive launches.  pair_order = "sampled" keeps the sampler's order.
+    spread = walk_ordered() && pair_order_request != 1 && !grouped;
+    for (int p = 0; p < num_partition && spread; p++)
+        if (hubs && hub_rows[p] == part_rows) spread = false;  // every row a chain: the pairs train nothing
     if (routed()) {
         if (pool_size % num_worker)
             return gvk_fail(GVK_EINVAL, "episode_size * batch_size (%zu) must be a multiple of #worker (%d) for the "
@@ -1028,7 +1037,7 @@ int gvx_solver::allocate_pools() {
                                              hub_chain_cap_request, &bytes));
                         need = std::max(need, bytes);
                     }
-                if (need <= gpu_memory_limit / 8 || hub_chunk == 1) break;
+                if (need <= gpu_memory_limit / 16 || hub_chunk == 1) break;
             }
             if (need > w.hub_workspace_bytes) {
                 hipFree(w.hub_workspace);
@@ -1534,7 +1543,7 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int
         int n = 1;  // up to, not including, this worker's next logging batch
         while (n < end - done && (first + (uint64_t)n * W) % config.log_frequency) n++;
         const uint32_t kv = hubs ? hub_rows[hp] : 0, kc = hubs ? hub_rows[tp] : 0;
-        if (kv + kc > 0 && optimizer.schedule != 2) {
+        if (kv + kc > 0) {
             // hub rows by chains: the work lists of up to kHubChunk batches, then their launches, on the same stream
             // a small table — every row a hub row, many samples per row and batch — is trained as the parts gvk_train_launches
             // prescribes for it (§7.8): a chain then sees its partners at most a part old
@@ -1550,13 +1559,17 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int
                 HIP_TRY(hipMalloc(&w.hub_workspace, need));
                 w.hub_workspace_bytes = need;
             }
-            for (int at = 0; at < n; at += hub_chunk) {
-                const int m = std::min(hub_chunk, n - at);
-                const uint32_t id = (uint32_t)(first + (uint64_t)at * W);
+            // a schedule computed by a callback (optimizer.h:132-134) gives every batch its learning rate on the host: a call per batch
+            const int chunk = optimizer.schedule == 2 ? 1 : hub_chunk;
+            for (int at = 0; at < n; at += chunk) {
+                const int m = std::min(chunk, n - at);
+                const uint64_t id = first + (uint64_t)at * W;
                 const uint32_t *batches = pool + (size_t)(done + at) * B * 2;
-                GVK_TRY(gvk_hot_build(w.compute, dim, w.hub_workspace, w.hub_workspace_bytes, batches, B, m, num_negative, &neg, id,
+                gvk_optimizer ob = o;
+                if (optimizer.schedule == 2) ob.lr = optimizer.lr * optimizer.schedule_function((int)id, (int)num_batch, optimizer.user);
+                GVK_TRY(gvk_hot_build(w.compute, dim, w.hub_workspace, w.hub_workspace_bytes, batches, B, m, num_negative, &neg, (uint32_t)id,
                                       (uint32_t)W, kv, kc, parts, chain_cap));
-                GVK_TRY(gvk_train_episode_hot(w.compute, dim, &o, optimizer.schedule == 1, &t, batches, &neg, id, (uint32_t)W,
+                GVK_TRY(gvk_train_episode_hot(w.compute, dim, &ob, optimizer.schedule == 1, &t, batches, &neg, (uint32_t)id, (uint32_t)W,
                                               (uint32_t)num_batch, m, w.loss, B, num_negative, config.negative_weight,
                                               w.hub_workspace, w.hub_workspace_bytes, kv, kc, m, parts, chain_cap, form));
             }
@@ -1593,7 +1606,7 @@ int gvx_solver::stage(Worker &w, int step, int set, int b) {
         HIP_TRY(hipStreamWaitEvent(w.copy, w.filled[set], 0));
         source = block_pool(w, set, hp, tp);
     } else {
-        uint32_t *target = grouped ? w.landing : w.pool[b];
+        uint32_t *target = reordered() ? w.landing : w.pool[b];
         HIP_TRY(hipMemcpyAsync(target, host_sets[set][(size_t)hp * P + tp], pool_elems * 4, hipMemcpyHostToDevice, w.copy));
         hipEvent_t copied;
         HIP_TRY(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
@@ -1606,6 +1619,9 @@ int gvx_solver::stage(Worker &w, int step, int set, int b) {
         const int parts = gvk_train_launches(batch_size, part_rows);
         GVK_TRY(gvk_group_pairs(w.copy, source, w.pool[b], w.group_workspace, &w.group_workspace_bytes, batch_size / parts,
                                 episode_size * parts, row_bits));
+    } else if (spread) {  // consecutive records of a walk-ordered pool to consecutive launches (one per part of a batch)
+        Range regroup("Spread");
+        GVK_TRY(gvk_spread_pairs(w.copy, source, w.pool[b], (size_t)episode_size * batch_size, episode_size * hub_parts_of(hp, tp)));
     }
     HIP_TRY(hipEventRecord(w.uploaded[b], w.copy));
     return GVK_OK;
@@ -2021,7 +2037,7 @@ extern "C" int gvx_solver_get(gvx_solver *s, gvx_solver_members *out) {
     out->optimizer = s->optimizer;
     out->batch_id = s->batch_id, out->num_batch = s->num_batch, out->train_seconds = s->train_seconds;
     out->rank = s->first_rank, out->num_local_worker = s->num_local();
-    out->pair_order = s->grouped ? 2 : 1;
+    out->pair_order = s->grouped ? 2 : (s->spread ? 3 : 1);
     out->sampler_mode = s->mode, out->device_sampling = s->device_sampling;
     out->partition_rows = s->part_rows;
     out->transport = s->transport_name.c_str();

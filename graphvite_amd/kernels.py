@@ -293,6 +293,15 @@ class HipKernels(object):
                                       batch_size, num_batch, row_bits)
         _lib.check(rc, "gvk_group_pairs")
 
+    def spread_pairs(self, pool_in, pool_out, num_pair, units):
+        """pool_out = pool_in with record i at place (i % units) * (num_pair / units) + i / units (gvk_spread_pairs)."""
+        dev = pool_in.device
+        _need(pool_in, torch.int32, "pool_in", dev)
+        _need(pool_out, torch.int32, "pool_out", dev)
+        if pool_in.numel() < 2 * num_pair or pool_out.numel() < 2 * num_pair:
+            raise ValueError("pools hold fewer than %d pairs" % num_pair)
+        _lib.check(self.lib.gvk_spread_pairs(self._stream(pool_in), _ptr(pool_in), _ptr(pool_out), num_pair, units), "gvk_spread_pairs")
+
     def sample_walks(self, walk_graph, seed, first_walk, pool, pool_pairs, walk_length, augmentation_step,
                      shuffle_base):
         """pool[:pool_pairs] = random-walk positive pairs drawn on the device (gvk_sample_walks).

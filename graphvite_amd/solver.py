@@ -313,7 +313,7 @@ class GraphSolver(object):
         self.model = (m.model or b"").decode()
         self.num_local_worker = m.num_local_worker
         self.num_sampler_per_worker = m.num_sampler // max(m.num_worker, 1)
-        self.pair_order = "grouped" if m.pair_order == 2 else "sampled"
+        self.pair_order = {2: "grouped", 3: "spread"}.get(m.pair_order, "sampled")
         self.partition_rows = m.partition_rows
         self.hub_rows = m.hub_rows
         self.hub_parts_used, self.hub_lerp_used = m.hub_parts_used, bool(m.hub_lerp_used)

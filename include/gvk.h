@@ -26,6 +26,7 @@
  *                        SamplerMixin::sample, GraphSampler::sample_random_walk / sample_biased_random_walk
  *                        (include/core/solver.h:1012-1055, include/instance/graph.cuh:298-450) on the device (opt-in)
  *   gvk_group_pairs      no counterpart: a per-batch pre-pass (same samples, shared rows adjacent)
+ *   gvk_spread_pairs     no counterpart: a per-pool pre-pass for walk-ordered pools (consecutive samples to consecutive launches)
  *   gvk_probe_row_traffic, gvk_describe_train, gvk_set_tuning, gvk_range_push / _pop
  *                        measurement aids (roofline.access_pattern, kernel label, A/B knobs, roctx ranges at the
  *                        reference's Timer scopes, include/util/time.h:28-60)
@@ -294,6 +295,14 @@ int gvk_sample_walks_blocks(void *stream, const gvk_walk_graph *graph, const int
  * *workspace_bytes; otherwise workspace must hold *workspace_bytes bytes of device memory. */
 int gvk_group_pairs(void *stream, const uint32_t *pool_in, uint32_t *pool_out, void *workspace,
                     size_t *workspace_bytes, int batch_size, int num_batch, int row_bits);
+
+/* Optional pool pre-pass for the walk-ordered pools of DeepWalk / node2vec (a walk emits the pairs of a head node back to back
+ * and meets a tail node in pairs a few records apart, graph.cuh:320-348): record i of pool_in goes to place
+ * (i % units) * (num_pair / units) + i / units of pool_out (distinct from pool_in; units divides num_pair) — with units = the
+ * number of launches that train the pool, consecutive records are trained by consecutive launches instead of side by side in
+ * one, where all but one of the updates of the row they share would be lost.  Same records; the reference's sequential loop
+ * does not care about their order. */
+int gvk_spread_pairs(void *stream, const uint32_t *pool_in, uint32_t *pool_out, size_t num_pair, int units);
 
 /* Host: Vose alias construction exactly as the reference orders it (FIFO queues, double mean).
  * index_bytes 4 -> uint32 alias[] (n <= 2^32 - 1), 8 -> uint64 alias[].  n must be > 0.  (The reference's loop

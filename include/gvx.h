@@ -83,7 +83,7 @@ typedef struct {
     uint64_t batch_id, num_batch;
     double train_seconds;        /* wall time of the episode loop of the last train() */
     int rank, num_local_worker;  /* rank of the first local worker; how many workers this process drives */
-    int pair_order;              /* what the last train() did: 1 the sampler's order, 2 regrouped */
+    int pair_order;              /* what the last train() did: 1 the sampler's order, 2 regrouped, 3 spread (walk-ordered pools, gvk_spread_pairs) */
     int sampler_mode;            /* GVS_MODE_* of the last train() */
     int device_sampling;
     uint32_t partition_rows;     /* S: rows of a partition's table */
@@ -130,7 +130,9 @@ void gvx_solver_destroy(gvx_solver *s);
 #define GVX_DEVICE_SAMPLING 1
 /* GVX_PAIR_ORDER 0 (default): by table size — regrouped (gvk_group_pairs: the pairs of a part of a batch
  * that share a head row made adjacent) for cache-resident tables and for shard-sized tables of independent edge draws,
- * the sampler's order otherwise; 1: always the sampler's order; 2: always regrouped. */
+ * the sampler's order otherwise — except the walk-ordered pools of DeepWalk / node2vec, which are spread (gvk_spread_pairs:
+ * consecutive records to consecutive launches) unless chains own every row; 1: always the sampler's order; 2: always
+ * regrouped. */
 #define GVX_PAIR_ORDER 2
 /* GVX_SEED: seeds the embedding initialisation, the host samplers, the device samplers and the negative draws (default 0:
  * the values the engine has always used). */
@@ -149,13 +151,14 @@ void gvx_solver_destroy(gvx_solver *s);
  * Batches keep the sampler's order. */
 #define GVX_HUB_ROWS 6
 /* GVX_HUB_PARTS: with hub rows trained by chains, a batch is trained as this many equal parts (a divisor of the batch size),
- * each with its own chains and pairs; 0 (default): gvk_train_launches() parts where every row is a hub row, one otherwise. */
+ * each with its own chains and pairs; 0 (default): gvk_train_launches() parts where every row is a hub row, otherwise so many
+ * that the largest hub row meets about 250 of its updates per part. */
 #define GVX_HUB_PARTS 7
 /* GVX_FIDELITY -1 (default, `auto`): the reference's learning quality wherever chains exist — on tables that do not live in
  * the caches, the rows a batch is expected to hit twice or more are trained by chains (GVX_HUB_ROWS -1) and a batch as so many
  * parts that the largest hub row meets about 250 of its updates per part (eight on the headline shape): link-prediction AUC
- * within 0.002 of the reference's sequential loop there; optimizers and schedules without chains (anything
- * but SGD with a constant or linear schedule) train every row pair by pair and say so once.  1 (`reference`): the same, but a
+ * within 0.002 of the reference's sequential loop there; the moment optimizers have no chains: they train every
+ * row pair by pair and say so once.  1 (`reference`): the same, but a
  * configuration without chains is an error.  0 (`throughput`): every row is trained pair by pair (Hogwild, as the reference's
  * kernel); the hub rows of a hub-heavy graph then keep only some of their updates.  GVX_HUB_ROWS / GVX_HUB_PARTS given
  * explicitly take precedence. */

@@ -25,12 +25,23 @@ for name in ("bench_n1.json", "bench_n1_steps20.json", "configs_2_4.jsonl", "con
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, name))
 
 # ---- kernel trace -------------------------------------------------------------------------------------------------
+# algorithmic bytes of one launch of the training kernel: what the bench line of the same job says (a batch trained as parts is
+# several launches of train_hot_kernel)
+PER_LAUNCH, LAUNCHES = 308800000, 1
+for name in ("bench_n1_steps20.json", "bench_n1.json"):
+    path = os.path.join(SRC, name)
+    if os.path.exists(path) and os.path.getsize(path):
+        line = [l for l in open(path) if l.startswith("{")]
+        if line:
+            roofline = json.loads(line[-1])["roofline"]
+            PER_LAUNCH, LAUNCHES = roofline["algorithmic_bytes_per_launch"], roofline.get("launches_per_step", 1)
+            break
 stats, trace = find("prof_kernel", "kernel_stats.csv"), find("prof_kernel", "kernel_trace.csv")
 if stats:
     shutil.copy(stats, os.path.join(DST, "kernel_stats_bench_n1.csv"))
 if trace:
     every = list(csv.DictReader(open(trace)))
-    rows = [r for r in every if "train_" in r["Kernel_Name"]]
+    rows = [r for r in every if "train_" in r["Kernel_Name"] and (LAUNCHES == 1 or int(r["Grid_Size_X"]) > 250000)]  # with parts: the launches that hold pairs (the first of a call holds chains only)
     probe = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in every if "probe_rows_kernel" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
@@ -39,8 +50,8 @@ if trace:
     summary = {"command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline "
                           "--no-end-to-end (the driver's command, end-to-end legs off)", "kernels": dict(by_name), "launches": len(rows), "mean_ns": sum(dur) / len(dur),
                "min_ns": min(dur), "max_ns": max(dur), "median_gap_ns": gap[len(gap) // 2], "grid": rows[0]["Grid_Size_X"],
-               "workgroup": rows[0]["Workgroup_Size_X"], "achieved_GBps": 308800000 / (sum(dur) / len(dur)),
-               "fraction_of_hbm_peak": 308800000 / (sum(dur) / len(dur)) / 8000.0}
+               "workgroup": rows[0]["Workgroup_Size_X"], "algorithmic_bytes_per_launch": PER_LAUNCH, "launches_per_batch": LAUNCHES,
+               "achieved_GBps": PER_LAUNCH / (sum(dur) / len(dur)), "fraction_of_hbm_peak": PER_LAUNCH / (sum(dur) / len(dur)) / 8000.0}
     if probe:  # roofline.access_pattern: the rows of a batch read and written back, nothing else
         summary["access_pattern_probe"] = {"kernel": "probe_rows_kernel", "launches": len(probe),
                                            "mean_ns": sum(probe) / len(probe),
@@ -60,7 +71,7 @@ def counters(directory):
     acc, kernel = collections.defaultdict(list), None
     if path:
         for r in csv.DictReader(open(path)):
-            if "train_" in r["Kernel_Name"]:
+            if "train_" in r["Kernel_Name"] and (LAUNCHES == 1 or int(r.get("Grid_Size", r.get("Grid_Size_X", 1 << 30))) > 250000):
                 kernel = r["Kernel_Name"]
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {"dispatches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)} for k, v in acc.items()}, kernel
@@ -72,7 +83,7 @@ for dim in (32, 64, 96, 128, 256, 512):
     if "FETCH_SIZE" not in fetch or "WRITE_SIZE" not in write:
         continue
     f, w = fetch["FETCH_SIZE"]["mean"] * 1024, write["WRITE_SIZE"]["mean"] * 1024
-    algorithmic = (8 * dim * 3 + 16) * 100000
+    algorithmic = (8 * dim * 3 + 16) * 100000 // (LAUNCHES if dim == 128 else 1)
     entry = {"kernel": kernel, "FETCH_SIZE": fetch["FETCH_SIZE"], "WRITE_SIZE": write["WRITE_SIZE"],
              "hbm_read_bytes_per_launch_corrected": 2 * f, "hbm_write_bytes_per_launch": w,
              "traffic_bytes_per_launch": 2 * f + w, "algorithmic_bytes_per_launch": algorithmic,

@@ -127,8 +127,11 @@ def hub_row_rules():
             assert trained["expected hits"] == s.hub_rows
         else:
             assert s.hub_rows == want, (name, s.hub_rows, want)
-        trained.setdefault(model, s.vertex_embeddings.copy())
-        assert (trained[model] == s.vertex_embeddings).all(), name
+        # ... among the runs that train the pools in the same order (a walk-ordered pool is spread over the launches unless
+        # chains own every row, gvk_spread_pairs: the same samples in another order)
+        trained.setdefault((model, s.pair_order), s.vertex_embeddings.copy())
+        assert (trained[model, s.pair_order] == s.vertex_embeddings).all(), name
+        assert s.pair_order == ("spread" if model == "DeepWalk" and s.hub_rows < g.num_vertex else "sampled"), (name, s.pair_order)
     # several workers / partitions with hub rows: the engine's bookkeeping (work lists per block visit, per-worker workspaces,
     # partitions with different numbers of hub rows) — the tables must still be those of the plain run
     plain = None
@@ -160,10 +163,29 @@ def hub_row_rules():
             assert "chains" in str(e)
         else:
             raise AssertionError("chains were promised for Adam")
+    # a schedule computed by a callback: chains all the same (a call per batch, its learning rate from the host)
+    tables = {}
+    for name, schedule in (("linear", "linear"), ("callback", lambda batch_id, num_batch: max(1 - batch_id / num_batch, 1e-4))):
+        s = gv.solver.GraphSolver(32, num_sampler_per_worker=2, seed=1, hub_rows=50)
+        s.build(g, optimizer=gv.optimizer.SGD(0.025, 0.005, schedule), batch_size=1000, episode_size=4)
+        s.train(model="LINE", num_epoch=2, log_frequency=1 << 30)
+        assert s.hub_rows == 50
+        tables[name] = s.vertex_embeddings.copy()
+    assert np.abs(tables["linear"] - tables["callback"]).max() < 1e-6
     s = gv.solver.GraphSolver(32, num_sampler_per_worker=2, seed=1, hub_rows=50)
     s.hub_parts = 7  # not a divisor of the batch size: the rule's parts stay
     s.build(g, batch_size=1000, episode_size=4)
     s.train(model="LINE", num_epoch=1, log_frequency=1 << 30)
+    # the embedding views keep the solver that owns their memory alive (the reference's binding does the same, bind.h:90-106)
+    def views():
+        t = gv.solver.GraphSolver(32, num_sampler_per_worker=1, seed=2)
+        t.build(g, batch_size=1000, episode_size=2)
+        t.train(model="LINE", num_epoch=1, log_frequency=1 << 30)
+        return t.vertex_embeddings, t.context_embeddings
+    import gc
+    v, c = views()
+    gc.collect()
+    assert v.shape == (g.num_vertex, 32) and np.isfinite(v).all() and np.isfinite(c).all() and np.abs(c).max() > 0
     for bad in (lambda: gv.solver.GraphSolver(32, fidelity="exact"), lambda: gv.solver.GraphSolver(32, hub_rows=-5).build(g)):
         try:
             bad()

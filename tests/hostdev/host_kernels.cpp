@@ -360,6 +360,17 @@ int gvk_sample_walks_blocks(void *, const gvk_walk_graph *g, const int32_t *part
     return GVK_OK;
 }
 
+int gvk_spread_pairs(void *, const uint32_t *pool_in, uint32_t *pool_out, size_t num_pair, int units) {
+    if (units < 1 || num_pair % (size_t)units || !pool_in || !pool_out || pool_in == pool_out)
+        return gvk_fail(GVK_EINVAL, "gvk_spread_pairs: bad argument");
+    const size_t per = num_pair / (size_t)units;
+    for (size_t i = 0; i < num_pair; i++) {
+        const size_t to = (i % (size_t)units) * per + i / (size_t)units;
+        pool_out[2 * to] = pool_in[2 * i], pool_out[2 * to + 1] = pool_in[2 * i + 1];
+    }
+    return GVK_OK;
+}
+
 // per batch: a stable sort of the records by the low row bits of the head (what gvk_group_pairs promises)
 int gvk_group_pairs(void *, const uint32_t *pool_in, uint32_t *pool_out, void *workspace, size_t *workspace_bytes, int batch_size,
                     int num_batch, int row_bits) {

@@ -791,3 +791,19 @@ def test_group_pairs_edge_cases(hip):
     assert lib.gvk_group_pairs(None, None, None, None, None, 4, 2, 10) == _lib.GVK_EINVAL
     with pytest.raises(ValueError):
         hip.group_pairs(a, b, 4, 3, 10)
+
+
+def test_spread_pairs_sends_consecutive_records_to_consecutive_units(hip):
+    """gvk_spread_pairs: record i of the pool to place (i % units) * (n / units) + i / units — unit u holds the records u, u +
+    units, ...: what sat side by side in a walk-ordered pool is trained by consecutive launches."""
+    rng = np.random.default_rng(3)
+    for n, units in ((1200, 8), (4096, 64), (1000, 1), (600, 600)):
+        pool = rng.integers(0, 1 << 31, (n, 2)).astype(np.uint32)
+        a = torch.from_numpy(pool.view(np.int32)).to(DEV)
+        b = torch.zeros_like(a)
+        hip.spread_pairs(a, b, n, units)
+        torch.cuda.synchronize()
+        want = pool.reshape(n // units, units, 2).transpose(1, 0, 2).reshape(n, 2)
+        assert (b.cpu().numpy().view(np.uint32) == want).all()
+    with pytest.raises(ValueError):
+        hip.spread_pairs(a, b, 600, 7)

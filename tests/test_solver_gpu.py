@@ -86,11 +86,11 @@ def test_walk_mode_matches_the_sequential_oracle(tmp_path):
 WALKS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_walks.npz")
 
 
-def _walk_shape():
-    """The "blog" shape and the walk hyper-parameters recorded in tests/golden/reference_walks.npz."""
+def _walk_shape(shape="blog"):
+    """A shape ("blog", "tube") and the walk hyper-parameters recorded for it in tests/golden/reference_walks.npz."""
     G = np.load(WALKS)
-    n, e, communities, graph_seed, batch, episode, epochs, aug, length, walk_batch = [int(x) for x in G["blog_args"]]
-    gamma, p_in = [float(x) for x in G["blog_gamma_p_in"]]
+    n, e, communities, graph_seed, batch, episode, epochs, aug, length, walk_batch = [int(x) for x in G[shape + "_args"]]
+    gamma, p_in = [float(x) for x in G[shape + "_gamma_p_in"]]
     edges = synthetic.hub_community_edges(n, e, gamma=gamma, num_community=communities, p_in=p_in, seed=graph_seed)
     train, (valid, test) = synthetic.link_prediction_split(edges, (100, 1, 1))
     build = dict(batch_size=batch, episode_size=episode)
@@ -133,6 +133,40 @@ def test_walk_models_match_the_reference_training_loop(name, sampling):
     print("blog %s (%s): AUC here %s (mean %.6f) | reference training loop %s (mean %.6f)" % (
         name, sampling, " ".join("%.6f" % a for a in aucs), np.mean(aucs), " ".join("%.6f" % a for a in reference),
         reference.mean()))
+    assert abs(np.mean(aucs) - reference.mean()) <= 0.002
+
+
+@pytest.mark.parametrize("sampling", ["tables", "rejection", "device"])
+@pytest.mark.parametrize("name", ["deepwalk", "node2vec_p0.25_q0.25"])
+def test_walk_models_at_youtube_scale_match_the_reference_training_loop(name, sampling):
+    """The same at the scale BASELINE configs[2] / [3] run at: "tube" (scripts/experiments/reference_concurrency.py) is a
+    Youtube-like graph — 200k nodes / 1M edges, the largest hub 7 % of the nodes (Youtube: 1.1M / 4.9M, 2.5 %), the sum of squared
+    degrees just below the 2^30 entries node2vec's per-edge tables may have — trained for 3 000 batches of 100 000 (episodes of
+    200) with the walk settings the reference ships.  The table has 200k rows: hub rows (the ~10k rows a batch is expected to
+    hit twice) by chains, a batch as parts, every other row pair by pair in the sampler's order — the default executor.
+    Means over seeds within +-0.002 of the reference's own training loop (tests/golden/make_walk_golden.py, SHAPE=tube)."""
+    G, train, test, build, fit = _walk_shape("tube")
+    model = "DeepWalk" if name == "deepwalk" else "node2vec"
+    if model == "DeepWalk" and sampling == "rejection":
+        pytest.skip("rejection sampling is node2vec's")
+    p, q = [float(x) for x in G["tube_%s_p_q" % name]]
+    reference = G["tube_" + name]
+    reference = reference[~np.isnan(reference)]
+    gv.init_logging(logging.ERROR)
+    g = gv.graph.Graph()
+    g.load(train)
+    aucs = []
+    for seed in [int(x) for x in G["tube_seeds"]][:3]:
+        s = gv.solver.GraphSolver(128, num_sampler_per_worker=8, seed=seed, device_sampling=sampling == "device")
+        if sampling == "rejection":
+            s.node2vec_table_limit = 0
+        s.build(g, **build)
+        s.train(model=model, p=p, q=q, log_frequency=1 << 30, **fit)
+        assert 0 < s.hub_rows < s.partition_rows and s.hub_parts_used > 1 and s.pair_order == "spread"
+        aucs.append(auc_of(g, s, test))
+    print("tube %s (%s): %d hub rows, a batch as %d parts: AUC here %s (mean %.6f) | reference training loop %s (mean %.6f)" % (
+        name, sampling, s.hub_rows, s.hub_parts_used, " ".join("%.6f" % a for a in aucs), np.mean(aucs),
+        " ".join("%.6f" % a for a in reference), reference.mean()))
     assert abs(np.mean(aucs) - reference.mean()) <= 0.002
 
 
