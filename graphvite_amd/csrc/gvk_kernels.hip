@@ -44,6 +44,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 int g_variant = 0;         // GVK_TUNE_VARIANT
 int g_run_cap = 0;         // GVK_TUNE_RUN_CAP (0 = the default of 20, run_cap_for)
 int g_split_hits = 2;      // GVK_TUNE_SPLIT_HITS (samples per table row one launch may hold; 0 = never split a batch)
+int g_hot_order = 1;       // GVK_TUNE_HOT_ORDER (measurement: which blocks of a train_hot_kernel launch come first; 1 = long chains, pairs, the other chains)
 int g_hot_serialized = 0;  // GVK_TUNE_HOT_SERIALIZED (measurement: gvk_train_episode_hot launches the chains and the pairs of a unit one after the other)
 int g_chain_cap = 0;       // GVK_TUNE_CHAIN_CAP (entries one chain task trains in sequence; 0 = the default of 7)
 #if defined(GVK_AB_BUILDS)  // knobs of the A/B library only (make ab -> build/ab/libgvk_ab.so)
@@ -689,6 +690,7 @@ struct HotArgs {
     uint32_t cap;                 // entries of one task (at most kShortEntries)
     float lr;                     // learning rate of the chains' batch (the pairs of the same launch may belong to another batch)
     float log2_decay_positive, log2_decay_negative;  // log2(1 - lr wd), log2(1 - lr negative_weight wd): decay of an entry by label
+    int order, pair_blocks;       // grid order (0: chains first, 1: long chains, pairs, the other chains, 2: pairs first)
     int long_blocks, short_blocks, copy_blocks;  // grid: [long chains | chains of 1 .. cap entries, kBlock / G per block | rows without entries | pairs]
 };
 
@@ -777,34 +779,22 @@ __device__ __forceinline__ float group_count(const uint32_t x) {
 // together with the list's length), then its own row and every partner row at once; then at most seven steps.
 constexpr int kShortEntries = 7;
 
-template <int DIM, int G>
-__device__ __forceinline__ void train_short_chains(const TrainArgs &a, const HotArgs &h, const uint32_t block) {
-    typedef ChainShape<DIM, G> S;
-    constexpr int V = S::V, N = kShortEntries;
-    constexpr int D = V <= 8 ? N : 3;  // partner rows in flight: all of them where the registers hold them
-    constexpr int LW = G < 16 ? G : 16;                // lanes that hold the record's sixteen words
-    const int lane = threadIdx.x % G, group = threadIdx.x / G;
-    const uint32_t at = block * S::NG + group;
-    // the record's sixteen words across the lanes of the group; the list's length arrives with them
-    const uint32_t *record = h.short_list + 16 + 16 * (size_t)(at < h.chains ? at : h.chains - 1);
-    const uint32_t word0 = record[lane % LW], word1 = LW < 16 ? record[8 + lane % LW] : 0;
-    const uint32_t count = h.short_list[0] < h.chains ? h.short_list[0] : h.chains;
-    if (block * S::NG >= count) return;  // the whole block at once
-    auto word = [&](const int i) __attribute__((always_inline)) -> uint32_t {
-        return (uint32_t)(i < LW ? __shfl((int)word0, i, G) : __shfl((int)word1, i - LW, G));
-    };
-    const bool mine = at < count;
-    const uint32_t chain = mine ? word(0) : 0, n = mine ? word(1) : 0;
+// The n <= kShortEntries entries entry_of(0 .. n - 1) of one chain applied one after the other to `own`: every partner row is
+// requested before the first step (where the registers hold them: dims up to 128), so the chain waits for memory once.
+template <int DIM, int G, class EntryOf>
+__device__ __forceinline__ void short_steps(const TrainArgs &a, const HotArgs &h, const uint32_t chain, const uint32_t n, const int lane,
+                                            float (&own)[DIM / G], EntryOf entry_of) {
+    constexpr int V = DIM / G, N = kShortEntries;
+    constexpr int D = V <= 8 ? N : (V <= 12 ? 3 : 2);  // partner rows in flight: all of them where the registers hold them
     const bool is_vertex = chain < a.hot_vertex;
     const float *partner_table = is_vertex ? a.context : a.vertex;
     const uint32_t partner_hot = is_vertex ? a.hot_context : a.hot_vertex;
     const float *partner_mirror = h.from + (is_vertex ? (size_t)a.hot_vertex * DIM : (size_t)0);
     const float *idle = h.from + (size_t)chain * DIM;
-    float own[V], ring[D][V];
-    load_row_at<DIM, G>(idle, lane, own);
+    float ring[D][V];
     uint32_t labels = 0;
     auto request = [&](const int i) __attribute__((always_inline)) {  // the row of entry i into its slot of the ring
-        const uint32_t e = word(4 + i);
+        const uint32_t e = entry_of(i);
         const uint32_t id = e & 0x7fffffffu;
         const float *row = id < partner_hot ? partner_mirror + (size_t)id * DIM : partner_table + (size_t)id * DIM;
         load_row_at<DIM, G>((uint32_t)i < n ? row : idle, lane, ring[i % D]);
@@ -826,6 +816,27 @@ __device__ __forceinline__ void train_short_chains(const TrainArgs &a, const Hot
         for (int x = 0; x < V; x++) own[x] -= h.lr * weight * (gradient * c[x] + a.wd * own[x]);  // optimizer.h:161-164
         if (i + D < N) request(i + D);
     }
+}
+
+template <int DIM, int G>
+__device__ __forceinline__ void train_short_chains(const TrainArgs &a, const HotArgs &h, const uint32_t block) {
+    typedef ChainShape<DIM, G> S;
+    constexpr int LW = G < 16 ? G : 16;  // lanes that hold the record's sixteen words
+    const int lane = threadIdx.x % G, group = threadIdx.x / G;
+    const uint32_t at = block * S::NG + group;
+    // the record's sixteen words across the lanes of the group; the list's length arrives with them
+    const uint32_t *record = h.short_list + 16 + 16 * (size_t)(at < h.chains ? at : h.chains - 1);
+    const uint32_t word0 = record[lane % LW], word1 = LW < 16 ? record[8 + lane % LW] : 0;
+    const uint32_t count = h.short_list[0] < h.chains ? h.short_list[0] : h.chains;
+    if (block * S::NG >= count) return;  // the whole block at once
+    auto word = [&](const int i) __attribute__((always_inline)) -> uint32_t {
+        return (uint32_t)(i < LW ? __shfl((int)word0, i, G) : __shfl((int)word1, i - LW, G));
+    };
+    const bool mine = at < count;
+    const uint32_t chain = mine ? word(0) : 0, n = mine ? word(1) : 0;
+    float own[S::V];
+    load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, own);
+    short_steps<DIM, G>(a, h, chain, n, lane, own, [&](const int i) __attribute__((always_inline)) { return word(4 + i); });
     if (mine) store_row_at<DIM, G>(h.to + (size_t)chain * DIM, lane, own);
 }
 
@@ -887,8 +898,9 @@ __device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotA
         const uint32_t end = last - begin > per ? begin + per : last;
         float own[V];
         load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, own);
-        uint32_t inside = 0;
-        for (uint32_t p = begin + lane; p < end; p += G) inside += h.entries[p] >> 31;
+        const uint32_t mine_entry = begin + lane < end ? h.entries[begin + lane] : 0;  // the task's first G entries, one per lane
+        uint32_t inside = mine_entry >> 31;
+        for (uint32_t p = begin + G + lane; p < end; p += G) inside += h.entries[p] >> 31;
         const float pi = group_count<G>(inside);
         if (lane == 0) positives[group] = pi;
         __syncthreads();
@@ -903,7 +915,11 @@ __device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotA
         const float total = exp2f((pb + pi + pa) * h.log2_decay_positive + ((float)n - (pb + pi + pa)) * h.log2_decay_negative);
 #pragma unroll
         for (int x = 0; x < V; x++) own[x] *= before_;
-        chain_steps<DIM, G>(a, h, chain, begin, end, lane, own);
+        if (per <= (uint32_t)kShortEntries)  // the usual task: all its partner rows at once
+            short_steps<DIM, G>(a, h, chain, end - begin, lane, own,
+                                [&](const int i) __attribute__((always_inline)) { return (uint32_t)__shfl((int)mine_entry, i, G); });
+        else  // a chain of more than NG tasks of seven entries (the largest hubs): longer tasks, rows D at a time
+            chain_steps<DIM, G>(a, h, chain, begin, end, lane, own);
         if (mine) {
 #pragma unroll
             for (int x = 0; x < V; x++) own[x] *= after_;
@@ -929,19 +945,25 @@ __device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotA
 
 // HOT: 1 = the pairs read a hub row as the chains of their unit left it, 2 = on the straight line from where those chains
 // found it to where they left it, at the sample's place in the unit (lerp)
-// Built for four wavefronts per SIMD (128 registers; the short chains keep seven partner rows per lane group in flight): the
-// chains and the pairs of a unit of the sizes this kernel trains (a part of a batch) are then resident side by side.
+// Built for four wavefronts per SIMD (128 registers; the short chains keep seven partner rows per lane group in flight; three
+// at dims 256 and 512, sixteen floats of a row per lane): the chains and the pairs of a unit of the sizes this kernel trains (a
+// part of a batch) are then resident side by side.
 template <int DIM, int G, int KT, int HOT>
-__global__ void __launch_bounds__(kBlock, 4) train_hot_kernel(const TrainArgs a, const HotArgs h) {
-    const int chain_blocks = h.long_blocks + h.short_blocks + h.copy_blocks;
-    if ((int)blockIdx.x < h.long_blocks) {
-        train_long_chains<DIM, G>(a, h, blockIdx.x);
-    } else if ((int)blockIdx.x < h.long_blocks + h.short_blocks) {
-        train_short_chains<DIM, G>(a, h, blockIdx.x - h.long_blocks);
-    } else if ((int)blockIdx.x < chain_blocks) {
-        copy_idle_rows<DIM, G>(h, blockIdx.x - h.long_blocks - h.short_blocks);
+__global__ void __launch_bounds__(kBlock, DIM / G > 12 ? 3 : 4) train_hot_kernel(const TrainArgs a, const HotArgs h) {
+    // the grid: [long chains | pairs | short chains | idle rows] — the long chains, whose tasks wait for memory three times in
+    // a row, are dispatched first, the bulk (the pairs) next; the short chains and the copies fill in behind
+    const int b = blockIdx.x;
+    const int pairs_first = h.order == 2 ? 0 : (h.order == 1 ? h.long_blocks : h.long_blocks + h.short_blocks + h.copy_blocks);
+    const int long_first = h.order == 2 ? h.pair_blocks : 0;
+    const int short_first = h.order == 0 ? h.long_blocks : h.long_blocks + h.pair_blocks;
+    if (b >= long_first && b < long_first + h.long_blocks) {
+        train_long_chains<DIM, G>(a, h, b - long_first);
+    } else if (b >= pairs_first && b < pairs_first + h.pair_blocks) {
+        train_pair<DIM, G, GVK_SGD, KT, 1, HOT>(a, (b - pairs_first) * kBlock + threadIdx.x);
+    } else if (b >= short_first && b < short_first + h.short_blocks) {
+        train_short_chains<DIM, G>(a, h, b - short_first);
     } else {
-        train_pair<DIM, G, GVK_SGD, KT, 1, HOT>(a, (blockIdx.x - chain_blocks) * kBlock + threadIdx.x);
+        copy_idle_rows<DIM, G>(h, b - short_first - h.short_blocks);
     }
 }
 
@@ -1993,7 +2015,9 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
         h.long_blocks = with_chains ? long_blocks : 0;
         h.short_blocks = with_chains ? short_blocks : 0;
         h.copy_blocks = with_chains ? copy_blocks : 0;
-        const unsigned grid = (unsigned)(h.long_blocks + h.short_blocks + h.copy_blocks) + (with_pairs ? pair_blocks : 0u);
+        h.pair_blocks = with_pairs ? (int)pair_blocks : 0;
+        h.order = g_hot_order;
+        const unsigned grid = (unsigned)(h.long_blocks + h.short_blocks + h.copy_blocks + h.pair_blocks);
         if (grid) hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, h);
     };
     const unsigned mirror_blocks = (unsigned)(((size_t)l.chains * (size_t)(dim / 4) + kBlock - 1) / kBlock);
@@ -2260,6 +2284,11 @@ int gvk_set_tuning(int key, int value) {
     if (key == GVK_TUNE_CHAIN_CAP) {
         if (value < 0 || value > (1 << 20)) return fail(GVK_EINVAL, "gvk_set_tuning: chain cap must be in [0, 2^20]");
         g_chain_cap = value;
+        return GVK_OK;
+    }
+    if (key == GVK_TUNE_HOT_ORDER) {
+        if (value < 0 || value > 2) return fail(GVK_EINVAL, "gvk_set_tuning: block order must be 0 .. 2");
+        g_hot_order = value;
         return GVK_OK;
     }
     if (key == GVK_TUNE_HOT_SERIALIZED) {

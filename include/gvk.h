@@ -336,6 +336,8 @@ int gvk_probe_row_traffic(void *stream, int dim, float *vertex, float *context, 
                                      holds at most `value` samples per row of the head table: default 2 (what keeps small
                                      partitions at the reference's learning quality); 0 = always one launch
                                      per batch */
+#define GVK_TUNE_HOT_ORDER 10      /* measurement: which blocks of a train_hot_kernel launch are dispatched first — 0 the chains, 1 (default)
+                                     the long chains, then the pairs, then the other chains, 2 the pairs */
 #define GVK_TUNE_HOT_SERIALIZED 9 /* measurement: 1 = gvk_train_episode_hot always launches the chains and the pairs of a unit one after the
                                      other (GVK_HOT_SERIALIZED): their durations apart in a kernel trace */
 #define GVK_TUNE_CHAIN_CAP 8      /* gvk_train_episode_hot: entries one chain task trains in sequence (a longer chain is cut into

@@ -47,7 +47,7 @@ for config in extra.get("configs", "hub=auto").split(";"):
         aucs.append(link_prediction_auc(s.vertex_embeddings, s.context_embeddings, name2id[H[keep]], name2id[T[keep]], Y[keep]))
         rate = s.timing["batches"] * s.batch_size / s.timing["episodes"] / 1e6
     P = int(kw.get("partitions", 0)) or 1
-    key = "c2_line_sequential" if P == 1 else "c2_line_p%d" % P
+    key = "c2_line_sequential" if P == 1 else "c2_line_p%d" % P + ("_e%s" % kw["episode"] if "episode" in kw else "")
     want = float(np.nanmean(reference[key])) if key in reference and N == 1000000 else float("nan")
     print("C2 [%s] %d hub rows, %d partitions: AUC %s mean %.6f (reference loop %.6f: %+.6f) | %.0f M edge-samples/s" % (
         config, s.hub_rows, s.num_partition, " ".join("%.6f" % a for a in aucs), np.mean(aucs), want, np.mean(aucs) - want, rate), flush=True)

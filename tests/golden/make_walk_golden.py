@@ -10,7 +10,8 @@ a Youtube-like graph (scripts/experiments/reference_concurrency.py SHAPES: 200k 
 nodes; 3 000 batches in episodes of 200), the scale BASELINE configs[2] / [3] run at.
 
     python tests/golden/make_walk_golden.py deepwalk node2vec_p0.25_q0.25 node2vec_p4_q2     # any subset; resumable
-    SHAPE=tube EPOCHS=300 SEEDS=2 python tests/golden/make_walk_golden.py deepwalk node2vec_p0.25_q0.25
+    SHAPE=tube EPOCHS=300 SEEDS=4 python tests/golden/make_walk_golden.py deepwalk node2vec_p0.25_q0.25
+    SHAPE=tube EPOCHS=300 SEEDS=2 PARTITIONS=4 EPISODE=12 python tests/golden/make_walk_golden.py deepwalk node2vec_p0.25_q0.25
 """
 import fcntl
 import os
@@ -28,6 +29,7 @@ from reference_concurrency import SHAPES  # noqa: E402
 
 PATH = os.path.join(HERE, "reference_walks.npz")
 SHAPE = os.environ.get("SHAPE", "blog")
+PARTITIONS = int(os.environ.get("PARTITIONS", "1"))  # > 1: keys <shape>_p<P>_<model>, episode EPISODE batches per block
 EPOCHS = int(os.environ.get("EPOCHS", "2000"))
 WALK = dict(augmentation_step=5, walk_length=40, walk_batch=100, shuffle_base=1)
 MODELS = {
@@ -60,13 +62,15 @@ def main():
     train, (valid, test) = synthetic.link_prediction_split(edges, (100, 1, 1))
     for name in names:
         model, p, q = MODELS[name]
-        key = "%s_%s" % (SHAPE, name)
+        key = "%s_%s" % (SHAPE if PARTITIONS == 1 else "%s_p%d" % (SHAPE, PARTITIONS), name)
         for i, seed in enumerate(SEEDS):
             done = dict(np.load(PATH)) if os.path.exists(PATH) else {}
             if key in done and i < len(done[key]) and not np.isnan(done[key][i]):
                 continue
             t0 = time.time()
-            rs = ReferenceSolver(oracle, seed, train.astype(np.uint32), None, True, 1, 4, 1, 1, batch, episode)
+            if PARTITIONS > 1:
+                episode = int(os.environ.get("EPISODE", "12"))
+            rs = ReferenceSolver(oracle, seed, train.astype(np.uint32), None, True, 1, 4, PARTITIONS, 1, batch, episode)
             vertex, context, batch_id = reference_train(rs, model, EPOCHS, p=p, q=q, **WALK)
             labels = rs.partition()[0]
             name2id = {int(label): j for j, label in enumerate(labels)}
@@ -79,7 +83,8 @@ def main():
                                            EPOCHS, WALK["augmentation_step"], WALK["walk_length"], WALK["walk_batch"]], np.int64),
                 SHAPE + "_gamma_p_in": np.array([kw["gamma"], kw["p_in"]], np.float64),
                 key + "_p_q": np.array([p, q], np.float64),
-                ("seeds" if SHAPE == "blog" else SHAPE + "_seeds"): np.array(SEEDS, np.int64)})
+                key + "_episode": np.int64(episode),
+                ("seeds" if SHAPE == "blog" else (SHAPE if PARTITIONS == 1 else "%s_p%d" % (SHAPE, PARTITIONS)) + "_seeds"): np.array(SEEDS, np.int64)})
 
 
 if __name__ == "__main__":

@@ -136,9 +136,10 @@ def test_walk_models_match_the_reference_training_loop(name, sampling):
     assert abs(np.mean(aucs) - reference.mean()) <= 0.002
 
 
+@pytest.mark.parametrize("partitions", [1, 4])
 @pytest.mark.parametrize("sampling", ["tables", "rejection", "device"])
 @pytest.mark.parametrize("name", ["deepwalk", "node2vec_p0.25_q0.25"])
-def test_walk_models_at_youtube_scale_match_the_reference_training_loop(name, sampling):
+def test_walk_models_at_youtube_scale_match_the_reference_training_loop(name, sampling, partitions):
     """The same at the scale BASELINE configs[2] / [3] run at: "tube" (scripts/experiments/reference_concurrency.py) is a
     Youtube-like graph — 200k nodes / 1M edges, the largest hub 7 % of the nodes (Youtube: 1.1M / 4.9M, 2.5 %), the sum of squared
     degrees just below the 2^30 entries node2vec's per-edge tables may have — trained for 3 000 batches of 100 000 (episodes of
@@ -149,14 +150,21 @@ def test_walk_models_at_youtube_scale_match_the_reference_training_loop(name, sa
     model = "DeepWalk" if name == "deepwalk" else "node2vec"
     if model == "DeepWalk" and sampling == "rejection":
         pytest.skip("rejection sampling is node2vec's")
+    key = "tube_" + name if partitions == 1 else "tube_p%d_%s" % (partitions, name)
+    if key not in G.files:
+        pytest.skip("no golden %s (tests/golden/make_walk_golden.py)" % key)
+    if partitions > 1:  # configs[3]'s per-GPU shape: the table in 4 partitions, the golden's episode size per block
+        if sampling == "rejection":
+            pytest.skip("one CPU sampler per shape at P > 1")
+        build = dict(build, num_partition=partitions, episode_size=int(G[key + "_episode"]))
     p, q = [float(x) for x in G["tube_%s_p_q" % name]]
-    reference = G["tube_" + name]
+    reference = G[key]
     reference = reference[~np.isnan(reference)]
     gv.init_logging(logging.ERROR)
     g = gv.graph.Graph()
     g.load(train)
     aucs = []
-    for seed in [int(x) for x in G["tube_seeds"]][:3]:
+    for seed in [int(x) for x in G["tube_seeds"]][:3 if partitions == 1 else 2]:
         s = gv.solver.GraphSolver(128, num_sampler_per_worker=8, seed=seed, device_sampling=sampling == "device")
         if sampling == "rejection":
             s.node2vec_table_limit = 0
@@ -164,8 +172,8 @@ def test_walk_models_at_youtube_scale_match_the_reference_training_loop(name, sa
         s.train(model=model, p=p, q=q, log_frequency=1 << 30, **fit)
         assert 0 < s.hub_rows < s.partition_rows and s.hub_parts_used > 1 and s.pair_order == "spread"
         aucs.append(auc_of(g, s, test))
-    print("tube %s (%s): %d hub rows, a batch as %d parts: AUC here %s (mean %.6f) | reference training loop %s (mean %.6f)" % (
-        name, sampling, s.hub_rows, s.hub_parts_used, " ".join("%.6f" % a for a in aucs), np.mean(aucs),
+    print("tube %s (%s, %d partition(s)): %d hub rows, a batch as %d parts: AUC here %s (mean %.6f) | reference training loop %s (mean %.6f)" % (
+        name, sampling, partitions, s.hub_rows, s.hub_parts_used, " ".join("%.6f" % a for a in aucs), np.mean(aucs),
         " ".join("%.6f" % a for a in reference), reference.mean()))
     assert abs(np.mean(aucs) - reference.mean()) <= 0.002
 
@@ -549,3 +557,36 @@ def test_headline_shape_matches_the_reference_training_loop():
     assert abs(aucs["default"] - reference.mean()) <= 0.002
     assert abs(aucs["default, device sampling"] - reference.mean()) <= 0.002
     assert aucs["throughput"] >= float(G["c2_line_lock_step"][0]) - 0.01
+
+
+@pytest.mark.parametrize("partitions,episode,device_sampling", [(2, 128, False), (4, 32, False), (4, 32, True), (8, 8, False), (4, 0, False)])
+def test_headline_shape_in_partitions_matches_the_reference_training_loop(partitions, episode, device_sampling):
+    """configs[1] cut into the P = 2 / 4 / 8 partitions `bench.py --gpus N` trains, against the reference's OWN loop at the same P
+    (one worker; tests/golden/make_c2_golden.py keys c2_line_p<P>_e<E>: episodes of E batches per block, ~512 batches per
+    episode — and c2_line_p4: the automatic episode size, with which this 5 000-batch training is shorter than ONE episode and
+    the reference itself ends at 0.488).  A block's top hub holds P times the share of its batch that it holds of the whole
+    graph's: hub rows by chains, a batch as up to 32 parts.  One worker keeps the reference's block order."""
+    G = np.load(C2)
+    key = "c2_line_p%d" % partitions + ("_e%d" % episode if episode else "")
+    reference = G[key]
+    reference = reference[~np.isnan(reference)]
+    n, e, graph_seed, batch, _, epochs = [int(x) for x in G["c2_args"]]
+    edges = synthetic.power_law_edges(n, e, seed=graph_seed)
+    train, (valid, test) = synthetic.link_prediction_split(edges, (100, 1, 1))
+    gv.init_logging(logging.ERROR)
+    g = gv.graph.Graph()
+    g.load(train)
+    H, T, Y = (np.asarray(x) for x in test)
+    name2id = np.full(n, -1, np.int64)
+    names = np.array([int(x) for x in g.id2name], np.int64)
+    name2id[names] = np.arange(len(names))
+    keep = (name2id[H] >= 0) & (name2id[T] >= 0)
+    s = gv.solver.GraphSolver(128, num_sampler_per_worker=8, seed=graph_seed, device_sampling=device_sampling)
+    s.build(g, batch_size=batch, num_partition=partitions, episode_size=episode or gv.auto)
+    s.train(model="LINE", num_epoch=epochs, augmentation_step=1, log_frequency=1 << 30)
+    assert s.num_partition == partitions and s.hub_rows > 0
+    auc = link_prediction_auc(s.vertex_embeddings, s.context_embeddings, name2id[H[keep]], name2id[T[keep]], Y[keep])
+    print("headline shape, %d partitions, episode %d%s: %d batches, a batch as up to %d parts: AUC %.6f | reference training loop %s "
+          "(mean %.6f)" % (partitions, s.episode_size, ", device sampling" if device_sampling else "", s.batch_id, s.hub_parts_used,
+                           auc, " ".join("%.6f" % a for a in reference), reference.mean()))
+    assert abs(auc - reference.mean()) <= 0.002
