@@ -6,9 +6,11 @@ power-law graph BASELINE.json's metric is quoted on (configs[1]: 1M nodes / 10M 
 augmentation_step 1), driven through the product path — the native solver engine (include/gvx.h, one process per GPU,
 RCCL over xGMI) stepped through its session API: Graph -> GraphSolver.build (degree partition; P = N partitions) -> the
 native CPU edge sampler fills the block pools -> pools uploaded to HBM -> per block visit, as in the episode loop:
-[regrouping pass gvk_group_pairs on the copy stream while the previous block trains] -> the slot claim -> gvk_train_episode
-(negatives drawn in-kernel, lr schedule per batch) for `--block-batches` batches -> with N > 1 ONE in-place ncclAllGather
-of the head group's slab (asynchronous).
+[regrouping pass gvk_group_pairs on the copy stream while the previous block trains] -> the slot claim -> the block's
+`--block-batches` batches (negatives drawn in-kernel, lr schedule per batch): gvk_train_episode_hot wherever a table has hub
+rows — the default executor of the headline shape: hub rows by chains, a batch as 8 launches of train_hot_kernel, within
+0.002 AUC of the reference's sequential loop —, gvk_train_episode (one launch per batch) otherwise or with
+`--fidelity throughput` -> with N > 1 ONE in-place ncclAllGather of the head group's slab (asynchronous).
 
 The timed region is WHOLE block visits: it starts on a block boundary, so every block visit whose batches are timed
 has its regrouping pass, its staging and its exchange inside the region too (`regroup` / `exchange` report what ran
@@ -32,8 +34,11 @@ sampling, and (`module`) through the pybind11 module `libgraphvite`, the boundar
 package loads).  `auc` is the link-prediction AUC of a training of THIS configuration (same graph shape, same worker and
 partition count) next to the reference's own loop on the same shape (tests/golden/reference_c2.npz).  `roofline` is for
 the training kernel (HBM-bound): achieved = algorithmic bytes per launch (3088 B per edge-sample at dim 128, k = 1;
-SURVEY.md §8d) / the average launch duration measured with HIP events on the launch stream over the timed region;
-`roofline.kernel` is what the library says it launched (gvk_describe_train).  `cpu_baseline` (N = 1, rank 0) times the
+SURVEY.md §8d; a launch of train_hot_kernel trains batch / `launches_per_step` samples) / the average launch duration
+measured with HIP events on the launch stream over the timed region; `roofline.kernel` is what ran; `roofline.traffic` is null
+unless a PMC summary of the same round's command sits under profiles/ (`traffic_source`).  N > 1 adds
+`single_gpu_same_shards`: the one-GPU rate at the same shard size (`--gpus 1 --partitions N`, run by rank 0 after the
+measurement), so that scaling and the cache effect of smaller shards can be told apart.  `cpu_baseline` (N = 1, rank 0) times the
 reference's own host-compiled arithmetic (oracle/_ref, Hogwild over all host cores) on a bounded sample of the same
 batches — on this workload (configs[1]) and on the BlogCatalog-sized quick-start shape (configs[0]).
 """
@@ -320,6 +325,31 @@ def module_leg(args, world, timeout=240):
     return json.loads(lines[-1])
 
 
+def same_shards_on_one_gpu(args, world, timeout=300):
+    """The one-GPU rate at the shard size of this N-GPU run (`bench.py --gpus 1 --partitions N`, the same steps, in a process
+    of its own on rank 0's GPU while the other ranks wait): the tables of a block then live where they live in the N-GPU run
+    (L2 / Infinity Cache from a few partitions on), so value / (N x this) separates scaling from the cache effect."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--partitions", str(world), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--vertices", str(args.vertices), "--edges", str(args.edges), "--dim", str(args.dim),
+           "--batch", str(args.batch), "--negatives", str(args.negatives), "--seed", str(args.seed), "--fidelity", args.fidelity,
+           "--block-batches", str(args.block_batches), "--no-end-to-end", "--no-cpu-baseline", "--no-module", "--no-access-pattern"]
+    env = dict(os.environ)
+    for name in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK"):
+        env.pop(name, None)
+    env["HIP_VISIBLE_DEVICES"] = os.environ.get("HIP_VISIBLE_DEVICES", "").split(",")[0] or "0"
+    try:
+        run = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after %d s" % timeout}
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    if run.returncode != 0 or not lines:
+        return {"error": "exit code %d: %s" % (run.returncode, run.stderr.strip()[-300:])}
+    r = json.loads(lines[-1])
+    return {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "partitions": world,
+            "kernel": r["roofline"]["kernel"], "shard": r["config"]["shard"],
+            "note": "bench.py --gpus 1 --partitions %d: the same shard size on ONE GPU" % world}
+
+
 # True only inside tests/bench_dry_run.py (the loop's logic on the CPU over the host build of the engine; no command line
 # and no environment variable of bench.py sets it)
 DRY_RUN = False
@@ -499,9 +529,12 @@ def main(argv=None):
     traffic, pmc_path = None, None
     if world == 1 and partitions == 1 and dim == 128 and k == 1 and B == 100000 and N == 1000000 and moments == 0:
         import glob
+        wanted = "train_hot_kernel" if solver.hub_rows else "train_kernel"
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary_bench_n1.json")), reverse=True):
-            traffic, pmc_path = json.load(open(path)).get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT)
-            break
+            summary = json.load(open(path))  # the committed PMC passes of this command — of the kernel this run launched only
+            if wanted in summary.get("kernel", "") and summary.get("launches_per_batch", 1) == launches:
+                traffic, pmc_path = summary.get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT)
+                break
     rows = solver.partition_rows
     kernel_name = solver.kernels.describe_train(dim, args.optimizer, k, False, B, rows)
     if solver.hub_rows:  # gvk_train_episode_hot: the pairs of a part of a batch + the chains of the next part's hub rows in one launch
@@ -570,6 +603,10 @@ def main(argv=None):
         if rank == 0 and not args.no_module:
             torch.cuda.empty_cache()
             result["end_to_end"]["module"] = module_leg(args, world)
+    if world > 1 and cuda:
+        if rank == 0:
+            result["single_gpu_same_shards"] = same_shards_on_one_gpu(args, world)
+        dist.barrier()
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

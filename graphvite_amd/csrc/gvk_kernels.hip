@@ -680,6 +680,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_runs_kernel(const TrainAr
 // work lists are built by hot_list_kernel.
 struct HotArgs {
     const uint32_t *chain_start;  // [chains + 1] offsets of this unit into entries
+    const uint32_t *before_start[2];  // the same of the one or two units before it (null: none): which rows the mirror `to` has missed
     const uint32_t *entries;      // partner row | label << 31 (label 1 = positive)
     const uint32_t *long_list;    // [0] = number of long chains (more than cap entries), then from [4] on a record {chain, first entry, entries, -} each
     const uint32_t *short_list;   // [0] = number of chains of 1 .. cap entries, then from [16] on a record of 16 words each: {chain, entries, -, -, the entries themselves}
@@ -840,29 +841,36 @@ __device__ __forceinline__ void train_short_chains(const TrainArgs &a, const Hot
     if (mine) store_row_at<DIM, G>(h.to + (size_t)chain * DIM, lane, own);
 }
 
-// Hub rows the unit has no entry for pass from mirror to mirror unchanged: block b looks at chains [64 b, 64 b + 64), each
-// lane group at four of them (all four rows requested before the first is stored).
+// Hub rows the unit has no entry for pass from mirror to mirror unchanged — those that need it: the mirror `to` was last
+// written R units ago (R mirrors in rotation), so a row is behind there only if a chain stored it since, i.e. if it had
+// entries in one of the R - 1 units before this one (all mirrors start a call equal).  Block b looks at chains [64 b, 64 b +
+// 64), each lane group at four of them (all four rows requested before the first is stored).
 template <int DIM, int G>
 __device__ __forceinline__ void copy_idle_rows(const HotArgs &h, const uint32_t block) {
     typedef ChainShape<DIM, G> S;
     constexpr int R = 4;
     const int lane = threadIdx.x % G, group = threadIdx.x / G;
     float row[R][S::V];
-    bool idle[R];
+    bool behind[R];
 #pragma unroll
     for (int i = 0; i < R; i++) {
         const uint32_t chain = (block * R + i) * S::NG + group;
-        idle[i] = chain < h.chains && h.chain_start[chain] == h.chain_start[chain + 1];
+        behind[i] = false;
+        if (chain < h.chains && h.chain_start[chain] == h.chain_start[chain + 1]) {
+#pragma unroll
+            for (int v = 0; v < 2; v++)
+                if (h.before_start[v]) behind[i] = behind[i] || h.before_start[v][chain] != h.before_start[v][chain + 1];
+        }
     }
 #pragma unroll
     for (int i = 0; i < R; i++) {
         const uint32_t chain = (block * R + i) * S::NG + group;
-        if (idle[i]) load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, row[i]);
+        if (behind[i]) load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, row[i]);
     }
 #pragma unroll
     for (int i = 0; i < R; i++) {
         const uint32_t chain = (block * R + i) * S::NG + group;
-        if (idle[i]) store_row_at<DIM, G>(h.to + (size_t)chain * DIM, lane, row[i]);
+        if (behind[i]) store_row_at<DIM, G>(h.to + (size_t)chain * DIM, lane, row[i]);
     }
 }
 
@@ -1980,7 +1988,10 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     // when every row of both tables is a hub row the pairs have nothing to store: they run for the last batch only, whose
     // per-sample loss a caller may read
     const bool chains_only = hot_vertex == tables->n_vertex && hot_context == tables->n_context;
-    auto mirror = [&](int u) { return reinterpret_cast<float *>(base + l.mirrors + (size_t)((u + 3) % 3) * l.mirror_bytes); };
+    // mirrors in rotation: the chains of unit u read M[(u - 1) % R] and store to M[u % R], the pairs of unit u read M[u % R] — and,
+    // lerp, M[(u - 1) % R], which the chains of unit u + 1 (same launch) must then not store to: R = 3; else R = 2
+    const int R = lerp ? 3 : 2;
+    auto mirror = [&](int u) { return reinterpret_cast<float *>(base + l.mirrors + (size_t)((u + R) % R) * l.mirror_bytes); };
     auto lr_of = [&](int i) {
         const uint32_t id = first_batch_id + (uint32_t)i * batch_id_stride;
         float scale = 1;
@@ -1996,6 +2007,8 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
         h.long_list = reinterpret_cast<const uint32_t *>(base + l.long_list) + (size_t)u * 4 * (1 + (size_t)l.long_capacity);
         h.short_list = reinterpret_cast<const uint32_t *>(base + l.short_list) + (size_t)u * 16 * (1 + (size_t)l.chains);
         h.from = mirror(u - 1), h.to = mirror(u);
+        for (int v = 0; v < 2; v++)  // the units since M[u % R] was last stored to: u - 1 .. u - R + 1
+            h.before_start[v] = v < R - 1 && u - 1 - v >= 0 ? h.chain_start - (size_t)(v + 1) * (l.chains + 1) : nullptr;
         h.lr = lr_of(u / parts);
         h.log2_decay_positive = (float)std::log2(1.0 - (double)h.lr * a.wd);
         h.log2_decay_negative = (float)std::log2(1.0 - (double)h.lr * a.neg_weight * a.wd);
@@ -2021,9 +2034,11 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
         if (grid) hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, h);
     };
     const unsigned mirror_blocks = (unsigned)(((size_t)l.chains * (size_t)(dim / 4) + kBlock - 1) / kBlock);
-    // the hub rows enter the mirrors: M[-1] = the tables' rows
-    hipLaunchKernelGGL(hub_rows_kernel, dim3(mirror_blocks), dim3(kBlock), 0, (hipStream_t)stream, a.vertex, a.context, mirror(-1),
-                       hot_vertex, hot_context, dim, 1);
+    // the hub rows enter the mirrors: every mirror = the tables' rows (a row without entries is only copied on while a mirror
+    // is behind: copy_idle_rows)
+    for (int m = 0; m < R; m++)
+        hipLaunchKernelGGL(hub_rows_kernel, dim3(mirror_blocks), dim3(kBlock), 0, (hipStream_t)stream, a.vertex, a.context, mirror(m),
+                           hot_vertex, hot_context, dim, 1);
     // A sample's updates to its rows are all computed from the rows as the sample found them (model/graph.h:47-58).  The
     // chains of a unit therefore run BEFORE its pairs: a chain reads the partner rows before the unit's pairs move them
     // towards the hub row (a chain that read them afterwards would compound the step it is about to take — every sample of a

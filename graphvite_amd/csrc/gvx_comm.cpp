@@ -46,7 +46,8 @@ Rccl *rccl() {
         for (const char *name : names)
             if ((lib.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
         if (!lib.handle) {
-            lib.error = std::string("librccl is not loadable: ") + dlerror();
+            const char *why = dlerror();
+            lib.error = std::string("librccl is not loadable: ") + (why ? why : "unknown dlopen error");
             return;
         }
         bool ok = true;

@@ -46,7 +46,7 @@ namespace {
 constexpr int kMaxPartition = 16;  // solver.h:51-57
 constexpr int kMinBatchSize = 10000;
 constexpr int kSamplePerVertex = 175;
-constexpr double kHubHits = 2;          // GVX_HUB_ROWS -1: a row a batch is expected to hit this often is a hub row
+constexpr double kHubHits = 1;          // GVX_HUB_ROWS -1: a row a batch is expected to hit this often is a hub row (§7.10: 2 -> 1 is -0.0016 -> -0.0009 on the headline shape)
 constexpr uint64_t kMaxHubRows = 16384;  // per table (gvk_hot_build counts the chains of both tables in LDS)
 constexpr int kHubChunk = 128;          // batches whose work lists are built at once
 constexpr int kHubEntriesPerPart = 250;  // with hub rows by chains a batch is trained as so many parts that its largest hub row meets about this many of its updates per part
@@ -1608,6 +1608,11 @@ int gvx_solver::stage(Worker &w, int step, int set, int b) {
     } else {
         uint32_t *target = reordered() ? w.landing : w.pool[b];
         HIP_TRY(hipMemcpyAsync(target, host_sets[set][(size_t)hp * P + tp], pool_elems * 4, hipMemcpyHostToDevice, w.copy));
+        // copies that have landed need no event any more (a session stages block after block without the episode loop's drain)
+        while (!w.copied.empty() && hipEventQuery(w.copied.front()) == hipSuccess) {
+            hipEventDestroy(w.copied.front());
+            w.copied.erase(w.copied.begin());
+        }
         hipEvent_t copied;
         HIP_TRY(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(copied, w.copy));
@@ -1979,6 +1984,8 @@ extern "C" int gvx_solver_predict(gvx_solver *s, const int64_t *samples, size_t 
     if (!s || !s->graph) return gvk_fail(GVK_EINVAL, "The model must be built on a graph first");
     if (n == 0) return GVK_OK;
     if (!samples || !logits) return gvk_fail(GVK_EINVAL, "gvx_solver_predict: null pointer");
+    if (s->session_open)  // the tables live in HBM until the session closes: the host tables are those of before the session
+        return gvk_fail(GVK_EINVAL, "predict: a training session is open; close it first (its tables are written back then)");
     std::vector<uint32_t> records(2 * n);
     for (size_t i = 0; i < n; i++) {
         const int64_t v = samples[2 * i], c = samples[2 * i + 1];
@@ -1997,9 +2004,10 @@ extern "C" int gvx_solver_predict(gvx_solver *s, const int64_t *samples, size_t 
     if (hipMalloc(&dv, table) != hipSuccess || hipMalloc(&dc, table) != hipSuccess || hipMalloc(&dl, n * 4) != hipSuccess ||
         hipMalloc(&dp, n * 8) != hipSuccess)
         return done(gvk_fail(GVK_ENOMEM, "predict: out of GPU memory"));
-    hipMemcpy(dv, s->vertex.data(), table, hipMemcpyHostToDevice);
-    hipMemcpy(dc, s->context.data(), table, hipMemcpyHostToDevice);
-    hipMemcpy(dp, records.data(), n * 8, hipMemcpyHostToDevice);
+    if (hipMemcpy(dv, s->vertex.data(), table, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dc, s->context.data(), table, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dp, records.data(), n * 8, hipMemcpyHostToDevice) != hipSuccess)
+        return done(gvk_fail(GVK_EHIP, "predict: copy to the GPU failed"));
     for (size_t start = 0; start < n; start += B) {
         const int rc = gvk_predict(nullptr, s->dim, dv, dc, dp + 2 * start, dl + start, (int)std::min(B, n - start));
         if (rc != GVK_OK) return done(rc);

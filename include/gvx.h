@@ -147,7 +147,7 @@ void gvx_solver_destroy(gvx_solver *s);
  * wavefront per hub row applies all the updates a batch has for the row one after the other, so none of them is lost to a
  * concurrent one.  -2 (default): where that is pinned against the reference's training loop — DeepWalk /
  * node2vec on one partition of at most 16384 rows: every row is a hub row —, off otherwise; -1: the rows a batch is expected
- * to hit twice or more (by degree share; at most 16384 per table); N > 0: the first N rows of every partition; 0: off.
+ * to hit once or more (by degree share; at most 16384 per table); N > 0: the first N rows of every partition; 0: off.
  * Batches keep the sampler's order. */
 #define GVX_HUB_ROWS 6
 /* GVX_HUB_PARTS: with hub rows trained by chains, a batch is trained as this many equal parts (a divisor of the batch size),
@@ -155,7 +155,7 @@ void gvx_solver_destroy(gvx_solver *s);
  * that the largest hub row meets about 250 of its updates per part. */
 #define GVX_HUB_PARTS 7
 /* GVX_FIDELITY -1 (default, `auto`): the reference's learning quality wherever chains exist — on tables that do not live in
- * the caches, the rows a batch is expected to hit twice or more are trained by chains (GVX_HUB_ROWS -1) and a batch as so many
+ * the caches, the rows a batch is expected to hit once or more are trained by chains (GVX_HUB_ROWS -1) and a batch as so many
  * parts that the largest hub row meets about 250 of its updates per part (eight on the headline shape): link-prediction AUC
  * within 0.002 of the reference's sequential loop there; the moment optimizers have no chains: they train every
  * row pair by pair and say so once.  1 (`reference`): the same, but a

@@ -87,7 +87,7 @@ for dim in (32, 64, 96, 128, 256, 512):
     entry = {"kernel": kernel, "FETCH_SIZE": fetch["FETCH_SIZE"], "WRITE_SIZE": write["WRITE_SIZE"],
              "hbm_read_bytes_per_launch_corrected": 2 * f, "hbm_write_bytes_per_launch": w,
              "traffic_bytes_per_launch": 2 * f + w, "algorithmic_bytes_per_launch": algorithmic,
-             "traffic_over_algorithmic": (2 * f + w) / algorithmic}
+             "launches_per_batch": LAUNCHES if dim == 128 else 1, "traffic_over_algorithmic": (2 * f + w) / algorithmic}
     if dim == 128:
         l2, _ = counters("pmc_L2_128")
         if "TCC_HIT_sum" in l2:

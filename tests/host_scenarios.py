@@ -121,7 +121,7 @@ def hub_row_rules():
         s = gv.solver.GraphSolver(32, num_sampler_per_worker=2, seed=1, **kw)
         s.build(g, batch_size=1000, episode_size=4)
         s.train(model=model, num_epoch=2, augmentation_step=1 if model == "LINE" else 2, log_frequency=1 << 30)
-        if want is None:  # rows a 1000-sample batch is expected to hit twice: a few dozen of 2000, the same for both requests
+        if want is None:  # rows a 1000-sample batch is expected to hit once or more: some dozens of 2000, the same for both requests
             assert 0 < s.hub_rows < g.num_vertex // 4, (name, s.hub_rows)
             trained.setdefault("expected hits", s.hub_rows)
             assert trained["expected hits"] == s.hub_rows

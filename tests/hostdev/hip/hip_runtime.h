@@ -55,6 +55,7 @@ inline hipError_t hipEventCreate(hipEvent_t *e) { return hipEventCreateWithFlags
 inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 1.0f; return hipSuccess; }
 inline hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = 1; return hipSuccess; }
 inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
