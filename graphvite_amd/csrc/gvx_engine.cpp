@@ -46,7 +46,7 @@ namespace {
 constexpr int kMaxPartition = 16;  // solver.h:51-57
 constexpr int kMinBatchSize = 10000;
 constexpr int kSamplePerVertex = 175;
-constexpr double kHubHits = 1;          // GVX_HUB_ROWS -1: a row a batch is expected to hit this often is a hub row (§7.10: 2 -> 1 is -0.0016 -> -0.0009 on the headline shape)
+constexpr double kHubHitsPerPart = 0.125;  // GVX_HUB_ROWS -1: a row a PART of a batch is expected to hit this often is a hub row (§7.10)
 constexpr uint64_t kMaxHubRows = 16384;  // per table (gvk_hot_build counts the chains of both tables in LDS)
 constexpr int kHubChunk = 128;          // batches whose work lists are built at once
 constexpr int kHubEntriesPerPart = 250;  // with hub rows by chains a batch is trained as so many parts that its largest hub row meets about this many of its updates per part
@@ -760,20 +760,22 @@ int gvx_solver::configure(const gvx_train_config &in) {
     grouped = pair_order_request == 2 ||
               (pair_order_request == 0 && dim >= 64 && !walk_ordered() &&
                (table_bytes < ((size_t)16 << 20) || (table_bytes < ((size_t)256 << 20) && mode == GVS_MODE_EDGE)));
-    // hub rows (GVX_HUB_ROWS): the rows a batch is expected to hit kHubHits times or more — as a head / tail (degree share of
+    // hub rows (GVX_HUB_ROWS): the rows a part of a batch is expected to hit kHubHitsPerPart times or more — as a head / tail (degree share of
     // the partition) or as a negative (share of degree^exponent) — are trained by chains; their batches keep the sampler's order
     hub_rows.assign(num_partition, 0);
     hub_top_entries.assign(num_partition, 0);
     hubs = false;
     // the default rule (-2): every row of the walk-ordered pools of DeepWalk / node2vec on one partition of at most kMaxHubRows
-    // rows; else the rows a batch is expected to hit kHubHits times — on tables that do not live in the caches
+    // rows; else the rows a part of a batch is expected to hit kHubHitsPerPart times — on tables that do not live in the caches
     // (smaller ones are regrouped and trained as runs of same-head samples, §3.1.1, pinned against the reference's loop the
     // same way); GVX_FIDELITY 0: none, every row pair by pair (Hogwild)
     int64_t request = hub_rows_request;
+    // a cache-resident LINE table gets chains, too, where its hottest row leaves that feasible (below): else runs, as before
+    const bool small_table = hub_rows_request == -2 && fidelity == -1 && !walk_ordered() && table_bytes < ((size_t)16 << 20);
     if (request == -2) {
-        if (fidelity == 0) request = 0;
+        if (fidelity == 0 || (fidelity == -1 && pair_order_request == 2)) request = 0;  // "grouped" asked for: regrouped batches, no chains
         else if (walk_ordered() && num_partition == 1 && part_rows <= kMaxHubRows) request = (int64_t)part_rows;
-        else request = walk_ordered() || table_bytes >= ((size_t)16 << 20) || fidelity == 1 ? -1 : 0;
+        else request = -1;
     }
     // chains apply SGD updates (a row's update composes in closed form), under any schedule; the moment optimizers have none:
     // asked for explicitly that is an error, by default it is said once
@@ -797,21 +799,41 @@ int gvx_solver::configure(const gvx_train_config &in) {
             } else {
                 double total = 0, total_negative = 0;
                 for (uint32_t id : ids) total += vertex_weights[id], total_negative += std::pow((double)vertex_weights[id], (double)c.negative_sample_exponent);
+                // the largest row: the head of batch_size * share samples, (num_negative + 1) chain entries each -> the parts a
+                // batch of this partition's blocks is trained as (hub_parts_of)
+                if (!ids.empty())
+                    hub_top_entries[p] = (int)std::min(1e9, (double)batch_size * (num_negative + 1) * vertex_weights[ids[0]] / std::max(total, 1e-30));
+                const int parts = std::min(std::max((hub_top_entries[p] + kHubEntriesPerPart / 2) / kHubEntriesPerPart, 1), kHubMaxParts);
+                // A row a batch hits h times meets another of its hits inside a part with probability ~ h / parts, and of two
+                // concurrent updates one is lost: the rows a PART is expected to hit kHubHitsPerPart times or more are hub rows
+                // (one hit per batch at the eight parts of the headline shape, §7.10; four at the 32 parts of its P = 4 blocks)
+                const double hits = kHubHitsPerPart * parts;
                 for (uint32_t id : ids) {  // falling degree: stop at the first row below both thresholds
                     const double w = vertex_weights[id];
-                    const bool often = batch_size * w >= kHubHits * total ||
-                                       (double)batch_size * num_negative * std::pow(w, (double)c.negative_sample_exponent) >= kHubHits * total_negative;
+                    const bool often = batch_size * w >= hits * total ||
+                                       (double)batch_size * num_negative * std::pow(w, (double)c.negative_sample_exponent) >= hits * total_negative;
                     if (!often) break;
                     rows++;
                 }
             }
             hub_rows[p] = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(rows, ids.size()), kMaxHubRows);
-            if (!ids.empty()) {  // the head of batch_size * share samples, (num_negative + 1) chain entries each
+            if (request > 0 && !ids.empty()) {
                 double total = 0;
                 for (uint32_t id : ids) total += vertex_weights[id];
                 hub_top_entries[p] = (int)std::min(1e9, (double)batch_size * (num_negative + 1) * vertex_weights[ids[0]] / std::max(total, 1e-30));
             }
             hubs = hubs || hub_rows[p] > 0;
+        }
+        // Chains need so many parts that the largest hub row meets about kHubEntriesPerPart of its updates per part (tasks of one
+        // chain run side by side from the same start: with thousands of entries per part their steps add up and the row
+        // overshoots — a 6 250-row partition of a 100k-node graph at P = 16 diverges).  Where that takes more than
+        // kHubMaxParts parts a cache-resident table keeps regrouping + runs (§3.1.1, pinned at P = 8 / 16 in §7.8).
+        if (small_table && hubs) {
+            const int worst = *std::max_element(hub_top_entries.begin(), hub_top_entries.end());
+            if ((worst + kHubEntriesPerPart - 1) / kHubEntriesPerPart > kHubMaxParts) {
+                hub_rows.assign(num_partition, 0);
+                hubs = false;
+            }
         }
         if (hubs) grouped = false;
     }
@@ -1495,18 +1517,17 @@ int gvx_solver::hub_parts_of(int hp, int tp) const {
     const uint32_t kv = hubs ? hub_rows[hp] : 0, kc = hubs ? hub_rows[tp] : 0;
     if (kv + kc == 0) return 1;
     if (hub_parts_request > 0 && B % hub_parts_request == 0) return hub_parts_request;
-    // a small table — every row a hub row, many samples per row and batch — is trained as the parts gvk_train_launches
-    // prescribes for it (§7.8): a chain then sees its partners at most a part old
-    int parts = kv == part_rows && kc == part_rows ? gvk_train_launches(B, part_rows) : 1;
-    if (parts == 1) {
-        // so many parts that the largest hub row meets about kHubEntriesPerPart of its updates per part (DESIGN.md §3.1.2,
-        // §7.10), a divisor of the batch size, at most kHubMaxParts
-        const int want = std::min(std::max((std::max(hub_top_entries[hp], hub_top_entries[tp]) + kHubEntriesPerPart / 2) / kHubEntriesPerPart, 1), kHubMaxParts);
-        for (int q = want; q <= 2 * want && parts == 1 && want > 1; q++)
-            if (B % q == 0) parts = q;
-        for (int q = want; q >= 2 && parts == 1; q--)
-            if (B % q == 0) parts = q;
-    }
+    // so many parts that the largest hub row meets about kHubEntriesPerPart of its updates per part —
+    // and, where every row is a hub row (a small table: many samples per row and batch), at least the parts
+    // gvk_train_launches prescribes for it (§7.8: a chain then sees its partners at most a part old) —, a divisor of the
+    // batch size, at most kHubMaxParts
+    int want = std::min(std::max((std::max(hub_top_entries[hp], hub_top_entries[tp]) + kHubEntriesPerPart / 2) / kHubEntriesPerPart, 1), kHubMaxParts);
+    if (kv == part_rows && kc == part_rows) want = std::max(want, gvk_train_launches(B, part_rows));
+    int parts = 1;
+    for (int q = want; q <= 2 * want && parts == 1 && want > 1; q++)
+        if (B % q == 0) parts = q;
+    for (int q = want; q >= 2 && parts == 1; q--)
+        if (B % q == 0) parts = q;
     return parts;
 }
 

@@ -113,7 +113,7 @@ def hub_row_rules():
     kernels are sequential — what chains restore — so the trained tables must not depend on the choice."""
     g = make_graph(n=2000, e=30000)
     trained = {}
-    for name, kw, model, want in (("default, LINE", {}, "LINE", 0), ("off", dict(hub_rows=0), "DeepWalk", 0),
+    for name, kw, model, want in (("default, LINE", {}, "LINE", None), ("off", dict(hub_rows=0), "DeepWalk", 0),
                                   ("default, DeepWalk: every row", {}, "DeepWalk", g.num_vertex),
                                   ("by expected hits", dict(hub_rows="auto"), "LINE", None), ("given", dict(hub_rows=100), "LINE", 100),
                                   ("more than there are", dict(hub_rows=10 ** 6), "LINE", g.num_vertex),
@@ -121,8 +121,8 @@ def hub_row_rules():
         s = gv.solver.GraphSolver(32, num_sampler_per_worker=2, seed=1, **kw)
         s.build(g, batch_size=1000, episode_size=4)
         s.train(model=model, num_epoch=2, augmentation_step=1 if model == "LINE" else 2, log_frequency=1 << 30)
-        if want is None:  # rows a 1000-sample batch is expected to hit once or more: some dozens of 2000, the same for both requests
-            assert 0 < s.hub_rows < g.num_vertex // 4, (name, s.hub_rows)
+        if want is None:  # rows a part of a batch (here: the 1000-sample batch) is expected to hit 0.125 times or more: most of 2000
+            assert 0 < s.hub_rows < g.num_vertex, (name, s.hub_rows)
             trained.setdefault("expected hits", s.hub_rows)
             assert trained["expected hits"] == s.hub_rows
         else:
@@ -147,7 +147,7 @@ def hub_row_rules():
     s = gv.solver.GraphSolver(32, num_sampler_per_worker=2, seed=1)
     s.build(g, batch_size=1000, episode_size=4, num_partition=2)
     s.train(model="DeepWalk", num_epoch=1, augmentation_step=2, log_frequency=1 << 30)
-    assert 0 < s.hub_rows < g.num_vertex // 2
+    assert 0 < s.hub_rows <= g.num_vertex // 2  # per partition (1000 rows each)
     # moment optimizers have no chains: by default every row is trained pair by pair (and the log says so), asked for
     # explicitly — hub_rows / fidelity="reference" — it is an error
     s = gv.solver.GraphSolver(32, num_sampler_per_worker=2, seed=1)
@@ -247,7 +247,7 @@ def models_and_samplers(model, aug):
     assert s.batch_id % 8 == 0 and s.batch_id >= s.num_batch  # episodes of 4 x reuse 2
     assert np.abs(s.context_embeddings).max() > 0
     if model != "LINE":
-        assert s.shuffle_base == 1 and s.pair_order == "sampled"  # walk-ordered pools are trained as they come
+        assert s.shuffle_base == 1 and s.pair_order in ("sampled", "spread")  # walk-ordered pools: as they come where chains own every row, else spread over the launches
     s.node2vec_table_limit = 10  # force the O(|E|)-memory sampler
     s.train("node2vec", num_epoch=2, augmentation_step=2, random_walk_length=8, random_walk_batch_size=5, p=0.5, q=2.0)
     assert s._mode == "biased_reject" and np.abs(s.context_embeddings).max() > 0

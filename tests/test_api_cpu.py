@@ -128,7 +128,7 @@ def test_bench_loop_dry_run(world, partitions, order):
         assert r["exchange"]["transport"] == "caller-supplied transport"
     else:
         assert r["exchange"] is None
-    assert r["config"]["block_visits_timed"] == 6 and r["roofline"]["kernel"].startswith("host build")
+    assert r["config"]["block_visits_timed"] == 6 and r["roofline"]["kernel"].startswith(("host build", "train_hot_kernel"))
 
 
 def test_bench_rounds_a_multi_gpu_run_up_to_whole_block_visits():
@@ -216,3 +216,31 @@ def test_another_kernel_library_is_a_test_switch():
     run = subprocess.run([sys.executable, "-c", "import graphvite_amd; from graphvite_amd import _lib; print(_lib.LIB_PATH)"],
                          cwd=root, capture_output=True, text=True, env=env)
     assert run.returncode == 0 and run.stdout.strip() == host, run.stderr[-2000:]
+
+
+def test_node_classification_matches_the_reference_routine():
+    """f2: the scoring of GraphApplication.node_classification — one-vs-rest logistic regression on frozen
+    embeddings, SGD(lr 1, weight decay 2e-5, momentum 0.9) until the loss has not improved for `patience` epochs, a test node
+    with n true labels assigned its n top-scoring classes, macro / micro F1 — against the REFERENCE's own routine
+    (python/graphvite/application/application.py:456-533 + application/network.py, imported where they lie by
+    tests/golden/make_application_golden.py -> reference_application.npz) on the same embeddings and labels, the same split
+    (numpy seed) and the same initial weights (torch seed): F1 within 0.005 for every (portion, normalization)."""
+    import os
+    import torch
+    from graphvite_amd.application.application import linear_classification
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_application.npz"))
+    times, patience, seed = [int(x) for x in G["times_patience_seed"]]
+    rng = np.random.default_rng(5)  # tests/golden/make_application_golden.py fixed_problem()
+    n, dim, classes = 600, 32, 4
+    membership = rng.random((n, classes)) < 0.3
+    membership[np.arange(n), rng.integers(0, classes, n)] = True
+    centres = rng.normal(0, 1, (classes, dim))
+    embeddings = (membership.astype(np.float64) @ centres + rng.normal(0, 2.5, (n, dim))).astype(np.float32)
+    labels = membership.astype(np.int64)
+    for i, (portion, normalization) in enumerate(G["cases"]):
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        got = linear_classification(embeddings, labels, float(portion), bool(normalization), times, patience)
+        macro, micro = G["f1_%d" % i]
+        assert abs(got["macro-F1@%g%%" % (portion * 100)] - macro) <= 0.005, (portion, normalization, got, macro)
+        assert abs(got["micro-F1@%g%%" % (portion * 100)] - micro) <= 0.005, (portion, normalization, got, micro)

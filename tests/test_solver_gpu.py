@@ -164,7 +164,7 @@ def test_walk_models_at_youtube_scale_match_the_reference_training_loop(name, sa
     g = gv.graph.Graph()
     g.load(train)
     aucs = []
-    for seed in [int(x) for x in G["tube_seeds"]][:3 if partitions == 1 else 2]:
+    for seed in [int(x) for x in G["tube_seeds"]][:3]:
         s = gv.solver.GraphSolver(128, num_sampler_per_worker=8, seed=seed, device_sampling=sampling == "device")
         if sampling == "rejection":
             s.node2vec_table_limit = 0
@@ -223,12 +223,11 @@ def test_hub_heavy_shapes_match_the_reference_training_loop(shape):
     batch of 100 000 — every batch hits a hub row hundreds of times, which is where execution order decides what is
     learned.  The two pipelines share no random stream, so means over seeds are compared.
 
-    * the product as shipped — the cache-resident "blog" tables regrouped and trained as runs of up to 20 same-head samples;
-      the 51 MB tables of "hub100k" in the sampler's order, hub rows by chains and a batch as parts:
-      link-prediction AUC within +-0.002 of the sequential reference;
-    * with pair_order forced to the other value ("blog" pair by pair in sampler order; "hub100k" regrouped — its hub rows are
-      still trained by chains) it stays inside the bracket the reference's own models span, 0.002 around
-      [chunk-synchronous, sequential];
+    * the product as shipped — both in the sampler's order, hub rows by chains and a batch as parts: on
+      "blog" nearly every row is a hub row, on the 51 MB tables of "hub100k" the 16 384 largest: link-prediction AUC within
+      +-0.002 of the sequential reference;
+    * with pair_order="grouped" asked for (the hub rows are still trained by chains) the same bracket around the reference's own
+      models, 0.002 around [chunk-synchronous, sequential];
     * and the product is never below the chunk-synchronous models: what a lock-step launch loses, it does not."""
     train, test, build, fit, golden = _hub_shape(shape)
     sequential, floor = golden["sequential"].mean(), min(golden["lock_step"].mean(), golden["reads_at_start"].mean())
@@ -238,7 +237,7 @@ def test_hub_heavy_shapes_match_the_reference_training_loop(shape):
     print("%s: reference loop sequential %.6f | lock step %.6f | reads at start %.6f || here auto (%s) %.6f +- %.6f | "
           "%s %.6f" % (shape, sequential, golden["lock_step"].mean(), golden["reads_at_start"].mean(),
                       solver.pair_order, default.mean(), default.std(), other_order, other.mean()))
-    assert solver.pair_order == ("grouped" if shape == "blog" else "sampled") and (solver.hub_rows > 0) == (shape == "hub100k")
+    assert solver.pair_order == "sampled" and solver.hub_rows > 0
     assert abs(default.mean() - sequential) <= 0.002
     assert floor - 0.002 <= other.mean() <= sequential + 0.002
     assert default.mean() >= floor
@@ -543,13 +542,16 @@ def test_headline_shape_matches_the_reference_training_loop():
     keep = (name2id[H] >= 0) & (name2id[T] >= 0)
     aucs = {}
     for name, kw in (("default", {}), ("default, device sampling", dict(device_sampling=True)), ("throughput", dict(fidelity="throughput"))):
-        s = gv.solver.GraphSolver(128, num_sampler_per_worker=8, seed=graph_seed, **kw)
-        s.build(g, batch_size=batch)
-        assert s.episode_size in (episode, episode + 1)  # the reference's automatic size for this graph (solver.h:426-436)
-        s.train(model="LINE", num_epoch=epochs, augmentation_step=1, log_frequency=1 << 30)
-        assert (s.hub_rows > 0) == (name != "throughput")
-        aucs[name] = link_prediction_auc(s.vertex_embeddings, s.context_embeddings, name2id[H[keep]], name2id[T[keep]], Y[keep])
-        s.clear()
+        values = []
+        for seed in (graph_seed, 5, 6) if name != "throughput" else (graph_seed,):  # seeds differ by +-0.0005: means are compared
+            s = gv.solver.GraphSolver(128, num_sampler_per_worker=8, seed=seed, **kw)
+            s.build(g, batch_size=batch)
+            assert s.episode_size in (episode, episode + 1)  # the reference's automatic size for this graph (solver.h:426-436)
+            s.train(model="LINE", num_epoch=epochs, augmentation_step=1, log_frequency=1 << 30)
+            assert (s.hub_rows > 0) == (name != "throughput")
+            values.append(link_prediction_auc(s.vertex_embeddings, s.context_embeddings, name2id[H[keep]], name2id[T[keep]], Y[keep]))
+            s.clear()
+        aucs[name] = float(np.mean(values))
     print("headline shape: AUC default %.6f, with device sampling %.6f, fidelity='throughput' %.6f | reference training loop %s "
           "(mean %.6f), its lock-step model %.6f" % (aucs["default"], aucs["default, device sampling"], aucs["throughput"],
                                                       " ".join("%.6f" % a for a in reference), reference.mean(),
@@ -581,12 +583,15 @@ def test_headline_shape_in_partitions_matches_the_reference_training_loop(partit
     names = np.array([int(x) for x in g.id2name], np.int64)
     name2id[names] = np.arange(len(names))
     keep = (name2id[H] >= 0) & (name2id[T] >= 0)
-    s = gv.solver.GraphSolver(128, num_sampler_per_worker=8, seed=graph_seed, device_sampling=device_sampling)
-    s.build(g, batch_size=batch, num_partition=partitions, episode_size=episode or gv.auto)
-    s.train(model="LINE", num_epoch=epochs, augmentation_step=1, log_frequency=1 << 30)
-    assert s.num_partition == partitions and s.hub_rows > 0
-    auc = link_prediction_auc(s.vertex_embeddings, s.context_embeddings, name2id[H[keep]], name2id[T[keep]], Y[keep])
-    print("headline shape, %d partitions, episode %d%s: %d batches, a batch as up to %d parts: AUC %.6f | reference training loop %s "
-          "(mean %.6f)" % (partitions, s.episode_size, ", device sampling" if device_sampling else "", s.batch_id, s.hub_parts_used,
-                           auc, " ".join("%.6f" % a for a in reference), reference.mean()))
-    assert abs(auc - reference.mean()) <= 0.002
+    aucs = []
+    for seed in (graph_seed, 5):  # means are compared (the reference's goldens: two seeds)
+        s = gv.solver.GraphSolver(128, num_sampler_per_worker=8, seed=seed, device_sampling=device_sampling)
+        s.build(g, batch_size=batch, num_partition=partitions, episode_size=episode or gv.auto)
+        s.train(model="LINE", num_epoch=epochs, augmentation_step=1, log_frequency=1 << 30)
+        assert s.num_partition == partitions and s.hub_rows > 0
+        aucs.append(link_prediction_auc(s.vertex_embeddings, s.context_embeddings, name2id[H[keep]], name2id[T[keep]], Y[keep]))
+    print("headline shape, %d partitions, episode %d%s: %d batches, a batch as up to %d parts: AUC %s (mean %.6f) | reference training "
+          "loop %s (mean %.6f)" % (partitions, s.episode_size, ", device sampling" if device_sampling else "", s.batch_id,
+                                   s.hub_parts_used, " ".join("%.6f" % a for a in aucs), np.mean(aucs),
+                                   " ".join("%.6f" % a for a in reference), reference.mean()))
+    assert abs(np.mean(aucs) - reference.mean()) <= 0.002
