@@ -984,8 +984,8 @@ int gvx_solver::prepare_devices() {
             }
         }
     }
+    GVK_TRY(prepare_comm());  // before the pools: ranks agree on the episode size through it
     GVK_TRY(allocate_pools());
-    GVK_TRY(prepare_comm());
     const size_t n = (size_t)episode_size * batch_size;
     for (Worker &w : workers) {
         if (!w.block_pools[0]) break;
@@ -1006,6 +1006,7 @@ int gvx_solver::prepare_devices() {
 int gvx_solver::allocate_pools() {
     const int W = num_worker;
     const bool in_hbm = device_sampling || resident_pools || routed();
+    bool agreed = !distributed || W == 1 || !comm;  // one process per GPU: every rank must end with the same episode size
     while (true) {
         bool ok = true;
         const size_t bytes = (size_t)episode_size * batch_size * 8;
@@ -1017,13 +1018,42 @@ int gvx_solver::allocate_pools() {
                 ok = ok && (!in_hbm || hipMalloc(&pools, w.tails.size() * num_partition * bytes) == hipSuccess);
             if (!ok) break;
         }
+        auto release_pools = [&]() {
+            for (Worker &w : workers) {
+                hipSetDevice(w.device);
+                hipFree(w.pool[0]), hipFree(w.pool[1]), hipFree(w.landing), hipFree(w.block_pools[0]), hipFree(w.block_pools[1]);
+                w.pool[0] = w.pool[1] = w.landing = w.block_pools[0] = w.block_pools[1] = nullptr;
+            }
+        };
+        if (ok && !agreed) {
+            // a rank with less free memory has halved further: the smallest size any rank settled on is everyone's (ranks with
+            // different episode sizes would issue collectives of different sizes and hang)
+            Worker &w = workers[0];
+            int32_t *sizes = nullptr;
+            HIP_TRY(hipMalloc(&sizes, (size_t)W * 4));
+            std::vector<int32_t> host(W, 0);
+            host[w.rank] = episode_size;
+            HIP_TRY(hipMemcpyAsync(sizes, host.data(), (size_t)W * 4, hipMemcpyHostToDevice, w.exchange));
+            const int rc = comm->all_gather({{w.rank, w.device, w.exchange}}, {sizes}, 4);
+            if (rc == GVK_OK) HIP_TRY(hipMemcpyAsync(host.data(), sizes, (size_t)W * 4, hipMemcpyDeviceToHost, w.exchange));
+            if (rc == GVK_OK) HIP_TRY(hipStreamSynchronize(w.exchange));
+            hipFree(sizes);
+            GVK_TRY(rc);
+            agreed = true;
+            const int smallest = *std::min_element(host.begin(), host.end());
+            if (smallest < episode_size) {
+                log_message(1, "Another worker fits an episode size of %d only. Use %d instead of %d.", smallest, smallest, episode_size);
+                release_pools();
+                episode_size = smallest;
+                make_info();
+                continue;
+            }
+        }
         if (ok) break;
         (void)hipGetLastError();
-        for (Worker &w : workers) {
-            hipSetDevice(w.device);
-            hipFree(w.pool[0]), hipFree(w.pool[1]), hipFree(w.landing), hipFree(w.block_pools[0]), hipFree(w.block_pools[1]);
-            w.pool[0] = w.pool[1] = w.landing = w.block_pools[0] = w.block_pools[1] = nullptr;
-        }
+        release_pools();
+        if (agreed && distributed && W > 1 && comm)  // the size every rank agreed on does not fit after all: no second round (the others have left)
+            return gvk_fail(GVK_ENOMEM, "Out of GPU memory for the episode size of %d the workers agreed on", episode_size);
         if (episode_size <= 1)
             return gvk_fail(GVK_ENOMEM, "Out of GPU memory. Try to reduce the size of your graph or the dimension of your embeddings.");
         // the halved episode keeps what configure() checked: a whole number of shuffle bases per pool — per slice, when

@@ -47,11 +47,11 @@ for config in extra.get("configs", "hub=0").split(";"):
     for seed in [int(x) for x in extra.get("seeds", "3").split(",")]:
         t0 = time.time()
         hub = kw.get("hub", "0")
-        s = gv.solver.GraphSolver(128, num_sampler_per_worker=6, seed=seed, hub_rows=hub if hub == "auto" else int(hub),
+        s = gv.solver.GraphSolver(128, num_sampler_per_worker=6, seed=seed, hub_rows=None if hub == "default" else (hub if hub == "auto" else int(hub)),
                                   pair_order=kw.get("order", "sampled") if kw.get("order", "sampled") != "auto" else gv.auto)
         s.hub_parts, s.hub_chain_cap = int(kw.get("parts", 0)), int(kw.get("cap", 0))
         s.hub_lerp = None if "lerp" not in kw else bool(int(kw["lerp"]))
-        s.build(g, batch_size=B, episode_size=int(kw.get("episode", 20)))
+        s.build(g, batch_size=B, episode_size=int(kw.get("episode", 20)), num_partition=int(kw.get("partitions", 0)))
         s.train(model="LINE", num_epoch=int(extra.get("epochs", 50)), augmentation_step=1, log_frequency=1 << 30)
         aucs.append(link_prediction_auc(s.vertex_embeddings, s.context_embeddings, name2id[H[keep]], name2id[T[keep]], Y[keep]))
         print("    seed %d: AUC %.6f (%d batches, %.0f s)" % (seed, aucs[-1], s.batch_id, time.time() - t0), flush=True)
