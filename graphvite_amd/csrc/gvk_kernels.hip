@@ -693,7 +693,20 @@ struct HotArgs {
     float log2_decay_positive, log2_decay_negative;  // log2(1 - lr wd), log2(1 - lr negative_weight wd): decay of an entry by label
     int order, pair_blocks;       // grid order (0: chains first, 1: long chains, pairs, the other chains, 2: pairs first)
     int long_blocks, short_blocks, copy_blocks;  // grid: [long chains | chains of 1 .. cap entries, kBlock / G per block | rows without entries | pairs]
+#if defined(GVK_TIMESTAMPS)  // measurement build (make ts): where the time of a launch goes, eight 100 MHz stamps per workgroup
+    unsigned long long *stamps;
+#endif
 };
+
+// Measurement build only (make -C graphvite_amd/csrc ts -> build/ts/libgvk_ts.so, scripts/experiments/stamps.py): thread 0 of
+// every workgroup of a train_hot_kernel launch leaves eight words — its role and the 100 MHz clock at the points of its path.
+#if defined(GVK_TIMESTAMPS)
+#define GVK_STAMP(h, slot) do { if ((h).stamps && threadIdx.x == 0) (h).stamps[(size_t)blockIdx.x * 8 + (slot)] = (unsigned long long)wall_clock64(); } while (0)
+#define GVK_STAMP_VALUE(h, slot, value) do { if ((h).stamps && threadIdx.x == 0) (h).stamps[(size_t)blockIdx.x * 8 + (slot)] = (unsigned long long)(value); } while (0)
+#else
+#define GVK_STAMP(h, slot) do { } while (0)
+#define GVK_STAMP_VALUE(h, slot, value) do { } while (0)
+#endif
 
 template <int DIM, int G>
 struct ChainShape {
@@ -830,6 +843,8 @@ __device__ __forceinline__ void train_short_chains(const TrainArgs &a, const Hot
     const uint32_t word0 = record[lane % LW], word1 = LW < 16 ? record[8 + lane % LW] : 0;
     const uint32_t count = h.short_list[0] < h.chains ? h.short_list[0] : h.chains;
     if (block * S::NG >= count) return;  // the whole block at once
+    GVK_STAMP_VALUE(h, 0, 2);
+    GVK_STAMP(h, 2);  // the record is here
     auto word = [&](const int i) __attribute__((always_inline)) -> uint32_t {
         return (uint32_t)(i < LW ? __shfl((int)word0, i, G) : __shfl((int)word1, i - LW, G));
     };
@@ -838,6 +853,7 @@ __device__ __forceinline__ void train_short_chains(const TrainArgs &a, const Hot
     float own[S::V];
     load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, own);
     short_steps<DIM, G>(a, h, chain, n, lane, own, [&](const int i) __attribute__((always_inline)) { return word(4 + i); });
+    GVK_STAMP(h, 5);  // steps done
     if (mine) store_row_at<DIM, G>(h.to + (size_t)chain * DIM, lane, own);
 }
 
@@ -897,6 +913,11 @@ __device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotA
     for (uint32_t j = block; j < count; j += (uint32_t)h.long_blocks) {
         if (j != block) record = *reinterpret_cast<const u32x4 *>(h.long_list + 4 + 4 * (size_t)j);
         const uint32_t chain = record.x, first = record.y, n = record.z, last = first + n;
+        if (j == block) {
+            GVK_STAMP_VALUE(h, 0, 1);
+            GVK_STAMP(h, 2);  // the record is here
+            GVK_STAMP_VALUE(h, 7, n);
+        }
         // NG tasks at most: a longer chain gets longer tasks
         uint32_t per = h.cap;
         if ((uint64_t)per * NG < n) per = (n + NG - 1) / NG;
@@ -912,6 +933,7 @@ __device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotA
         const float pi = group_count<G>(inside);
         if (lane == 0) positives[group] = pi;
         __syncthreads();
+        if (j == block) GVK_STAMP(h, 3);  // own row and the task's entries are here
         float pb = 0, pa = 0;
         for (uint32_t t = 0; t < tasks; t++) {
             const float x = positives[t];
@@ -933,7 +955,9 @@ __device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotA
             for (int x = 0; x < V; x++) own[x] *= after_;
             store_row_at<DIM, G>(&ends[group][0], lane, own);
         }
+        if (j == block) GVK_STAMP(h, 4);  // this task's steps are done
         __syncthreads();
+        if (j == block) GVK_STAMP(h, 5);  // every task's steps are done
         if (group == 0) {
             float sum[V], row0[V];
             load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, row0);
@@ -948,6 +972,7 @@ __device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotA
             store_row_at<DIM, G>(h.to + (size_t)chain * DIM, lane, sum);
         }
         __syncthreads();
+        if (j == block) GVK_STAMP(h, 6);  // composed and stored
     }
 }
 
@@ -961,13 +986,17 @@ __global__ void __launch_bounds__(kBlock, DIM / G > 12 ? 3 : 4) train_hot_kernel
     // the grid: [long chains | pairs | short chains | idle rows] — the long chains, whose tasks wait for memory three times in
     // a row, are dispatched first, the bulk (the pairs) next; the short chains and the copies fill in behind
     const int b = blockIdx.x;
+    GVK_STAMP_VALUE(h, 0, 0);
+    GVK_STAMP(h, 1);  // the workgroup starts
     const int pairs_first = h.order == 2 ? 0 : (h.order == 1 ? h.long_blocks : h.long_blocks + h.short_blocks + h.copy_blocks);
     const int long_first = h.order == 2 ? h.pair_blocks : 0;
     const int short_first = h.order == 0 ? h.long_blocks : h.long_blocks + h.pair_blocks;
     if (b >= long_first && b < long_first + h.long_blocks) {
         train_long_chains<DIM, G>(a, h, b - long_first);
     } else if (b >= pairs_first && b < pairs_first + h.pair_blocks) {
+        GVK_STAMP_VALUE(h, 0, 3);
         train_pair<DIM, G, GVK_SGD, KT, 1, HOT>(a, (b - pairs_first) * kBlock + threadIdx.x);
+        GVK_STAMP(h, 5);  // thread 0's sample is trained (its stores are on their way)
     } else if (b >= short_first && b < short_first + h.short_blocks) {
         train_short_chains<DIM, G>(a, h, b - short_first);
     } else {
@@ -2024,6 +2053,12 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
         a.hub_step = 1.0f / (float)part_size;
         return !chains_only || i == num_batches - 1;
     };
+#if defined(GVK_TIMESTAMPS)
+    static unsigned long long *stamps = nullptr;
+    constexpr size_t kStampBlocks = 8192;
+    if (!stamps && hipMalloc(&stamps, kStampBlocks * 64) != hipSuccess) stamps = nullptr;
+    h.stamps = stamps;
+#endif
     auto launch = [&](bool with_chains, bool with_pairs) {
         h.long_blocks = with_chains ? long_blocks : 0;
         h.short_blocks = with_chains ? short_blocks : 0;
@@ -2031,7 +2066,29 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
         h.pair_blocks = with_pairs ? (int)pair_blocks : 0;
         h.order = g_hot_order;
         const unsigned grid = (unsigned)(h.long_blocks + h.short_blocks + h.copy_blocks + h.pair_blocks);
+#if defined(GVK_TIMESTAMPS)
+        h.stamps = grid > kStampBlocks ? nullptr : stamps;
+        if (h.stamps && hipMemsetAsync(stamps, 0, kStampBlocks * 64, (hipStream_t)stream) != hipSuccess) h.stamps = nullptr;
+#endif
         if (grid) hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, h);
+#if defined(GVK_TIMESTAMPS)
+        // GVK_STAMP_FILE=<prefix>: the stamps of the first 64 launches that carry chains and pairs, each run on its own (the stream
+        // is drained after it), to <prefix>.<n>: eight ints {grid, long, pair, short, copy blocks, order, -, -}, then the records
+        static int written = 0;
+        if (h.stamps && getenv("GVK_STAMP_FILE") && with_chains && with_pairs && written < 64) {
+            static std::vector<unsigned long long> host(kStampBlocks * 8);
+            char name[512];
+            snprintf(name, sizeof name, "%s.%d", getenv("GVK_STAMP_FILE"), written++);
+            if (hipStreamSynchronize((hipStream_t)stream) == hipSuccess &&
+                hipMemcpy(host.data(), stamps, kStampBlocks * 64, hipMemcpyDeviceToHost) == hipSuccess)
+                if (FILE *f = fopen(name, "wb")) {
+                    const int header[8] = {(int)grid, h.long_blocks, h.pair_blocks, h.short_blocks, h.copy_blocks, h.order, 0, 0};
+                    fwrite(header, sizeof header, 1, f);
+                    fwrite(host.data(), 64, grid, f);
+                    fclose(f);
+                }
+        }
+#endif
     };
     const unsigned mirror_blocks = (unsigned)(((size_t)l.chains * (size_t)(dim / 4) + kBlock - 1) / kBlock);
     // the hub rows enter the mirrors: every mirror = the tables' rows (a row without entries is only copied on while a mirror

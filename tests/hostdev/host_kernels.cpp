@@ -259,6 +259,59 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
         return gvo_train_pairs_hot(dim, tables->vertex, tables->context, part, negatives, loss + (size_t)q * n, n, k, lr, optimizer->weight_decay,
                                    negative_weight, hot_vertex, hot_context, lerp ? before_v : nullptr, lerp ? before_c : nullptr);
     };
+    if (strstr(executor, "batch")) {
+        // "batchahead": the chains of a whole batch (unit after unit, the hub rows after every unit kept) run BEFORE the pairs of
+        // the batch before it — the chain front one to two batches ahead of the pairs, as a chain stream beside one pairs launch
+        // per batch would run —, and the pairs of unit u then read the hub rows as the chains of unit u left them.
+        // "batchlerp": the same chains; the pairs of a batch read a hub row on the straight line between GVH_KNOTS + 1 kept
+        // states (1: from the batch's start to its end).
+        const bool whole = strstr(executor, "batchlerp") != nullptr;
+        const int knots = getenv("GVH_KNOTS") ? atoi(getenv("GVH_KNOTS")) : 1;
+        if (whole && (knots < 1 || parts % knots)) return gvk_fail(GVK_EINVAL, "GVH_KNOTS must divide the parts");
+        std::vector<std::vector<float>> sv(2 * (parts + 1)), sc(2 * (parts + 1));
+        auto save = [&](int b, int j) {
+            auto &v = sv[(b & 1) * (parts + 1) + j], &c = sc[(b & 1) * (parts + 1) + j];
+            v.assign(tables->vertex, tables->vertex + hv), c.assign(tables->context, tables->context + hc);
+        };
+        auto put = [&](const std::vector<float> &v, const std::vector<float> &c) {
+            memcpy(tables->vertex, v.data(), hv * 4), memcpy(tables->context, c.data(), hc * 4);
+        };
+        auto chains_of_batch = [&](int b) {
+            save(b, 0);
+            for (int q = 0; q < parts; q++) {
+                if (unit(b * parts + q, true, false, nullptr, nullptr)) return 1;
+                save(b, q + 1);
+            }
+            return 0;
+        };
+        auto pairs_range = [&](int i, int q0, int count, const float *bv, const float *bc) {
+            const uint32_t *part = pairs + ((size_t)i * batch_size + (size_t)q0 * n) * 2, *negatives = all.data() + ((size_t)i * batch_size + (size_t)q0 * n) * k;
+            const float lr = gvo_lr(optimizer->lr, linear_schedule, (int)(first_batch_id + (uint32_t)i * batch_id_stride), (int)total_batches);
+            return gvo_train_pairs_hot(dim, tables->vertex, tables->context, part, negatives, loss + (size_t)q0 * n, n * count, k, lr,
+                                       optimizer->weight_decay, negative_weight, hot_vertex, hot_context, bv, bc);
+        };
+        if (chains_of_batch(0)) return gvk_fail(GVK_ENOMEM, "gvk_train_episode_hot: out of memory");
+        std::vector<float> front_v(hv), front_c(hc);
+        for (int i = 0; i < num_batches; i++) {
+            if (i + 1 < num_batches && chains_of_batch(i + 1)) return gvk_fail(GVK_ENOMEM, "gvk_train_episode_hot: out of memory");
+            front_v.assign(tables->vertex, tables->vertex + hv), front_c.assign(tables->context, tables->context + hc);
+            const int base = (i & 1) * (parts + 1);
+            if (whole) {
+                const int seg = parts / knots;
+                for (int j = 0; j < knots; j++) {
+                    put(sv[base + (j + 1) * seg], sc[base + (j + 1) * seg]);
+                    if (pairs_range(i, j * seg, seg, sv[base + j * seg].data(), sc[base + j * seg].data())) return gvk_fail(GVK_ENOMEM, "out of memory");
+                }
+            } else {
+                for (int q = 0; q < parts; q++) {
+                    put(sv[base + q + 1], sc[base + q + 1]);
+                    if (pairs_range(i, q, 1, lerp ? sv[base + q].data() : nullptr, lerp ? sc[base + q].data() : nullptr)) return gvk_fail(GVK_ENOMEM, "out of memory");
+                }
+            }
+            put(front_v, front_c);
+        }
+        return GVK_OK;
+    }
     if (!pipelined) {
         for (int u = 0; u < units; u++)
             if (unit(u, true, true, nullptr, nullptr)) return gvk_fail(GVK_ENOMEM, "gvk_train_episode_hot: out of memory");
