@@ -466,7 +466,19 @@ __device__ __forceinline__ void train_pair(const TrainArgs &a, const int tid) {
     if constexpr (NM >= 2) store_row<DIM, G>(a.vm2, head, lane, reinterpret_cast<float(&)[V]>(vm2));
 }
 
-template <int DIM, int G, int OPT, int KT = 0, int DRAW = -1, int WAVES = 4>
+// Waves per SIMD the training kernels are built for: four (128 registers) wherever the rows a lane group holds at once — the
+// head row, the current and the next target row, each with its moment rows — fit; the moment optimizers at 12 or 16 floats per
+// lane do not (76 .. 456 bytes of scratch per lane at four): three waves (168 registers), Adam at 16 floats per lane two (256).
+constexpr int train_waves(int v, int opt, bool runs) {
+    const int m = opt == GVK_SGD ? 0 : (opt == GVK_ADAM ? 2 : 1);
+    if (m == 0) return 4;
+    if (v >= 16) return m == 2 ? 2 : 3;
+    if (v >= 12) return m == 2 ? (runs ? 2 : 3) : (runs ? 3 : 4);
+    if (v >= 8) return m == 2 ? 3 : 4;
+    return 4;
+}
+
+template <int DIM, int G, int OPT, int KT = 0, int DRAW = -1, int WAVES = train_waves(DIM / G, OPT, false)>
 __global__ void __launch_bounds__(kBlock, WAVES) train_kernel(const TrainArgs a) {
     train_pair<DIM, G, OPT, KT, DRAW, 0>(a, blockIdx.x * kBlock + threadIdx.x);
 }
@@ -493,7 +505,7 @@ __global__ void __launch_bounds__(kBlock, WAVES) train_kernel(const TrainArgs a)
 // Pipelining inside a run: the header of pair j + 1 is loaded one pair ahead, its first alias slot as soon as the
 // header says the run continues, and its first target row while the positive target of pair j is computed — the
 // one-ahead row prefetch of the per-pair kernel carried across pairs.
-template <int DIM, int G, int OPT, int KT = 0, int DRAW = -1, int WAVES = 4>
+template <int DIM, int G, int OPT, int KT = 0, int DRAW = -1, int WAVES = train_waves(DIM / G, OPT, true)>
 __global__ void __launch_bounds__(kBlock, WAVES) train_runs_kernel(const TrainArgs a) {
     constexpr int V = DIM / G;
     constexpr int NM = OPT == GVK_SGD ? 0 : (OPT == GVK_ADAM ? 2 : 1);  // moments per row
