@@ -50,7 +50,9 @@ constexpr double kHubHitsPerPart = 0.125;  // GVX_HUB_ROWS -1: a row a PART of a
 constexpr uint64_t kMaxHubRows = 16384;  // per table (gvk_hot_build counts the chains of both tables in LDS)
 constexpr int kHubChunk = 128;          // batches whose work lists are built at once
 constexpr int kHubEntriesPerPart = 250;  // with hub rows by chains a batch is trained as so many parts that its largest hub row meets about this many of its updates per part
-constexpr int kHubMaxParts = 50;
+constexpr int kHubMaxParts = 32;  // measured on the headline shape at P = 8 (a block's top hub holds 16 % of its samples: the rule asks for 64): 25 / 32 / 40 / 50
+                                  // parts end -0.0013 / +0.0008 / +0.0013 / +0.0022 from the reference's loop — past 32 the parts only cost launches
+constexpr int kHubMaxPartsResident = 50;  // cache-resident tables (< 16 MiB): a small partition's chains are feasible up to this many parts (§7.8)
 constexpr int kHubLerp = 0;              // GVX_HUB_LERP -1: the pairs read hub rows as their part's chains left them
 constexpr int kMinEpisodeSample = 20000000;
 constexpr int kExpectedDegree = 1600;  // graph.cuh:55
@@ -175,6 +177,7 @@ struct gvx_solver {
     int64_t hub_rows_request = -2;  // GVX_HUB_ROWS: -2 the default rule, -1 by expected hits per batch, 0 off, N > 0 the first N rows
     int hub_lerp_request = -1;      // GVX_HUB_LERP: -1 the rule, 0 / 1: the pairs read hub rows as their unit's chains left them / along the chains' way
     int hub_chunk = kHubChunk;      // batches whose work lists are built at once (fewer where memory is short)
+    int hub_max_parts = kHubMaxParts;  // most parts a batch is trained as (kHubMaxPartsResident for cache-resident tables)
     int hub_chain_cap_request = 0;  // GVX_HUB_CHAIN_CAP: entries one chain task trains in sequence (0 = the kernels' default)
     uint64_t node2vec_table_limit = (uint64_t)1 << 30;
     // build
@@ -772,6 +775,7 @@ int gvx_solver::configure(const gvx_train_config &in) {
     int64_t request = hub_rows_request;
     // a cache-resident LINE table gets chains, too, where its hottest row leaves that feasible (below): else runs, as before
     const bool small_table = hub_rows_request == -2 && fidelity == -1 && !walk_ordered() && table_bytes < ((size_t)16 << 20);
+    hub_max_parts = table_bytes < ((size_t)16 << 20) ? kHubMaxPartsResident : kHubMaxParts;
     if (request == -2) {
         if (fidelity == 0 || (fidelity == -1 && pair_order_request == 2)) request = 0;  // "grouped" asked for: regrouped batches, no chains
         else if (walk_ordered() && num_partition == 1 && part_rows <= kMaxHubRows) request = (int64_t)part_rows;
@@ -803,7 +807,7 @@ int gvx_solver::configure(const gvx_train_config &in) {
                 // batch of this partition's blocks is trained as (hub_parts_of)
                 if (!ids.empty())
                     hub_top_entries[p] = (int)std::min(1e9, (double)batch_size * (num_negative + 1) * vertex_weights[ids[0]] / std::max(total, 1e-30));
-                const int parts = std::min(std::max((hub_top_entries[p] + kHubEntriesPerPart / 2) / kHubEntriesPerPart, 1), kHubMaxParts);
+                const int parts = std::min(std::max((hub_top_entries[p] + kHubEntriesPerPart / 2) / kHubEntriesPerPart, 1), hub_max_parts);
                 // A row a batch hits h times meets another of its hits inside a part with probability ~ h / parts, and of two
                 // concurrent updates one is lost: the rows a PART is expected to hit kHubHitsPerPart times or more are hub rows
                 // (one hit per batch at the eight parts of the headline shape, §7.10; four at the 32 parts of its P = 4 blocks)
@@ -827,10 +831,10 @@ int gvx_solver::configure(const gvx_train_config &in) {
         // Chains need so many parts that the largest hub row meets about kHubEntriesPerPart of its updates per part (tasks of one
         // chain run side by side from the same start: with thousands of entries per part their steps add up and the row
         // overshoots — a 6 250-row partition of a 100k-node graph at P = 16 diverges).  Where that takes more than
-        // kHubMaxParts parts a cache-resident table keeps regrouping + runs (§3.1.1, pinned at P = 8 / 16 in §7.8).
+        // kHubMaxPartsResident parts a cache-resident table keeps regrouping + runs (§3.1.1, pinned at P = 8 / 16 in §7.8).
         if (small_table && hubs) {
             const int worst = *std::max_element(hub_top_entries.begin(), hub_top_entries.end());
-            if ((worst + kHubEntriesPerPart - 1) / kHubEntriesPerPart > kHubMaxParts) {
+            if ((worst + kHubEntriesPerPart - 1) / kHubEntriesPerPart > kHubMaxPartsResident) {
                 hub_rows.assign(num_partition, 0);
                 hubs = false;
             }
@@ -1550,8 +1554,8 @@ int gvx_solver::hub_parts_of(int hp, int tp) const {
     // so many parts that the largest hub row meets about kHubEntriesPerPart of its updates per part —
     // and, where every row is a hub row (a small table: many samples per row and batch), at least the parts
     // gvk_train_launches prescribes for it (§7.8: a chain then sees its partners at most a part old) —, a divisor of the
-    // batch size, at most kHubMaxParts
-    int want = std::min(std::max((std::max(hub_top_entries[hp], hub_top_entries[tp]) + kHubEntriesPerPart / 2) / kHubEntriesPerPart, 1), kHubMaxParts);
+    // batch size, at most hub_max_parts (32; 50 for cache-resident tables)
+    int want = std::min(std::max((std::max(hub_top_entries[hp], hub_top_entries[tp]) + kHubEntriesPerPart / 2) / kHubEntriesPerPart, 1), hub_max_parts);
     if (kv == part_rows && kc == part_rows) want = std::max(want, gvk_train_launches(B, part_rows));
     int parts = 1;
     for (int q = want; q <= 2 * want && parts == 1 && want > 1; q++)

@@ -33,6 +33,10 @@ reference = dict(np.load(golden)) if os.path.exists(golden) else {}
 for config in extra.get("configs", "hub=auto").split(";"):
     kw = dict(kv.split("=") for kv in config.split(",") if kv)
     aucs = []
+    if "GVK_LIBRARY" not in os.environ or "host" not in os.environ["GVK_LIBRARY"]:  # tune<key>=<value>: gvk_set_tuning (include/gvk.h), e.g. tune9=1
+        from graphvite_amd.kernels import HipKernels
+        for key in (9, 10):
+            HipKernels().set_tuning(key, int(kw.get("tune%d" % key, 1 if key == 10 else 0)))
     for seed in [int(x) for x in extra.get("seeds", "1024").split(",")]:
         hub = kw.get("hub", "default")
         s = gv.solver.GraphSolver(128, num_sampler_per_worker=15, seed=seed, device_sampling=kw.get("device", "0") == "1",

@@ -42,6 +42,8 @@ def main():
     # size, which at P >= 4 makes this 5 000-batch training shorter than ONE episode (every block visited once, under a
     # learning rate that has decayed by the time the last blocks are met): keys c2_line_p<P>_e<E>
     jobs += [("p%d_e%d" % (P, E), 0, False, i, SEEDS[i]) for P, E in ((4, 32), (8, 8), (2, 128)) for i in range(2)]
+    # a third seed where the product sits near the tolerance (P = 8: the two-seed means differ by 0.0022; seeds differ by 0.001)
+    jobs += [("p%d_e%d" % (P, E), 0, False, 2, SEEDS[2]) for P, E in ((8, 8), (4, 32))]
     if len(sys.argv) > 1:
         jobs = [j for j in jobs if j[0] in sys.argv[1:]]
     for model, chunk, reads_at_start, i, seed in jobs:
@@ -50,6 +52,8 @@ def main():
         episode = int(model.split("_e")[1]) if "_e" in model else 0  # 0: automatic
         out = dict(np.load(PATH)) if os.path.exists(PATH) else {}
         values = out.get(key, np.full(len(SEEDS) if model == "sequential" else (2 if partitions > 1 else 1), np.nan))
+        if i >= len(values):
+            values = np.concatenate([values, np.full(i + 1 - len(values), np.nan)])
         if not np.isnan(values[i]):
             continue
         t0 = time.time()
