@@ -194,6 +194,32 @@ def hub_row_rules():
         raise AssertionError("an invalid argument was accepted")
 
 
+def executor_simulator():
+    """GVH_EXECUTOR (tests/hostdev/host_kernels.cpp): the host build trains hub rows the way a device executor would — unit by unit
+    ("units"), the chains of unit u + 1 before the pairs of unit u write ("pipelined": the product's launch), the chains of a whole
+    batch ahead of the pairs ("batchahead"), the pairs reading hub rows on a straight line across the batch ("batchlerp") —, so
+    that a change of the device path can be judged by what it learns before it is written.  Every form trains the same samples:
+    the tables stay close to the sequential ones, and differ from them (the forms are not the sequential loop)."""
+    g = make_graph(n=2000, e=30000)
+    trained = {}
+    for executor in ("sequential", "units", "pipelined", "batchahead", "batchlerp"):
+        os.environ["GVH_EXECUTOR"] = executor
+        s = gv.solver.GraphSolver(32, num_sampler_per_worker=2, seed=1, hub_rows=200)
+        s.hub_parts = 4
+        s.build(g, batch_size=1000, episode_size=4)
+        s.train(model="LINE", num_epoch=20, augmentation_step=1, log_frequency=1 << 30)
+        assert s.hub_rows == 200
+        trained[executor] = np.concatenate([s.vertex_embeddings.ravel(), s.context_embeddings.ravel()]).astype(np.float64)
+        assert np.isfinite(trained[executor]).all(), executor
+    os.environ.pop("GVH_EXECUTOR")
+    base = trained["sequential"]
+    for executor, x in trained.items():
+        cosine = float(x @ base / np.sqrt((x @ x) * (base @ base)))
+        print("executor %-10s cosine to sequential %.5f" % (executor, cosine))
+        assert cosine > 0.995, (executor, cosine)
+        assert executor == "sequential" or not (x == base).all(), executor
+
+
 def accounting_and_determinism():
     g = make_graph()
     log = Launches()

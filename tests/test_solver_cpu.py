@@ -55,6 +55,10 @@ def test_hub_row_rules(host_build):
     scenario(host_build, "hub_row_rules")
 
 
+def test_executor_simulator_forms(host_build):
+    scenario(host_build, "executor_simulator")
+
+
 def test_train_accounting_and_determinism(host_build):
     scenario(host_build, "accounting_and_determinism")
 
