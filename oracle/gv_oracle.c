@@ -260,7 +260,42 @@ int gvo_hot_unit_chains(int dim, float *vertex, float *context, float lr, float 
 /* The pairs of one unit: every sample in order as gvo_train, except that hub rows (the first kv / kc rows: in the tables as
  * the unit's chains left them) are read and never written.  before_vertex / before_context non-NULL (lerp): the hub rows as
  * those chains FOUND them — a sample then reads a hub row where its chain was when it met the sample, approximated by the
- * straight line from the row before the chains to the row after them: sample s of n reads before + (s + 1/2) / n (now - before). */
+ * straight line from the row before the chains to the row after them: sample s of n reads before + (s + 1/2) / n (now - before).
+ *
+ * gvo_set_pairs_concurrent(1) (executor simulator, GVH_PAIRS=concurrent): the samples of the unit run as one launch of the
+ * product runs them — every sample reads its rows as the UNIT found them (not as the samples before it left them), and of two
+ * samples that write the same row the later one's row stays: what Hogwild inside a launch does to rows that are not hub rows. */
+static int gvo_pairs_concurrent = 0;
+void gvo_set_pairs_concurrent(int on) { gvo_pairs_concurrent = on != 0; }
+
+typedef struct {
+    uint64_t *keys;   /* (table << 32 | row) + 1; 0 = empty */
+    uint32_t *slots;  /* index of the row's saved original */
+    float *rows;      /* saved originals, dim floats each */
+    size_t mask, used;
+} gvo_originals;
+
+static const float *gvo_original_of(const gvo_originals *o, int dim, int table, size_t row) {
+    const uint64_t key = ((uint64_t)table << 32 | (uint64_t)row) + 1;
+    for (size_t h = (size_t)(key * 0x9E3779B97F4A7C15ull) & o->mask;; h = (h + 1) & o->mask) {
+        if (o->keys[h] == key) return o->rows + (size_t)o->slots[h] * dim;
+        if (o->keys[h] == 0) return NULL;
+    }
+}
+
+static void gvo_save_original(gvo_originals *o, int dim, int table, size_t row, const float *current) {
+    const uint64_t key = ((uint64_t)table << 32 | (uint64_t)row) + 1;
+    for (size_t h = (size_t)(key * 0x9E3779B97F4A7C15ull) & o->mask;; h = (h + 1) & o->mask) {
+        if (o->keys[h] == key) return;
+        if (o->keys[h] == 0) {
+            o->keys[h] = key, o->slots[h] = (uint32_t)o->used;
+            memcpy(o->rows + o->used * dim, current, sizeof(float) * dim);
+            o->used++;
+            return;
+        }
+    }
+}
+
 int gvo_train_pairs_hot(int dim, float *vertex, float *context, const uint32_t *batch, const uint32_t *negatives, float *loss,
                         int batch_size, int k, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
                         const float *before_vertex, const float *before_context) {
@@ -268,13 +303,24 @@ int gvo_train_pairs_hot(int dim, float *vertex, float *context, const uint32_t *
     float *own = (float *)malloc(sizeof(float) * dim);
     float dummy1 = 0, dummy2 = 0;
     if (!buf || !hub || !own) return -1;
+    gvo_originals seen = {NULL, NULL, NULL, 0, 0};
+    if (gvo_pairs_concurrent) {
+        size_t capacity = 1;
+        while (capacity < 4 * (size_t)(k + 2) * (size_t)(batch_size > 0 ? batch_size : 1)) capacity <<= 1;
+        seen.keys = (uint64_t *)calloc(capacity, sizeof(uint64_t)), seen.slots = (uint32_t *)malloc(capacity * sizeof(uint32_t));
+        seen.rows = (float *)malloc(sizeof(float) * dim * (size_t)(k + 2) * (size_t)(batch_size > 0 ? batch_size : 1));
+        seen.mask = capacity - 1;
+        if (!seen.keys || !seen.slots || !seen.rows) return -1;
+    }
     for (int s = 0; s < batch_size; s++) {
         const float at = (s + 0.5f) / batch_size;
         const size_t head = batch[2 * s + 1];
-        if (head < kv && before_vertex)
+        if (head < kv && before_vertex) {
             for (int i = 0; i < dim; i++) buf[i] = before_vertex[head * dim + i] + at * (vertex[head * dim + i] - before_vertex[head * dim + i]);
-        else
-            memcpy(buf, vertex + head * dim, sizeof(float) * dim);
+        } else {
+            const float *start = gvo_pairs_concurrent && head >= kv ? gvo_original_of(&seen, dim, 0, head) : NULL;
+            memcpy(buf, start ? start : vertex + head * dim, sizeof(float) * dim);
+        }
         float sample_loss = 0;
         size_t last = 0;
         int have = 0;
@@ -292,6 +338,13 @@ int gvo_train_pairs_hot(int dim, float *vertex, float *context, const uint32_t *
                     for (int i = 0; i < dim; i++) hub[i] = before_context[tail * dim + i] + at * (c[i] - before_context[tail * dim + i]);
                     from = hub;
                 }
+            } else if (gvo_pairs_concurrent) {
+                if (have && tail == last) {
+                    from = own;  /* its own update, carried in registers */
+                } else {
+                    const float *start = gvo_original_of(&seen, dim, 1, tail);
+                    if (start) from = start;
+                }
             }
             float logit = 0;
             for (int i = 0; i < dim; i++) logit += buf[i] * from[i];
@@ -304,6 +357,7 @@ int gvo_train_pairs_hot(int dim, float *vertex, float *context, const uint32_t *
                 gradient = prob, weight = negative_weight;
                 sample_loss += weight * -logf(1 - prob + GVO_EPS);
             }
+            if (gvo_pairs_concurrent && tail >= kc) gvo_save_original(&seen, dim, 1, tail, c);
             for (int i = 0; i < dim; i++) {
                 const float vi = buf[i], ci = from[i];
                 buf[i] -= gvo_update(0, lr, wd, NULL, vi, gradient * ci, weight, &dummy1, &dummy2);
@@ -314,9 +368,13 @@ int gvo_train_pairs_hot(int dim, float *vertex, float *context, const uint32_t *
             last = tail, have = 1;
         }
         loss[s] = sample_loss / (1 + k * negative_weight);
-        if (head >= kv) memcpy(vertex + head * dim, buf, sizeof(float) * dim);
+        if (head >= kv) {
+            if (gvo_pairs_concurrent) gvo_save_original(&seen, dim, 0, head, vertex + head * dim);
+            memcpy(vertex + head * dim, buf, sizeof(float) * dim);
+        }
     }
     free(buf), free(hub), free(own);
+    free(seen.keys), free(seen.slots), free(seen.rows);
     return 0;
 }
 

@@ -202,8 +202,9 @@ def executor_simulator():
     the tables stay close to the sequential ones, and differ from them (the forms are not the sequential loop)."""
     g = make_graph(n=2000, e=30000)
     trained = {}
-    for executor in ("sequential", "units", "pipelined", "batchahead", "batchlerp"):
-        os.environ["GVH_EXECUTOR"] = executor
+    for executor in ("sequential", "units", "pipelined", "batchahead", "batchlerp", "pipelined, concurrent pairs"):
+        os.environ["GVH_EXECUTOR"] = executor.split(",")[0]
+        os.environ["GVH_PAIRS"] = "concurrent" if "concurrent" in executor else "in order"  # Hogwild inside a unit's pairs, modelled
         s = gv.solver.GraphSolver(32, num_sampler_per_worker=2, seed=1, hub_rows=200)
         s.hub_parts = 4
         s.build(g, batch_size=1000, episode_size=4)
@@ -211,11 +212,11 @@ def executor_simulator():
         assert s.hub_rows == 200
         trained[executor] = np.concatenate([s.vertex_embeddings.ravel(), s.context_embeddings.ravel()]).astype(np.float64)
         assert np.isfinite(trained[executor]).all(), executor
-    os.environ.pop("GVH_EXECUTOR")
+    os.environ.pop("GVH_EXECUTOR"), os.environ.pop("GVH_PAIRS")
     base = trained["sequential"]
     for executor, x in trained.items():
         cosine = float(x @ base / np.sqrt((x @ x) * (base @ base)))
-        print("executor %-10s cosine to sequential %.5f" % (executor, cosine))
+        print("executor %-28s cosine to sequential %.5f" % (executor, cosine))
         assert cosine > 0.995, (executor, cosine)
         assert executor == "sequential" or not (x == base).all(), executor
 

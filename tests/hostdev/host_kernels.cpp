@@ -28,6 +28,7 @@ int gvo_train_hot(int dim, float *vertex, float *context, const uint32_t *batch,
                   const uint32_t *chain_start, const uint32_t *entries, uint32_t cap, uint32_t max_tasks, int lerp);
 int gvo_hot_unit_chains(int dim, float *vertex, float *context, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
                         const uint32_t *chain_start, const uint32_t *entries, uint32_t cap, uint32_t max_tasks, int k);
+void gvo_set_pairs_concurrent(int on);
 int gvo_train_pairs_hot(int dim, float *vertex, float *context, const uint32_t *batch, const uint32_t *negatives, float *loss,
                         int batch_size, int k, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
                         const float *before_vertex, const float *before_context);
@@ -225,6 +226,8 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
         return gvk_train_episode(stream, dim, optimizer, linear_schedule, tables, pairs, negative, first_batch_id, batch_id_stride,
                                  total_batches, num_batches, loss, batch_size, num_negative, negative_weight);
     const int lerp = (form & GVK_HOT_LERP) || (getenv("GVH_LERP") && atoi(getenv("GVH_LERP")));
+    // GVH_PAIRS=concurrent: the pairs of a unit as one launch runs them (reads as the unit found the rows, the later of two writers stays)
+    gvo_set_pairs_concurrent(getenv("GVH_PAIRS") && !strcmp(getenv("GVH_PAIRS"), "concurrent"));
     const int pipelined = strstr(executor, "pipelined") != nullptr, n = batch_size / parts, k = num_negative;
     if (getenv("GVH_CHAIN_CAP")) chain_cap = atoi(getenv("GVH_CHAIN_CAP"));
     const uint32_t cap = (uint32_t)std::min(chain_cap > 0 ? chain_cap : 7, 7);  // chain_cap_for, gvk_kernels.hip
