@@ -918,7 +918,8 @@ __device__ __forceinline__ void copy_idle_rows(const HotArgs &h, const uint32_t 
 //     row <- total row - sum over tasks after_t sum_j kappa_tj c_tj,
 // summed per wavefront in registers, across the 16 lanes of a row by DPP, across wavefronts through LDS in wavefront order: the
 // same bits on every run.  In exact arithmetic this is train_long_chains with tasks of 16 entries and as many tasks as it takes
-// (oracle: gvo_hot_unit_chains with cap 16, max_tasks 64); chains of more than 16 x kGramTiles entries keep the steps.
+// (oracle: gvo_hot_unit_chains with cap 16, max_tasks 64); a chain of more than 16 x kGramTiles entries is trained as segments
+// of that many, one after the other.
 constexpr int kGramTiles = 64;
 
 template <int J>
@@ -931,9 +932,9 @@ __device__ __forceinline__ void long_chain_gram(const TrainArgs &a, const HotArg
                                                 const uint32_t n, const float *row0) {
     constexpr int NCH = DIM / 16;  // float4 chunks of a row per lane: lane (r, q) of a wavefront holds chunks q, q + 4, ... of row r
     static_assert(DIM % 16 == 0 && kBlock == 256, "four wavefronts, rows in sixteenths");
-    __shared__ float gram[4][4][256];  // [wavefront][quarter][16 x 16], row-major (symmetric)
-    __shared__ float part[4][DIM];     // a wavefront's weighted sum of its tasks' rows
-    __shared__ float own_row[DIM];     // the chain's row as the unit found it
+    __shared__ __attribute__((aligned(16))) float gram[4][4][256];  // [wavefront][quarter][16 x 16], row-major (symmetric)
+    __shared__ __attribute__((aligned(16))) float part[4][DIM];     // a wavefront's weighted sum of its tasks' rows
+    __shared__ __attribute__((aligned(16))) float own_row[DIM];     // the chain's row as the unit found it
     __shared__ float positives[kGramTiles];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = threadIdx.x & 63, r = l & 15, q = l >> 4;  // wave: in a scalar register
     const uint32_t last = first + n, tiles = (n + 15) / 16, rounds = (tiles + 15) / 16;

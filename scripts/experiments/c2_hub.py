@@ -35,7 +35,7 @@ for config in extra.get("configs", "hub=auto").split(";"):
     aucs = []
     if "GVK_LIBRARY" not in os.environ or "host" not in os.environ["GVK_LIBRARY"]:  # tune<key>=<value>: gvk_set_tuning (include/gvk.h), e.g. tune9=1
         from graphvite_amd.kernels import HipKernels
-        for key in (9, 10):
+        for key in (9, 10, 11):  # 11 = GVK_TUNE_HOT_GRAM (long chains by Gram matrices)
             HipKernels().set_tuning(key, int(kw.get("tune%d" % key, 1 if key == 10 else 0)))
     for seed in [int(x) for x in extra.get("seeds", "1024").split(",")]:
         hub = kw.get("hub", "default")
