@@ -230,8 +230,10 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     gvo_set_pairs_concurrent(getenv("GVH_PAIRS") && !strcmp(getenv("GVH_PAIRS"), "concurrent"));
     const int pipelined = strstr(executor, "pipelined") != nullptr, n = batch_size / parts, k = num_negative;
     if (getenv("GVH_CHAIN_CAP")) chain_cap = atoi(getenv("GVH_CHAIN_CAP"));
-    const uint32_t cap = (uint32_t)std::min(chain_cap > 0 ? chain_cap : 7, 7);  // chain_cap_for, gvk_kernels.hip
-    const uint32_t max_tasks = getenv("GVH_MAX_TASKS") ? (uint32_t)atoi(getenv("GVH_MAX_TASKS")) : (dim == 512 ? 8u : (dim == 32 || dim == 96 ? 32u : 16u));
+    // GVH_GRAM=1: the tasks of the device path's GVK_TUNE_HOT_GRAM form (long_chain_gram, gvk_kernels.hip): 16 entries each, up to 64 side by side
+    const bool gram = getenv("GVH_GRAM") && atoi(getenv("GVH_GRAM"));
+    const uint32_t cap = gram ? 16u : (uint32_t)std::min(chain_cap > 0 ? chain_cap : 7, 7);  // chain_cap_for, gvk_kernels.hip
+    const uint32_t max_tasks = gram ? 64u : getenv("GVH_MAX_TASKS") ? (uint32_t)atoi(getenv("GVH_MAX_TASKS")) : (dim == 512 ? 8u : (dim == 32 || dim == 96 ? 32u : 16u));
     std::vector<uint32_t> start(hot_vertex + hot_context + 1), entries(2 * (size_t)(k + 1) * n + 1);
     std::vector<uint32_t> all((size_t)num_batches * batch_size * std::max(k, 1));
     for (int i = 0; i < num_batches; i++) {

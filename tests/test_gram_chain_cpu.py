@@ -224,16 +224,19 @@ def test_gram_form_of_a_long_chain_matches_the_oracle(dim, n):
         hub = rng.random(n) < 0.25  # a quarter of the entries name hub rows (read from the mirror)
         partners[hub] = rng.integers(0, kc if chain < kv else kv, hub.sum())
         labels = (rng.random(n) < 0.4).astype(np.uint32)
-        entries = (partners | labels << 31).astype(np.uint32)
+        # the chain before this one owns the first 37 entries of the list: the chain under test starts at an odd offset
+        junk = rng.integers(kv + kc, rows, 37).astype(np.uint32)
+        entries = np.concatenate([junk, partners | labels << 31]).astype(np.uint32)
         chain_start = np.zeros(kv + kc + 1, np.uint32)
-        chain_start[chain + 1:] = n
+        chain_start[chain:] = 37
+        chain_start[chain + 1:] = 37 + n
         ov, oc = oracle_chain(oracle, dim, vertex, context, lr, wd, nw, kv, kc, chain_start, entries, 16, 64)
         want = ov[chain] if chain < kv else oc[chain - kv]
         a = dict(vertex=vertex, context=context, hot_vertex=kv, hot_context=kc, wd=wd, neg_weight=nw)
         h = dict(entries=entries, mirror=np.concatenate([vertex[:kv], context[:kc]]), lr=lr,
                  log2_decay_positive=F(np.log2(1.0 - float(lr) * float(wd))),
                  log2_decay_negative=F(np.log2(1.0 - float(lr) * float(nw) * float(wd))))
-        got = long_chain_gram(dim, a, h, chain, 0, n)
+        got = long_chain_gram(dim, a, h, chain, 37, n)
         start = vertex[chain] if chain < kv else context[chain - kv]
         assert np.abs(want - start).max() > 1e-3  # the chain moved the row
         np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)  # rows of magnitude 1: fp32 sums in another order
