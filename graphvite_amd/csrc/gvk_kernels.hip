@@ -1206,7 +1206,7 @@ __device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotA
 // at dims 256 and 512, sixteen floats of a row per lane): the chains and the pairs of a unit of the sizes this kernel trains (a
 // part of a batch) are then resident side by side.
 template <int DIM, int G, int KT, int HOT, int GRAM = 0>
-__global__ void __launch_bounds__(kBlock, DIM / G > 12 || GRAM ? 3 : 4) train_hot_kernel(const TrainArgs a, const HotArgs h) {
+__global__ void __launch_bounds__(kBlock, DIM / G > 12 || GRAM == 1 ? 3 : 4) train_hot_kernel(const TrainArgs a, const HotArgs h) {
     // the grid: [long chains | pairs | short chains | idle rows] — the long chains, whose tasks wait for memory three times in
     // a row, are dispatched first, the bulk (the pairs) next; the short chains and the copies fill in behind
     const int b = blockIdx.x;
@@ -2141,12 +2141,17 @@ HotKernel pick_hot(int dim, int k, int lerp) {
     case D:                                                                                                         \
         return k == 1 ? (lerp ? train_hot_kernel<D, GG, 1, 2> : train_hot_kernel<D, GG, 1, 1>)                      \
                       : (lerp ? train_hot_kernel<D, GG, 0, 2> : train_hot_kernel<D, GG, 0, 1>);
-#define GVK_HOT_GRAM(D, GG)                                                                                         \
+#define GVK_HOT_GRAM(D, GG, W)                                                                                      \
     case D:                                                                                                         \
-        return k == 1 ? (lerp ? train_hot_kernel<D, GG, 1, 2, 1> : train_hot_kernel<D, GG, 1, 1, 1>)                \
-                      : (lerp ? train_hot_kernel<D, GG, 0, 2, 1> : train_hot_kernel<D, GG, 0, 1, 1>);
-    if (g_hot_gram && dim <= 128) {  // experiment: long chains as tasks of 16 entries by Gram matrices (long_chain_gram)
-        switch (dim) { GVK_HOT_GRAM(32, 8) GVK_HOT_GRAM(64, 16) GVK_HOT_GRAM(96, 8) GVK_HOT_GRAM(128, 16) }
+        return k == 1 ? (lerp ? train_hot_kernel<D, GG, 1, 2, W> : train_hot_kernel<D, GG, 1, 1, W>)                \
+                      : (lerp ? train_hot_kernel<D, GG, 0, 2, W> : train_hot_kernel<D, GG, 0, 1, W>);
+    // experiment: long chains as tasks of 16 entries by Gram matrices (long_chain_gram); 1: the kernel built for three wavefronts
+    // per SIMD (168 registers), 2: for four as the default kernel (128 registers, more of long_chain_gram's invariants in scratch)
+    if (g_hot_gram == 1 && dim <= 128) {
+        switch (dim) { GVK_HOT_GRAM(32, 8, 1) GVK_HOT_GRAM(64, 16, 1) GVK_HOT_GRAM(96, 8, 1) GVK_HOT_GRAM(128, 16, 1) }
+    }
+    if (g_hot_gram == 2 && dim <= 128) {
+        switch (dim) { GVK_HOT_GRAM(32, 8, 2) GVK_HOT_GRAM(64, 16, 2) GVK_HOT_GRAM(96, 8, 2) GVK_HOT_GRAM(128, 16, 2) }
     }
     switch (dim) {
         GVK_HOT(32, 8) GVK_HOT(64, 16) GVK_HOT(96, 8) GVK_HOT(128, 16) GVK_HOT(256, 16) GVK_HOT(512, 32)
@@ -2596,7 +2601,8 @@ int gvk_set_tuning(int key, int value) {
         return GVK_OK;
     }
     if (key == GVK_TUNE_HOT_GRAM) {
-        g_hot_gram = value != 0;
+        if (value < 0 || value > 2) return fail(GVK_EINVAL, "gvk_set_tuning: the Gram form is 0 (off), 1 or 2");
+        g_hot_gram = value;
         return GVK_OK;
     }
     if (key == GVK_TUNE_HOT_SERIALIZED) {

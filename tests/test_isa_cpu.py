@@ -34,10 +34,11 @@ def test_training_kernels_do_not_spill(resources):
     training = {k: r for k, r in resources.items() if k.startswith(("train_kernel<", "train_runs_kernel<", "train_hot_kernel<"))}
     # the experiment builds of the hot kernel (GVK_TUNE_HOT_GRAM, fifth template argument 1: long chains by Gram matrices, written
     # without a GPU and off by default) are budgeted on their own below
-    gram = {k: r for k, r in training.items() if k.startswith("train_hot_kernel<") and k.endswith(", 1>")}
-    assert len(gram) == 16  # dims 32 .. 128 x (one negative / several) x (lerp or not)
+    gram = {k: r for k, r in training.items() if k.startswith("train_hot_kernel<") and k.endswith((", 1>", ", 2>"))}
+    assert len(gram) == 32  # dims 32 .. 128 x (one negative / several) x (lerp or not) x (built for three / four wavefronts per SIMD)
     training = {k: r for k, r in training.items() if k not in gram}
-    assert all(r["scratch"] <= 160 and r["occupancy"] >= 3 for r in gram.values()), gram  # loop invariants of long_chain_gram, to be tuned on the GPU
+    # loop invariants of long_chain_gram in scratch, to be tuned on the GPU
+    assert all(r["scratch"] <= (160 if k.endswith(", 1>") else 320) and r["occupancy"] >= (3 if k.endswith(", 1>") else 4) for k, r in gram.items()), gram
     assert len(training) > 100  # six dims x five optimizers x the builds of each
     spilling = {k: r["scratch"] for k, r in training.items() if r["scratch"] > 0}
     # what is left: 12 bytes in the RMSprop builds of the runs kernel at 16 floats per lane (three wavefronts per SIMD)
