@@ -13,5 +13,5 @@ mkdir -p $O
 GVK_TEST_GRAM=1 timeout 240 python -m pytest tests/test_hub_chains_gpu.py -q -k gram_matrices -x 2>&1 | tail -15 | tee $O/r5_gram_test.log
 if ! grep -q "passed" $O/r5_gram_test.log || grep -q "failed" $O/r5_gram_test.log; then echo "gram test red: no timing"; exit 1; fi
 STEPS=200 bash scripts/experiments/gpu_ab.sh "steps|" "gram|--tune 11=1" "gram4w|--tune 11=2" "steps2|" "gram2|--tune 11=1" "gram4w2|--tune 11=2" \
-  "p8_steps|--partitions 8" "p8_gram|--partitions 8 --tune 11=1" 2>&1 | tee $O/r5_gram_ab.log
+  "gram_chains_first|--tune 11=1 --tune 10=0" "p8_steps|--partitions 8" "p8_gram|--partitions 8 --tune 11=1" 2>&1 | tee $O/r5_gram_ab.log
 timeout 200 python scripts/experiments/c2_hub.py 'configs=hub=default;hub=default,tune11=1;hub=default,tune11=1,partitions=8,episode=8' 2>&1 | tail -6 | tee $O/r5_gram_auc.log
