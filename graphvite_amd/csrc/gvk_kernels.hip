@@ -936,7 +936,11 @@ __device__ __forceinline__ void long_chain_gram(const TrainArgs &a, const HotArg
     __shared__ __attribute__((aligned(16))) float part[4][DIM];     // a wavefront's weighted sum of its tasks' rows
     __shared__ __attribute__((aligned(16))) float own_row[DIM];     // the chain's row as the unit found it
     __shared__ float positives[kGramTiles];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = threadIdx.x & 63, r = l & 15, q = l >> 4;  // wave: in a scalar register
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // in a scalar register
+    int l = threadIdx.x & 63, r = l & 15, q = l >> 4;
+    // what depends on the lane only (addresses in LDS, shuffle indices, masks) is derived again at the start of every phase instead of
+    // living in registers across the whole function: the compiler cannot see through the empty asm
+#define GVK_GRAM_FRESH() do { asm volatile("" : "+v"(l)); r = l & 15; q = l >> 4; } while (0)
     const uint32_t last = first + n, tiles = (n + 15) / 16, rounds = (tiles + 15) / 16;
     const bool is_vertex = chain < a.hot_vertex;
     const float *partner_table = is_vertex ? a.context : a.vertex;
@@ -971,9 +975,20 @@ __device__ __forceinline__ void long_chain_gram(const TrainArgs &a, const HotArg
         const bool exists = t_own < tiles;
         const uint32_t at = first + 16 * t_own + r;
         const uint32_t e_own = p == 0 ? e_first : (at < last ? h.entries[at] : 0);
+        GVK_GRAM_FRESH();
         // 1. per tile of this wavefront: rows, Gram matrix, start logits; the next tile's rows are asked for before this one's matrix
         float logit = 0;
         {
+            // every lane touches the 128-byte lines of its own entry's row first: the rows of all four tiles are on their way
+            // (one register per line) while the first two tiles are asked for in full
+            float warm[DIM / 32];
+            {
+                const uint32_t id = e_own & 0x7fffffffu;
+                const float *row = id < partner_hot ? partner_mirror + (size_t)id * DIM : partner_table + (size_t)id * DIM;
+                const float *touch = at < last ? row : row0;
+#pragma unroll
+                for (int i = 0; i < DIM / 32; i++) warm[i] = touch[32 * i];
+            }
             f32x4 ca[NCH], cb[NCH];
             auto matrix = [&](const int qq, const f32x4 (&c)[NCH]) __attribute__((always_inline)) {
                 f32x4 g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0};
@@ -1009,6 +1024,8 @@ __device__ __forceinline__ void long_chain_gram(const TrainArgs &a, const HotArg
                 matrix(2, ca);
                 matrix(3, cb);
             }
+#pragma unroll
+            for (int i = 0; i < DIM / 32; i++) asm volatile("" : : "v"(warm[i]));  // the touches are loads the compiler must keep
         }
         // the decay of the entries before / after this lane's own tile
         float pb = 0;
@@ -1019,6 +1036,7 @@ __device__ __forceinline__ void long_chain_gram(const TrainArgs &a, const HotArg
         const float before_ = exists ? exp2f(pb * h.log2_decay_positive + (nb - pb) * h.log2_decay_negative) : 0.0f;
         const float after_ = exists ? exp2f(pa * h.log2_decay_positive + (na - pa) * h.log2_decay_negative) : 0.0f;
         __syncthreads();
+        GVK_GRAM_FRESH();
         // 2. the recurrence of this lane's own tile (quarter q): lane r holds logit_r, kappa_r and row r of the Gram matrix
         float gr[16];
 #pragma unroll
@@ -1047,6 +1065,7 @@ __device__ __forceinline__ void long_chain_gram(const TrainArgs &a, const HotArg
 #undef GVK_GRAM_STEP
         kappa = exists && valid ? kappa * after_ : 0.0f;
         asm volatile("" : "+v"(kappa) : : "memory");  // the rows of step 3 are asked for after the recurrence, not during it (registers)
+        GVK_GRAM_FRESH();
         // 3. the rows again (they are in the L2), weighted; the sixteen rows of every quarter meet by DPP, the rounds in LDS
         {
             f32x4 ca[NCH], cb[NCH], acc[NCH];
@@ -1094,6 +1113,8 @@ __device__ __forceinline__ void long_chain_gram(const TrainArgs &a, const HotArg
     }
     __syncthreads();
 }
+
+#undef GVK_GRAM_FRESH
 
 #if defined(GVK_GRAM_PROBE)  // compile-time probe only (register need of long_chain_gram on its own)
 template <int DIM>
