@@ -296,6 +296,11 @@ def test_long_chains_by_gram_matrices(hip, oracle, dim, k):
                                   serialized=serialized)
             torch.cuda.synchronize()
             sv, sc = tv.cpu().numpy(), tc.cpu().numpy()
+            # chain by chain first, so that a red run says which lengths are off (one tile, several, more than one round)
+            lengths = np.diff(starts.astype(np.int64))
+            off = [(ch, int(lengths[ch]), float(np.abs(g - w).max())) for ch, (g, w) in
+                   enumerate(list(zip(sv[:kv], ov[:kv])) + list(zip(sc[:kc], oc[:kc]))) if not np.allclose(g, w, rtol=1e-4, atol=1e-5)]
+            assert not off, "chains off the oracle (chain, entries, largest difference): %s" % off
             for got, want, keep in ((sv, ov, keep_v), (sc, oc, keep_c)):
                 np.testing.assert_allclose(got[keep], want[keep], rtol=1e-4, atol=1e-5)
             runs.append((sv[:kv].copy(), sc[:kc].copy()))
