@@ -527,10 +527,13 @@ def main(argv=None):
     # HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM); bench.py cannot read PMCs itself
     traffic, pmc_path = None, None
+    same_job = bool(os.environ.get("GVK_BENCH_PMC_SUMMARY"))
     if world == 1 and partitions == 1 and dim == 128 and k == 1 and B == 100000 and N == 1000000 and moments == 0:
         import glob
         wanted = "train_hot_kernel" if solver.hub_rows else "train_kernel"
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary_bench_n1.json")), reverse=True):
+        candidates = [os.environ["GVK_BENCH_PMC_SUMMARY"]] if same_job else \
+            sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary_bench_n1.json")), reverse=True)
+        for path in candidates:
             summary = json.load(open(path))  # the committed PMC passes of this command — of the kernel this run launched only
             if wanted in summary.get("kernel", "") and summary.get("launches_per_batch", 1) == launches:
                 traffic, pmc_path = summary.get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT)
@@ -575,7 +578,14 @@ def main(argv=None):
                      "note": "one in-place ncclAllGather of a head group's slab per schedule step"}
         if world > 1 else None,
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": pmc_path,
+                     "frac": achieved / HBM_PEAK,
+                     # a PMC pass cannot run inside this process: `traffic` is a number only when the job that runs this command also ran
+                     # the PMC passes and says so (GVK_BENCH_PMC_SUMMARY=<the summary it wrote>); otherwise null, with the committed
+                     # passes of the same kernel and launch count beside it
+                     "traffic": traffic if same_job else None,
+                     "traffic_profiled": None if traffic is None or same_job else {"bytes_per_launch": traffic, "source": pmc_path,
+                                         "note": "rocprofv3 --pmc passes of this command on another box (profiles/), not of this run"},
+                     "traffic_source": pmc_path if same_job else None,
                      "kernel": kernel_name, "kernel_ms": kernel_ms, "launches_per_step": launches,
                      "algorithmic_bytes_per_launch": bytes_per_launch},
         "sampler": {"value": sampled / fill_s / 1e6, "unit": "million edge-samples/sec per GPU", "threads": threads,
