@@ -1,0 +1,35 @@
+#!/bin/bash
+# Round 5: the judged measurements on one MI355X in one job (outputs under gpurun_out/, summarised into profiles/r5 by
+# `python scripts/summarize_profiles.py r5`): GPU suite first (parity is the gate), the driver's bench command, its kernel trace,
+# its PMC passes — and then the bench command once more in the SAME job with GVK_BENCH_PMC_SUMMARY pointing at the summary those
+# passes produced, so that its `roofline.traffic` is a number of this job and box (bench.py prints null otherwise).
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export TMPDIR=/tmp
+R=$PWD
+O=$R/gpurun_out
+mkdir -p $O
+timeout 2800 python -m pytest tests -q -m gpu -rP > $O/pytest_gpu_full.log 2>&1
+grep -E "passed|failed" $O/pytest_gpu_full.log | tail -2; grep -E "^FAILED" $O/pytest_gpu_full.log
+grep -hE "^(headline|tube|hub100k|blog|AUC here|module)" $O/pytest_gpu_full.log > $O/parity_auc.log
+timeout 1200 python bench.py --steps 20 --warmup 5 > $O/bench_n1_steps20.json 2> $O/bench_n1_steps20.err
+tail -c 1500 $O/bench_n1_steps20.json
+SHORT="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-end-to-end --no-module"
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kernel -- $SHORT > $O/prof_kernel.log 2>&1
+for counter in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $counter --output-format csv -d $O/pmc_${counter}_128 -- $SHORT > $O/pmc_${counter}_128.log 2>&1
+done
+timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_L2_128 -- $SHORT > $O/pmc_L2_128.log 2>&1
+cd $R
+find $O -name "*kernel_trace.csv" -size +30M -delete
+# the summary of this job's passes, then the bench line that may quote it
+mkdir -p profiles/r5
+timeout 300 python scripts/summarize_profiles.py r5 > $O/summarize.log 2>&1; tail -3 $O/summarize.log
+if [ -f profiles/r5/pmc_summary_bench_n1.json ]; then
+  cp profiles/r5/pmc_summary_bench_n1.json $O/pmc_summary_bench_n1.json
+  GVK_BENCH_PMC_SUMMARY=$O/pmc_summary_bench_n1.json timeout 600 python bench.py --steps 20 --warmup 5 --no-end-to-end --no-module > $O/bench_n1_steps20_with_traffic.json 2>> $O/bench_n1_steps20.err
+  tail -c 600 $O/bench_n1_steps20_with_traffic.json
+fi
+timeout 600 python bench.py --steps 400 --warmup 50 --no-end-to-end --no-module > $O/bench_n1.json 2> $O/bench_n1.err
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
+tail -2 $O/smoke.log
