@@ -1,0 +1,115 @@
+"""TEST INFRASTRUCTURE: builds tests/hostdev/build/libsimt_gram.so — the SOURCE of `long_chain_gram` (and of the cross-lane helpers it
+uses) cut out of graphvite_amd/csrc/gvk_kernels.hip as written, compiled for the host over tests/hostdev/simt.h (one host thread per
+lane, cross-lane operations as rendezvous).  The empty `asm volatile` statements of the device code (compiler fences with AMDGPU
+register constraints) are the only thing removed."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SOURCE = os.path.join(ROOT, "graphvite_amd", "csrc", "gvk_kernels.hip")
+HOSTDEV = os.path.join(ROOT, "tests", "hostdev")
+OUT = os.path.join(HOSTDEV, "build", "libsimt_gram.so")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+WRAPPER = r'''
+}  // namespace
+
+simt::Group *simt::group = nullptr;
+
+namespace {
+struct Task {
+    unsigned index;
+    int dim;
+    TrainArgs a;
+    HotArgs h;
+    uint32_t chain, first, n;
+};
+
+template <int DIM>
+void chain_of(const Task &t) {
+    // the caller's loop (train_long_chains, GRAM builds): segments of 16 x kGramTiles entries, one after the other
+    for (uint32_t done = 0; done < t.n; done += 16u * kGramTiles)
+        long_chain_gram<DIM>(t.a, t.h, t.chain, t.first + done, t.n - done < 16u * kGramTiles ? t.n - done : 16u * kGramTiles,
+                             (done == 0 ? t.h.from : t.h.to) + (size_t)t.chain * DIM);
+}
+
+void *lane_main(void *p) {
+    const Task &t = *static_cast<const Task *>(p);
+    threadIdx.x = t.index;
+    switch (t.dim) {
+        case 32: chain_of<32>(t); break;
+        case 64: chain_of<64>(t); break;
+        case 96: chain_of<96>(t); break;
+        case 128: chain_of<128>(t); break;
+    }
+    return nullptr;
+}
+}  // namespace
+
+extern "C" int simt_long_chain_gram(int dim, float *vertex, float *context, uint32_t hot_vertex, uint32_t hot_context, float wd,
+                                    float neg_weight, const uint32_t *entries, const float *from, float *to, float lr,
+                                    float log2_decay_positive, float log2_decay_negative, uint32_t chain, uint32_t first, uint32_t n) {
+    if (dim != 32 && dim != 64 && dim != 96 && dim != 128) return -1;
+    static simt::Group g;
+    simt::group = &g;
+    pthread_barrier_init(&g.barrier, nullptr, simt::kThreads);
+    for (auto &w : g.wave) pthread_barrier_init(&w.barrier, nullptr, simt::kWave);
+    Task proto;
+    memset(&proto, 0, sizeof(proto));
+    proto.dim = dim, proto.chain = chain, proto.first = first, proto.n = n;
+    proto.a.vertex = vertex, proto.a.context = context, proto.a.hot_vertex = hot_vertex, proto.a.hot_context = hot_context;
+    proto.a.wd = wd, proto.a.neg_weight = neg_weight;
+    proto.h.entries = entries, proto.h.from = from, proto.h.to = to, proto.h.lr = lr;
+    proto.h.log2_decay_positive = log2_decay_positive, proto.h.log2_decay_negative = log2_decay_negative;
+    static Task tasks[simt::kThreads];
+    pthread_t threads[simt::kThreads];
+    pthread_attr_t attr;
+    pthread_attr_init(&attr);
+    pthread_attr_setstacksize(&attr, 1 << 20);
+    for (int i = 0; i < simt::kThreads; i++) {
+        tasks[i] = proto, tasks[i].index = (unsigned)i;
+        if (pthread_create(&threads[i], &attr, lane_main, &tasks[i]) != 0) return -2;
+    }
+    for (int i = 0; i < simt::kThreads; i++) pthread_join(threads[i], nullptr);
+    pthread_barrier_destroy(&g.barrier);
+    for (auto &w : g.wave) pthread_barrier_destroy(&w.barrier);
+    return 0;
+}
+'''
+
+
+def cut(text, begin, end, include_end=True):
+    a = text.index(begin)
+    b = text.index(end, a)
+    return text[a:b + (len(end) if include_end else 0)]
+
+
+def host_source():
+    text = open(SOURCE).read()
+    pieces = [
+        '#include "simt.h"\n#include <algorithm>\nstruct gvk_alias_entry;\nstruct gvk_class_entry;\nnamespace {\nconstexpr int kBlock = 256;\n',
+        cut(text, "struct TrainArgs {", "\n};\n"),
+        cut(text, "struct HotArgs {", "\n};\n"),
+        cut(text, "template <int CTRL>\n__device__ __forceinline__ float dpp(float x) {", "// ---- Philox4x32-10", include_end=False),
+        cut(text, "constexpr int kGramTiles = 64;", "#undef GVK_GRAM_FRESH"),
+    ]
+    body = "\n".join(pieces)
+    body, fences = re.subn(r'asm volatile\(""[^;]*\);', ";", body)
+    assert fences >= 3, "the device function's compiler fences were expected"
+    assert "asm volatile" not in body and "long_chain_gram" in body
+    return body + "\n" + WRAPPER
+
+
+def build():
+    """Rebuilds when the kernel source, the stand-in or this file is newer than the library; returns its path."""
+    inputs = [SOURCE, os.path.join(HOSTDEV, "simt.h"), os.path.abspath(__file__)]
+    if os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(p) for p in inputs):
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    generated = os.path.join(os.path.dirname(OUT), "simt_gram.cpp")
+    with open(generated, "w") as f:
+        f.write(host_source())
+    compiler = CLANG if os.path.exists(CLANG) else "clang++"
+    subprocess.check_call([compiler, "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-I" + HOSTDEV, generated, "-o", OUT])
+    return OUT
