@@ -91,8 +91,10 @@ inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
 }  // namespace simt
 
 inline void __syncthreads() { pthread_barrier_wait(&simt::group->barrier); }
-inline int __shfl(int v, int source, int width = 64) { (void)width; return (int)simt::exchange((uint32_t)v, source); }
-inline float __shfl(float v, int source, int width = 64) { (void)width; return simt::real(simt::exchange(simt::bits(v), source)); }
+// __shfl(value, source, width): lane `source` of the caller's own group of `width` lanes (hip/amd_detail/amd_warp_functions.h)
+inline int shfl_source(int source, int width) { return (simt::lane() & ~(width - 1)) | (source & (width - 1)); }
+inline int __shfl(int v, int source, int width = 64) { return (int)simt::exchange((uint32_t)v, shfl_source(source, width)); }
+inline float __shfl(float v, int source, int width = 64) { return simt::real(simt::exchange(simt::bits(v), shfl_source(source, width))); }
 inline float __shfl_xor(float v, int mask, int width = 64) { (void)width; return simt::real(simt::exchange(simt::bits(v), simt::lane() ^ mask)); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline float __expf(float x) { return expf(x); }

@@ -76,6 +76,72 @@ extern "C" int simt_long_chain_gram(int dim, float *vertex, float *context, uint
     for (auto &w : g.wave) pthread_barrier_destroy(&w.barrier);
     return 0;
 }
+
+// ---- the chain side of one unit as train_hot_kernel runs it: train_long_chains (GRAM = 0: the steps, 1: Gram matrices) for every
+// long-chain workgroup, then train_short_chains for every workgroup of short chains; one workgroup at a time
+namespace {
+struct Block {
+    unsigned index;
+    int dim, gram, role;  // role 0: long chains, 1: short chains
+    uint32_t block;
+    const TrainArgs *a;
+    const HotArgs *h;
+};
+
+template <int DIM, int G>
+void block_of(const Block &t) {
+    if (t.role == 1) train_short_chains<DIM, G>(*t.a, *t.h, t.block);
+    else if (t.gram) train_long_chains<DIM, G, 1>(*t.a, *t.h, t.block);
+    else train_long_chains<DIM, G, 0>(*t.a, *t.h, t.block);
+}
+
+void *block_main(void *p) {
+    const Block &t = *static_cast<const Block *>(p);
+    threadIdx.x = t.index;
+    switch (t.dim) {
+        case 32: block_of<32, 8>(t); break;
+        case 64: block_of<64, 16>(t); break;
+        case 96: block_of<96, 8>(t); break;
+        case 128: block_of<128, 16>(t); break;
+    }
+    return nullptr;
+}
+}  // namespace
+
+extern "C" int simt_unit_chains(int dim, int gram, float *vertex, float *context, uint32_t hot_vertex, uint32_t hot_context, float wd,
+                                float neg_weight, const uint32_t *chain_start, const uint32_t *entries, const uint32_t *long_list,
+                                const uint32_t *short_list, uint32_t long_capacity, uint32_t cap, const float *from, float *to, float lr,
+                                float log2_decay_positive, float log2_decay_negative, int long_blocks, int short_blocks) {
+    if (dim != 32 && dim != 64 && dim != 96 && dim != 128) return -1;
+    static simt::Group g;
+    simt::group = &g;
+    TrainArgs a;
+    HotArgs h;
+    memset(&a, 0, sizeof(a)), memset(&h, 0, sizeof(h));
+    a.vertex = vertex, a.context = context, a.hot_vertex = hot_vertex, a.hot_context = hot_context, a.wd = wd, a.neg_weight = neg_weight;
+    h.chain_start = chain_start, h.entries = entries, h.long_list = long_list, h.short_list = short_list;
+    h.from = from, h.to = to, h.chains = hot_vertex + hot_context, h.long_capacity = long_capacity, h.cap = cap, h.lr = lr;
+    h.log2_decay_positive = log2_decay_positive, h.log2_decay_negative = log2_decay_negative;
+    h.long_blocks = long_blocks, h.short_blocks = short_blocks;
+    pthread_attr_t attr;
+    pthread_attr_init(&attr);
+    pthread_attr_setstacksize(&attr, 1 << 20);
+    for (int role = 0; role < 2; role++)
+        for (int b = 0; b < (role ? short_blocks : long_blocks); b++) {
+            pthread_barrier_init(&g.barrier, nullptr, simt::kThreads);
+            for (auto &w : g.wave) pthread_barrier_init(&w.barrier, nullptr, simt::kWave);
+            static Block blocks[simt::kThreads];
+            pthread_t threads[simt::kThreads];
+            for (int i = 0; i < simt::kThreads; i++) {
+                blocks[i] = Block{(unsigned)i, dim, gram, role, (uint32_t)b, &a, &h};
+                if (pthread_create(&threads[i], &attr, block_main, &blocks[i]) != 0) return -2;
+            }
+            for (int i = 0; i < simt::kThreads; i++) pthread_join(threads[i], nullptr);
+            pthread_barrier_destroy(&g.barrier);
+            for (auto &w : g.wave) pthread_barrier_destroy(&w.barrier);
+        }
+    return 0;
+}
 '''
 
 
@@ -90,9 +156,11 @@ def host_source():
     pieces = [
         '#include "simt.h"\n#include <algorithm>\nstruct gvk_alias_entry;\nstruct gvk_class_entry;\nnamespace {\nconstexpr int kBlock = 256;\n',
         cut(text, "struct TrainArgs {", "\n};\n"),
-        cut(text, "struct HotArgs {", "\n};\n"),
         cut(text, "template <int CTRL>\n__device__ __forceinline__ float dpp(float x) {", "// ---- Philox4x32-10", include_end=False),
-        cut(text, "constexpr int kGramTiles = 64;", "#undef GVK_GRAM_FRESH"),
+        cut(text, "template <int DIM, int G>\nstruct Layout {", "// ---- arithmetic", include_end=False),
+        cut(text, "__device__ __forceinline__ float sigmoidf(float x) {", "\n}\n"),
+        # HotArgs, the chains of 1 .. 7 entries, the idle rows, long_chain_gram, train_long_chains: everything up to the kernel itself
+        cut(text, "struct HotArgs {", "// HOT: 1 = the pairs read a hub row as the chains of their unit left it", include_end=False),
     ]
     body = "\n".join(pieces)
     body, fences = re.subn(r'asm volatile\(""[^;]*\);', ";", body)

@@ -28,6 +28,7 @@ def simt():
     return lib
 
 
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("dim,n", [(128, 8), (128, 17), (128, 250), (128, 257), (128, 1024), (128, 1500), (32, 100), (64, 257), (96, 40)])
 def test_device_source_of_the_gram_form_matches_the_oracle(simt, dim, n):
     rng = np.random.default_rng(77 * dim + n)
@@ -71,3 +72,80 @@ def test_device_source_of_the_gram_form_matches_the_oracle(simt, dim, n):
         others = np.ones(kv + kc, bool)
         others[chain] = False
         assert (to[others] == mirror[others]).all()  # a chain stores its own row and nothing else
+
+
+LANES_PER_CHAIN = {32: 8, 64: 16, 96: 8, 128: 16}  # default_lanes, gvk_kernels.hip
+
+
+def unit_lists(rng, rows, kv, kc, samples, k):
+    """A unit of `samples` samples with skewed hub rows on both sides, its work lists by the oracle (gvo_hot_lists) and the two
+    record lists in the layout hot_list_kernel writes (long: {chain, first, n, -} from word 4; short: 16 words {chain, n, -, -,
+    entries} from word 16; word 0 of each = the number of records)."""
+    def column(hot):
+        ids = rng.integers(hot, rows, samples)
+        pick = rng.random(samples) < 0.5
+        ids[pick] = np.minimum((rng.pareto(0.9, pick.sum()) * 1.5).astype(np.int64), hot - 1)
+        return ids
+    batch = np.stack([column(kc), column(kv)], 1).astype(np.uint32)  # records are {tail, head}
+    negatives = column(kc).astype(np.uint32).reshape(samples, k)
+    start, entries = Oracle().hot_lists(batch, negatives, kv, kc)
+    return batch, negatives, start, entries
+
+
+def records(start, entries, chains, cap):
+    lengths = np.diff(start.astype(np.int64))
+    long_chains = [c for c in range(chains) if lengths[c] > cap]
+    short_chains = [c for c in range(chains) if 0 < lengths[c] <= cap]
+    long_list = np.zeros(4 * (1 + chains), np.uint32)
+    long_list[0] = len(long_chains)
+    for j, c in enumerate(long_chains):
+        long_list[4 + 4 * j:8 + 4 * j] = (c, start[c], lengths[c], 0)
+    short_list = np.zeros(16 * (1 + chains), np.uint32)
+    short_list[0] = len(short_chains)
+    for j, c in enumerate(short_chains):
+        short_list[16 + 16 * j], short_list[17 + 16 * j] = c, lengths[c]
+        short_list[20 + 16 * j:20 + 16 * j + lengths[c]] = entries[start[c]:start[c + 1]]
+    return long_list, short_list, long_chains, short_chains, lengths
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("dim", [128, 32, 64, 96])
+@pytest.mark.parametrize("gram", [0, 1])
+def test_chain_side_of_a_unit_from_the_device_source(simt, dim, gram):
+    """train_long_chains (the shipped steps, GRAM = 0, and the Gram form, GRAM = 1) and train_short_chains as train_hot_kernel runs
+    them — record lists, workgroup loops, composition in LDS — against gvo_hot_unit_chains on the same lists."""
+    fp, up = np.ctypeslib.ndpointer(np.float32, flags="C"), np.ctypeslib.ndpointer(np.uint32, flags="C")
+    simt.simt_unit_chains.restype = C.c_int
+    simt.simt_unit_chains.argtypes = [C.c_int, C.c_int, fp, fp, C.c_uint32, C.c_uint32, C.c_float, C.c_float, up, up, up, up, C.c_uint32,
+                                      C.c_uint32, fp, fp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
+    rng = np.random.default_rng(31 * dim + gram)
+    oracle = Oracle()
+    kv, kc, rows, samples, k, cap = 30, 44, 300, 700, 1, 7
+    vertex = (rng.standard_normal((rows, dim)) * 0.3).astype(F)
+    context = (rng.standard_normal((rows, dim)) * 0.3).astype(F)
+    lr, wd, nw = F(0.025), F(0.005), F(5.0)
+    batch, negatives, start, entries = unit_lists(rng, rows, kv, kc, samples, k)
+    chains = kv + kc
+    long_list, short_list, long_chains, short_chains, lengths = records(start, entries, chains, cap)
+    G = LANES_PER_CHAIN[dim]
+    # the stand-in cannot run a shuffle that only some lane groups of a wavefront take part in (train_short_chains reads its record
+    # under `mine`): whole wavefronts of short chains only — the chains beyond are left out of the run and of the comparison
+    whole = len(short_chains) // (64 // G) * (64 // G)
+    left_out, short_chains = short_chains[whole:], short_chains[:whole]
+    short_list[0] = whole
+    assert lengths.max() > cap * (256 // G) and len(short_chains) >= 64 // G and len(long_chains) >= 5  # steps beyond seven per task, too
+    mirror = np.ascontiguousarray(np.concatenate([vertex[:kv], context[:kc]]))
+    to = mirror.copy()
+    entries = np.ascontiguousarray(np.concatenate([entries, np.zeros(64, np.uint32)]))
+    rc = simt.simt_unit_chains(dim, gram, vertex, context, kv, kc, wd, nw, np.ascontiguousarray(start, np.uint32), entries, long_list,
+                               short_list, chains, cap, mirror, to, lr, F(np.log2(1.0 - float(lr) * float(wd))),
+                               F(np.log2(1.0 - float(lr) * float(nw) * float(wd))), len(long_chains), -(-len(short_chains) // (256 // G)))
+    assert rc == 0
+    ov, oc = oracle_chain(oracle, dim, vertex, context, lr, wd, nw, kv, kc, np.ascontiguousarray(start, np.uint32), entries,
+                          16 if gram else cap, 64 if gram else 256 // G)
+    want = np.concatenate([ov[:kv], oc[:kc]])
+    for chain in range(chains):
+        if lengths[chain] == 0 or chain in left_out:
+            assert (to[chain] == mirror[chain]).all()  # rows without entries are copy_idle_rows' business
+        else:
+            np.testing.assert_allclose(to[chain], want[chain], rtol=1e-4, atol=1e-5, err_msg="chain %d of %d entries" % (chain, lengths[chain]))
