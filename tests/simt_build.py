@@ -103,6 +103,8 @@ void *block_main(void *p) {
         case 64: block_of<64, 16>(t); break;
         case 96: block_of<96, 8>(t); break;
         case 128: block_of<128, 16>(t); break;
+        case 256: block_of<256, 16>(t); break;  // no Gram form beyond dim 128: GRAM is ignored there
+        case 512: block_of<512, 32>(t); break;
     }
     return nullptr;
 }
@@ -112,7 +114,7 @@ extern "C" int simt_unit_chains(int dim, int gram, float *vertex, float *context
                                 float neg_weight, const uint32_t *chain_start, const uint32_t *entries, const uint32_t *long_list,
                                 const uint32_t *short_list, uint32_t long_capacity, uint32_t cap, const float *from, float *to, float lr,
                                 float log2_decay_positive, float log2_decay_negative, int long_blocks, int short_blocks) {
-    if (dim != 32 && dim != 64 && dim != 96 && dim != 128) return -1;
+    if (dim != 32 && dim != 64 && dim != 96 && dim != 128 && dim != 256 && dim != 512) return -1;
     static simt::Group g;
     simt::group = &g;
     TrainArgs a;

@@ -74,7 +74,7 @@ def test_device_source_of_the_gram_form_matches_the_oracle(simt, dim, n):
         assert (to[others] == mirror[others]).all()  # a chain stores its own row and nothing else
 
 
-LANES_PER_CHAIN = {32: 8, 64: 16, 96: 8, 128: 16}  # default_lanes, gvk_kernels.hip
+LANES_PER_CHAIN = {32: 8, 64: 16, 96: 8, 128: 16, 256: 16, 512: 32}  # default_lanes, gvk_kernels.hip
 
 
 def unit_lists(rng, rows, kv, kc, samples, k):
@@ -109,8 +109,7 @@ def records(start, entries, chains, cap):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("dim", [128, 32, 64, 96])
-@pytest.mark.parametrize("gram", [0, 1])
+@pytest.mark.parametrize("dim,gram", [(128, 0), (128, 1), (32, 0), (32, 1), (64, 0), (64, 1), (96, 0), (96, 1), (256, 0), (512, 0)])
 def test_chain_side_of_a_unit_from_the_device_source(simt, dim, gram):
     """train_long_chains (the shipped steps, GRAM = 0, and the Gram form, GRAM = 1) and train_short_chains as train_hot_kernel runs
     them — record lists, workgroup loops, composition in LDS — against gvo_hot_unit_chains on the same lists."""
