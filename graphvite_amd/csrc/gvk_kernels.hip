@@ -929,7 +929,8 @@ __device__ __forceinline__ float row_bcast(float x) {  // lane J of every 16-lan
 
 template <int DIM>
 __device__ __forceinline__ void long_chain_gram(const TrainArgs &a, const HotArgs &h, const uint32_t chain, const uint32_t first,
-                                                const uint32_t n, const float *row0) {
+                                                const uint32_t n, const float *row0, const bool stamp) {
+    (void)stamp;  // measurement build only: the workgroup's first chain leaves its stamps
     constexpr int NCH = DIM / 16;  // float4 chunks of a row per lane: lane (r, q) of a wavefront holds chunks q, q + 4, ... of row r
     static_assert(DIM % 16 == 0 && kBlock == 256, "four wavefronts, rows in sixteenths");
     __shared__ __attribute__((aligned(16))) float gram[4][4][256];  // [wavefront][quarter][16 x 16], row-major (symmetric)
@@ -966,6 +967,7 @@ __device__ __forceinline__ void long_chain_gram(const TrainArgs &a, const HotArg
         if (r == 0) positives[t] = (float)__popcll((mask >> (16 * q)) & 0xffffull);
     }
     __syncthreads();
+    if (stamp) GVK_STAMP(h, 3);  // own row and the entries are here
     float all = 0;
     for (uint32_t t = 0; t < tiles; t++) all += positives[t];
     const float total = exp2f(all * h.log2_decay_positive + ((float)n - all) * h.log2_decay_negative);
@@ -1036,6 +1038,7 @@ __device__ __forceinline__ void long_chain_gram(const TrainArgs &a, const HotArg
         const float before_ = exists ? exp2f(pb * h.log2_decay_positive + (nb - pb) * h.log2_decay_negative) : 0.0f;
         const float after_ = exists ? exp2f(pa * h.log2_decay_positive + (na - pa) * h.log2_decay_negative) : 0.0f;
         __syncthreads();
+        if (stamp && p == 0) GVK_STAMP(h, 4);  // the round's rows and Gram matrices are here
         GVK_GRAM_FRESH();
         // 2. the recurrence of this lane's own tile (quarter q): lane r holds logit_r, kappa_r and row r of the Gram matrix
         float gr[16];
@@ -1065,6 +1068,7 @@ __device__ __forceinline__ void long_chain_gram(const TrainArgs &a, const HotArg
 #undef GVK_GRAM_STEP
         kappa = exists && valid ? kappa * after_ : 0.0f;
         asm volatile("" : "+v"(kappa) : : "memory");  // the rows of step 3 are asked for after the recurrence, not during it (registers)
+        if (stamp && p == 0) GVK_STAMP(h, 5);  // the recurrence is done
         GVK_GRAM_FRESH();
         // 3. the rows again (they are in the L2), weighted; the sixteen rows of every quarter meet by DPP, the rounds in LDS
         {
@@ -1120,7 +1124,7 @@ __device__ __forceinline__ void long_chain_gram(const TrainArgs &a, const HotArg
 template <int DIM>
 __global__ void __launch_bounds__(kBlock, 4) gram_probe_kernel(const TrainArgs a, const HotArgs h) {
     const u32x4 record = *reinterpret_cast<const u32x4 *>(h.long_list + 4 + 4 * (size_t)blockIdx.x);
-    long_chain_gram<DIM>(a, h, record.x, record.y, record.z, h.from + (size_t)record.x * DIM);
+    long_chain_gram<DIM>(a, h, record.x, record.y, record.z, h.from + (size_t)record.x * DIM, false);
 }
 template __global__ void gram_probe_kernel<32>(const TrainArgs, const HotArgs);
 template __global__ void gram_probe_kernel<128>(const TrainArgs, const HotArgs);
@@ -1159,8 +1163,8 @@ __device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotA
             // is the one this workgroup has just stored: __syncthreads orders a workgroup's own stores and loads)
             for (uint32_t done = 0; done < n; done += 16u * kGramTiles)
                 long_chain_gram<DIM>(a, h, chain, first + done, n - done < 16u * kGramTiles ? n - done : 16u * kGramTiles,
-                                     (done == 0 ? h.from : h.to) + (size_t)chain * DIM);
-            if (j == block) GVK_STAMP(h, 6);
+                                     (done == 0 ? h.from : h.to) + (size_t)chain * DIM, j == block && done == 0);
+            if (j == block) GVK_STAMP(h, 6);  // composed and stored
         } else {
         // NG tasks at most: a longer chain gets longer tasks
         uint32_t per = h.cap;

@@ -31,7 +31,7 @@ void chain_of(const Task &t) {
     // the caller's loop (train_long_chains, GRAM builds): segments of 16 x kGramTiles entries, one after the other
     for (uint32_t done = 0; done < t.n; done += 16u * kGramTiles)
         long_chain_gram<DIM>(t.a, t.h, t.chain, t.first + done, t.n - done < 16u * kGramTiles ? t.n - done : 16u * kGramTiles,
-                             (done == 0 ? t.h.from : t.h.to) + (size_t)t.chain * DIM);
+                             (done == 0 ? t.h.from : t.h.to) + (size_t)t.chain * DIM, false);
 }
 
 void *lane_main(void *p) {
