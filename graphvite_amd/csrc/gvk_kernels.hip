@@ -971,12 +971,27 @@ __device__ __forceinline__ void long_chain_gram(const TrainArgs &a, const HotArg
     float all = 0;
     for (uint32_t t = 0; t < tiles; t++) all += positives[t];
     const float total = exp2f(all * h.log2_decay_positive + ((float)n - all) * h.log2_decay_negative);
+    uint32_t e_carry = e_first;  // this lane's entry of the round at hand (the next round's is asked for a round ahead)
     for (uint32_t p = 0; p < rounds; p++) {  // the same for the whole block
         const uint32_t t_wave = (uint32_t)wave + 16 * p;          // this wavefront's tiles of the round: t_wave + 4 qq
         const uint32_t t_own = t_wave + 4 * (uint32_t)q;          // this lane's own tile
         const bool exists = t_own < tiles;
         const uint32_t at = first + 16 * t_own + r;
-        const uint32_t e_own = p == 0 ? e_first : (at < last ? h.entries[at] : 0);
+        const uint32_t e_own = e_carry;
+        // a chain of more than 256 entries: the next round's entry of this lane, and the lines of its row, are asked for now
+        uint32_t e_next = 0;
+        float warm_next[DIM / 32];
+#pragma unroll
+        for (int i = 0; i < DIM / 32; i++) warm_next[i] = 0;
+        if (p + 1 < rounds) {
+            const uint32_t at_next = at + 256;
+            e_next = at_next < last ? h.entries[at_next] : 0;
+            const uint32_t id = e_next & 0x7fffffffu;
+            const float *row = id < partner_hot ? partner_mirror + (size_t)id * DIM : partner_table + (size_t)id * DIM;
+            const float *touch = at_next < last ? row : row0;
+#pragma unroll
+            for (int i = 0; i < DIM / 32; i++) warm_next[i] = touch[32 * i];
+        }
         GVK_GRAM_FRESH();
         // 1. per tile of this wavefront: rows, Gram matrix, start logits; the next tile's rows are asked for before this one's matrix
         float logit = 0;
@@ -1103,6 +1118,9 @@ __device__ __forceinline__ void long_chain_gram(const TrainArgs &a, const HotArg
                 }
             }
         }
+#pragma unroll
+        for (int i = 0; i < DIM / 32; i++) asm volatile("" : : "v"(warm_next[i]));
+        e_carry = e_next;
         __syncthreads();  // the next round writes the Gram tiles again; after the last one the wavefronts' sums are in LDS
     }
     if (threadIdx.x < DIM / 4) {
