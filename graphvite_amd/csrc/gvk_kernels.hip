@@ -933,7 +933,7 @@ __device__ __forceinline__ void long_chain_gram(const TrainArgs &a, const HotArg
     (void)stamp;  // measurement build only: the workgroup's first chain leaves its stamps
     constexpr int NCH = DIM / 16;  // float4 chunks of a row per lane: lane (r, q) of a wavefront holds chunks q, q + 4, ... of row r
     static_assert(DIM % 16 == 0 && kBlock == 256, "four wavefronts, rows in sixteenths");
-    __shared__ __attribute__((aligned(16))) float gram[4][4][256];  // [wavefront][quarter][16 x 16], row-major (symmetric)
+    __shared__ __attribute__((aligned(16))) float gram[4][2][4][256];  // [wavefront][sub-round][quarter][16 x 16], row-major (symmetric)
     __shared__ __attribute__((aligned(16))) float part[4][DIM];     // a wavefront's weighted sum of its tasks' rows
     __shared__ __attribute__((aligned(16))) float own_row[DIM];     // the chain's row as the unit found it
     __shared__ float positives[kGramTiles];
@@ -958,11 +958,16 @@ __device__ __forceinline__ void long_chain_gram(const TrainArgs &a, const HotArg
     };
     // tile t = wave + 4 quarter + 16 round.  The own row into LDS; the positives of every tile; this lane's entry of round 0
     if (threadIdx.x < DIM / 4) reinterpret_cast<f32x4 *>(own_row)[threadIdx.x] = reinterpret_cast<const f32x4 *>(row0)[threadIdx.x];
-    uint32_t e_first = 0;
+    // A PASS takes up to 32 tiles: two per quarter of a wavefront (sub-rounds s = 0, 1: tile t = wave + 4 quarter + 16 (2 pass + s)),
+    // whose recurrences run in the same sixteen steps — two independent dependency chains per lane.  A chain of up to 256 entries
+    // has one sub-round; the top hub's 250 +- 16 entries, or its 290 at the shard size of an 8-GPU run, spill a few tiles into the
+    // second, which then costs them their rows and matrices and little else.
+    uint32_t e_first[2] = {0, 0};
     for (uint32_t p = 0; p < rounds; p++) {
         const uint32_t t = (uint32_t)(wave + 4 * q) + 16 * p, at = first + 16 * t + r;
         const uint32_t e = at < last ? h.entries[at] : 0;
-        if (p == 0) e_first = e;
+        if (p == 0) e_first[0] = e;
+        if (p == 1) e_first[1] = e;
         const unsigned long long mask = __builtin_amdgcn_ballot_w64((e >> 31) != 0);
         if (r == 0) positives[t] = (float)__popcll((mask >> (16 * q)) & 0xffffull);
     }
@@ -971,43 +976,37 @@ __device__ __forceinline__ void long_chain_gram(const TrainArgs &a, const HotArg
     float all = 0;
     for (uint32_t t = 0; t < tiles; t++) all += positives[t];
     const float total = exp2f(all * h.log2_decay_positive + ((float)n - all) * h.log2_decay_negative);
-    uint32_t e_carry = e_first;  // this lane's entry of the round at hand (the next round's is asked for a round ahead)
-    for (uint32_t p = 0; p < rounds; p++) {  // the same for the whole block
-        const uint32_t t_wave = (uint32_t)wave + 16 * p;          // this wavefront's tiles of the round: t_wave + 4 qq
-        const uint32_t t_own = t_wave + 4 * (uint32_t)q;          // this lane's own tile
-        const bool exists = t_own < tiles;
-        const uint32_t at = first + 16 * t_own + r;
-        const uint32_t e_own = e_carry;
-        // a chain of more than 256 entries: the next round's entry of this lane, and the lines of its row, are asked for now
-        uint32_t e_next = 0;
-        float warm_next[DIM / 32];
+    const uint32_t passes = (rounds + 1) / 2;
+    for (uint32_t pass = 0; pass < passes; pass++) {  // the same for the whole block
+        const bool second = 16 * (2 * pass + 1) < tiles;  // the pass has tiles in its second sub-round (the same for the whole block)
+        uint32_t t_wave[2], t_own[2], at[2], e_own[2];
+        bool exists[2];
 #pragma unroll
-        for (int i = 0; i < DIM / 32; i++) warm_next[i] = 0;
-        if (p + 1 < rounds) {
-            const uint32_t at_next = at + 256;
-            e_next = at_next < last ? h.entries[at_next] : 0;
-            const uint32_t id = e_next & 0x7fffffffu;
-            const float *row = id < partner_hot ? partner_mirror + (size_t)id * DIM : partner_table + (size_t)id * DIM;
-            const float *touch = at_next < last ? row : row0;
-#pragma unroll
-            for (int i = 0; i < DIM / 32; i++) warm_next[i] = touch[32 * i];
+        for (int s = 0; s < 2; s++) {
+            t_wave[s] = (uint32_t)wave + 16 * (2 * pass + s);  // this wavefront's tiles of the sub-round: t_wave + 4 qq
+            t_own[s] = t_wave[s] + 4 * (uint32_t)q;            // this lane's own tile
+            exists[s] = t_own[s] < tiles;
+            at[s] = first + 16 * t_own[s] + r;
+            // (a second pass — a chain of more than 512 entries, rare — reads its entries when it starts)
+            e_own[s] = pass == 0 ? e_first[s] : (at[s] < last ? h.entries[at[s]] : 0);
         }
         GVK_GRAM_FRESH();
         // 1. per tile of this wavefront: rows, Gram matrix, start logits; the next tile's rows are asked for before this one's matrix
-        float logit = 0;
+        float logit[2] = {0, 0};
         {
-            // every lane touches the 128-byte lines of its own entry's row first: the rows of all four tiles are on their way
-            // (one register per line) while the first two tiles are asked for in full
-            float warm[DIM / 32];
-            {
-                const uint32_t id = e_own & 0x7fffffffu;
-                const float *row = id < partner_hot ? partner_mirror + (size_t)id * DIM : partner_table + (size_t)id * DIM;
-                const float *touch = at < last ? row : row0;
+            // every lane touches the 128-byte lines of its own entries' rows first: the rows of all the wavefront's tiles are on their
+            // way (one register per line) while the first two tiles are asked for in full
+            float warm[2][DIM / 32];
 #pragma unroll
-                for (int i = 0; i < DIM / 32; i++) warm[i] = touch[32 * i];
+            for (int s = 0; s < 2; s++) {
+                const uint32_t id = e_own[s] & 0x7fffffffu;
+                const float *row = id < partner_hot ? partner_mirror + (size_t)id * DIM : partner_table + (size_t)id * DIM;
+                const float *touch = at[s] < last ? row : row0;
+#pragma unroll
+                for (int i = 0; i < DIM / 32; i++) warm[s][i] = (s == 0 || second) ? touch[32 * i] : 0.0f;
             }
             f32x4 ca[NCH], cb[NCH];
-            auto matrix = [&](const int qq, const f32x4 (&c)[NCH]) __attribute__((always_inline)) {
+            auto matrix = [&](const int s, const int qq, const f32x4 (&c)[NCH]) __attribute__((always_inline)) {
                 f32x4 g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0};
                 float dot = 0;
 #pragma unroll
@@ -1020,108 +1019,144 @@ __device__ __forceinline__ void long_chain_gram(const TrainArgs &a, const HotArg
                     dot += c[m].x * v.x + c[m].y * v.y + c[m].z * v.z + c[m].w * v.w;
                 }
                 // lane (column r, quarter q) holds G[4 q + v][r] in component v
-                float *tile = &gram[wave][qq][0];
+                float *tile = &gram[wave][s][qq][0];
                 tile[(4 * q + 0) * 16 + r] = g0.x + g1.x;
                 tile[(4 * q + 1) * 16 + r] = g0.y + g1.y;
                 tile[(4 * q + 2) * 16 + r] = g0.z + g1.z;
                 tile[(4 * q + 3) * 16 + r] = g0.w + g1.w;
                 dot += __shfl_xor(dot, 16, 64);
                 dot += __shfl_xor(dot, 32, 64);
-                if (q == qq) logit = dot;  // own row . c_r of this lane's own tile
+                if (q == qq) logit[s] = dot;  // own row . c_r of this lane's own tile
             };
-            // no branches: a tile past the chain's end is sixteen copies of the own row with weight 0 (the longest chain, whose
-            // wavefronts all have four tiles, is what the launch waits for)
-            if (t_wave < tiles) {
-                load_tile(t_wave, e_own, 0, ca);
-                load_tile(t_wave + 4, e_own, 1, cb);
-                matrix(0, ca);
-                load_tile(t_wave + 8, e_own, 2, ca);
-                matrix(1, cb);
-                load_tile(t_wave + 12, e_own, 3, cb);
-                matrix(2, ca);
-                matrix(3, cb);
+            // no branches inside a sub-round: a tile past the chain's end is sixteen copies of the own row with weight 0 (the longest
+            // chain, whose wavefronts all have four tiles, is what the launch waits for)
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                if (t_wave[s] < tiles) {  // the same for the whole wavefront
+                    load_tile(t_wave[s], e_own[s], 0, ca);
+                    load_tile(t_wave[s] + 4, e_own[s], 1, cb);
+                    matrix(s, 0, ca);
+                    load_tile(t_wave[s] + 8, e_own[s], 2, ca);
+                    matrix(s, 1, cb);
+                    load_tile(t_wave[s] + 12, e_own[s], 3, cb);
+                    matrix(s, 2, ca);
+                    matrix(s, 3, cb);
+                }
             }
 #pragma unroll
-            for (int i = 0; i < DIM / 32; i++) asm volatile("" : : "v"(warm[i]));  // the touches are loads the compiler must keep
-        }
-        // the decay of the entries before / after this lane's own tile
-        float pb = 0;
-        for (uint32_t t = 0; t < tiles; t++) pb += t < t_own ? positives[t] : 0.0f;
-        const float pi = exists ? positives[exists ? t_own : 0] : 0.0f;
-        const float nb = (float)(16 * t_own), ni = exists ? (float)(n - 16 * t_own < 16 ? n - 16 * t_own : 16) : 0.0f;
-        const float pa = all - pb - pi, na = (float)n - nb - ni;
-        const float before_ = exists ? exp2f(pb * h.log2_decay_positive + (nb - pb) * h.log2_decay_negative) : 0.0f;
-        const float after_ = exists ? exp2f(pa * h.log2_decay_positive + (na - pa) * h.log2_decay_negative) : 0.0f;
-        __syncthreads();
-        if (stamp && p == 0) GVK_STAMP(h, 4);  // the round's rows and Gram matrices are here
-        GVK_GRAM_FRESH();
-        // 2. the recurrence of this lane's own tile (quarter q): lane r holds logit_r, kappa_r and row r of the Gram matrix
-        float gr[16];
+            for (int s = 0; s < 2; s++)
 #pragma unroll
-        for (int x = 0; x < 4; x++) {
-            const f32x4 g = reinterpret_cast<const f32x4 *>(&gram[wave][q][r * 16])[x];
-            gr[4 * x + 0] = exists ? g.x : 0.0f; gr[4 * x + 1] = exists ? g.y : 0.0f;
-            gr[4 * x + 2] = exists ? g.z : 0.0f; gr[4 * x + 3] = exists ? g.w : 0.0f;
+                for (int i = 0; i < DIM / 32; i++) asm volatile("" : : "v"(warm[s][i]));  // the touches are loads the compiler must keep
         }
-        const bool valid = at < last, positive = (e_own >> 31) != 0;
-        // weight and label of this lane's entry in one word for the row broadcasts: + 1 positive, - negative_weight negative, 0 past the end
-        const float signed_weight = valid ? (positive ? 1.0f : -a.neg_weight) : 0.0f;
-        logit = exists ? logit * before_ : 0.0f;
-        float kappa = 0;
-        auto step = [&](const float s, const float sw, const float g_jr, const bool own) __attribute__((always_inline)) {
-            const float w = fabsf(sw), aj = 1.0f - h.lr * w * a.wd;
-            // lr w (prob - label): model/graph.h:47-58; the sigmoid by v_exp_f32 and v_rcp_f32 (a few ulp from sigmoidf's; this
-            // path reorders the sums of a task anyway)
-            const float ex = __expf(-fabsf(s));
-            const float b = h.lr * w * ((s > 0 ? 1.0f : ex) * __builtin_amdgcn_rcpf(1.0f + ex) - (sw > 0 ? 1.0f : 0.0f));
-            logit = aj * logit - b * g_jr;
-            kappa = own ? b : kappa * aj;
-        };
-#define GVK_GRAM_STEP(J) step(row_bcast<J>(logit), row_bcast<J>(signed_weight), gr[J], r == J);
-        GVK_GRAM_STEP(0) GVK_GRAM_STEP(1) GVK_GRAM_STEP(2) GVK_GRAM_STEP(3) GVK_GRAM_STEP(4) GVK_GRAM_STEP(5) GVK_GRAM_STEP(6) GVK_GRAM_STEP(7)
-        GVK_GRAM_STEP(8) GVK_GRAM_STEP(9) GVK_GRAM_STEP(10) GVK_GRAM_STEP(11) GVK_GRAM_STEP(12) GVK_GRAM_STEP(13) GVK_GRAM_STEP(14) GVK_GRAM_STEP(15)
-#undef GVK_GRAM_STEP
-        kappa = exists && valid ? kappa * after_ : 0.0f;
-        asm volatile("" : "+v"(kappa) : : "memory");  // the rows of step 3 are asked for after the recurrence, not during it (registers)
-        if (stamp && p == 0) GVK_STAMP(h, 5);  // the recurrence is done
+        // the decay of the entries before / after this lane's own tiles
+        float before_[2], after_[2];
+        {
+            float pb[2] = {0, 0};
+            for (uint32_t t = 0; t < tiles; t++) {
+                const float x = positives[t];
+                pb[0] += t < t_own[0] ? x : 0.0f;
+                pb[1] += t < t_own[1] ? x : 0.0f;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const float pi = exists[s] ? positives[exists[s] ? t_own[s] : 0] : 0.0f;
+                const float nb = (float)(16 * t_own[s]), ni = exists[s] ? (float)(n - 16 * t_own[s] < 16 ? n - 16 * t_own[s] : 16) : 0.0f;
+                const float pa = all - pb[s] - pi, na = (float)n - nb - ni;
+                before_[s] = exists[s] ? exp2f(pb[s] * h.log2_decay_positive + (nb - pb[s]) * h.log2_decay_negative) : 0.0f;
+                after_[s] = exists[s] ? exp2f(pa * h.log2_decay_positive + (na - pa) * h.log2_decay_negative) : 0.0f;
+            }
+        }
+        __syncthreads();
+        if (stamp && pass == 0) GVK_STAMP(h, 4);  // the pass's rows and Gram matrices are here
         GVK_GRAM_FRESH();
-        // 3. the rows again (they are in the L2), weighted; the sixteen rows of every quarter meet by DPP, the rounds in LDS
+        // 2. the recurrences of this lane's own tiles (quarter q): lane r holds logit_r, kappa_r and row r of each Gram matrix
+        float kappa[2] = {0, 0};
+        {
+            float gr[2][16];
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    const bool there = exists[s] && (s == 0 || second);
+                    const f32x4 g = there ? reinterpret_cast<const f32x4 *>(&gram[wave][s][q][r * 16])[x] : f32x4{0, 0, 0, 0};
+                    gr[s][4 * x + 0] = g.x; gr[s][4 * x + 1] = g.y; gr[s][4 * x + 2] = g.z; gr[s][4 * x + 3] = g.w;
+                }
+            // weight and label of this lane's entries in one word for the row broadcasts: + 1 positive, - negative_weight negative, 0 past the end
+            float signed_weight[2];
+            bool valid[2];
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                valid[s] = at[s] < last;
+                signed_weight[s] = valid[s] ? ((e_own[s] >> 31) != 0 ? 1.0f : -a.neg_weight) : 0.0f;
+                logit[s] = exists[s] ? logit[s] * before_[s] : 0.0f;
+            }
+            auto step = [&](const int s, const float sl, const float sw, const float g_jr, const bool own) __attribute__((always_inline)) {
+                const float w = fabsf(sw), aj = 1.0f - h.lr * w * a.wd;
+                // lr w (prob - label): model/graph.h:47-58; the sigmoid by v_exp_f32 and v_rcp_f32 (a few ulp from sigmoidf's; this
+                // path reorders the sums of a task anyway)
+                const float ex = __expf(-fabsf(sl));
+                const float b = h.lr * w * ((sl > 0 ? 1.0f : ex) * __builtin_amdgcn_rcpf(1.0f + ex) - (sw > 0 ? 1.0f : 0.0f));
+                logit[s] = aj * logit[s] - b * g_jr;
+                kappa[s] = own ? b : kappa[s] * aj;
+            };
+#define GVK_GRAM_STEP(S, J) step(S, row_bcast<J>(logit[S]), row_bcast<J>(signed_weight[S]), gr[S][J], r == J);
+#define GVK_GRAM_STEPS(S) \
+    GVK_GRAM_STEP(S, 0) GVK_GRAM_STEP(S, 1) GVK_GRAM_STEP(S, 2) GVK_GRAM_STEP(S, 3) GVK_GRAM_STEP(S, 4) GVK_GRAM_STEP(S, 5) \
+    GVK_GRAM_STEP(S, 6) GVK_GRAM_STEP(S, 7) GVK_GRAM_STEP(S, 8) GVK_GRAM_STEP(S, 9) GVK_GRAM_STEP(S, 10) GVK_GRAM_STEP(S, 11) \
+    GVK_GRAM_STEP(S, 12) GVK_GRAM_STEP(S, 13) GVK_GRAM_STEP(S, 14) GVK_GRAM_STEP(S, 15)
+#define GVK_GRAM_BOTH(J) GVK_GRAM_STEP(0, J) GVK_GRAM_STEP(1, J)
+            if (second) {  // two chains per lane, step by step side by side
+                GVK_GRAM_BOTH(0) GVK_GRAM_BOTH(1) GVK_GRAM_BOTH(2) GVK_GRAM_BOTH(3) GVK_GRAM_BOTH(4) GVK_GRAM_BOTH(5) GVK_GRAM_BOTH(6) GVK_GRAM_BOTH(7)
+                GVK_GRAM_BOTH(8) GVK_GRAM_BOTH(9) GVK_GRAM_BOTH(10) GVK_GRAM_BOTH(11) GVK_GRAM_BOTH(12) GVK_GRAM_BOTH(13) GVK_GRAM_BOTH(14) GVK_GRAM_BOTH(15)
+            } else {
+                GVK_GRAM_STEPS(0)
+            }
+#undef GVK_GRAM_BOTH
+#undef GVK_GRAM_STEPS
+#undef GVK_GRAM_STEP
+#pragma unroll
+            for (int s = 0; s < 2; s++) kappa[s] = exists[s] && valid[s] && (s == 0 || second) ? kappa[s] * after_[s] : 0.0f;
+        }
+        asm volatile("" : "+v"(kappa[0]), "+v"(kappa[1]) : : "memory");  // the rows of step 3 are asked for after the recurrence, not during it (registers)
+        if (stamp && pass == 0) GVK_STAMP(h, 5);  // the recurrences are done
+        GVK_GRAM_FRESH();
+        // 3. the rows again (they are in the L2), weighted; the sixteen rows of every quarter meet by DPP, the passes in LDS
         {
             f32x4 ca[NCH], cb[NCH], acc[NCH];
 #pragma unroll
             for (int m = 0; m < NCH; m++) acc[m] = f32x4{0, 0, 0, 0};
-            auto weigh = [&](const int qq, const f32x4 (&c)[NCH]) __attribute__((always_inline)) {
-                const float cf = __shfl(kappa, r + 16 * qq, 64);
+            auto weigh = [&](const int s, const int qq, const f32x4 (&c)[NCH]) __attribute__((always_inline)) {
+                const float cf = __shfl(kappa[s], r + 16 * qq, 64);
 #pragma unroll
                 for (int m = 0; m < NCH; m++) {
                     acc[m].x += cf * c[m].x; acc[m].y += cf * c[m].y; acc[m].z += cf * c[m].z; acc[m].w += cf * c[m].w;
                 }
             };
-            if (t_wave < tiles) {
-                load_tile(t_wave, e_own, 0, ca);
-                load_tile(t_wave + 4, e_own, 1, cb);
-                weigh(0, ca);
-                load_tile(t_wave + 8, e_own, 2, ca);
-                weigh(1, cb);
-                load_tile(t_wave + 12, e_own, 3, cb);
-                weigh(2, ca);
-                weigh(3, cb);
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                if (t_wave[s] < tiles) {
+                    load_tile(t_wave[s], e_own[s], 0, ca);
+                    load_tile(t_wave[s] + 4, e_own[s], 1, cb);
+                    weigh(s, 0, ca);
+                    load_tile(t_wave[s] + 8, e_own[s], 2, ca);
+                    weigh(s, 1, cb);
+                    load_tile(t_wave[s] + 12, e_own[s], 3, cb);
+                    weigh(s, 2, ca);
+                    weigh(s, 3, cb);
+                }
             }
 #pragma unroll
             for (int m = 0; m < NCH; m++) {
                 acc[m].x = group_sum<16>(acc[m].x); acc[m].y = group_sum<16>(acc[m].y);
                 acc[m].z = group_sum<16>(acc[m].z); acc[m].w = group_sum<16>(acc[m].w);
-                if (r == 0) {  // one lane per (wavefront, chunk) adds the rounds in order
+                if (r == 0) {  // one lane per (wavefront, chunk) adds the passes in order
                     f32x4 *sum = reinterpret_cast<f32x4 *>(&part[wave][0]) + 4 * m + q;
-                    if (p == 0) *sum = acc[m];
+                    if (pass == 0) *sum = acc[m];
                     else *sum = *sum + acc[m];
                 }
             }
         }
-#pragma unroll
-        for (int i = 0; i < DIM / 32; i++) asm volatile("" : : "v"(warm_next[i]));
-        e_carry = e_next;
-        __syncthreads();  // the next round writes the Gram tiles again; after the last one the wavefronts' sums are in LDS
+        __syncthreads();  // the next pass writes the Gram tiles again; after the last one the wavefronts' sums are in LDS
     }
     if (threadIdx.x < DIM / 4) {
         const f32x4 v = reinterpret_cast<const f32x4 *>(own_row)[threadIdx.x];

@@ -3,7 +3,8 @@ a lane-level twin of the device code on the CPU, checked against the oracle.
 
 The device function could not be run when it was written (no GPU minutes were left in round 4), and what can go wrong in it is
 index arithmetic: which lane holds which chunk of which row, where `v_mfma_f32_16x16x4_f32` puts its results, which lane a DPP
-row broadcast or a wavefront shuffle reads.  The twin below is the same algorithm statement by statement on arrays of 64 lanes
+row broadcast or a wavefront shuffle reads.  The twin below is the same algorithm on arrays of 64 lanes, one tile per quarter of a wavefront per round (the device function
+runs two rounds' tiles in one pass, their recurrences side by side: tests/test_gram_simt_cpu.py runs its own source)
 (four of them: the wavefronts of a workgroup), with the matrix instruction, the broadcasts and the shuffles in the lane maps of
 /opt/skills/guides/cdna_hip_programming.md ("A[l&15][k=l>>4] / B[k=l>>4][l&15]", "col=lane&15, row=(lane>>4)*4+reg_idx"); it is
 compared with the oracle's tasks-of-16 form (`gvo_hot_unit_chains`, cap 16, max_tasks 64: oracle/gv_oracle.c), which is what

@@ -29,7 +29,7 @@ def simt():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("dim,n", [(128, 17), (128, 257), (128, 1500), (32, 100), (96, 40)])
+@pytest.mark.parametrize("dim,n", [(128, 17), (128, 257), (128, 600), (128, 1500), (32, 100), (96, 40), (64, 300)])
 def test_device_source_of_the_gram_form_matches_the_oracle(simt, dim, n):
     rng = np.random.default_rng(77 * dim + n)
     oracle = Oracle()
