@@ -254,8 +254,9 @@ def test_a_batch_trained_as_parts(hip, oracle):
 
 @pytest.mark.skipif(os.environ.get("GVK_TEST_GRAM") != "1",
                     reason="experiment written without a GPU (round 4, no GPU minutes left): GVK_TEST_GRAM=1 runs it")
+@pytest.mark.parametrize("form", [1, 2])  # the kernel built for three / for four wavefronts per SIMD
 @pytest.mark.parametrize("dim,k", [(128, 1), (128, 3), (32, 1), (64, 1), (96, 2)])
-def test_long_chains_by_gram_matrices(hip, oracle, dim, k):
+def test_long_chains_by_gram_matrices(hip, oracle, dim, k, form):
     """GVK_TUNE_HOT_GRAM (long_chain_gram, gvk_kernels.hip): a long chain as tasks of 16 entries whose steps run on the task's Gram
     matrix.  In exact arithmetic that is the oracle's chains with cap 16, max_tasks 64; the lane maps of the device code are
     pinned on the CPU by tests/test_gram_chain_cpu.py."""
@@ -286,7 +287,7 @@ def test_long_chains_by_gram_matrices(hip, oracle, dim, k):
     lr = oracle.lr(0.025, True, FIRST_ID, TOTAL)
     ov, oc = v.copy(), c.copy()
     oracle.train_hot(ov, oc, pool, nb, lr, 0.005, 5.0, kv, kc, starts, entries[:starts[-1]], 16, max_tasks=64, lerp=False)
-    hip.set_tuning(11, 1)  # GVK_TUNE_HOT_GRAM
+    hip.set_tuning(11, form)  # GVK_TUNE_HOT_GRAM
     try:
         runs = []
         for serialized in (True, False, False):
