@@ -23,6 +23,10 @@
 #undef __device__
 #define __device__ __attribute__((device)) __attribute__((host))
 
+#ifndef GVREF_DIM
+#define GVREF_DIM 128  // the embedding dimension this build of the reference's solver is instantiated for (oracle/Makefile: 128 and 96)
+#endif
+
 int gvref_device_count = 1;
 size_t gvref_device_memory = (size_t)16 << 30;  // a P100's 16 GB, the card the reference's defaults were tuned on
 gvref_uniform_source_t gvref_uniform_source = nullptr;
@@ -35,7 +39,7 @@ int gvref_generator_count = 0;
 // kernels (instance/gpu/graph.cuh, written for nvcc: `model.backward<...>` without the `template` disambiguator does
 // not parse under clang), so they are specialised away before anything instantiates the worker class.
 namespace graphvite {
-typedef SolverMixin<128, float, uint32_t, Graph, GraphSampler, GraphWorker> HarnessSolverBase;
+typedef SolverMixin<GVREF_DIM, float, uint32_t, Graph, GraphSampler, GraphWorker> HarnessSolverBase;
 // gpu::Sample (alias_table.cuh:176-185) run on the host: one draw per pair of uniforms, narrowed to Float as the kernel
 // narrows them, through the table's own sample().  One guard the kernel does not have: a double uniform within 2^-25
 // of 1 narrows to 1.0f, sample() then computes index == count and reads one entry past both tables (AddressSanitizer
@@ -81,15 +85,60 @@ int gvref_kernel_threads = 1;  // host threads that share the (independent) per-
 
 template <>
 bool GraphWorker<HarnessSolverBase>::train_dispatch() {
-    auto *solver = reinterpret_cast<graphvite::GraphSolver<128, float, uint32_t> *>(this->solver);
-    if (num_moment != 0 || optimizer.type != "SGD") return false;
-    typedef graphvite::Vector<128, float> Vec;
+    auto *solver = reinterpret_cast<graphvite::GraphSolver<GVREF_DIM, float, uint32_t> *>(this->solver);
+    typedef graphvite::Vector<GVREF_DIM, float> Vec;
     typedef LINE<Vec> Model;  // DeepWalk and Node2Vec are the same arithmetic (model/graph.h:60-85)
     Vec *vertex_embeddings = embeddings[0]->device_ptr, *context_embeddings = embeddings[1]->device_ptr;
     const uint32_t *samples = batch.device_ptr, *negatives = negative_batch.device_ptr;
     const int num_sample = batch.count / 2, k = negative_batch.count / num_sample;
     const float negative_weight = solver->negative_weight;
     const Optimizer opt = optimizer;
+    if (num_moment != 0) {
+        // train_1_moment / train_2_moment (instance/gpu/graph.cuh:104-242) under the SEQUENTIAL model only: the vertex row is
+        // buffered, its moment rows and the context's row and moment rows are updated in place, sample after sample; the
+        // optimizer's update is bound exactly as graph.cuh:494-551 binds it.
+        if (gvref_kernel_chunk > 0) return false;
+        Vec *vm1 = (*moments[0])[0].device_ptr, *cm1 = (*moments[1])[0].device_ptr;
+        Vec *vm2 = num_moment > 1 ? (*moments[0])[1].device_ptr : nullptr, *cm2 = num_moment > 1 ? (*moments[1])[1].device_ptr : nullptr;
+        const int type = optimizer.type == "Momentum" ? 1 : optimizer.type == "AdaGrad" ? 2 : optimizer.type == "RMSprop" ? 3
+                         : optimizer.type == "Adam" ? 4 : 0;
+        if (!type || (type == 4) != (num_moment == 2)) return false;
+        Vec vertex_buffer;
+        for (int sample_id = 0; sample_id < num_sample; sample_id++) {
+            const uint32_t head_id = samples[sample_id * 2 + 1];
+            Vec &vertex = vertex_embeddings[head_id];
+            vertex_buffer = vertex;
+            float sample_loss = 0;
+            for (int s = 0; s <= k; s++) {
+                const bool label = s == k;
+                const uint32_t tail_id = label ? samples[sample_id * 2] : negatives[sample_id * k + s];
+                Vec &context = context_embeddings[tail_id];
+                float logit;
+                Model::forward(vertex_buffer, context, logit);
+                const float prob = sigmoid(logit);
+                float gradient, weight;
+                if (label) {
+                    gradient = prob - 1;
+                    weight = 1;
+                    sample_loss += weight * -log(prob + kEpsilon);
+                } else {
+                    gradient = prob;
+                    weight = negative_weight;
+                    sample_loss += weight * -log(1 - prob + kEpsilon);
+                }
+                switch (type) {
+                    case 1: Model::template backward<kMomentum>(vertex_buffer, context, vm1[head_id], cm1[tail_id], gradient, opt, weight); break;
+                    case 2: Model::template backward<kAdaGrad>(vertex_buffer, context, vm1[head_id], cm1[tail_id], gradient, opt, weight); break;
+                    case 3: Model::template backward<kRMSprop>(vertex_buffer, context, vm1[head_id], cm1[tail_id], gradient, opt, weight); break;
+                    default: Model::template backward<kAdam>(vertex_buffer, context, vm1[head_id], cm1[tail_id], vm2[head_id], cm2[tail_id], gradient, opt, weight);
+                }
+            }
+            loss.device_ptr[sample_id] = sample_loss / (1 + k * negative_weight);
+            vertex = vertex_buffer;
+        }
+        return true;
+    }
+    if (optimizer.type != "SGD") return false;
     // one target of one sample: graph.cuh:63-88
     auto target = [&](Vec &vertex_buffer, Vec &context, bool label, float &sample_loss) {
         float logit;
@@ -190,7 +239,7 @@ bool GraphWorker<HarnessSolverBase>::predict_dispatch() { return false; }
 
 namespace {
 typedef graphvite::Graph<uint32_t> GraphT;
-typedef graphvite::GraphSolver<128, float, uint32_t> SolverT;
+typedef graphvite::GraphSolver<GVREF_DIM, float, uint32_t> SolverT;
 struct Handle {
     GraphT graph;
     SolverT *solver = nullptr;
@@ -208,6 +257,27 @@ void gvref_set_kernel_model(int chunk, int reads_at_start, int threads) {
     graphvite::gvref_kernel_chunk = chunk;
     graphvite::gvref_kernel_reads = reads_at_start;
     graphvite::gvref_kernel_threads = threads;
+}
+
+int gvref_solver_dim() { return GVREF_DIM; }
+
+// The optimizer the next gvref_solver_create builds with (core/optimizer.h:272-330; kAuto = the solver's default, SGD 0.025 / 5e-3
+// linear, graph.cuh:634-636).  type: "" / "Default", "SGD", "Momentum", "AdaGrad", "RMSprop", "Adam"; the helper classes' own
+// defaults for everything but lr and weight decay.
+static std::string g_optimizer_type;
+static float g_optimizer_lr = 0, g_optimizer_wd = 0;
+void gvref_set_optimizer(const char *type, float lr, float weight_decay) {
+    g_optimizer_type = type ? type : "";
+    g_optimizer_lr = lr, g_optimizer_wd = weight_decay;
+}
+static graphvite::Optimizer chosen_optimizer() {
+    using namespace graphvite;
+    if (g_optimizer_type == "SGD") return SGD(g_optimizer_lr, g_optimizer_wd);
+    if (g_optimizer_type == "Momentum") return Momentum(g_optimizer_lr, g_optimizer_wd);
+    if (g_optimizer_type == "AdaGrad") return AdaGrad(g_optimizer_lr, g_optimizer_wd);
+    if (g_optimizer_type == "RMSprop") return RMSprop(g_optimizer_lr, g_optimizer_wd);
+    if (g_optimizer_type == "Adam") return Adam(g_optimizer_lr, g_optimizer_wd);
+    return Optimizer(kAuto);
 }
 
 void *gvref_solver_create(const uint32_t *edges, const float *weights, uint64_t n, int as_undirected, int num_worker,
@@ -228,7 +298,7 @@ void *gvref_solver_create(const uint32_t *edges, const float *weights, uint64_t 
     for (int i = 0; i < num_worker; i++) devices.push_back(i);
     gvref_generator_count = 0;  // generator index == sampler index (SolverMixin constructor, solver.h:212-214)
     h->solver = new SolverT(devices, num_sampler_per_worker);
-    h->solver->build(h->graph, graphvite::kAuto, num_partition, num_negative, batch_size, episode_size);
+    h->solver->build(h->graph, chosen_optimizer(), num_partition, num_negative, batch_size, episode_size);
     return h;
 }
 
@@ -318,7 +388,7 @@ int gvref_solver_sample(void *handle, const char *model, int augmentation_step, 
 
 // GraphSolver::train (graph.cuh:770-793 -> solver.h:588-654) as written: sampler threads and worker threads, episode
 // after episode; only the kernel launch and the negative draw inside a worker are the host loops above.  Afterwards
-// vertex / context receive the embeddings (num_vertex x 128 each, global ids).
+// vertex / context receive the embeddings (num_vertex x GVREF_DIM each, global ids).
 int gvref_solver_train(void *handle, const char *model, int num_epoch, int augmentation_step, int walk_length,
                        int walk_batch, int shuffle_base, float p, float q, float negative_sample_exponent,
                        float negative_weight, float *vertex, float *context) {
@@ -326,8 +396,8 @@ int gvref_solver_train(void *handle, const char *model, int num_epoch, int augme
     s.train(model, num_epoch, false, augmentation_step, walk_length, walk_batch, shuffle_base, p, q, 1,
             negative_sample_exponent, negative_weight, 1 << 30);
     for (uint32_t v = 0; v < s.num_vertex; v++) {
-        memcpy(vertex + (size_t)v * 128, &(*s.vertex_embeddings)[v], 128 * sizeof(float));
-        memcpy(context + (size_t)v * 128, &(*s.context_embeddings)[v], 128 * sizeof(float));
+        memcpy(vertex + (size_t)v * GVREF_DIM, &(*s.vertex_embeddings)[v], GVREF_DIM * sizeof(float));
+        memcpy(context + (size_t)v * GVREF_DIM, &(*s.context_embeddings)[v], GVREF_DIM * sizeof(float));
     }
     return (int)s.batch_id;
 }

@@ -394,17 +394,23 @@ class ReferenceSolver(object):
     samplers consume — so that the edge sampler can be compared draw for draw.  One instance = one built solver."""
 
     PATH = os.path.join(ORACLE_DIR, "_ref", "libgvref_solver.so")
-    _lib = None
+    PATHS = {128: PATH, 96: os.path.join(ORACLE_DIR, "_ref", "libgvref_solver_96.so")}  # one build per dim (oracle/Makefile)
+    _libs = {}
     _callback = None
 
     @classmethod
-    def available(cls):
-        return os.path.exists(cls.PATH)
+    def available(cls, dim=128):
+        return os.path.exists(cls.PATHS[dim])
 
     @classmethod
-    def lib(cls):
-        if cls._lib is None:
-            cls._lib = lib = C.CDLL(cls.PATH)
+    def lib(cls, dim=128):
+        if dim not in cls._libs:
+            cls._libs[dim] = lib = C.CDLL(cls.PATHS[dim])
+            assert lib.gvref_solver_dim() == dim
+            lib.gvref_set_optimizer.argtypes = [C.c_char_p, C.c_float, C.c_float]
+            lib.gvref_set_kernel_model.argtypes = [C.c_int, C.c_int, C.c_int]
+            lib.gvref_solver_train.restype = C.c_int
+            lib.gvref_solver_train.argtypes = [C.c_void_p, C.c_char_p] + [C.c_int] * 5 + [C.c_float] * 4 + [C.c_void_p] * 2
             lib.gvref_solver_create.restype = C.c_void_p
             lib.gvref_solver_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64] + [C.c_int] * 7
             lib.gvref_solver_destroy.argtypes = [C.c_void_p]
@@ -421,11 +427,15 @@ class ReferenceSolver(object):
                                                         C.c_void_p, C.c_uint64]
             lib.gvref_solver_table.restype = C.c_uint64
             lib.gvref_solver_table.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
-        return cls._lib
+        return cls._libs[dim]
 
     def __init__(self, oracle, seed, edges, weights=None, as_undirected=True, num_worker=1, num_sampler_per_worker=1,
-                 num_partition=0, num_negative=1, batch_size=100000, episode_size=0):
-        lib = self.lib()
+                 num_partition=0, num_negative=1, batch_size=100000, episode_size=0, dim=128, optimizer=None):
+        """optimizer: None = the solver's default (SGD 0.025 / 5e-3 linear, graph.cuh:634-636) or (type, lr, weight_decay) with
+        type one of core/optimizer.h's helper classes ("SGD", "Momentum", "AdaGrad", "RMSprop", "Adam")."""
+        self.dim = dim
+        lib = self.lib(dim)
+        lib.gvref_set_optimizer(*((b"", 0.0, 0.0) if optimizer is None else (optimizer[0].encode(), optimizer[1], optimizer[2])))
         source_type = C.CFUNCTYPE(None, C.c_int, C.c_ulonglong, C.POINTER(C.c_double), C.c_size_t)
 
         def source(generator, position, out, n):  # generator index == sampler index == uniform stream
@@ -448,46 +458,46 @@ class ReferenceSolver(object):
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None
         if h:
-            self.lib().gvref_solver_destroy(h)
+            self.lib(self.dim).gvref_solver_destroy(h)
 
     def partition(self):
         """(labels, part, local, vertex_weights) per vertex id."""
         N = self.num_vertex
         labels, part = np.zeros(N, np.uint32), np.zeros(N, np.int32)
         local, weights = np.zeros(N, np.uint32), np.zeros(N, np.float32)
-        self.lib().gvref_solver_partition(self.handle, labels.ctypes.data, part.ctypes.data, local.ctypes.data,
+        self.lib(self.dim).gvref_solver_partition(self.handle, labels.ctypes.data, part.ctypes.data, local.ctypes.data,
                                           weights.ctypes.data)
         return labels, part, local, weights
 
     def edges(self):
         uv, w = np.zeros((self.num_directed_edge, 2), np.uint32), np.zeros(self.num_directed_edge, np.float32)
-        self.lib().gvref_solver_edges(self.handle, uv.ctypes.data, w.ctypes.data)
+        self.lib(self.dim).gvref_solver_edges(self.handle, uv.ctypes.data, w.ctypes.data)
         return uv, w
 
     def schedule(self):
         out = np.zeros(4096 * self.num_worker * 2, np.int32)
-        steps = self.lib().gvref_solver_schedule(self.handle, out.ctypes.data, 4096)
+        steps = self.lib(self.dim).gvref_solver_schedule(self.handle, out.ctypes.data, 4096)
         return out[:steps * self.num_worker * 2].reshape(steps, self.num_worker, 2)
 
     def sample(self, model="LINE", augmentation_step=1, walk_length=40, walk_batch=100, shuffle_base=1, p=1.0, q=1.0):
         """Pools [P][P][episode_size * batch_size][2] = {tail, head} of the first episode's fill."""
         P, n = self.num_partition, self.episode_size * self.batch_size
         pools = np.zeros((P, P, n, 2), np.uint32)
-        self.lib().gvref_solver_sample(self.handle, model.encode(), augmentation_step, walk_length, walk_batch,
+        self.lib(self.dim).gvref_solver_sample(self.handle, model.encode(), augmentation_step, walk_length, walk_batch,
                                        shuffle_base, p, q, pools.ctypes.data)
         return pools
 
     def negative_table(self, head_partition, tail_partition, exponent=0.75, worker=0):
         """WorkerMixin::build_negative_sampler for the block: (prob, alias) over the tail partition's vertices."""
         prob, alias = np.zeros(self.partition_size, np.float32), np.zeros(self.partition_size, np.uint32)
-        n = self.lib().gvref_solver_negative_table(self.handle, worker, head_partition, tail_partition, exponent,
+        n = self.lib(self.dim).gvref_solver_negative_table(self.handle, worker, head_partition, tail_partition, exponent,
                                                    prob.ctypes.data, alias.ctypes.data, self.partition_size)
         return prob[:n], alias[:n]
 
     def table(self, which, index=0, capacity=1 << 16):
         """which: 0 the global edge table, 1 vertex_edge_tables[index], 2 edge_edge_tables[index] (after sample())."""
         prob, alias = np.zeros(capacity, np.float32), np.zeros(capacity, np.uint64)
-        n = self.lib().gvref_solver_table(self.handle, which, index, prob.ctypes.data, alias.ctypes.data, capacity)
+        n = self.lib(self.dim).gvref_solver_table(self.handle, which, index, prob.ctypes.data, alias.ctypes.data, capacity)
         return prob[:n], alias[:n]
 
 
@@ -521,13 +531,10 @@ def reference_train(rs, model="LINE", num_epoch=50, augmentation_step=1, walk_le
     (5120 on a V100) — lock step inside a chunk (reads_at_start: every row of the chunk read before any is written),
     last writer wins.  Returns (vertex_embeddings, context_embeddings,
     batch_id)."""
-    lib = ReferenceSolver.lib()
-    lib.gvref_set_kernel_model.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib = ReferenceSolver.lib(rs.dim)
     lib.gvref_set_kernel_model(int(kernel_chunk), int(bool(reads_at_start)), int(threads))
-    lib.gvref_solver_train.restype = C.c_int
-    lib.gvref_solver_train.argtypes = [C.c_void_p, C.c_char_p] + [C.c_int] * 5 + [C.c_float] * 4 + [C.c_void_p] * 2
-    vertex = np.zeros((rs.num_vertex, 128), np.float32)
-    context = np.zeros((rs.num_vertex, 128), np.float32)
+    vertex = np.zeros((rs.num_vertex, rs.dim), np.float32)
+    context = np.zeros((rs.num_vertex, rs.dim), np.float32)
     batch_id = lib.gvref_solver_train(rs.handle, model.encode(), num_epoch, augmentation_step, walk_length, walk_batch,
                                       shuffle_base, p, q, negative_sample_exponent, negative_weight,
                                       vertex.ctypes.data, context.ctypes.data)
