@@ -45,7 +45,6 @@ int g_variant = 0;         // GVK_TUNE_VARIANT
 int g_run_cap = 0;         // GVK_TUNE_RUN_CAP (0 = the default of 20, run_cap_for)
 int g_split_hits = 2;      // GVK_TUNE_SPLIT_HITS (samples per table row one launch may hold; 0 = never split a batch)
 int g_hot_order = 1;       // GVK_TUNE_HOT_ORDER (measurement: which blocks of a train_hot_kernel launch come first; 1 = long chains, pairs, the other chains)
-int g_hot_gram = 0;        // GVK_TUNE_HOT_GRAM (experiment: long chains as tasks of 16 entries by Gram matrices on the matrix cores, long_chain_gram)
 int g_hot_serialized = 0;  // GVK_TUNE_HOT_SERIALIZED (measurement: gvk_train_episode_hot launches the chains and the pairs of a unit one after the other)
 int g_chain_cap = 0;       // GVK_TUNE_CHAIN_CAP (entries one chain task trains in sequence; 0 = the default of 7)
 #if defined(GVK_AB_BUILDS)  // knobs of the A/B library only (make ab -> build/ab/libgvk_ab.so)
@@ -903,286 +902,6 @@ __device__ __forceinline__ void copy_idle_rows(const HotArgs &h, const uint32_t 
     }
 }
 
-// ---- long chains by Gram matrices (GVK_TUNE_HOT_GRAM; off by default, first measured in round 5) -------------------------------
-// What a long chain waits for today is its steps: 17 dependent rounds of dot -> butterfly -> sigmoid -> update, 0.5 us each for the
-// unit's largest hub.  Within a task the rows a step needs are known up front, and the only thing a step
-// needs from the steps before it is the logit  v . c_j  of the row as they left it.  With  v <- a_i v - b_i c_i  (a_i = 1 - lr w_i
-// wd, b_i = lr w_i g_i) that logit obeys   t_j <- a_i t_j - b_i (c_i . c_j)   — a scalar recurrence over the task's Gram matrix
-// C C^T and the start logits C v0.  So a task of 16 entries is: its 16 rows once (one round trip), the Gram matrix by 32
-// v_mfma_f32_16x16x4_f32 (exact fp32; A and B are the SAME register: lane l holds C[l & 15][k = l >> 4]), 16 steps of a dozen
-// dependent instructions with no memory and no cross-lane sum in them, and the row's change as ONE weighted sum of the task's
-// rows:   end = (prod a) start - sum_j kappa_j c_j,  kappa_j = b_j prod_{i > j} a_i.
-// A wavefront runs four tasks side by side, one per 16-lane row of the wavefront (the recurrences of the four share every
-// instruction); the four wavefronts of the block take tiles t = wave + 4 quarter + 16 round.  Tasks compose as in
-// train_long_chains — every task starts from the row as the decay of the entries before it leaves it — which leaves
-//     row <- total row - sum over tasks after_t sum_j kappa_tj c_tj,
-// summed per wavefront in registers, across the 16 lanes of a row by DPP, across wavefronts through LDS in wavefront order: the
-// same bits on every run.  In exact arithmetic this is train_long_chains with tasks of 16 entries and as many tasks as it takes
-// (oracle: gvo_hot_unit_chains with cap 16, max_tasks 64); a chain of more than 16 x kGramTiles entries is trained as segments
-// of that many, one after the other.
-constexpr int kGramTiles = 64;
-
-template <int J>
-__device__ __forceinline__ float row_bcast(float x) {  // lane J of every 16-lane row to the whole row (DPP row_newbcast)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x150 + J, 0xf, 0xf, false));
-}
-
-template <int DIM>
-__device__ __forceinline__ void long_chain_gram(const TrainArgs &a, const HotArgs &h, const uint32_t chain, const uint32_t first,
-                                                const uint32_t n, const float *row0, const bool stamp) {
-    (void)stamp;  // measurement build only: the workgroup's first chain leaves its stamps
-    constexpr int NCH = DIM / 16;  // float4 chunks of a row per lane: lane (r, q) of a wavefront holds chunks q, q + 4, ... of row r
-    static_assert(DIM % 16 == 0 && kBlock == 256, "four wavefronts, rows in sixteenths");
-    __shared__ __attribute__((aligned(16))) float gram[4][2][4][256];  // [wavefront][sub-round][quarter][16 x 16], row-major (symmetric)
-    __shared__ __attribute__((aligned(16))) float part[4][DIM];     // a wavefront's weighted sum of its tasks' rows
-    __shared__ __attribute__((aligned(16))) float own_row[DIM];     // the chain's row as the unit found it
-    __shared__ float positives[kGramTiles];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // in a scalar register
-    int l = threadIdx.x & 63, r = l & 15, q = l >> 4;
-    // what depends on the lane only (addresses in LDS, shuffle indices, masks) is derived again at the start of every phase instead of
-    // living in registers across the whole function: the compiler cannot see through the empty asm
-#define GVK_GRAM_FRESH() do { asm volatile("" : "+v"(l)); r = l & 15; q = l >> 4; } while (0)
-    const uint32_t last = first + n, tiles = (n + 15) / 16, rounds = (tiles + 15) / 16;
-    const bool is_vertex = chain < a.hot_vertex;
-    const float *partner_table = is_vertex ? a.context : a.vertex;
-    const uint32_t partner_hot = is_vertex ? a.hot_context : a.hot_vertex;
-    const float *partner_mirror = h.from + (is_vertex ? (size_t)a.hot_vertex * DIM : (size_t)0);
-    // the rows of tile t as this lane sees them: entry r of the tile (held by lane r of the tile's quarter), chunks q, q + 4, ...
-    auto load_tile = [&](const uint32_t t, const uint32_t e_own, const int qq, f32x4 (&c)[NCH]) __attribute__((always_inline)) {
-        const uint32_t e = (uint32_t)__shfl((int)e_own, r + 16 * qq, 64), id = e & 0x7fffffffu;
-        const float *row = id < partner_hot ? partner_mirror + (size_t)id * DIM : partner_table + (size_t)id * DIM;
-        // an entry past the chain's end: the own row (its weight is 0)
-        const f32x4 *from = reinterpret_cast<const f32x4 *>(first + 16 * t + r < last ? row : row0) + q;
-#pragma unroll
-        for (int m = 0; m < NCH; m++) c[m] = from[4 * m];
-    };
-    // tile t = wave + 4 quarter + 16 round.  The own row into LDS; the positives of every tile; this lane's entry of round 0
-    if (threadIdx.x < DIM / 4) reinterpret_cast<f32x4 *>(own_row)[threadIdx.x] = reinterpret_cast<const f32x4 *>(row0)[threadIdx.x];
-    // A PASS takes up to 32 tiles: two per quarter of a wavefront (sub-rounds s = 0, 1: tile t = wave + 4 quarter + 16 (2 pass + s)),
-    // whose recurrences run in the same sixteen steps — two independent dependency chains per lane.  A chain of up to 256 entries
-    // has one sub-round; the top hub's 250 +- 16 entries, or its 290 at the shard size of an 8-GPU run, spill a few tiles into the
-    // second, which then costs them their rows and matrices and little else.
-    uint32_t e_first[2] = {0, 0};
-    for (uint32_t p = 0; p < rounds; p++) {
-        const uint32_t t = (uint32_t)(wave + 4 * q) + 16 * p, at = first + 16 * t + r;
-        const uint32_t e = at < last ? h.entries[at] : 0;
-        if (p == 0) e_first[0] = e;
-        if (p == 1) e_first[1] = e;
-        const unsigned long long mask = __builtin_amdgcn_ballot_w64((e >> 31) != 0);
-        if (r == 0) positives[t] = (float)__popcll((mask >> (16 * q)) & 0xffffull);
-    }
-    __syncthreads();
-    if (stamp) GVK_STAMP(h, 3);  // own row and the entries are here
-    float all = 0;
-    for (uint32_t t = 0; t < tiles; t++) all += positives[t];
-    const float total = exp2f(all * h.log2_decay_positive + ((float)n - all) * h.log2_decay_negative);
-    const uint32_t passes = (rounds + 1) / 2;
-    for (uint32_t pass = 0; pass < passes; pass++) {  // the same for the whole block
-        const bool second = 16 * (2 * pass + 1) < tiles;  // the pass has tiles in its second sub-round (the same for the whole block)
-        uint32_t t_wave[2], t_own[2], at[2], e_own[2];
-        bool exists[2];
-#pragma unroll
-        for (int s = 0; s < 2; s++) {
-            t_wave[s] = (uint32_t)wave + 16 * (2 * pass + s);  // this wavefront's tiles of the sub-round: t_wave + 4 qq
-            t_own[s] = t_wave[s] + 4 * (uint32_t)q;            // this lane's own tile
-            exists[s] = t_own[s] < tiles;
-            at[s] = first + 16 * t_own[s] + r;
-            // (a second pass — a chain of more than 512 entries, rare — reads its entries when it starts)
-            e_own[s] = pass == 0 ? e_first[s] : (at[s] < last ? h.entries[at[s]] : 0);
-        }
-        GVK_GRAM_FRESH();
-        // 1. per tile of this wavefront: rows, Gram matrix, start logits; the next tile's rows are asked for before this one's matrix
-        float logit[2] = {0, 0};
-        {
-            // every lane touches the 128-byte lines of its own entries' rows first: the rows of all the wavefront's tiles are on their
-            // way (one register per line) while the first two tiles are asked for in full
-            float warm[2][DIM / 32];
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                const uint32_t id = e_own[s] & 0x7fffffffu;
-                const float *row = id < partner_hot ? partner_mirror + (size_t)id * DIM : partner_table + (size_t)id * DIM;
-                const float *touch = at[s] < last ? row : row0;
-#pragma unroll
-                for (int i = 0; i < DIM / 32; i++) warm[s][i] = (s == 0 || second) ? touch[32 * i] : 0.0f;
-            }
-            f32x4 ca[NCH], cb[NCH];
-            auto matrix = [&](const int s, const int qq, const f32x4 (&c)[NCH]) __attribute__((always_inline)) {
-                f32x4 g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0};
-                float dot = 0;
-#pragma unroll
-                for (int m = 0; m < NCH; m++) {
-                    const f32x4 v = reinterpret_cast<const f32x4 *>(own_row)[4 * m + q];
-                    g0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c[m].x, c[m].x, g0, 0, 0, 0);
-                    g1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c[m].y, c[m].y, g1, 0, 0, 0);
-                    g0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c[m].z, c[m].z, g0, 0, 0, 0);
-                    g1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c[m].w, c[m].w, g1, 0, 0, 0);
-                    dot += c[m].x * v.x + c[m].y * v.y + c[m].z * v.z + c[m].w * v.w;
-                }
-                // lane (column r, quarter q) holds G[4 q + v][r] in component v
-                float *tile = &gram[wave][s][qq][0];
-                tile[(4 * q + 0) * 16 + r] = g0.x + g1.x;
-                tile[(4 * q + 1) * 16 + r] = g0.y + g1.y;
-                tile[(4 * q + 2) * 16 + r] = g0.z + g1.z;
-                tile[(4 * q + 3) * 16 + r] = g0.w + g1.w;
-                dot += __shfl_xor(dot, 16, 64);
-                dot += __shfl_xor(dot, 32, 64);
-                if (q == qq) logit[s] = dot;  // own row . c_r of this lane's own tile
-            };
-            // no branches inside a sub-round: a tile past the chain's end is sixteen copies of the own row with weight 0 (the longest
-            // chain, whose wavefronts all have four tiles, is what the launch waits for)
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                if (t_wave[s] < tiles) {  // the same for the whole wavefront
-                    load_tile(t_wave[s], e_own[s], 0, ca);
-                    load_tile(t_wave[s] + 4, e_own[s], 1, cb);
-                    matrix(s, 0, ca);
-                    load_tile(t_wave[s] + 8, e_own[s], 2, ca);
-                    matrix(s, 1, cb);
-                    load_tile(t_wave[s] + 12, e_own[s], 3, cb);
-                    matrix(s, 2, ca);
-                    matrix(s, 3, cb);
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 2; s++)
-#pragma unroll
-                for (int i = 0; i < DIM / 32; i++) asm volatile("" : : "v"(warm[s][i]));  // the touches are loads the compiler must keep
-        }
-        // the decay of the entries before / after this lane's own tiles
-        float before_[2], after_[2];
-        {
-            float pb[2] = {0, 0};
-            for (uint32_t t = 0; t < tiles; t++) {
-                const float x = positives[t];
-                pb[0] += t < t_own[0] ? x : 0.0f;
-                pb[1] += t < t_own[1] ? x : 0.0f;
-            }
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                const float pi = exists[s] ? positives[exists[s] ? t_own[s] : 0] : 0.0f;
-                const float nb = (float)(16 * t_own[s]), ni = exists[s] ? (float)(n - 16 * t_own[s] < 16 ? n - 16 * t_own[s] : 16) : 0.0f;
-                const float pa = all - pb[s] - pi, na = (float)n - nb - ni;
-                before_[s] = exists[s] ? exp2f(pb[s] * h.log2_decay_positive + (nb - pb[s]) * h.log2_decay_negative) : 0.0f;
-                after_[s] = exists[s] ? exp2f(pa * h.log2_decay_positive + (na - pa) * h.log2_decay_negative) : 0.0f;
-            }
-        }
-        __syncthreads();
-        if (stamp && pass == 0) GVK_STAMP(h, 4);  // the pass's rows and Gram matrices are here
-        GVK_GRAM_FRESH();
-        // 2. the recurrences of this lane's own tiles (quarter q): lane r holds logit_r, kappa_r and row r of each Gram matrix
-        float kappa[2] = {0, 0};
-        {
-            float gr[2][16];
-#pragma unroll
-            for (int s = 0; s < 2; s++)
-#pragma unroll
-                for (int x = 0; x < 4; x++) {
-                    const bool there = exists[s] && (s == 0 || second);
-                    const f32x4 g = there ? reinterpret_cast<const f32x4 *>(&gram[wave][s][q][r * 16])[x] : f32x4{0, 0, 0, 0};
-                    gr[s][4 * x + 0] = g.x; gr[s][4 * x + 1] = g.y; gr[s][4 * x + 2] = g.z; gr[s][4 * x + 3] = g.w;
-                }
-            // weight and label of this lane's entries in one word for the row broadcasts: + 1 positive, - negative_weight negative, 0 past the end
-            float signed_weight[2];
-            bool valid[2];
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                valid[s] = at[s] < last;
-                signed_weight[s] = valid[s] ? ((e_own[s] >> 31) != 0 ? 1.0f : -a.neg_weight) : 0.0f;
-                logit[s] = exists[s] ? logit[s] * before_[s] : 0.0f;
-            }
-            auto step = [&](const int s, const float sl, const float sw, const float g_jr, const bool own) __attribute__((always_inline)) {
-                const float w = fabsf(sw), aj = 1.0f - h.lr * w * a.wd;
-                // lr w (prob - label): model/graph.h:47-58; the sigmoid by v_exp_f32 and v_rcp_f32 (a few ulp from sigmoidf's; this
-                // path reorders the sums of a task anyway)
-                const float ex = __expf(-fabsf(sl));
-                const float b = h.lr * w * ((sl > 0 ? 1.0f : ex) * __builtin_amdgcn_rcpf(1.0f + ex) - (sw > 0 ? 1.0f : 0.0f));
-                logit[s] = aj * logit[s] - b * g_jr;
-                kappa[s] = own ? b : kappa[s] * aj;
-            };
-#define GVK_GRAM_STEP(S, J) step(S, row_bcast<J>(logit[S]), row_bcast<J>(signed_weight[S]), gr[S][J], r == J);
-#define GVK_GRAM_STEPS(S) \
-    GVK_GRAM_STEP(S, 0) GVK_GRAM_STEP(S, 1) GVK_GRAM_STEP(S, 2) GVK_GRAM_STEP(S, 3) GVK_GRAM_STEP(S, 4) GVK_GRAM_STEP(S, 5) \
-    GVK_GRAM_STEP(S, 6) GVK_GRAM_STEP(S, 7) GVK_GRAM_STEP(S, 8) GVK_GRAM_STEP(S, 9) GVK_GRAM_STEP(S, 10) GVK_GRAM_STEP(S, 11) \
-    GVK_GRAM_STEP(S, 12) GVK_GRAM_STEP(S, 13) GVK_GRAM_STEP(S, 14) GVK_GRAM_STEP(S, 15)
-#define GVK_GRAM_BOTH(J) GVK_GRAM_STEP(0, J) GVK_GRAM_STEP(1, J)
-            if (second) {  // two chains per lane, step by step side by side
-                GVK_GRAM_BOTH(0) GVK_GRAM_BOTH(1) GVK_GRAM_BOTH(2) GVK_GRAM_BOTH(3) GVK_GRAM_BOTH(4) GVK_GRAM_BOTH(5) GVK_GRAM_BOTH(6) GVK_GRAM_BOTH(7)
-                GVK_GRAM_BOTH(8) GVK_GRAM_BOTH(9) GVK_GRAM_BOTH(10) GVK_GRAM_BOTH(11) GVK_GRAM_BOTH(12) GVK_GRAM_BOTH(13) GVK_GRAM_BOTH(14) GVK_GRAM_BOTH(15)
-            } else {
-                GVK_GRAM_STEPS(0)
-            }
-#undef GVK_GRAM_BOTH
-#undef GVK_GRAM_STEPS
-#undef GVK_GRAM_STEP
-#pragma unroll
-            for (int s = 0; s < 2; s++) kappa[s] = exists[s] && valid[s] && (s == 0 || second) ? kappa[s] * after_[s] : 0.0f;
-        }
-        asm volatile("" : "+v"(kappa[0]), "+v"(kappa[1]) : : "memory");  // the rows of step 3 are asked for after the recurrence, not during it (registers)
-        if (stamp && pass == 0) GVK_STAMP(h, 5);  // the recurrences are done
-        GVK_GRAM_FRESH();
-        // 3. the rows again (they are in the L2), weighted; the sixteen rows of every quarter meet by DPP, the passes in LDS
-        {
-            f32x4 ca[NCH], cb[NCH], acc[NCH];
-#pragma unroll
-            for (int m = 0; m < NCH; m++) acc[m] = f32x4{0, 0, 0, 0};
-            auto weigh = [&](const int s, const int qq, const f32x4 (&c)[NCH]) __attribute__((always_inline)) {
-                const float cf = __shfl(kappa[s], r + 16 * qq, 64);
-#pragma unroll
-                for (int m = 0; m < NCH; m++) {
-                    acc[m].x += cf * c[m].x; acc[m].y += cf * c[m].y; acc[m].z += cf * c[m].z; acc[m].w += cf * c[m].w;
-                }
-            };
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                if (t_wave[s] < tiles) {
-                    load_tile(t_wave[s], e_own[s], 0, ca);
-                    load_tile(t_wave[s] + 4, e_own[s], 1, cb);
-                    weigh(s, 0, ca);
-                    load_tile(t_wave[s] + 8, e_own[s], 2, ca);
-                    weigh(s, 1, cb);
-                    load_tile(t_wave[s] + 12, e_own[s], 3, cb);
-                    weigh(s, 2, ca);
-                    weigh(s, 3, cb);
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < NCH; m++) {
-                acc[m].x = group_sum<16>(acc[m].x); acc[m].y = group_sum<16>(acc[m].y);
-                acc[m].z = group_sum<16>(acc[m].z); acc[m].w = group_sum<16>(acc[m].w);
-                if (r == 0) {  // one lane per (wavefront, chunk) adds the passes in order
-                    f32x4 *sum = reinterpret_cast<f32x4 *>(&part[wave][0]) + 4 * m + q;
-                    if (pass == 0) *sum = acc[m];
-                    else *sum = *sum + acc[m];
-                }
-            }
-        }
-        __syncthreads();  // the next pass writes the Gram tiles again; after the last one the wavefronts' sums are in LDS
-    }
-    if (threadIdx.x < DIM / 4) {
-        const f32x4 v = reinterpret_cast<const f32x4 *>(own_row)[threadIdx.x];
-        f32x4 out = {total * v.x, total * v.y, total * v.z, total * v.w};
-#pragma unroll
-        for (int wv = 0; wv < 4; wv++) {
-            const f32x4 s = reinterpret_cast<const f32x4 *>(&part[wv][0])[threadIdx.x];
-            out.x -= s.x; out.y -= s.y; out.z -= s.z; out.w -= s.w;
-        }
-        reinterpret_cast<f32x4 *>(h.to + (size_t)chain * DIM)[threadIdx.x] = out;
-    }
-    __syncthreads();
-}
-
-#undef GVK_GRAM_FRESH
-
-#if defined(GVK_GRAM_PROBE)  // compile-time probe only (register need of long_chain_gram on its own)
-template <int DIM>
-__global__ void __launch_bounds__(kBlock, 4) gram_probe_kernel(const TrainArgs a, const HotArgs h) {
-    const u32x4 record = *reinterpret_cast<const u32x4 *>(h.long_list + 4 + 4 * (size_t)blockIdx.x);
-    long_chain_gram<DIM>(a, h, record.x, record.y, record.z, h.from + (size_t)record.x * DIM, false);
-}
-template __global__ void gram_probe_kernel<32>(const TrainArgs, const HotArgs);
-template __global__ void gram_probe_kernel<128>(const TrainArgs, const HotArgs);
-#endif
-
 // Long chains, one workgroup each (block b takes long chains b, b + long_blocks, ...): T <= NG tasks of consecutive
 // entries (whole samples for a head chain) trained side by side by the block's lane groups and composed.  An update is
 // own <- d own - lr w g c with d = 1 - lr w wd: weight decay is a factor that depends on the entry's label only, so the
@@ -1193,7 +912,7 @@ template __global__ void gram_probe_kernel<128>(const TrainArgs, const HotArgs);
 // which composes the tasks' decay exactly (a hub row of the benchmark graph decays to 0.48 of itself within ONE batch —
 // summing plain deltas of 8 tasks would take it to 0.30) and leaves only the gradients' dependence on the other tasks'
 // steps to first order.  The sum runs in task order in one lane group: the same bits on every run.
-template <int DIM, int G, int GRAM = 0>
+template <int DIM, int G>
 __device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotArgs &h, const uint32_t block) {
     typedef ChainShape<DIM, G> S;
     constexpr int V = S::V, NG = S::NG;
@@ -1211,14 +930,6 @@ __device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotA
             GVK_STAMP(h, 2);  // the record is here
             GVK_STAMP_VALUE(h, 7, n);
         }
-        if constexpr (GRAM != 0 && DIM <= 128) {  // experiment (GVK_TUNE_HOT_GRAM): tasks of 16 entries by Gram matrices
-            // a chain of more than 16 kGramTiles entries: segments of that many, one after the other (the row of a later segment
-            // is the one this workgroup has just stored: __syncthreads orders a workgroup's own stores and loads)
-            for (uint32_t done = 0; done < n; done += 16u * kGramTiles)
-                long_chain_gram<DIM>(a, h, chain, first + done, n - done < 16u * kGramTiles ? n - done : 16u * kGramTiles,
-                                     (done == 0 ? h.from : h.to) + (size_t)chain * DIM, j == block && done == 0);
-            if (j == block) GVK_STAMP(h, 6);  // composed and stored
-        } else {
         // NG tasks at most: a longer chain gets longer tasks
         uint32_t per = h.cap;
         if ((uint64_t)per * NG < n) per = (n + NG - 1) / NG;
@@ -1274,7 +985,6 @@ __device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotA
         }
         __syncthreads();
         if (j == block) GVK_STAMP(h, 6);  // composed and stored
-        }  // the steps (GRAM == 0)
     }
 }
 
@@ -1283,8 +993,8 @@ __device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotA
 // Built for four wavefronts per SIMD (128 registers; the short chains keep seven partner rows per lane group in flight; three
 // at dims 256 and 512, sixteen floats of a row per lane): the chains and the pairs of a unit of the sizes this kernel trains (a
 // part of a batch) are then resident side by side.
-template <int DIM, int G, int KT, int HOT, int GRAM = 0>
-__global__ void __launch_bounds__(kBlock, DIM / G > 12 || GRAM == 1 ? 3 : 4) train_hot_kernel(const TrainArgs a, const HotArgs h) {
+template <int DIM, int G, int KT, int HOT>
+__global__ void __launch_bounds__(kBlock, DIM / G > 12 ? 3 : 4) train_hot_kernel(const TrainArgs a, const HotArgs h) {
     // the grid: [long chains | pairs | short chains | idle rows] — the long chains, whose tasks wait for memory three times in
     // a row, are dispatched first, the bulk (the pairs) next; the short chains and the copies fill in behind
     const int b = blockIdx.x;
@@ -1294,7 +1004,7 @@ __global__ void __launch_bounds__(kBlock, DIM / G > 12 || GRAM == 1 ? 3 : 4) tra
     const int long_first = h.order == 2 ? h.pair_blocks : 0;
     const int short_first = h.order == 0 ? h.long_blocks : h.long_blocks + h.pair_blocks;
     if (b >= long_first && b < long_first + h.long_blocks) {
-        train_long_chains<DIM, G, GRAM>(a, h, b - long_first);
+        train_long_chains<DIM, G>(a, h, b - long_first);
     } else if (b >= pairs_first && b < pairs_first + h.pair_blocks) {
         GVK_STAMP_VALUE(h, 0, 3);
         train_pair<DIM, G, GVK_SGD, KT, 1, HOT>(a, (b - pairs_first) * kBlock + threadIdx.x);
@@ -2219,23 +1929,10 @@ HotKernel pick_hot(int dim, int k, int lerp) {
     case D:                                                                                                         \
         return k == 1 ? (lerp ? train_hot_kernel<D, GG, 1, 2> : train_hot_kernel<D, GG, 1, 1>)                      \
                       : (lerp ? train_hot_kernel<D, GG, 0, 2> : train_hot_kernel<D, GG, 0, 1>);
-#define GVK_HOT_GRAM(D, GG, W)                                                                                      \
-    case D:                                                                                                         \
-        return k == 1 ? (lerp ? train_hot_kernel<D, GG, 1, 2, W> : train_hot_kernel<D, GG, 1, 1, W>)                \
-                      : (lerp ? train_hot_kernel<D, GG, 0, 2, W> : train_hot_kernel<D, GG, 0, 1, W>);
-    // experiment: long chains as tasks of 16 entries by Gram matrices (long_chain_gram); 1: the kernel built for three wavefronts
-    // per SIMD (168 registers), 2: for four as the default kernel (128 registers, more of long_chain_gram's invariants in scratch)
-    if (g_hot_gram == 1 && dim <= 128) {
-        switch (dim) { GVK_HOT_GRAM(32, 8, 1) GVK_HOT_GRAM(64, 16, 1) GVK_HOT_GRAM(96, 8, 1) GVK_HOT_GRAM(128, 16, 1) }
-    }
-    if (g_hot_gram == 2 && dim <= 128) {
-        switch (dim) { GVK_HOT_GRAM(32, 8, 2) GVK_HOT_GRAM(64, 16, 2) GVK_HOT_GRAM(96, 8, 2) GVK_HOT_GRAM(128, 16, 2) }
-    }
     switch (dim) {
         GVK_HOT(32, 8) GVK_HOT(64, 16) GVK_HOT(96, 8) GVK_HOT(128, 16) GVK_HOT(256, 16) GVK_HOT(512, 32)
     }
 #undef GVK_HOT
-#undef GVK_HOT_GRAM
     return nullptr;
 }
 
@@ -2676,11 +2373,6 @@ int gvk_set_tuning(int key, int value) {
     if (key == GVK_TUNE_HOT_ORDER) {
         if (value < 0 || value > 2) return fail(GVK_EINVAL, "gvk_set_tuning: block order must be 0 .. 2");
         g_hot_order = value;
-        return GVK_OK;
-    }
-    if (key == GVK_TUNE_HOT_GRAM) {
-        if (value < 0 || value > 2) return fail(GVK_EINVAL, "gvk_set_tuning: the Gram form is 0 (off), 1 or 2");
-        g_hot_gram = value;
         return GVK_OK;
     }
     if (key == GVK_TUNE_HOT_SERIALIZED) {

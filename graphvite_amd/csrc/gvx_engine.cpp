@@ -50,6 +50,7 @@ constexpr double kHubHitsPerPart = 0.125;  // GVX_HUB_ROWS -1: a row a PART of a
 constexpr uint64_t kMaxHubRows = 16384;  // per table (gvk_hot_build counts the chains of both tables in LDS)
 constexpr int kHubChunk = 128;          // batches whose work lists are built at once
 constexpr int kHubEntriesPerPart = 250;  // with hub rows by chains a batch is trained as so many parts that its largest hub row meets about this many of its updates per part
+constexpr int kHubMaxEntriesPerPart = 1000;  // ... and past this many per part chains are not used (configure): the entries of a part are worked side by side from its start state
 constexpr int kHubMaxParts = 32;  // measured on the headline shape at P = 8 (a block's top hub holds 16 % of its samples: the rule asks for 64): 25 / 32 / 40 / 50
                                   // parts end -0.0013 / +0.0008 / +0.0013 / +0.0022 from the reference's loop — past 32 the parts only cost launches
 constexpr int kHubMaxPartsResident = 50;  // cache-resident tables (< 16 MiB): a small partition's chains are feasible up to this many parts (§7.8)
@@ -175,6 +176,7 @@ struct gvx_solver {
     int fidelity = -1;              // GVX_FIDELITY: -1 = the default rule (hub rows by chains where chains exist), 0 = throughput (no chains), 1 = chains or an error
     int hub_parts_request = 0;      // GVX_HUB_PARTS: 0 the rule (gvk_train_launches when every row is a hub row, else 1), Q > 0 given
     int64_t hub_rows_request = -2;  // GVX_HUB_ROWS: -2 the default rule, -1 by expected hits per batch, 0 off, N > 0 the first N rows
+    bool hogwild_said = false, order_said = false;  // warnings of configure() that are given once per solver
     int hub_lerp_request = -1;      // GVX_HUB_LERP: -1 the rule, 0 / 1: the pairs read hub rows as their unit's chains left them / along the chains' way
     int hub_chunk = kHubChunk;      // batches whose work lists are built at once (fewer where memory is short)
     int hub_max_parts = kHubMaxParts;  // most parts a batch is trained as (kHubMaxPartsResident for cache-resident tables)
@@ -385,7 +387,9 @@ size_t gvx_solver::memory_demand(int P, int requested_episode, bool as_streamed)
     // hub rows by chains: the work lists of up to kHubChunk batches (8 bytes per list entry, 2 (k + 1) entries per sample at
     // most, as much again for the chains' records) — of fewer batches where that would be more than a sixteenth of the memory
     // (prepare_devices).  The mirrors of the hub rows (at most 3 x 2 x kMaxHubRows rows: 50 MB at dim 128) are not counted.
-    demand += std::min((size_t)kHubChunk * batch_size * (num_negative + 1) * 32, gpu_memory_limit / 16);
+    // — only where chains can exist: SGD, and not fidelity = "throughput"
+    if (optimizer.type == GVK_SGD && fidelity != 0)
+        demand += std::min((size_t)kHubChunk * batch_size * (num_negative + 1) * 32, gpu_memory_limit / 16);
     if (device_sampling && !as_streamed) {
         // the pools of every block a worker trains, two episodes, + its slices on their way to the owners (send + receive)
         demand += 4 * tails * P * pool;
@@ -629,6 +633,7 @@ extern "C" int gvx_solver_build(gvx_solver *s, const gvs_graph *graph, const gvx
         }
     }
     s->streamed = false;
+    s->gpu_memory_limit = limit;  // memory_demand reads it (the hub workspace term): set before partitions are chosen
     if (num_partition == GVX_AUTO) {
         // resident, the design of this engine: N * dim * 4 * (1 + m) * (1 + 1 / W) bytes of tables whatever the partition
         // count — more partitions only shrink the pools.  When even the most partitions do not fit, the reference's
@@ -784,14 +789,16 @@ int gvx_solver::configure(const gvx_train_config &in) {
     // chains apply SGD updates (a row's update composes in closed form), under any schedule; the moment optimizers have none:
     // asked for explicitly that is an error, by default it is said once
     const bool chains_exist = optimizer.type == GVK_SGD;
-    if (request != 0 && !chains_exist) {
-        if (fidelity == 1 || hub_rows_request > -2)
-            return gvk_fail(GVK_EINVAL, "hub rows are trained by chains for SGD only: fidelity='reference' / hub_rows cannot be "
-                            "honoured for this optimizer (use fidelity='throughput')");
-        if (first_rank == 0)
-            log_message(1, "WARNING: this optimizer has no chains for hub rows: every row is trained pair by pair "
-                        "(Hogwild); on hub-heavy graphs the hub rows then keep a few of their updates per batch");
-        request = 0;
+    if (request != 0 && !chains_exist && (fidelity == 1 || hub_rows_request > -2))
+        return gvk_fail(GVK_EINVAL, "hub rows are trained by chains for SGD only: fidelity='reference' / hub_rows cannot be "
+                        "honoured for this optimizer (use fidelity='throughput')");
+    if (hub_rows_request == -2 && fidelity == -1 && pair_order_request == 2 && first_rank == 0 && !order_said) {
+        log_message(1, "pair_order='grouped': batches are regrouped and trained pair by pair; hub rows get no chains (fidelity='reference' asks for them)");
+        order_said = true;
+    }
+    if (fidelity == 1 && pair_order_request == 2 && first_rank == 0 && !order_said) {
+        log_message(1, "fidelity='reference' with pair_order='grouped': tables with hub rows keep the sampler's order (chains), the regrouping is dropped there");
+        order_said = true;
     }
     if (request != 0) {
         const float *vertex_weights = gvs_graph_vertex_weights(graph);
@@ -835,6 +842,42 @@ int gvx_solver::configure(const gvx_train_config &in) {
         if (small_table && hubs) {
             const int worst = *std::max_element(hub_top_entries.begin(), hub_top_entries.end());
             if ((worst + kHubEntriesPerPart - 1) / kHubEntriesPerPart > kHubMaxPartsResident) {
+                hub_rows.assign(num_partition, 0);
+                hubs = false;
+            }
+        }
+        if (hubs && !chains_exist) {  // the rule found hub rows and this optimizer has no chains for them: said once per solver
+            if (first_rank == 0 && !hogwild_said)
+                log_message(1, "WARNING: this optimizer has no chains for hub rows: every row is trained pair by pair "
+                            "(Hogwild); on this graph the %u largest rows of a partition then keep a few of their updates per batch",
+                            *std::max_element(hub_rows.begin(), hub_rows.end()));
+            hogwild_said = true;
+            hub_rows.assign(num_partition, 0);
+            hubs = false;
+        }
+        if (hubs && hub_parts_request > 0 && batch_size % hub_parts_request)
+            return gvk_fail(GVK_EINVAL, "hub_parts (%d) must divide the batch size (%d)", hub_parts_request, batch_size);
+        // ... and the same question for every table, with the parts a block can actually be given (hub_parts_of: a divisor of the
+        // batch size near the rule's, at most hub_max_parts — a prime batch size has none): past kHubMaxEntriesPerPart updates of
+        // its largest hub row per part the chains' entries, side by side from the part's start state, overshoot; such a block's
+        // rows are trained pair by pair and the log says so (asked for explicitly: an error)
+        if (hubs) {
+            int worst = 0, worst_parts = 1;
+            for (int hp = 0; hp < num_partition; hp++)
+                for (int tp = 0; tp < num_partition; tp++) {
+                    if (hub_rows[hp] + hub_rows[tp] == 0) continue;
+                    const int parts = hub_parts_of(hp, tp), top = std::max(hub_top_entries[hp], hub_top_entries[tp]);
+                    if ((top + parts - 1) / parts > worst) worst = (top + parts - 1) / parts, worst_parts = parts;
+                }
+            if (worst > kHubMaxEntriesPerPart) {
+                if (fidelity == 1 || hub_rows_request > -2)
+                    return gvk_fail(GVK_EINVAL, "hub rows by chains: the largest hub row would meet %d of its updates per part (a batch as %d "
+                                    "parts; at most %d keep the chains stable): use a batch size with more divisors or set hub_parts",
+                                    worst, worst_parts, kHubMaxEntriesPerPart);
+                if (first_rank == 0)
+                    log_message(1, "WARNING: the largest hub row would meet %d of its updates per part of a batch (%d parts can be given, "
+                                "at most %d updates per part keep chains stable): every row is trained pair by pair (Hogwild)",
+                                worst, worst_parts, kHubMaxEntriesPerPart);
                 hub_rows.assign(num_partition, 0);
                 hubs = false;
             }
@@ -1010,8 +1053,20 @@ int gvx_solver::prepare_devices() {
 int gvx_solver::allocate_pools() {
     const int W = num_worker;
     const bool in_hbm = device_sampling || resident_pools || routed();
-    bool agreed = !distributed || W == 1 || !comm;  // one process per GPU: every rank must end with the same episode size
-    while (true) {
+    // one process per GPU: every rank must end with the same episode size (ranks with different episode sizes would issue
+    // collectives of different sizes and hang).  The agreement is itself collective, so every rank takes part in it whatever
+    // happened to it locally: two all-gathers — the size a rank fits (-1: none), then whether the smallest of them was
+    // allocated — and every rank returns the same verdict.  (With a transport supplied by the embedding program, gvx.h
+    // gvx_transport, these two gathers of 4 bytes per rank run through its all_gather at build time.)
+    const bool agree = distributed && W > 1 && comm;
+    auto release_pools = [&]() {
+        for (Worker &w : workers) {
+            hipSetDevice(w.device);
+            hipFree(w.pool[0]), hipFree(w.pool[1]), hipFree(w.landing), hipFree(w.block_pools[0]), hipFree(w.block_pools[1]);
+            w.pool[0] = w.pool[1] = w.landing = w.block_pools[0] = w.block_pools[1] = nullptr;
+        }
+    };
+    auto try_allocate = [&]() {  // every pool at the current episode size, or none
         bool ok = true;
         const size_t bytes = (size_t)episode_size * batch_size * 8;
         for (Worker &w : workers) {
@@ -1022,55 +1077,71 @@ int gvx_solver::allocate_pools() {
                 ok = ok && (!in_hbm || hipMalloc(&pools, w.tails.size() * num_partition * bytes) == hipSuccess);
             if (!ok) break;
         }
-        auto release_pools = [&]() {
-            for (Worker &w : workers) {
-                hipSetDevice(w.device);
-                hipFree(w.pool[0]), hipFree(w.pool[1]), hipFree(w.landing), hipFree(w.block_pools[0]), hipFree(w.block_pools[1]);
-                w.pool[0] = w.pool[1] = w.landing = w.block_pools[0] = w.block_pools[1] = nullptr;
-            }
-        };
-        if (ok && !agreed) {
-            // a rank with less free memory has halved further: the smallest size any rank settled on is everyone's (ranks with
-            // different episode sizes would issue collectives of different sizes and hang)
-            Worker &w = workers[0];
-            int32_t *sizes = nullptr;
-            HIP_TRY(hipMalloc(&sizes, (size_t)W * 4));
-            std::vector<int32_t> host(W, 0);
-            host[w.rank] = episode_size;
-            HIP_TRY(hipMemcpyAsync(sizes, host.data(), (size_t)W * 4, hipMemcpyHostToDevice, w.exchange));
-            const int rc = comm->all_gather({{w.rank, w.device, w.exchange}}, {sizes}, 4);
-            if (rc == GVK_OK) HIP_TRY(hipMemcpyAsync(host.data(), sizes, (size_t)W * 4, hipMemcpyDeviceToHost, w.exchange));
-            if (rc == GVK_OK) HIP_TRY(hipStreamSynchronize(w.exchange));
-            hipFree(sizes);
-            GVK_TRY(rc);
-            agreed = true;
-            const int smallest = *std::min_element(host.begin(), host.end());
-            if (smallest < episode_size) {
-                log_message(1, "Another worker fits an episode size of %d only. Use %d instead of %d.", smallest, smallest, episode_size);
-                release_pools();
-                episode_size = smallest;
-                make_info();
-                continue;
-            }
+        if (!ok) {
+            (void)hipGetLastError();
+            release_pools();
         }
-        if (ok) break;
-        (void)hipGetLastError();
-        release_pools();
-        if (agreed && distributed && W > 1 && comm)  // the size every rank agreed on does not fit after all: no second round (the others have left)
-            return gvk_fail(GVK_ENOMEM, "Out of GPU memory for the episode size of %d the workers agreed on", episode_size);
-        if (episode_size <= 1)
-            return gvk_fail(GVK_ENOMEM, "Out of GPU memory. Try to reduce the size of your graph or the dimension of your embeddings.");
+        return ok;
+    };
+    auto smallest_of = [&](int32_t mine, int32_t *smallest) {  // collective; nothing of it outlives the call
+        Worker &w = workers[0];
+        int32_t *sizes = nullptr;
+        std::vector<int32_t> host(W, 0);
+        host[w.rank] = mine;
+        int rc = hipSetDevice(w.device) == hipSuccess && hipMalloc(&sizes, (size_t)W * 4) == hipSuccess ? GVK_OK : GVK_EHIP;
+        // a rank whose staging buffer failed still enters the gather (from a null buffer the carrier reports the error on every rank)
+        if (rc == GVK_OK && hipMemcpyAsync(sizes, host.data(), (size_t)W * 4, hipMemcpyHostToDevice, w.exchange) != hipSuccess) rc = GVK_EHIP;
+        const int gathered = comm->all_gather({{w.rank, w.device, w.exchange}}, {sizes}, 4);
+        if (rc == GVK_OK) rc = gathered;
+        if (rc == GVK_OK && (hipMemcpyAsync(host.data(), sizes, (size_t)W * 4, hipMemcpyDeviceToHost, w.exchange) != hipSuccess ||
+                             hipStreamSynchronize(w.exchange) != hipSuccess))
+            rc = GVK_EHIP;
+        hipFree(sizes);
+        if (rc != GVK_OK) return gvk_fail(rc, "GraphSolver: the workers could not agree on an episode size (%s)", gvk_last_error());
+        *smallest = *std::min_element(host.begin(), host.end());
+        return GVK_OK;
+    };
+    int local = GVK_OK;  // what this rank's own memory says
+    while (!try_allocate()) {
+        if (episode_size <= 1) {
+            local = gvk_fail(GVK_ENOMEM, "Out of GPU memory. Try to reduce the size of your graph or the dimension of your embeddings.");
+            break;
+        }
         // the halved episode keeps what configure() checked: a whole number of shuffle bases per pool — per slice, when
         // every worker samples a slice of every pool
         const size_t base = (size_t)(config.augmentation_step > 1 ? std::max(config.shuffle_base, 1) : 1) * (routed() ? W : 1);
         int half = episode_size / 2;
         while (half > 1 && ((size_t)half * batch_size) % base) half--;
-        if (((size_t)std::max(half, 1) * batch_size) % base)
-            return gvk_fail(GVK_ENOMEM, "Out of GPU memory for an episode of %d batches, and no smaller episode is a multiple of "
-                            "the shuffle base times the number of workers", episode_size);
+        if (((size_t)std::max(half, 1) * batch_size) % base) {
+            local = gvk_fail(GVK_ENOMEM, "Out of GPU memory for an episode of %d batches, and no smaller episode is a multiple of "
+                             "the shuffle base times the number of workers", episode_size);
+            break;
+        }
         log_message(1, "Fail to allocate GPU memory for episode size of %d. Use %d instead.", episode_size, std::max(half, 1));
         episode_size = std::max(half, 1);
         make_info();
+    }
+    if (!agree) {
+        if (local != GVK_OK) return local;
+    } else {
+        const std::string mine = local != GVK_OK ? gvk_last_error() : "";
+        int32_t smallest = 0;
+        GVK_TRY(smallest_of(local == GVK_OK ? episode_size : -1, &smallest));
+        bool ok = smallest > 0;
+        if (ok && smallest < episode_size) {  // a rank with less free memory has halved further: its size is everyone's
+            log_message(1, "Another worker fits an episode size of %d only. Use %d instead of %d.", smallest, smallest, episode_size);
+            release_pools();
+            episode_size = smallest;
+            make_info();
+            ok = try_allocate();
+        }
+        int32_t all_fit = 0;
+        GVK_TRY(smallest_of(ok ? 1 : -1, &all_fit));
+        if (smallest <= 0 || all_fit <= 0) {
+            release_pools();
+            if (local != GVK_OK) return gvk_fail(local, "%s", mine.c_str());
+            return gvk_fail(GVK_ENOMEM, smallest <= 0 ? "Out of GPU memory on another worker" : "Out of GPU memory for the episode size of %d the workers agreed on", episode_size);
+        }
     }
     for (Worker &w : workers) {
         HIP_TRY(hipSetDevice(w.device));
@@ -1550,7 +1621,7 @@ int gvx_solver::hub_parts_of(int hp, int tp) const {
     const int B = batch_size;
     const uint32_t kv = hubs ? hub_rows[hp] : 0, kc = hubs ? hub_rows[tp] : 0;
     if (kv + kc == 0) return 1;
-    if (hub_parts_request > 0 && B % hub_parts_request == 0) return hub_parts_request;
+    if (hub_parts_request > 0) return hub_parts_request;  // divides the batch size (configure)
     // so many parts that the largest hub row meets about kHubEntriesPerPart of its updates per part —
     // and, where every row is a hub row (a small table: many samples per row and batch), at least the parts
     // gvk_train_launches prescribes for it (§7.8: a chain then sees its partners at most a part old) —, a divisor of the

@@ -340,9 +340,6 @@ int gvk_probe_row_traffic(void *stream, int dim, float *vertex, float *context, 
                                      the long chains, then the pairs, then the other chains, 2 the pairs */
 #define GVK_TUNE_HOT_SERIALIZED 9 /* measurement: 1 = gvk_train_episode_hot always launches the chains and the pairs of a unit one after the
                                      other (GVK_HOT_SERIALIZED): their durations apart in a kernel trace */
-#define GVK_TUNE_HOT_GRAM 11      /* experiment (off by default): 1 (kernel built for three wavefronts per SIMD) or 2 (four) = a long chain (dims up to 128, up to 1024 entries) is trained as tasks of
-                                     16 entries whose steps run on the task's Gram matrix (v_mfma_f32_16x16x4_f32) instead of on the rows
-                                     (long_chain_gram in gvk_kernels.hip); the oracle's form of it is cap 16, max_tasks 64 */
 #define GVK_TUNE_CHAIN_CAP 8      /* gvk_train_episode_hot: entries one chain task trains in sequence (a longer chain is cut into
                                      tasks trained side by side and composed): 0 = the default, 7 (also the most) */
 /* A/B library only: */

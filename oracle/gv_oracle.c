@@ -190,13 +190,21 @@ static void gvo_chain(int dim, float *own, const float *partner, const uint32_t 
  * from `own_table` and leaves there; partner rows are read from `partner_vertex` / `partner_context` (the caller passes the
  * tables as the unit found them).  A chain longer than cap entries is trained as tasks of consecutive entries side by side
  * and the tasks are composed (below): tasks of cap entries, or — past max_tasks of them (0 = no limit) — of
- * ceil(n / max_tasks) entries, what one workgroup of the product trains
- * (train_long_chains, graphvite_amd/csrc/gvk_kernels.hip). */
+ * ceil(n / max_tasks) entries, what one workgroup of the product trains (train_long_chains,
+ * graphvite_amd/csrc/gvk_kernels.hip).  gvo_set_long_task(t > 0) (executor-simulator experiments): tasks of t entries, as many
+ * as it takes; t = 1 is "every entry of a long chain on its own from the row as the decay of the entries before it leaves it"
+ * (measured in round 5: profiles/r5/experiments/r5_entries_side_by_side.txt). */
+static uint32_t gvo_long_task = 0;
+void gvo_set_long_task(uint32_t entries) { gvo_long_task = entries; }
+
 static int gvo_hot_chains(int dim, float *vertex, float *context, const float *partner_vertex, const float *partner_context,
                           float lr, float wd, float negative_weight, uint32_t kv, const uint32_t *chain_start,
                           const uint32_t *entries, uint32_t cap, uint32_t max_tasks, int k, uint32_t first_chain,
                           uint32_t last_chain) {
-    float *own = (float *)malloc(sizeof(float) * dim), *sum = (float *)malloc(sizeof(float) * dim);
+    /* the tasks' sum in double: after * own and total * row are nearly equal numbers (exact as double products), and a long chain
+     * adds thousands of their differences */
+    float *own = (float *)malloc(sizeof(float) * dim);
+    double *sum = (double *)malloc(sizeof(double) * dim);
     if (!own || !sum) return -1;
     for (uint32_t chain = first_chain; chain < last_chain; chain++) {
         float *row = chain < kv ? vertex + (size_t)chain * dim : context + (size_t)(chain - kv) * dim;
@@ -206,31 +214,33 @@ static int gvo_hot_chains(int dim, float *vertex, float *context, const float *p
             gvo_chain(dim, row, partner, entries, first, last, lr, wd, negative_weight);
             continue;
         }
-        uint32_t per = cap;
-        if (max_tasks && (uint64_t)per * max_tasks < n) per = (n + max_tasks - 1) / max_tasks;
+        uint32_t per = gvo_long_task ? gvo_long_task : cap;
+        if (!gvo_long_task && max_tasks && (uint64_t)per * max_tasks < n) per = (n + max_tasks - 1) / max_tasks;
         (void)k;
         /* tasks: weight decay composes in closed form (a factor per entry that depends on its label only), so every task
          * starts from the row as the decay of the entries before it leaves it, and its end state is carried through the
          * decay of the entries after it: row <- total row + sum over tasks (after end - total row) */
-        const float decay_positive = 1 - lr * wd, decay_negative = 1 - lr * negative_weight * wd;
+        /* the decay factors of an entry in double: 1 - lr wd rounded to float is off by 3e-8, i.e. by 2e-4 of its distance from 1,
+         * which a chain of a thousand entries raises to 3e-5 of the row */
+        const double decay_positive = 1.0 - (double)lr * (double)wd, decay_negative = 1.0 - (double)lr * (double)negative_weight * (double)wd;
         uint32_t positives_all = 0;
         for (uint32_t p = first; p < last; p++) positives_all += entries[p] >> 31;
-        const float total = powf(decay_positive, (float)positives_all) * powf(decay_negative, (float)(n - positives_all));
-        memset(sum, 0, sizeof(float) * dim);
+        const float total = (float)(pow(decay_positive, (double)positives_all) * pow(decay_negative, (double)(n - positives_all)));
+        memset(sum, 0, sizeof(double) * dim);
         uint32_t positives_before = 0;
         for (uint32_t begin = first; begin < last; begin += per) {
             const uint32_t end = last - begin > per ? begin + per : last;
             uint32_t positives_inside = 0;
             for (uint32_t p = begin; p < end; p++) positives_inside += entries[p] >> 31;
             const uint32_t positives_after = positives_all - positives_before - positives_inside;
-            const float before = powf(decay_positive, (float)positives_before) * powf(decay_negative, (float)(begin - first - positives_before));
-            const float after = powf(decay_positive, (float)positives_after) * powf(decay_negative, (float)(last - end - positives_after));
+            const float before = (float)(pow(decay_positive, (double)positives_before) * pow(decay_negative, (double)(begin - first - positives_before)));
+            const float after = (float)(pow(decay_positive, (double)positives_after) * pow(decay_negative, (double)(last - end - positives_after)));
             for (int i = 0; i < dim; i++) own[i] = before * row[i];
             gvo_chain(dim, own, partner, entries, begin, end, lr, wd, negative_weight);
-            for (int i = 0; i < dim; i++) sum[i] += after * own[i] - total * row[i];
+            for (int i = 0; i < dim; i++) sum[i] += (double)after * (double)own[i] - (double)total * (double)row[i];
             positives_before += positives_inside;
         }
-        for (int i = 0; i < dim; i++) row[i] = total * row[i] + sum[i];
+        for (int i = 0; i < dim; i++) row[i] = (float)((double)total * (double)row[i] + sum[i]);
     }
     free(own), free(sum);
     return 0;

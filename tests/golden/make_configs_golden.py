@@ -5,7 +5,8 @@ state, for the optimizers the reference ships beside SGD, and on a hub-heavy gra
   fs_line_p8      configs[4]'s shape: a Friendster-like power-law graph (2M nodes / 40M edges; the real one has 65M / 1.8B and
                   does not fit a host training loop), **dim 96** (oracle/_ref/libgvref_solver_96.so), LINE with augmentation_step 2
                   (random walks of 40, pools in walk order, shuffle_base 2), 8 partitions on one worker, episodes of 8 batches per
-                  block, SGD 0.025 / 0.005 (config/graph/line_friendster.yaml:7-27), 13 epochs = 5 200 batches of 100 000
+                  block, SGD 0.025 / 0.005 (config/graph/line_friendster.yaml:7-27), 50 epochs = 20 000 batches of 100 000 (13 epochs
+                  leave the reference's own loop at AUC 0.506: nothing learnt yet, nothing to compare)
   yt_deepwalk     configs[2]'s shape AT ITS STATED SIZE: a Youtube-sized hub / community graph (1 138 499 nodes / 4 945 382 edge
   yt_p4_deepwalk  lines), DeepWalk, augmentation_step 5, walks of 40 (config/graph/deepwalk_youtube.yaml:7-27), 100 epochs = 4 900
                   batches in episodes of 500 — one partition, and the 4 partitions of configs[3]'s per-GPU shape (episodes of 30)
@@ -18,6 +19,7 @@ state, for the optimizers the reference ships beside SGD, and on a hub-heavy gra
 Every job: SEEDS seeds.  ~10-25 minutes of host time per training.
 
     python tests/golden/make_configs_golden.py [job ...]         # resumable, lock-protected: several processes may run side by side
+    SEED_INDEX=1 python tests/golden/make_configs_golden.py fs_line_p8     # one seed of a job per process
 """
 import fcntl
 import os
@@ -39,7 +41,7 @@ WALK = dict(walk_length=40, walk_batch=100)
 
 # name: (graph, dim, model, train kwargs, partitions, episode (0 = automatic), epochs, optimizer)
 JOBS = {
-    "fs_line_p8": ("friendster_like", 96, "LINE", dict(augmentation_step=2, shuffle_base=2, **WALK), 8, 8, 13, None),
+    "fs_line_p8": ("friendster_like", 96, "LINE", dict(augmentation_step=2, shuffle_base=2, **WALK), 8, 8, 50, None),
     "yt_deepwalk": ("youtube_like", 128, "DeepWalk", dict(augmentation_step=5, shuffle_base=1, **WALK), 1, 500, 100, None),
     "yt_p4_deepwalk": ("youtube_like", 128, "DeepWalk", dict(augmentation_step=5, shuffle_base=1, **WALK), 4, 30, 100, None),
     "c2_adam": ("headline", 128, "LINE", dict(augmentation_step=1), 1, 0, 50, ("Adam", 1e-3, 0.005)),
@@ -83,6 +85,8 @@ def main():
     for name in names:
         graph, dim, model, train_kw, partitions, episode, epochs, optimizer = JOBS[name]
         for i, seed in enumerate(SEEDS):
+            if os.environ.get("SEED_INDEX") and i != int(os.environ["SEED_INDEX"]):
+                continue  # one seed per process: several processes of one job side by side
             done = dict(np.load(PATH)) if os.path.exists(PATH) else {}
             if name in done and i < len(done[name]) and not np.isnan(done[name][i]):
                 continue

@@ -29,6 +29,7 @@ int gvo_train_hot(int dim, float *vertex, float *context, const uint32_t *batch,
 int gvo_hot_unit_chains(int dim, float *vertex, float *context, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
                         const uint32_t *chain_start, const uint32_t *entries, uint32_t cap, uint32_t max_tasks, int k);
 void gvo_set_pairs_concurrent(int on);
+void gvo_set_long_task(uint32_t entries);
 int gvo_train_pairs_hot(int dim, float *vertex, float *context, const uint32_t *batch, const uint32_t *negatives, float *loss,
                         int batch_size, int k, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
                         const float *before_vertex, const float *before_context);
@@ -228,12 +229,13 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     const int lerp = (form & GVK_HOT_LERP) || (getenv("GVH_LERP") && atoi(getenv("GVH_LERP")));
     // GVH_PAIRS=concurrent: the pairs of a unit as one launch runs them (reads as the unit found the rows, the later of two writers stays)
     gvo_set_pairs_concurrent(getenv("GVH_PAIRS") && !strcmp(getenv("GVH_PAIRS"), "concurrent"));
+    // GVH_LONG_TASK=t (experiments): a chain of more than cap entries as tasks of t entries, as many as it takes (1: every entry on
+    // its own); default 0: the device path's tasks of cap entries side by side, at most GVH_MAX_TASKS
+    gvo_set_long_task(getenv("GVH_LONG_TASK") ? (uint32_t)atoi(getenv("GVH_LONG_TASK")) : 0u);
     const int pipelined = strstr(executor, "pipelined") != nullptr, n = batch_size / parts, k = num_negative;
     if (getenv("GVH_CHAIN_CAP")) chain_cap = atoi(getenv("GVH_CHAIN_CAP"));
-    // GVH_GRAM=1: the tasks of the device path's GVK_TUNE_HOT_GRAM form (long_chain_gram, gvk_kernels.hip): 16 entries each, up to 64 side by side
-    const bool gram = getenv("GVH_GRAM") && atoi(getenv("GVH_GRAM"));
-    const uint32_t cap = gram ? 16u : (uint32_t)std::min(chain_cap > 0 ? chain_cap : 7, 7);  // chain_cap_for, gvk_kernels.hip
-    const uint32_t max_tasks = gram ? 64u : getenv("GVH_MAX_TASKS") ? (uint32_t)atoi(getenv("GVH_MAX_TASKS")) : (dim == 512 ? 8u : (dim == 32 || dim == 96 ? 32u : 16u));
+    const uint32_t cap = (uint32_t)std::min(chain_cap > 0 ? chain_cap : 7, 7);  // chain_cap_for, gvk_kernels.hip
+    const uint32_t max_tasks = getenv("GVH_MAX_TASKS") ? (uint32_t)atoi(getenv("GVH_MAX_TASKS")) : (dim == 512 ? 8u : (dim == 32 || dim == 96 ? 32u : 16u));
     std::vector<uint32_t> start(hot_vertex + hot_context + 1), entries(2 * (size_t)(k + 1) * n + 1);
     std::vector<uint32_t> all((size_t)num_batches * batch_size * std::max(k, 1));
     for (int i = 0; i < num_batches; i++) {

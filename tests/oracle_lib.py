@@ -128,10 +128,12 @@ class Oracle(object):
         return start, entries[:n].copy()
 
     def train_hot(self, vertex, context, batch, negatives, lr, wd, negative_weight, hot_vertex, hot_context, chain_start,
-                  entries, cap, max_tasks=0, lerp=False):
+                  entries, cap, max_tasks=0, lerp=False, long_task=0):
         """One unit in the product's serialized hub-chain form (gvk_train_episode_hot(serialized=1)): the chains of both
         families from the unit's start state, then its pairs (`lerp`: hub rows read along the chains' way); in place.
-        max_tasks: tasks one workgroup of the product trains side by side (256 / lanes per pair; 0 = no limit)."""
+        A chain of more than cap entries: tasks of cap entries side by side, at most max_tasks of them (the tasks one workgroup of
+        the product trains: 256 / lanes per pair; 0 = no limit) — or, long_task > 0 (experiments), tasks of long_task entries."""
+        self.lib.gvo_set_long_task(int(long_task))
         B = batch.shape[0]
         k = negatives.size // B if B else 0
         loss = np.zeros(max(B, 1), np.float32)

@@ -1,7 +1,7 @@
-"""TEST INFRASTRUCTURE: builds tests/hostdev/build/libsimt_gram.so — the SOURCE of `long_chain_gram` (and of the cross-lane helpers it
-uses) cut out of graphvite_amd/csrc/gvk_kernels.hip as written, compiled for the host over tests/hostdev/simt.h (one host thread per
-lane, cross-lane operations as rendezvous).  The empty `asm volatile` statements of the device code (compiler fences with AMDGPU
-register constraints) are the only thing removed."""
+"""TEST INFRASTRUCTURE: builds tests/hostdev/build/libsimt_chains.so — the SOURCE of the hub chains' device functions
+(train_long_chains / chain_steps, train_short_chains and the cross-lane helpers they use) cut out of
+graphvite_amd/csrc/gvk_kernels.hip as written, compiled for the host over tests/hostdev/simt.h (one host thread per lane,
+cross-lane operations as rendezvous of a wavefront's 64 threads, __syncthreads as a barrier of 256)."""
 import os
 import re
 import subprocess
@@ -9,7 +9,7 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SOURCE = os.path.join(ROOT, "graphvite_amd", "csrc", "gvk_kernels.hip")
 HOSTDEV = os.path.join(ROOT, "tests", "hostdev")
-OUT = os.path.join(HOSTDEV, "build", "libsimt_gram.so")
+OUT = os.path.join(HOSTDEV, "build", "libsimt_chains.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 WRAPPER = r'''
@@ -17,72 +17,12 @@ WRAPPER = r'''
 
 simt::Group *simt::group = nullptr;
 
-namespace {
-struct Task {
-    unsigned index;
-    int dim;
-    TrainArgs a;
-    HotArgs h;
-    uint32_t chain, first, n;
-};
-
-template <int DIM>
-void chain_of(const Task &t) {
-    // the caller's loop (train_long_chains, GRAM builds): segments of 16 x kGramTiles entries, one after the other
-    for (uint32_t done = 0; done < t.n; done += 16u * kGramTiles)
-        long_chain_gram<DIM>(t.a, t.h, t.chain, t.first + done, t.n - done < 16u * kGramTiles ? t.n - done : 16u * kGramTiles,
-                             (done == 0 ? t.h.from : t.h.to) + (size_t)t.chain * DIM, false);
-}
-
-void *lane_main(void *p) {
-    const Task &t = *static_cast<const Task *>(p);
-    threadIdx.x = t.index;
-    switch (t.dim) {
-        case 32: chain_of<32>(t); break;
-        case 64: chain_of<64>(t); break;
-        case 96: chain_of<96>(t); break;
-        case 128: chain_of<128>(t); break;
-    }
-    return nullptr;
-}
-}  // namespace
-
-extern "C" int simt_long_chain_gram(int dim, float *vertex, float *context, uint32_t hot_vertex, uint32_t hot_context, float wd,
-                                    float neg_weight, const uint32_t *entries, const float *from, float *to, float lr,
-                                    float log2_decay_positive, float log2_decay_negative, uint32_t chain, uint32_t first, uint32_t n) {
-    if (dim != 32 && dim != 64 && dim != 96 && dim != 128) return -1;
-    static simt::Group g;
-    simt::group = &g;
-    pthread_barrier_init(&g.barrier, nullptr, simt::kThreads);
-    for (auto &w : g.wave) pthread_barrier_init(&w.barrier, nullptr, simt::kWave);
-    Task proto;
-    memset(&proto, 0, sizeof(proto));
-    proto.dim = dim, proto.chain = chain, proto.first = first, proto.n = n;
-    proto.a.vertex = vertex, proto.a.context = context, proto.a.hot_vertex = hot_vertex, proto.a.hot_context = hot_context;
-    proto.a.wd = wd, proto.a.neg_weight = neg_weight;
-    proto.h.entries = entries, proto.h.from = from, proto.h.to = to, proto.h.lr = lr;
-    proto.h.log2_decay_positive = log2_decay_positive, proto.h.log2_decay_negative = log2_decay_negative;
-    static Task tasks[simt::kThreads];
-    pthread_t threads[simt::kThreads];
-    pthread_attr_t attr;
-    pthread_attr_init(&attr);
-    pthread_attr_setstacksize(&attr, 1 << 20);
-    for (int i = 0; i < simt::kThreads; i++) {
-        tasks[i] = proto, tasks[i].index = (unsigned)i;
-        if (pthread_create(&threads[i], &attr, lane_main, &tasks[i]) != 0) return -2;
-    }
-    for (int i = 0; i < simt::kThreads; i++) pthread_join(threads[i], nullptr);
-    pthread_barrier_destroy(&g.barrier);
-    for (auto &w : g.wave) pthread_barrier_destroy(&w.barrier);
-    return 0;
-}
-
-// ---- the chain side of one unit as train_hot_kernel runs it: train_long_chains (GRAM = 0: the steps, 1: Gram matrices) for every
-// long-chain workgroup, then train_short_chains for every workgroup of short chains; one workgroup at a time
+// ---- the chain side of one unit as train_hot_kernel runs it: train_long_chains for every long-chain workgroup, then
+// train_short_chains for every workgroup of short chains; one workgroup at a time
 namespace {
 struct Block {
     unsigned index;
-    int dim, gram, role;  // role 0: long chains, 1: short chains
+    int dim, role;  // role 0: long chains, 1: short chains
     uint32_t block;
     const TrainArgs *a;
     const HotArgs *h;
@@ -91,8 +31,7 @@ struct Block {
 template <int DIM, int G>
 void block_of(const Block &t) {
     if (t.role == 1) train_short_chains<DIM, G>(*t.a, *t.h, t.block);
-    else if (t.gram) train_long_chains<DIM, G, 1>(*t.a, *t.h, t.block);
-    else train_long_chains<DIM, G, 0>(*t.a, *t.h, t.block);
+    else train_long_chains<DIM, G>(*t.a, *t.h, t.block);
 }
 
 void *block_main(void *p) {
@@ -103,14 +42,14 @@ void *block_main(void *p) {
         case 64: block_of<64, 16>(t); break;
         case 96: block_of<96, 8>(t); break;
         case 128: block_of<128, 16>(t); break;
-        case 256: block_of<256, 16>(t); break;  // no Gram form beyond dim 128: GRAM is ignored there
+        case 256: block_of<256, 16>(t); break;
         case 512: block_of<512, 32>(t); break;
     }
     return nullptr;
 }
 }  // namespace
 
-extern "C" int simt_unit_chains(int dim, int gram, float *vertex, float *context, uint32_t hot_vertex, uint32_t hot_context, float wd,
+extern "C" int simt_unit_chains(int dim, float *vertex, float *context, uint32_t hot_vertex, uint32_t hot_context, float wd,
                                 float neg_weight, const uint32_t *chain_start, const uint32_t *entries, const uint32_t *long_list,
                                 const uint32_t *short_list, uint32_t long_capacity, uint32_t cap, const float *from, float *to, float lr,
                                 float log2_decay_positive, float log2_decay_negative, int long_blocks, int short_blocks) {
@@ -135,7 +74,7 @@ extern "C" int simt_unit_chains(int dim, int gram, float *vertex, float *context
             static Block blocks[simt::kThreads];
             pthread_t threads[simt::kThreads];
             for (int i = 0; i < simt::kThreads; i++) {
-                blocks[i] = Block{(unsigned)i, dim, gram, role, (uint32_t)b, &a, &h};
+                blocks[i] = Block{(unsigned)i, dim, role, (uint32_t)b, &a, &h};
                 if (pthread_create(&threads[i], &attr, block_main, &blocks[i]) != 0) return -2;
             }
             for (int i = 0; i < simt::kThreads; i++) pthread_join(threads[i], nullptr);
@@ -161,13 +100,11 @@ def host_source():
         cut(text, "template <int CTRL>\n__device__ __forceinline__ float dpp(float x) {", "// ---- Philox4x32-10", include_end=False),
         cut(text, "template <int DIM, int G>\nstruct Layout {", "// ---- arithmetic", include_end=False),
         cut(text, "__device__ __forceinline__ float sigmoidf(float x) {", "\n}\n"),
-        # HotArgs, the chains of 1 .. 7 entries, the idle rows, long_chain_gram, train_long_chains: everything up to the kernel itself
+        # HotArgs, the chains of 1 .. 7 entries, the idle rows, chain_steps, train_long_chains: everything up to the kernel itself
         cut(text, "struct HotArgs {", "// HOT: 1 = the pairs read a hub row as the chains of their unit left it", include_end=False),
     ]
     body = "\n".join(pieces)
-    body, fences = re.subn(r'asm volatile\(""[^;]*\);', ";", body)
-    assert fences >= 3, "the device function's compiler fences were expected"
-    assert "asm volatile" not in body and "long_chain_gram" in body
+    assert "asm volatile" not in body and "chain_steps" in body
     return body + "\n" + WRAPPER
 
 
@@ -177,7 +114,7 @@ def build():
     if os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(p) for p in inputs):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    generated = os.path.join(os.path.dirname(OUT), "simt_gram.cpp")
+    generated = os.path.join(os.path.dirname(OUT), "simt_chains.cpp")
     with open(generated, "w") as f:
         f.write(host_source())
     compiler = CLANG if os.path.exists(CLANG) else "clang++"

@@ -5,7 +5,6 @@ every hub row, (2) that the serialized form (per unit: chains, then pairs) compu
 lists — chains of both families from the unit's start state, long chains as tasks composed in order, pairs reading hub rows as
 the chains left them or along their way (lerp) —, and (3) that the pipelined product form stays with it; what the chains are
 FOR — the reference's learning quality on hub-heavy shapes — is pinned end to end in tests/test_solver_gpu.py."""
-import os
 
 import numpy as np
 import pytest
@@ -250,61 +249,3 @@ def test_a_batch_trained_as_parts(hip, oracle):
         np.testing.assert_allclose(tv.cpu().numpy(), ov, rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(tc.cpu().numpy(), oc, rtol=1e-4, atol=1e-6)
     assert np.isfinite(loss[:300].cpu().numpy()).all() and loss[:300].abs().sum() > 0
-
-
-@pytest.mark.skipif(os.environ.get("GVK_TEST_GRAM") != "1",
-                    reason="experiment written without a GPU (round 4, no GPU minutes left): GVK_TEST_GRAM=1 runs it")
-@pytest.mark.parametrize("form", [1, 2])  # the kernel built for three / for four wavefronts per SIMD
-@pytest.mark.parametrize("dim,k", [(128, 1), (128, 3), (32, 1), (64, 1), (96, 2)])
-def test_long_chains_by_gram_matrices(hip, oracle, dim, k, form):
-    """GVK_TUNE_HOT_GRAM (long_chain_gram, gvk_kernels.hip): a long chain as tasks of 16 entries whose steps run on the task's Gram
-    matrix.  In exact arithmetic that is the oracle's chains with cap 16, max_tasks 64; the lane maps of the device code are
-    pinned on the CPU by tests/test_gram_chain_cpu.py."""
-    rng = np.random.default_rng(dim * 10 + k + 1)
-    N, B, batches, kv, kc = 1 << 15, 1500, 1, 24, 40
-    v = (rng.uniform(-0.5, 0.5, (N, dim)) * 0.05).astype(np.float32)
-    c = (rng.uniform(-0.5, 0.5, (N, dim)) * 0.05).astype(np.float32)
-    v[:kv] *= 40  # hub rows of the size training leaves them at: logits that matter
-    c[:kc] *= 40
-    pool, w = hub_case(rng, N, B, batches, kv, kc)
-    table = negative_table(w, False)
-    opt = K.OptimizerSpec("SGD", 0.025, 0.005)
-    dpool = torch.from_numpy(pool.view(np.int32)).to(DEV)
-    ws = torch.zeros(hip.hot_plan(dim, B, k, kv, kc, batches), dtype=torch.uint8, device=DEV)
-    hip.hot_build(dim, ws, dpool, B, batches, k, table, SEED, FIRST_ID, kv, kc)
-    torch.cuda.synchronize()
-    chains = kv + kc
-    _, entry_capacity, off = layout(B, k, chains, batches, 0)
-    raw = ws.cpu().numpy()
-    starts = raw[:(chains + 1) * 4].view(np.uint32)
-    entries = raw[off:off + entry_capacity * 4].view(np.uint32)
-    longest = int(np.diff(starts.astype(np.int64)).max())
-    assert 16 < longest <= 1024  # several tiles, inside what the Gram form takes
-    negs = torch.zeros(B * k, dtype=torch.int32, device=DEV)
-    hip.negative_draw(table, SEED, FIRST_ID, negs, B, k)
-    nb = negs.cpu().numpy().view(np.uint32).reshape(B, k)
-    keep_v, keep_c = clean_rows(pool, nb, N, kv, kc)
-    lr = oracle.lr(0.025, True, FIRST_ID, TOTAL)
-    ov, oc = v.copy(), c.copy()
-    oracle.train_hot(ov, oc, pool, nb, lr, 0.005, 5.0, kv, kc, starts, entries[:starts[-1]], 16, max_tasks=64, lerp=False)
-    hip.set_tuning(11, form)  # GVK_TUNE_HOT_GRAM
-    try:
-        runs = []
-        for serialized in (True, False, False):
-            tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
-            loss = torch.zeros(B, device=DEV)
-            hip.train_episode_hot(tv, tc, dpool, loss, opt, k, 5.0, table, SEED, FIRST_ID, TOTAL, batches, B, ws, kv, kc,
-                                  serialized=serialized)
-            torch.cuda.synchronize()
-            sv, sc = tv.cpu().numpy(), tc.cpu().numpy()
-            # chain by chain first, so that a red run says which lengths are off (one tile, several, more than one round)
-            lengths = np.diff(starts.astype(np.int64))
-            off = [(ch, int(lengths[ch]), float(np.abs(g - w).max())) for ch, (g, w) in
-                   enumerate(list(zip(sv[:kv], ov[:kv])) + list(zip(sc[:kc], oc[:kc]))) if not np.allclose(g, w, rtol=1e-4, atol=1e-5)]
-            assert not off, "chains off the oracle (chain, entries, largest difference): %s" % off
-            for got, want, keep in ((sv, ov, keep_v), (sc, oc, keep_c)):
-                np.testing.assert_allclose(got[keep], want[keep], rtol=1e-4, atol=1e-5)
-            runs.append((sv[:kv].copy(), sc[:kc].copy()))
-        assert all((runs[0][i] == runs[j][i]).all() for i in range(2) for j in (1, 2))  # the same bits on every run
-    finally:
-        hip.set_tuning(11, 0)
