@@ -1,0 +1,746 @@
+// gvk_chains.hip — hub rows trained by chains: the work lists (hot_list_kernel), the chains of 1 .. 7
+// entries and the long chains, the launch that trains a unit's pairs beside the next unit's chains (train_hot_kernel), and their
+// C-ABI (include/gvk.h: gvk_hot_plan, gvk_hot_build, gvk_train_episode_hot).
+#include "gvk_device.hpp"
+
+namespace {
+
+// ---- hub rows: chains --------------------------------------------------------------------------------------------------
+//
+// The samples of a launch run concurrently, and of the updates that hold a row at the same time one survives (Hogwild, as
+// between two warps of the reference).  For most rows of a large table that never happens; a HUB row — the top hub of the
+// benchmark graph is the head of 1 in 100 samples and the tail of as many — is in flight hundreds of times per launch
+// and keeps a handful of its updates, where the reference's CPU solver (and its GPU kernel on the card it was written
+// for, far less concurrent) keeps them all: link-prediction AUC 0.650 against 0.668 on the headline shape.
+//
+// With hub rows, a batch is trained as UNITS (its `parts`), and a unit is two kinds of work.  The hub rows of both tables —
+// the first hot_vertex / hot_context local ids; partitions are ordered by falling degree — are each owned by a CHAIN: a
+// lane group holds the row in registers and applies every update the unit has for it one after the other (for a head row
+// the targets of its samples, negatives first; for a context row the heads it is the tail or the negative of), reading
+// the partner rows (D of them in flight) and writing nothing but its own row, once, at the end.  Everything else is the
+// per-pair body (train_pair<HOT>): every sample, all arithmetic, but hub rows are only read.  So a hub row has ONE writer
+// per unit and loses nothing.
+//
+// Where hub rows live.  During a call they live in three MIRRORS M[0..2] ([hot_vertex + hot_context][dim], head rows
+// first) in the workspace, not in the tables: the chains of unit u read M[(u - 1) % 3] — their own row AND every partner
+// that is a hub row itself, so that a sample between two hub rows updates both from the values the unit started with, as
+// the reference does (model/graph.h:47-58); two chains that read each other's fresh stores would compound the step they
+// share, DESIGN.md §3.1.2 — and store to M[u % 3]; the pairs of unit u read M[u % 3] (and, lerp, M[(u - 1) % 3]).  One
+// launch runs the pairs of unit u and, in its first blocks, the chains of unit u + 1: nothing it reads is written by it.
+// The tables' hub rows are written once, when the call ends (hub_rows_kernel).
+//
+// A chain longer than `cap` entries is a LONG chain: a whole workgroup trains it, up to kBlock / G tasks of consecutive
+// entries side by side, composed through LDS in task order — deterministic given the work lists, no atomics.  The chains'
+// work lists are built by hot_list_kernel.
+struct HotArgs {
+    const uint32_t *chain_start;  // [chains + 1] offsets of this unit into entries
+    const uint32_t *before_start[2];  // the same of the one or two units before it (null: none): which rows the mirror `to` has missed
+    const uint32_t *entries;      // partner row | label << 31 (label 1 = positive)
+    const uint32_t *long_list;    // [0] = number of long chains (more than cap entries), then from [4] on a record {chain, first entry, entries, -} each
+    const uint32_t *short_list;   // [0] = number of chains of 1 .. cap entries, then from [16] on a record of 16 words each: {chain, entries, -, -, the entries themselves}
+    const float *from;            // mirror the chains read: own rows and hub partners as the unit finds them
+    float *to;                    // mirror the chains store to
+    uint32_t chains;              // hot_vertex + hot_context
+    uint32_t long_capacity;
+    uint32_t cap;                 // entries of one task (at most kShortEntries)
+    float lr;                     // learning rate of the chains' batch (the pairs of the same launch may belong to another batch)
+    float log2_decay_positive, log2_decay_negative;  // log2(1 - lr wd), log2(1 - lr negative_weight wd): decay of an entry by label
+    int order, pair_blocks;       // grid order (0: chains first, 1: long chains, pairs, the other chains, 2: pairs first)
+    int long_blocks, short_blocks, copy_blocks;  // grid: [long chains | chains of 1 .. cap entries, kBlock / G per block | rows without entries | pairs]
+#if defined(GVK_TIMESTAMPS)  // measurement build (make ts): where the time of a launch goes, eight 100 MHz stamps per workgroup
+    unsigned long long *stamps;
+#endif
+};
+
+// Measurement build only (make -C graphvite_amd/csrc ts -> build/ts/libgvk_ts.so, scripts/experiments/stamps.py): thread 0 of
+// every workgroup of a train_hot_kernel launch leaves eight words — its role and the 100 MHz clock at the points of its path.
+#if defined(GVK_TIMESTAMPS)
+#define GVK_STAMP(h, slot) do { if ((h).stamps && threadIdx.x == 0) (h).stamps[(size_t)blockIdx.x * 8 + (slot)] = (unsigned long long)wall_clock64(); } while (0)
+#define GVK_STAMP_VALUE(h, slot, value) do { if ((h).stamps && threadIdx.x == 0) (h).stamps[(size_t)blockIdx.x * 8 + (slot)] = (unsigned long long)(value); } while (0)
+#else
+#define GVK_STAMP(h, slot) do { } while (0)
+#define GVK_STAMP_VALUE(h, slot, value) do { } while (0)
+#endif
+
+template <int DIM, int G>
+struct ChainShape {
+    static constexpr int V = DIM / G;
+    static constexpr int D = V <= 4 ? 8 : (V <= 8 ? 4 : 2);  // partner rows in flight per lane group of a long chain's task
+    static constexpr int NG = kBlock / G;     // lane groups of a block = most tasks of a long chain
+    static_assert(D <= G, "the entry window is two fetches of G entries");
+};
+
+// Entries [begin, end) of one chain applied one after the other to `own` (the row of `chain`, in the registers of a lane
+// group).  Every lane group of the wavefront comes here together, each with its own chain and range (an empty range: a
+// group without work) — the loop runs as long as any group has entries left; a group past its end keeps requesting its own
+// mirror row and trains with weight 0.  Every step issues exactly one row request and consumes the one issued D steps
+// earlier, with no branch around either, so the wait before a step is "all but the D - 1 youngest" and not "all".
+template <int DIM, int G>
+__device__ __forceinline__ void chain_steps(const TrainArgs &a, const HotArgs &h, const uint32_t chain, const uint32_t begin,
+                                            const uint32_t end, const int lane, float (&own)[DIM / G]) {
+    typedef ChainShape<DIM, G> S;
+    constexpr int V = S::V, D = S::D;
+    const bool is_vertex = chain < a.hot_vertex;
+    const float *partner_table = is_vertex ? a.context : a.vertex;
+    const uint32_t partner_hot = is_vertex ? a.hot_context : a.hot_vertex;  // partners below this id are hub rows: read from the mirror
+    const float *partner_mirror = h.from + (is_vertex ? (size_t)a.hot_vertex * DIM : (size_t)0);
+    const float *idle = h.from + (size_t)chain * DIM;
+    // the work list, G entries per fetch, two fetches resident: entries [blk, blk + 2 G)
+    uint32_t blk = begin;
+    uint32_t e_cur = blk + lane < end ? h.entries[blk + lane] : 0;
+    uint32_t e_nxt = blk + G + lane < end ? h.entries[blk + G + lane] : 0;
+    // entry p of the list (through the window): the row it names (past the end: the group's own mirror row) and its label
+    auto row_of = [&](const uint32_t p, uint32_t &label) __attribute__((always_inline)) -> const float * {
+        const uint32_t o = p - blk;
+        const uint32_t e = (uint32_t)__shfl((int)(o < (uint32_t)G ? e_cur : e_nxt), (int)(o & (G - 1)), G);
+        label = e >> 31;
+        const uint32_t id = e & 0x7fffffffu;
+        const float *row = id < partner_hot ? partner_mirror + (size_t)id * DIM : partner_table + (size_t)id * DIM;
+        return p < end ? row : idle;
+    };
+    float ring[D][V];
+    uint32_t labels = 0;  // bit i: the label of the entry whose row sits in ring[i]
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        uint32_t label;
+        load_row_at<DIM, G>(row_of(begin + i, label), lane, ring[i]);
+        labels |= label << i;
+    }
+    for (uint32_t base = begin; __builtin_amdgcn_ballot_w64(base < end) != 0; base += D) {
+        const uint32_t f = blk + 2 * G + lane;
+        const uint32_t e_fut = h.entries[f < end ? f : (begin < end ? end - 1 : 0)];  // the window after e_nxt, asked for ahead of its use
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            const uint32_t p = base + i;
+            const bool positive = (labels >> i & 1u) != 0;
+            const float(&c)[V] = ring[i];
+            // forward / backward of one target: model/graph.h:40-58, gpu/graph.cuh:77-87 — on the own row only
+            float partial = 0;
+#pragma unroll
+            for (int x = 0; x < V; x++) partial += own[x] * c[x];
+            const float prob = sigmoidf(group_sum<G>(partial));
+            const float gradient = positive ? prob - 1 : prob;
+            const float weight = p < end ? (positive ? 1.0f : a.neg_weight) : 0.0f;
+#pragma unroll
+            for (int x = 0; x < V; x++) own[x] -= h.lr * weight * (gradient * c[x] + a.wd * own[x]);  // optimizer.h:161-164
+            // the slot is free: the row of entry p + D takes it (D - 1 requests stay in flight while a step computes)
+            uint32_t label;
+            load_row_at<DIM, G>(row_of(p + D, label), lane, ring[i]);
+            labels = (labels & ~(1u << i)) | label << i;
+        }
+        if (base + D >= blk + G) {  // the next steps look beyond e_nxt: move the window
+            blk += G;
+            e_cur = e_nxt;
+            e_nxt = e_fut;
+        }
+    }
+}
+
+// Sum over the lanes of a group of a small count (exact in fp32).
+template <int G>
+__device__ __forceinline__ float group_count(const uint32_t x) {
+    return group_sum<G>((float)x);
+}
+
+// Chains of 1 .. cap entries (cap <= kShortEntries = 7), one lane group each: block b trains records [b NG, (b + 1) NG) of the
+// unit's short list.  A record carries the chain's entries, so a chain costs two dependent round trips: its record (asked for
+// together with the list's length), then its own row and every partner row at once; then at most seven steps.
+constexpr int kShortEntries = 7;
+
+// The n <= kShortEntries entries entry_of(0 .. n - 1) of one chain applied one after the other to `own`: every partner row is
+// requested before the first step (where the registers hold them: dims up to 128), so the chain waits for memory once.
+template <int DIM, int G, class EntryOf>
+__device__ __forceinline__ void short_steps(const TrainArgs &a, const HotArgs &h, const uint32_t chain, const uint32_t n, const int lane,
+                                            float (&own)[DIM / G], EntryOf entry_of) {
+    constexpr int V = DIM / G, N = kShortEntries;
+    constexpr int D = V <= 8 ? N : (V <= 12 ? 3 : 2);  // partner rows in flight: all of them where the registers hold them
+    const bool is_vertex = chain < a.hot_vertex;
+    const float *partner_table = is_vertex ? a.context : a.vertex;
+    const uint32_t partner_hot = is_vertex ? a.hot_context : a.hot_vertex;
+    const float *partner_mirror = h.from + (is_vertex ? (size_t)a.hot_vertex * DIM : (size_t)0);
+    const float *idle = h.from + (size_t)chain * DIM;
+    float ring[D][V];
+    uint32_t labels = 0;
+    auto request = [&](const int i) __attribute__((always_inline)) {  // the row of entry i into its slot of the ring
+        const uint32_t e = entry_of(i);
+        const uint32_t id = e & 0x7fffffffu;
+        const float *row = id < partner_hot ? partner_mirror + (size_t)id * DIM : partner_table + (size_t)id * DIM;
+        load_row_at<DIM, G>((uint32_t)i < n ? row : idle, lane, ring[i % D]);
+        labels |= (e >> 31) << i;
+    };
+#pragma unroll
+    for (int i = 0; i < D; i++) request(i);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const bool positive = (labels >> i & 1u) != 0;
+        const float(&c)[V] = ring[i % D];
+        float partial = 0;
+#pragma unroll
+        for (int x = 0; x < V; x++) partial += own[x] * c[x];
+        const float prob = sigmoidf(group_sum<G>(partial));
+        const float gradient = positive ? prob - 1 : prob;
+        const float weight = (uint32_t)i < n ? (positive ? 1.0f : a.neg_weight) : 0.0f;
+#pragma unroll
+        for (int x = 0; x < V; x++) own[x] -= h.lr * weight * (gradient * c[x] + a.wd * own[x]);  // optimizer.h:161-164
+        if (i + D < N) request(i + D);
+    }
+}
+
+template <int DIM, int G>
+__device__ __forceinline__ void train_short_chains(const TrainArgs &a, const HotArgs &h, const uint32_t block) {
+    typedef ChainShape<DIM, G> S;
+    constexpr int LW = G < 16 ? G : 16;  // lanes that hold the record's sixteen words
+    const int lane = threadIdx.x % G, group = threadIdx.x / G;
+    const uint32_t at = block * S::NG + group;
+    // the record's sixteen words across the lanes of the group; the list's length arrives with them
+    const uint32_t *record = h.short_list + 16 + 16 * (size_t)(at < h.chains ? at : h.chains - 1);
+    const uint32_t word0 = record[lane % LW], word1 = LW < 16 ? record[8 + lane % LW] : 0;
+    const uint32_t count = h.short_list[0] < h.chains ? h.short_list[0] : h.chains;
+    if (block * S::NG >= count) return;  // the whole block at once
+    GVK_STAMP_VALUE(h, 0, 2);
+    GVK_STAMP(h, 2);  // the record is here
+    auto word = [&](const int i) __attribute__((always_inline)) -> uint32_t {
+        return (uint32_t)(i < LW ? __shfl((int)word0, i, G) : __shfl((int)word1, i - LW, G));
+    };
+    const bool mine = at < count;
+    const uint32_t chain = mine ? word(0) : 0, n = mine ? word(1) : 0;
+    float own[S::V];
+    load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, own);
+    short_steps<DIM, G>(a, h, chain, n, lane, own, [&](const int i) __attribute__((always_inline)) { return word(4 + i); });
+    GVK_STAMP(h, 5);  // steps done
+    if (mine) store_row_at<DIM, G>(h.to + (size_t)chain * DIM, lane, own);
+}
+
+// Hub rows the unit has no entry for pass from mirror to mirror unchanged — those that need it: the mirror `to` was last
+// written R units ago (R mirrors in rotation), so a row is behind there only if a chain stored it since, i.e. if it had
+// entries in one of the R - 1 units before this one (all mirrors start a call equal).  Block b looks at chains [64 b, 64 b +
+// 64), each lane group at four of them (all four rows requested before the first is stored).
+template <int DIM, int G>
+__device__ __forceinline__ void copy_idle_rows(const HotArgs &h, const uint32_t block) {
+    typedef ChainShape<DIM, G> S;
+    constexpr int R = 4;
+    const int lane = threadIdx.x % G, group = threadIdx.x / G;
+    float row[R][S::V];
+    bool behind[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const uint32_t chain = (block * R + i) * S::NG + group;
+        behind[i] = false;
+        if (chain < h.chains && h.chain_start[chain] == h.chain_start[chain + 1]) {
+#pragma unroll
+            for (int v = 0; v < 2; v++)
+                if (h.before_start[v]) behind[i] = behind[i] || h.before_start[v][chain] != h.before_start[v][chain + 1];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const uint32_t chain = (block * R + i) * S::NG + group;
+        if (behind[i]) load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, row[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        const uint32_t chain = (block * R + i) * S::NG + group;
+        if (behind[i]) store_row_at<DIM, G>(h.to + (size_t)chain * DIM, lane, row[i]);
+    }
+}
+
+// Long chains, one workgroup each (block b takes long chains b, b + long_blocks, ...): T <= NG tasks of consecutive
+// entries (whole samples for a head chain) trained side by side by the block's lane groups and composed.  An update is
+// own <- d own - lr w g c with d = 1 - lr w wd: weight decay is a factor that depends on the entry's label only, so the
+// decay of the entries BEFORE a task (before_), of the task itself and of the entries AFTER it (after_) are known in closed
+// form from label counts (every task counts its own positives; the counts meet in LDS).  A task starts from the row as the
+// earlier tasks' decay leaves it, and what it adds to the row is its end state carried through the later tasks' decay:
+//     row <- total row + sum over tasks (after_t end_t - total row),         total = before_ x task x after_
+// which composes the tasks' decay exactly (a hub row of the benchmark graph decays to 0.48 of itself within ONE batch —
+// summing plain deltas of 8 tasks would take it to 0.30) and leaves only the gradients' dependence on the other tasks'
+// steps to first order.  The sum runs in task order in one lane group: the same bits on every run.
+template <int DIM, int G>
+__device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotArgs &h, const uint32_t block) {
+    typedef ChainShape<DIM, G> S;
+    constexpr int V = S::V, NG = S::NG;
+    __shared__ float ends[NG][DIM];
+    __shared__ float positives[NG];
+    const int lane = threadIdx.x % G, group = threadIdx.x / G;
+    // the block's first record is asked for together with the list's length (one round trip)
+    u32x4 record = *reinterpret_cast<const u32x4 *>(h.long_list + 4 + 4 * (size_t)(block < h.long_capacity ? block : 0));
+    const uint32_t count = h.long_list[0] < h.long_capacity ? h.long_list[0] : h.long_capacity;
+    for (uint32_t j = block; j < count; j += (uint32_t)h.long_blocks) {
+        if (j != block) record = *reinterpret_cast<const u32x4 *>(h.long_list + 4 + 4 * (size_t)j);
+        const uint32_t chain = record.x, first = record.y, n = record.z, last = first + n;
+        if (j == block) {
+            GVK_STAMP_VALUE(h, 0, 1);
+            GVK_STAMP(h, 2);  // the record is here
+            GVK_STAMP_VALUE(h, 7, n);
+        }
+        // NG tasks at most: a longer chain gets longer tasks
+        uint32_t per = h.cap;
+        if ((uint64_t)per * NG < n) per = (n + NG - 1) / NG;
+        const uint32_t tasks = (n + per - 1) / per;
+        const bool mine = (uint32_t)group < tasks;
+        const uint32_t begin = mine ? first + (uint32_t)group * per : last;
+        const uint32_t end = last - begin > per ? begin + per : last;
+        float own[V];
+        load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, own);
+        const uint32_t mine_entry = begin + lane < end ? h.entries[begin + lane] : 0;  // the task's first G entries, one per lane
+        uint32_t inside = mine_entry >> 31;
+        for (uint32_t p = begin + G + lane; p < end; p += G) inside += h.entries[p] >> 31;
+        const float pi = group_count<G>(inside);
+        if (lane == 0) positives[group] = pi;
+        __syncthreads();
+        if (j == block) GVK_STAMP(h, 3);  // own row and the task's entries are here
+        float pb = 0, pa = 0;
+        for (uint32_t t = 0; t < tasks; t++) {
+            const float x = positives[t];
+            pb += t < (uint32_t)group ? x : 0.0f;
+            pa += t > (uint32_t)group ? x : 0.0f;
+        }
+        const float before_ = exp2f(pb * h.log2_decay_positive + ((float)(begin - first) - pb) * h.log2_decay_negative);
+        const float after_ = exp2f(pa * h.log2_decay_positive + ((float)(last - end) - pa) * h.log2_decay_negative);
+        const float total = exp2f((pb + pi + pa) * h.log2_decay_positive + ((float)n - (pb + pi + pa)) * h.log2_decay_negative);
+#pragma unroll
+        for (int x = 0; x < V; x++) own[x] *= before_;
+        if (per <= (uint32_t)kShortEntries)  // the usual task: all its partner rows at once
+            short_steps<DIM, G>(a, h, chain, end - begin, lane, own,
+                                [&](const int i) __attribute__((always_inline)) { return (uint32_t)__shfl((int)mine_entry, i, G); });
+        else  // a chain of more than NG tasks of seven entries (the largest hubs): longer tasks, rows D at a time
+            chain_steps<DIM, G>(a, h, chain, begin, end, lane, own);
+        if (mine) {
+#pragma unroll
+            for (int x = 0; x < V; x++) own[x] *= after_;
+            store_row_at<DIM, G>(&ends[group][0], lane, own);
+        }
+        if (j == block) GVK_STAMP(h, 4);  // this task's steps are done
+        __syncthreads();
+        if (j == block) GVK_STAMP(h, 5);  // every task's steps are done
+        if (group == 0) {
+            float sum[V], row0[V];
+            load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, row0);
+#pragma unroll
+            for (int x = 0; x < V; x++) sum[x] = (1.0f - (float)tasks) * total * row0[x];
+            for (uint32_t t = 0; t < tasks; t++) {
+                float part[V];
+                load_row_at<DIM, G>(&ends[t][0], lane, part);
+#pragma unroll
+                for (int x = 0; x < V; x++) sum[x] += part[x];
+            }
+            store_row_at<DIM, G>(h.to + (size_t)chain * DIM, lane, sum);
+        }
+        __syncthreads();
+        if (j == block) GVK_STAMP(h, 6);  // composed and stored
+    }
+}
+
+// HOT: 1 = the pairs read a hub row as the chains of their unit left it, 2 = on the straight line from where those chains
+// found it to where they left it, at the sample's place in the unit (lerp)
+// Built for four wavefronts per SIMD (128 registers; the short chains keep seven partner rows per lane group in flight; three
+// at dims 256 and 512, sixteen floats of a row per lane): the chains and the pairs of a unit of the sizes this kernel trains (a
+// part of a batch) are then resident side by side.
+template <int DIM, int G, int KT, int HOT>
+__global__ void __launch_bounds__(kBlock, DIM / G > 12 ? 3 : 4) train_hot_kernel(const TrainArgs a, const HotArgs h) {
+    // the grid: [long chains | pairs | short chains | idle rows] — the long chains, whose tasks wait for memory three times in
+    // a row, are dispatched first, the bulk (the pairs) next; the short chains and the copies fill in behind
+    const int b = blockIdx.x;
+    GVK_STAMP_VALUE(h, 0, 0);
+    GVK_STAMP(h, 1);  // the workgroup starts
+    const int pairs_first = h.order == 2 ? 0 : (h.order == 1 ? h.long_blocks : h.long_blocks + h.short_blocks + h.copy_blocks);
+    const int long_first = h.order == 2 ? h.pair_blocks : 0;
+    const int short_first = h.order == 0 ? h.long_blocks : h.long_blocks + h.pair_blocks;
+    if (b >= long_first && b < long_first + h.long_blocks) {
+        train_long_chains<DIM, G>(a, h, b - long_first);
+    } else if (b >= pairs_first && b < pairs_first + h.pair_blocks) {
+        GVK_STAMP_VALUE(h, 0, 3);
+        train_pair<DIM, G, GVK_SGD, KT, 1, HOT>(a, (b - pairs_first) * kBlock + threadIdx.x);
+        GVK_STAMP(h, 5);  // thread 0's sample is trained (its stores are on their way)
+    } else if (b >= short_first && b < short_first + h.short_blocks) {
+        train_short_chains<DIM, G>(a, h, b - short_first);
+    } else {
+        copy_idle_rows<DIM, G>(h, b - short_first - h.short_blocks);
+    }
+}
+
+// Hub rows between the tables and a mirror: to_mirror != 0 copies the first hot_vertex rows of the head table and the first
+// hot_context rows of the tail table into the mirror (a call's first step), else the mirror into the tables (its last).
+__global__ void __launch_bounds__(kBlock) hub_rows_kernel(float *vertex, float *context, float *mirror, const uint32_t hot_vertex,
+                                                          const uint32_t hot_context, const int dim, const int to_mirror) {
+    const size_t quads = (size_t)dim / 4, head_quads = (size_t)hot_vertex * quads, all = head_quads + (size_t)hot_context * quads;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= all) return;
+    f32x4 *in_table = i < head_quads ? reinterpret_cast<f32x4 *>(vertex) + i : reinterpret_cast<f32x4 *>(context) + (i - head_quads);
+    f32x4 *in_mirror = reinterpret_cast<f32x4 *>(mirror) + i;
+    if (to_mirror) *in_mirror = *in_table;
+    else *in_table = *in_mirror;
+}
+
+// The chains' work lists, one workgroup per unit: counting sort of the unit's updates to hub rows by row.  Chain c <
+// hot_vertex is head row c: per sample with that head, the sample's k negatives (label 0) then its tail (label 1), in
+// that order.  Chain hot_vertex + r is context row r: the head of every sample r is the tail (label 1) or a negative
+// (label 0) of.  Negatives are drawn exactly as the training kernel draws them (same counters, same tables).  The order
+// of the samples inside a chain is the order the atomics retire in — any order is a valid sequential order.  Chains of
+// more than cap entries are listed in long_list (train_long_chains: records {chain, first entry, entries, -} from word 4 on),
+// those of 1 .. cap entries in short_list (train_short_chains: records of 16 words from word 16 on — {chain, entries, first
+// entry, -} and, from word 4, the entries themselves).
+constexpr int kListThreads = 1024;
+
+__global__ void __launch_bounds__(kListThreads) hot_list_kernel(TrainArgs a, const uint32_t first_batch_id, const uint32_t stride,
+                                                                uint32_t *chain_start_all, uint32_t *entries_all, uint32_t *long_all,
+                                                                uint32_t *short_all, const uint32_t entry_capacity, const uint32_t long_capacity,
+                                                                const uint32_t cap, const int parts) {
+    extern __shared__ uint32_t bins[];  // [chains]
+    __shared__ uint32_t wave_total[kListThreads / 64];
+    __shared__ uint32_t long_count, short_count;
+    const uint32_t chains = a.hot_vertex + a.hot_context;
+    // list blockIdx.x = part (blockIdx.x % parts) of batch (blockIdx.x / parts): samples [lo, hi) of the batch
+    const int B = a.batch_size, k = a.k;
+    const int batch = blockIdx.x / parts, lo = (int)(blockIdx.x % parts) * (B / parts), hi = lo + B / parts;
+    const u32x2 *records = reinterpret_cast<const u32x2 *>(a.pairs) + (size_t)batch * B;
+    uint32_t *chain_start = chain_start_all + (size_t)blockIdx.x * (chains + 1);
+    uint32_t *entries = entries_all + (size_t)blockIdx.x * entry_capacity;
+    uint32_t *long_list = long_all + (size_t)blockIdx.x * 4 * (1 + (size_t)long_capacity);
+    uint32_t *short_list = short_all + (size_t)blockIdx.x * 16 * (1 + (size_t)chains);
+    a.batch_id = first_batch_id + (uint32_t)batch * stride;
+
+    for (uint32_t i = threadIdx.x; i < chains; i += kListThreads) bins[i] = 0;
+    if (threadIdx.x == 0) long_count = 0, short_count = 0;
+    __syncthreads();
+    // A: how many entries every chain gets
+    for (int s = lo + threadIdx.x; s < hi; s += kListThreads) {
+        const u32x2 pr = records[s];
+        if (pr.y < a.hot_vertex) atomicAdd(&bins[pr.y], (uint32_t)(k + 1));
+        if (pr.x < a.hot_context) atomicAdd(&bins[a.hot_vertex + pr.x], 1u);
+        for (int j = 0; j < k; j++) {
+            const Draw d = negative_slot(a, (uint32_t)s, (uint32_t)j);
+            const uint32_t n = resolve(a, d, load_entry(a, d));
+            if (n < a.hot_context) atomicAdd(&bins[a.hot_vertex + n], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan over the chains: thread t owns the bins [t * per, (t + 1) * per)
+    {
+        const uint32_t per = (chains + kListThreads - 1) / kListThreads;
+        const uint32_t lo = threadIdx.x * per < chains ? threadIdx.x * per : chains;
+        const uint32_t hi = lo + per < chains ? lo + per : chains;
+        uint32_t sum = 0;
+        for (uint32_t i = lo; i < hi; i++) sum += bins[i];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        uint32_t inclusive = sum;
+        for (int step = 1; step < 64; step <<= 1) {
+            const uint32_t up = __shfl_up(inclusive, step);
+            if (lane >= step) inclusive += up;
+        }
+        if (lane == 63) wave_total[wave] = inclusive;
+        __syncthreads();
+        uint32_t running = inclusive - sum;
+        for (int w = 0; w < wave; w++) running += wave_total[w];
+        for (uint32_t i = lo; i < hi; i++) {
+            const uint32_t count = bins[i];
+            chain_start[i] = running;
+            bins[i] = running;  // the chain's cursor
+            if (count > cap) {
+                const uint32_t slot = atomicAdd(&long_count, 1u);
+                if (slot < long_capacity) *reinterpret_cast<u32x4 *>(long_list + 4 + 4 * (size_t)slot) = u32x4{i, running, count, 0u};
+            } else if (count > 0) {
+                const uint32_t slot = atomicAdd(&short_count, 1u);
+                *reinterpret_cast<u32x4 *>(short_list + 16 + 16 * (size_t)slot) = u32x4{i, count, running, 0u};
+            }
+            running += count;
+        }
+        if (threadIdx.x == kListThreads - 1) chain_start[chains] = running;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) long_list[0] = long_count, short_list[0] = short_count;
+    // B: scatter
+    for (int s = lo + threadIdx.x; s < hi; s += kListThreads) {
+        const u32x2 pr = records[s];
+        const bool hot_head = pr.y < a.hot_vertex;
+        uint32_t at = hot_head ? atomicAdd(&bins[pr.y], (uint32_t)(k + 1)) : 0;
+        for (int j = 0; j < k; j++) {
+            const Draw d = negative_slot(a, (uint32_t)s, (uint32_t)j);
+            const uint32_t n = resolve(a, d, load_entry(a, d));
+            if (hot_head) entries[at + j] = n;
+            if (n < a.hot_context) entries[atomicAdd(&bins[a.hot_vertex + n], 1u)] = pr.y;
+        }
+        if (hot_head) entries[at + k] = pr.x | 0x80000000u;
+        if (pr.x < a.hot_context) entries[atomicAdd(&bins[a.hot_vertex + pr.x], 1u)] = pr.y | 0x80000000u;
+    }
+    __syncthreads();
+    // C: the short chains' entries into their records (written by this workgroup above: its own stores are visible to it
+    // after the barrier)
+    __threadfence_block();
+    for (uint32_t r = threadIdx.x / 8; r < short_count; r += kListThreads / 8) {
+        uint32_t *record = short_list + 16 + 16 * (size_t)r;
+        const uint32_t n = record[1], first = record[2], i = threadIdx.x % 8;
+        if (i < n) record[4 + i] = entries[first + i];
+    }
+}
+
+// ---- hub rows: work lists + launch (train_hot_kernel) -----------------------------------------------------------------
+
+struct HotLayout {
+    size_t chain_start = 0, entries = 0, long_list = 0, short_list = 0, mirrors = 0, mirror_bytes = 0, bytes = 0;  // offsets into the workspace
+    uint32_t chains = 0, entry_capacity = 0, long_capacity = 0, cap = 0;
+};
+
+constexpr uint32_t kMaxChains = 32768;  // one LDS counter per chain in hot_list_kernel (128 KB of the CU's 160 KB)
+constexpr int kLongBlocks = 256;        // workgroups that walk the long chains of a unit (one per CU)
+
+// entries one chain task trains in sequence: at most what a short record holds (train_short_chains)
+constexpr uint32_t kDefaultChainCap = 7, kMaxChainCap = 7;
+
+uint32_t chain_cap_for(int chain_cap) {
+    const uint32_t want = chain_cap > 0 ? (uint32_t)chain_cap : (g_chain_cap > 0 ? (uint32_t)g_chain_cap : kDefaultChainCap);
+    return std::min(want, kMaxChainCap);
+}
+
+// One work list per part of a batch (parts divides batch_size: gvk_train_launches): num_batch * parts lists; behind them
+// the three mirrors of the hub rows (train_hot_kernel).
+HotLayout hot_layout(int dim, int batch_size, int k, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts, int chain_cap) {
+    HotLayout l;
+    l.chains = hot_vertex + hot_context;
+    l.cap = chain_cap_for(chain_cap);
+    num_batch *= parts;
+    batch_size /= parts;
+    // a sample adds at most k + 1 entries to its head's chain and one to the chain of each of its k + 1 targets
+    l.entry_capacity = (uint32_t)(2 * (size_t)(k + 1) * (size_t)batch_size);
+    l.long_capacity = std::min(l.chains, l.entry_capacity / (l.cap + 1) + 1);  // a long chain holds more than cap entries
+    auto align = [](size_t x) { return (x + 255) / 256 * 256; };
+    l.chain_start = 0;
+    l.entries = align((size_t)num_batch * (l.chains + 1) * 4);
+    l.long_list = l.entries + align((size_t)num_batch * l.entry_capacity * 4);
+    l.short_list = l.long_list + align((size_t)num_batch * (1 + (size_t)l.long_capacity) * 16);
+    l.mirrors = l.short_list + align((size_t)num_batch * (1 + (size_t)l.chains) * 64);
+    l.mirror_bytes = align((size_t)l.chains * dim * 4);
+    l.bytes = l.mirrors + 3 * l.mirror_bytes;
+    return l;
+}
+
+int validate_hot(const char *what, int dim, int batch_size, int k, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts) {
+    if (!default_lanes(dim)) return gvk_fail(GVK_EDIM, "%s: dim must be one of 32, 64, 96, 128, 256, 512", what);
+    if (batch_size <= 0 || k < 0 || num_batch < 0) return gvk_fail(GVK_EINVAL, "%s: bad sizes", what);
+    if (parts < 1 || batch_size % parts) return gvk_fail(GVK_EINVAL, "%s: parts (%d) must divide the batch size", what, parts);
+    if ((uint64_t)hot_vertex + hot_context == 0) return gvk_fail(GVK_EINVAL, "%s: no hub rows given", what);
+    if ((uint64_t)hot_vertex + hot_context > kMaxChains)
+        return gvk_fail(GVK_EINVAL, "%s: at most %u hub rows in all (%u + %u given)", what, kMaxChains, hot_vertex, hot_context);
+    if (2 * (uint64_t)(k + 1) * (uint64_t)batch_size > 0x7fffffffull) return gvk_fail(GVK_EINVAL, "%s: batch too large", what);
+    return GVK_OK;
+}
+
+void fill_negative(TrainArgs &a, const gvk_negative_source *neg) {
+    a.negatives = nullptr; a.table = neg->table; a.seed = neg->seed; a.count = neg->count;
+    if (neg->classes) a.classes = neg->classes, a.count = neg->class_count;
+}
+
+typedef void (*HotKernel)(const TrainArgs, const HotArgs);
+
+HotKernel pick_hot(int dim, int k, int lerp) {
+#define GVK_HOT(D, GG)                                                                                              \
+    case D:                                                                                                         \
+        return k == 1 ? (lerp ? train_hot_kernel<D, GG, 1, 2> : train_hot_kernel<D, GG, 1, 1>)                      \
+                      : (lerp ? train_hot_kernel<D, GG, 0, 2> : train_hot_kernel<D, GG, 0, 1>);
+    switch (dim) {
+        GVK_HOT(32, 8) GVK_HOT(64, 16) GVK_HOT(96, 8) GVK_HOT(128, 16) GVK_HOT(256, 16) GVK_HOT(512, 32)
+    }
+#undef GVK_HOT
+    return nullptr;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gvk_hot_plan(int dim, int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts,
+                 int chain_cap, size_t *bytes) {
+    if (!bytes) return fail(GVK_EINVAL, "gvk_hot_plan: bytes is null");
+    int rc = validate_hot("gvk_hot_plan", dim, batch_size, num_negative, hot_vertex, hot_context, num_batch, parts);
+    if (rc != GVK_OK) return rc;
+    if (chain_cap < 0) return fail(GVK_EINVAL, "gvk_hot_plan: negative chain_cap");
+    *bytes = hot_layout(dim, batch_size, num_negative, hot_vertex, hot_context, num_batch, parts, chain_cap).bytes;
+    return GVK_OK;
+}
+
+int gvk_hot_build(void *stream, int dim, void *workspace, size_t workspace_bytes, const uint32_t *pool, int batch_size, int num_batch,
+                  int num_negative, const gvk_negative_source *negative, uint32_t first_batch_id, uint32_t batch_id_stride,
+                  uint32_t hot_vertex, uint32_t hot_context, int parts, int chain_cap) {
+    int rc = validate_hot("gvk_hot_build", dim, batch_size, num_negative, hot_vertex, hot_context, num_batch, parts);
+    if (rc != GVK_OK) return rc;
+    if (num_batch == 0) return GVK_OK;
+    if (!workspace || !pool || !negative) return fail(GVK_EINVAL, "gvk_hot_build: null workspace / pool / negative source");
+    if (negative->negatives) return fail(GVK_EINVAL, "gvk_hot_build: the chains need negatives drawn on the device");
+    if (num_negative > 0 && (!negative->table || negative->count == 0) && (!negative->classes || negative->class_count == 0))
+        return fail(GVK_EINVAL, "gvk_hot_build: no alias table given");
+    if (chain_cap < 0) return fail(GVK_EINVAL, "gvk_hot_build: negative chain_cap");
+    const HotLayout l = hot_layout(dim, batch_size, num_negative, hot_vertex, hot_context, num_batch, parts, chain_cap);
+    if (workspace_bytes < l.bytes) return gvk_fail(GVK_EINVAL, "gvk_hot_build: workspace holds %zu bytes, %zu needed", workspace_bytes, l.bytes);
+    TrainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pairs = pool;
+    fill_negative(a, negative);
+    a.batch_size = batch_size; a.k = num_negative;
+    a.hot_vertex = hot_vertex; a.hot_context = hot_context;
+    char *base = static_cast<char *>(workspace);
+    const size_t lds = (size_t)l.chains * 4;
+    if (lds > 48 * 1024) {  // beyond the default limit of dynamic LDS the kernel needs the attribute (per device)
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(hot_list_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kMaxChains * 4));
+        if (e != hipSuccess) return gvk_fail(GVK_EHIP, "gvk_hot_build: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(hot_list_kernel, dim3((unsigned)(num_batch * parts)), dim3(kListThreads), lds, (hipStream_t)stream, a,
+                       first_batch_id, batch_id_stride, reinterpret_cast<uint32_t *>(base + l.chain_start),
+                       reinterpret_cast<uint32_t *>(base + l.entries), reinterpret_cast<uint32_t *>(base + l.long_list),
+                       reinterpret_cast<uint32_t *>(base + l.short_list), l.entry_capacity, l.long_capacity, l.cap, parts);
+    return check_launch("gvk_hot_build");
+}
+
+int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer, int linear_schedule, const gvk_tables *tables,
+                          const uint32_t *pairs, const gvk_negative_source *negative, uint32_t first_batch_id,
+                          uint32_t batch_id_stride, uint32_t total_batches, int num_batches, float *loss, int batch_size,
+                          int num_negative, float negative_weight, void *workspace, size_t workspace_bytes,
+                          uint32_t hot_vertex, uint32_t hot_context, int workspace_batches, int parts, int chain_cap,
+                          int form) {
+    if (num_batches < 0 || num_batches > workspace_batches) return fail(GVK_EINVAL, "gvk_train_episode_hot: more batches than the work lists cover");
+    int rc = validate_train(dim, optimizer, tables, pairs, negative, loss, batch_size, num_negative);
+    if (rc <= 0) return rc;
+    rc = validate_hot("gvk_train_episode_hot", dim, batch_size, num_negative, hot_vertex, hot_context, workspace_batches, parts);
+    if (rc != GVK_OK) return rc;
+    if (optimizer->type != GVK_SGD) return fail(GVK_EINVAL, "gvk_train_episode_hot: chains exist for SGD only");
+    if (negative->negatives) return fail(GVK_EINVAL, "gvk_train_episode_hot draws negatives on device");
+    if (hot_vertex > tables->n_vertex || hot_context > tables->n_context)
+        return fail(GVK_EINVAL, "gvk_train_episode_hot: more hub rows than table rows");
+    if (chain_cap < 0) return fail(GVK_EINVAL, "gvk_train_episode_hot: negative chain_cap");
+    if (form & ~(GVK_HOT_SERIALIZED | GVK_HOT_LERP)) return fail(GVK_EINVAL, "gvk_train_episode_hot: unknown form bits");
+    const HotLayout l = hot_layout(dim, batch_size, num_negative, hot_vertex, hot_context, workspace_batches, parts, chain_cap);
+    if (!workspace || workspace_bytes < l.bytes) return fail(GVK_EINVAL, "gvk_train_episode_hot: workspace too small (gvk_hot_plan)");
+    const bool lerp = (form & GVK_HOT_LERP) != 0, serialized = (form & GVK_HOT_SERIALIZED) != 0 || g_hot_serialized != 0;
+    const HotKernel kernel = pick_hot(dim, num_negative, lerp);
+    if (!kernel) return fail(GVK_EDIM, "gvk_train_episode_hot: no kernel for this dim");
+    const int lanes = default_lanes(dim);
+    char *base = static_cast<char *>(workspace);
+    TrainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.vertex = tables->vertex; a.context = tables->context;
+    a.loss = loss;
+    fill_negative(a, negative);
+    a.batch_size = batch_size; a.k = num_negative; a.run_cap = 1;
+    a.wd = optimizer->weight_decay; a.neg_weight = negative_weight;
+    a.hot_vertex = hot_vertex; a.hot_context = hot_context;
+    HotArgs h;
+    memset(&h, 0, sizeof(h));
+    h.chains = l.chains; h.long_capacity = l.long_capacity; h.cap = l.cap;
+    const int groups = kBlock / lanes;
+    const int short_blocks = (int)((l.chains + groups - 1) / groups);
+    const int long_blocks = (int)std::min<uint32_t>(l.long_capacity, (uint32_t)kLongBlocks);
+    const int copy_blocks = (int)((l.chains + 4 * groups - 1) / (4 * groups));
+    // the unit of work is a PART of a batch (parts = 1: the batch): unit u = part u % parts of batch u / parts
+    const int part_size = batch_size / parts, units = num_batches * parts;
+    const unsigned pair_blocks = (unsigned)(((int64_t)part_size * lanes + kBlock - 1) / kBlock);
+    if (num_batches == 0) return GVK_OK;
+    // when every row of both tables is a hub row the pairs have nothing to store: they run for the last batch only, whose
+    // per-sample loss a caller may read
+    const bool chains_only = hot_vertex == tables->n_vertex && hot_context == tables->n_context;
+    // mirrors in rotation: the chains of unit u read M[(u - 1) % R] and store to M[u % R], the pairs of unit u read M[u % R] — and,
+    // lerp, M[(u - 1) % R], which the chains of unit u + 1 (same launch) must then not store to: R = 3; else R = 2
+    const int R = lerp ? 3 : 2;
+    auto mirror = [&](int u) { return reinterpret_cast<float *>(base + l.mirrors + (size_t)((u + R) % R) * l.mirror_bytes); };
+    auto lr_of = [&](int i) {
+        const uint32_t id = first_batch_id + (uint32_t)i * batch_id_stride;
+        float scale = 1;
+        if (linear_schedule) {  // optimizer.h:77-79
+            scale = 1 - float(int(id)) / int(total_batches);
+            if (scale < 1e-4f) scale = 1e-4f;
+        }
+        return optimizer->lr * scale;
+    };
+    auto chains_of = [&](int u) {  // the chain blocks of a launch work on unit u: from mirror u - 1 to mirror u
+        h.chain_start = reinterpret_cast<const uint32_t *>(base + l.chain_start) + (size_t)u * (l.chains + 1);
+        h.entries = reinterpret_cast<const uint32_t *>(base + l.entries) + (size_t)u * l.entry_capacity;
+        h.long_list = reinterpret_cast<const uint32_t *>(base + l.long_list) + (size_t)u * 4 * (1 + (size_t)l.long_capacity);
+        h.short_list = reinterpret_cast<const uint32_t *>(base + l.short_list) + (size_t)u * 16 * (1 + (size_t)l.chains);
+        h.from = mirror(u - 1), h.to = mirror(u);
+        for (int v = 0; v < 2; v++)  // the units since M[u % R] was last stored to: u - 1 .. u - R + 1
+            h.before_start[v] = v < R - 1 && u - 1 - v >= 0 ? h.chain_start - (size_t)(v + 1) * (l.chains + 1) : nullptr;
+        h.lr = lr_of(u / parts);
+        h.log2_decay_positive = (float)std::log2(1.0 - (double)h.lr * a.wd);
+        h.log2_decay_negative = (float)std::log2(1.0 - (double)h.lr * a.neg_weight * a.wd);
+    };
+    auto pairs_of = [&](int u) {  // the pair blocks of a launch work on unit u; false: nothing to do
+        const int i = u / parts;
+        a.lr = lr_of(i);
+        a.batch_id = first_batch_id + (uint32_t)i * batch_id_stride;
+        a.pairs = pairs + (size_t)i * batch_size * 2;
+        a.first_sample = (u % parts) * part_size;
+        a.batch_size = a.first_sample + part_size;
+        a.hub_now = mirror(u), a.hub_before = mirror(u - 1);
+        a.hub_step = 1.0f / (float)part_size;
+        return !chains_only || i == num_batches - 1;
+    };
+#if defined(GVK_TIMESTAMPS)
+    static unsigned long long *stamps = nullptr;
+    constexpr size_t kStampBlocks = 8192;
+    if (!stamps && hipMalloc(&stamps, kStampBlocks * 64) != hipSuccess) stamps = nullptr;
+    h.stamps = stamps;
+#endif
+    auto launch = [&](bool with_chains, bool with_pairs) {
+        h.long_blocks = with_chains ? long_blocks : 0;
+        h.short_blocks = with_chains ? short_blocks : 0;
+        h.copy_blocks = with_chains ? copy_blocks : 0;
+        h.pair_blocks = with_pairs ? (int)pair_blocks : 0;
+        h.order = g_hot_order;
+        const unsigned grid = (unsigned)(h.long_blocks + h.short_blocks + h.copy_blocks + h.pair_blocks);
+#if defined(GVK_TIMESTAMPS)
+        h.stamps = grid > kStampBlocks ? nullptr : stamps;
+        if (h.stamps && hipMemsetAsync(stamps, 0, kStampBlocks * 64, (hipStream_t)stream) != hipSuccess) h.stamps = nullptr;
+#endif
+        if (grid) hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, h);
+#if defined(GVK_TIMESTAMPS)
+        // GVK_STAMP_FILE=<prefix>: the stamps of the first 64 launches that carry chains and pairs, each run on its own (the stream
+        // is drained after it), to <prefix>.<n>: eight ints {grid, long, pair, short, copy blocks, order, -, -}, then the records
+        static int written = 0;
+        if (h.stamps && getenv("GVK_STAMP_FILE") && with_chains && with_pairs && written < 64) {
+            static std::vector<unsigned long long> host(kStampBlocks * 8);
+            char name[512];
+            snprintf(name, sizeof name, "%s.%d", getenv("GVK_STAMP_FILE"), written++);
+            if (hipStreamSynchronize((hipStream_t)stream) == hipSuccess &&
+                hipMemcpy(host.data(), stamps, kStampBlocks * 64, hipMemcpyDeviceToHost) == hipSuccess)
+                if (FILE *f = fopen(name, "wb")) {
+                    const int header[8] = {(int)grid, h.long_blocks, h.pair_blocks, h.short_blocks, h.copy_blocks, h.order, 0, 0};
+                    fwrite(header, sizeof header, 1, f);
+                    fwrite(host.data(), 64, grid, f);
+                    fclose(f);
+                }
+        }
+#endif
+    };
+    const unsigned mirror_blocks = (unsigned)(((size_t)l.chains * (size_t)(dim / 4) + kBlock - 1) / kBlock);
+    // the hub rows enter the mirrors: every mirror = the tables' rows (a row without entries is only copied on while a mirror
+    // is behind: copy_idle_rows)
+    for (int m = 0; m < R; m++)
+        hipLaunchKernelGGL(hub_rows_kernel, dim3(mirror_blocks), dim3(kBlock), 0, (hipStream_t)stream, a.vertex, a.context, mirror(m),
+                           hot_vertex, hot_context, dim, 1);
+    // A sample's updates to its rows are all computed from the rows as the sample found them (model/graph.h:47-58).  The
+    // chains of a unit therefore run BEFORE its pairs: a chain reads the partner rows before the unit's pairs move them
+    // towards the hub row (a chain that read them afterwards would compound the step it is about to take — every sample of a
+    // hub row, thousands per epoch: the row's norm explodes), and the pairs train against the hub rows the chains left.
+    // Pipelined: launch u trains the pairs of unit u and, in its first blocks, the chains of unit u + 1 — different samples,
+    // different mirrors, so neither waits for the other — which hides the chains (few, sequential) behind the pairs (the bulk).
+    if (serialized) {  // tests: per unit the chains, then the pairs, as two launches — a pure function of the work lists
+        for (int u = 0; u < units; u++) {
+            chains_of(u);
+            const bool with_pairs = pairs_of(u);
+            launch(true, false);
+            launch(false, with_pairs);
+        }
+    } else {
+        chains_of(0);
+        launch(true, false);
+        for (int u = 0; u < units; u++) {
+            const bool with_pairs = pairs_of(u);
+            if (u + 1 < units) chains_of(u + 1);
+            launch(u + 1 < units, with_pairs);
+        }
+    }
+    // ... and leave them: the tables' hub rows = M[last unit]
+    hipLaunchKernelGGL(hub_rows_kernel, dim3(mirror_blocks), dim3(kBlock), 0, (hipStream_t)stream, a.vertex, a.context, mirror(units - 1),
+                       hot_vertex, hot_context, dim, 0);
+    return check_launch("gvk_train_episode_hot");
+}
+
+}  // extern "C"

@@ -191,7 +191,7 @@ static void gvo_chain(int dim, float *own, const float *partner, const uint32_t 
  * tables as the unit found them).  A chain longer than cap entries is trained as tasks of consecutive entries side by side
  * and the tasks are composed (below): tasks of cap entries, or — past max_tasks of them (0 = no limit) — of
  * ceil(n / max_tasks) entries, what one workgroup of the product trains (train_long_chains,
- * graphvite_amd/csrc/gvk_kernels.hip).  gvo_set_long_task(t > 0) (executor-simulator experiments): tasks of t entries, as many
+ * graphvite_amd/csrc/gvk_chains.hip).  gvo_set_long_task(t > 0) (executor-simulator experiments): tasks of t entries, as many
  * as it takes; t = 1 is "every entry of a long chain on its own from the row as the decay of the entries before it leaves it"
  * (measured in round 5: profiles/r5/experiments/r5_entries_side_by_side.txt). */
 static uint32_t gvo_long_task = 0;

@@ -26,7 +26,7 @@ from oracle_lib import link_prediction_auc  # noqa: E402
 extra = dict(kv.split("=", 1) for kv in sys.argv[1:])
 gv.init_logging(logging.ERROR)
 N, E, B = int(extra.get("nodes", 200000)), int(extra.get("edges", 2000000)), int(extra.get("batch", 100000))
-edges = synthetic.power_law_edges(N, E, seed=int(extra.get("graph_seed", 5)))  # nodes=1000000 edges=10000000 graph_seed=1024: the headline shape itself
+edges = synthetic.power_law_edges(N, E, gamma=float(extra.get("gamma", 2.3)), seed=int(extra.get("graph_seed", 5)))  # gamma=2.0: a heavier head (the held-out graph of tests/golden/make_configs_golden.py)  # nodes=1000000 edges=10000000 graph_seed=1024: the headline shape itself
 train, (valid, test) = synthetic.link_prediction_split(edges, (100, 1, 1))
 g = gv.graph.Graph()
 g.load(train)

@@ -23,7 +23,7 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         flags = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
         rows = []
-        for source in ("gvk_kernels.hip", "gvk_group.hip"):
+        for source in ("gvk_pairs.hip", "gvk_chains.hip", "gvk_samplers.hip", "gvk_group.hip"):
             run = subprocess.run(flags + ["-c", os.path.join(CSRC, source), "-o", os.path.join(tmp, source + ".o"),
                                           "-Rpass-analysis=kernel-resource-usage", "--save-temps=obj"], capture_output=True, text=True, cwd=tmp)
             blocks = re.split(r"Function Name: ", run.stderr)[1:]
@@ -42,11 +42,11 @@ def main():
         for row in shown:
             print("%-100s %5d %5d %5d %8d %5d %6d" % row)
         # instruction mix of the shipped kernels from the device assembly
-        asm = [os.path.join(tmp, f) for f in os.listdir(tmp) if f.endswith(".s") and "gfx950" in f and "gvk_kernels" in f]
+        asm = [os.path.join(tmp, f) for f in os.listdir(tmp) if f.endswith(".s") and "gfx950" in f and "gvk_pairs" in f]
         if not asm:
             return
         text = open(asm[0]).read()
-        print("\nInstruction mix (static, per wavefront pass through the kernel body; device assembly of gvk_kernels.hip)")
+        print("\nInstruction mix (static, per wavefront pass through the kernel body; device assembly of gvk_pairs.hip)")
         for want in ("train_kernelILi128ELi16ELi0ELi1ELi1ELi4E", "train_runs_kernelILi128ELi16ELi0ELi1ELi1ELi4E", "probe_rows_kernelILi128ELi16E",
                      "train_kernelILi96ELi8ELi0ELi1ELi1ELi4E", "train_kernelILi64ELi16ELi0ELi1ELi1ELi4E"):
             m = re.search(r"^(_ZN\S*" + want + r"\S*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)

@@ -234,7 +234,7 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     gvo_set_long_task(getenv("GVH_LONG_TASK") ? (uint32_t)atoi(getenv("GVH_LONG_TASK")) : 0u);
     const int pipelined = strstr(executor, "pipelined") != nullptr, n = batch_size / parts, k = num_negative;
     if (getenv("GVH_CHAIN_CAP")) chain_cap = atoi(getenv("GVH_CHAIN_CAP"));
-    const uint32_t cap = (uint32_t)std::min(chain_cap > 0 ? chain_cap : 7, 7);  // chain_cap_for, gvk_kernels.hip
+    const uint32_t cap = (uint32_t)std::min(chain_cap > 0 ? chain_cap : 7, 7);  // chain_cap_for, gvk_chains.hip
     const uint32_t max_tasks = getenv("GVH_MAX_TASKS") ? (uint32_t)atoi(getenv("GVH_MAX_TASKS")) : (dim == 512 ? 8u : (dim == 32 || dim == 96 ? 32u : 16u));
     std::vector<uint32_t> start(hot_vertex + hot_context + 1), entries(2 * (size_t)(k + 1) * n + 1);
     std::vector<uint32_t> all((size_t)num_batches * batch_size * std::max(k, 1));
@@ -460,7 +460,7 @@ int gvk_set_tuning(int key, int value) {
     return GVK_OK;
 }
 
-int gvk_train_launches(int batch_size, uint32_t rows) {  // the product's rule (gvk_kernels.hip launches_for)
+int gvk_train_launches(int batch_size, uint32_t rows) {  // the product's rule (gvk_pairs.hip launches_for)
     if (g_split_hits <= 0 || rows == 0 || batch_size <= 0) return 1;
     const int64_t per_launch = (int64_t)rows * g_split_hits, want = ((int64_t)batch_size + per_launch - 1) / per_launch;
     if (want <= 1) return 1;

@@ -1,5 +1,5 @@
 // simt.h — TEST INFRASTRUCTURE: a stand-in for one 256-thread workgroup of wave64 hardware on the CPU, so that the SOURCE of a
-// device function (extracted from graphvite_amd/csrc/gvk_kernels.hip by tests/simt_build.py) runs as written: one host thread per
+// device function (extracted from graphvite_amd/csrc/gvk_chains.hip by tests/simt_build.py) runs as written: one host thread per
 // lane, the cross-lane operations (wavefront shuffles, DPP, ballot, the fp32 matrix instruction) as rendezvous of the 64 threads
 // of a wavefront, __syncthreads as a barrier of all 256.  Valid for code whose branches around cross-lane operations are the same
 // for a whole wavefront (long_chain_gram is).  Lane maps: /opt/skills/guides/cdna_hip_programming.md (v_mfma_f32_16x16x4_f32:

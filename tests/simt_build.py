@@ -1,13 +1,14 @@
 """TEST INFRASTRUCTURE: builds tests/hostdev/build/libsimt_chains.so — the SOURCE of the hub chains' device functions
 (train_long_chains / chain_steps, train_short_chains and the cross-lane helpers they use) cut out of
-graphvite_amd/csrc/gvk_kernels.hip as written, compiled for the host over tests/hostdev/simt.h (one host thread per lane,
+graphvite_amd/csrc/gvk_chains.hip (and gvk_device.hpp) as written, compiled for the host over tests/hostdev/simt.h (one host thread per lane,
 cross-lane operations as rendezvous of a wavefront's 64 threads, __syncthreads as a barrier of 256)."""
 import os
 import re
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SOURCE = os.path.join(ROOT, "graphvite_amd", "csrc", "gvk_kernels.hip")
+COMMON = os.path.join(ROOT, "graphvite_amd", "csrc", "gvk_device.hpp")  # TrainArgs, cross-lane helpers, rows in registers, sigmoid
+SOURCE = os.path.join(ROOT, "graphvite_amd", "csrc", "gvk_chains.hip")  # HotArgs and the chains' device functions
 HOSTDEV = os.path.join(ROOT, "tests", "hostdev")
 OUT = os.path.join(HOSTDEV, "build", "libsimt_chains.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
@@ -93,13 +94,13 @@ def cut(text, begin, end, include_end=True):
 
 
 def host_source():
-    text = open(SOURCE).read()
+    common, text = open(COMMON).read(), open(SOURCE).read()
     pieces = [
         '#include "simt.h"\n#include <algorithm>\nstruct gvk_alias_entry;\nstruct gvk_class_entry;\nnamespace {\nconstexpr int kBlock = 256;\n',
-        cut(text, "struct TrainArgs {", "\n};\n"),
-        cut(text, "template <int CTRL>\n__device__ __forceinline__ float dpp(float x) {", "// ---- Philox4x32-10", include_end=False),
-        cut(text, "template <int DIM, int G>\nstruct Layout {", "// ---- arithmetic", include_end=False),
-        cut(text, "__device__ __forceinline__ float sigmoidf(float x) {", "\n}\n"),
+        cut(common, "struct TrainArgs {", "\n};\n"),
+        cut(common, "template <int CTRL>\n__device__ __forceinline__ float dpp(float x) {", "// ---- Philox4x32-10", include_end=False),
+        cut(common, "template <int DIM, int G>\nstruct Layout {", "// ---- arithmetic", include_end=False),
+        cut(common, "__device__ __forceinline__ float sigmoidf(float x) {", "\n}\n"),
         # HotArgs, the chains of 1 .. 7 entries, the idle rows, chain_steps, train_long_chains: everything up to the kernel itself
         cut(text, "struct HotArgs {", "// HOT: 1 = the pairs read a hub row as the chains of their unit left it", include_end=False),
     ]
@@ -110,7 +111,7 @@ def host_source():
 
 def build():
     """Rebuilds when the kernel source, the stand-in or this file is newer than the library; returns its path."""
-    inputs = [SOURCE, os.path.join(HOSTDEV, "simt.h"), os.path.abspath(__file__)]
+    inputs = [COMMON, SOURCE, os.path.join(HOSTDEV, "simt.h"), os.path.abspath(__file__)]
     if os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(p) for p in inputs):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)

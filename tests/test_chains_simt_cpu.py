@@ -1,4 +1,4 @@
-"""The SOURCE of the hub chains' device functions (graphvite_amd/csrc/gvk_kernels.hip: train_long_chains / entry_sums,
+"""The SOURCE of the hub chains' device functions (graphvite_amd/csrc/gvk_chains.hip: train_long_chains / entry_sums,
 train_short_chains), compiled for the host as written over a stand-in for one wave64 workgroup (tests/hostdev/simt.h,
 tests/simt_build.py: one host thread per lane, DPP / shuffles / ballot as rendezvous of a wavefront's 64 threads, __syncthreads
 as a barrier of 256) and run against the oracle's chains (`gvo_hot_unit_chains`: chains of up to 7 entries in sequence, a longer
@@ -34,7 +34,7 @@ def oracle_chain(oracle, dim, vertex, context, lr, wd, nw, kv, kc, chain_start, 
     return v, c
 
 
-LANES_PER_CHAIN = {32: 8, 64: 16, 96: 8, 128: 16, 256: 16, 512: 32}  # default_lanes, gvk_kernels.hip
+LANES_PER_CHAIN = {32: 8, 64: 16, 96: 8, 128: 16, 256: 16, 512: 32}  # default_lanes, gvk_tuning.h
 
 
 def unit_lists(rng, rows, kv, kc, samples, k):

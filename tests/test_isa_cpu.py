@@ -15,17 +15,18 @@ CSRC = os.path.join(ROOT, "graphvite_amd", "csrc")
 @pytest.fixture(scope="module")
 def resources(tmp_path_factory):
     tmp = tmp_path_factory.mktemp("isa")
-    run = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-                          "-c", os.path.join(CSRC, "gvk_kernels.hip"), "-o", str(tmp / "k.o"), "-Rpass-analysis=kernel-resource-usage"],
-                         capture_output=True, text=True, cwd=str(tmp))
-    assert run.returncode == 0, run.stderr[-3000:]
     names, rows = [], []
-    for block in re.split(r"Function Name: ", run.stderr)[1:]:
-        def field(key):
-            m = re.search(re.escape(key) + r": (\d+)", block)
-            return int(m.group(1)) if m else -1
-        names.append(block.split()[0])
-        rows.append(dict(vgpr=field("VGPRs"), scratch=field("ScratchSize [bytes/lane]"), occupancy=field("Occupancy [waves/SIMD]")))
+    for source in ("gvk_pairs.hip", "gvk_chains.hip"):  # the training kernels' translation units
+        run = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+                              "-c", os.path.join(CSRC, source), "-o", str(tmp / (source + ".o")), "-Rpass-analysis=kernel-resource-usage"],
+                             capture_output=True, text=True, cwd=str(tmp))
+        assert run.returncode == 0, run.stderr[-3000:]
+        for block in re.split(r"Function Name: ", run.stderr)[1:]:
+            def field(key):
+                m = re.search(re.escape(key) + r": (\d+)", block)
+                return int(m.group(1)) if m else -1
+            names.append(block.split()[0])
+            rows.append(dict(vgpr=field("VGPRs"), scratch=field("ScratchSize [bytes/lane]"), occupancy=field("Occupancy [waves/SIMD]")))
     plain = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
     return {p.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", ""): r for p, r in zip(plain, rows)}
 

@@ -35,3 +35,20 @@ def power_law_weights(rng, n, exponent=0.75):
     """Degree-like weights: Zipf-ish degrees raised to the negative-sampling exponent."""
     deg = np.floor(rng.pareto(1.5, n) + 1).astype(np.float32)
     return deg ** np.float32(exponent)
+
+
+def compare_auc(label, here, reference, tolerance=0.002):
+    """T3: mean AUC here against the mean of the reference's own training loop, with the standard error of the
+    difference (seeds are independent random streams on both sides).  Asserts |difference| <= tolerance and says on its line
+    whether the verdict survives two standard errors ("clear") or not ("MARGINAL": |difference| + 2 SE > tolerance)."""
+    here, reference = np.asarray(here, np.float64), np.asarray(reference, np.float64)
+    reference = reference[~np.isnan(reference)]
+    difference = float(here.mean() - reference.mean())
+    se = float(np.sqrt((here.std(ddof=1) ** 2 / len(here) if len(here) > 1 else 0.0) +
+                       (reference.std(ddof=1) ** 2 / len(reference) if len(reference) > 1 else 0.0)))
+    verdict = "clear" if abs(difference) + 2 * se <= tolerance else "MARGINAL" if abs(difference) <= tolerance else "OUTSIDE"
+    print("%s: AUC here %s (mean %.6f, %d seeds) | reference training loop %s (mean %.6f, %d seeds) | difference %+.6f, SE %.6f: %s" % (
+        label, " ".join("%.6f" % a for a in here), here.mean(), len(here), " ".join("%.6f" % a for a in reference), reference.mean(),
+        len(reference), difference, se, verdict))
+    assert abs(difference) <= tolerance, (label, difference, se)
+    return difference, se
