@@ -69,7 +69,7 @@ class WalkGraph(C.Structure):
 # ---- include/gvx.h ---------------------------------------------------------------------------------------------------
 GVX_AUTO = 0
 GVX_DEVICE_SAMPLING, GVX_PAIR_ORDER, GVX_SEED, GVX_NEGATIVE_TABLE, GVX_NODE2VEC_TABLE_LIMIT, GVX_HUB_ROWS, GVX_HUB_PARTS, GVX_FIDELITY = 1, 2, 3, 4, 5, 6, 7, 8
-GVX_HUB_LERP, GVX_HUB_CHAIN_CAP = 9, 10
+GVX_HUB_LERP, GVX_HUB_CHAIN_CAP, GVX_HUB_ROUNDS = 9, 10, 11
 GVX_UNIQUE_ID_BYTES = 256
 SCHEDULE_FUNCTION = C.CFUNCTYPE(C.c_float, C.c_int, C.c_int, C.c_void_p)
 TRANSPORT_ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -99,7 +99,7 @@ class SolverMembers(C.Structure):  # gvx_solver_members
                 ("optimizer", SolverOptimizer), ("batch_id", C.c_uint64), ("num_batch", C.c_uint64),
                 ("train_seconds", C.c_double), ("rank", C.c_int), ("num_local_worker", C.c_int), ("pair_order", C.c_int),
                 ("sampler_mode", C.c_int), ("device_sampling", C.c_int), ("partition_rows", C.c_uint32),
-                ("transport", C.c_char_p), ("hub_rows", C.c_uint32), ("hub_parts_used", C.c_int32), ("hub_lerp_used", C.c_int32)]
+                ("transport", C.c_char_p), ("hub_rows", C.c_uint32), ("hub_parts", C.c_int32), ("hub_lerp", C.c_int32), ("hub_rounds", C.c_int32)]
 
 
 class Transport(C.Structure):  # gvx_transport

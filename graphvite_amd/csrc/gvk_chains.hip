@@ -43,6 +43,7 @@ struct HotArgs {
     uint32_t chains;              // hot_vertex + hot_context
     uint32_t long_capacity;
     uint32_t cap;                 // entries of one task (at most kShortEntries)
+    uint32_t round_steps;         // a task of more entries applies so many per round (gvk.h GVK_HOT_ROUND_STEPS; 0: all of them in one round)
     float lr;                     // learning rate of the chains' batch (the pairs of the same launch may belong to another batch)
     float log2_decay_positive, log2_decay_negative;  // log2(1 - lr wd), log2(1 - lr negative_weight wd): decay of an entry by label
     int order, pair_blocks;       // grid order (0: chains first, 1: long chains, pairs, the other chains, 2: pairs first)
@@ -62,6 +63,9 @@ struct HotArgs {
 #define GVK_STAMP_VALUE(h, slot, value) do { } while (0)
 #endif
 
+#if !defined(GVK_CHAIN_STEPS_INLINE)
+#define GVK_CHAIN_STEPS_INLINE __forceinline__
+#endif
 template <int DIM, int G>
 struct ChainShape {
     static constexpr int V = DIM / G;
@@ -76,7 +80,7 @@ struct ChainShape {
 // mirror row and trains with weight 0.  Every step issues exactly one row request and consumes the one issued D steps
 // earlier, with no branch around either, so the wait before a step is "all but the D - 1 youngest" and not "all".
 template <int DIM, int G>
-__device__ __forceinline__ void chain_steps(const TrainArgs &a, const HotArgs &h, const uint32_t chain, const uint32_t begin,
+__device__ GVK_CHAIN_STEPS_INLINE void chain_steps(const TrainArgs &a, const HotArgs &h, const uint32_t chain, const uint32_t begin,
                                             const uint32_t end, const int lane, float (&own)[DIM / G]) {
     typedef ChainShape<DIM, G> S;
     constexpr int V = S::V, D = S::D;
@@ -255,7 +259,7 @@ __device__ __forceinline__ void copy_idle_rows(const HotArgs &h, const uint32_t 
 // summing plain deltas of 8 tasks would take it to 0.30) and leaves only the gradients' dependence on the other tasks'
 // steps to first order.  The sum runs in task order in one lane group: the same bits on every run.
 template <int DIM, int G>
-__device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotArgs &h, const uint32_t block) {
+__device__ __forceinline__ void train_long_chains_one_round(const TrainArgs &a, const HotArgs &h, const uint32_t block) {
     typedef ChainShape<DIM, G> S;
     constexpr int V = S::V, NG = S::NG;
     __shared__ float ends[NG][DIM];
@@ -330,12 +334,247 @@ __device__ __forceinline__ void train_long_chains(const TrainArgs &a, const HotA
     }
 }
 
+// The same with ROUNDS (gvk_train_episode_hot form GVK_HOT_ROUNDS; a kernel build of its own, so that each build has one stream loop
+// and stays within its registers).
+// Long chains in rounds, one workgroup each (block b takes long chains b, b + long_blocks, ...): T <= NG tasks of consecutive
+// entries (whole samples for a head chain) trained side by side by the block's lane groups and composed.  An update is
+// own <- d own - lr w g c with d = 1 - lr w wd: weight decay is a factor that depends on the entry's label only, so the
+// decay of the entries BEFORE a task (before_), of the task itself and of the entries AFTER it (after_) are known in closed
+// form from label counts (every task counts its own positives; the counts meet in LDS).  A task starts from the row as the
+// earlier tasks' decay leaves it, and what it adds to the row is its end state carried through the later tasks' decay:
+//     row <- total row + sum over tasks (after_t end_t - total row),         total = before_ x task x after_
+// which composes the tasks' decay exactly (a hub row of the benchmark graph decays to 0.48 of itself within ONE batch —
+// summing plain deltas of 8 tasks would take it to 0.30) and leaves only the gradients' dependence on the other tasks'
+// steps to first order.  The sum runs in task order: the same bits on every run given the work lists.
+//
+// ROUNDS.  "To first order" has a price that grows with the entries that work side by side from one state: their gradient
+// steps add up where the sequential loop's would have seen each other — on a graph whose largest hub heads 6 % of the
+// samples a unit's 400 entries of that row, 16 tasks of 25, overshoot the reference's loop (AUC +0.008; sequential chains at
+// the same parts: +0.0001).  Tasks of more than h.round_steps entries therefore work in rounds of that many:
+// after every round the tasks' end states are composed — by every lane group on its own, from LDS — and the next round
+// starts from the composed row: at most NG x round_steps entries side by side, however long the chain.  The entries of a
+// task are still one stream through the ring of D rows in flight (a round's end does not drain it), the label counts of the
+// next round's segments travel with the end states: ONE barrier per round.
+template <int DIM, int G>
+__device__ __forceinline__ void train_long_chains_in_rounds(const TrainArgs &a, const HotArgs &h, const uint32_t block) {
+    constexpr int ROUNDS = 1;
+    typedef ChainShape<DIM, G> S;
+#if !defined(GVK_ROUND_RING)
+#define GVK_ROUND_RING 4
+#endif
+    // rows in flight: a round's end waits for the slowest lane group, so the rows of a round are asked for more than a round ahead where the registers allow
+    constexpr int V = S::V, NG = S::NG, D = V <= 8 ? (GVK_ROUND_RING < G ? GVK_ROUND_RING : G) : S::D;
+    __shared__ float ends[2][NG][DIM];
+    __shared__ float counts[2][NG][2];  // per round (two in rotation) and task: positives, entries of the task's segment
+    const int lane = threadIdx.x % G, group = threadIdx.x / G;
+    // the block's first record is asked for together with the list's length (one round trip)
+    u32x4 record = *reinterpret_cast<const u32x4 *>(h.long_list + 4 + 4 * (size_t)(block < h.long_capacity ? block : 0));
+    const uint32_t count = h.long_list[0] < h.long_capacity ? h.long_list[0] : h.long_capacity;
+    for (uint32_t j = block; j < count; j += (uint32_t)h.long_blocks) {
+        if (j != block) record = *reinterpret_cast<const u32x4 *>(h.long_list + 4 + 4 * (size_t)j);
+        const uint32_t chain = record.x, first = record.y, n = record.z, last = first + n;
+        if (j == block) {
+            GVK_STAMP_VALUE(h, 0, 1);
+            GVK_STAMP(h, 2);  // the record is here
+            GVK_STAMP_VALUE(h, 7, n);
+        }
+        // NG tasks at most: a longer chain gets longer tasks
+        uint32_t per = h.cap;
+        if ((uint64_t)per * NG < n) per = (n + NG - 1) / NG;
+        const uint32_t tasks = (n + per - 1) / per;
+        const bool mine = (uint32_t)group < tasks;
+        const uint32_t begin = mine ? first + (uint32_t)group * per : last;
+        const uint32_t end = last - begin > per ? begin + per : last;
+        // entries a task applies per round (a round's segment fits one fetch of G entries)
+        // (ROUNDS = 0: the build without them — one stream loop per kernel keeps both within their registers)
+        const uint32_t steps = ROUNDS && h.round_steps && per > h.round_steps ? (h.round_steps < (uint32_t)G ? h.round_steps : (uint32_t)G) : per;
+        float row[V], own[V];
+        load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, row);
+        const uint32_t mine_entry = begin + lane < end ? h.entries[begin + lane] : 0;  // the task's first G entries, one per lane
+        // what the tasks of a round need from each other: {positives, entries} of every task's segment, through LDS
+        auto share_counts = [&](const int buffer, const uint32_t positives, const uint32_t length) __attribute__((always_inline)) {
+            if (lane == 0) counts[buffer][group][0] = (float)positives, counts[buffer][group][1] = (float)length;
+        };
+        float after_ = 1, total = 1;
+        uint32_t active = 0;  // tasks with entries in the round
+        auto enter_round = [&](const int buffer) __attribute__((always_inline)) {  // after the barrier: own <- the row under the decay of the tasks before this one
+            float pb = 0, nb = 0, pa = 0, na = 0, pi = 0, ni = 0;
+            active = 0;
+            for (uint32_t t = 0; t < tasks; t++) {
+                const float p = counts[buffer][t][0], len = counts[buffer][t][1];
+                pb += t < (uint32_t)group ? p : 0.0f, nb += t < (uint32_t)group ? len - p : 0.0f;
+                pa += t > (uint32_t)group ? p : 0.0f, na += t > (uint32_t)group ? len - p : 0.0f;
+                pi += t == (uint32_t)group ? p : 0.0f, ni += t == (uint32_t)group ? len - p : 0.0f;
+                active += len > 0 ? 1u : 0u;
+            }
+            const float before_ = exp2f(pb * h.log2_decay_positive + nb * h.log2_decay_negative);
+            after_ = exp2f(pa * h.log2_decay_positive + na * h.log2_decay_negative);
+            total = exp2f((pb + pi + pa) * h.log2_decay_positive + (nb + ni + na) * h.log2_decay_negative);
+#pragma unroll
+            for (int x = 0; x < V; x++) own[x] = before_ * row[x];
+        };
+        auto compose = [&](const int buffer) __attribute__((always_inline)) {  // after the barrier: the round's end states into the row, by every group
+            // one round: the row it started from is the mirror's, asked for again rather than kept in registers through the steps
+            if constexpr (!ROUNDS) load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, row);
+#pragma unroll
+            for (int x = 0; x < V; x++) row[x] *= (1.0f - (float)active) * total;
+            for (uint32_t t = 0; t < active; t++) {
+                float part[V];
+                load_row_at<DIM, G>(&ends[buffer][t][0], lane, part);
+#pragma unroll
+                for (int x = 0; x < V; x++) row[x] += part[x];
+            }
+        };
+        if (per <= (uint32_t)kShortEntries && steps == per) {
+            // the usual long chain: tasks of up to seven entries, one round, all partner rows of a task at once
+            share_counts(0, (uint32_t)group_count<G>(mine_entry >> 31), end - begin);
+            __syncthreads();
+            if (j == block) GVK_STAMP(h, 3);  // own row and the task's entries are here
+            enter_round(0);
+            short_steps<DIM, G>(a, h, chain, end - begin, lane, own,
+                                [&](const int i) __attribute__((always_inline)) { return (uint32_t)__shfl((int)mine_entry, i, G); });
+            if (mine) {
+#pragma unroll
+                for (int x = 0; x < V; x++) own[x] *= after_;
+                store_row_at<DIM, G>(&ends[0][group][0], lane, own);
+            }
+            if (j == block) GVK_STAMP(h, 4);  // this task's steps are done
+            __syncthreads();
+            if (j == block) GVK_STAMP(h, 5);  // every task's steps are done
+            compose(0);
+        } else if (!ROUNDS || steps == per) {
+          if constexpr (!ROUNDS) {
+            // longer tasks, one round (chains of up to NG x 16 entries unless the caller asks for rounds): the task's entries as one
+            // stream, rows D at a time in flight
+            uint32_t inside = mine_entry >> 31;
+            for (uint32_t p = begin + G + lane; p < end; p += G) inside += h.entries[p] >> 31;
+            share_counts(0, (uint32_t)group_count<G>(inside), end - begin);
+            __syncthreads();
+            if (j == block) GVK_STAMP(h, 3);  // own row and the task's entries are here
+            enter_round(0);
+            chain_steps<DIM, G>(a, h, chain, begin, end, lane, own);
+            if (mine) {
+#pragma unroll
+                for (int x = 0; x < V; x++) own[x] *= after_;
+                store_row_at<DIM, G>(&ends[0][group][0], lane, own);
+            }
+            if (j == block) GVK_STAMP(h, 4);  // this task's steps are done
+            __syncthreads();
+            if (j == block) GVK_STAMP(h, 5);  // every task's steps are done
+            compose(0);
+          }
+        }
+        if constexpr (ROUNDS != 0) if (!(per <= (uint32_t)kShortEntries && steps == per)) {
+            // longer tasks in rounds of `steps` entries (one round when steps == per): the task's entries as one stream, rows D at a time in flight
+            const bool is_vertex = chain < a.hot_vertex;
+            const float *partner_table = is_vertex ? a.context : a.vertex;
+            const uint32_t partner_hot = is_vertex ? a.hot_context : a.hot_vertex;  // partners below this id are hub rows: read from the mirror
+            const float *partner_mirror = h.from + (is_vertex ? (size_t)a.hot_vertex * DIM : (size_t)0);
+            const float *idle = h.from + (size_t)chain * DIM;
+            // the work list, G entries per fetch, two fetches resident: entries [blk, blk + 2 G)
+            uint32_t blk = begin;
+            uint32_t e_cur = mine_entry;
+            uint32_t e_nxt = blk + G + lane < end ? h.entries[blk + G + lane] : 0;
+            // entry p of the list (through the window): the row it names (past the end: the group's own mirror row) and its label
+            auto row_of = [&](const uint32_t p, uint32_t &label) __attribute__((always_inline)) -> const float * {
+                const uint32_t o = p - blk;
+                const uint32_t e = (uint32_t)__shfl((int)(o < (uint32_t)G ? e_cur : e_nxt), (int)(o & (G - 1)), G);
+                label = e >> 31;
+                const uint32_t id = e & 0x7fffffffu;
+                const float *at = id < partner_hot ? partner_mirror + (size_t)id * DIM : partner_table + (size_t)id * DIM;
+                return p < end ? at : idle;
+            };
+            float ring[D][V];
+            uint32_t labels = 0;  // bit i: the label of the entry whose row sits in ring[i]
+#pragma unroll
+            for (int i = 0; i < D; i++) {
+                uint32_t label;
+                load_row_at<DIM, G>(row_of(begin + i, label), lane, ring[i]);
+                labels |= label << i;
+            }
+            // the label count of the first round's segment — of a task's whole range when there is one round
+            uint32_t segment = begin, length = end - segment < steps ? end - segment : steps;
+            uint32_t inside = (uint32_t)lane < length ? mine_entry >> 31 : 0;
+            for (uint32_t p = begin + G + lane; p < begin + length; p += G) inside += h.entries[p] >> 31;
+            share_counts(0, (uint32_t)group_count<G>(inside), length);
+            // the next round's segment, asked for a round ahead of its count
+            auto segment_ahead = [&](const uint32_t from) __attribute__((always_inline)) -> uint32_t {
+                return steps < per && from + lane < end && (uint32_t)lane < steps ? h.entries[from + lane] : 0;
+            };
+            uint32_t ahead = segment_ahead(begin + steps);
+            __syncthreads();
+            if (j == block) GVK_STAMP(h, 3);  // own row and the task's entries are here
+            enter_round(0);
+            uint32_t round = 0, in_round = 0;
+            for (uint32_t base = 0; base < per; base += D) {  // `per` is the workgroup's: every lane group takes every step
+                const uint32_t f = blk + 2 * G + lane;
+                const uint32_t e_fut = h.entries[f < end ? f : (begin < end ? end - 1 : 0)];  // the window after e_nxt, asked for ahead of its use
+#pragma unroll
+                for (int i = 0; i < D; i++) {
+                    const uint32_t p = begin + base + i;
+                    const bool positive = (labels >> i & 1u) != 0;
+                    const float(&c)[V] = ring[i];
+                    // forward / backward of one target: model/graph.h:40-58, gpu/graph.cuh:77-87 — on the own row only
+                    float partial = 0;
+#pragma unroll
+                    for (int x = 0; x < V; x++) partial += own[x] * c[x];
+                    const float prob = sigmoidf(group_sum<G>(partial));
+                    const float gradient = positive ? prob - 1 : prob;
+                    const float weight = p < end && base + i < per ? (positive ? 1.0f : a.neg_weight) : 0.0f;
+#pragma unroll
+                    for (int x = 0; x < V; x++) own[x] -= h.lr * weight * (gradient * c[x] + a.wd * own[x]);  // optimizer.h:161-164
+                    // the slot is free: the row of entry p + D takes it (D - 1 requests stay in flight while a step computes)
+                    uint32_t label;
+                    load_row_at<DIM, G>(row_of(p + D, label), lane, ring[i]);
+                    labels = (labels & ~(1u << i)) | label << i;
+                    if (++in_round == steps && base + i + 1 < per) {
+                        // the round ends (the same step for every lane group): end states and the next segments' counts out, ...
+                        const int buffer = (int)(round & 1u);
+                        if (segment < end) {
+#pragma unroll
+                            for (int x = 0; x < V; x++) own[x] *= after_;
+                            store_row_at<DIM, G>(&ends[buffer][group][0], lane, own);
+                        }
+                        segment += steps;
+                        length = segment < end ? (end - segment < steps ? end - segment : steps) : 0;
+                        share_counts(buffer ^ 1, (uint32_t)group_count<G>((uint32_t)lane < length ? ahead >> 31 : 0), length);
+                        ahead = segment_ahead(segment + steps);
+                        __syncthreads();
+                        // ... composed by every group, and the next round starts from the composed row
+                        compose(buffer);
+                        enter_round(buffer ^ 1);
+                        round++, in_round = 0;
+                    }
+                }
+                if (base + D >= blk - begin + G) {  // the next steps look beyond e_nxt: move the window
+                    blk += G;
+                    e_cur = e_nxt;
+                    e_nxt = e_fut;
+                }
+            }
+            const int buffer = (int)(round & 1u);
+            if (segment < end) {
+#pragma unroll
+                for (int x = 0; x < V; x++) own[x] *= after_;
+                store_row_at<DIM, G>(&ends[buffer][group][0], lane, own);
+            }
+            if (j == block) GVK_STAMP(h, 4);  // this task's steps are done
+            __syncthreads();
+            if (j == block) GVK_STAMP(h, 5);  // every task's steps are done
+            compose(buffer);
+        }
+        if (group == 0) store_row_at<DIM, G>(h.to + (size_t)chain * DIM, lane, row);
+        __syncthreads();
+        if (j == block) GVK_STAMP(h, 6);  // composed and stored
+    }
+}
+
 // HOT: 1 = the pairs read a hub row as the chains of their unit left it, 2 = on the straight line from where those chains
 // found it to where they left it, at the sample's place in the unit (lerp)
 // Built for four wavefronts per SIMD (128 registers; the short chains keep seven partner rows per lane group in flight; three
 // at dims 256 and 512, sixteen floats of a row per lane): the chains and the pairs of a unit of the sizes this kernel trains (a
 // part of a batch) are then resident side by side.
-template <int DIM, int G, int KT, int HOT>
+template <int DIM, int G, int KT, int HOT, int ROUNDS>
 __global__ void __launch_bounds__(kBlock, DIM / G > 12 ? 3 : 4) train_hot_kernel(const TrainArgs a, const HotArgs h) {
     // the grid: [long chains | pairs | short chains | idle rows] — the long chains, whose tasks wait for memory three times in
     // a row, are dispatched first, the bulk (the pairs) next; the short chains and the copies fill in behind
@@ -346,7 +585,8 @@ __global__ void __launch_bounds__(kBlock, DIM / G > 12 ? 3 : 4) train_hot_kernel
     const int long_first = h.order == 2 ? h.pair_blocks : 0;
     const int short_first = h.order == 0 ? h.long_blocks : h.long_blocks + h.pair_blocks;
     if (b >= long_first && b < long_first + h.long_blocks) {
-        train_long_chains<DIM, G>(a, h, b - long_first);
+        if constexpr (ROUNDS != 0) train_long_chains_in_rounds<DIM, G>(a, h, b - long_first);
+        else train_long_chains_one_round<DIM, G>(a, h, b - long_first);
     } else if (b >= pairs_first && b < pairs_first + h.pair_blocks) {
         GVK_STAMP_VALUE(h, 0, 3);
         train_pair<DIM, G, GVK_SGD, KT, 1, HOT>(a, (b - pairs_first) * kBlock + threadIdx.x);
@@ -531,14 +771,18 @@ void fill_negative(TrainArgs &a, const gvk_negative_source *neg) {
 
 typedef void (*HotKernel)(const TrainArgs, const HotArgs);
 
-HotKernel pick_hot(int dim, int k, int lerp) {
+HotKernel pick_hot(int dim, int k, int lerp, int rounds) {
+#define GVK_HOT_R(D, GG, R)                                                                                         \
+        return k == 1 ? (lerp ? train_hot_kernel<D, GG, 1, 2, R> : train_hot_kernel<D, GG, 1, 1, R>)                \
+                      : (lerp ? train_hot_kernel<D, GG, 0, 2, R> : train_hot_kernel<D, GG, 0, 1, R>);
 #define GVK_HOT(D, GG)                                                                                              \
     case D:                                                                                                         \
-        return k == 1 ? (lerp ? train_hot_kernel<D, GG, 1, 2> : train_hot_kernel<D, GG, 1, 1>)                      \
-                      : (lerp ? train_hot_kernel<D, GG, 0, 2> : train_hot_kernel<D, GG, 0, 1>);
+        if (rounds) { GVK_HOT_R(D, GG, 1) }                                                                         \
+        GVK_HOT_R(D, GG, 0)
     switch (dim) {
         GVK_HOT(32, 8) GVK_HOT(64, 16) GVK_HOT(96, 8) GVK_HOT(128, 16) GVK_HOT(256, 16) GVK_HOT(512, 32)
     }
+#undef GVK_HOT_R
 #undef GVK_HOT
     return nullptr;
 }
@@ -606,11 +850,13 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     if (hot_vertex > tables->n_vertex || hot_context > tables->n_context)
         return fail(GVK_EINVAL, "gvk_train_episode_hot: more hub rows than table rows");
     if (chain_cap < 0) return fail(GVK_EINVAL, "gvk_train_episode_hot: negative chain_cap");
-    if (form & ~(GVK_HOT_SERIALIZED | GVK_HOT_LERP)) return fail(GVK_EINVAL, "gvk_train_episode_hot: unknown form bits");
+    if (form & ~(GVK_HOT_SERIALIZED | GVK_HOT_LERP | GVK_HOT_ROUNDS)) return fail(GVK_EINVAL, "gvk_train_episode_hot: unknown form bits");
     const HotLayout l = hot_layout(dim, batch_size, num_negative, hot_vertex, hot_context, workspace_batches, parts, chain_cap);
     if (!workspace || workspace_bytes < l.bytes) return fail(GVK_EINVAL, "gvk_train_episode_hot: workspace too small (gvk_hot_plan)");
     const bool lerp = (form & GVK_HOT_LERP) != 0, serialized = (form & GVK_HOT_SERIALIZED) != 0 || g_hot_serialized != 0;
-    const HotKernel kernel = pick_hot(dim, num_negative, lerp);
+    // rounds: asked for by the caller (GVK_HOT_ROUNDS) or forced either way by the measurement knob GVK_TUNE_ROUND_STEPS (0: never)
+    const uint32_t round_steps = g_round_steps >= 0 ? (uint32_t)g_round_steps : ((form & GVK_HOT_ROUNDS) ? (uint32_t)GVK_HOT_ROUND_STEPS : 0u);
+    const HotKernel kernel = pick_hot(dim, num_negative, lerp, round_steps != 0);
     if (!kernel) return fail(GVK_EDIM, "gvk_train_episode_hot: no kernel for this dim");
     const int lanes = default_lanes(dim);
     char *base = static_cast<char *>(workspace);
@@ -625,6 +871,7 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     HotArgs h;
     memset(&h, 0, sizeof(h));
     h.chains = l.chains; h.long_capacity = l.long_capacity; h.cap = l.cap;
+    h.round_steps = round_steps;
     const int groups = kBlock / lanes;
     const int short_blocks = (int)((l.chains + groups - 1) / groups);
     const int long_blocks = (int)std::min<uint32_t>(l.long_capacity, (uint32_t)kLongBlocks);

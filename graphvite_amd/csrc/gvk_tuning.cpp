@@ -6,6 +6,7 @@ int g_run_cap = 0;         // GVK_TUNE_RUN_CAP (0 = the default of 20, run_cap_f
 int g_split_hits = 2;      // GVK_TUNE_SPLIT_HITS (samples per table row one launch may hold; 0 = never split a batch)
 int g_hot_order = 1;       // GVK_TUNE_HOT_ORDER (measurement: which blocks of a train_hot_kernel launch come first; 1 = long chains, pairs, the other chains)
 int g_hot_serialized = 0;  // GVK_TUNE_HOT_SERIALIZED (measurement: gvk_train_episode_hot launches the chains and the pairs of a unit one after the other)
+int g_round_steps = -1;   // GVK_TUNE_ROUND_STEPS (-1 = as the caller's form says; 0 = never rounds; 1 .. 8 = rounds of so many entries per task)
 int g_chain_cap = 0;       // GVK_TUNE_CHAIN_CAP (entries one chain task trains in sequence; 0 = the default of 7)
 #if defined(GVK_AB_BUILDS)  // knobs of the A/B library only (make ab -> build/ab/libgvk_ab.so)
 int g_lanes_per_pair = 0;  // GVK_TUNE_LANES_PER_PAIR
@@ -35,6 +36,11 @@ int gvk_set_tuning(int key, int value) {
     if (key == GVK_TUNE_CHAIN_CAP) {
         if (value < 0 || value > (1 << 20)) return fail(GVK_EINVAL, "gvk_set_tuning: chain cap must be in [0, 2^20]");
         g_chain_cap = value;
+        return GVK_OK;
+    }
+    if (key == GVK_TUNE_ROUND_STEPS) {
+        if (value < -1 || value > 8) return fail(GVK_EINVAL, "gvk_set_tuning: round steps must be -1 (default), 0 (one round) or 1 .. 8");
+        g_round_steps = value;
         return GVK_OK;
     }
     if (key == GVK_TUNE_HOT_ORDER) {

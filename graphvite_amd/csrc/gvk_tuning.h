@@ -12,6 +12,7 @@ extern GVK_HIDDEN int g_run_cap;         // GVK_TUNE_RUN_CAP (0 = the default of
 extern GVK_HIDDEN int g_split_hits;      // GVK_TUNE_SPLIT_HITS (samples per table row one launch may hold; 0 = never split a batch)
 extern GVK_HIDDEN int g_hot_order;       // GVK_TUNE_HOT_ORDER (measurement: which blocks of a train_hot_kernel launch come first; 1 = long chains, pairs, the other chains)
 extern GVK_HIDDEN int g_hot_serialized;  // GVK_TUNE_HOT_SERIALIZED (measurement: gvk_train_episode_hot launches the chains and the pairs of a unit one after the other)
+extern GVK_HIDDEN int g_round_steps;    // GVK_TUNE_ROUND_STEPS (-1 = as the caller's form says; 0 = never rounds; 1 .. 8 = rounds of so many entries per task)
 extern GVK_HIDDEN int g_chain_cap;       // GVK_TUNE_CHAIN_CAP (entries one chain task trains in sequence; 0 = the default of 7)
 #if defined(GVK_AB_BUILDS)  // knobs of the A/B library only (make ab -> build/ab/libgvk_ab.so)
 extern GVK_HIDDEN int g_lanes_per_pair;  // GVK_TUNE_LANES_PER_PAIR

@@ -46,7 +46,9 @@ namespace {
 constexpr int kMaxPartition = 16;  // solver.h:51-57
 constexpr int kMinBatchSize = 10000;
 constexpr int kSamplePerVertex = 175;
-constexpr double kHubHitsPerPart = 0.125;  // GVX_HUB_ROWS -1: a row a PART of a batch is expected to hit this often is a hub row (§7.10)
+constexpr double kHubHits = 1.0;           // GVX_HUB_ROWS -1: a row a BATCH is expected to hit this often is a hub row (§7.10)
+constexpr double kHubHitsPerPart = 0.125;  // ... and no row outside the chains is to be hit more often than this per PART of a batch: the parts follow (hub_parts_of)
+constexpr double kHubRoundShare = 0.02;    // GVX_HUB_ROUNDS -1: long chains work in rounds where the graph's largest vertex takes more than this share of its total degree (§7.11)
 constexpr uint64_t kMaxHubRows = 16384;  // per table (gvk_hot_build counts the chains of both tables in LDS)
 constexpr int kHubChunk = 128;          // batches whose work lists are built at once
 constexpr int kHubEntriesPerPart = 250;  // with hub rows by chains a batch is trained as so many parts that its largest hub row meets about this many of its updates per part
@@ -177,6 +179,7 @@ struct gvx_solver {
     int hub_parts_request = 0;      // GVX_HUB_PARTS: 0 the rule (gvk_train_launches when every row is a hub row, else 1), Q > 0 given
     int64_t hub_rows_request = -2;  // GVX_HUB_ROWS: -2 the default rule, -1 by expected hits per batch, 0 off, N > 0 the first N rows
     bool hogwild_said = false, order_said = false;  // warnings of configure() that are given once per solver
+    int hub_rounds_request = -1;    // GVX_HUB_ROUNDS: -1 the rule (kHubRoundEntries), 0 / 1: long chains in one round / in rounds
     int hub_lerp_request = -1;      // GVX_HUB_LERP: -1 the rule, 0 / 1: the pairs read hub rows as their unit's chains left them / along the chains' way
     int hub_chunk = kHubChunk;      // batches whose work lists are built at once (fewer where memory is short)
     int hub_max_parts = kHubMaxParts;  // most parts a batch is trained as (kHubMaxPartsResident for cache-resident tables)
@@ -326,6 +329,9 @@ struct gvx_solver {
     int device_fill(int set);
     int route_slices(int set);
     int hub_parts_of(int hp, int tp) const;
+    bool hub_rounds_of(int hp, int tp) const;
+    double hub_graph_share = 0;  // the largest vertex's share of the graph's total degree
+    std::vector<double> hub_top_share, hub_next_hits;  // per partition: the largest row's share of the partition's degree; expected hits per batch of the first row that is not a hub row
     int stage(Worker &w, int step, int set, int b);
     int train_step(int step, int set, int first, int count, bool stage_next, int next_step, int next_set);
     int claim_slots(int step);
@@ -581,6 +587,10 @@ extern "C" int gvx_solver_set(gvx_solver *s, int option, int64_t value) {
         s->hub_lerp_request = (int)value;
         return GVK_OK;
     }
+    if (option == GVX_HUB_ROUNDS && value >= -1 && value <= 1) {
+        s->hub_rounds_request = (int)value;
+        return GVK_OK;
+    }
     if (option == GVX_HUB_CHAIN_CAP && value >= 0 && value <= (1 << 20)) {
         s->hub_chain_cap_request = (int)value;
         return GVK_OK;
@@ -772,6 +782,7 @@ int gvx_solver::configure(const gvx_train_config &in) {
     // the partition) or as a negative (share of degree^exponent) — are trained by chains; their batches keep the sampler's order
     hub_rows.assign(num_partition, 0);
     hub_top_entries.assign(num_partition, 0);
+    hub_top_share.assign(num_partition, 0.0), hub_next_hits.assign(num_partition, 0.0);
     hubs = false;
     // the default rule (-2): every row of the walk-ordered pools of DeepWalk / node2vec on one partition of at most kMaxHubRows
     // rows; else the rows a part of a batch is expected to hit kHubHitsPerPart times — on tables that do not live in the caches
@@ -802,6 +813,12 @@ int gvx_solver::configure(const gvx_train_config &in) {
     }
     if (request != 0) {
         const float *vertex_weights = gvs_graph_vertex_weights(graph);
+        {
+            double all = 0, largest = 0;
+            for (int p = 0; p < num_partition; p++)
+                for (uint32_t id : part_ids[p]) all += vertex_weights[id], largest = std::max(largest, (double)vertex_weights[id]);
+            hub_graph_share = largest / std::max(all, 1e-30);
+        }
         for (int p = 0; p < num_partition; p++) {
             const std::vector<uint32_t> &ids = part_ids[p];
             uint64_t rows = 0;
@@ -814,24 +831,30 @@ int gvx_solver::configure(const gvx_train_config &in) {
                 // batch of this partition's blocks is trained as (hub_parts_of)
                 if (!ids.empty())
                     hub_top_entries[p] = (int)std::min(1e9, (double)batch_size * (num_negative + 1) * vertex_weights[ids[0]] / std::max(total, 1e-30));
-                const int parts = std::min(std::max((hub_top_entries[p] + kHubEntriesPerPart / 2) / kHubEntriesPerPart, 1), hub_max_parts);
-                // A row a batch hits h times meets another of its hits inside a part with probability ~ h / parts, and of two
-                // concurrent updates one is lost: the rows a PART is expected to hit kHubHitsPerPart times or more are hub rows
-                // (one hit per batch at the eight parts of the headline shape, §7.10; four at the 32 parts of its P = 4 blocks)
-                const double hits = kHubHitsPerPart * parts;
-                for (uint32_t id : ids) {  // falling degree: stop at the first row below both thresholds
+                hub_top_share[p] = ids.empty() ? 0.0 : vertex_weights[ids[0]] / std::max(total, 1e-30);
+                // The rows a BATCH is expected to hit kHubHits = once or more — as a head / tail (its share of the partition's degree) or as
+                // a negative (its share of degree^exponent) — are hub rows: of two concurrent updates of a row one is lost, and a row that
+                // is hit h times per batch meets another of its hits inside a part with probability ~ h / parts.  What the chains do
+                // not own (the table is larger than kMaxHubRows, or the rule stops first) decides the parts with the largest hub
+                // row (hub_parts_of): no row outside the chains is to be hit more than kHubHitsPerPart times per part.
+                auto hits_of = [&](uint32_t id) {
                     const double w = vertex_weights[id];
-                    const bool often = batch_size * w >= hits * total ||
-                                       (double)batch_size * num_negative * std::pow(w, (double)c.negative_sample_exponent) >= hits * total_negative;
-                    if (!often) break;
+                    return std::max(batch_size * w / std::max(total, 1e-30),
+                                    (double)batch_size * num_negative * std::pow(w, (double)c.negative_sample_exponent) / std::max(total_negative, 1e-30));
+                };
+                for (uint32_t id : ids) {  // falling degree: stop at the first row below the threshold
+                    if (hits_of(id) < kHubHits || rows >= kMaxHubRows) break;
                     rows++;
                 }
+                hub_next_hits[p] = rows < ids.size() ? hits_of(ids[rows]) : 0.0;
             }
             hub_rows[p] = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(rows, ids.size()), kMaxHubRows);
             if (request > 0 && !ids.empty()) {
                 double total = 0;
                 for (uint32_t id : ids) total += vertex_weights[id];
                 hub_top_entries[p] = (int)std::min(1e9, (double)batch_size * (num_negative + 1) * vertex_weights[ids[0]] / std::max(total, 1e-30));
+                hub_top_share[p] = vertex_weights[ids[0]] / std::max(total, 1e-30);
+                hub_next_hits[p] = 0;  // the caller chose the hub rows: the parts follow the largest of them
             }
             hubs = hubs || hub_rows[p] > 0;
         }
@@ -869,7 +892,11 @@ int gvx_solver::configure(const gvx_train_config &in) {
                     const int parts = hub_parts_of(hp, tp), top = std::max(hub_top_entries[hp], hub_top_entries[tp]);
                     if ((top + parts - 1) / parts > worst) worst = (top + parts - 1) / parts, worst_parts = parts;
                 }
-            if (worst > kHubMaxEntriesPerPart) {
+            bool in_rounds = true;  // with rounds no more than 16 x 4 entries work side by side however long the chain: nothing to overshoot
+            for (int hp = 0; hp < num_partition && in_rounds; hp++)
+                for (int tp = 0; tp < num_partition && in_rounds; tp++)
+                    if (hub_rows[hp] + hub_rows[tp] > 0 && !hub_rounds_of(hp, tp)) in_rounds = false;
+            if (worst > kHubMaxEntriesPerPart && !in_rounds) {
                 if (fidelity == 1 || hub_rows_request > -2)
                     return gvk_fail(GVK_EINVAL, "hub rows by chains: the largest hub row would meet %d of its updates per part (a batch as %d "
                                     "parts; at most %d keep the chains stable): use a batch size with more divisors or set hub_parts",
@@ -1617,6 +1644,20 @@ int gvx_solver::fill(int set) { return device_sampling ? device_fill(set) : host
 // stream; batch ids interleave over the workers as the reference's shared atomic counter hands them out (solver.h:1520):
 // `base` is the id of the block visit's first batch on worker 0.
 // With hub rows trained by chains, the parts a batch of block (hp, tp) is trained as (GVX_HUB_PARTS; gvk.h `parts`).
+bool gvx_solver::hub_rounds_of(int hp, int tp) const {
+    if (!hubs || hub_rows[hp] + hub_rows[tp] == 0) return false;
+    if (hub_rounds_request >= 0) return hub_rounds_request != 0;
+    // The gradient steps of entries that work side by side from one state add up where the sequential loop's see each other; how much
+    // that matters grows with the norms of the rows a hub row meets, and those grow with how large a share of ALL training the
+    // largest hubs take — a property of the graph, not of the block (a block of the headline shape at P = 8 has a row that heads
+    // 8 % of its samples, yet that row is trained no more often than at P = 1: one round is within 0.001 AUC there, rounds add
+    // nothing).  Measured: one round of 16 x 16 entries stays with the reference's loop where the largest hub
+    // takes 1 % of the graph's degree (the headline shape, any P) and overshoots it by 0.004-0.008 AUC where it takes 6 % (even at
+    // 250 entries per part); rounds of four are within 0.001 on both.
+    (void)hp, (void)tp;
+    return hub_graph_share > kHubRoundShare;
+}
+
 int gvx_solver::hub_parts_of(int hp, int tp) const {
     const int B = batch_size;
     const uint32_t kv = hubs ? hub_rows[hp] : 0, kc = hubs ? hub_rows[tp] : 0;
@@ -1626,7 +1667,14 @@ int gvx_solver::hub_parts_of(int hp, int tp) const {
     // and, where every row is a hub row (a small table: many samples per row and batch), at least the parts
     // gvk_train_launches prescribes for it (§7.8: a chain then sees its partners at most a part old) —, a divisor of the
     // batch size, at most hub_max_parts (32; 50 for cache-resident tables)
-    int want = std::min(std::max((std::max(hub_top_entries[hp], hub_top_entries[tp]) + kHubEntriesPerPart / 2) / kHubEntriesPerPart, 1), hub_max_parts);
+    int want = std::max((std::max(hub_top_entries[hp], hub_top_entries[tp]) + kHubEntriesPerPart / 2) / kHubEntriesPerPart, 1);
+    // ... and so many that no row the chains do not own is expected to be hit more than kHubHitsPerPart times per part
+    want = std::max(want, (int)std::ceil(std::min(1e6, std::max(hub_next_hits[hp], hub_next_hits[tp]) / kHubHitsPerPart)));
+    // ... and, for the walk-ordered pools of DeepWalk / node2vec spread over the units (record i to unit i % units): one walk writes a
+    // node's pairs — it heads `augmentation_step` consecutive records and is the tail of as many, spread over the
+    // augmentation_step^2 + 1 records around them (graph.cuh:428-434) — so only with that many units no two of them share a unit
+    if (spread) want = std::max(want, config.augmentation_step * config.augmentation_step + 1);
+    want = std::min(want, hub_max_parts);
     if (kv == part_rows && kc == part_rows) want = std::max(want, gvk_train_launches(B, part_rows));
     int parts = 1;
     for (int q = want; q <= 2 * want && parts == 1 && want > 1; q++)
@@ -1675,7 +1723,11 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int
             // prescribes for it (§7.8): a chain then sees its partners at most a part old
             const int parts = hub_parts_of(hp, tp);
             const int chain_cap = hub_chain_cap_request;
-            const int form = (hub_lerp_request < 0 ? kHubLerp : hub_lerp_request) ? GVK_HOT_LERP : 0;
+            // rounds (gvk.h GVK_HOT_ROUNDS): where the parts a block can be given leave its largest hub row more updates per part than
+            // one round holds side by side — the parts rule aims at kHubEntriesPerPart = 250 = what 16 tasks of 16 entries hold; beyond
+            // kHubRoundEntries the gradient steps of entries that start from one state add up past the reference's loop
+            const bool rounds = hub_rounds_of(hp, tp);
+            const int form = ((hub_lerp_request < 0 ? kHubLerp : hub_lerp_request) ? GVK_HOT_LERP : 0) | (rounds ? GVK_HOT_ROUNDS : 0);
             size_t need = 0;
             GVK_TRY(gvk_hot_plan(dim, B, num_negative, kv, kc, hub_chunk, parts, chain_cap, &need));
             if (need > w.hub_workspace_bytes) {  // first block, or a block with more hub rows / parts than any before it
@@ -2176,10 +2228,13 @@ extern "C" int gvx_solver_get(gvx_solver *s, gvx_solver_members *out) {
     out->partition_rows = s->part_rows;
     out->transport = s->transport_name.c_str();
     out->hub_rows = s->hubs && !s->hub_rows.empty() ? *std::max_element(s->hub_rows.begin(), s->hub_rows.end()) : 0;
-    out->hub_parts = 0;
+    out->hub_parts = 0, out->hub_rounds = 0;
     if (out->hub_rows)
         for (int hp = 0; hp < s->num_partition; hp++)
-            for (int tp = 0; tp < s->num_partition; tp++) out->hub_parts = std::max(out->hub_parts, s->hub_parts_of(hp, tp));
+            for (int tp = 0; tp < s->num_partition; tp++) {
+                out->hub_parts = std::max(out->hub_parts, s->hub_parts_of(hp, tp));
+                out->hub_rounds = out->hub_rounds || s->hub_rounds_of(hp, tp);
+            }
     out->hub_lerp = out->hub_rows ? (s->hub_lerp_request < 0 ? kHubLerp : s->hub_lerp_request) : 0;
     return GVK_OK;
 }

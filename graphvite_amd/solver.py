@@ -248,6 +248,7 @@ class GraphSolver(object):
         self.hub_rows_request = -2 if hub_rows is None else (-1 if hub_rows == "auto" else int(hub_rows))
         self.hub_parts = 0  # GVX_HUB_PARTS (gvx.h): 0 = the rule
         self.hub_lerp = None  # GVX_HUB_LERP (gvx.h): None = the rule, False / True
+        self.hub_rounds = None  # GVX_HUB_ROUNDS (gvx.h): None = the rule, False / True: long chains in one round / in rounds
         self.hub_chain_cap = 0  # GVX_HUB_CHAIN_CAP (gvx.h): 0 = the kernels' default
         if fidelity is not auto and fidelity not in ("auto", "throughput", "reference"):
             raise ValueError("fidelity must be auto, 'throughput' or 'reference', not %r" % (fidelity,))
@@ -291,6 +292,7 @@ class GraphSolver(object):
                               (_lib.GVX_NODE2VEC_TABLE_LIMIT, int(self.node2vec_table_limit)),
                               (_lib.GVX_HUB_ROWS, int(self.hub_rows_request)), (_lib.GVX_HUB_PARTS, int(self.hub_parts)),
                               (_lib.GVX_HUB_LERP, -1 if self.hub_lerp is None else int(bool(self.hub_lerp))),
+                              (_lib.GVX_HUB_ROUNDS, -1 if self.hub_rounds is None else int(bool(self.hub_rounds))),
                               (_lib.GVX_HUB_CHAIN_CAP, int(self.hub_chain_cap)),
                               (_lib.GVX_FIDELITY, {"auto": -1, "throughput": 0, "reference": 1}[self.fidelity])):
             self._check(self._lib.gvx_solver_set(self._handle, option, value), "GraphSolver")
@@ -316,7 +318,7 @@ class GraphSolver(object):
         self.pair_order = {2: "grouped", 3: "spread"}.get(m.pair_order, "sampled")
         self.partition_rows = m.partition_rows
         self.hub_rows = m.hub_rows
-        self.hub_parts_used, self.hub_lerp_used = m.hub_parts_used, bool(m.hub_lerp_used)
+        self.hub_parts_used, self.hub_lerp_used, self.hub_rounds_used = m.hub_parts, bool(m.hub_lerp), bool(m.hub_rounds)
         self.transport = (m.transport or b"").decode()
         self.train_seconds = m.train_seconds
         self._mode = _MODES.get(m.sampler_mode, "edge")

@@ -189,11 +189,17 @@ int gvk_train_episode(void *stream, int dim, const gvk_optimizer *optimizer, int
  * both tables is a hub row the pairs have nothing to store and only run for the last batch (its loss).
  * chain_cap (the same in all three calls; 0 = the default and the most, 7): entries one chain task trains in sequence — what a
  * chain's record carries, so that a chain of up to chain_cap entries costs two dependent round trips (its record; its own row
- * and all partner rows at once).  A longer chain is cut into up to 256 / lanes tasks trained side by side by one workgroup and
- * composed in task order (weight decay in closed form; deterministic given the work lists); beyond that many tasks of chain_cap
- * entries the tasks grow. */
+ * and all partner rows at once).  A longer chain is one workgroup's: up to 256 / lanes tasks of consecutive entries (chain_cap
+ * each; longer tasks beyond that many) trained side by side and composed in task order (weight decay in closed form;
+ * deterministic given the work lists).  form & GVK_HOT_ROUNDS: tasks of more than GVK_HOT_ROUND_STEPS entries work in ROUNDS of
+ * that many — the tasks' end states are composed after every round and the next round starts from the composed row, so that
+ * no more than (256 / lanes) x GVK_HOT_ROUND_STEPS entries ever work side by side from the same state, however many updates a
+ * hub row meets in a unit (side by side, the entries' gradient steps add up where the sequential loop's see each other:
+ * measured on a graph whose largest hub heads 6 % of the samples; a round's end costs a barrier). */
+#define GVK_HOT_ROUND_STEPS 4 /* entries a task of a long chain applies per round when the caller asks for rounds (form GVK_HOT_ROUNDS) */
 #define GVK_HOT_SERIALIZED 1
 #define GVK_HOT_LERP 2
+#define GVK_HOT_ROUNDS 4
 int gvk_hot_plan(int dim, int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts,
                  int chain_cap, size_t *bytes);
 int gvk_hot_build(void *stream, int dim, void *workspace, size_t workspace_bytes, const uint32_t *pool, int batch_size,
@@ -336,6 +342,8 @@ int gvk_probe_row_traffic(void *stream, int dim, float *vertex, float *context, 
                                      holds at most `value` samples per row of the head table: default 2 (what keeps small
                                      partitions at the reference's learning quality); 0 = always one launch
                                      per batch */
+#define GVK_TUNE_ROUND_STEPS 12    /* gvk_train_episode_hot: entries a task of a long chain applies per round: -1 (default) = what the caller's form says,
+                                     0 = all of them in one round whatever the form says, 1 .. 8 = rounds of so many whatever it says */
 #define GVK_TUNE_HOT_ORDER 10      /* measurement: which blocks of a train_hot_kernel launch are dispatched first — 0 the chains, 1 (default)
                                      the long chains, then the pairs, then the other chains, 2 the pairs */
 #define GVK_TUNE_HOT_SERIALIZED 9 /* measurement: 1 = gvk_train_episode_hot always launches the chains and the pairs of a unit one after the

@@ -91,6 +91,7 @@ typedef struct {
     uint32_t hub_rows;           /* rows per table the last train() trained by chains (the largest partition value; 0 = none) */
     int32_t hub_parts;           /* ... the parts it trained a batch as (the largest block value; 0 = no hub rows) */
     int32_t hub_lerp;            /* ... 1 = its pairs read hub rows along the chains' way (gvk.h GVK_HOT_LERP) */
+    int32_t hub_rounds;          /* ... 1 = some block's long chains worked in rounds (gvk.h GVK_HOT_ROUNDS) */
 } gvx_solver_members;
 
 /* device_ids: num_device GPU ids (an id may repeat: its workers then share that GPU), or num_device == 0 for all
@@ -168,6 +169,9 @@ void gvx_solver_destroy(gvx_solver *s);
  * (gvk.h GVK_HOT_LERP).  GVX_HUB_CHAIN_CAP: entries one chain task trains in sequence (gvk.h chain_cap; 0 = the default). */
 #define GVX_HUB_LERP 9
 #define GVX_HUB_CHAIN_CAP 10
+/* GVX_HUB_ROUNDS -1 (default): the rule — long chains work in rounds (gvk.h GVK_HOT_ROUNDS) on graphs whose largest vertex takes
+ * more than 2 % of the total degree; 0 / 1: never / always. */
+#define GVX_HUB_ROUNDS 11
 int gvx_solver_set(gvx_solver *s, int option, int64_t value);
 
 /* The graph is borrowed until the next build / destroy (solver.h:289).  num_partition / episode_size: GVX_AUTO. */

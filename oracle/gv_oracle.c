@@ -188,14 +188,20 @@ static void gvo_chain(int dim, float *own, const float *partner, const uint32_t 
 
 /* The chains [first_chain, last_chain) of one unit (SGD): each over its entries in list order on its own row, which it reads
  * from `own_table` and leaves there; partner rows are read from `partner_vertex` / `partner_context` (the caller passes the
- * tables as the unit found them).  A chain longer than cap entries is trained as tasks of consecutive entries side by side
- * and the tasks are composed (below): tasks of cap entries, or — past max_tasks of them (0 = no limit) — of
- * ceil(n / max_tasks) entries, what one workgroup of the product trains (train_long_chains,
- * graphvite_amd/csrc/gvk_chains.hip).  gvo_set_long_task(t > 0) (executor-simulator experiments): tasks of t entries, as many
- * as it takes; t = 1 is "every entry of a long chain on its own from the row as the decay of the entries before it leaves it"
- * (measured in round 5: profiles/r5/experiments/r5_entries_side_by_side.txt). */
-static uint32_t gvo_long_task = 0;
+ * tables as the unit found them).  A chain longer than cap entries is trained by up to max_tasks tasks side by side, as one
+ * workgroup of the product trains it (train_long_chains, graphvite_amd/csrc/gvk_chains.hip): task g owns the consecutive
+ * entries [first + g per, first + (g + 1) per), per = cap or — past max_tasks tasks of cap entries (0 = no limit) —
+ * ceil(n / max_tasks).  The tasks work in ROUNDS of gvo_round_steps entries each (0: one round, the product's form until
+ * round 4): in round r every task applies its entries [r steps, (r + 1) steps) in sequence to the row as the round found it
+ * under the weight decay of the tasks before it in the round, and the round's end states are composed (below) into the row the
+ * next round starts from — so no more than max_tasks x gvo_round_steps entries ever work side by side from the same state,
+ * however many updates a hub row meets in a unit.  (The order in which a chain's entries are applied is then round by round,
+ * task by task: any order of a unit's samples is a sequential order.)
+ * gvo_set_long_task(t > 0) (executor-simulator experiments): tasks of t entries, as many as it takes, one round; t = 1 is
+ * "every entry of a long chain on its own" (measured in round 5: profiles/r5/experiments/r5_entries_side_by_side.txt). */
+static uint32_t gvo_long_task = 0, gvo_round_steps = 0;
 void gvo_set_long_task(uint32_t entries) { gvo_long_task = entries; }
+void gvo_set_round_steps(uint32_t steps) { gvo_round_steps = steps; }
 
 static int gvo_hot_chains(int dim, float *vertex, float *context, const float *partner_vertex, const float *partner_context,
                           float lr, float wd, float negative_weight, uint32_t kv, const uint32_t *chain_start,
@@ -206,6 +212,9 @@ static int gvo_hot_chains(int dim, float *vertex, float *context, const float *p
     float *own = (float *)malloc(sizeof(float) * dim);
     double *sum = (double *)malloc(sizeof(double) * dim);
     if (!own || !sum) return -1;
+    /* the decay factors of an entry in double: 1 - lr wd rounded to float is off by 3e-8, i.e. by 2e-4 of its distance from 1,
+     * which a chain of a thousand entries raises to 3e-5 of the row */
+    const double decay_positive = 1.0 - (double)lr * (double)wd, decay_negative = 1.0 - (double)lr * (double)negative_weight * (double)wd;
     for (uint32_t chain = first_chain; chain < last_chain; chain++) {
         float *row = chain < kv ? vertex + (size_t)chain * dim : context + (size_t)(chain - kv) * dim;
         const float *partner = chain < kv ? partner_context : partner_vertex;
@@ -217,30 +226,37 @@ static int gvo_hot_chains(int dim, float *vertex, float *context, const float *p
         uint32_t per = gvo_long_task ? gvo_long_task : cap;
         if (!gvo_long_task && max_tasks && (uint64_t)per * max_tasks < n) per = (n + max_tasks - 1) / max_tasks;
         (void)k;
+        const uint32_t steps = gvo_round_steps && !gvo_long_task && per > gvo_round_steps ? gvo_round_steps : per;
         /* tasks: weight decay composes in closed form (a factor per entry that depends on its label only), so every task
          * starts from the row as the decay of the entries before it leaves it, and its end state is carried through the
          * decay of the entries after it: row <- total row + sum over tasks (after end - total row) */
-        /* the decay factors of an entry in double: 1 - lr wd rounded to float is off by 3e-8, i.e. by 2e-4 of its distance from 1,
-         * which a chain of a thousand entries raises to 3e-5 of the row */
-        const double decay_positive = 1.0 - (double)lr * (double)wd, decay_negative = 1.0 - (double)lr * (double)negative_weight * (double)wd;
-        uint32_t positives_all = 0;
-        for (uint32_t p = first; p < last; p++) positives_all += entries[p] >> 31;
-        const float total = (float)(pow(decay_positive, (double)positives_all) * pow(decay_negative, (double)(n - positives_all)));
-        memset(sum, 0, sizeof(double) * dim);
-        uint32_t positives_before = 0;
-        for (uint32_t begin = first; begin < last; begin += per) {
-            const uint32_t end = last - begin > per ? begin + per : last;
-            uint32_t positives_inside = 0;
-            for (uint32_t p = begin; p < end; p++) positives_inside += entries[p] >> 31;
-            const uint32_t positives_after = positives_all - positives_before - positives_inside;
-            const float before = (float)(pow(decay_positive, (double)positives_before) * pow(decay_negative, (double)(begin - first - positives_before)));
-            const float after = (float)(pow(decay_positive, (double)positives_after) * pow(decay_negative, (double)(last - end - positives_after)));
-            for (int i = 0; i < dim; i++) own[i] = before * row[i];
-            gvo_chain(dim, own, partner, entries, begin, end, lr, wd, negative_weight);
-            for (int i = 0; i < dim; i++) sum[i] += (double)after * (double)own[i] - (double)total * (double)row[i];
-            positives_before += positives_inside;
+        for (uint32_t done = 0; done < per; done += steps) {  /* one round: the segment [done, done + steps) of every task's range */
+            uint32_t positives_all = 0, entries_all = 0;
+            for (uint32_t begin = first; begin < last; begin += per) {
+                const uint32_t end = last - begin > per ? begin + per : last;
+                for (uint32_t p = begin + done; p < end && p < begin + done + steps; p++) positives_all += entries[p] >> 31, entries_all++;
+            }
+            if (!entries_all) break;
+            const float total = (float)(pow(decay_positive, (double)positives_all) * pow(decay_negative, (double)(entries_all - positives_all)));
+            memset(sum, 0, sizeof(double) * dim);
+            uint32_t positives_before = 0, entries_before = 0;
+            for (uint32_t begin = first; begin < last; begin += per) {
+                const uint32_t end = last - begin > per ? begin + per : last;
+                const uint32_t from = begin + done < end ? begin + done : end, to = end - from > steps ? from + steps : end;
+                if (from == to) continue;  /* a task whose range ended in an earlier round */
+                uint32_t positives_inside = 0;
+                for (uint32_t p = from; p < to; p++) positives_inside += entries[p] >> 31;
+                const uint32_t positives_after = positives_all - positives_before - positives_inside;
+                const uint32_t entries_after = entries_all - entries_before - (to - from);
+                const float before = (float)(pow(decay_positive, (double)positives_before) * pow(decay_negative, (double)(entries_before - positives_before)));
+                const float after = (float)(pow(decay_positive, (double)positives_after) * pow(decay_negative, (double)(entries_after - positives_after)));
+                for (int i = 0; i < dim; i++) own[i] = before * row[i];
+                gvo_chain(dim, own, partner, entries, from, to, lr, wd, negative_weight);
+                for (int i = 0; i < dim; i++) sum[i] += (double)after * (double)own[i] - (double)total * (double)row[i];
+                positives_before += positives_inside, entries_before += to - from;
+            }
+            for (int i = 0; i < dim; i++) row[i] = (float)((double)total * (double)row[i] + sum[i]);
         }
-        for (int i = 0; i < dim; i++) row[i] = (float)((double)total * (double)row[i] + sum[i]);
     }
     free(own), free(sum);
     return 0;

@@ -35,8 +35,8 @@ for config in extra.get("configs", "hub=auto").split(";"):
     aucs = []
     if "GVK_LIBRARY" not in os.environ or "host" not in os.environ["GVK_LIBRARY"]:  # tune<key>=<value>: gvk_set_tuning (include/gvk.h), e.g. tune9=1
         from graphvite_amd.kernels import HipKernels
-        for key in (9, 10, 11):  # 11 = GVK_TUNE_HOT_GRAM (long chains by Gram matrices)
-            HipKernels().set_tuning(key, int(kw.get("tune%d" % key, 1 if key == 10 else 0)))
+        for key, default in ((9, 0), (10, 1), (12, -1)):  # GVK_TUNE_HOT_SERIALIZED, GVK_TUNE_HOT_ORDER, GVK_TUNE_ROUND_STEPS
+            HipKernels().set_tuning(key, int(kw.get("tune%d" % key, default)))
     for seed in [int(x) for x in extra.get("seeds", "1024").split(",")]:
         hub = kw.get("hub", "default")
         s = gv.solver.GraphSolver(128, num_sampler_per_worker=15, seed=seed, device_sampling=kw.get("device", "0") == "1",

@@ -121,7 +121,7 @@ def hub_row_rules():
         s = gv.solver.GraphSolver(32, num_sampler_per_worker=2, seed=1, **kw)
         s.build(g, batch_size=1000, episode_size=4)
         s.train(model=model, num_epoch=2, augmentation_step=1 if model == "LINE" else 2, log_frequency=1 << 30)
-        if want is None:  # rows a part of a batch (here: the 1000-sample batch) is expected to hit 0.125 times or more: most of 2000
+        if want is None:  # rows a batch (1000 samples) is expected to hit once or more: some of the 2000
             assert 0 < s.hub_rows < g.num_vertex, (name, s.hub_rows)
             trained.setdefault("expected hits", s.hub_rows)
             assert trained["expected hits"] == s.hub_rows
@@ -173,9 +173,14 @@ def hub_row_rules():
         tables[name] = s.vertex_embeddings.copy()
     assert np.abs(tables["linear"] - tables["callback"]).max() < 1e-6
     s = gv.solver.GraphSolver(32, num_sampler_per_worker=2, seed=1, hub_rows=50)
-    s.hub_parts = 7  # not a divisor of the batch size: the rule's parts stay
+    s.hub_parts = 7  # not a divisor of the batch size: an error, not a silent fall-back to the rule
     s.build(g, batch_size=1000, episode_size=4)
-    s.train(model="LINE", num_epoch=1, log_frequency=1 << 30)
+    try:
+        s.train(model="LINE", num_epoch=1, log_frequency=1 << 30)
+    except ValueError as e:
+        assert "must divide the batch size" in str(e)
+    else:
+        raise AssertionError("hub_parts = 7 does not divide a batch of 1000")
     # the embedding views keep the solver that owns their memory alive (the reference's binding does the same, bind.h:90-106)
     def views():
         t = gv.solver.GraphSolver(32, num_sampler_per_worker=1, seed=2)

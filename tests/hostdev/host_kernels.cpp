@@ -30,6 +30,7 @@ int gvo_hot_unit_chains(int dim, float *vertex, float *context, float lr, float 
                         const uint32_t *chain_start, const uint32_t *entries, uint32_t cap, uint32_t max_tasks, int k);
 void gvo_set_pairs_concurrent(int on);
 void gvo_set_long_task(uint32_t entries);
+void gvo_set_round_steps(uint32_t steps);
 int gvo_train_pairs_hot(int dim, float *vertex, float *context, const uint32_t *batch, const uint32_t *negatives, float *loss,
                         int batch_size, int k, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
                         const float *before_vertex, const float *before_context);
@@ -232,6 +233,9 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     // GVH_LONG_TASK=t (experiments): a chain of more than cap entries as tasks of t entries, as many as it takes (1: every entry on
     // its own); default 0: the device path's tasks of cap entries side by side, at most GVH_MAX_TASKS
     gvo_set_long_task(getenv("GVH_LONG_TASK") ? (uint32_t)atoi(getenv("GVH_LONG_TASK")) : 0u);
+    // form & GVK_HOT_ROUNDS: the tasks of a long chain work in rounds of GVK_HOT_ROUND_STEPS entries, the row re-composed between rounds
+    // (train_long_chains_in_rounds); GVH_ROUND_STEPS=s overrides (0: one round)
+    gvo_set_round_steps(getenv("GVH_ROUND_STEPS") ? (uint32_t)atoi(getenv("GVH_ROUND_STEPS")) : ((form & GVK_HOT_ROUNDS) ? (uint32_t)GVK_HOT_ROUND_STEPS : 0u));
     const int pipelined = strstr(executor, "pipelined") != nullptr, n = batch_size / parts, k = num_negative;
     if (getenv("GVH_CHAIN_CAP")) chain_cap = atoi(getenv("GVH_CHAIN_CAP"));
     const uint32_t cap = (uint32_t)std::min(chain_cap > 0 ? chain_cap : 7, 7);  // chain_cap_for, gvk_chains.hip

@@ -128,12 +128,14 @@ class Oracle(object):
         return start, entries[:n].copy()
 
     def train_hot(self, vertex, context, batch, negatives, lr, wd, negative_weight, hot_vertex, hot_context, chain_start,
-                  entries, cap, max_tasks=0, lerp=False, long_task=0):
+                  entries, cap, max_tasks=0, lerp=False, long_task=0, round_steps=0):
         """One unit in the product's serialized hub-chain form (gvk_train_episode_hot(serialized=1)): the chains of both
         families from the unit's start state, then its pairs (`lerp`: hub rows read along the chains' way); in place.
         A chain of more than cap entries: tasks of cap entries side by side, at most max_tasks of them (the tasks one workgroup of
-        the product trains: 256 / lanes per pair; 0 = no limit) — or, long_task > 0 (experiments), tasks of long_task entries."""
+        the product trains: 256 / lanes per pair; 0 = no limit), in rounds of round_steps entries per task (the product with form
+        GVK_HOT_ROUNDS: 4; 0 = one round) — or, long_task > 0 (experiments), tasks of long_task entries."""
         self.lib.gvo_set_long_task(int(long_task))
+        self.lib.gvo_set_round_steps(int(round_steps))  # gvk.h GVK_HOT_ROUNDS: rounds of GVK_HOT_ROUND_STEPS = 4 entries per task; 0 = one round
         B = batch.shape[0]
         k = negatives.size // B if B else 0
         loss = np.zeros(max(B, 1), np.float32)

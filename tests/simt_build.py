@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE: builds tests/hostdev/build/libsimt_chains.so — the SOURCE of the hub chains' device functions
-(train_long_chains / chain_steps, train_short_chains and the cross-lane helpers they use) cut out of
+(train_long_chains_one_round, train_long_chains_in_rounds, train_short_chains and the cross-lane helpers they use) cut out of
 graphvite_amd/csrc/gvk_chains.hip (and gvk_device.hpp) as written, compiled for the host over tests/hostdev/simt.h (one host thread per lane,
 cross-lane operations as rendezvous of a wavefront's 64 threads, __syncthreads as a barrier of 256)."""
 import os
@@ -32,7 +32,8 @@ struct Block {
 template <int DIM, int G>
 void block_of(const Block &t) {
     if (t.role == 1) train_short_chains<DIM, G>(*t.a, *t.h, t.block);
-    else train_long_chains<DIM, G>(*t.a, *t.h, t.block);
+    else if (t.h->round_steps) train_long_chains_in_rounds<DIM, G>(*t.a, *t.h, t.block);
+    else train_long_chains_one_round<DIM, G>(*t.a, *t.h, t.block);
 }
 
 void *block_main(void *p) {
@@ -52,7 +53,7 @@ void *block_main(void *p) {
 
 extern "C" int simt_unit_chains(int dim, float *vertex, float *context, uint32_t hot_vertex, uint32_t hot_context, float wd,
                                 float neg_weight, const uint32_t *chain_start, const uint32_t *entries, const uint32_t *long_list,
-                                const uint32_t *short_list, uint32_t long_capacity, uint32_t cap, const float *from, float *to, float lr,
+                                const uint32_t *short_list, uint32_t long_capacity, uint32_t cap, uint32_t round_steps, const float *from, float *to, float lr,
                                 float log2_decay_positive, float log2_decay_negative, int long_blocks, int short_blocks) {
     if (dim != 32 && dim != 64 && dim != 96 && dim != 128 && dim != 256 && dim != 512) return -1;
     static simt::Group g;
@@ -62,7 +63,7 @@ extern "C" int simt_unit_chains(int dim, float *vertex, float *context, uint32_t
     memset(&a, 0, sizeof(a)), memset(&h, 0, sizeof(h));
     a.vertex = vertex, a.context = context, a.hot_vertex = hot_vertex, a.hot_context = hot_context, a.wd = wd, a.neg_weight = neg_weight;
     h.chain_start = chain_start, h.entries = entries, h.long_list = long_list, h.short_list = short_list;
-    h.from = from, h.to = to, h.chains = hot_vertex + hot_context, h.long_capacity = long_capacity, h.cap = cap, h.lr = lr;
+    h.from = from, h.to = to, h.chains = hot_vertex + hot_context, h.long_capacity = long_capacity, h.cap = cap, h.round_steps = round_steps, h.lr = lr;
     h.log2_decay_positive = log2_decay_positive, h.log2_decay_negative = log2_decay_negative;
     h.long_blocks = long_blocks, h.short_blocks = short_blocks;
     pthread_attr_t attr;
@@ -101,11 +102,11 @@ def host_source():
         cut(common, "template <int CTRL>\n__device__ __forceinline__ float dpp(float x) {", "// ---- Philox4x32-10", include_end=False),
         cut(common, "template <int DIM, int G>\nstruct Layout {", "// ---- arithmetic", include_end=False),
         cut(common, "__device__ __forceinline__ float sigmoidf(float x) {", "\n}\n"),
-        # HotArgs, the chains of 1 .. 7 entries, the idle rows, chain_steps, train_long_chains: everything up to the kernel itself
+        # HotArgs, the chains of 1 .. 7 entries, the idle rows, train_long_chains: everything up to the kernel itself
         cut(text, "struct HotArgs {", "// HOT: 1 = the pairs read a hub row as the chains of their unit left it", include_end=False),
     ]
     body = "\n".join(pieces)
-    assert "asm volatile" not in body and "chain_steps" in body
+    assert "asm volatile" not in body and "train_long_chains_in_rounds" in body
     return body + "\n" + WRAPPER
 
 

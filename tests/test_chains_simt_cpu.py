@@ -2,7 +2,7 @@
 train_short_chains), compiled for the host as written over a stand-in for one wave64 workgroup (tests/hostdev/simt.h,
 tests/simt_build.py: one host thread per lane, DPP / shuffles / ballot as rendezvous of a wavefront's 64 threads, __syncthreads
 as a barrier of 256) and run against the oracle's chains (`gvo_hot_unit_chains`: chains of up to 7 entries in sequence, a longer
-chain as up to 256 / lanes tasks side by side, composed).  What is left to the GPU is whether the hardware's lane maps are the
+chain as up to 256 / lanes tasks side by side, composed — in one round, or in rounds of GVK_HOT_ROUND_STEPS = 4 entries per task (form GVK_HOT_ROUNDS)).  What is left to the GPU is whether the hardware's lane maps are the
 documented ones (tests/test_hub_chains_gpu.py)."""
 import ctypes as C
 import os
@@ -23,12 +23,13 @@ def simt():
     return C.CDLL(simt_build.build())
 
 
-def oracle_chain(oracle, dim, vertex, context, lr, wd, nw, kv, kc, chain_start, entries, cap, max_tasks, long_task=0):
+def oracle_chain(oracle, dim, vertex, context, lr, wd, nw, kv, kc, chain_start, entries, cap, max_tasks, long_task=0, round_steps=0):
     fn = oracle.lib.gvo_hot_unit_chains
     fp, up = np.ctypeslib.ndpointer(np.float32, flags="C"), np.ctypeslib.ndpointer(np.uint32, flags="C")
     fn.restype = C.c_int
     fn.argtypes = [C.c_int, fp, fp, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, up, up, C.c_uint32, C.c_uint32, C.c_int]
     oracle.lib.gvo_set_long_task(int(long_task))
+    oracle.lib.gvo_set_round_steps(int(round_steps))
     v, c = vertex.copy(), context.copy()
     assert fn(dim, v, c, lr, wd, nw, kv, kc, chain_start, entries, cap, max_tasks, 1) == 0
     return v, c
@@ -69,19 +70,22 @@ def records(start, entries, chains, cap):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("dim", [128, 32, 64, 96, 256, 512])
-def test_chain_side_of_a_unit_from_the_device_source(simt, dim):
+@pytest.mark.parametrize("dim,round_steps", [(128, 4), (128, 0), (128, 2), (128, 5), (128, 8), (32, 4), (32, 0), (64, 4), (64, 0), (96, 4), (96, 0), (256, 4), (256, 0), (512, 4), (512, 0)])
+def test_chain_side_of_a_unit_from_the_device_source(simt, dim, round_steps):
     """train_long_chains and train_short_chains as train_hot_kernel runs them — record lists, workgroup loops, the tasks of a long
     chain over the lane groups, composition in LDS — against gvo_hot_unit_chains on the same lists."""
     fp, up = np.ctypeslib.ndpointer(np.float32, flags="C"), np.ctypeslib.ndpointer(np.uint32, flags="C")
     simt.simt_unit_chains.restype = C.c_int
     simt.simt_unit_chains.argtypes = [C.c_int, fp, fp, C.c_uint32, C.c_uint32, C.c_float, C.c_float, up, up, up, up, C.c_uint32,
-                                      C.c_uint32, fp, fp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
+                                      C.c_uint32, C.c_uint32, fp, fp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
     rng = np.random.default_rng(31 * dim)
     oracle = Oracle()
     kv, kc, rows, samples, k, cap = 30, 44, 300, 2600, 1, 7
-    vertex = (rng.standard_normal((rows, dim)) * 0.3).astype(F)
-    context = (rng.standard_normal((rows, dim)) * 0.3).astype(F)
+    # rows of the same norm at every dim: with |c|^2 = 46 (0.3 per coordinate at dim 512) a step moves a logit by more than itself and
+    # rounding differences between two correct implementations grow from round to round
+    scale = 0.3 * min(1.0, (128.0 / dim) ** 0.5)
+    vertex = (rng.standard_normal((rows, dim)) * scale).astype(F)
+    context = (rng.standard_normal((rows, dim)) * scale).astype(F)
     lr, wd, nw = F(0.025), F(0.005), F(5.0)
     batch, negatives, start, entries = unit_lists(rng, rows, kv, kc, samples, k)
     chains = kv + kc
@@ -97,11 +101,11 @@ def test_chain_side_of_a_unit_from_the_device_source(simt, dim):
     to = mirror.copy()
     entries = np.ascontiguousarray(np.concatenate([entries, np.zeros(64, np.uint32)]))
     rc = simt.simt_unit_chains(dim, vertex, context, kv, kc, wd, nw, np.ascontiguousarray(start, np.uint32), entries, long_list,
-                               short_list, chains, cap, mirror, to, lr, F(np.log2(1.0 - float(lr) * float(wd))),
+                               short_list, chains, cap, round_steps, mirror, to, lr, F(np.log2(1.0 - float(lr) * float(wd))),
                                F(np.log2(1.0 - float(lr) * float(nw) * float(wd))), len(long_chains), -(-len(short_chains) // (256 // G)))
     assert rc == 0
     ov, oc = oracle_chain(oracle, dim, vertex, context, lr, wd, nw, kv, kc, np.ascontiguousarray(start, np.uint32), entries,
-                          cap, 256 // G)
+                          cap, 256 // G, round_steps=round_steps)
     want = np.concatenate([ov[:kv], oc[:kc]])
     for chain in range(chains):
         if lengths[chain] == 0 or chain in left_out:

@@ -67,11 +67,24 @@ def clean_rows(pool, allneg, N, kv, kc):
     return keep_v, keep_c
 
 
+@pytest.mark.parametrize("rounds", [0, 4])
 @pytest.mark.parametrize("by_class", [False, True])
 @pytest.mark.parametrize("dim,k,cap", [(128, 1, 0), (128, 1, 4), (128, 3, 5), (32, 1, 0), (64, 1, 3), (96, 2, 6), (256, 1, 0), (512, 1, 2)])
-def test_chains_match_the_oracle(hip, oracle, dim, k, cap, by_class):
+def test_chains_match_the_oracle(hip, oracle, dim, k, cap, by_class, rounds):
+    """rounds = 4: the long chains' tasks in rounds of four entries (gvk.h GVK_HOT_ROUNDS, asked for through GVK_TUNE_ROUND_STEPS here;
+    the oracle's gvo_set_round_steps)."""
     if by_class and (dim, k, cap) not in ((128, 1, 0), (128, 3, 5)):
         pytest.skip("the class table is exercised at dim 128")
+    if rounds and (by_class or cap not in (0, 6, 2)):
+        pytest.skip("rounds are exercised with the row table at every dim")
+    hip.set_tuning(12, rounds if rounds else -1)  # GVK_TUNE_ROUND_STEPS
+    try:
+        _chains_match_the_oracle(hip, oracle, dim, k, cap, by_class, rounds)
+    finally:
+        hip.set_tuning(12, -1)
+
+
+def _chains_match_the_oracle(hip, oracle, dim, k, cap, by_class, rounds):
     rng = np.random.default_rng(dim * 10 + k)
     # one batch: from the second batch on the chains would read rows that the first batch's pair launch trained Hogwild
     N, B, batches, kv, kc = 1 << 15, 1500, 1, 24, 40
@@ -98,6 +111,7 @@ def test_chains_match_the_oracle(hip, oracle, dim, k, cap, by_class):
     for ch in range(chains):
         assert (np.sort(en[st[ch]:st[ch + 1]]) == np.sort(entries[0, st[ch]:st[ch + 1]])).all(), ch
     longest = int(np.diff(st.astype(np.int64)).max())
+    assert not rounds or longest > rounds * (256 // LANES[dim])  # with rounds on, some chain works in more than one
     assert longest > cap_entries  # the hub rows of this case have long chains: tasks side by side, composed
     keep_v, keep_c = clean_rows(pool, nb, N, kv, kc)
     lr = oracle.lr(0.025, True, FIRST_ID, TOTAL)
@@ -107,7 +121,7 @@ def test_chains_match_the_oracle(hip, oracle, dim, k, cap, by_class):
         # within 1e-7 of the oracle's (summation order of the dot product, expf / exp2f of the device library)
         ov, oc = v.copy(), c.copy()
         oracle.train_hot(ov, oc, pool, nb, lr, 0.005, 5.0, kv, kc, starts[0], entries[0, :st[-1]], cap_entries,
-                         max_tasks=256 // LANES[dim], lerp=lerp)
+                         max_tasks=256 // LANES[dim], lerp=lerp, round_steps=rounds)
         for serialized in (True, False):
             tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
             loss = torch.zeros(B, device=DEV)
@@ -177,7 +191,7 @@ def test_hub_rows_keep_their_updates(hip, oracle):
     want = np.linalg.norm(sv[0] - v[0])
     print("a head row of 400 samples in one unit: chain %.4f, pair by pair %.4f of the sequential row's movement away from it" % (
         np.linalg.norm(results["chain"] - sv[0]) / want, np.linalg.norm(results["pair by pair"] - sv[0]) / want))
-    assert np.linalg.norm(results["chain"] - sv[0]) < 0.15 * want        # the chain: the sequential row (its partners read as the batch found them)
+    assert np.linalg.norm(results["chain"] - sv[0]) < 0.10 * want        # the chain: the sequential row (measured: 0.056; its partners read as the batch found them)
     assert np.linalg.norm(results["pair by pair"] - v[0]) < 0.5 * want   # one launch of concurrent pairs: most updates lost
 
 
@@ -321,9 +335,12 @@ def test_hub_rows_of_headline_batches_stay_with_the_sequential_loop(hip, oracle)
             report[name, upto] = off
             print("hub rows after %2d batch(es), %s table: distance from the sequential row / the row's own movement: rank 0 %.3f, 1 %.3f, 2 %.3f, "
                   "9 %.3f, 99 %.3f | median of the top 100 %.3f, max %.3f" % (upto, name, off[0], off[1], off[2], off[9], off[99], np.median(off), off.max()))
-    for key, off in report.items():
-        assert np.median(off) <= HUB_DISTANCE_MEDIAN and off.max() <= HUB_DISTANCE_MAX, (key, float(np.median(off)), float(off.max()))
+    for (name, upto), off in report.items():
+        median_bound, max_bound = HUB_DISTANCE[upto]
+        assert np.median(off) <= median_bound and off.max() <= max_bound, (name, upto, float(np.median(off)), float(off.max()))
 
 
-# measured on the MI355X (round 5, profiles/r5/): see DESIGN.md section 7 for the table these bounds come from
-HUB_DISTANCE_MEDIAN, HUB_DISTANCE_MAX = 0.5, 1.0
+# batches: (median, max) over the 100 largest hub rows of a table.  Measured on the MI355X (round 5, profiles/r5/parity_auc.log):
+# after 1 batch median 0.05-0.08, max 0.85-1.6 (one batch moves a row little: a single stale partner shows); after 20 batches
+# median 0.06, max 0.24-0.36.  The bounds are those plus a margin; pair by pair the same rows end 0.97 of their movement away.
+HUB_DISTANCE = {1: (0.15, 2.5), 20: (0.12, 0.6)}

@@ -44,7 +44,7 @@ def test_occupancy_the_kernels_are_built_for(resources):
     # the shipped per-pair kernel (dim 128, SGD, one negative drawn in the kernel): eight wavefronts per SIMD
     assert resources["train_kernel<128, 16, 0, 1, 1, 4>"]["occupancy"] == 8
     # hub rows by chains + the pairs of a unit in one launch: four (the short chains keep seven partner rows in flight)
-    for hot in ("train_hot_kernel<128, 16, 1, 1>", "train_hot_kernel<128, 16, 1, 2>", "train_hot_kernel<64, 16, 1, 1>", "train_hot_kernel<32, 8, 1, 1>"):
+    for hot in ("train_hot_kernel<128, 16, 1, 1, 0>", "train_hot_kernel<128, 16, 1, 1, 1>", "train_hot_kernel<128, 16, 1, 2, 0>", "train_hot_kernel<64, 16, 1, 1, 0>", "train_hot_kernel<32, 8, 1, 1, 1>"):
         assert resources[hot]["occupancy"] >= 4, (hot, resources[hot])
     # moment optimizers: waves per SIMD by the rows a lane group holds (train_waves)
     assert resources["train_kernel<256, 16, 4, 0, -1, 2>"]["occupancy"] == 2  # Adam, 16 floats per lane
