@@ -506,6 +506,19 @@ def main(argv=None):
     wall = time.perf_counter() - t0
     timing["on"] = False
     after = solver._exchange_stats()
+    # N > 1: one exchange on its own, nothing else in flight (fence before and after, wall clock, max over ranks): next to the
+    # kernels' time per visit it says whether a visit is kernel-limited or fabric-limited
+    exchange_ms = None
+    if world > 1:
+        isolated = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            session.exchange(walk["visit"] % session.steps)
+            fence()
+            isolated.append(time.perf_counter() - t1)
+        t = torch.tensor([min(isolated)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exchange_ms = float(t.item()) * 1e3
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -575,6 +588,8 @@ def main(argv=None):
         "exchange": {"collectives_timed": collectives,
                      "bytes_sent_per_gpu_per_collective": (after["bytes_sent_per_gpu"] - before["bytes_sent_per_gpu"]) // max(collectives, 1),
                      "transport": solver.transport,
+                     "isolated_ms": exchange_ms,  # one exchange with nothing else in flight (it overlaps the next visit's kernels in the timed region)
+                     "kernels_ms_per_visit": kernel_ms * args.block_batches,
                      "note": "one in-place ncclAllGather of a head group's slab per schedule step"}
         if world > 1 else None,
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
@@ -615,7 +630,16 @@ def main(argv=None):
             result["end_to_end"]["module"] = module_leg(args, world)
     if world > 1 and cuda:
         if rank == 0:
-            result["single_gpu_same_shards"] = same_shards_on_one_gpu(args, world)
+            same = result["single_gpu_same_shards"] = same_shards_on_one_gpu(args, world)
+            if "value" in same:  # what N GPUs deliver if nothing but their kernels limits them, and what was measured
+                expected = world * same["value"]
+                kernels, exchange = result["exchange"]["kernels_ms_per_visit"], result["exchange"]["isolated_ms"]
+                result["scaling_readout"] = {
+                    "expected_if_kernel_limited": expected, "measured": result["value"], "measured_over_expected": result["value"] / expected,
+                    "limited_by": "kernels" if result["value"] >= 0.9 * expected else
+                                  ("fabric: one exchange takes longer than a visit's kernels" if exchange and exchange > kernels else
+                                   "neither alone: imbalance between ranks, host pacing or exchanges that did not overlap"),
+                    "note": "expected = N x single_gpu_same_shards.value (the same shard size on ONE GPU: no exchange, no imbalance)"}
         dist.barrier()
     if rank == 0:
         print(json.dumps(result))

@@ -26,7 +26,7 @@ from oracle_lib import Oracle, ReferenceSolver, link_prediction_auc, reference_t
 PATH = os.path.join(HERE, "reference_c2.npz")
 N, E, GRAPH_SEED, BATCH = 1000000, 10000000, 1024, 100000
 EPOCHS = int(os.environ.get("EPOCHS", "50"))
-SEEDS = (17, 18, 19)
+SEEDS = (17, 18, 19, 20)
 
 
 def main():
@@ -35,7 +35,7 @@ def main():
     train, (valid, test) = synthetic.link_prediction_split(edges, (100, 1, 1))
     # sequential: three seeds; the two chunk-synchronous models of the reference's own <<<8192, 512>>> launch on a V100
     # (5120 resident warps; tests/golden/make_concurrency_golden.py): one seed each — the bracket the product is read against
-    jobs = [("sequential", 0, False, i, seed) for i, seed in enumerate(SEEDS)]
+    jobs = [("sequential", 0, False, i, seed) for i, seed in enumerate(SEEDS[:3])]
     jobs += [("lock_step", 5120, False, 0, SEEDS[0]), ("reads_at_start", 5120, True, 0, SEEDS[0])]
     jobs += [("p%d" % P, 0, False, i, SEEDS[i]) for P in (4, 2) for i in range(2)]
     # ... and with episodes of about 512 batches (episode_size 128 / 32 / 8 per block at P = 2 / 4 / 8) instead of the automatic
@@ -44,6 +44,8 @@ def main():
     jobs += [("p%d_e%d" % (P, E), 0, False, i, SEEDS[i]) for P, E in ((4, 32), (8, 8), (2, 128)) for i in range(2)]
     # a third seed where the product sits near the tolerance (P = 8: the two-seed means differ by 0.0022; seeds differ by 0.001)
     jobs += [("p%d_e%d" % (P, E), 0, False, 2, SEEDS[2]) for P, E in ((8, 8), (4, 32), (2, 128))]
+    # a fourth (round 5: the product side runs four seeds as well; means and their standard errors are compared, tests/util.py compare_auc)
+    jobs += [("p%d_e%d" % (P, E), 0, False, 3, SEEDS[3]) for P, E in ((8, 8), (4, 32), (2, 128))]
     if len(sys.argv) > 1:
         jobs = [j for j in jobs if j[0] in sys.argv[1:]]
     for model, chunk, reads_at_start, i, seed in jobs:
@@ -51,7 +53,7 @@ def main():
         partitions = int(model[1:].split("_e")[0]) if model[0] == "p" and model[1:].split("_e")[0].isdigit() else 1
         episode = int(model.split("_e")[1]) if "_e" in model else 0  # 0: automatic
         out = dict(np.load(PATH)) if os.path.exists(PATH) else {}
-        values = out.get(key, np.full(len(SEEDS) if model == "sequential" else (2 if partitions > 1 else 1), np.nan))
+        values = out.get(key, np.full(3 if model == "sequential" else (2 if partitions > 1 else 1), np.nan))
         if i >= len(values):
             values = np.concatenate([values, np.full(i + 1 - len(values), np.nan)])
         if not np.isnan(values[i]):

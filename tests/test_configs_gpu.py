@@ -133,6 +133,9 @@ def test_moment_optimizers_on_the_headline_shape(job, optimizer):
         auc, reference, info = train(job, seed, optimizer=make())
         aucs.append(auc)
     here, ref = np.mean(aucs), reference[~np.isnan(reference)].mean()
+    if ref < 0.55:
+        pytest.skip("the reference's own loop ends at AUC %.3f with this optimizer on this shape (below 0.5: true edges rank BELOW random pairs — "
+                    "nothing learnt to compare); here %.3f" % (ref, here))
     print("headline shape, %s: AUC here %s (mean %.6f) | reference training loop %s (mean %.6f) | difference %+.6f | %s" % (
         optimizer, " ".join("%.6f" % a for a in aucs), here, " ".join("%.6f" % a for a in reference), ref, here - ref, info))
     assert abs(here - ref) <= MOMENT_BOUND[optimizer]
