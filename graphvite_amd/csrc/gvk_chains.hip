@@ -32,6 +32,11 @@ namespace {
 // A chain longer than `cap` entries is a LONG chain: a whole workgroup trains it, up to kBlock / G tasks of consecutive
 // entries side by side, composed through LDS in task order — deterministic given the work lists, no atomics.  The chains'
 // work lists are built by hot_list_kernel.
+#if !defined(GVK_HOT_BLOCK)
+#define GVK_HOT_BLOCK 256
+#endif
+constexpr int kHotBlock = GVK_HOT_BLOCK;  // threads of a train_hot_kernel workgroup: kHotBlock / lanes lane groups = the most tasks of a long chain
+
 struct HotArgs {
     const uint32_t *chain_start;  // [chains + 1] offsets of this unit into entries
     const uint32_t *before_start[2];  // the same of the one or two units before it (null: none): which rows the mirror `to` has missed
@@ -70,7 +75,7 @@ template <int DIM, int G>
 struct ChainShape {
     static constexpr int V = DIM / G;
     static constexpr int D = V <= 4 ? 8 : (V <= 8 ? 4 : 2);  // partner rows in flight per lane group of a long chain's task
-    static constexpr int NG = kBlock / G;     // lane groups of a block = most tasks of a long chain
+    static constexpr int NG = kHotBlock / G;  // lane groups of a block = most tasks of a long chain
     static_assert(D <= G, "the entry window is two fetches of G entries");
 };
 
@@ -575,7 +580,7 @@ __device__ __forceinline__ void train_long_chains_in_rounds(const TrainArgs &a, 
 // at dims 256 and 512, sixteen floats of a row per lane): the chains and the pairs of a unit of the sizes this kernel trains (a
 // part of a batch) are then resident side by side.
 template <int DIM, int G, int KT, int HOT, int ROUNDS>
-__global__ void __launch_bounds__(kBlock, DIM / G > 12 ? 3 : 4) train_hot_kernel(const TrainArgs a, const HotArgs h) {
+__global__ void __launch_bounds__(kHotBlock, DIM / G > 12 ? 3 : 4) train_hot_kernel(const TrainArgs a, const HotArgs h) {
     // the grid: [long chains | pairs | short chains | idle rows] — the long chains, whose tasks wait for memory three times in
     // a row, are dispatched first, the bulk (the pairs) next; the short chains and the copies fill in behind
     const int b = blockIdx.x;
@@ -589,7 +594,7 @@ __global__ void __launch_bounds__(kBlock, DIM / G > 12 ? 3 : 4) train_hot_kernel
         else train_long_chains_one_round<DIM, G>(a, h, b - long_first);
     } else if (b >= pairs_first && b < pairs_first + h.pair_blocks) {
         GVK_STAMP_VALUE(h, 0, 3);
-        train_pair<DIM, G, GVK_SGD, KT, 1, HOT>(a, (b - pairs_first) * kBlock + threadIdx.x);
+        train_pair<DIM, G, GVK_SGD, KT, 1, HOT>(a, (b - pairs_first) * kHotBlock + threadIdx.x);
         GVK_STAMP(h, 5);  // thread 0's sample is trained (its stores are on their way)
     } else if (b >= short_first && b < short_first + h.short_blocks) {
         train_short_chains<DIM, G>(a, h, b - short_first);
@@ -872,13 +877,13 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     memset(&h, 0, sizeof(h));
     h.chains = l.chains; h.long_capacity = l.long_capacity; h.cap = l.cap;
     h.round_steps = round_steps;
-    const int groups = kBlock / lanes;
+    const int groups = kHotBlock / lanes;
     const int short_blocks = (int)((l.chains + groups - 1) / groups);
     const int long_blocks = (int)std::min<uint32_t>(l.long_capacity, (uint32_t)kLongBlocks);
     const int copy_blocks = (int)((l.chains + 4 * groups - 1) / (4 * groups));
     // the unit of work is a PART of a batch (parts = 1: the batch): unit u = part u % parts of batch u / parts
     const int part_size = batch_size / parts, units = num_batches * parts;
-    const unsigned pair_blocks = (unsigned)(((int64_t)part_size * lanes + kBlock - 1) / kBlock);
+    const unsigned pair_blocks = (unsigned)(((int64_t)part_size * lanes + kHotBlock - 1) / kHotBlock);
     if (num_batches == 0) return GVK_OK;
     // when every row of both tables is a hub row the pairs have nothing to store: they run for the last batch only, whose
     // per-sample loss a caller may read
@@ -936,7 +941,7 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
         h.stamps = grid > kStampBlocks ? nullptr : stamps;
         if (h.stamps && hipMemsetAsync(stamps, 0, kStampBlocks * 64, (hipStream_t)stream) != hipSuccess) h.stamps = nullptr;
 #endif
-        if (grid) hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, a, h);
+        if (grid) hipLaunchKernelGGL(kernel, dim3(grid), dim3(kHotBlock), 0, (hipStream_t)stream, a, h);
 #if defined(GVK_TIMESTAMPS)
         // GVK_STAMP_FILE=<prefix>: the stamps of the first 64 launches that carry chains and pairs, each run on its own (the stream
         // is drained after it), to <prefix>.<n>: eight ints {grid, long, pair, short, copy blocks, order, -, -}, then the records

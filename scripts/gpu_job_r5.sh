@@ -10,7 +10,7 @@ O=$R/gpurun_out
 mkdir -p $O
 timeout 2800 python -m pytest tests -q -m gpu -rP > $O/pytest_gpu_full.log 2>&1
 grep -E "passed|failed" $O/pytest_gpu_full.log | tail -2; grep -E "^FAILED" $O/pytest_gpu_full.log
-grep -hE "^(headline|tube|hub100k|blog|AUC here|module)" $O/pytest_gpu_full.log > $O/parity_auc.log
+grep -hE "^(headline|tube|hub100k|blog|module|friendster|youtube|held|hub rows after|a head row|DeepWalk over)|AUC here" $O/pytest_gpu_full.log | grep -v "print(" > $O/parity_auc.log
 timeout 1200 python bench.py --steps 20 --warmup 5 > $O/bench_n1_steps20.json 2> $O/bench_n1_steps20.err
 tail -c 1500 $O/bench_n1_steps20.json
 SHORT="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-end-to-end --no-module"
@@ -20,6 +20,14 @@ for counter in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $counter --output-format csv -d $O/pmc_${counter}_128 -- $SHORT > $O/pmc_${counter}_128.log 2>&1
 done
 timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_L2_128 -- $SHORT > $O/pmc_L2_128.log 2>&1
+# traffic by role: the serialized form (--tune 9=1) launches a unit's chains and its pairs one after the other — which of partner rows,
+# mirror rows and records the bytes beyond the algorithmic ones are (summarize_profiles.py splits the dispatches by grid size)
+for counter in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $counter --output-format csv -d $O/pmc_${counter}_roles -- $SHORT --tune 9=1 > $O/pmc_${counter}_roles.log 2>&1
+done
+timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_L2_roles -- $SHORT --tune 9=1 > $O/pmc_L2_roles.log 2>&1
+# the shard size of an 8-GPU run on this one GPU: kernel trace
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kernel_p8 -- $SHORT --partitions 8 > $O/prof_kernel_p8.log 2>&1
 cd $R
 find $O -name "*kernel_trace.csv" -size +30M -delete
 # the summary of this job's passes, then the bench line that may quote it
@@ -31,5 +39,7 @@ if [ -f profiles/r5/pmc_summary_bench_n1.json ]; then
   tail -c 600 $O/bench_n1_steps20_with_traffic.json
 fi
 timeout 600 python bench.py --steps 400 --warmup 50 --no-end-to-end --no-module > $O/bench_n1.json 2> $O/bench_n1.err
+for p in 2 4 8; do timeout 300 python bench.py --steps 200 --warmup 20 --partitions $p --no-cpu-baseline --no-end-to-end --no-module --no-access-pattern 2>/dev/null | tail -n 1; done > $O/bench_by_partitions.jsonl
+timeout 900 python scripts/measure_configs.py --epochs 100 > $O/configs_2_4.jsonl 2> $O/configs_2_4.err; tail -c 400 $O/configs_2_4.jsonl
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
 tail -2 $O/smoke.log

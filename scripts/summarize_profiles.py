@@ -20,7 +20,7 @@ def find(directory, suffix):
     return hits[0] if hits else None
 
 
-for name in ("bench_n1.json", "bench_n1_steps20.json", "configs_2_4.jsonl", "configs_4.jsonl", "friendster_shard.json", "engine_e2e.jsonl", "access_pattern_probe.jsonl", "dim_sweep.jsonl", "shard_sweep.jsonl", "parity_auc.log", "c2_parity.log", "pytest_gpu_full.log", "smoke.log", "bench_n1_steps20_throughput.json", "bench_n1_steps20_with_traffic.json"):
+for name in ("bench_n1.json", "bench_n1_steps20.json", "configs_2_4.jsonl", "configs_4.jsonl", "friendster_shard.json", "engine_e2e.jsonl", "access_pattern_probe.jsonl", "dim_sweep.jsonl", "shard_sweep.jsonl", "parity_auc.log", "c2_parity.log", "pytest_gpu_full.log", "smoke.log", "bench_n1_steps20_throughput.json", "bench_n1_steps20_with_traffic.json", "bench_by_partitions.jsonl"):
     if os.path.exists(os.path.join(SRC, name)) and os.path.getsize(os.path.join(SRC, name)):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, name))
 
@@ -97,6 +97,47 @@ for dim in (32, 64, 96, 128, 256, 512):
         json.dump(out, open(os.path.join(DST, "pmc_summary_bench_n1.json"), "w"), indent=1)
     by_dim["dim_%d" % dim] = entry
     print("dim %d: traffic / algorithmic = %.3f" % (dim, entry["traffic_over_algorithmic"]))
+# ---- traffic by role: the serialized form's launches are a unit's chains (long + short + idle-row blocks) or its pairs ----------------
+def by_role(directory):
+    path = find(directory, "counter_collection.csv")
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    if path:
+        for r in csv.DictReader(open(path)):
+            if "train_hot_kernel" in r["Kernel_Name"]:
+                grid = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)))
+                acc["pairs" if grid < 250000 else "chains"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {role: {k: sum(v) / len(v) for k, v in c.items()} for role, c in acc.items()}
+
+
+roles = {}
+for directory, names in (("pmc_FETCH_SIZE_roles", ("FETCH_SIZE",)), ("pmc_WRITE_SIZE_roles", ("WRITE_SIZE",)), ("pmc_L2_roles", ("TCC_HIT_sum", "TCC_MISS_sum"))):
+    for role, values in by_role(directory).items():
+        roles.setdefault(role, {}).update(values)
+if roles:
+    for role, v in roles.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            v["traffic_bytes_per_launch"] = 2 * v["FETCH_SIZE"] * 1024 + v["WRITE_SIZE"] * 1024
+        if "TCC_HIT_sum" in v:
+            v["l2_hit_rate"] = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
+    roles["note"] = ("bench.py --tune 9=1 (GVK_TUNE_HOT_SERIALIZED): per unit one launch of its chains, then one of its pairs; means per launch; "
+                     "FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE doubled in traffic_bytes_per_launch, MI355X_MICROARCH.md); the pairs' algorithmic "
+                     "bytes per launch: %d" % PER_LAUNCH)
+    json.dump(roles, open(os.path.join(DST, "pmc_summary_by_role.json"), "w"), indent=1)
+    print("traffic by role:", json.dumps({k: v.get("traffic_bytes_per_launch") for k, v in roles.items() if isinstance(v, dict)}))
+
+# ---- the shard size of an 8-GPU run: kernel trace -------------------------------------------------------------------------
+trace8 = find("prof_kernel_p8", "kernel_trace.csv")
+if trace8:
+    rows8 = [r for r in csv.DictReader(open(trace8)) if "train_hot_kernel" in r["Kernel_Name"]]
+    dur8 = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows8]
+    if dur8:
+        json.dump({"command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --partitions 8 ...", "kernel": rows8[0]["Kernel_Name"],
+                   "launches": len(dur8), "mean_ns": sum(dur8) / len(dur8), "min_ns": min(dur8), "max_ns": max(dur8)},
+                  open(os.path.join(DST, "kernel_trace_summary_bench_p8.json"), "w"), indent=1)
+    stats8 = find("prof_kernel_p8", "kernel_stats.csv")
+    if stats8:
+        shutil.copy(stats8, os.path.join(DST, "kernel_stats_bench_p8.csv"))
+
 fetch, kernel = counters("pmc_FETCH_SIZE_shard96")
 write, _ = counters("pmc_WRITE_SIZE_shard96")
 if "FETCH_SIZE" in fetch and "WRITE_SIZE" in write:  # configs[4]'s kernel: dim 96 on one Friendster shard (8.2M rows)

@@ -6,6 +6,8 @@ lists — chains of both families from the unit's start state, long chains as ta
 the chains left them or along their way (lerp) —, and (3) that the pipelined product form stays with it; what the chains are
 FOR — the reference's learning quality on hub-heavy shapes — is pinned end to end in tests/test_solver_gpu.py."""
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -16,6 +18,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 SEED, FIRST_ID, TOTAL = 5, 7, 100
 LANES = {32: 8, 64: 16, 96: 8, 128: 16, 256: 16, 512: 32}  # lanes per pair = per chain (default_lanes, gvk_tuning.h)
+HOT_BLOCK = int(os.environ.get("GVK_TEST_HOT_BLOCK", "256"))  # threads of a train_hot_kernel workgroup (gvk_chains.hip kHotBlock; a measurement variant may differ)
 
 
 def layout(batch_size, k, chains, num_batch, cap, parts=1):
@@ -111,7 +114,7 @@ def _chains_match_the_oracle(hip, oracle, dim, k, cap, by_class, rounds):
     for ch in range(chains):
         assert (np.sort(en[st[ch]:st[ch + 1]]) == np.sort(entries[0, st[ch]:st[ch + 1]])).all(), ch
     longest = int(np.diff(st.astype(np.int64)).max())
-    assert not rounds or longest > rounds * (256 // LANES[dim])  # with rounds on, some chain works in more than one
+    assert not rounds or longest > rounds * (HOT_BLOCK // LANES[dim])  # with rounds on, some chain works in more than one
     assert longest > cap_entries  # the hub rows of this case have long chains: tasks side by side, composed
     keep_v, keep_c = clean_rows(pool, nb, N, kv, kc)
     lr = oracle.lr(0.025, True, FIRST_ID, TOTAL)
@@ -121,7 +124,7 @@ def _chains_match_the_oracle(hip, oracle, dim, k, cap, by_class, rounds):
         # within 1e-7 of the oracle's (summation order of the dot product, expf / exp2f of the device library)
         ov, oc = v.copy(), c.copy()
         oracle.train_hot(ov, oc, pool, nb, lr, 0.005, 5.0, kv, kc, starts[0], entries[0, :st[-1]], cap_entries,
-                         max_tasks=256 // LANES[dim], lerp=lerp, round_steps=rounds)
+                         max_tasks=HOT_BLOCK // LANES[dim], lerp=lerp, round_steps=rounds)
         for serialized in (True, False):
             tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
             loss = torch.zeros(B, device=DEV)
@@ -227,7 +230,7 @@ def test_a_batch_trained_as_parts(hip, oracle):
             for ch in range(chains):
                 assert (np.sort(en[st[ch]:st[ch + 1]]) == np.sort(entries[q, st[ch]:st[ch + 1]])).all()
             oracle.train_hot(ov, oc, pool[lo:hi], nb[lo:hi], lr, 0.005, 5.0, kv, kc, starts[q], entries[q, :st[-1]], cap_entries,
-                             max_tasks=16, lerp=lerp)
+                             max_tasks=HOT_BLOCK // 16, lerp=lerp)
         tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
         loss = torch.zeros(B, device=DEV)
         hip.train_episode_hot(tv, tc, dpool, loss, opt, k, 5.0, table, SEED, FIRST_ID, TOTAL, 1, B, ws, kv, kc, serialized=True,
@@ -256,7 +259,7 @@ def test_a_batch_trained_as_parts(hip, oracle):
         b, lo = u // 3, (u % 3) * 100
         oracle.train_hot(ov, oc, small[b * 300 + lo:b * 300 + lo + 100], nb2[b, lo:lo + 100].reshape(100, 1),
                          oracle.lr(0.025, True, FIRST_ID + b, TOTAL), 0.005, 5.0, 64, 64, starts2[u], entries2[u, :starts2[u, -1]],
-                         cap2, max_tasks=16)
+                         cap2, max_tasks=HOT_BLOCK // 16)
     for serialized in (True, False):  # nothing but hub rows: the pipelined form reads and writes the same mirrors
         tv, tc = torch.from_numpy(small_v).to(DEV), torch.from_numpy(small_c).to(DEV)
         hip.train_episode_hot(tv, tc, dsmall, loss, opt, 1, 5.0, t2, SEED, FIRST_ID, TOTAL, 2, 300, ws2, 64, 64, parts=3,
