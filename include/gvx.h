@@ -145,15 +145,16 @@ void gvx_solver_destroy(gvx_solver *s);
  * 656-677) beyond which the CPU samplers switch to rejection over the per-vertex tables (default 2^30). */
 #define GVX_NODE2VEC_TABLE_LIMIT 5
 /* GVX_HUB_ROWS (SGD): the hub rows of every partition are trained by chains (gvk_train_episode_hot): one
- * wavefront per hub row applies all the updates a batch has for the row one after the other, so none of them is lost to a
- * concurrent one.  -2 (default): where that is pinned against the reference's training loop — DeepWalk /
- * node2vec on one partition of at most 16384 rows: every row is a hub row —, off otherwise; -1: the rows a batch is expected
- * to hit once or more (by degree share; at most 16384 per table); N > 0: the first N rows of every partition; 0: off.
- * Batches keep the sampler's order. */
+ * lane group per hub row applies all the updates a unit has for the row one after the other, so none of them is lost to a
+ * concurrent one.  -2 (default): as GVX_FIDELITY says — with `auto`, -1 wherever chains exist (DeepWalk / node2vec on one
+ * partition of at most 16384 rows: every row); -1: the rows a batch is expected to hit once or more (by its share of the
+ * partition's degree, or of degree^exponent as a negative; at most 16384 per table); N > 0: the first N rows of every
+ * partition; 0: off.  Batches keep the sampler's order (walk-ordered pools: spread over the units). */
 #define GVX_HUB_ROWS 6
-/* GVX_HUB_PARTS: with hub rows trained by chains, a batch is trained as this many equal parts (a divisor of the batch size),
- * each with its own chains and pairs; 0 (default): gvk_train_launches() parts where every row is a hub row, otherwise so many
- * that the largest hub row meets about 250 of its updates per part. */
+/* GVX_HUB_PARTS: with hub rows trained by chains, a batch is trained as this many equal parts (it must divide the batch size:
+ * otherwise train() fails), each with its own chains and pairs; 0 (default): the rule — the largest hub row meets about 250 of its
+ * updates per part, no row outside the chains is expected to be hit more than 0.125 times per part, walk-ordered pools get at
+ * least augmentation_step^2 + 1 parts; at most 32 (gvk_train_launches() parts where every row is a hub row). */
 #define GVX_HUB_PARTS 7
 /* GVX_FIDELITY -1 (default, `auto`): the reference's learning quality wherever chains exist — on tables that do not live in
  * the caches, the rows a batch is expected to hit once or more are trained by chains (GVX_HUB_ROWS -1) and a batch as so many
@@ -166,7 +167,8 @@ void gvx_solver_destroy(gvx_solver *s);
 #define GVX_FIDELITY 8
 /* GVX_HUB_LERP -1 (default): the rule; 0 / 1: with hub rows trained by chains, a sample reads a hub row as the chains of its
  * part left it / on the straight line from where they found it to where they left it, at the sample's place in the part
- * (gvk.h GVK_HOT_LERP).  GVX_HUB_CHAIN_CAP: entries one chain task trains in sequence (gvk.h chain_cap; 0 = the default). */
+ * (gvk.h GVK_HOT_LERP).  GVX_HUB_CHAIN_CAP: entries one chain trains in sequence before it counts as a long chain (gvk.h chain_cap;
+ * 0 = the default, 7; larger values are clamped to 7). */
 #define GVX_HUB_LERP 9
 #define GVX_HUB_CHAIN_CAP 10
 /* GVX_HUB_ROUNDS -1 (default): the rule — long chains work in rounds (gvk.h GVK_HOT_ROUNDS) on graphs whose largest vertex takes
