@@ -778,6 +778,7 @@ int gvx_solver::configure(const gvx_train_config &in) {
     grouped = pair_order_request == 2 ||
               (pair_order_request == 0 && dim >= 64 && !walk_ordered() &&
                (table_bytes < ((size_t)16 << 20) || (table_bytes < ((size_t)256 << 20) && mode == GVS_MODE_EDGE)));
+    spread = walk_ordered() && pair_order_request != 1 && !grouped;  // hub_parts_of reads it (refined below once the hub rows are known)
     // hub rows (GVX_HUB_ROWS): the rows a part of a batch is expected to hit kHubHitsPerPart times or more — as a head / tail (degree share of
     // the partition) or as a negative (share of degree^exponent) — are trained by chains; their batches keep the sampler's order
     hub_rows.assign(num_partition, 0);

@@ -97,7 +97,7 @@ def cut(text, begin, end, include_end=True):
 def host_source():
     common, text = open(COMMON).read(), open(SOURCE).read()
     pieces = [
-        '#include "simt.h"\n#include <algorithm>\nstruct gvk_alias_entry;\nstruct gvk_class_entry;\nnamespace {\nconstexpr int kBlock = 256;\n',
+        '#include "simt.h"\n#include <algorithm>\nstruct gvk_alias_entry;\nstruct gvk_class_entry;\nnamespace {\nconstexpr int kBlock = 256, kHotBlock = 256;\n',
         cut(common, "struct TrainArgs {", "\n};\n"),
         cut(common, "template <int CTRL>\n__device__ __forceinline__ float dpp(float x) {", "// ---- Philox4x32-10", include_end=False),
         cut(common, "template <int DIM, int G>\nstruct Layout {", "// ---- arithmetic", include_end=False),
