@@ -103,7 +103,9 @@ gvx_solver *gvx_solver_create(int dim, const int *device_ids, int num_device, in
  * calls are collective over the world_size processes, operate on memory of the engine's device, may be asynchronous on
  * `stream` (the engine orders its own work behind that stream) and return GVK_OK or a negative code.
  *   all_gather  in place: `slab` holds world_size parts of `bytes` bytes, this rank's part already at slab + rank * bytes;
- *   all_to_all  part q of `send` arrives as part `rank` of rank q's `recv` (world_size parts of `bytes` bytes each). */
+ *   all_to_all  part q of `send` arrives as part `rank` of rank q's `recv` (world_size parts of `bytes` bytes each).
+ * Besides the exchanges of train(), build() calls all_gather twice with 4 bytes per rank (the ranks agree on the episode size every
+ * one of them can allocate: gvx_engine.cpp allocate_pools) — on every rank, whatever happened to the rank locally. */
 typedef struct {
     int (*all_gather)(void *user, void *slab, size_t bytes, void *stream);
     int (*all_to_all)(void *user, const void *send, void *recv, size_t bytes, void *stream);
