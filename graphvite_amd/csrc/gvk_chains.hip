@@ -32,6 +32,40 @@ namespace {
 // A chain longer than `cap` entries is a LONG chain: a whole workgroup trains it, up to kBlock / G tasks of consecutive
 // entries side by side, composed through LDS in task order — deterministic given the work lists, no atomics.  The chains'
 // work lists are built by hot_list_kernel.
+// The logistic function of a chain step: v_exp_f32 + v_rcp_f32 — about 1e-7 relative, a dozen instructions where the expf and the
+// division of sigmoidf (the pairs' form) take about forty.  A chain's step is a dependency chain of ~100 instructions that nothing
+// else on its SIMD hides: at the shard size of an 8-GPU run, where a launch IS its longest chain, 13.0 -> 11.9 us per launch
+// (profiles/r5/experiments/r5_chain_step_instructions.txt).  GVK_CHAIN_SIGMOID=0 builds the chains with sigmoidf.
+#if !defined(GVK_CHAIN_SIGMOID)
+#define GVK_CHAIN_SIGMOID 1
+#endif
+__device__ __forceinline__ float chain_sigmoid(float x) {
+#if GVK_CHAIN_SIGMOID && !defined(GVK_SIMT_HOST)
+    const float t = __builtin_amdgcn_exp2f(-fabsf(x) * 1.44269504088896340736f);
+    return (x > 0 ? 1.0f : t) * __builtin_amdgcn_rcpf(1.0f + t);
+#else
+    return sigmoidf(x);
+#endif
+}
+
+// own <- own - lr w (g c + wd own)  (optimizer.h:161-164).  GVK_CHAIN_UPDATE_FORM=1 (measurement variant): as (1 - lr w wd) own - (lr w g) c, two
+// instructions per element instead of three — but the dim-128 build then spills 20 bytes
+#if !defined(GVK_CHAIN_UPDATE_FORM)
+#define GVK_CHAIN_UPDATE_FORM 0
+#endif
+#if GVK_CHAIN_UPDATE_FORM
+#define GVK_CHAIN_UPDATE(own, c, weight, gradient)                                             \
+    do {                                                                                       \
+        const float keep_ = 1.0f - h.lr * (weight) * a.wd, push_ = h.lr * (weight) * (gradient); \
+        _Pragma("unroll") for (int x = 0; x < V; x++) own[x] = keep_ * own[x] - push_ * c[x];  \
+    } while (0)
+#else
+#define GVK_CHAIN_UPDATE(own, c, weight, gradient)                                             \
+    do {                                                                                       \
+        _Pragma("unroll") for (int x = 0; x < V; x++) own[x] -= h.lr * (weight) * ((gradient) * c[x] + a.wd * own[x]); \
+    } while (0)
+#endif
+
 #if !defined(GVK_HOT_BLOCK)
 #define GVK_HOT_BLOCK 256
 #endif
@@ -127,11 +161,10 @@ __device__ GVK_CHAIN_STEPS_INLINE void chain_steps(const TrainArgs &a, const Hot
             float partial = 0;
 #pragma unroll
             for (int x = 0; x < V; x++) partial += own[x] * c[x];
-            const float prob = sigmoidf(group_sum<G>(partial));
+            const float prob = chain_sigmoid(group_sum<G>(partial));
             const float gradient = positive ? prob - 1 : prob;
             const float weight = p < end ? (positive ? 1.0f : a.neg_weight) : 0.0f;
-#pragma unroll
-            for (int x = 0; x < V; x++) own[x] -= h.lr * weight * (gradient * c[x] + a.wd * own[x]);  // optimizer.h:161-164
+            GVK_CHAIN_UPDATE(own, c, weight, gradient);  // optimizer.h:161-164
             // the slot is free: the row of entry p + D takes it (D - 1 requests stay in flight while a step computes)
             uint32_t label;
             load_row_at<DIM, G>(row_of(p + D, label), lane, ring[i]);
@@ -186,11 +219,10 @@ __device__ __forceinline__ void short_steps(const TrainArgs &a, const HotArgs &h
         float partial = 0;
 #pragma unroll
         for (int x = 0; x < V; x++) partial += own[x] * c[x];
-        const float prob = sigmoidf(group_sum<G>(partial));
+        const float prob = chain_sigmoid(group_sum<G>(partial));
         const float gradient = positive ? prob - 1 : prob;
         const float weight = (uint32_t)i < n ? (positive ? 1.0f : a.neg_weight) : 0.0f;
-#pragma unroll
-        for (int x = 0; x < V; x++) own[x] -= h.lr * weight * (gradient * c[x] + a.wd * own[x]);  // optimizer.h:161-164
+        GVK_CHAIN_UPDATE(own, c, weight, gradient);  // optimizer.h:161-164
         if (i + D < N) request(i + D);
     }
 }
@@ -523,11 +555,10 @@ __device__ __forceinline__ void train_long_chains_in_rounds(const TrainArgs &a, 
                     float partial = 0;
 #pragma unroll
                     for (int x = 0; x < V; x++) partial += own[x] * c[x];
-                    const float prob = sigmoidf(group_sum<G>(partial));
+                    const float prob = chain_sigmoid(group_sum<G>(partial));
                     const float gradient = positive ? prob - 1 : prob;
                     const float weight = p < end && base + i < per ? (positive ? 1.0f : a.neg_weight) : 0.0f;
-#pragma unroll
-                    for (int x = 0; x < V; x++) own[x] -= h.lr * weight * (gradient * c[x] + a.wd * own[x]);  // optimizer.h:161-164
+                    GVK_CHAIN_UPDATE(own, c, weight, gradient);  // optimizer.h:161-164
                     // the slot is free: the row of entry p + D takes it (D - 1 requests stay in flight while a step computes)
                     uint32_t label;
                     load_row_at<DIM, G>(row_of(p + D, label), lane, ring[i]);

@@ -97,13 +97,13 @@ def cut(text, begin, end, include_end=True):
 def host_source():
     common, text = open(COMMON).read(), open(SOURCE).read()
     pieces = [
-        '#include "simt.h"\n#include <algorithm>\nstruct gvk_alias_entry;\nstruct gvk_class_entry;\nnamespace {\nconstexpr int kBlock = 256, kHotBlock = 256;\n',
+        '#include "simt.h"\n#include <algorithm>\nstruct gvk_alias_entry;\nstruct gvk_class_entry;\nnamespace {\nconstexpr int kBlock = 256;\n#define GVK_SIMT_HOST 1\n',
         cut(common, "struct TrainArgs {", "\n};\n"),
         cut(common, "template <int CTRL>\n__device__ __forceinline__ float dpp(float x) {", "// ---- Philox4x32-10", include_end=False),
         cut(common, "template <int DIM, int G>\nstruct Layout {", "// ---- arithmetic", include_end=False),
         cut(common, "__device__ __forceinline__ float sigmoidf(float x) {", "\n}\n"),
         # HotArgs, the chains of 1 .. 7 entries, the idle rows, train_long_chains: everything up to the kernel itself
-        cut(text, "struct HotArgs {", "// HOT: 1 = the pairs read a hub row as the chains of their unit left it", include_end=False),
+        cut(text, "// The logistic function of a chain step", "// HOT: 1 = the pairs read a hub row as the chains of their unit left it", include_end=False),
     ]
     body = "\n".join(pieces)
     assert "asm volatile" not in body and "train_long_chains_in_rounds" in body
