@@ -31,6 +31,9 @@ for variant in extra.get("variants", "default").split(";"):
         solver_kw["device_sampling"] = True
     if "fidelity" in kw:
         solver_kw["fidelity"] = kw["fidelity"]
+    if "tune" in kw:  # gvk_set_tuning key:value, e.g. tune=12:2 (rounds of two entries per task whatever the engine says)
+        from graphvite_amd.kernels import HipKernels
+        HipKernels().set_tuning(int(kw["tune"].split(":")[0]), int(kw["tune"].split(":")[1]))
     aucs = []
     for seed in seeds:
         auc, reference, info = T.train(job, seed, tweak=tweak, **solver_kw)

@@ -8,9 +8,13 @@ export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out
 mkdir -p $O
-timeout 2800 python -m pytest tests -q -m gpu -rP > $O/pytest_gpu_full.log 2>&1
-grep -E "passed|failed" $O/pytest_gpu_full.log | tail -2; grep -E "^FAILED" $O/pytest_gpu_full.log
-grep -hE "^(headline|tube|hub100k|blog|module|friendster|youtube|held|hub rows after|a head row|DeepWalk over)|AUC here" $O/pytest_gpu_full.log | grep -v "print(" > $O/parity_auc.log
+# REFRESH=1: a later job of the same round on a later tree (the full suite and configs[2..4] are in the first job's files): a subset of
+# the suite into pytest_gpu_refresh.log / parity_auc_refresh.log, then the bench command, its trace and its PMC passes as below
+LOG=pytest_gpu_full.log; PARITY=parity_auc.log; WHAT="tests -m gpu"
+if [ "$REFRESH" = "1" ]; then LOG=pytest_gpu_refresh.log; PARITY=parity_auc_refresh.log; WHAT="tests/test_configs_gpu.py tests/test_hub_chains_gpu.py tests/test_kernel_gpu.py -m gpu"; fi
+timeout 2800 python -m pytest $WHAT -q -rP > $O/$LOG 2>&1
+grep -E "passed|failed" $O/$LOG | tail -2; grep -E "^FAILED" $O/$LOG
+grep -hE "^(headline|tube|hub100k|blog|module|friendster|youtube|held|hub rows after|a head row|DeepWalk over)|AUC here" $O/$LOG | grep -v "print(" > $O/$PARITY
 timeout 1200 python bench.py --steps 20 --warmup 5 > $O/bench_n1_steps20.json 2> $O/bench_n1_steps20.err
 tail -c 1500 $O/bench_n1_steps20.json
 SHORT="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-end-to-end --no-module"
@@ -40,6 +44,6 @@ if [ -f profiles/r5/pmc_summary_bench_n1.json ]; then
 fi
 timeout 600 python bench.py --steps 400 --warmup 50 --no-end-to-end --no-module > $O/bench_n1.json 2> $O/bench_n1.err
 for p in 2 4 8; do timeout 300 python bench.py --steps 200 --warmup 20 --partitions $p --no-cpu-baseline --no-end-to-end --no-module --no-access-pattern 2>/dev/null | tail -n 1; done > $O/bench_by_partitions.jsonl
-timeout 900 python scripts/measure_configs.py --epochs 100 > $O/configs_2_4.jsonl 2> $O/configs_2_4.err; tail -c 400 $O/configs_2_4.jsonl
+if [ "$REFRESH" != "1" ]; then timeout 900 python scripts/measure_configs.py --epochs 100 > $O/configs_2_4.jsonl 2> $O/configs_2_4.err; tail -c 400 $O/configs_2_4.jsonl; fi
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
 tail -2 $O/smoke.log

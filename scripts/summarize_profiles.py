@@ -20,7 +20,7 @@ def find(directory, suffix):
     return hits[0] if hits else None
 
 
-for name in ("bench_n1.json", "bench_n1_steps20.json", "configs_2_4.jsonl", "configs_4.jsonl", "friendster_shard.json", "engine_e2e.jsonl", "access_pattern_probe.jsonl", "dim_sweep.jsonl", "shard_sweep.jsonl", "parity_auc.log", "c2_parity.log", "pytest_gpu_full.log", "smoke.log", "bench_n1_steps20_throughput.json", "bench_n1_steps20_with_traffic.json", "bench_by_partitions.jsonl"):
+for name in ("bench_n1.json", "bench_n1_steps20.json", "configs_2_4.jsonl", "configs_4.jsonl", "friendster_shard.json", "engine_e2e.jsonl", "access_pattern_probe.jsonl", "dim_sweep.jsonl", "shard_sweep.jsonl", "parity_auc.log", "c2_parity.log", "pytest_gpu_full.log", "smoke.log", "bench_n1_steps20_throughput.json", "bench_n1_steps20_with_traffic.json", "bench_by_partitions.jsonl", "pytest_gpu_refresh.log", "parity_auc_refresh.log"):
     if os.path.exists(os.path.join(SRC, name)) and os.path.getsize(os.path.join(SRC, name)):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, name))
 

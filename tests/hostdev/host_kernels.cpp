@@ -185,6 +185,21 @@ int gvk_train(void *, int dim, const gvk_optimizer *optimizer, const gvk_tables 
 int gvk_train_episode(void *, int dim, const gvk_optimizer *optimizer, int linear_schedule, const gvk_tables *tables,
                       const uint32_t *pairs, const gvk_negative_source *negative, uint32_t first_batch_id, uint32_t batch_id_stride,
                       uint32_t total_batches, int num_batches, float *loss, int batch_size, int num_negative, float negative_weight) {
+    // GVH_SHUFFLE_POOL=1 (experiment): the samples of the call — a block visit's batches — in a random order before they are trained: what
+    // sequential SGD learns from a well-mixed stream (the order thousands of concurrent device walks produce) instead of the
+    // samplers' walk order
+    std::vector<uint32_t> shuffled;
+    if (getenv("GVH_SHUFFLE_POOL") && atoi(getenv("GVH_SHUFFLE_POOL")) && num_batches > 0) {
+        const size_t n = (size_t)num_batches * batch_size;
+        shuffled.assign(pairs, pairs + 2 * n);
+        uint64_t state = 0x9E3779B97F4A7C15ull * (first_batch_id + 1);
+        for (size_t i = n - 1; i > 0; i--) {
+            state = state * 6364136223846793005ull + 1442695040888963407ull;
+            const size_t j = (size_t)((state >> 33) % (i + 1));
+            std::swap(shuffled[2 * i], shuffled[2 * j]), std::swap(shuffled[2 * i + 1], shuffled[2 * j + 1]);
+        }
+        pairs = shuffled.data();
+    }
     for (int i = 0; i < num_batches; i++) {
         const uint32_t id = first_batch_id + (uint32_t)i * batch_id_stride;
         const float lr = gvo_lr(optimizer->lr, linear_schedule, (int)id, (int)total_batches);
