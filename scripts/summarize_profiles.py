@@ -16,8 +16,8 @@ os.makedirs(DST, exist_ok=True)
 
 
 def find(directory, suffix):
-    hits = sorted(glob.glob(os.path.join(SRC, directory, "**", "*" + suffix), recursive=True))
-    return hits[0] if hits else None
+    hits = sorted(glob.glob(os.path.join(SRC, directory, "**", "*" + suffix), recursive=True), key=os.path.getmtime)
+    return hits[-1] if hits else None  # gpurun_out/ accumulates the runs of a round: the newest
 
 
 for name in ("bench_n1.json", "bench_n1_steps20.json", "configs_2_4.jsonl", "configs_4.jsonl", "friendster_shard.json", "engine_e2e.jsonl", "access_pattern_probe.jsonl", "dim_sweep.jsonl", "shard_sweep.jsonl", "parity_auc.log", "c2_parity.log", "pytest_gpu_full.log", "smoke.log", "bench_n1_steps20_throughput.json", "bench_n1_steps20_with_traffic.json", "bench_by_partitions.jsonl", "pytest_gpu_refresh.log", "parity_auc_refresh.log"):
