@@ -182,24 +182,26 @@ int gvk_train(void *, int dim, const gvk_optimizer *optimizer, const gvk_tables 
     return train_batch(dim, optimizer, optimizer->lr, tables, pairs, negative, batch_id, loss, batch_size, num_negative, negative_weight);
 }
 
+// GVH_SHUFFLE_POOL=1 (experiment): the samples of a call — a block visit's batches — in a random order before they are trained: what
+// an executor learns from a well-mixed stream (the order thousands of concurrent device walks produce) instead of the samplers' walk order
+static const uint32_t *shuffled_pool(const uint32_t *pairs, int num_batches, int batch_size, uint32_t first_batch_id, std::vector<uint32_t> &shuffled) {
+    if (!(getenv("GVH_SHUFFLE_POOL") && atoi(getenv("GVH_SHUFFLE_POOL")) && num_batches > 0)) return pairs;
+    const size_t n = (size_t)num_batches * batch_size;
+    shuffled.assign(pairs, pairs + 2 * n);
+    uint64_t state = 0x9E3779B97F4A7C15ull * (first_batch_id + 1);
+    for (size_t i = n - 1; i > 0; i--) {
+        state = state * 6364136223846793005ull + 1442695040888963407ull;
+        const size_t j = (size_t)((state >> 33) % (i + 1));
+        std::swap(shuffled[2 * i], shuffled[2 * j]), std::swap(shuffled[2 * i + 1], shuffled[2 * j + 1]);
+    }
+    return shuffled.data();
+}
+
 int gvk_train_episode(void *, int dim, const gvk_optimizer *optimizer, int linear_schedule, const gvk_tables *tables,
                       const uint32_t *pairs, const gvk_negative_source *negative, uint32_t first_batch_id, uint32_t batch_id_stride,
                       uint32_t total_batches, int num_batches, float *loss, int batch_size, int num_negative, float negative_weight) {
-    // GVH_SHUFFLE_POOL=1 (experiment): the samples of the call — a block visit's batches — in a random order before they are trained: what
-    // sequential SGD learns from a well-mixed stream (the order thousands of concurrent device walks produce) instead of the
-    // samplers' walk order
     std::vector<uint32_t> shuffled;
-    if (getenv("GVH_SHUFFLE_POOL") && atoi(getenv("GVH_SHUFFLE_POOL")) && num_batches > 0) {
-        const size_t n = (size_t)num_batches * batch_size;
-        shuffled.assign(pairs, pairs + 2 * n);
-        uint64_t state = 0x9E3779B97F4A7C15ull * (first_batch_id + 1);
-        for (size_t i = n - 1; i > 0; i--) {
-            state = state * 6364136223846793005ull + 1442695040888963407ull;
-            const size_t j = (size_t)((state >> 33) % (i + 1));
-            std::swap(shuffled[2 * i], shuffled[2 * j]), std::swap(shuffled[2 * i + 1], shuffled[2 * j + 1]);
-        }
-        pairs = shuffled.data();
-    }
+    pairs = shuffled_pool(pairs, num_batches, batch_size, first_batch_id, shuffled);
     for (int i = 0; i < num_batches; i++) {
         const uint32_t id = first_batch_id + (uint32_t)i * batch_id_stride;
         const float lr = gvo_lr(optimizer->lr, linear_schedule, (int)id, (int)total_batches);
@@ -238,7 +240,9 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     // learning, no GPU needed.  "units": unit after unit; "pipelined": the chains of unit u + 1 are computed before the pairs of
     // unit u have written anything, as one launch of the product does.  (The Hogwild losses of rows that are not hub rows are
     // not simulated: the pairs run in sample order.)
+    std::vector<uint32_t> shuffled_pairs;
     const char *executor = getenv("GVH_EXECUTOR");
+    if (executor && *executor && strcmp(executor, "sequential")) pairs = shuffled_pool(pairs, num_batches, batch_size, first_batch_id, shuffled_pairs);
     if (!executor || !*executor || !strcmp(executor, "sequential"))
         return gvk_train_episode(stream, dim, optimizer, linear_schedule, tables, pairs, negative, first_batch_id, batch_id_stride,
                                  total_batches, num_batches, loss, batch_size, num_negative, negative_weight);
