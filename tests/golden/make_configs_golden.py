@@ -43,6 +43,9 @@ WALK = dict(walk_length=40, walk_batch=100)
 # name: (graph, dim, model, train kwargs, partitions, episode (0 = automatic), epochs, optimizer)
 JOBS = {
     "fs_line_p8": ("friendster_like", 96, "LINE", dict(augmentation_step=2, shuffle_base=2, **WALK), 8, 8, 50, None),
+    # diagnostics for the open line of DESIGN.md section 7.11 (a): the same shape at dim 128, and in one partition
+    "fs128_line_p8": ("friendster_like", 128, "LINE", dict(augmentation_step=2, shuffle_base=2, **WALK), 8, 8, 50, None),
+    "fs_line_p1": ("friendster_like", 96, "LINE", dict(augmentation_step=2, shuffle_base=2, **WALK), 1, 0, 50, None),
     "yt_deepwalk": ("youtube_like", 128, "DeepWalk", dict(augmentation_step=5, shuffle_base=1, **WALK), 1, 500, 100, None),
     "yt_p4_deepwalk": ("youtube_like", 128, "DeepWalk", dict(augmentation_step=5, shuffle_base=1, **WALK), 4, 30, 100, None),
     "c2_adam": ("headline", 128, "LINE", dict(augmentation_step=1), 1, 0, 50, ("Adam", 1e-3, 0.005)),
