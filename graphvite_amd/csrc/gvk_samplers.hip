@@ -161,10 +161,16 @@ __global__ void __launch_bounds__(kBlock) sample_walks_kernel(const gvk_walk_gra
 // pair is binned into the pool of its block, b = part[head] * P + part[tail] (GraphSampler::sample_random_walk's
 // per-block pools, graph.cuh:357-373, filled by GPU threads instead of CPU threads).  Pairs for a block whose pool is
 // full, or which this call does not collect, are dropped, as the reference drops them (solver.h:1045-1052).
-// A pool is cut into `stripes` stripes with one slot counter each and a wavefront appends to stripe (wavefront id mod
-// stripes): a single counter per block would take every atomic of the launch on P * P addresses (measured: 0.36 G
-// pairs/s at 16 blocks), striped they spread over a few hundred times as many.  counters[b][stripe] keeps counting
-// past the stripe's capacity, so the caller sees each block's share and which stripes are full.
+// A pool is cut into `stripes` stripes with one slot counter each and a wavefront appends to stripes: a single counter
+// per block would take every atomic of the launch on P * P addresses (measured: 0.36 G pairs/s at 16 blocks), striped
+// they spread over a few hundred times as many.  counters[b][stripe] keeps counting past the stripe's capacity, so the
+// caller sees each block's share and which stripes are full.
+// The pseudo shuffle (graph.cuh:713-728) keeps the pairs of a walk that share a row — pair i and pairs i + 1 .. i + 2 aug
+// - 1 — out of one another's batch: pair i goes to part i % sb of the pool.  A wavefront's 64 walks append in lock step, so
+// here the part is chosen by the pair's INDEX IN ITS WALK, not by the slot it is handed: pair i of wavefront w goes to
+// stripe (w + (i % sb) * (stripes / sb)) % stripes — capacity / sb records away from pair i + 1.  (Choosing the part by
+// the slot, as a sequential sampler may, left a walk's pairs 32 slots apart in one launch; profiles/r5/experiments/
+// r5_fs_shuffle_base.txt: +0.007 link-prediction AUC against the sequential loop on LINE with augmentation_step 2.)
 
 struct BlockPools {
     u32x2 *pools;
@@ -180,16 +186,16 @@ __global__ void __launch_bounds__(kBlock) sample_walks_blocks_kernel(const gvk_w
                                                                      uint64_t num_walks) {
     const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (t >= num_walks) return;
-    const uint32_t stripe = (uint32_t)((t / 64) % b.stripes), stride = b.capacity / b.sb;
-    walk_pairs(g, seed, first_walk + t, pairs_per_walk, L, aug, [&](uint32_t head, uint32_t tail, uint64_t) {
+    const uint32_t wave = (uint32_t)((t / 64) % b.stripes), apart = b.stripes / b.sb > 0 ? b.stripes / b.sb : 1;
+    walk_pairs(g, seed, first_walk + t, pairs_per_walk, L, aug, [&](uint32_t head, uint32_t tail, uint64_t i) {
         const int block = b.part[head] * b.P + b.part[tail];
         const uint64_t first = b.offsets[block];
         if (first == ~(uint64_t)0) return;
+        const uint32_t stripe = (wave + (uint32_t)(i % b.sb) * apart) % b.stripes;
         const uint32_t slot = atomicAdd(b.counters + (size_t)block * b.stripes + stripe, 1u);
         if (slot >= b.stripe_capacity) return;
-        const uint32_t position = stripe * b.stripe_capacity + slot;
         u32x2 record = {g.local[tail], g.local[head]};
-        __builtin_nontemporal_store(record, b.pools + first + (position % b.sb * stride + position / b.sb));
+        __builtin_nontemporal_store(record, b.pools + first + ((size_t)stripe * b.stripe_capacity + slot));
     });
 }
 

@@ -34,10 +34,15 @@ for variant in extra.get("variants", "default").split(";"):
     if "tune" in kw:  # gvk_set_tuning key:value, e.g. tune=12:2 (rounds of two entries per task whatever the engine says)
         from graphvite_amd.kernels import HipKernels
         HipKernels().set_tuning(int(kw["tune"].split(":")[0]), int(kw["tune"].split(":")[1]))
+    base = T.JOBS[job][3].get("shuffle_base")
+    if "sb" in kw:  # the pseudo shuffle's base (graph.cuh:713-728) — a large one mixes the CPU samplers' walk-ordered pools
+        T.JOBS[job][3]["shuffle_base"] = int(kw["sb"])
     aucs = []
     for seed in seeds:
         auc, reference, info = T.train(job, seed, tweak=tweak, **solver_kw)
         aucs.append(auc)
+    if "sb" in kw:
+        T.JOBS[job][3]["shuffle_base"] = base
     reference = reference[~np.isnan(reference)]
     print("%s [%s]: AUC %s mean %.6f | reference %.6f | difference %+.6f | %s" % (job, variant, " ".join("%.6f" % a for a in aucs), np.mean(aucs),
                                                                                  reference.mean(), np.mean(aucs) - reference.mean(), info), flush=True)

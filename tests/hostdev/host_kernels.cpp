@@ -408,7 +408,7 @@ int gvk_sample_walks(void *, const gvk_walk_graph *g, uint64_t seed, uint64_t fi
 }
 
 // gvk_sample_walks_blocks restated: the walks of gvk_sample_walks (vertex ids instead of rows), every pair binned into the
-// pool of its (head partition, tail partition) block, stripe (walk / 64) % stripes, in walk order.
+// pool of its (head partition, tail partition) block; pair i of a walk to stripe ((walk / 64) + (i % sb) * (stripes / sb)) % stripes, in walk order.
 int gvk_sample_walks_blocks(void *, const gvk_walk_graph *g, const int32_t *part, int P, uint64_t seed, uint64_t first_walk,
                             uint64_t num_walks, uint32_t *pools, const uint64_t *offsets, uint32_t *counters, uint32_t capacity,
                             int num_stripe, int walk_length, int aug, int shuffle_base) {
@@ -420,23 +420,24 @@ int gvk_sample_walks_blocks(void *, const gvk_walk_graph *g, const int32_t *part
     unpack(g->neighbor_table, g->num_edge_entries, np, na);
     for (uint32_t v = 0; v < g->num_vertex; v++) identity[v] = v;
     const uint64_t per_walk = (uint64_t)aug * walk_length - (uint64_t)aug * (aug - 1) / 2;
-    const uint32_t stripe_capacity = capacity / (uint32_t)num_stripe, stride = capacity / (uint32_t)shuffle_base;
+    const uint32_t stripe_capacity = capacity / (uint32_t)num_stripe, sb = (uint32_t)shuffle_base;
+    const uint32_t apart = (uint32_t)num_stripe / sb > 0 ? (uint32_t)num_stripe / sb : 1;
     std::vector<uint32_t> pairs(per_walk * 2);
     for (uint64_t t = 0; t < num_walks; t++) {
         if (gvo_sample_walks_device(g->flat_offsets, g->edges_uv, ep.data(), ea.data(), g->num_edge_entries, np.data(), na.data(),
                                     g->sorted_neighbors, identity.data(), g->biased, g->p, g->q, seed, first_walk + t, pairs.data(),
                                     per_walk, walk_length, aug, 1) != 0)
             return gvk_fail(GVK_EINVAL, "gvk_sample_walks_blocks: bad arguments");
-        const uint32_t stripe = (uint32_t)((t / 64) % (uint64_t)num_stripe);
+        const uint32_t wave = (uint32_t)((t / 64) % (uint64_t)num_stripe);
         for (uint64_t i = 0; i < per_walk; i++) {
+            const uint32_t stripe = (wave + (uint32_t)(i % sb) * apart) % (uint32_t)num_stripe;
             const uint32_t tail = pairs[2 * i], head = pairs[2 * i + 1];
             const int block = part[head] * P + part[tail];
             const uint64_t first = offsets[block];
             if (first == ~(uint64_t)0) continue;
             const uint32_t slot = counters[(size_t)block * num_stripe + stripe]++;
             if (slot >= stripe_capacity) continue;
-            const uint32_t position = stripe * stripe_capacity + slot;
-            uint32_t *record = pools + 2 * (first + (position % (uint32_t)shuffle_base * stride + position / (uint32_t)shuffle_base));
+            uint32_t *record = pools + 2 * (first + ((size_t)stripe * stripe_capacity + slot));
             record[0] = g->local[tail], record[1] = g->local[head];
         }
     }

@@ -536,10 +536,12 @@ def test_sample_walks_blocks_matches_the_oracle_per_block(hip, oracle, biased):
     want = oracle.sample_walks_device(flat, E, edge_prob, edge_alias, nb_prob, nb_alias, sorted_nb, identity, biased, 0.5,
                                       2.0, seed, first, walks * per_walk, L, aug, 1)  # {tail vertex, head vertex}
     block = part[want[:, 1]].astype(np.int64) * P + part[want[:, 0]]
-    stripes = 5
-    stripe_of = (np.arange(len(want)) // per_walk // 64) % stripes  # a wavefront (64 walks) appends to one stripe
+    stripes, sb = 7, 3
+    # pair i of a walk of wavefront w (64 walks) goes to stripe (w + (i % sb) * (stripes // sb)) % stripes: the pseudo shuffle's
+    # parts (graph.cuh:713-728) chosen by the pair's index in its walk
+    index = np.arange(len(want))
+    stripe_of = (index // per_walk // 64 + index % per_walk % sb * (stripes // sb)) % stripes
     per_stripe = max(np.bincount(block[stripe_of == k], minlength=P * P).max() for k in range(stripes))
-    sb = 3
     capacity = (int(per_stripe) + 3) * stripes
     capacity += -capacity % (sb * stripes)
     where = np.arange(P * P, dtype=np.int64) * capacity
@@ -561,8 +563,7 @@ def test_sample_walks_blocks_matches_the_oracle_per_block(hip, oracle, biased):
         for k in range(stripes):
             mine = want[(block == b) & (stripe_of == k)]
             assert count[b, k] == len(mine)
-            position = k * (capacity // stripes) + np.arange(len(mine))
-            stored = got[b][position % sb * (capacity // sb) + position // sb]
+            stored = got[b][k * (capacity // stripes) + np.arange(len(mine))]
             expect = np.stack([local[mine[:, 0]], local[mine[:, 1]]], 1)
             assert sorted(map(tuple, stored.tolist())) == sorted(map(tuple, expect.tolist()))
     # the wrapper: small pools, repeated until every collected pool is full; only pairs of the block, local ids
