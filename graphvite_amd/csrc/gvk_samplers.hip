@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(kBlock) sample_walks_kernel(const gvk_walk_gra
 // - 1 — out of one another's batch: pair i goes to part i % sb of the pool.  A wavefront's 64 walks append in lock step, so
 // here the part is chosen by the pair's INDEX IN ITS WALK, not by the slot it is handed: pair i of wavefront w goes to
 // stripe (w + (i % sb) * (stripes / sb)) % stripes — capacity / sb records away from pair i + 1.  (Choosing the part by
-// the slot, as a sequential sampler may, left a walk's pairs 32 slots apart in one launch; profiles/r5/experiments/
+// the slot, as a sequential sampler may, left a walk's pairs of a block a few slots apart in one launch; profiles/r5/experiments/
 // r5_fs_shuffle_base.txt: +0.007 link-prediction AUC against the sequential loop on LINE with augmentation_step 2.)
 
 struct BlockPools {

@@ -85,7 +85,7 @@ def test_friendster_like_shape_matches_the_reference_training_loop(device_sampli
     print("friendster-like, dim 96, 8 partitions%s: %s" % (", device sampling" if device_sampling else "", info))
     # Positive samples drawn on the device (the opt-in extension of SURVEY.md §8 f4, beyond north_star's CPU samplers): +0.0017 on this shape
     # (two seeds; dim 128: +0.0017) — until gvk_sample_walks_blocks chose the pseudo shuffle's part by the pair's index in its walk the pairs
-    # of one walk sat 32 slots apart inside one launch and the line ended +0.0071 (DESIGN.md §7.11 a).  The bound: +-0.002 plus the
+    # of one walk sat a few slots apart inside one launch and the line ended +0.0071 (DESIGN.md §7.11 a).  The bound: +-0.002 plus the
     # run-to-run spread of pools filled through atomics (0.0002).
     compare_auc("friendster-like LINE dim 96 P=8%s" % (" device sampling" if device_sampling else ""), aucs, reference,
                 tolerance=0.0025 if device_sampling else 0.002)
