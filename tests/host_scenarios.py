@@ -292,7 +292,7 @@ def device_sampling():
     nbrs = [set() for _ in range(g.num_vertex)]
     for u, v in g.edges.tolist():
         nbrs[u].add(v)
-    for model, aug, P in (("LINE", 1, 1), ("LINE", 1, 3), ("DeepWalk", 3, 1), ("node2vec", 2, 3), ("LINE", 2, 1)):
+    for model, aug, P in (("LINE", 1, 1), ("LINE", 1, 3), ("DeepWalk", 3, 1), ("node2vec", 2, 3), ("LINE", 2, 1), ("LINE", 2, 3)):
         s = gv.solver.GraphSolver(32, num_sampler_per_worker=1, device_sampling=True, seed=4)
         s.build(g, batch_size=300, episode_size=4, num_partition=P)
         part, local = hostlib.partition(g.vertex_weights, P)[:2]
