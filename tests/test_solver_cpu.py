@@ -86,7 +86,8 @@ def test_custom_schedule_and_optimizers(host_build):
 
 @pytest.mark.parametrize("workers,partitions,model,aug,device_sampling,order", [
     (2, 2, "LINE", 1, False, "sampled"), (2, 4, "LINE", 1, False, "grouped"), (4, 8, "LINE", 1, False, "grouped"),
-    (2, 2, "DeepWalk", 2, False, "sampled"), (2, 4, "LINE", 1, True, "grouped"), (2, 4, "node2vec", 2, True, "sampled")])
+    (2, 2, "DeepWalk", 2, False, "sampled"), (2, 4, "LINE", 1, True, "grouped"), (2, 4, "node2vec", 2, True, "sampled"),
+    (2, 4, "LINE", 2, True, "sampled"), (2, 4, "LINE", 2, False, "sampled")])
 def test_workers_of_one_process(host_build, workers, partitions, model, aug, device_sampling, order):
     """device_ids = [0] * W: slot claims, one in-place all-gather per step (the copies carrier), interleaved head groups,
     pinned context shards, routed walk pools — every pair trained in the block it belongs to, every batch id once."""
@@ -118,7 +119,8 @@ def test_word_graph_application_trains_a_corpus(host_build, tmp_path):
 @pytest.mark.parametrize("world,model,aug,partitions,order,device_sampling", [
     (2, "LINE", 1, 0, "sampled", False), (2, "DeepWalk", 2, 0, "sampled", False), (2, "node2vec", 2, 0, "sampled", False),
     (2, "LINE", 1, 4, "grouped", False), (2, "DeepWalk", 2, 4, "sampled", False), (4, "LINE", 1, 8, "grouped", False),
-    (2, "LINE", 1, 4, "grouped", True), (2, "DeepWalk", 2, 2, "sampled", True), (2, "node2vec", 2, 4, "sampled", True)])
+    (2, "LINE", 1, 4, "grouped", True), (2, "DeepWalk", 2, 2, "sampled", True), (2, "node2vec", 2, 4, "sampled", True),
+    (2, "LINE", 2, 4, "sampled", True)])
 def test_processes_over_gloo(host_build, tmp_path, world, model, aug, partitions, order, device_sampling):
     """gvx_solver_create_distributed with the collectives carried by gloo (the transport hook): after write-back every
     process holds the same, complete tables; batch ids interleave, every id exactly once; context shards pinned per
