@@ -459,6 +459,64 @@ def workers_in_one_process(workers, partitions, model, aug, device_sampling, ord
     assert (t.vertex_embeddings == tables[0][0]).all() and (t.context_embeddings == tables[0][1]).all()
 
 
+def walk_blocks_layout():
+    """gvk_sample_walks_blocks as the CPU scenarios train on it (the host restatement; tests/test_kernel_gpu.py pins the device kernel to
+    the same rule with the same arithmetic): per block and stripe the oracle's walk pairs, pair i of a walk of wavefront w in stripe
+    (w + i % sb * (stripes // sb)) % stripes — and what the rule is for (DESIGN.md section 7.11 a): two consecutive pairs of one walk,
+    the ones that share a row, never lie in the same part of a pool, whichever walks surround them."""
+    from graphvite_amd import kernels as K
+    from oracle_lib import Oracle
+    oracle, lib = Oracle(), _lib.lib()
+    g = gv.graph.Graph()
+    edges = synthetic.power_law_edges(3000, 30000, seed=4)
+    g.load(edges)
+    for P, stripes, sb, L, aug in ((3, 8, 2, 12, 2), (2, 7, 3, 9, 3), (4, 16, 1, 10, 3)):
+        part, local, _ = hostlib.partition(g.vertex_weights, P)
+        s = hostlib.Sampler(g, part, local, P, seed=0)
+        s.prepare("walk", num_thread=2)
+        D = g.num_directed_edge
+        nb_prob, nb_alias = [np.ascontiguousarray(a) for a in s.neighbor_tables(D)]
+        edge_prob, edge_alias, edge_packed = K.alias_build(g.edge_weights)
+        E, flat = np.ascontiguousarray(g.edges), np.ascontiguousarray(g.flat_offsets)  # uint64 offsets
+        nb = np.zeros(D, np.dtype([("prob", np.float32), ("alias", np.uint32)]))
+        nb["prob"], nb["alias"] = nb_prob, nb_alias
+        local32, part32 = np.ascontiguousarray(local.astype(np.uint32)), np.ascontiguousarray(part.astype(np.int32))
+        desc = _lib.WalkGraph(flat.ctypes.data, E.ctypes.data, edge_packed.ctypes.data, nb.ctypes.data, None, local32.ctypes.data,
+                              g.num_vertex, D, 0, 1.0, 1.0)
+        seed, first, walks = 77, (1 << 32) + 9, 1500
+        per_walk = aug * L - aug * (aug - 1) // 2
+        identity = np.arange(g.num_vertex, dtype=np.uint32)
+        sorted_nb = np.ascontiguousarray(E[np.lexsort((E[:, 1], E[:, 0])), 1])
+        want = oracle.sample_walks_device(flat, E, edge_prob, edge_alias, nb_prob, nb_alias, sorted_nb, identity, False, 1.0, 1.0,
+                                          seed, first, walks * per_walk, L, aug, 1)  # {tail vertex, head vertex}
+        block = part[want[:, 1]].astype(np.int64) * P + part[want[:, 0]]
+        index = np.arange(len(want))
+        apart = max(stripes // sb, 1)
+        stripe_of = (index // per_walk // 64 + index % per_walk % sb * apart) % stripes
+        per_stripe = max(np.bincount(block[stripe_of == k], minlength=P * P).max() for k in range(stripes))
+        capacity = (int(per_stripe) + 3) * stripes
+        capacity += -capacity % (sb * stripes)
+        where = np.arange(P * P, dtype=np.uint64) * capacity
+        pools = np.zeros((P * P, capacity, 2), np.uint32)
+        counters = np.zeros((P * P, stripes), np.uint32)
+        rc = lib.gvk_sample_walks_blocks(None, C.byref(desc), part32.ctypes.data, P, seed, first, walks, pools.ctypes.data,
+                                         where.ctypes.data, counters.ctypes.data, capacity, stripes, L, aug, sb)
+        assert rc == 0
+        for b in range(P * P):
+            for k in range(stripes):
+                mine = want[(block == b) & (stripe_of == k)]
+                assert counters[b, k] == len(mine)
+                stored = pools[b][k * (capacity // stripes) + np.arange(len(mine))]
+                expect = np.stack([local[mine[:, 0]], local[mine[:, 1]]], 1)
+                assert sorted(map(tuple, stored.tolist())) == sorted(map(tuple, expect.tolist()))
+        if sb > 1:  # pairs i and i + 1 of a walk: different parts of the pool — at least a part minus a stripe of records between them
+            same_walk = index[:-1] // per_walk == index[1:] // per_walk
+            gap = np.abs(stripe_of[1:] - stripe_of[:-1])[same_walk]
+            gap = np.minimum(gap, stripes - gap)
+            assert gap.min() >= min(apart, stripes - apart * (sb - 1)) >= 1, (gap.min(), apart)
+            assert (gap.min() - 1) * (capacity // stripes) >= capacity // sb - 2 * (capacity // stripes) or stripes < 2 * sb
+
+
 def streamed_partitions():
     """gpu_memory_limit below what the resident design needs: partitions travel through host memory (the reference's
     load_partition / write_back scheme); same accounting, the model learns."""

@@ -94,6 +94,12 @@ def test_workers_of_one_process(host_build, workers, partitions, model, aug, dev
     scenario(host_build, "workers_in_one_process", workers, partitions, model, aug, device_sampling, order)
 
 
+def test_walk_pairs_binned_per_block_keep_a_walk_s_pairs_apart(host_build):
+    """The host restatement of gvk_sample_walks_blocks follows the rule the device kernel is pinned to (tests/test_kernel_gpu.py): per
+    block and stripe the oracle's pairs, the pseudo shuffle's part chosen by the pair's index in its walk (DESIGN.md section 7.11 a)."""
+    scenario(host_build, "walk_blocks_layout")
+
+
 def test_partitions_travel_through_host_memory_when_the_model_does_not_fit(host_build):
     scenario(host_build, "streamed_partitions")
 
