@@ -534,6 +534,7 @@ def main(argv=None):
     # With hub rows trained by chains a batch is `launches` launches of train_hot_kernel, each the pairs of one part of the
     # batch (and the chains of the next part): the roofline is stated per launch, as for the one-launch-per-batch kernels
     launches = max(solver.hub_parts_used, 1) if solver.hub_rows else 1
+    kernel_ms_per_batch = kernel_ms  # HIP events bracket whole batches: every launch of a batch, its work lists and mirror copies
     kernel_ms /= launches
     bytes_per_launch = (8 * dim * (k + 2) * (1 + moments) + 16) * B // launches  # moment tables are rows read + written too
     achieved = bytes_per_launch / (kernel_ms * 1e-3)
@@ -589,7 +590,7 @@ def main(argv=None):
                      "bytes_sent_per_gpu_per_collective": (after["bytes_sent_per_gpu"] - before["bytes_sent_per_gpu"]) // max(collectives, 1),
                      "transport": solver.transport,
                      "isolated_ms": exchange_ms,  # one exchange with nothing else in flight (it overlaps the next visit's kernels in the timed region)
-                     "kernels_ms_per_visit": kernel_ms * args.block_batches,
+                     "kernels_ms_per_visit": kernel_ms_per_batch * args.block_batches,
                      "note": "one in-place ncclAllGather of a head group's slab per schedule step"}
         if world > 1 else None,
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

@@ -3,6 +3,10 @@
 // C-ABI (include/gvk.h: gvk_hot_plan, gvk_hot_build, gvk_train_episode_hot).
 #include "gvk_device.hpp"
 
+#include <chrono>
+#include <map>
+#include <mutex>
+
 namespace {
 
 // ---- hub rows: chains --------------------------------------------------------------------------------------------------
@@ -77,8 +81,14 @@ struct HotArgs {
     const uint32_t *entries;      // partner row | label << 31 (label 1 = positive)
     const uint32_t *long_list;    // [0] = number of long chains (more than cap entries), then from [4] on a record {chain, first entry, entries, -} each
     const uint32_t *short_list;   // [0] = number of chains of 1 .. cap entries, then from [16] on a record of 16 words each: {chain, entries, -, -, the entries themselves}
-    const float *from;            // mirror the chains read: own rows and hub partners as the unit finds them
-    float *to;                    // mirror the chains store to
+    const float *from;            // mirror the chains read: own rows and hub partners as the unit finds them (versioned: the ring)
+    float *to;                    // mirror the chains store to (versioned: the ring)
+    // versioned (gvk_train_episode_ahead): the hub rows live in a ring of `ring_slots` versions PER ROW — version v of row i at
+    // ring[(v % ring_slots) * slot_stride + i] — instead of whole mirrors; a chain reads its row at the slot its record names and
+    // stores it to the next one, a hub partner is read at the slot its entry names (written there by hot_slots_kernel)
+    uint32_t slot_stride;         // rows between two slots of the ring (versioned: chains; mirrors: 0)
+    uint32_t ring_slots;
+    int versioned;
     uint32_t chains;              // hot_vertex + hot_context
     uint32_t long_capacity;
     uint32_t cap;                 // entries of one task (at most kShortEntries)
@@ -102,13 +112,41 @@ struct HotArgs {
 #define GVK_STAMP_VALUE(h, slot, value) do { } while (0)
 #endif
 
+// Where hub rows are read and stored.  Mirrors: row `index` of the mirror, whatever the slot.  Versioned: the row's version at
+// `slot` of the ring; a chain stores its row one slot on.
+template <int DIM>
+__device__ __forceinline__ const float *hub_from(const HotArgs &h, const uint32_t index, const uint32_t slot) {
+    return h.from + ((size_t)slot * h.slot_stride + index) * DIM;
+}
+template <int DIM>
+__device__ __forceinline__ float *hub_to(const HotArgs &h, const uint32_t chain, const uint32_t slot_from) {
+    const uint32_t slot = h.versioned ? (slot_from + 1 == h.ring_slots ? 0u : slot_from + 1) : 0u;
+    return h.to + ((size_t)slot * h.slot_stride + chain) * DIM;
+}
+// The partner row an entry names.  Mirrors: entry = id | label << 31, a partner below partner_hot is a hub row of the mirror.
+// Versioned (hot_slots_kernel): a hub partner is id (15 bits) | slot << 16 | 1 << 30 | label << 31, any other row id (30 bits) | label << 31.
+constexpr uint32_t kEntryHub = 0x40000000u;
+template <int DIM>
+__device__ __forceinline__ const float *partner_of(const HotArgs &h, const uint32_t e, const float *partner_table, const uint32_t partner_hot,
+                                                   const uint32_t partner_base) {
+    if (h.versioned) {
+        if (e & kEntryHub) return h.from + ((size_t)((e >> 16) & 0xffu) * h.slot_stride + partner_base + (e & 0x7fffu)) * DIM;
+        return partner_table + (size_t)(e & 0x3fffffffu) * DIM;
+    }
+    const uint32_t id = e & 0x7fffffffu;
+    return id < partner_hot ? h.from + (size_t)(partner_base + id) * DIM : partner_table + (size_t)id * DIM;
+}
+
 #if !defined(GVK_CHAIN_STEPS_INLINE)
 #define GVK_CHAIN_STEPS_INLINE __forceinline__
 #endif
 template <int DIM, int G>
 struct ChainShape {
     static constexpr int V = DIM / G;
-    static constexpr int D = V <= 4 ? 8 : (V <= 8 ? 4 : 2);  // partner rows in flight per lane group of a long chain's task
+#if !defined(GVK_CHAIN_RING)
+#define GVK_CHAIN_RING 4  // measurement knob: partner rows in flight per lane group at 8 floats per lane (dims 128 and 96 x 8 lanes: 12)
+#endif
+    static constexpr int D = V <= 4 ? 8 : (V <= 8 ? GVK_CHAIN_RING : 2);  // partner rows in flight per lane group of a long chain's task
     static constexpr int NG = kHotBlock / G;  // lane groups of a block = most tasks of a long chain
     static_assert(D <= G, "the entry window is two fetches of G entries");
 };
@@ -119,15 +157,15 @@ struct ChainShape {
 // mirror row and trains with weight 0.  Every step issues exactly one row request and consumes the one issued D steps
 // earlier, with no branch around either, so the wait before a step is "all but the D - 1 youngest" and not "all".
 template <int DIM, int G>
-__device__ GVK_CHAIN_STEPS_INLINE void chain_steps(const TrainArgs &a, const HotArgs &h, const uint32_t chain, const uint32_t begin,
-                                            const uint32_t end, const int lane, float (&own)[DIM / G]) {
+__device__ GVK_CHAIN_STEPS_INLINE void chain_steps(const TrainArgs &a, const HotArgs &h, const uint32_t chain, const uint32_t slot_from,
+                                            const uint32_t begin, const uint32_t end, const int lane, float (&own)[DIM / G]) {
     typedef ChainShape<DIM, G> S;
     constexpr int V = S::V, D = S::D;
     const bool is_vertex = chain < a.hot_vertex;
     const float *partner_table = is_vertex ? a.context : a.vertex;
     const uint32_t partner_hot = is_vertex ? a.hot_context : a.hot_vertex;  // partners below this id are hub rows: read from the mirror
-    const float *partner_mirror = h.from + (is_vertex ? (size_t)a.hot_vertex * DIM : (size_t)0);
-    const float *idle = h.from + (size_t)chain * DIM;
+    const uint32_t partner_base = is_vertex ? a.hot_vertex : 0u;
+    const float *idle = hub_from<DIM>(h, chain, slot_from);
     // the work list, G entries per fetch, two fetches resident: entries [blk, blk + 2 G)
     uint32_t blk = begin;
     uint32_t e_cur = blk + lane < end ? h.entries[blk + lane] : 0;
@@ -137,8 +175,7 @@ __device__ GVK_CHAIN_STEPS_INLINE void chain_steps(const TrainArgs &a, const Hot
         const uint32_t o = p - blk;
         const uint32_t e = (uint32_t)__shfl((int)(o < (uint32_t)G ? e_cur : e_nxt), (int)(o & (G - 1)), G);
         label = e >> 31;
-        const uint32_t id = e & 0x7fffffffu;
-        const float *row = id < partner_hot ? partner_mirror + (size_t)id * DIM : partner_table + (size_t)id * DIM;
+        const float *row = partner_of<DIM>(h, e, partner_table, partner_hot, partner_base);
         return p < end ? row : idle;
     };
     float ring[D][V];
@@ -192,21 +229,20 @@ constexpr int kShortEntries = 7;
 // The n <= kShortEntries entries entry_of(0 .. n - 1) of one chain applied one after the other to `own`: every partner row is
 // requested before the first step (where the registers hold them: dims up to 128), so the chain waits for memory once.
 template <int DIM, int G, class EntryOf>
-__device__ __forceinline__ void short_steps(const TrainArgs &a, const HotArgs &h, const uint32_t chain, const uint32_t n, const int lane,
-                                            float (&own)[DIM / G], EntryOf entry_of) {
+__device__ __forceinline__ void short_steps(const TrainArgs &a, const HotArgs &h, const uint32_t chain, const uint32_t slot_from, const uint32_t n,
+                                            const int lane, float (&own)[DIM / G], EntryOf entry_of) {
     constexpr int V = DIM / G, N = kShortEntries;
     constexpr int D = V <= 8 ? N : (V <= 12 ? 3 : 2);  // partner rows in flight: all of them where the registers hold them
     const bool is_vertex = chain < a.hot_vertex;
     const float *partner_table = is_vertex ? a.context : a.vertex;
     const uint32_t partner_hot = is_vertex ? a.hot_context : a.hot_vertex;
-    const float *partner_mirror = h.from + (is_vertex ? (size_t)a.hot_vertex * DIM : (size_t)0);
-    const float *idle = h.from + (size_t)chain * DIM;
+    const uint32_t partner_base = is_vertex ? a.hot_vertex : 0u;
+    const float *idle = hub_from<DIM>(h, chain, slot_from);
     float ring[D][V];
     uint32_t labels = 0;
     auto request = [&](const int i) __attribute__((always_inline)) {  // the row of entry i into its slot of the ring
         const uint32_t e = entry_of(i);
-        const uint32_t id = e & 0x7fffffffu;
-        const float *row = id < partner_hot ? partner_mirror + (size_t)id * DIM : partner_table + (size_t)id * DIM;
+        const float *row = partner_of<DIM>(h, e, partner_table, partner_hot, partner_base);
         load_row_at<DIM, G>((uint32_t)i < n ? row : idle, lane, ring[i % D]);
         labels |= (e >> 31) << i;
     };
@@ -244,12 +280,12 @@ __device__ __forceinline__ void train_short_chains(const TrainArgs &a, const Hot
         return (uint32_t)(i < LW ? __shfl((int)word0, i, G) : __shfl((int)word1, i - LW, G));
     };
     const bool mine = at < count;
-    const uint32_t chain = mine ? word(0) : 0, n = mine ? word(1) : 0;
+    const uint32_t chain = mine ? word(0) : 0, n = mine ? word(1) : 0, slot_from = mine && h.versioned ? word(3) : 0;
     float own[S::V];
-    load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, own);
-    short_steps<DIM, G>(a, h, chain, n, lane, own, [&](const int i) __attribute__((always_inline)) { return word(4 + i); });
+    load_row_at<DIM, G>(hub_from<DIM>(h, chain, slot_from), lane, own);
+    short_steps<DIM, G>(a, h, chain, slot_from, n, lane, own, [&](const int i) __attribute__((always_inline)) { return word(4 + i); });
     GVK_STAMP(h, 5);  // steps done
-    if (mine) store_row_at<DIM, G>(h.to + (size_t)chain * DIM, lane, own);
+    if (mine) store_row_at<DIM, G>(hub_to<DIM>(h, chain, slot_from), lane, own);
 }
 
 // Hub rows the unit has no entry for pass from mirror to mirror unchanged — those that need it: the mirror `to` was last
@@ -307,7 +343,7 @@ __device__ __forceinline__ void train_long_chains_one_round(const TrainArgs &a, 
     const uint32_t count = h.long_list[0] < h.long_capacity ? h.long_list[0] : h.long_capacity;
     for (uint32_t j = block; j < count; j += (uint32_t)h.long_blocks) {
         if (j != block) record = *reinterpret_cast<const u32x4 *>(h.long_list + 4 + 4 * (size_t)j);
-        const uint32_t chain = record.x, first = record.y, n = record.z, last = first + n;
+        const uint32_t chain = record.x, first = record.y, n = record.z, last = first + n, slot_from = h.versioned ? record.w : 0u;
         if (j == block) {
             GVK_STAMP_VALUE(h, 0, 1);
             GVK_STAMP(h, 2);  // the record is here
@@ -321,7 +357,7 @@ __device__ __forceinline__ void train_long_chains_one_round(const TrainArgs &a, 
         const uint32_t begin = mine ? first + (uint32_t)group * per : last;
         const uint32_t end = last - begin > per ? begin + per : last;
         float own[V];
-        load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, own);
+        load_row_at<DIM, G>(hub_from<DIM>(h, chain, slot_from), lane, own);
         const uint32_t mine_entry = begin + lane < end ? h.entries[begin + lane] : 0;  // the task's first G entries, one per lane
         uint32_t inside = mine_entry >> 31;
         for (uint32_t p = begin + G + lane; p < end; p += G) inside += h.entries[p] >> 31;
@@ -341,10 +377,10 @@ __device__ __forceinline__ void train_long_chains_one_round(const TrainArgs &a, 
 #pragma unroll
         for (int x = 0; x < V; x++) own[x] *= before_;
         if (per <= (uint32_t)kShortEntries)  // the usual task: all its partner rows at once
-            short_steps<DIM, G>(a, h, chain, end - begin, lane, own,
+            short_steps<DIM, G>(a, h, chain, slot_from, end - begin, lane, own,
                                 [&](const int i) __attribute__((always_inline)) { return (uint32_t)__shfl((int)mine_entry, i, G); });
         else  // a chain of more than NG tasks of seven entries (the largest hubs): longer tasks, rows D at a time
-            chain_steps<DIM, G>(a, h, chain, begin, end, lane, own);
+            chain_steps<DIM, G>(a, h, chain, slot_from, begin, end, lane, own);
         if (mine) {
 #pragma unroll
             for (int x = 0; x < V; x++) own[x] *= after_;
@@ -355,7 +391,7 @@ __device__ __forceinline__ void train_long_chains_one_round(const TrainArgs &a, 
         if (j == block) GVK_STAMP(h, 5);  // every task's steps are done
         if (group == 0) {
             float sum[V], row0[V];
-            load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, row0);
+            load_row_at<DIM, G>(hub_from<DIM>(h, chain, slot_from), lane, row0);
 #pragma unroll
             for (int x = 0; x < V; x++) sum[x] = (1.0f - (float)tasks) * total * row0[x];
             for (uint32_t t = 0; t < tasks; t++) {
@@ -364,7 +400,7 @@ __device__ __forceinline__ void train_long_chains_one_round(const TrainArgs &a, 
 #pragma unroll
                 for (int x = 0; x < V; x++) sum[x] += part[x];
             }
-            store_row_at<DIM, G>(h.to + (size_t)chain * DIM, lane, sum);
+            store_row_at<DIM, G>(hub_to<DIM>(h, chain, slot_from), lane, sum);
         }
         __syncthreads();
         if (j == block) GVK_STAMP(h, 6);  // composed and stored
@@ -394,7 +430,6 @@ __device__ __forceinline__ void train_long_chains_one_round(const TrainArgs &a, 
 // next round's segments travel with the end states: ONE barrier per round.
 template <int DIM, int G>
 __device__ __forceinline__ void train_long_chains_in_rounds(const TrainArgs &a, const HotArgs &h, const uint32_t block) {
-    constexpr int ROUNDS = 1;
     typedef ChainShape<DIM, G> S;
 #if !defined(GVK_ROUND_RING)
 #define GVK_ROUND_RING 4
@@ -409,7 +444,7 @@ __device__ __forceinline__ void train_long_chains_in_rounds(const TrainArgs &a, 
     const uint32_t count = h.long_list[0] < h.long_capacity ? h.long_list[0] : h.long_capacity;
     for (uint32_t j = block; j < count; j += (uint32_t)h.long_blocks) {
         if (j != block) record = *reinterpret_cast<const u32x4 *>(h.long_list + 4 + 4 * (size_t)j);
-        const uint32_t chain = record.x, first = record.y, n = record.z, last = first + n;
+        const uint32_t chain = record.x, first = record.y, n = record.z, last = first + n, slot_from = h.versioned ? record.w : 0u;
         if (j == block) {
             GVK_STAMP_VALUE(h, 0, 1);
             GVK_STAMP(h, 2);  // the record is here
@@ -423,10 +458,9 @@ __device__ __forceinline__ void train_long_chains_in_rounds(const TrainArgs &a, 
         const uint32_t begin = mine ? first + (uint32_t)group * per : last;
         const uint32_t end = last - begin > per ? begin + per : last;
         // entries a task applies per round (a round's segment fits one fetch of G entries)
-        // (ROUNDS = 0: the build without them — one stream loop per kernel keeps both within their registers)
-        const uint32_t steps = ROUNDS && h.round_steps && per > h.round_steps ? (h.round_steps < (uint32_t)G ? h.round_steps : (uint32_t)G) : per;
+        const uint32_t steps = h.round_steps && per > h.round_steps ? (h.round_steps < (uint32_t)G ? h.round_steps : (uint32_t)G) : per;
         float row[V], own[V];
-        load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, row);
+        load_row_at<DIM, G>(hub_from<DIM>(h, chain, slot_from), lane, row);
         const uint32_t mine_entry = begin + lane < end ? h.entries[begin + lane] : 0;  // the task's first G entries, one per lane
         // what the tasks of a round need from each other: {positives, entries} of every task's segment, through LDS
         auto share_counts = [&](const int buffer, const uint32_t positives, const uint32_t length) __attribute__((always_inline)) {
@@ -451,8 +485,6 @@ __device__ __forceinline__ void train_long_chains_in_rounds(const TrainArgs &a, 
             for (int x = 0; x < V; x++) own[x] = before_ * row[x];
         };
         auto compose = [&](const int buffer) __attribute__((always_inline)) {  // after the barrier: the round's end states into the row, by every group
-            // one round: the row it started from is the mirror's, asked for again rather than kept in registers through the steps
-            if constexpr (!ROUNDS) load_row_at<DIM, G>(h.from + (size_t)chain * DIM, lane, row);
 #pragma unroll
             for (int x = 0; x < V; x++) row[x] *= (1.0f - (float)active) * total;
             for (uint32_t t = 0; t < active; t++) {
@@ -468,7 +500,7 @@ __device__ __forceinline__ void train_long_chains_in_rounds(const TrainArgs &a, 
             __syncthreads();
             if (j == block) GVK_STAMP(h, 3);  // own row and the task's entries are here
             enter_round(0);
-            short_steps<DIM, G>(a, h, chain, end - begin, lane, own,
+            short_steps<DIM, G>(a, h, chain, slot_from, end - begin, lane, own,
                                 [&](const int i) __attribute__((always_inline)) { return (uint32_t)__shfl((int)mine_entry, i, G); });
             if (mine) {
 #pragma unroll
@@ -479,35 +511,13 @@ __device__ __forceinline__ void train_long_chains_in_rounds(const TrainArgs &a, 
             __syncthreads();
             if (j == block) GVK_STAMP(h, 5);  // every task's steps are done
             compose(0);
-        } else if (!ROUNDS || steps == per) {
-          if constexpr (!ROUNDS) {
-            // longer tasks, one round (chains of up to NG x 16 entries unless the caller asks for rounds): the task's entries as one
-            // stream, rows D at a time in flight
-            uint32_t inside = mine_entry >> 31;
-            for (uint32_t p = begin + G + lane; p < end; p += G) inside += h.entries[p] >> 31;
-            share_counts(0, (uint32_t)group_count<G>(inside), end - begin);
-            __syncthreads();
-            if (j == block) GVK_STAMP(h, 3);  // own row and the task's entries are here
-            enter_round(0);
-            chain_steps<DIM, G>(a, h, chain, begin, end, lane, own);
-            if (mine) {
-#pragma unroll
-                for (int x = 0; x < V; x++) own[x] *= after_;
-                store_row_at<DIM, G>(&ends[0][group][0], lane, own);
-            }
-            if (j == block) GVK_STAMP(h, 4);  // this task's steps are done
-            __syncthreads();
-            if (j == block) GVK_STAMP(h, 5);  // every task's steps are done
-            compose(0);
-          }
-        }
-        if constexpr (ROUNDS != 0) if (!(per <= (uint32_t)kShortEntries && steps == per)) {
+        } else {
             // longer tasks in rounds of `steps` entries (one round when steps == per): the task's entries as one stream, rows D at a time in flight
             const bool is_vertex = chain < a.hot_vertex;
             const float *partner_table = is_vertex ? a.context : a.vertex;
             const uint32_t partner_hot = is_vertex ? a.hot_context : a.hot_vertex;  // partners below this id are hub rows: read from the mirror
-            const float *partner_mirror = h.from + (is_vertex ? (size_t)a.hot_vertex * DIM : (size_t)0);
-            const float *idle = h.from + (size_t)chain * DIM;
+            const uint32_t partner_base = is_vertex ? a.hot_vertex : 0u;
+            const float *idle = hub_from<DIM>(h, chain, slot_from);
             // the work list, G entries per fetch, two fetches resident: entries [blk, blk + 2 G)
             uint32_t blk = begin;
             uint32_t e_cur = mine_entry;
@@ -517,8 +527,7 @@ __device__ __forceinline__ void train_long_chains_in_rounds(const TrainArgs &a, 
                 const uint32_t o = p - blk;
                 const uint32_t e = (uint32_t)__shfl((int)(o < (uint32_t)G ? e_cur : e_nxt), (int)(o & (G - 1)), G);
                 label = e >> 31;
-                const uint32_t id = e & 0x7fffffffu;
-                const float *at = id < partner_hot ? partner_mirror + (size_t)id * DIM : partner_table + (size_t)id * DIM;
+                const float *at = partner_of<DIM>(h, e, partner_table, partner_hot, partner_base);
                 return p < end ? at : idle;
             };
             float ring[D][V];
@@ -599,7 +608,7 @@ __device__ __forceinline__ void train_long_chains_in_rounds(const TrainArgs &a, 
             if (j == block) GVK_STAMP(h, 5);  // every task's steps are done
             compose(buffer);
         }
-        if (group == 0) store_row_at<DIM, G>(h.to + (size_t)chain * DIM, lane, row);
+        if (group == 0) store_row_at<DIM, G>(hub_to<DIM>(h, chain, slot_from), lane, row);
         __syncthreads();
         if (j == block) GVK_STAMP(h, 6);  // composed and stored
     }
@@ -611,7 +620,10 @@ __device__ __forceinline__ void train_long_chains_in_rounds(const TrainArgs &a, 
 // at dims 256 and 512, sixteen floats of a row per lane): the chains and the pairs of a unit of the sizes this kernel trains (a
 // part of a batch) are then resident side by side.
 template <int DIM, int G, int KT, int HOT, int ROUNDS>
-__global__ void __launch_bounds__(kHotBlock, DIM / G > 12 ? 3 : 4) train_hot_kernel(const TrainArgs a, const HotArgs h) {
+#if !defined(GVK_HOT_WAVES)
+#define GVK_HOT_WAVES 4  // measurement knob: wavefronts per SIMD train_hot_kernel / chain_kernel are built for
+#endif
+__global__ void __launch_bounds__(kHotBlock, DIM / G > 12 ? 3 : GVK_HOT_WAVES) train_hot_kernel(const TrainArgs a, const HotArgs h) {
     // the grid: [long chains | pairs | short chains | idle rows] — the long chains, whose tasks wait for memory three times in
     // a row, are dispatched first, the bulk (the pairs) next; the short chains and the copies fill in behind
     const int b = blockIdx.x;
@@ -749,11 +761,128 @@ __global__ void __launch_bounds__(kListThreads) hot_list_kernel(TrainArgs a, con
     }
 }
 
+// ---- the chain stream (gvk_train_episode_ahead) -----------------------------------------------------------------------------
+//
+// The same chains as a kernel of their own, on a stream of their own, a batch AHEAD of the pairs: a launch
+// of train_hot_kernel lasts as long as its longest chain — record, row + entries, 16 dependent steps, compose, store: 10-12 us —
+// while its pairs are done after 5-6; the chains are a dependency chain from unit to unit, the pairs are not.  So the chains of
+// every unit run back to back on the chain stream (chain_kernel: the long and the short chains, nothing else) and the pairs of a
+// batch follow on the caller's stream once that batch's chains are done (hot_pairs_kernel), while the chains of the next batch
+// already run.  What makes that possible is where the hub rows live: not in whole mirrors (a mirror per unit in flight would have
+// to be completed by copies of every row a unit did NOT touch), but in a ring of VERSIONS per row — a row's version advances by one
+// in every unit that has entries for it; version v sits at slot v % ring_slots.  The work lists say which slot to read:
+// hot_version_kernel counts the versions (ver[unit][row] = the row's slot after that unit), hot_slots_kernel writes them where they
+// are needed — a chain's record (the slot its row is read at; it is stored one slot on), every entry whose partner is a hub row (the
+// partner's slot BEFORE the unit: a sample between two hub rows updates both from the values the unit started with, as the mirrors
+// did), and per sample the slots its pairs read its hub rows at (after the unit's chains).  Nothing is copied for rows without
+// entries.  The ring holds 2 parts + 1 versions: the chains of batch b + 2 wait for the pairs of batch b, so between the oldest
+// version a running pairs launch may read and the newest a chain writes lie at most 2 parts units.
+template <int DIM, int G, int ROUNDS>
+__global__ void __launch_bounds__(kHotBlock, DIM / G > 12 ? 3 : GVK_HOT_WAVES) chain_kernel(const TrainArgs a, const HotArgs h) {
+    const int b = blockIdx.x;
+    GVK_STAMP_VALUE(h, 0, 0);
+    GVK_STAMP(h, 1);  // the workgroup starts
+    if (b < h.long_blocks) {
+        if constexpr (ROUNDS != 0) train_long_chains_in_rounds<DIM, G>(a, h, b);
+        else train_long_chains_one_round<DIM, G>(a, h, b);
+    } else {
+        train_short_chains<DIM, G>(a, h, b - h.long_blocks);
+    }
+}
+
+template <int DIM, int G, int KT>
+__global__ void __launch_bounds__(kBlock, 4) hot_pairs_kernel(const TrainArgs a) {
+    train_pair<DIM, G, GVK_SGD, KT, 1, 3>(a, blockIdx.x * kBlock + threadIdx.x);
+}
+
+// ver[u][c] = slot of chain c's row after unit u: the number of units up to u that have entries for it, modulo the ring
+__global__ void __launch_bounds__(kBlock) hot_version_kernel(const uint32_t *chain_start_all, uint8_t *ver_all, const uint32_t chains,
+                                                             const int units, const uint32_t ring_slots) {
+    const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= chains) return;
+    uint32_t v = 0;
+    for (int u = 0; u < units; u++) {
+        const uint32_t *start = chain_start_all + (size_t)u * (chains + 1);
+        if (start[c + 1] != start[c]) v = v + 1 == ring_slots ? 0u : v + 1;
+        ver_all[(size_t)u * chains + c] = (uint8_t)v;
+    }
+}
+
+// One workgroup per unit: the slots into the unit's work lists and the samples' slot words (see above)
+__global__ void __launch_bounds__(kListThreads) hot_slots_kernel(TrainArgs a, const uint32_t first_batch_id, const uint32_t stride,
+                                                                 const uint32_t *chain_start_all, uint32_t *entries_all, uint32_t *long_all,
+                                                                 uint32_t *short_all, const uint8_t *ver_all, uint32_t *slots_all,
+                                                                 const uint32_t entry_capacity, const uint32_t long_capacity, const int parts,
+                                                                 const int slot_words) {
+    const uint32_t chains = a.hot_vertex + a.hot_context;
+    const int B = a.batch_size, k = a.k, u = blockIdx.x;
+    const int batch = u / parts, lo = (u % parts) * (B / parts), hi = lo + B / parts;
+    const u32x2 *records = reinterpret_cast<const u32x2 *>(a.pairs) + (size_t)batch * B;
+    const uint32_t *chain_start = chain_start_all + (size_t)u * (chains + 1);
+    uint32_t *entries = entries_all + (size_t)u * entry_capacity;
+    uint32_t *long_list = long_all + (size_t)u * 4 * (1 + (size_t)long_capacity);
+    uint32_t *short_list = short_all + (size_t)u * 16 * (1 + (size_t)chains);
+    const uint8_t *now = ver_all + (size_t)u * chains, *before = u ? now - chains : nullptr;
+    a.batch_id = first_batch_id + (uint32_t)batch * stride;
+    // the samples: where the unit's pairs read their hub rows — as the unit's chains left them
+    for (int s = lo + threadIdx.x; s < hi; s += kListThreads) {
+        const u32x2 pr = records[s];
+        uint32_t *words = slots_all + ((size_t)batch * B + s) * slot_words;
+        uint32_t word = (pr.y < a.hot_vertex ? (uint32_t)now[pr.y] : 0u) | (pr.x < a.hot_context ? (uint32_t)now[a.hot_vertex + pr.x] : 0u) << 8;
+        for (int j = 0; j < k; j++) {
+            const Draw d = negative_slot(a, (uint32_t)s, (uint32_t)j);
+            const uint32_t n = resolve(a, d, load_entry(a, d));
+            const int which = 2 + j;
+            if ((which & 3) == 0) words[(which >> 2) - 1] = word, word = 0;
+            word |= (n < a.hot_context ? (uint32_t)now[a.hot_vertex + n] : 0u) << (8 * (which & 3));
+        }
+        words[(k + 1) >> 2] = word;
+    }
+    // the entries: a hub partner is read at its slot BEFORE the unit
+    const uint32_t total = chain_start[chains], head_entries = chain_start[a.hot_vertex];
+    for (uint32_t e = threadIdx.x; e < total; e += kListThreads) {
+        const uint32_t x = entries[e], label = x & 0x80000000u, id = x & 0x7fffffffu;
+        const bool of_head = e < head_entries;  // the chains are listed by row, head rows first: this entry's partner is a context row
+        const uint32_t hot = of_head ? a.hot_context : a.hot_vertex, base = of_head ? a.hot_vertex : 0u;
+        entries[e] = id < hot ? (label | kEntryHub | (before ? (uint32_t)before[base + id] : 0u) << 16 | id) : x;
+    }
+    __syncthreads();
+    __threadfence_block();
+    // the records: the slot the chain's own row is read at, and (short chains) the entries as rewritten above
+    const uint32_t long_count = long_list[0] < long_capacity ? long_list[0] : long_capacity, short_count = short_list[0];
+    for (uint32_t j = threadIdx.x; j < long_count; j += kListThreads) {
+        uint32_t *record = long_list + 4 + 4 * (size_t)j;
+        record[3] = before ? (uint32_t)before[record[0]] : 0u;
+    }
+    for (uint32_t r = threadIdx.x / 8; r < short_count; r += kListThreads / 8) {
+        uint32_t *record = short_list + 16 + 16 * (size_t)r;
+        const uint32_t n = record[1], first = record[2], i = threadIdx.x % 8;
+        if (i == 7) record[3] = before ? (uint32_t)before[record[0]] : 0u;
+        if (i < n) record[4 + i] = entries[first + i];
+    }
+}
+
+// The hub rows between the tables and the ring: into slot 0 (a call's first step; every version count starts at 0), and the
+// tables' rows from each row's last version (its last step)
+__global__ void __launch_bounds__(kBlock) hub_versions_kernel(float *vertex, float *context, float *ring, const uint8_t *last, const uint32_t hot_vertex,
+                                                              const uint32_t hot_context, const int dim, const int to_ring) {
+    const size_t quads = (size_t)dim / 4, head_quads = (size_t)hot_vertex * quads, all = head_quads + (size_t)hot_context * quads;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= all) return;
+    f32x4 *in_table = i < head_quads ? reinterpret_cast<f32x4 *>(vertex) + i : reinterpret_cast<f32x4 *>(context) + (i - head_quads);
+    const size_t slot = to_ring || !last ? 0 : last[i / quads];
+    f32x4 *in_ring = reinterpret_cast<f32x4 *>(ring) + slot * all + i;
+    if (to_ring) *in_ring = *in_table;
+    else *in_table = *in_ring;
+}
+
 // ---- hub rows: work lists + launch (train_hot_kernel) -----------------------------------------------------------------
 
 struct HotLayout {
     size_t chain_start = 0, entries = 0, long_list = 0, short_list = 0, mirrors = 0, mirror_bytes = 0, bytes = 0;  // offsets into the workspace
-    uint32_t chains = 0, entry_capacity = 0, long_capacity = 0, cap = 0;
+    size_t versions = 0, slots = 0;  // versioned (gvk_ahead_*): ver[units][chains] bytes, the samples' slot words; `mirrors` is the ring
+    uint32_t chains = 0, entry_capacity = 0, long_capacity = 0, cap = 0, ring_slots = 0;
+    int slot_words = 0;
 };
 
 constexpr uint32_t kMaxChains = 32768;  // one LDS counter per chain in hot_list_kernel (128 KB of the CU's 160 KB)
@@ -769,10 +898,12 @@ uint32_t chain_cap_for(int chain_cap) {
 
 // One work list per part of a batch (parts divides batch_size: gvk_train_launches): num_batch * parts lists; behind them
 // the three mirrors of the hub rows (train_hot_kernel).
-HotLayout hot_layout(int dim, int batch_size, int k, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts, int chain_cap) {
+HotLayout hot_layout(int dim, int batch_size, int k, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts, int chain_cap,
+                     bool versioned = false) {
     HotLayout l;
     l.chains = hot_vertex + hot_context;
     l.cap = chain_cap_for(chain_cap);
+    const size_t samples = (size_t)num_batch * batch_size;
     num_batch *= parts;
     batch_size /= parts;
     // a sample adds at most k + 1 entries to its head's chain and one to the chain of each of its k + 1 targets
@@ -786,6 +917,14 @@ HotLayout hot_layout(int dim, int batch_size, int k, uint32_t hot_vertex, uint32
     l.mirrors = l.short_list + align((size_t)num_batch * (1 + (size_t)l.chains) * 64);
     l.mirror_bytes = align((size_t)l.chains * dim * 4);
     l.bytes = l.mirrors + 3 * l.mirror_bytes;
+    if (versioned) {  // the ring of 2 parts + 1 versions per hub row in place of the mirrors (slot s at mirrors + s * chains * dim * 4: no padding between slots)
+        l.ring_slots = 2u * (uint32_t)parts + 1;
+        l.slot_words = (k + 2 + 3) / 4;
+        l.mirror_bytes = (size_t)l.chains * dim * 4;
+        l.versions = l.mirrors + align((size_t)l.ring_slots * l.mirror_bytes);
+        l.slots = l.versions + align((size_t)num_batch * l.chains);
+        l.bytes = l.slots + align(samples * l.slot_words * 4);
+    }
     return l;
 }
 
@@ -1024,6 +1163,229 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     hipLaunchKernelGGL(hub_rows_kernel, dim3(mirror_blocks), dim3(kBlock), 0, (hipStream_t)stream, a.vertex, a.context, mirror(units - 1),
                        hot_vertex, hot_context, dim, 0);
     return check_launch("gvk_train_episode_hot");
+}
+
+
+// ---- the chain stream: gvk_ahead_plan / gvk_ahead_build / gvk_train_episode_ahead (include/gvk.h) ---------------------------
+
+int gvk_ahead_plan(int dim, int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts,
+                   int chain_cap, size_t *bytes) {
+    if (!bytes) return fail(GVK_EINVAL, "gvk_ahead_plan: bytes is null");
+    int rc = validate_hot("gvk_ahead_plan", dim, batch_size, num_negative, hot_vertex, hot_context, num_batch, parts);
+    if (rc != GVK_OK) return rc;
+    if (chain_cap < 0) return fail(GVK_EINVAL, "gvk_ahead_plan: negative chain_cap");
+    if (parts > 127) return fail(GVK_EINVAL, "gvk_ahead_plan: at most 127 parts (a slot is a byte, the ring holds 2 parts + 1 versions)");
+    *bytes = hot_layout(dim, batch_size, num_negative, hot_vertex, hot_context, num_batch, parts, chain_cap, true).bytes;
+    return GVK_OK;
+}
+
+int gvk_ahead_build(void *stream, int dim, void *workspace, size_t workspace_bytes, const uint32_t *pool, int batch_size, int num_batch,
+                    int num_negative, const gvk_negative_source *negative, uint32_t first_batch_id, uint32_t batch_id_stride,
+                    uint32_t hot_vertex, uint32_t hot_context, int parts, int chain_cap) {
+    if (parts > 127) return fail(GVK_EINVAL, "gvk_ahead_build: at most 127 parts");
+    if (num_batch <= 0) return num_batch < 0 ? fail(GVK_EINVAL, "gvk_ahead_build: negative num_batch") : GVK_OK;
+    if (hot_vertex > 0x7fffu || hot_context > 0x7fffu) return fail(GVK_EINVAL, "gvk_ahead_build: at most 32767 hub rows per table");
+    const HotLayout l = hot_layout(dim, batch_size, num_negative, hot_vertex, hot_context, num_batch, parts, chain_cap, true);
+    if (workspace_bytes < l.bytes) return gvk_fail(GVK_EINVAL, "gvk_ahead_build: workspace holds %zu bytes, %zu needed", workspace_bytes, l.bytes);
+    // the work lists as gvk_hot_build writes them (the layouts share their first part) ...
+    int rc = gvk_hot_build(stream, dim, workspace, workspace_bytes, pool, batch_size, num_batch, num_negative, negative, first_batch_id,
+                           batch_id_stride, hot_vertex, hot_context, parts, chain_cap);
+    if (rc != GVK_OK) return rc;
+    // ... then the versions and the slots
+    TrainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pairs = pool;
+    fill_negative(a, negative);
+    a.batch_size = batch_size; a.k = num_negative;
+    a.hot_vertex = hot_vertex; a.hot_context = hot_context;
+    char *base = static_cast<char *>(workspace);
+    const int units = num_batch * parts;
+    hipLaunchKernelGGL(hot_version_kernel, dim3((l.chains + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint32_t *>(base + l.chain_start), reinterpret_cast<uint8_t *>(base + l.versions), l.chains, units,
+                       l.ring_slots);
+    hipLaunchKernelGGL(hot_slots_kernel, dim3((unsigned)units), dim3(kListThreads), 0, (hipStream_t)stream, a, first_batch_id, batch_id_stride,
+                       reinterpret_cast<const uint32_t *>(base + l.chain_start), reinterpret_cast<uint32_t *>(base + l.entries),
+                       reinterpret_cast<uint32_t *>(base + l.long_list), reinterpret_cast<uint32_t *>(base + l.short_list),
+                       reinterpret_cast<const uint8_t *>(base + l.versions), reinterpret_cast<uint32_t *>(base + l.slots), l.entry_capacity,
+                       l.long_capacity, parts, l.slot_words);
+    return check_launch("gvk_ahead_build");
+}
+
+namespace {
+
+typedef void (*ChainKernel)(const TrainArgs, const HotArgs);
+typedef void (*HotPairsKernel)(const TrainArgs);
+
+ChainKernel pick_chain(int dim, int rounds) {
+#define GVK_CHAIN(D, GG) case D: return rounds ? chain_kernel<D, GG, 1> : chain_kernel<D, GG, 0>;
+    switch (dim) { GVK_CHAIN(32, 8) GVK_CHAIN(64, 16) GVK_CHAIN(96, 8) GVK_CHAIN(128, 16) GVK_CHAIN(256, 16) GVK_CHAIN(512, 32) }
+#undef GVK_CHAIN
+    return nullptr;
+}
+
+HotPairsKernel pick_hot_pairs(int dim, int k) {
+#define GVK_HOT_PAIRS(D, GG) case D: return k == 1 ? hot_pairs_kernel<D, GG, 1> : hot_pairs_kernel<D, GG, 0>;
+    switch (dim) { GVK_HOT_PAIRS(32, 8) GVK_HOT_PAIRS(64, 16) GVK_HOT_PAIRS(96, 8) GVK_HOT_PAIRS(128, 16) GVK_HOT_PAIRS(256, 16) GVK_HOT_PAIRS(512, 32) }
+#undef GVK_HOT_PAIRS
+    return nullptr;
+}
+
+// events of a chain stream, made once: "the chains of batch b are done" / "the pairs of batch b are done", four of each in rotation
+struct AheadEvents {
+    hipEvent_t chains_done[4], pairs_done[4], start;
+};
+std::mutex g_ahead_mutex;
+std::map<void *, AheadEvents> g_ahead_events;
+
+int ahead_events(void *chain_stream, AheadEvents **out) {
+    std::lock_guard<std::mutex> lock(g_ahead_mutex);
+    auto it = g_ahead_events.find(chain_stream);
+    if (it == g_ahead_events.end()) {
+        AheadEvents e;
+        for (int i = 0; i < 4; i++)
+            if (hipEventCreateWithFlags(&e.chains_done[i], hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
+                hipEventCreateWithFlags(&e.pairs_done[i], hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess)
+                return fail(GVK_EHIP, "gvk_train_episode_ahead: hipEventCreate failed");
+        if (hipEventCreateWithFlags(&e.start, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) return fail(GVK_EHIP, "gvk_train_episode_ahead: hipEventCreate failed");
+        it = g_ahead_events.emplace(chain_stream, e).first;
+    }
+    *out = &it->second;
+    return GVK_OK;
+}
+
+}  // namespace
+
+void gvk_ahead_release(void *chain_stream) {  // before the stream is destroyed: the events made for it
+    std::lock_guard<std::mutex> lock(g_ahead_mutex);
+    auto it = g_ahead_events.find(chain_stream);
+    if (it == g_ahead_events.end()) return;
+    for (int i = 0; i < 4; i++) (void)hipEventDestroy(it->second.chains_done[i]), (void)hipEventDestroy(it->second.pairs_done[i]);
+    (void)hipEventDestroy(it->second.start);
+    g_ahead_events.erase(it);
+}
+
+int gvk_train_episode_ahead(void *stream, void *chain_stream, int dim, const gvk_optimizer *optimizer, int linear_schedule,
+                            const gvk_tables *tables, const uint32_t *pairs, const gvk_negative_source *negative, uint32_t first_batch_id,
+                            uint32_t batch_id_stride, uint32_t total_batches, int num_batches, float *loss, int batch_size,
+                            int num_negative, float negative_weight, void *workspace, size_t workspace_bytes, uint32_t hot_vertex,
+                            uint32_t hot_context, int workspace_batches, int parts, int chain_cap, int pair_launches, int form) {
+    if (num_batches < 0 || num_batches > workspace_batches) return fail(GVK_EINVAL, "gvk_train_episode_ahead: more batches than the work lists cover");
+    int rc = validate_train(dim, optimizer, tables, pairs, negative, loss, batch_size, num_negative);
+    if (rc <= 0) return rc;
+    rc = validate_hot("gvk_train_episode_ahead", dim, batch_size, num_negative, hot_vertex, hot_context, workspace_batches, parts);
+    if (rc != GVK_OK) return rc;
+    if (optimizer->type != GVK_SGD) return fail(GVK_EINVAL, "gvk_train_episode_ahead: chains exist for SGD only");
+    if (negative->negatives) return fail(GVK_EINVAL, "gvk_train_episode_ahead draws negatives on device");
+    if (hot_vertex > tables->n_vertex || hot_context > tables->n_context)
+        return fail(GVK_EINVAL, "gvk_train_episode_ahead: more hub rows than table rows");
+    if (tables->n_vertex > 0x3fffffffu || tables->n_context > 0x3fffffffu)
+        return fail(GVK_EINVAL, "gvk_train_episode_ahead: at most 2^30 rows per table (an entry's id field)");
+    if (chain_cap < 0 || parts > 127) return fail(GVK_EINVAL, "gvk_train_episode_ahead: bad chain_cap / parts");
+    if (form & ~(GVK_HOT_SERIALIZED | GVK_HOT_ROUNDS)) return fail(GVK_EINVAL, "gvk_train_episode_ahead: unknown form bits");
+    if (pair_launches <= 0) pair_launches = parts;
+    if (parts % pair_launches) return fail(GVK_EINVAL, "gvk_train_episode_ahead: pair_launches must divide parts");
+    const bool serialized = (form & GVK_HOT_SERIALIZED) != 0 || g_hot_serialized != 0;
+    if (!serialized && (!chain_stream || chain_stream == stream))
+        return fail(GVK_EINVAL, "gvk_train_episode_ahead: the chains need a stream of their own (chain_stream)");
+    const HotLayout l = hot_layout(dim, batch_size, num_negative, hot_vertex, hot_context, workspace_batches, parts, chain_cap, true);
+    if (!workspace || workspace_bytes < l.bytes) return fail(GVK_EINVAL, "gvk_train_episode_ahead: workspace too small (gvk_ahead_plan)");
+    const uint32_t round_steps = g_round_steps >= 0 ? (uint32_t)g_round_steps : ((form & GVK_HOT_ROUNDS) ? (uint32_t)GVK_HOT_ROUND_STEPS : 0u);
+    const ChainKernel chain = pick_chain(dim, round_steps != 0);
+    const HotPairsKernel pair = pick_hot_pairs(dim, num_negative);
+    if (!chain || !pair) return fail(GVK_EDIM, "gvk_train_episode_ahead: no kernel for this dim");
+    if (num_batches == 0) return GVK_OK;
+    const int lanes = default_lanes(dim);
+    char *base = static_cast<char *>(workspace);
+    float *ring = reinterpret_cast<float *>(base + l.mirrors);
+    const uint8_t *versions = reinterpret_cast<const uint8_t *>(base + l.versions);
+    TrainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.vertex = tables->vertex; a.context = tables->context;
+    a.loss = loss;
+    fill_negative(a, negative);
+    a.batch_size = batch_size; a.k = num_negative; a.run_cap = 1;
+    a.wd = optimizer->weight_decay; a.neg_weight = negative_weight;
+    a.hot_vertex = hot_vertex; a.hot_context = hot_context;
+    a.hub_now = ring;
+    a.slot_words = l.slot_words;
+    HotArgs h;
+    memset(&h, 0, sizeof(h));
+    h.chains = l.chains; h.long_capacity = l.long_capacity; h.cap = l.cap;
+    h.round_steps = round_steps;
+    h.from = ring, h.to = ring;
+    h.slot_stride = l.chains, h.ring_slots = l.ring_slots, h.versioned = 1;
+    const int groups = kHotBlock / lanes;
+    h.short_blocks = (int)((l.chains + groups - 1) / groups);
+    h.long_blocks = (int)std::min<uint32_t>(l.long_capacity, (uint32_t)kLongBlocks);
+    const int part_size = batch_size / parts;
+    const bool chains_only = hot_vertex == tables->n_vertex && hot_context == tables->n_context;
+    auto lr_of = [&](int i) {
+        const uint32_t id = first_batch_id + (uint32_t)i * batch_id_stride;
+        float scale = 1;
+        if (linear_schedule) {  // optimizer.h:77-79
+            scale = 1 - float(int(id)) / int(total_batches);
+            if (scale < 1e-4f) scale = 1e-4f;
+        }
+        return optimizer->lr * scale;
+    };
+    auto chains_of = [&](int u, hipStream_t on) {  // the chains of unit u
+        h.chain_start = reinterpret_cast<const uint32_t *>(base + l.chain_start) + (size_t)u * (l.chains + 1);
+        h.entries = reinterpret_cast<const uint32_t *>(base + l.entries) + (size_t)u * l.entry_capacity;
+        h.long_list = reinterpret_cast<const uint32_t *>(base + l.long_list) + (size_t)u * 4 * (1 + (size_t)l.long_capacity);
+        h.short_list = reinterpret_cast<const uint32_t *>(base + l.short_list) + (size_t)u * 16 * (1 + (size_t)l.chains);
+        h.lr = lr_of(u / parts);
+        h.log2_decay_positive = (float)std::log2(1.0 - (double)h.lr * a.wd);
+        h.log2_decay_negative = (float)std::log2(1.0 - (double)h.lr * a.neg_weight * a.wd);
+        a.lr = h.lr;
+        hipLaunchKernelGGL(chain, dim3((unsigned)(h.long_blocks + h.short_blocks)), dim3(kHotBlock), 0, on, a, h);
+    };
+    auto pairs_of = [&](int i, int first_part, int count, hipStream_t on) {  // the pairs of parts [first_part, first_part + count) of batch i
+        if (chains_only && i != num_batches - 1) return;
+        a.lr = lr_of(i);
+        a.batch_id = first_batch_id + (uint32_t)i * batch_id_stride;
+        a.pairs = pairs + (size_t)i * batch_size * 2;
+        a.slots = reinterpret_cast<const uint32_t *>(base + l.slots) + (size_t)i * batch_size * l.slot_words;
+        a.first_sample = first_part * part_size;
+        a.batch_size = a.first_sample + count * part_size;
+        const unsigned blocks = (unsigned)(((int64_t)count * part_size * lanes + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(pair, dim3(blocks), dim3(kBlock), 0, on, a);
+    };
+    const hipStream_t main = (hipStream_t)stream, side = (hipStream_t)chain_stream;
+    const unsigned ring_blocks = (unsigned)(((size_t)l.chains * (size_t)(dim / 4) + kBlock - 1) / kBlock);
+    // the hub rows enter the ring at slot 0
+    hipLaunchKernelGGL(hub_versions_kernel, dim3(ring_blocks), dim3(kBlock), 0, main, a.vertex, a.context, ring, nullptr, hot_vertex, hot_context, dim, 1);
+    if (serialized) {  // tests: per unit the chains, then the pairs, on one stream — a pure function of the work lists
+        for (int u = 0; u < num_batches * parts; u++) {
+            chains_of(u, main);
+            pairs_of(u / parts, u % parts, 1, main);
+        }
+    } else {
+        AheadEvents *events = nullptr;
+        rc = ahead_events(chain_stream, &events);
+        if (rc != GVK_OK) return rc;
+        // what the caller put on `stream` before this call (the work lists, the tables) comes before the chains, too
+        if (hipEventRecord(events->start, main) != hipSuccess || hipStreamWaitEvent(side, events->start, 0) != hipSuccess)
+            return fail(GVK_EHIP, "gvk_train_episode_ahead: event record / wait failed");
+        const int per_launch = parts / pair_launches;
+        const auto host_t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < num_batches; i++) {
+            // the chains of batch i wait for the pairs of batch i - 2: what those pairs read of the ring may be overwritten now
+            if (i >= 2 && hipStreamWaitEvent(side, events->pairs_done[(i - 2) & 3], 0) != hipSuccess)
+                return fail(GVK_EHIP, "gvk_train_episode_ahead: event wait failed");
+            for (int q = 0; q < parts; q++) chains_of(i * parts + q, side);
+            if (hipEventRecord(events->chains_done[i & 3], side) != hipSuccess || hipStreamWaitEvent(main, events->chains_done[i & 3], 0) != hipSuccess)
+                return fail(GVK_EHIP, "gvk_train_episode_ahead: event record / wait failed");
+            for (int q = 0; q < parts; q += per_launch) pairs_of(i, q, per_launch, main);
+            if (hipEventRecord(events->pairs_done[i & 3], main) != hipSuccess) return fail(GVK_EHIP, "gvk_train_episode_ahead: event record failed");
+        }
+        if (getenv("GVK_AHEAD_DEBUG"))  // measurement: what the host pays to enqueue a batch
+            fprintf(stderr, "gvk_train_episode_ahead: %d batches enqueued in %.1f us per batch (%d + %d launches, 4 event calls each)\n", num_batches,
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count() / num_batches, parts, pair_launches);
+    }
+    // ... and leave it: the tables' hub rows = each row's last version (the pairs of the last batch have waited for its chains)
+    hipLaunchKernelGGL(hub_versions_kernel, dim3(ring_blocks), dim3(kBlock), 0, main, a.vertex, a.context, ring,
+                       versions + (size_t)(num_batches * parts - 1) * l.chains, hot_vertex, hot_context, dim, 0);
+    return check_launch("gvk_train_episode_ahead");
 }
 
 }  // extern "C"

@@ -62,6 +62,11 @@ struct TrainArgs {
     const float *hub_now;     // HOT builds: the hub rows [hot_vertex + hot_context][dim] (head rows first) as the chains of the pairs' unit left them
     const float *hub_before;  // HOT == 2: ... and as those chains found them (a sample reads a hub row on the straight line between the two)
     float hub_step;           // HOT == 2: 1 / samples of the unit
+    // HOT == 3 (gvk_train_episode_ahead): hub_now is a ring of versions per hub row, version at slot s of row i at
+    // hub_now[(s * (hot_vertex + hot_context) + i) * dim]; slots: per sample of the batch slot_words words whose bytes name the slot its
+    // head row (byte 0), its tail (byte 1) and its negatives (bytes 2 ..) are read at — written by hot_slots_kernel
+    const uint32_t *slots;
+    int slot_words;
     float lr, wd, neg_weight, hp0, hp1, eps;
 };
 
@@ -278,7 +283,8 @@ __device__ __forceinline__ float update(const TrainArgs &a, float parameter, flo
 // up front); DRAW fixes the negative source (-1: decided at run time).  WAVES is the occupancy the register
 // allocator is asked for (waves per SIMD).
 // HOT: the hub rows of both tables — local ids below a.hot_vertex / a.hot_context; partitions are ordered by falling
-// degree — belong to the chains of train_hot_kernel: this body reads them and never stores them.
+// degree — belong to the chains of train_hot_kernel: this body reads them and never stores them (1: from the mirror hub_now, 2: on
+// the line from hub_before to hub_now, 3: from the ring of versions hub_now at the slots a.slots names for the sample).
 template <int DIM, int G, int OPT, int KT, int DRAW, int HOT>
 __device__ __forceinline__ void train_pair(const TrainArgs &a, const int tid) {
     constexpr int V = DIM / G;
@@ -294,6 +300,8 @@ __device__ __forceinline__ void train_pair(const TrainArgs &a, const int tid) {
     // round trip 1: the pair, requested before anything is computed, and the first negative's alias slot (Philox runs
     // while the pair is on its way)
     const u32x2 pr = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(a.pairs) + s);
+    uint32_t slot_word0 = 0;
+    if constexpr (HOT == 3) slot_word0 = __builtin_nontemporal_load(a.slots + (size_t)s * a.slot_words);
     Draw d0 = {0, 0, 0};
     NegEntry e0 = {0, 0, 0, 0};
     uint32_t neg0 = 0;
@@ -308,13 +316,21 @@ __device__ __forceinline__ void train_pair(const TrainArgs &a, const int tid) {
     const uint32_t tail = pr.x, head = pr.y;  // records are {tail, head}
 
     // HOT: a hub row is read from the mirror the chains of the unit stored it to (the table's copy is written once, when
-    // the call ends), every other row from its table
+    // the call ends), every other row from its table.  HOT == 3: from the ring, at the slot byte `which` of the sample's slot
+    // words names (0 the head, 1 the tail, 2 + j negative j)
+    auto slot_of = [&](const int which) __attribute__((always_inline)) -> size_t {
+        if constexpr (HOT == 3) {
+            const uint32_t word = which < 4 ? slot_word0 : a.slots[(size_t)s * a.slot_words + (which >> 2)];
+            return (size_t)((word >> (8 * (which & 3))) & 0xffu) * (a.hot_vertex + a.hot_context);
+        }
+        return 0;
+    };
     auto vertex_row = [&](const uint32_t id) __attribute__((always_inline)) -> const float * {
-        if (HOT != 0 && id < a.hot_vertex) return a.hub_now + (size_t)id * DIM;
+        if (HOT != 0 && id < a.hot_vertex) return a.hub_now + (slot_of(0) + id) * DIM;
         return a.vertex + (size_t)id * DIM;
     };
-    auto context_row = [&](const uint32_t id) __attribute__((always_inline)) -> const float * {
-        if (HOT != 0 && id < a.hot_context) return a.hub_now + ((size_t)a.hot_vertex + id) * DIM;
+    auto context_row = [&](const uint32_t id, const int which) __attribute__((always_inline)) -> const float * {
+        if (HOT != 0 && id < a.hot_context) return a.hub_now + (slot_of(which) + a.hot_vertex + id) * DIM;
         return a.context + (size_t)id * DIM;
     };
 
@@ -349,14 +365,14 @@ __device__ __forceinline__ void train_pair(const TrainArgs &a, const int tid) {
     float early[kTailEarly ? V : 1], early_before[kTailEarly ? VB : 1];
     const bool early_hub = HOT == 2 && kTailEarly && tail < a.hot_context;
     if constexpr (kTailEarly) {
-        load_row_at<DIM, G>(context_row(tail), lane, reinterpret_cast<float(&)[V]>(early));
+        load_row_at<DIM, G>(context_row(tail, 1), lane, reinterpret_cast<float(&)[V]>(early));
         before_row(early_hub, (size_t)a.hot_vertex + tail, reinterpret_cast<float(&)[VB]>(early_before));
     }
 
     uint32_t id_cur = k > 0 ? (draw ? resolve(a, d0, e0) : neg0) : tail;
     float cur[V], cur1[M1], cur2[M2], cur_before[VB];
     bool cur_hub = HOT == 2 && id_cur < a.hot_context;
-    load_row_at<DIM, G>(context_row(id_cur), lane, cur);
+    load_row_at<DIM, G>(context_row(id_cur, k > 0 ? 2 : 1), lane, cur);
     before_row(cur_hub, (size_t)a.hot_vertex + id_cur, cur_before);
     if constexpr (NM >= 1) load_row<DIM, G>(a.cm1, id_cur, lane, reinterpret_cast<float(&)[V]>(cur1));
     if constexpr (NM >= 2) load_row<DIM, G>(a.cm2, id_cur, lane, reinterpret_cast<float(&)[V]>(cur2));
@@ -384,7 +400,7 @@ __device__ __forceinline__ void train_pair(const TrainArgs &a, const int tid) {
                 nxt_hub = early_hub;
             } else {
                 nxt_hub = HOT == 2 && id_nxt < a.hot_context;
-                load_row_at<DIM, G>(context_row(id_nxt), lane, nxt);
+                load_row_at<DIM, G>(context_row(id_nxt, j + 1 < k ? 3 + j : 1), lane, nxt);
                 before_row(nxt_hub, (size_t)a.hot_vertex + id_nxt, nxt_before);
                 if constexpr (NM >= 1) load_row<DIM, G>(a.cm1, id_nxt, lane, reinterpret_cast<float(&)[V]>(nxt1));
                 if constexpr (NM >= 2) load_row<DIM, G>(a.cm2, id_nxt, lane, reinterpret_cast<float(&)[V]>(nxt2));

@@ -57,6 +57,7 @@ constexpr int kHubMaxParts = 32;  // measured on the headline shape at P = 8 (a 
                                   // parts end -0.0013 / +0.0008 / +0.0013 / +0.0022 from the reference's loop — past 32 the parts only cost launches
 constexpr int kHubMaxPartsResident = 50;  // cache-resident tables (< 16 MiB): a small partition's chains are feasible up to this many parts (§7.8)
 constexpr int kHubLerp = 0;              // GVX_HUB_LERP -1: the pairs read hub rows as their part's chains left them
+constexpr int kHubExecutor = 0;          // GVX_HUB_EXECUTOR -1: one launch per unit carries its pairs and the next unit's chains (gvk_train_episode_hot); 1: the chains as a stream of their own, a batch ahead of the pairs (gvk_train_episode_ahead: measured slower)
 constexpr int kMinEpisodeSample = 20000000;
 constexpr int kExpectedDegree = 1600;  // graph.cuh:55
 constexpr float kMaxNegativeWeight = 10;
@@ -132,8 +133,14 @@ struct Worker {
     uint32_t *pool[2] = {nullptr, nullptr}, *landing = nullptr;
     void *group_workspace = nullptr;
     size_t group_workspace_bytes = 0;
-    void *hub_workspace = nullptr;  // work lists of the hub rows' chains for kHubChunk batches (gvk_hot_build)
+    // hub rows by chains: the work lists of hub_chunk batches (gvk_hot_build) in two workspaces — the lists of the NEXT chunk are built
+    // on the `lists` stream while this one trains out of the other; `chains`: the chains' stream of the chain-stream executor
+    void *hub_workspaces[2] = {nullptr, nullptr};
     size_t hub_workspace_bytes = 0;
+    hipStream_t chains = nullptr, lists = nullptr;
+    hipEvent_t lists_built[2] = {nullptr, nullptr}, lists_trained[2] = {nullptr, nullptr};
+    bool lists_trained_valid[2] = {false, false};
+    uint64_t chunks_built = 0, chunks_trained = 0;
     hipEvent_t uploaded[2] = {nullptr, nullptr}, released[2] = {nullptr, nullptr}, trained = nullptr;
     bool released_valid[2] = {false, false};
     std::vector<hipEvent_t> copied;     // H2D copies of the current pool set still reading pinned memory
@@ -181,6 +188,12 @@ struct gvx_solver {
     bool hogwild_said = false, order_said = false;  // warnings of configure() that are given once per solver
     int hub_rounds_request = -1;    // GVX_HUB_ROUNDS: -1 the rule (kHubRoundEntries), 0 / 1: long chains in one round / in rounds
     int hub_lerp_request = -1;      // GVX_HUB_LERP: -1 the rule, 0 / 1: the pairs read hub rows as their unit's chains left them / along the chains' way
+    int hub_executor_request = -1;  // GVX_HUB_EXECUTOR: -1 the rule (kHubExecutor; the fused launches where lerp is asked for), 0 / 1
+    int hub_pair_launches_request = 0;  // GVX_HUB_PAIR_LAUNCHES: launches the pairs of a batch are trained as under the chain-stream executor (0: one per part)
+    bool hub_ahead() const {  // the chain-stream executor trains the hub rows (a schedule computed by a callback trains batch by batch: fused)
+        const int lerp = hub_lerp_request < 0 ? kHubLerp : hub_lerp_request;
+        return (hub_executor_request < 0 ? (lerp ? 0 : kHubExecutor) : hub_executor_request) == 1 && optimizer.schedule != 2;
+    }
     int hub_chunk = kHubChunk;      // batches whose work lists are built at once (fewer where memory is short)
     int hub_max_parts = kHubMaxParts;  // most parts a batch is trained as (kHubMaxPartsResident for cache-resident tables)
     int hub_chain_cap_request = 0;  // GVX_HUB_CHAIN_CAP: entries one chain task trains in sequence (0 = the kernels' default)
@@ -259,7 +272,13 @@ struct gvx_solver {
         for (Worker &w : workers) {
             hipSetDevice(w.device);
             hipFree(w.head), hipFree(w.context), hipFree(w.loss), hipFree(w.pool[0]), hipFree(w.pool[1]);
-            hipFree(w.landing), hipFree(w.group_workspace), hipFree(w.hub_workspace);
+            hipFree(w.landing), hipFree(w.group_workspace), hipFree(w.hub_workspaces[0]), hipFree(w.hub_workspaces[1]);
+            for (int b = 0; b < 2; b++) {
+                if (w.lists_built[b]) hipEventDestroy(w.lists_built[b]);
+                if (w.lists_trained[b]) hipEventDestroy(w.lists_trained[b]);
+            }
+            if (w.chains) gvk_ahead_release(w.chains), hipStreamDestroy(w.chains);
+            if (w.lists) hipStreamDestroy(w.lists);
             for (auto *t : w.negative_tables) hipFree(t);
             for (auto *t : w.negative_classes) hipFree(t);
             hipFree(w.block_pools[0]), hipFree(w.block_pools[1]), hipFree(w.route_send), hipFree(w.route_recv);
@@ -329,6 +348,7 @@ struct gvx_solver {
     int device_fill(int set);
     int route_slices(int set);
     int hub_parts_of(int hp, int tp) const;
+    int hub_workspace_for(Worker &w, size_t need);
     bool hub_rounds_of(int hp, int tp) const;
     double hub_graph_share = 0;  // the largest vertex's share of the graph's total degree
     std::vector<double> hub_top_share, hub_next_hits;  // per partition: the largest row's share of the partition's degree; expected hits per batch of the first row that is not a hub row
@@ -394,8 +414,9 @@ size_t gvx_solver::memory_demand(int P, int requested_episode, bool as_streamed)
     // most, as much again for the chains' records) — of fewer batches where that would be more than a sixteenth of the memory
     // (prepare_devices).  The mirrors of the hub rows (at most 3 x 2 x kMaxHubRows rows: 50 MB at dim 128) are not counted.
     // — only where chains can exist: SGD, and not fidelity = "throughput"
-    if (optimizer.type == GVK_SGD && fidelity != 0)
-        demand += std::min((size_t)kHubChunk * batch_size * (num_negative + 1) * 32, gpu_memory_limit / 16);
+    // Two such workspaces: the lists of the next chunk are built while this one trains.
+    if (optimizer.type == GVK_SGD && (fidelity != 0 || hub_rows_request > -2) && hub_rows_request != 0)
+        demand += 2 * std::min((size_t)kHubChunk * batch_size * (num_negative + 1) * 32, gpu_memory_limit / 16);
     if (device_sampling && !as_streamed) {
         // the pools of every block a worker trains, two episodes, + its slices on their way to the owners (send + receive)
         demand += 4 * tails * P * pool;
@@ -585,6 +606,14 @@ extern "C" int gvx_solver_set(gvx_solver *s, int option, int64_t value) {
     }
     if (option == GVX_HUB_LERP && value >= -1 && value <= 1) {
         s->hub_lerp_request = (int)value;
+        return GVK_OK;
+    }
+    if (option == GVX_HUB_EXECUTOR && value >= -1 && value <= 1) {
+        s->hub_executor_request = (int)value;
+        return GVK_OK;
+    }
+    if (option == GVX_HUB_PAIR_LAUNCHES && value >= 0 && value <= 127) {
+        s->hub_pair_launches_request = (int)value;
         return GVK_OK;
     }
     if (option == GVX_HUB_ROUNDS && value >= -1 && value <= 1) {
@@ -1015,6 +1044,12 @@ int gvx_solver::prepare_devices() {
         HIP_TRY(hipStreamCreateWithFlags(&w.compute, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&w.copy, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&w.exchange, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&w.chains, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&w.lists, hipStreamNonBlocking));
+        for (int b = 0; b < 2; b++) {
+            HIP_TRY(hipEventCreateWithFlags(&w.lists_built[b], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&w.lists_trained[b], hipEventDisableTiming));
+        }
         const size_t head_slots = streamed ? 1 : (size_t)P, context_slots = streamed ? 1 : w.tails.size();
         HIP_TRY(hipMalloc(&w.head, head_slots * slot_floats() * 4));
         HIP_TRY(hipMalloc(&w.context, context_slots * slot_floats() * 4));
@@ -1188,18 +1223,13 @@ int gvx_solver::allocate_pools() {
                     for (int tp = 0; tp < num_partition; tp++) {
                         if (hub_rows[hp] + hub_rows[tp] == 0) continue;
                         size_t bytes = 0;
-                        GVK_TRY(gvk_hot_plan(dim, batch_size, num_negative, hub_rows[hp], hub_rows[tp], hub_chunk, hub_parts_of(hp, tp),
-                                             hub_chain_cap_request, &bytes));
+                        GVK_TRY((hub_ahead() ? gvk_ahead_plan : gvk_hot_plan)(dim, batch_size, num_negative, hub_rows[hp], hub_rows[tp], hub_chunk,
+                                                                              hub_parts_of(hp, tp), hub_chain_cap_request, &bytes));
                         need = std::max(need, bytes);
                     }
-                if (need <= gpu_memory_limit / 16 || hub_chunk == 1) break;
+                if (need <= gpu_memory_limit / 32 || hub_chunk == 1) break;  // two workspaces
             }
-            if (need > w.hub_workspace_bytes) {
-                hipFree(w.hub_workspace);
-                w.hub_workspace = nullptr, w.hub_workspace_bytes = 0;
-                HIP_TRY(hipMalloc(&w.hub_workspace, need));
-                w.hub_workspace_bytes = need;
-            }
+            GVK_TRY(hub_workspace_for(w, need));
         }
     }
     return GVK_OK;
@@ -1659,6 +1689,24 @@ bool gvx_solver::hub_rounds_of(int hp, int tp) const {
     return hub_graph_share > kHubRoundShare;
 }
 
+// The two workspaces of a worker's chains hold at least `need` bytes each
+int gvx_solver::hub_workspace_for(Worker &w, size_t need) {
+    if (need <= w.hub_workspace_bytes) return GVK_OK;
+    HIP_TRY(hipSetDevice(w.device));
+    HIP_TRY(hipStreamSynchronize(w.compute));
+    HIP_TRY(hipStreamSynchronize(w.lists));
+    HIP_TRY(hipStreamSynchronize(w.chains));
+    for (int b = 0; b < 2; b++) {
+        hipFree(w.hub_workspaces[b]);
+        w.hub_workspaces[b] = nullptr;
+        w.lists_trained_valid[b] = false;
+    }
+    w.hub_workspace_bytes = 0;
+    for (int b = 0; b < 2; b++) HIP_TRY(hipMalloc(&w.hub_workspaces[b], need));
+    w.hub_workspace_bytes = need;
+    return GVK_OK;
+}
+
 int gvx_solver::hub_parts_of(int hp, int tp) const {
     const int B = batch_size;
     const uint32_t kv = hubs ? hub_rows[hp] : 0, kc = hubs ? hub_rows[tp] : 0;
@@ -1729,28 +1777,45 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int
             // kHubRoundEntries the gradient steps of entries that start from one state add up past the reference's loop
             const bool rounds = hub_rounds_of(hp, tp);
             const int form = ((hub_lerp_request < 0 ? kHubLerp : hub_lerp_request) ? GVK_HOT_LERP : 0) | (rounds ? GVK_HOT_ROUNDS : 0);
+            const bool ahead = hub_ahead();
             size_t need = 0;
-            GVK_TRY(gvk_hot_plan(dim, B, num_negative, kv, kc, hub_chunk, parts, chain_cap, &need));
-            if (need > w.hub_workspace_bytes) {  // first block, or a block with more hub rows / parts than any before it
-                HIP_TRY(hipStreamSynchronize(w.compute));
-                hipFree(w.hub_workspace);
-                w.hub_workspace = nullptr, w.hub_workspace_bytes = 0;
-                HIP_TRY(hipMalloc(&w.hub_workspace, need));
-                w.hub_workspace_bytes = need;
-            }
+            GVK_TRY((ahead ? gvk_ahead_plan : gvk_hot_plan)(dim, B, num_negative, kv, kc, hub_chunk, parts, chain_cap, &need));
+            GVK_TRY(hub_workspace_for(w, need));  // first block, or a block with more hub rows / parts than any before it
             // a schedule computed by a callback (optimizer.h:132-134) gives every batch its learning rate on the host: a call per batch
             const int chunk = optimizer.schedule == 2 ? 1 : hub_chunk;
+            // The work lists of a chunk depend on the pool and the draws' seed only, never on the embeddings: they are built on the
+            // lists stream into one of two workspaces while the chunk before trains out of the other (the lists stream has waited for
+            // the pool: train_step) — nothing but training launches on the compute stream.
+            const int pair_launches = hub_pair_launches_request > 0 && parts % hub_pair_launches_request == 0 ? hub_pair_launches_request : 0;
+            auto build = [&](int at) -> int {
+                const int slot = (int)(w.chunks_built & 1), m = std::min(chunk, n - at);
+                if (w.lists_trained_valid[slot]) HIP_TRY(hipStreamWaitEvent(w.lists, w.lists_trained[slot], 0));
+                GVK_TRY((ahead ? gvk_ahead_build : gvk_hot_build)(w.lists, dim, w.hub_workspaces[slot], w.hub_workspace_bytes, pool + (size_t)(done + at) * B * 2, B, m,
+                                                                  num_negative, &neg, (uint32_t)(first + (uint64_t)at * W), (uint32_t)W, kv, kc, parts, chain_cap));
+                HIP_TRY(hipEventRecord(w.lists_built[slot], w.lists));
+                w.chunks_built++;
+                return GVK_OK;
+            };
+            GVK_TRY(build(0));
             for (int at = 0; at < n; at += chunk) {
-                const int m = std::min(chunk, n - at);
+                const int slot = (int)(w.chunks_trained & 1), m = std::min(chunk, n - at);
                 const uint64_t id = first + (uint64_t)at * W;
                 const uint32_t *batches = pool + (size_t)(done + at) * B * 2;
                 gvk_optimizer ob = o;
                 if (optimizer.schedule == 2) ob.lr = optimizer.lr * optimizer.schedule_function((int)id, (int)num_batch, optimizer.user);
-                GVK_TRY(gvk_hot_build(w.compute, dim, w.hub_workspace, w.hub_workspace_bytes, batches, B, m, num_negative, &neg, (uint32_t)id,
-                                      (uint32_t)W, kv, kc, parts, chain_cap));
-                GVK_TRY(gvk_train_episode_hot(w.compute, dim, &ob, optimizer.schedule == 1, &t, batches, &neg, (uint32_t)id, (uint32_t)W,
-                                              (uint32_t)num_batch, m, w.loss, B, num_negative, config.negative_weight,
-                                              w.hub_workspace, w.hub_workspace_bytes, kv, kc, m, parts, chain_cap, form));
+                HIP_TRY(hipStreamWaitEvent(w.compute, w.lists_built[slot], 0));
+                if (ahead)
+                    GVK_TRY(gvk_train_episode_ahead(w.compute, w.chains, dim, &ob, optimizer.schedule == 1, &t, batches, &neg, (uint32_t)id, (uint32_t)W,
+                                                    (uint32_t)num_batch, m, w.loss, B, num_negative, config.negative_weight, w.hub_workspaces[slot],
+                                                    w.hub_workspace_bytes, kv, kc, m, parts, chain_cap, pair_launches, rounds ? GVK_HOT_ROUNDS : 0));
+                else
+                    GVK_TRY(gvk_train_episode_hot(w.compute, dim, &ob, optimizer.schedule == 1, &t, batches, &neg, (uint32_t)id, (uint32_t)W,
+                                                  (uint32_t)num_batch, m, w.loss, B, num_negative, config.negative_weight,
+                                                  w.hub_workspaces[slot], w.hub_workspace_bytes, kv, kc, m, parts, chain_cap, form));
+                HIP_TRY(hipEventRecord(w.lists_trained[slot], w.compute));
+                w.lists_trained_valid[slot] = true;
+                w.chunks_trained++;
+                if (at + chunk < n) GVK_TRY(build(at + chunk));
             }
         } else if (optimizer.schedule != 2) {
             GVK_TRY(gvk_train_episode(w.compute, dim, &o, optimizer.schedule == 1, &t, pool + (size_t)done * B * 2, &neg,
@@ -1888,7 +1953,11 @@ int gvx_solver::train_step(int step, int set, int first, int count, bool stage_n
         const int b = (int)(w.visits & 1);
         HIP_TRY(hipSetDevice(w.device));
         HIP_TRY(hipStreamWaitEvent(w.compute, w.uploaded[b], 0));
-        if (w.block_pools[0]) HIP_TRY(hipStreamWaitEvent(w.compute, w.filled[set], 0));
+        HIP_TRY(hipStreamWaitEvent(w.lists, w.uploaded[b], 0));  // the chains' work lists are built from the pool (train_block)
+        if (w.block_pools[0]) {
+            HIP_TRY(hipStreamWaitEvent(w.compute, w.filled[set], 0));
+            HIP_TRY(hipStreamWaitEvent(w.lists, w.filled[set], 0));
+        }
         if (stage_next) {
             w.visits++;
             const int rc = stage(w, next_step, next_set, (int)(w.visits & 1));

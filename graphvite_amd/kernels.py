@@ -202,6 +202,55 @@ class HipKernels(object):
                                             parts, chain_cap, (self.HOT_SERIALIZED if serialized else 0) | (self.HOT_LERP if lerp else 0))
         _lib.check(rc, "gvk_train_episode_hot")
 
+    HOT_ROUNDS = 4  # gvk.h GVK_HOT_ROUNDS
+
+    def ahead_plan(self, dim, batch_size, num_negative, hot_vertex, hot_context, num_batch, parts=1, chain_cap=0):
+        """gvk_ahead_plan: bytes of workspace of the chain-stream executor (work lists, versions, slot words, the ring)."""
+        n = C.c_size_t(0)
+        _lib.check(self.lib.gvk_ahead_plan(dim, batch_size, num_negative, hot_vertex, hot_context, num_batch, parts, chain_cap,
+                                           C.byref(n)), "gvk_ahead_plan")
+        return n.value
+
+    def ahead_build(self, dim, workspace, pool, batch_size, num_batch, num_negative, table, seed, first_batch_id, hot_vertex,
+                    hot_context, batch_id_stride=1, parts=1, chain_cap=0):
+        """gvk_ahead_build: the work lists of gvk_hot_build + the hub rows' versions and the slots that name them."""
+        dev = pool.device
+        _need(pool, torch.int32, "pool", dev)
+        neg = self._negative(None, table, seed, dev)
+        rc = self.lib.gvk_ahead_build(self._stream(pool), dim, _ptr(workspace), workspace.numel(), _ptr(pool), batch_size, num_batch,
+                                      num_negative, C.byref(neg), first_batch_id, batch_id_stride, hot_vertex, hot_context, parts,
+                                      chain_cap)
+        _lib.check(rc, "gvk_ahead_build")
+
+    def train_episode_ahead(self, vertex, context, pool, loss, optimizer, num_negative, negative_weight, table, seed,
+                            first_batch_id, total_batches, num_batches, batch_size, workspace, hot_vertex, hot_context,
+                            workspace_batches=None, batch_id_stride=1, serialized=False, parts=1, chain_cap=0, pair_launches=0,
+                            rounds=False, chain_stream=None):
+        """gvk_train_episode_ahead: the chains on `chain_stream` (a torch.cuda.Stream; made once per device when not given), a batch
+        ahead of the pairs on the current stream."""
+        dev = vertex.device
+        tables = self._tables(vertex, context, None)
+        _need(pool, torch.int32, "pool", dev)
+        _need(loss, torch.float32, "loss", dev)
+        neg = self._negative(None, table, seed, dev)
+        opt = optimizer.c_struct()
+        side = 0
+        if not serialized:
+            if chain_stream is None:
+                streams = self.__dict__.setdefault("_chain_streams", {})
+                chain_stream = streams.get(dev)
+                if chain_stream is None:
+                    chain_stream = streams[dev] = torch.cuda.Stream(device=dev)
+            side = chain_stream.cuda_stream
+        rc = self.lib.gvk_train_episode_ahead(self._stream(vertex), side, vertex.shape[1], C.byref(opt),
+                                              int(optimizer.schedule == "linear"), C.byref(tables), _ptr(pool), C.byref(neg),
+                                              first_batch_id, batch_id_stride, total_batches, num_batches, _ptr(loss), batch_size,
+                                              num_negative, negative_weight, _ptr(workspace), workspace.numel(), hot_vertex,
+                                              hot_context, num_batches if workspace_batches is None else workspace_batches,
+                                              parts, chain_cap, pair_launches,
+                                              (self.HOT_SERIALIZED if serialized else 0) | (self.HOT_ROUNDS if rounds else 0))
+        _lib.check(rc, "gvk_train_episode_ahead")
+
     def predict(self, vertex, context, pairs, logits):
         dev = vertex.device
         _need(vertex, torch.float32, "vertex")

@@ -212,6 +212,38 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
                           uint32_t hot_vertex, uint32_t hot_context, int workspace_batches, int parts, int chain_cap,
                           int form);
 
+/* The same chains as a stream of their own, a batch AHEAD of the pairs (the default executor of hub-heavy tables).
+ * A launch that carries a unit's pairs and the next unit's chains (gvk_train_episode_hot) lasts as long as its longest chain
+ * (10-12 us: a dependency chain) while its pairs are done after 5-6.  Here the chains of every unit run back to back as launches
+ * of their own on `chain_stream` and the pairs of a batch follow on `stream` once that batch's chains are done — while the
+ * chains of the next batch already run.  Same chains, same pairs, same units as gvk_train_episode_hot (what a unit's chains
+ * read of the hub rows, what its pairs read, is unchanged); what changes is when a chain sees the rows that are NOT hub rows:
+ * up to two batches before the pairs have caught up (such a row is hit less than once per batch).  The hub rows live in a ring
+ * of 2 parts + 1 versions per row inside the workspace — a row's version advances in every unit that has entries for it; the
+ * work lists name the slot of every hub row a chain or a pair reads — so nothing is copied for rows a unit does not touch.
+ *   gvk_ahead_plan   bytes of workspace: the work lists of num_batch batches, the versions, the samples' slot words, the ring
+ *   gvk_ahead_build  gvk_hot_build + the versions and slots; on `stream` (a caller builds the lists of the next chunk on its
+ *                    copy stream while this chunk trains)
+ *   gvk_train_episode_ahead   the chains on chain_stream, the pairs on stream, ordered by events (the chains of batch b + 2
+ *                    wait for the pairs of batch b); `stream` has everything of the call behind it when it returns, the
+ *                    tables hold the hub rows again.  pair_launches (a divisor of parts; 0 = parts): launches the pairs of
+ *                    a batch are trained as.  form: GVK_HOT_SERIALIZED (chain_stream unused: per unit the chains, then the
+ *                    pairs, on `stream` — the function of the work lists the oracle restates), GVK_HOT_ROUNDS.
+ * parts <= 127 (a slot is one byte); at most 32767 hub rows per table and 2^30 rows per table (fields of a work-list entry). */
+int gvk_ahead_plan(int dim, int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts,
+                   int chain_cap, size_t *bytes);
+int gvk_ahead_build(void *stream, int dim, void *workspace, size_t workspace_bytes, const uint32_t *pool, int batch_size,
+                    int num_batch, int num_negative, const gvk_negative_source *negative, uint32_t first_batch_id,
+                    uint32_t batch_id_stride, uint32_t hot_vertex, uint32_t hot_context, int parts, int chain_cap);
+int gvk_train_episode_ahead(void *stream, void *chain_stream, int dim, const gvk_optimizer *optimizer, int linear_schedule,
+                            const gvk_tables *tables, const uint32_t *pairs, const gvk_negative_source *negative,
+                            uint32_t first_batch_id, uint32_t batch_id_stride, uint32_t total_batches, int num_batches, float *loss,
+                            int batch_size, int num_negative, float negative_weight, void *workspace, size_t workspace_bytes,
+                            uint32_t hot_vertex, uint32_t hot_context, int workspace_batches, int parts, int chain_cap,
+                            int pair_launches, int form);
+/* the events gvk_train_episode_ahead keeps for a chain stream: to be released before the stream is destroyed */
+void gvk_ahead_release(void *chain_stream);
+
 /* logits[s] = dot(vertex[head_s], context[tail_s]) */
 int gvk_predict(void *stream, int dim, const float *vertex, const float *context, const uint32_t *pairs,
                 float *logits, int batch_size);

@@ -176,6 +176,13 @@ void gvx_solver_destroy(gvx_solver *s);
 /* GVX_HUB_ROUNDS -1 (default): the rule — long chains work in rounds (gvk.h GVK_HOT_ROUNDS) on graphs whose largest vertex takes
  * more than 2 % of the total degree; 0 / 1: never / always. */
 #define GVX_HUB_ROUNDS 11
+/* GVX_HUB_EXECUTOR -1 (default): the rule — the chains of the hub rows as a stream of their own, a batch ahead of the pairs
+ * (gvk.h gvk_train_episode_ahead; the fused launches where GVX_HUB_LERP 1 is asked for or a callback computes the schedule);
+ * 0: one launch per unit carries its pairs and the next unit's chains (gvk_train_episode_hot); 1: the chain stream.
+ * GVX_HUB_PAIR_LAUNCHES 0 (default): under the chain stream the pairs of a batch are one launch per part; N (a divisor of the
+ * parts, else ignored): N launches per batch. */
+#define GVX_HUB_EXECUTOR 12
+#define GVX_HUB_PAIR_LAUNCHES 13
 int gvx_solver_set(gvx_solver *s, int option, int64_t value);
 
 /* The graph is borrowed until the next build / destroy (solver.h:289).  num_partition / episode_size: GVX_AUTO. */

@@ -263,17 +263,20 @@ int gvref_solver_dim() { return GVREF_DIM; }
 
 // The optimizer the next gvref_solver_create builds with (core/optimizer.h:272-330; kAuto = the solver's default, SGD 0.025 / 5e-3
 // linear, graph.cuh:634-636).  type: "" / "Default", "SGD", "Momentum", "AdaGrad", "RMSprop", "Adam"; the helper classes' own
-// defaults for everything but lr and weight decay.
+// defaults for everything but lr and weight decay — and, gvref_set_optimizer_momentum, Momentum's coefficient (its third constructor
+// argument, optimizer.h:283-289; 0 = the class's own default 0.999).
 static std::string g_optimizer_type;
-static float g_optimizer_lr = 0, g_optimizer_wd = 0;
+static float g_optimizer_lr = 0, g_optimizer_wd = 0, g_optimizer_momentum = 0;
 void gvref_set_optimizer(const char *type, float lr, float weight_decay) {
     g_optimizer_type = type ? type : "";
-    g_optimizer_lr = lr, g_optimizer_wd = weight_decay;
+    g_optimizer_lr = lr, g_optimizer_wd = weight_decay, g_optimizer_momentum = 0;
 }
+void gvref_set_optimizer_momentum(float momentum) { g_optimizer_momentum = momentum; }
 static graphvite::Optimizer chosen_optimizer() {
     using namespace graphvite;
     if (g_optimizer_type == "SGD") return SGD(g_optimizer_lr, g_optimizer_wd);
-    if (g_optimizer_type == "Momentum") return Momentum(g_optimizer_lr, g_optimizer_wd);
+    if (g_optimizer_type == "Momentum")
+        return g_optimizer_momentum > 0 ? Momentum(g_optimizer_lr, g_optimizer_wd, g_optimizer_momentum) : Momentum(g_optimizer_lr, g_optimizer_wd);
     if (g_optimizer_type == "AdaGrad") return AdaGrad(g_optimizer_lr, g_optimizer_wd);
     if (g_optimizer_type == "RMSprop") return RMSprop(g_optimizer_lr, g_optimizer_wd);
     if (g_optimizer_type == "Adam") return Adam(g_optimizer_lr, g_optimizer_wd);

@@ -50,6 +50,13 @@ JOBS = {
     "yt_p4_deepwalk": ("youtube_like", 128, "DeepWalk", dict(augmentation_step=5, shuffle_base=1, **WALK), 4, 30, 100, None),
     "c2_adam": ("headline", 128, "LINE", dict(augmentation_step=1), 1, 0, 50, ("Adam", 1e-3, 0.005)),
     "c2_momentum": ("headline", 128, "LINE", dict(augmentation_step=1), 1, 0, 50, ("Momentum", 0.005, 0.005)),
+    # Momentum with the coefficient 0.9 at SGD's learning rate: where the reference's loop learns (with the class's default 0.999 a row's
+    # moment needs about a thousand of ITS OWN updates to warm up, more than most rows of this graph meet in 50 epochs: the loop ends below 0.5)
+    "c2_momentum09": ("headline", 128, "LINE", dict(augmentation_step=1), 1, 0, 50, ("Momentum", 0.025, 0.005, 0.9)),
+    # configs[3] as BASELINE words it: node2vec p = q = 0.25 at Youtube's size in 4 partitions.  The graph: the Youtube-sized generator
+    # with exponent 2.5 (largest degree 19 115; the real graph's: 28 754) — the reference's per-edge tables (graph.cuh:656-677) hold
+    # sum deg^2 = 2.3e9 entries = 18 GB here; on the exponent-2.3 graph of yt_deepwalk they would hold 8.3e9 = 66 GB, more than this host has
+    "yt_p4_node2vec": ("youtube_n2v", 128, "node2vec", dict(augmentation_step=5, shuffle_base=1, p=0.25, q=0.25, **WALK), 4, 30, 100, None),
     "held_p1": ("held_out", 128, "LINE", dict(augmentation_step=1), 1, 0, 42, None),
     "held_p8_e8": ("held_out", 128, "LINE", dict(augmentation_step=1), 8, 8, 42, None),
 }
@@ -61,6 +68,8 @@ def graph_edges(name):
         return synthetic.power_law_edges(2000000, 40000000, seed=65)
     if name == "youtube_like":
         return synthetic.hub_community_edges(num_vertex=1138499, num_edge=4945382, gamma=2.3, num_community=400, p_in=0.7, seed=1024)
+    if name == "youtube_n2v":
+        return synthetic.hub_community_edges(num_vertex=1138499, num_edge=4945382, gamma=2.5, num_community=400, p_in=0.7, seed=1024)
     if name == "headline":
         return synthetic.power_law_edges(1000000, 10000000, seed=1024)
     if name == "held_out":

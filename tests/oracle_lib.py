@@ -412,6 +412,7 @@ class ReferenceSolver(object):
             cls._libs[dim] = lib = C.CDLL(cls.PATHS[dim])
             assert lib.gvref_solver_dim() == dim
             lib.gvref_set_optimizer.argtypes = [C.c_char_p, C.c_float, C.c_float]
+            lib.gvref_set_optimizer_momentum.argtypes = [C.c_float]
             lib.gvref_set_kernel_model.argtypes = [C.c_int, C.c_int, C.c_int]
             lib.gvref_solver_train.restype = C.c_int
             lib.gvref_solver_train.argtypes = [C.c_void_p, C.c_char_p] + [C.c_int] * 5 + [C.c_float] * 4 + [C.c_void_p] * 2
@@ -436,10 +437,13 @@ class ReferenceSolver(object):
     def __init__(self, oracle, seed, edges, weights=None, as_undirected=True, num_worker=1, num_sampler_per_worker=1,
                  num_partition=0, num_negative=1, batch_size=100000, episode_size=0, dim=128, optimizer=None):
         """optimizer: None = the solver's default (SGD 0.025 / 5e-3 linear, graph.cuh:634-636) or (type, lr, weight_decay) with
-        type one of core/optimizer.h's helper classes ("SGD", "Momentum", "AdaGrad", "RMSprop", "Adam")."""
+        type one of core/optimizer.h's helper classes ("SGD", "Momentum", "AdaGrad", "RMSprop", "Adam"); a fourth element is
+        Momentum's coefficient (the class's default: 0.999)."""
         self.dim = dim
         lib = self.lib(dim)
         lib.gvref_set_optimizer(*((b"", 0.0, 0.0) if optimizer is None else (optimizer[0].encode(), optimizer[1], optimizer[2])))
+        if optimizer is not None and len(optimizer) > 3:
+            lib.gvref_set_optimizer_momentum(optimizer[3])
         source_type = C.CFUNCTYPE(None, C.c_int, C.c_ulonglong, C.POINTER(C.c_double), C.c_size_t)
 
         def source(generator, position, out, n):  # generator index == sampler index == uniform stream

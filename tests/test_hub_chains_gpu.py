@@ -21,6 +21,37 @@ LANES = {32: 8, 64: 16, 96: 8, 128: 16, 256: 16, 512: 32}  # lanes per pair = pe
 HOT_BLOCK = int(os.environ.get("GVK_TEST_HOT_BLOCK", "256"))  # threads of a train_hot_kernel workgroup (gvk_chains.hip kHotBlock; a measurement variant may differ)
 
 
+class Executor:
+    """The two executors of the chains behind one set of calls: "fused" = gvk_hot_plan / gvk_hot_build / gvk_train_episode_hot (one
+    launch per unit: its pairs + the next unit's chains), "ahead" = gvk_ahead_* (the chains as a stream of their own, a batch ahead of
+    the pairs; hub rows in a ring of versions — its work lists carry slots: decoded by `ids`)."""
+
+    def __init__(self, hip, name):
+        self.hip, self.name, self.ahead = hip, name, name == "ahead"
+
+    def plan(self, *args, **kw):
+        return (self.hip.ahead_plan if self.ahead else self.hip.hot_plan)(*args, **kw)
+
+    def build(self, *args, **kw):
+        return (self.hip.ahead_build if self.ahead else self.hip.hot_build)(*args, **kw)
+
+    def train(self, *args, lerp=False, **kw):
+        if self.ahead:
+            assert not lerp
+            return self.hip.train_episode_ahead(*args, **kw)
+        return self.hip.train_episode_hot(*args, lerp=lerp, **kw)
+
+    def ids(self, entries):
+        """Work-list entries as id | label << 31 (the fused form's; ahead: a hub partner carries its slot and a flag, gvk_chains.hip partner_of)."""
+        if not self.ahead:
+            return entries
+        hub = (entries & 0x40000000) != 0
+        return np.where(hub, entries & 0x80007fff, entries & 0xbfffffff).astype(np.uint32)
+
+
+EXECUTORS = ["fused", "ahead"]
+
+
 def layout(batch_size, k, chains, num_batch, cap, parts=1):
     """Offsets of gvk_hot_plan's workspace (hot_layout, graphvite_amd/csrc/gvk_chains.hip): one list per part of a batch."""
     cap = min(cap or 7, 7)  # chain_cap_for, gvk_chains.hip
@@ -70,10 +101,11 @@ def clean_rows(pool, allneg, N, kv, kc):
     return keep_v, keep_c
 
 
+@pytest.mark.parametrize("executor", EXECUTORS)
 @pytest.mark.parametrize("rounds", [0, 4])
 @pytest.mark.parametrize("by_class", [False, True])
 @pytest.mark.parametrize("dim,k,cap", [(128, 1, 0), (128, 1, 4), (128, 3, 5), (32, 1, 0), (64, 1, 3), (96, 2, 6), (256, 1, 0), (512, 1, 2)])
-def test_chains_match_the_oracle(hip, oracle, dim, k, cap, by_class, rounds):
+def test_chains_match_the_oracle(hip, oracle, dim, k, cap, by_class, rounds, executor):
     """rounds = 4: the long chains' tasks in rounds of four entries (gvk.h GVK_HOT_ROUNDS, asked for through GVK_TUNE_ROUND_STEPS here;
     the oracle's gvo_set_round_steps)."""
     if by_class and (dim, k, cap) not in ((128, 1, 0), (128, 3, 5)):
@@ -82,12 +114,12 @@ def test_chains_match_the_oracle(hip, oracle, dim, k, cap, by_class, rounds):
         pytest.skip("rounds are exercised with the row table at every dim")
     hip.set_tuning(12, rounds if rounds else -1)  # GVK_TUNE_ROUND_STEPS
     try:
-        _chains_match_the_oracle(hip, oracle, dim, k, cap, by_class, rounds)
+        _chains_match_the_oracle(hip, oracle, dim, k, cap, by_class, rounds, Executor(hip, executor))
     finally:
         hip.set_tuning(12, -1)
 
 
-def _chains_match_the_oracle(hip, oracle, dim, k, cap, by_class, rounds):
+def _chains_match_the_oracle(hip, oracle, dim, k, cap, by_class, rounds, ex):
     rng = np.random.default_rng(dim * 10 + k)
     # one batch: from the second batch on the chains would read rows that the first batch's pair launch trained Hogwild
     N, B, batches, kv, kc = 1 << 15, 1500, 1, 24, 40
@@ -97,14 +129,14 @@ def _chains_match_the_oracle(hip, oracle, dim, k, cap, by_class, rounds):
     table = negative_table(w, by_class)
     opt = K.OptimizerSpec("SGD", 0.025, 0.005)
     dpool = torch.from_numpy(pool.view(np.int32)).to(DEV)
-    ws = torch.zeros(hip.hot_plan(dim, B, k, kv, kc, batches, chain_cap=cap), dtype=torch.uint8, device=DEV)
-    hip.hot_build(dim, ws, dpool, B, batches, k, table, SEED, FIRST_ID, kv, kc, chain_cap=cap)
+    ws = torch.zeros(ex.plan(dim, B, k, kv, kc, batches, chain_cap=cap), dtype=torch.uint8, device=DEV)
+    ex.build(dim, ws, dpool, B, batches, k, table, SEED, FIRST_ID, kv, kc, chain_cap=cap)
     torch.cuda.synchronize()
     chains = kv + kc
     cap_entries, entry_capacity, off = layout(B, k, chains, batches, cap)
     raw = ws.cpu().numpy()
     starts = raw[:batches * (chains + 1) * 4].view(np.uint32).reshape(batches, chains + 1)
-    entries = raw[off:off + batches * entry_capacity * 4].view(np.uint32).reshape(batches, entry_capacity)
+    entries = ex.ids(raw[off:off + batches * entry_capacity * 4].view(np.uint32).reshape(batches, entry_capacity))
     negs = torch.zeros(B * k, dtype=torch.int32, device=DEV)
     hip.negative_draw(table, SEED, FIRST_ID, negs, B, k)
     nb = negs.cpu().numpy().view(np.uint32).reshape(B, k)
@@ -119,7 +151,7 @@ def _chains_match_the_oracle(hip, oracle, dim, k, cap, by_class, rounds):
     keep_v, keep_c = clean_rows(pool, nb, N, kv, kc)
     lr = oracle.lr(0.025, True, FIRST_ID, TOTAL)
     hub = {}
-    for lerp in (False, True):
+    for lerp in ((False,) if ex.ahead else (False, True)):
         # (2) chains, then pairs = the oracle on the same lists.  fp32 tolerance: a chain is dozens of dependent steps, each
         # within 1e-7 of the oracle's (summation order of the dot product, expf / exp2f of the device library)
         ov, oc = v.copy(), c.copy()
@@ -128,8 +160,8 @@ def _chains_match_the_oracle(hip, oracle, dim, k, cap, by_class, rounds):
         for serialized in (True, False):
             tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
             loss = torch.zeros(B, device=DEV)
-            hip.train_episode_hot(tv, tc, dpool, loss, opt, k, 5.0, table, SEED, FIRST_ID, TOTAL, batches, B, ws, kv, kc,
-                                  serialized=serialized, chain_cap=cap, lerp=lerp)
+            ex.train(tv, tc, dpool, loss, opt, k, 5.0, table, SEED, FIRST_ID, TOTAL, batches, B, ws, kv, kc,
+                     serialized=serialized, chain_cap=cap, lerp=lerp)
             torch.cuda.synchronize()
             sv, sc = tv.cpu().numpy(), tc.cpu().numpy()
             for got, want, keep in ((sv, ov, keep_v), (sc, oc, keep_c)):
@@ -139,26 +171,27 @@ def _chains_match_the_oracle(hip, oracle, dim, k, cap, by_class, rounds):
                 assert (hub[lerp, "hub"][0] == sv[:kv]).all() and (hub[lerp, "hub"][1] == sc[:kc]).all()
             hub[lerp, "hub"] = (sv[:kv].copy(), sc[:kc].copy())
         assert np.linalg.norm(sv[:kv] - v[:kv]) > 0 and np.linalg.norm(sc[:kc] - c[:kc]) > 0
-    assert (hub[False, "hub"][0] == hub[True, "hub"][0]).all()  # lerp changes what the pairs read, not the chains
+    assert ex.ahead or (hub[False, "hub"][0] == hub[True, "hub"][0]).all()  # lerp changes what the pairs read, not the chains
     # (3) several batches, the product form (launch u: the pairs of unit u and the chains of unit u + 1, which read the other
     # rows before those pairs have moved them): hub rows end near where the serialized form leaves them
     pool3, _ = hub_case(rng, N, B, 3, kv, kc)
     dpool3 = torch.from_numpy(pool3.view(np.int32)).to(DEV)
-    ws3 = torch.zeros(hip.hot_plan(dim, B, k, kv, kc, 3, chain_cap=cap), dtype=torch.uint8, device=DEV)
-    hip.hot_build(dim, ws3, dpool3, B, 3, k, table, SEED, FIRST_ID, kv, kc, chain_cap=cap)
+    ws3 = torch.zeros(ex.plan(dim, B, k, kv, kc, 3, chain_cap=cap), dtype=torch.uint8, device=DEV)
+    ex.build(dim, ws3, dpool3, B, 3, k, table, SEED, FIRST_ID, kv, kc, chain_cap=cap)
     ends = []
     for serialized in (True, False):
         tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
         loss = torch.zeros(B, device=DEV)
-        hip.train_episode_hot(tv, tc, dpool3, loss, opt, k, 5.0, table, SEED, FIRST_ID, TOTAL, 3, B, ws3, kv, kc,
-                              serialized=serialized, chain_cap=cap)
+        ex.train(tv, tc, dpool3, loss, opt, k, 5.0, table, SEED, FIRST_ID, TOTAL, 3, B, ws3, kv, kc,
+                 serialized=serialized, chain_cap=cap)
         torch.cuda.synchronize()
         ends.append((tv.cpu().numpy()[:kv], tc.cpu().numpy()[:kc]))
     for (a, b), start in zip(zip(*ends), (v[:kv], c[:kc])):
         assert np.isfinite(b).all() and np.linalg.norm(a - b) < 0.5 * np.linalg.norm(a - start)
 
 
-def test_hub_rows_keep_their_updates(hip, oracle):
+@pytest.mark.parametrize("executor", EXECUTORS)
+def test_hub_rows_keep_their_updates(hip, oracle, executor):
     """What the chains are for: a head row that heads 400 samples of a batch.  Pair by pair one launch keeps a handful of the
     400 updates; with the row owned by a chain it ends where 400 sequential updates take it."""
     rng = np.random.default_rng(1)
@@ -184,9 +217,10 @@ def test_hub_rows_keep_their_updates(hip, oracle):
         tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
         loss = torch.zeros(B, device=DEV)
         if hub:
-            ws = torch.zeros(hip.hot_plan(dim, B, 1, 1, 1, 1), dtype=torch.uint8, device=DEV)
-            hip.hot_build(dim, ws, dpool, B, 1, 1, table, SEED, FIRST_ID, 1, 1)
-            hip.train_episode_hot(tv, tc, dpool, loss, opt, 1, 5.0, table, SEED, FIRST_ID, TOTAL, 1, B, ws, 1, 1)
+            ex = Executor(hip, executor)
+            ws = torch.zeros(ex.plan(dim, B, 1, 1, 1, 1), dtype=torch.uint8, device=DEV)
+            ex.build(dim, ws, dpool, B, 1, 1, table, SEED, FIRST_ID, 1, 1)
+            ex.train(tv, tc, dpool, loss, opt, 1, 5.0, table, SEED, FIRST_ID, TOTAL, 1, B, ws, 1, 1)
         else:
             hip.train_episode(tv, tc, dpool, loss, opt, 1, 5.0, table, SEED, FIRST_ID, TOTAL, 1, B)
         torch.cuda.synchronize()
@@ -198,10 +232,12 @@ def test_hub_rows_keep_their_updates(hip, oracle):
     assert np.linalg.norm(results["pair by pair"] - v[0]) < 0.5 * want   # one launch of concurrent pairs: most updates lost
 
 
-def test_a_batch_trained_as_parts(hip, oracle):
+@pytest.mark.parametrize("executor", EXECUTORS)
+def test_a_batch_trained_as_parts(hip, oracle, executor):
     """parts = 3: the batch's samples [0, 500), [500, 1000), [1000, 1500) one after the other, each a unit with its own work
     lists (negatives keep their sample's index in the batch) — the oracle's unit form applied part by part."""
     rng = np.random.default_rng(9)
+    ex = Executor(hip, executor)
     N, B, kv, kc, dim, k, parts = 1 << 15, 1500, 24, 40, 128, 1, 3
     v = (rng.uniform(-0.5, 0.5, (N, dim)) * 0.05).astype(np.float32)
     c = (rng.uniform(-0.5, 0.5, (N, dim)) * 0.05).astype(np.float32)
@@ -209,19 +245,19 @@ def test_a_batch_trained_as_parts(hip, oracle):
     table = negative_table(w, False)
     opt = K.OptimizerSpec("SGD", 0.025, 0.005)
     dpool = torch.from_numpy(pool.view(np.int32)).to(DEV)
-    ws = torch.zeros(hip.hot_plan(dim, B, k, kv, kc, 1, parts), dtype=torch.uint8, device=DEV)
-    hip.hot_build(dim, ws, dpool, B, 1, k, table, SEED, FIRST_ID, kv, kc, parts=parts)
+    ws = torch.zeros(ex.plan(dim, B, k, kv, kc, 1, parts), dtype=torch.uint8, device=DEV)
+    ex.build(dim, ws, dpool, B, 1, k, table, SEED, FIRST_ID, kv, kc, parts=parts)
     torch.cuda.synchronize()
     chains = kv + kc
     cap_entries, entry_capacity, off = layout(B, k, chains, 1, 0, parts)
     raw = ws.cpu().numpy()
     starts = raw[:parts * (chains + 1) * 4].view(np.uint32).reshape(parts, chains + 1)
-    entries = raw[off:off + parts * entry_capacity * 4].view(np.uint32).reshape(parts, entry_capacity)
+    entries = ex.ids(raw[off:off + parts * entry_capacity * 4].view(np.uint32).reshape(parts, entry_capacity))
     negs = torch.zeros(B * k, dtype=torch.int32, device=DEV)
     hip.negative_draw(table, SEED, FIRST_ID, negs, B, k)
     nb = negs.cpu().numpy().view(np.uint32).reshape(B, k)
     lr = oracle.lr(0.025, True, FIRST_ID, TOTAL)
-    for lerp in (False, True):
+    for lerp in ((False,) if ex.ahead else (False, True)):
         ov, oc = v.copy(), c.copy()
         for q in range(parts):
             lo, hi = q * B // parts, (q + 1) * B // parts
@@ -233,8 +269,8 @@ def test_a_batch_trained_as_parts(hip, oracle):
                              max_tasks=HOT_BLOCK // 16, lerp=lerp)
         tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
         loss = torch.zeros(B, device=DEV)
-        hip.train_episode_hot(tv, tc, dpool, loss, opt, k, 5.0, table, SEED, FIRST_ID, TOTAL, 1, B, ws, kv, kc, serialized=True,
-                              parts=parts, lerp=lerp)
+        ex.train(tv, tc, dpool, loss, opt, k, 5.0, table, SEED, FIRST_ID, TOTAL, 1, B, ws, kv, kc, serialized=True,
+                 parts=parts, lerp=lerp)
         torch.cuda.synchronize()
         # hub rows: exact; other rows are trained Hogwild inside a part and may have been read by a later part's chains
         np.testing.assert_allclose(tv.cpu().numpy()[:kv], ov[:kv], rtol=2e-3, atol=2e-5)
@@ -244,8 +280,8 @@ def test_a_batch_trained_as_parts(hip, oracle):
     small = np.stack([rng.integers(0, 64, 600), rng.integers(0, 64, 600)], 1).astype(np.uint32)
     dsmall = torch.from_numpy(small.view(np.int32)).to(DEV)
     t2 = negative_table(np.ones(64, np.float32), False)
-    ws2 = torch.zeros(hip.hot_plan(dim, 300, 1, 64, 64, 2, 3), dtype=torch.uint8, device=DEV)
-    hip.hot_build(dim, ws2, dsmall, 300, 2, 1, t2, SEED, FIRST_ID, 64, 64, parts=3)
+    ws2 = torch.zeros(ex.plan(dim, 300, 1, 64, 64, 2, 3), dtype=torch.uint8, device=DEV)
+    ex.build(dim, ws2, dsmall, 300, 2, 1, t2, SEED, FIRST_ID, 64, 64, parts=3)
     nb2 = torch.zeros(2, 300, dtype=torch.int32, device=DEV)
     for b in range(2):
         hip.negative_draw(t2, SEED, FIRST_ID + b, nb2[b], 300, 1)
@@ -253,7 +289,7 @@ def test_a_batch_trained_as_parts(hip, oracle):
     raw2 = ws2.cpu().numpy()
     cap2, capacity2, off2 = layout(300, 1, 128, 2, 0, 3)
     starts2 = raw2[:6 * 129 * 4].view(np.uint32).reshape(6, 129)
-    entries2 = raw2[off2:off2 + 6 * capacity2 * 4].view(np.uint32).reshape(6, capacity2)
+    entries2 = ex.ids(raw2[off2:off2 + 6 * capacity2 * 4].view(np.uint32).reshape(6, capacity2))
     ov, oc = small_v.copy(), small_c.copy()
     for u in range(6):  # every sample between two hub rows: the whole training is the chains', deterministic given the lists
         b, lo = u // 3, (u % 3) * 100
@@ -262,15 +298,16 @@ def test_a_batch_trained_as_parts(hip, oracle):
                          cap2, max_tasks=HOT_BLOCK // 16)
     for serialized in (True, False):  # nothing but hub rows: the pipelined form reads and writes the same mirrors
         tv, tc = torch.from_numpy(small_v).to(DEV), torch.from_numpy(small_c).to(DEV)
-        hip.train_episode_hot(tv, tc, dsmall, loss, opt, 1, 5.0, t2, SEED, FIRST_ID, TOTAL, 2, 300, ws2, 64, 64, parts=3,
-                              serialized=serialized)
+        ex.train(tv, tc, dsmall, loss, opt, 1, 5.0, t2, SEED, FIRST_ID, TOTAL, 2, 300, ws2, 64, 64, parts=3,
+                 serialized=serialized)
         torch.cuda.synchronize()
         np.testing.assert_allclose(tv.cpu().numpy(), ov, rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(tc.cpu().numpy(), oc, rtol=1e-4, atol=1e-6)
     assert np.isfinite(loss[:300].cpu().numpy()).all() and loss[:300].abs().sum() > 0
 
 
-def test_hub_rows_of_headline_batches_stay_with_the_sequential_loop(hip, oracle):
+@pytest.mark.parametrize("executor", EXECUTORS)
+def test_hub_rows_of_headline_batches_stay_with_the_sequential_loop(hip, oracle, executor):
     """The chains pinned to the reference's SEQUENTIAL semantics at batch level (gpu/graph.cuh:54-94 in sample order = the oracle's
     gvo_train), not only by AUC: real batches of the headline shape (power-law 1M / 10M, 100 000 samples per batch drawn from its
     edges, rows in degree order, negatives by degree^0.75), the default executor (8 parts, tasks of seven side by side), from a
@@ -308,14 +345,15 @@ def test_hub_rows_of_headline_batches_stay_with_the_sequential_loop(hip, oracle)
     c = np.zeros((n, dim), np.float32)
     tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
     loss = torch.zeros(B, device=DEV)
-    ws = torch.zeros(hip.hot_plan(dim, B, k, kv, kc, chunk, parts), dtype=torch.uint8, device=DEV)
+    ex = Executor(hip, executor)
+    ws = torch.zeros(ex.plan(dim, B, k, kv, kc, chunk, parts), dtype=torch.uint8, device=DEV)
 
     def run(first_batch, count):
         for at in range(first_batch, first_batch + count, chunk):
             m = min(chunk, first_batch + count - at)
             dpool = torch.from_numpy(samples(at, m).view(np.int32)).to(DEV)
-            hip.hot_build(dim, ws, dpool, B, m, k, table, SEED, at, kv, kc, parts=parts)
-            hip.train_episode_hot(tv, tc, dpool, loss, opt, k, 5.0, table, SEED, at, total, m, B, ws, kv, kc, workspace_batches=m, parts=parts)
+            ex.build(dim, ws, dpool, B, m, k, table, SEED, at, kv, kc, parts=parts)
+            ex.train(tv, tc, dpool, loss, opt, k, 5.0, table, SEED, at, total, m, B, ws, kv, kc, workspace_batches=m, parts=parts)
         torch.cuda.synchronize()
 
     run(0, warm)
