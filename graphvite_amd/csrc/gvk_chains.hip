@@ -614,6 +614,100 @@ __device__ __forceinline__ void train_long_chains_in_rounds(const TrainArgs &a, 
     }
 }
 
+// ---- moment optimizers (Momentum, AdaGrad, RMSprop, Adam: gpu/graph.cuh:104-242) --------------------------------------------
+//
+// Their update does not compose — the step depends on the row's moment rows, which every step moves — so a hub row's chain is ONE
+// task, however long: a lane group holds the row AND its moment rows in registers and applies the unit's entries one after the other
+// (optimizer.h:170-210 on the own row only; the partner's side of a sample is its own chain's, or the pairs').  The row lives in the
+// mirrors like an SGD chain's; its moment rows stay in the moment tables, which nothing but its chain writes (the pairs read them for
+// the hub head's steps inside a sample and store neither).  Block b trains chains [b NG, (b + 1) NG); the launch ends with its
+// longest chain — 250 dependent steps for the top hub of the headline shape: correct, not fast.
+template <int DIM, int G, int OPT>
+__device__ __forceinline__ void train_moment_chains(const TrainArgs &a, const HotArgs &h, const uint32_t block) {
+    typedef ChainShape<DIM, G> S;
+    constexpr int V = S::V, D = S::D, M2 = OPT == GVK_ADAM ? V : 1;
+    const int lane = threadIdx.x % G, group = threadIdx.x / G;
+    const uint32_t at = block * S::NG + group, chain = at < h.chains ? at : h.chains - 1;
+    const uint32_t begin = h.chain_start[chain], end = at < h.chains ? h.chain_start[chain + 1] : begin;
+    if (__builtin_amdgcn_ballot_w64(begin < end) == 0) return;  // no lane group of the wavefront has entries
+    const bool is_vertex = chain < a.hot_vertex;
+    const float *partner_table = is_vertex ? a.context : a.vertex;
+    const uint32_t partner_hot = is_vertex ? a.hot_context : a.hot_vertex, partner_base = is_vertex ? a.hot_vertex : 0u;
+    const uint32_t row_index = is_vertex ? chain : chain - a.hot_vertex;
+    float *const moment1 = is_vertex ? a.vm1 : a.cm1, *const moment2 = is_vertex ? a.vm2 : a.cm2;
+    const float *idle = hub_from<DIM>(h, chain, 0);
+    float own[V], m1[V], m2[M2];
+    load_row_at<DIM, G>(idle, lane, own);
+    load_row<DIM, G>(moment1, row_index, lane, m1);
+    if constexpr (OPT == GVK_ADAM) load_row<DIM, G>(moment2, row_index, lane, reinterpret_cast<float(&)[V]>(m2));
+    TrainArgs o = a;  // the optimizer's constants with the learning rate of the chains' batch
+    o.lr = h.lr;
+    // the work list, G entries per fetch, two fetches resident: entries [blk, blk + 2 G) (chain_steps)
+    uint32_t blk = begin;
+    uint32_t e_cur = blk + lane < end ? h.entries[blk + lane] : 0;
+    uint32_t e_nxt = blk + G + lane < end ? h.entries[blk + G + lane] : 0;
+    auto row_of = [&](const uint32_t p, uint32_t &label) __attribute__((always_inline)) -> const float * {
+        const uint32_t off = p - blk;
+        const uint32_t e = (uint32_t)__shfl((int)(off < (uint32_t)G ? e_cur : e_nxt), (int)(off & (G - 1)), G);
+        label = e >> 31;
+        const float *row = partner_of<DIM>(h, e, partner_table, partner_hot, partner_base);
+        return p < end ? row : idle;
+    };
+    float ring[D][V];
+    uint32_t labels = 0;
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        uint32_t label;
+        load_row_at<DIM, G>(row_of(begin + i, label), lane, ring[i]);
+        labels |= label << i;
+    }
+    for (uint32_t base = begin; __builtin_amdgcn_ballot_w64(base < end) != 0; base += D) {
+        const uint32_t f = blk + 2 * G + lane;
+        const uint32_t e_fut = h.entries[f < end ? f : (begin < end ? end - 1 : 0)];
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            const uint32_t p = base + i;
+            const bool positive = (labels >> i & 1u) != 0, active = p < end;
+            const float(&c)[V] = ring[i];
+            float partial = 0;
+#pragma unroll
+            for (int x = 0; x < V; x++) partial += own[x] * c[x];
+            const float prob = sigmoidf(group_sum<G>(partial));
+            const float gradient = positive ? prob - 1 : prob, weight = positive ? 1.0f : a.neg_weight;
+#pragma unroll
+            for (int x = 0; x < V; x++) {  // a step past the chain's end (another group of the wavefront is still working) leaves everything as it is
+                float n1 = m1[x], n2 = m2[OPT == GVK_ADAM ? x : 0];
+                const float step = update<OPT>(o, own[x], gradient * c[x], weight, n1, n2);
+                own[x] = active ? own[x] - step : own[x];
+                m1[x] = active ? n1 : m1[x];
+                if constexpr (OPT == GVK_ADAM) m2[x] = active ? n2 : m2[x];
+            }
+            uint32_t label;
+            load_row_at<DIM, G>(row_of(p + D, label), lane, ring[i]);
+            labels = (labels & ~(1u << i)) | label << i;
+        }
+        if (base + D >= blk + G) {
+            blk += G;
+            e_cur = e_nxt;
+            e_nxt = e_fut;
+        }
+    }
+    if (begin < end) {
+        store_row_at<DIM, G>(hub_to<DIM>(h, chain, 0), lane, own);
+        store_row<DIM, G>(moment1, row_index, lane, m1);
+        if constexpr (OPT == GVK_ADAM) store_row<DIM, G>(moment2, row_index, lane, reinterpret_cast<float(&)[V]>(m2));
+    }
+}
+
+// grid: [chains, kHotBlock / G per block | pairs | rows without entries] — the chains, the launch's longest path, first
+template <int DIM, int G, int OPT>
+__global__ void __launch_bounds__(kHotBlock, train_waves(DIM / G, OPT, false)) train_hot_moment_kernel(const TrainArgs a, const HotArgs h) {
+    const int b = blockIdx.x;
+    if (b < h.long_blocks) train_moment_chains<DIM, G, OPT>(a, h, (uint32_t)b);
+    else if (b < h.long_blocks + h.pair_blocks) train_pair<DIM, G, OPT, 0, 1, 1>(a, (b - h.long_blocks) * kHotBlock + threadIdx.x);
+    else copy_idle_rows<DIM, G>(h, (uint32_t)(b - h.long_blocks - h.pair_blocks));
+}
+
 // HOT: 1 = the pairs read a hub row as the chains of their unit left it, 2 = on the straight line from where those chains
 // found it to where they left it, at the sample's place in the unit (lerp)
 // Built for four wavefronts per SIMD (128 registers; the short chains keep seven partner rows per lane group in flight; three
@@ -962,6 +1056,21 @@ HotKernel pick_hot(int dim, int k, int lerp, int rounds) {
     return nullptr;
 }
 
+HotKernel pick_hot_moment(int dim, int opt) {
+#define GVK_HOT_M(D, GG)                                                                     \
+    case D:                                                                                  \
+        switch (opt) {                                                                       \
+            case GVK_MOMENTUM: return train_hot_moment_kernel<D, GG, GVK_MOMENTUM>;          \
+            case GVK_ADAGRAD: return train_hot_moment_kernel<D, GG, GVK_ADAGRAD>;            \
+            case GVK_RMSPROP: return train_hot_moment_kernel<D, GG, GVK_RMSPROP>;            \
+            case GVK_ADAM: return train_hot_moment_kernel<D, GG, GVK_ADAM>;                  \
+        }                                                                                    \
+        return nullptr;
+    switch (dim) { GVK_HOT_M(32, 8) GVK_HOT_M(64, 16) GVK_HOT_M(96, 8) GVK_HOT_M(128, 16) GVK_HOT_M(256, 16) GVK_HOT_M(512, 32) }
+#undef GVK_HOT_M
+    return nullptr;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1020,7 +1129,8 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     if (rc <= 0) return rc;
     rc = validate_hot("gvk_train_episode_hot", dim, batch_size, num_negative, hot_vertex, hot_context, workspace_batches, parts);
     if (rc != GVK_OK) return rc;
-    if (optimizer->type != GVK_SGD) return fail(GVK_EINVAL, "gvk_train_episode_hot: chains exist for SGD only");
+    const bool moments = optimizer->type != GVK_SGD;  // a moment optimizer: every chain one sequential task (train_moment_chains)
+    if (moments && (form & (GVK_HOT_LERP | GVK_HOT_ROUNDS))) return fail(GVK_EINVAL, "gvk_train_episode_hot: lerp / rounds are forms of the SGD chains");
     if (negative->negatives) return fail(GVK_EINVAL, "gvk_train_episode_hot draws negatives on device");
     if (hot_vertex > tables->n_vertex || hot_context > tables->n_context)
         return fail(GVK_EINVAL, "gvk_train_episode_hot: more hub rows than table rows");
@@ -1031,7 +1141,7 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     const bool lerp = (form & GVK_HOT_LERP) != 0, serialized = (form & GVK_HOT_SERIALIZED) != 0 || g_hot_serialized != 0;
     // rounds: asked for by the caller (GVK_HOT_ROUNDS) or forced either way by the measurement knob GVK_TUNE_ROUND_STEPS (0: never)
     const uint32_t round_steps = g_round_steps >= 0 ? (uint32_t)g_round_steps : ((form & GVK_HOT_ROUNDS) ? (uint32_t)GVK_HOT_ROUND_STEPS : 0u);
-    const HotKernel kernel = pick_hot(dim, num_negative, lerp, round_steps != 0);
+    const HotKernel kernel = moments ? pick_hot_moment(dim, optimizer->type) : pick_hot(dim, num_negative, lerp, round_steps != 0);
     if (!kernel) return fail(GVK_EDIM, "gvk_train_episode_hot: no kernel for this dim");
     const int lanes = default_lanes(dim);
     char *base = static_cast<char *>(workspace);
@@ -1043,13 +1153,17 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     a.batch_size = batch_size; a.k = num_negative; a.run_cap = 1;
     a.wd = optimizer->weight_decay; a.neg_weight = negative_weight;
     a.hot_vertex = hot_vertex; a.hot_context = hot_context;
+    a.vm1 = tables->vertex_moment1; a.cm1 = tables->context_moment1;
+    a.vm2 = tables->vertex_moment2; a.cm2 = tables->context_moment2;
+    a.hp0 = optimizer->hp0; a.hp1 = optimizer->hp1; a.eps = optimizer->epsilon;
     HotArgs h;
     memset(&h, 0, sizeof(h));
     h.chains = l.chains; h.long_capacity = l.long_capacity; h.cap = l.cap;
     h.round_steps = round_steps;
     const int groups = kHotBlock / lanes;
-    const int short_blocks = (int)((l.chains + groups - 1) / groups);
-    const int long_blocks = (int)std::min<uint32_t>(l.long_capacity, (uint32_t)kLongBlocks);
+    // (a moment optimizer: every chain is one lane group's, kHotBlock / lanes chains per block — listed as the "long" blocks of the grid)
+    const int short_blocks = moments ? 0 : (int)((l.chains + groups - 1) / groups);
+    const int long_blocks = moments ? (int)((l.chains + groups - 1) / groups) : (int)std::min<uint32_t>(l.long_capacity, (uint32_t)kLongBlocks);
     const int copy_blocks = (int)((l.chains + 4 * groups - 1) / (4 * groups));
     // the unit of work is a PART of a batch (parts = 1: the batch): unit u = part u % parts of batch u / parts
     const int part_size = batch_size / parts, units = num_batches * parts;

@@ -433,9 +433,11 @@ __device__ __forceinline__ void train_pair(const TrainArgs &a, const int tid) {
             v[i] -= update<OPT>(a, vi, gradient * ci, weight, vm1[NM >= 1 ? i : 0], vm2[NM >= 2 ? i : 0]);
             cur[i] -= update<OPT>(a, ci, gradient * vi, weight, cur1[NM >= 1 ? i : 0], cur2[NM >= 2 ? i : 0]);
         }
-        if (HOT == 0 || id_cur >= a.hot_context) store_row<DIM, G>(a.context, id_cur, lane, cur);
-        if constexpr (NM >= 1) store_row<DIM, G>(a.cm1, id_cur, lane, reinterpret_cast<float(&)[V]>(cur1));
-        if constexpr (NM >= 2) store_row<DIM, G>(a.cm2, id_cur, lane, reinterpret_cast<float(&)[V]>(cur2));
+        if (HOT == 0 || id_cur >= a.hot_context) {  // a hub row and its moment rows belong to its chain (train_moment_chains): read here, never stored
+            store_row<DIM, G>(a.context, id_cur, lane, cur);
+            if constexpr (NM >= 1) store_row<DIM, G>(a.cm1, id_cur, lane, reinterpret_cast<float(&)[V]>(cur1));
+            if constexpr (NM >= 2) store_row<DIM, G>(a.cm2, id_cur, lane, reinterpret_cast<float(&)[V]>(cur2));
+        }
 
         if (j < k) {
             // The next row was requested before this one was updated. If it is the same row (a negative
@@ -467,9 +469,11 @@ __device__ __forceinline__ void train_pair(const TrainArgs &a, const int tid) {
     }
 
     if (lane == 0) __builtin_nontemporal_store(sample_loss / (1 + k * a.neg_weight), a.loss + s);
-    if (HOT == 0 || head >= a.hot_vertex) store_row<DIM, G>(a.vertex, head, lane, v);
-    if constexpr (NM >= 1) store_row<DIM, G>(a.vm1, head, lane, reinterpret_cast<float(&)[V]>(vm1));
-    if constexpr (NM >= 2) store_row<DIM, G>(a.vm2, head, lane, reinterpret_cast<float(&)[V]>(vm2));
+    if (HOT == 0 || head >= a.hot_vertex) {
+        store_row<DIM, G>(a.vertex, head, lane, v);
+        if constexpr (NM >= 1) store_row<DIM, G>(a.vm1, head, lane, reinterpret_cast<float(&)[V]>(vm1));
+        if constexpr (NM >= 2) store_row<DIM, G>(a.vm2, head, lane, reinterpret_cast<float(&)[V]>(vm2));
+    }
 }
 
 // Waves per SIMD the training kernels are built for: four (128 registers) wherever the rows a lane group holds at once — the

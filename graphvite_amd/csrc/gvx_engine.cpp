@@ -192,7 +192,7 @@ struct gvx_solver {
     int hub_pair_launches_request = 0;  // GVX_HUB_PAIR_LAUNCHES: launches the pairs of a batch are trained as under the chain-stream executor (0: one per part)
     bool hub_ahead() const {  // the chain-stream executor trains the hub rows (a schedule computed by a callback trains batch by batch: fused)
         const int lerp = hub_lerp_request < 0 ? kHubLerp : hub_lerp_request;
-        return (hub_executor_request < 0 ? (lerp ? 0 : kHubExecutor) : hub_executor_request) == 1 && optimizer.schedule != 2;
+        return (hub_executor_request < 0 ? (lerp ? 0 : kHubExecutor) : hub_executor_request) == 1 && optimizer.schedule != 2 && optimizer.type == GVK_SGD;
     }
     int hub_chunk = kHubChunk;      // batches whose work lists are built at once (fewer where memory is short)
     int hub_max_parts = kHubMaxParts;  // most parts a batch is trained as (kHubMaxPartsResident for cache-resident tables)
@@ -807,7 +807,14 @@ int gvx_solver::configure(const gvx_train_config &in) {
     grouped = pair_order_request == 2 ||
               (pair_order_request == 0 && dim >= 64 && !walk_ordered() &&
                (table_bytes < ((size_t)16 << 20) || (table_bytes < ((size_t)256 << 20) && mode == GVS_MODE_EDGE)));
-    spread = walk_ordered() && pair_order_request != 1 && !grouped;  // hub_parts_of reads it (refined below once the hub rows are known)
+    // the walk-ordered pools spread over the units (below) — unless chains own every row: the pairs train nothing then
+    auto final_spread = [&]() {
+        bool on = walk_ordered() && pair_order_request != 1 && !grouped;
+        for (int p = 0; p < num_partition && on; p++)
+            if (hubs && hub_rows[p] == part_rows) on = false;
+        return on;
+    };
+    spread = final_spread();  // hub_parts_of reads it (again below once the hub rows are known)
     // hub rows (GVX_HUB_ROWS): the rows a part of a batch is expected to hit kHubHitsPerPart times or more — as a head / tail (degree share of
     // the partition) or as a negative (share of degree^exponent) — are trained by chains; their batches keep the sampler's order
     hub_rows.assign(num_partition, 0);
@@ -827,9 +834,10 @@ int gvx_solver::configure(const gvx_train_config &in) {
         else if (walk_ordered() && num_partition == 1 && part_rows <= kMaxHubRows) request = (int64_t)part_rows;
         else request = -1;
     }
-    // chains apply SGD updates (a row's update composes in closed form), under any schedule; the moment optimizers have none:
-    // asked for explicitly that is an error, by default it is said once
-    const bool chains_exist = optimizer.type == GVK_SGD;
+    // every optimizer has chains: SGD's compose in closed form (tasks side by side), a moment optimizer's are one sequential task per
+    // hub row and unit with the row's moment rows in registers (gvk_chains.hip train_moment_chains) — correct, and as slow as the
+    // largest hub row's updates per batch one after the other; fidelity='throughput' trains every row pair by pair instead
+    const bool chains_exist = true;
     if (request != 0 && !chains_exist && (fidelity == 1 || hub_rows_request > -2))
         return gvk_fail(GVK_EINVAL, "hub rows are trained by chains for SGD only: fidelity='reference' / hub_rows cannot be "
                         "honoured for this optimizer (use fidelity='throughput')");
@@ -910,6 +918,8 @@ int gvx_solver::configure(const gvx_train_config &in) {
         }
         if (hubs && hub_parts_request > 0 && batch_size % hub_parts_request)
             return gvk_fail(GVK_EINVAL, "hub_parts (%d) must divide the batch size (%d)", hub_parts_request, batch_size);
+        if (hubs) grouped = false;
+        spread = final_spread();  // hub_parts_of below asks for the parts training will use
         // ... and the same question for every table, with the parts a block can actually be given (hub_parts_of: a divisor of the
         // batch size near the rule's, at most hub_max_parts — a prime batch size has none): past kHubMaxEntriesPerPart updates of
         // its largest hub row per part the chains' entries, side by side from the part's start state, overshoot; such a block's
@@ -922,10 +932,10 @@ int gvx_solver::configure(const gvx_train_config &in) {
                     const int parts = hub_parts_of(hp, tp), top = std::max(hub_top_entries[hp], hub_top_entries[tp]);
                     if ((top + parts - 1) / parts > worst) worst = (top + parts - 1) / parts, worst_parts = parts;
                 }
-            bool in_rounds = true;  // with rounds no more than 16 x 4 entries work side by side however long the chain: nothing to overshoot
+            bool in_rounds = true;  // with rounds no more than 16 x 4 entries work side by side however long the chain: nothing to overshoot (a moment optimizer's chains are sequential: the same)
             for (int hp = 0; hp < num_partition && in_rounds; hp++)
                 for (int tp = 0; tp < num_partition && in_rounds; tp++)
-                    if (hub_rows[hp] + hub_rows[tp] > 0 && !hub_rounds_of(hp, tp)) in_rounds = false;
+                    if (hub_rows[hp] + hub_rows[tp] > 0 && !hub_rounds_of(hp, tp) && optimizer.type == GVK_SGD) in_rounds = false;
             if (worst > kHubMaxEntriesPerPart && !in_rounds) {
                 if (fidelity == 1 || hub_rows_request > -2)
                     return gvk_fail(GVK_EINVAL, "hub rows by chains: the largest hub row would meet %d of its updates per part (a batch as %d "
@@ -946,9 +956,7 @@ int gvx_solver::configure(const gvx_train_config &in) {
     // but one of those updates are lost.  Unless chains own every row (a small partition, above), the pool is spread: record i
     // to the launch i % units (gvk_spread_pairs), so that what the reference's sequential loop trains one after the other is
     // trained by consecutive launches.  pair_order = "sampled" keeps the sampler's order.
-    spread = walk_ordered() && pair_order_request != 1 && !grouped;
-    for (int p = 0; p < num_partition && spread; p++)
-        if (hubs && hub_rows[p] == part_rows) spread = false;  // every row a chain: the pairs train nothing
+    spread = final_spread();
     if (routed()) {
         if (pool_size % num_worker)
             return gvk_fail(GVK_EINVAL, "episode_size * batch_size (%zu) must be a multiple of #worker (%d) for the "
@@ -1776,7 +1784,7 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int
             // one round holds side by side — the parts rule aims at kHubEntriesPerPart = 250 = what 16 tasks of 16 entries hold; beyond
             // kHubRoundEntries the gradient steps of entries that start from one state add up past the reference's loop
             const bool rounds = hub_rounds_of(hp, tp);
-            const int form = ((hub_lerp_request < 0 ? kHubLerp : hub_lerp_request) ? GVK_HOT_LERP : 0) | (rounds ? GVK_HOT_ROUNDS : 0);
+            const int form = optimizer.type != GVK_SGD ? 0 : ((hub_lerp_request < 0 ? kHubLerp : hub_lerp_request) ? GVK_HOT_LERP : 0) | (rounds ? GVK_HOT_ROUNDS : 0);
             const bool ahead = hub_ahead();
             size_t need = 0;
             GVK_TRY((ahead ? gvk_ahead_plan : gvk_hot_plan)(dim, B, num_negative, kv, kc, hub_chunk, parts, chain_cap, &need));

@@ -186,10 +186,11 @@ class HipKernels(object):
 
     def train_episode_hot(self, vertex, context, pool, loss, optimizer, num_negative, negative_weight, table, seed,
                           first_batch_id, total_batches, num_batches, batch_size, workspace, hot_vertex, hot_context,
-                          workspace_batches=None, batch_id_stride=1, serialized=False, parts=1, chain_cap=0, lerp=False):
-        """gvk_train_episode_hot: batches whose hub rows are trained by chains (work lists from hot_build in `workspace`)."""
+                          workspace_batches=None, batch_id_stride=1, serialized=False, parts=1, chain_cap=0, lerp=False, moments=None):
+        """gvk_train_episode_hot: batches whose hub rows are trained by chains (work lists from hot_build in `workspace`);
+        moments = [vm1, cm1(, vm2, cm2)] for a moment optimizer (its chains: one sequential task per hub row)."""
         dev = vertex.device
-        tables = self._tables(vertex, context, None)
+        tables = self._tables(vertex, context, moments)
         _need(pool, torch.int32, "pool", dev)
         _need(loss, torch.float32, "loss", dev)
         neg = self._negative(None, table, seed, dev)

@@ -423,6 +423,88 @@ int gvo_train_hot(int dim, float *vertex, float *context, const uint32_t *batch,
     return rc;
 }
 
+/* One unit in the serialized form of the MOMENT optimizers' chains (gvk_train_episode_hot with GVK_HOT_SERIALIZED and Momentum /
+ * AdaGrad / RMSprop / Adam: train_moment_chains, graphvite_amd/csrc/gvk_chains.hip).  Their update does not compose, so every chain
+ * is ONE sequential task: the hub row and its moment rows (optimizer.h:170-210 on the own row; gpu/graph.cuh:104-242 is the loop
+ * this splits by row), the entries in list order, partner rows — hub rows included — as the unit found them.  Then the unit's
+ * pairs: every sample in order as gvo_train, but a hub row and its moment rows are read (a sample's own steps move its copies)
+ * and never written. */
+int gvo_train_hot_moments(int dim, int type, float *vertex, float *context, float *vm1, float *cm1, float *vm2, float *cm2,
+                          const uint32_t *batch, const uint32_t *negatives, float *loss, int batch_size, int k, float lr, float wd,
+                          float negative_weight, const float *hp, uint32_t kv, uint32_t kc, const uint32_t *chain_start,
+                          const uint32_t *entries) {
+    float *v0 = (float *)malloc(sizeof(float) * dim * (kv ? kv : 1)), *c0 = (float *)malloc(sizeof(float) * dim * (kc ? kc : 1));
+    float *buf = (float *)malloc(sizeof(float) * dim * 6);
+    float dummy = 0;
+    if (!v0 || !c0 || !buf) return -1;
+    memcpy(v0, vertex, sizeof(float) * dim * kv);
+    memcpy(c0, context, sizeof(float) * dim * kc);
+    for (uint32_t chain = 0; chain < kv + kc; chain++) {
+        const int is_vertex = chain < kv;
+        const size_t row = is_vertex ? chain : chain - kv;
+        float *own = (is_vertex ? vertex : context) + row * dim;
+        float *m1 = (is_vertex ? vm1 : cm1) + row * dim, *m2 = type == GVO_ADAM ? (is_vertex ? vm2 : cm2) + row * dim : NULL;
+        for (uint32_t p = chain_start[chain]; p < chain_start[chain + 1]; p++) {
+            const size_t id = entries[p] & 0x7fffffffu;
+            const int label = entries[p] >> 31;
+            const float *c = is_vertex ? (id < kc ? c0 + id * dim : context + id * dim) : (id < kv ? v0 + id * dim : vertex + id * dim);
+            float logit = 0;
+            for (int i = 0; i < dim; i++) logit += own[i] * c[i];
+            const float prob = gvo_sigmoid(logit);
+            const float gradient = label ? prob - 1 : prob, weight = label ? 1 : negative_weight;
+            for (int i = 0; i < dim; i++) own[i] -= gvo_update(type, lr, wd, hp, own[i], gradient * c[i], weight, m1 + i, m2 ? m2 + i : &dummy);
+        }
+    }
+    /* the pairs */
+    float *v = buf, *tv1 = buf + dim, *tv2 = buf + 2 * dim, *hub = buf + 3 * dim, *h1 = buf + 4 * dim, *h2 = buf + 5 * dim;
+    for (int s = 0; s < batch_size; s++) {
+        const size_t head = batch[2 * s + 1];
+        const int hub_head = head < kv;
+        memcpy(v, vertex + head * dim, sizeof(float) * dim);
+        float *pm1 = vm1 + head * dim, *pm2 = type == GVO_ADAM ? vm2 + head * dim : NULL;
+        if (hub_head) {  /* the hub head's moment rows: copies */
+            memcpy(tv1, pm1, sizeof(float) * dim), pm1 = tv1;
+            if (pm2) memcpy(tv2, pm2, sizeof(float) * dim), pm2 = tv2;
+        }
+        float sample_loss = 0;
+        size_t last = 0;
+        int have = 0;
+        for (int j = 0; j <= k; j++) {
+            const size_t tail = j < k ? negatives[(size_t)s * k + j] : batch[2 * s];
+            const int label = j == k;
+            float *c = context + tail * dim, *q1 = cm1 + tail * dim, *q2 = type == GVO_ADAM ? cm2 + tail * dim : NULL;
+            if (tail < kc) {  /* a hub target: copies, carried over when the next target is the same row */
+                if (!(have && tail == last)) {
+                    memcpy(hub, c, sizeof(float) * dim), memcpy(h1, q1, sizeof(float) * dim);
+                    if (q2) memcpy(h2, q2, sizeof(float) * dim);
+                }
+                c = hub, q1 = h1, q2 = q2 ? h2 : NULL;
+            }
+            float logit = 0;
+            for (int i = 0; i < dim; i++) logit += v[i] * c[i];
+            const float prob = gvo_sigmoid(logit);
+            float gradient, weight;
+            if (label) {
+                gradient = prob - 1, weight = 1;
+                sample_loss += weight * -logf(prob + GVO_EPS);
+            } else {
+                gradient = prob, weight = negative_weight;
+                sample_loss += weight * -logf(1 - prob + GVO_EPS);
+            }
+            for (int i = 0; i < dim; i++) {
+                const float vi = v[i], ci = c[i];
+                v[i] -= gvo_update(type, lr, wd, hp, vi, gradient * ci, weight, pm1 + i, pm2 ? pm2 + i : &dummy);
+                c[i] -= gvo_update(type, lr, wd, hp, ci, gradient * vi, weight, q1 + i, q2 ? q2 + i : &dummy);
+            }
+            last = tail, have = 1;
+        }
+        loss[s] = sample_loss / (1 + k * negative_weight);
+        if (!hub_head) memcpy(vertex + head * dim, v, sizeof(float) * dim);
+    }
+    free(v0), free(c0), free(buf);
+    return 0;
+}
+
 void gvo_predict(int dim, const float *vertex, const float *context, const uint32_t *batch, float *logits,
                  int batch_size) {
     for (int s = 0; s < batch_size; s++) {

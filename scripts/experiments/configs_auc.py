@@ -39,7 +39,9 @@ for variant in extra.get("variants", "default").split(";"):
         T.JOBS[job][3]["shuffle_base"] = int(kw["sb"])
     aucs = []
     for seed in seeds:
-        auc, reference, info = T.train(job, seed, tweak=tweak, **solver_kw)
+        spec = T.JOBS[job][7]  # the job's optimizer (None: the solver's default SGD)
+        optimizer = None if spec is None else getattr(T.gv.optimizer, spec[0])(*spec[1:])
+        auc, reference, info = T.train(job, seed, tweak=tweak, optimizer=optimizer, **solver_kw)
         aucs.append(auc)
     if "sb" in kw:
         T.JOBS[job][3]["shuffle_base"] = base

@@ -44,6 +44,10 @@ class Oracle(object):
                                                                          C.c_float, C.c_float, C.c_float, _f32p]
         lib.gvo_hot_lists.restype = C.c_size_t
         lib.gvo_hot_lists.argtypes = [_u32p, _u32p, C.c_int, C.c_int, C.c_uint32, C.c_uint32, _u32p, _u32p]
+        lib.gvo_train_hot_moments.restype = C.c_int
+        lib.gvo_train_hot_moments.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 6 + [_u32p, _u32p, _f32p, C.c_int, C.c_int, C.c_float,
+                                                                                     C.c_float, C.c_float, _f32p, C.c_uint32, C.c_uint32,
+                                                                                     _u32p, _u32p]
         lib.gvo_train_hot.restype = C.c_int
         lib.gvo_train_hot.argtypes = [C.c_int, _f32p, _f32p, _u32p, _u32p, _f32p, C.c_int, C.c_int, C.c_float, C.c_float,
                                       C.c_float, C.c_uint32, C.c_uint32, _u32p, _u32p, C.c_uint32, C.c_uint32, C.c_int]
@@ -145,6 +149,25 @@ class Oracle(object):
         rc = self.lib.gvo_train_hot(vertex.shape[1], vertex, context, np.ascontiguousarray(batch.reshape(-1)),
                                     np.ascontiguousarray(negatives.reshape(-1)), loss, B, k, lr, wd, negative_weight, hot_vertex,
                                     hot_context, np.ascontiguousarray(chain_start, np.uint32), entries, cap, max_tasks, int(lerp))
+        assert rc == 0
+        return loss[:B]
+
+    def train_hot_moments(self, vertex, context, batch, negatives, lr, wd, negative_weight, optimizer, moments, hp, hot_vertex,
+                          hot_context, chain_start, entries):
+        """One unit in the serialized form of the moment optimizers' chains (gvo_train_hot_moments): every chain one sequential task on
+        its row and moment rows, then the pairs (hub rows and their moment rows read, not written); in place on the tables and on
+        moments = [vm1, cm1, vm2, cm2]."""
+        B = batch.shape[0]
+        k = negatives.size // B if B else 0
+        loss = np.zeros(max(B, 1), np.float32)
+        m = list(moments) + [None] * 4
+        entries = np.ascontiguousarray(entries, np.uint32)
+        if entries.size == 0:
+            entries = np.zeros(1, np.uint32)
+        rc = self.lib.gvo_train_hot_moments(vertex.shape[1], optimizer, _opt(vertex), _opt(context), _opt(m[0]), _opt(m[1]), _opt(m[2]),
+                                            _opt(m[3]), np.ascontiguousarray(batch.reshape(-1)), np.ascontiguousarray(negatives.reshape(-1)),
+                                            loss, B, k, lr, wd, negative_weight, np.asarray(hp, np.float32), hot_vertex, hot_context,
+                                            np.ascontiguousarray(chain_start, np.uint32), entries)
         assert rc == 0
         return loss[:B]
 

@@ -83,12 +83,10 @@ def test_friendster_like_shape_matches_the_reference_training_loop(device_sampli
         assert info["hub_rows"] > 0 and info["parts"] > 1, info
         aucs.append(auc)
     print("friendster-like, dim 96, 8 partitions%s: %s" % (", device sampling" if device_sampling else "", info))
-    # Positive samples drawn on the device (the opt-in extension of SURVEY.md §8 f4, beyond north_star's CPU samplers): +0.0017 on this shape
-    # (two seeds; dim 128: +0.0017) — until gvk_sample_walks_blocks chose the pseudo shuffle's part by the pair's index in its walk the pairs
-    # of one walk sat a few slots apart inside one launch and the line ended +0.0071 (DESIGN.md §7.11 a).  The bound: +-0.002 plus the
-    # run-to-run spread of pools filled through atomics (0.0002).
-    compare_auc("friendster-like LINE dim 96 P=8%s" % (" device sampling" if device_sampling else ""), aucs, reference,
-                tolerance=0.0025 if device_sampling else 0.002)
+    # Positive samples drawn on the device (the opt-in extension of SURVEY.md §8 f4, beyond north_star's CPU samplers) are held to the same
+    # +-0.002 on the same four seeds (until gvk_sample_walks_blocks chose the pseudo shuffle's part by the pair's index in its walk the
+    # pairs of one walk sat a few slots apart inside one launch and the line ended +0.0071: profiles/r5/README.md).
+    compare_auc("friendster-like LINE dim 96 P=8%s" % (" device sampling" if device_sampling else ""), aucs, reference)
 
 
 @pytest.mark.parametrize("partitions,sampling", [(1, "tables"), (1, "device"), (4, "tables"), (4, "device")])
@@ -121,26 +119,27 @@ def test_held_out_hub_heavy_graph_matches_the_reference_training_loop(job):
     compare_auc("held-out graph %s" % job, aucs, reference)
 
 
-@pytest.mark.parametrize("job,optimizer", [("c2_momentum", "Momentum"), ("c2_adam", "Adam")])
+@pytest.mark.parametrize("job,optimizer", [("c2_momentum09", "Momentum"), ("c2_adam", "Adam")])
 def test_moment_optimizers_on_the_headline_shape(job, optimizer):
-    """train_1_moment / train_2_moment (instance/gpu/graph.cuh:104-242) on the headline shape.  The moment optimizers have no
-    chains (their update does not compose in closed form): every row is trained pair by pair, and on a hub-heavy table the hub
-    rows keep a few of their updates per batch.  This test MEASURES what that costs against the reference's sequential loop and
-    holds the product to the bound DESIGN.md states for it."""
-    _, _, _, _, _, _, _, spec = JOBS[job]
-    make = dict(Momentum=lambda: gv.optimizer.Momentum(spec[1], spec[2]), Adam=lambda: gv.optimizer.Adam(spec[1], spec[2]))[optimizer]
+    """train_1_moment / train_2_moment (instance/gpu/graph.cuh:104-242) on the headline shape against the reference's own loop under the
+    same optimizer: Adam 1e-3 and Momentum 0.025 with the coefficient 0.9 (with the helper class's default 0.999 the reference's own
+    loop ends below 0.5 on this graph — c2_momentum in the goldens: a row's moment needs about a thousand of ITS OWN updates to warm
+    up).  The hub rows are trained by the moment optimizers' chains (one sequential task per hub row and unit, the row's moment rows in
+    registers: gvk_chains.hip train_moment_chains); pair by pair (fidelity="throughput") Adam ends 0.015 below the reference's loop."""
+    spec = JOBS[job][7]
+    make = dict(Momentum=lambda: gv.optimizer.Momentum(spec[1], spec[2], *spec[3:]), Adam=lambda: gv.optimizer.Adam(spec[1], spec[2]))[optimizer]
     aucs = []
     for seed in SEEDS[:3]:
         auc, reference, info = train(job, seed, optimizer=make())
+        assert info["hub_rows"] > 0 and info["parts"] > 1, info
         aucs.append(auc)
-    here, ref = np.mean(aucs), reference[~np.isnan(reference)].mean()
-    if ref < 0.55:
-        pytest.skip("the reference's own loop ends at AUC %.3f with this optimizer on this shape (below 0.5: true edges rank BELOW random pairs — "
-                    "nothing learnt to compare); here %.3f" % (ref, here))
-    print("headline shape, %s: AUC here %s (mean %.6f) | reference training loop %s (mean %.6f) | difference %+.6f | %s" % (
-        optimizer, " ".join("%.6f" % a for a in aucs), here, " ".join("%.6f" % a for a in reference), ref, here - ref, info))
-    assert abs(here - ref) <= MOMENT_BOUND[optimizer]
-
-
-# what pair-by-pair training of hub rows costs the moment optimizers on the headline shape (measured: DESIGN.md section 7)
-MOMENT_BOUND = {"Momentum": 0.03, "Adam": 0.03}
+    print("headline shape, %s: %s" % (optimizer, info))
+    try:
+        compare_auc("headline shape, %s" % optimizer, aucs, reference)
+    except AssertionError as outside:
+        if optimizer != "Adam":
+            raise
+        # Measured on the MI355X (round 6, profiles/r6/parity_auc.log): Adam 1e-3 with chains ends 0.0032 (SE 0.0011; the reference's own
+        # three seeds spread over 0.0033) below the reference's loop — pair by pair it was 0.0145 below.  north_star's +-0.002 is NOT met
+        # for this optimizer: an expected failure that says so, not a wider bound.
+        pytest.xfail("Adam on the headline shape: %s (tolerance 0.002; pair by pair: -0.0145)" % (outside.args[0],))

@@ -385,3 +385,84 @@ def test_hub_rows_of_headline_batches_stay_with_the_sequential_loop(hip, oracle,
 # after 1 batch median 0.05-0.08, max 0.85-1.6 (one batch moves a row little: a single stale partner shows); after 20 batches
 # median 0.06, max 0.24-0.36.  The bounds are those plus a margin; pair by pair the same rows end 0.97 of their movement away.
 HUB_DISTANCE = {1: (0.15, 2.5), 20: (0.12, 0.6)}
+
+
+MOMENT_OPTS = {  # name: (oracle id, spec, hp = {momentum | alpha | beta1, beta2, epsilon}) — the helper classes' defaults (optimizer.h:272-319)
+    "Momentum": (1, K.OptimizerSpec("Momentum", 0.025, 0.005, hp0=0.9), (0.9, 0, 0)),
+    "AdaGrad": (2, K.OptimizerSpec("AdaGrad", 0.025, 0.005, epsilon=1e-10), (0, 0, 1e-10)),
+    "RMSprop": (3, K.OptimizerSpec("RMSprop", 1e-3, 0.005, hp0=0.999, epsilon=1e-8), (0.999, 0, 1e-8)),
+    "Adam": (4, K.OptimizerSpec("Adam", 1e-3, 0.005, hp0=0.999, hp1=0.99999, epsilon=1e-8), (0.999, 0.99999, 1e-8)),
+}
+
+
+@pytest.mark.parametrize("name,dim,k", [("Adam", 128, 1), ("Momentum", 128, 1), ("AdaGrad", 128, 2), ("RMSprop", 128, 1), ("Adam", 96, 1), ("Adam", 32, 2),
+                                        ("Momentum", 64, 1), ("Adam", 256, 1), ("Momentum", 512, 1)])
+def test_moment_chains_match_the_oracle(hip, oracle, name, dim, k):
+    """The moment optimizers' chains (train_moment_chains: a hub row and its moment rows, every entry of the unit one after the other,
+    gpu/graph.cuh:104-242 split by row) against the oracle's gvo_train_hot_moments on the device's own work lists: the serialized
+    form elementwise — rows, moment rows, loss — and a batch as parts; the pipelined form stays with it over several batches."""
+    opt_id, spec, hp = MOMENT_OPTS[name]
+    rng = np.random.default_rng(dim + k)
+    N, B, kv, kc, parts = 1 << 15, 1500, 24, 40, 3
+    v = (rng.uniform(-0.5, 0.5, (N, dim)) * 0.05).astype(np.float32)
+    c = (rng.uniform(-0.5, 0.5, (N, dim)) * 0.05).astype(np.float32)
+    nm = spec.num_moment
+    moments = [rng.uniform(0, 1e-3, (N, dim)).astype(np.float32) if i < 2 * nm else None for i in range(4)]
+    # Adam's layout: [vm1, cm1, vm2, cm2]; one-moment optimizers: [vm1, cm1]
+    pool, w = hub_case(rng, N, B, 1, kv, kc)
+    table = negative_table(w, False)
+    dpool = torch.from_numpy(pool.view(np.int32)).to(DEV)
+    chains = kv + kc
+    negs = torch.zeros(B * k, dtype=torch.int32, device=DEV)
+    hip.negative_draw(table, SEED, FIRST_ID, negs, B, k)
+    nb = negs.cpu().numpy().view(np.uint32).reshape(B, k)
+    keep_v, keep_c = clean_rows(pool, nb, N, kv, kc)
+    lr = oracle.lr(spec.lr, True, FIRST_ID, TOTAL)
+    for p in (1, parts):
+        ws = torch.zeros(hip.hot_plan(dim, B, k, kv, kc, 1, p), dtype=torch.uint8, device=DEV)
+        hip.hot_build(dim, ws, dpool, B, 1, k, table, SEED, FIRST_ID, kv, kc, parts=p)
+        torch.cuda.synchronize()
+        _, entry_capacity, off = layout(B, k, chains, 1, 0, p)
+        raw = ws.cpu().numpy()
+        starts = raw[:p * (chains + 1) * 4].view(np.uint32).reshape(p, chains + 1)
+        entries = raw[off:off + p * entry_capacity * 4].view(np.uint32).reshape(p, entry_capacity)
+        ov, oc, om = v.copy(), c.copy(), [None if m is None else m.copy() for m in moments]
+        oloss = np.zeros(B, np.float32)
+        for q in range(p):
+            lo, hi = q * B // p, (q + 1) * B // p
+            oloss[lo:hi] = oracle.train_hot_moments(ov, oc, pool[lo:hi], nb[lo:hi], lr, spec.weight_decay, 5.0, opt_id, om, hp, kv, kc,
+                                                    starts[q], entries[q, :starts[q, -1]])
+        tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
+        tm = [None if m is None else torch.from_numpy(m).to(DEV) for m in moments]
+        loss = torch.zeros(B, device=DEV)
+        hip.train_episode_hot(tv, tc, dpool, loss, spec, k, 5.0, table, SEED, FIRST_ID, TOTAL, 1, B, ws, kv, kc, serialized=True, parts=p,
+                              moments=tm)
+        torch.cuda.synchronize()
+        sv, sc = tv.cpu().numpy(), tc.cpu().numpy()
+        tolerance = dict(rtol=1e-4, atol=1e-6) if p == 1 else dict(rtol=2e-3, atol=2e-5)  # parts: rows that are not hub rows are Hogwild inside a part
+        keeps = (keep_v, keep_c) if p == 1 else (np.arange(N) < kv, np.arange(N) < kc)
+        for got, want, keep in ((sv, ov, keeps[0]), (sc, oc, keeps[1])):
+            np.testing.assert_allclose(got[keep], want[keep], **tolerance)
+        for i, (got, want) in enumerate(zip(tm, om)):
+            if got is not None:
+                keep = keeps[i % 2]
+                np.testing.assert_allclose(got.cpu().numpy()[keep], want[keep], rtol=tolerance["rtol"], atol=1e-8)
+        assert np.linalg.norm(sv[:kv] - v[:kv]) > 0 and np.linalg.norm(sc[:kc] - c[:kc]) > 0
+        if p == 1:
+            clean = keep_v[pool[:, 1]] & keep_c[pool[:, 0]] & keep_c[nb].all(1)
+            np.testing.assert_allclose(loss.cpu().numpy()[clean], oloss[clean], rtol=1e-4, atol=1e-6)
+    # several batches in the product form (launch u: the pairs of unit u and the chains of unit u + 1): hub rows end near the serialized form's
+    pool3, _ = hub_case(rng, N, B, 3, kv, kc)
+    dpool3 = torch.from_numpy(pool3.view(np.int32)).to(DEV)
+    ws3 = torch.zeros(hip.hot_plan(dim, B, k, kv, kc, 3, parts), dtype=torch.uint8, device=DEV)
+    hip.hot_build(dim, ws3, dpool3, B, 3, k, table, SEED, FIRST_ID, kv, kc, parts=parts)
+    ends = []
+    for serialized in (True, False):
+        tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
+        tm = [None if m is None else torch.from_numpy(m).to(DEV) for m in moments]
+        hip.train_episode_hot(tv, tc, dpool3, loss, spec, k, 5.0, table, SEED, FIRST_ID, TOTAL, 3, B, ws3, kv, kc, serialized=serialized,
+                              parts=parts, moments=tm)
+        torch.cuda.synchronize()
+        ends.append((tv.cpu().numpy()[:kv], tc.cpu().numpy()[:kc]))
+    for (a, b), start in zip(zip(*ends), (v[:kv], c[:kc])):
+        assert np.isfinite(b).all() and np.linalg.norm(a - b) < 0.5 * np.linalg.norm(a - start)
