@@ -178,8 +178,8 @@ def cpu_baseline(args, graph):
 
     v, pool, prob, alias = sample(graph, "edge", 20, augmentation_step=1, shuffle_base=1)
     rate, done, el = time_reference(ref, cores, v, pool, prob, alias, B, k, args.cpu_seconds, args.seed + 7)
-    how = ("%.1f s wall, %d threads = the container's CPU quota on a %d-thread host, Hogwild; -Ofast x86-64-v3 host "
-           "build of the reference's own LINE::forward/backward + sgd_update" % (el, cores, os.cpu_count() or 1))
+    how = ("%.1f s wall, %d threads = the container's CPU quota on a %d-thread host, Hogwild; -Ofast -march=x86-64-v3 (not -march=native: built "
+           "in another container than the one that runs it, oracle/Makefile) host build of the reference's own LINE::forward/backward + sgd_update" % (el, cores, os.cpu_count() or 1))
     out = {"value": rate / 1e6, "unit": "million edge-samples/sec", "cores": cores, "kind": "reference",
            "sample": "%d batches of %d edge-samples drawn by the CPU edge sampler for this graph (%s)" % (done, B, how)}
     # configs[0]: the reference's CPU-runnable case — quick-start hyper-parameters on a BlogCatalog-sized graph
@@ -323,6 +323,31 @@ def module_leg(args, world, timeout=240):
     if run.returncode != 0 or not lines:
         return {"error": "exit code %d: %s" % (run.returncode, run.stderr.strip()[-300:])}
     return json.loads(lines[-1])
+
+
+def expected_curve():
+    """The prediction an N-GPU run tests, carried by the line itself: N x the one-GPU rate at the shard size of an N-GPU run, from the
+    newest committed `bench.py --partitions N` runs (profiles/r*/bench_by_partitions.jsonl) — what N GPUs deliver if nothing but their
+    kernels limits them.  No N-GPU run has been measured so far: this is an expectation, not a curve."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_by_partitions.jsonl")), reverse=True):
+        lines = [json.loads(l) for l in open(path) if l.startswith("{")]
+        curve = {}
+        for line in lines:
+            parts = line.get("config", {}).get("shard", {}).get("rows")
+            n = round(1000000 / parts) if parts else None
+            if n in (2, 4, 8):
+                curve[str(n)] = {"per_gpu_at_that_shard_size": line["value"], "expected_whole_job": n * line["value"]}
+        one = sorted(glob.glob(os.path.join(os.path.dirname(path), "bench_n1*.json")))
+        for name in one:
+            rows = [json.loads(l) for l in open(name) if l.startswith("{")]
+            if rows:
+                curve["1"] = {"per_gpu_at_that_shard_size": rows[-1]["value"], "expected_whole_job": rows[-1]["value"]}
+                break
+        if curve:
+            return {"unit": "million edge-samples/sec", "source": os.path.relpath(path, ROOT), "by_gpus": curve,
+                    "note": "one-GPU runs of the shard sizes (bench.py --partitions N), times N; north_star asks for >= 6 x at 8 GPUs"}
+    return None
 
 
 def same_shards_on_one_gpu(args, world, timeout=300):
@@ -631,6 +656,7 @@ def main(argv=None):
             result["end_to_end"]["module"] = module_leg(args, world)
     if world > 1 and cuda:
         if rank == 0:
+            result["expected_curve"] = expected_curve()
             same = result["single_gpu_same_shards"] = same_shards_on_one_gpu(args, world)
             if "value" in same:  # what N GPUs deliver if nothing but their kernels limits them, and what was measured
                 expected = world * same["value"]

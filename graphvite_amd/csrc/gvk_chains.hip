@@ -1483,9 +1483,13 @@ int gvk_train_episode_ahead(void *stream, void *chain_stream, int dim, const gvk
         const int per_launch = parts / pair_launches;
         const auto host_t0 = std::chrono::steady_clock::now();
         for (int i = 0; i < num_batches; i++) {
-            // the chains of batch i wait for the pairs of batch i - 2: what those pairs read of the ring may be overwritten now
-            if (i >= 2 && hipStreamWaitEvent(side, events->pairs_done[(i - 2) & 3], 0) != hipSuccess)
-                return fail(GVK_EHIP, "gvk_train_episode_ahead: event wait failed");
+            // the chains of batch i wait for the pairs of batch i - 2: what those pairs read of the ring may be overwritten now.
+            // GVK_AHEAD_THROTTLE=host (measurement): the HOST waits instead, so that the chain stream carries no barrier packet
+            if (i >= 2) {
+                static const bool on_host = getenv("GVK_AHEAD_THROTTLE") && !strcmp(getenv("GVK_AHEAD_THROTTLE"), "host");
+                const hipError_t e = on_host ? hipEventSynchronize(events->pairs_done[(i - 2) & 3]) : hipStreamWaitEvent(side, events->pairs_done[(i - 2) & 3], 0);
+                if (e != hipSuccess) return fail(GVK_EHIP, "gvk_train_episode_ahead: event wait failed");
+            }
             for (int q = 0; q < parts; q++) chains_of(i * parts + q, side);
             if (hipEventRecord(events->chains_done[i & 3], side) != hipSuccess || hipStreamWaitEvent(main, events->chains_done[i & 3], 0) != hipSuccess)
                 return fail(GVK_EHIP, "gvk_train_episode_ahead: event record / wait failed");

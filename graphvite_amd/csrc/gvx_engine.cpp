@@ -185,7 +185,7 @@ struct gvx_solver {
     int fidelity = -1;              // GVX_FIDELITY: -1 = the default rule (hub rows by chains where chains exist), 0 = throughput (no chains), 1 = chains or an error
     int hub_parts_request = 0;      // GVX_HUB_PARTS: 0 the rule (gvk_train_launches when every row is a hub row, else 1), Q > 0 given
     int64_t hub_rows_request = -2;  // GVX_HUB_ROWS: -2 the default rule, -1 by expected hits per batch, 0 off, N > 0 the first N rows
-    bool hogwild_said = false, order_said = false;  // warnings of configure() that are given once per solver
+    bool hogwild_said = false, order_said = false, rules_said = false;  // messages of configure() that are given once per solver
     int hub_rounds_request = -1;    // GVX_HUB_ROUNDS: -1 the rule (kHubRoundEntries), 0 / 1: long chains in one round / in rounds
     int hub_lerp_request = -1;      // GVX_HUB_LERP: -1 the rule, 0 / 1: the pairs read hub rows as their unit's chains left them / along the chains' way
     int hub_executor_request = -1;  // GVX_HUB_EXECUTOR: -1 the rule (kHubExecutor; the fused launches where lerp is asked for), 0 / 1
@@ -416,7 +416,7 @@ size_t gvx_solver::memory_demand(int P, int requested_episode, bool as_streamed)
     // — only where chains can exist: SGD, and not fidelity = "throughput"
     // Two such workspaces: the lists of the next chunk are built while this one trains.
     if (optimizer.type == GVK_SGD && (fidelity != 0 || hub_rows_request > -2) && hub_rows_request != 0)
-        demand += 2 * std::min((size_t)kHubChunk * batch_size * (num_negative + 1) * 32, gpu_memory_limit / 16);
+        demand += std::min((size_t)2 * kHubChunk * batch_size * (num_negative + 1) * 32, gpu_memory_limit / 16);
     if (device_sampling && !as_streamed) {
         // the pools of every block a worker trains, two episodes, + its slices on their way to the owners (send + receive)
         demand += 4 * tails * P * pool;
@@ -957,6 +957,26 @@ int gvx_solver::configure(const gvx_train_config &in) {
     // to the launch i % units (gvk_spread_pairs), so that what the reference's sequential loop trains one after the other is
     // trained by consecutive launches.  pair_order = "sampled" keeps the sampler's order.
     spread = final_spread();
+    if (hubs && first_rank == 0 && !rules_said) {  // which of the three rules fired and what they cost: once per solver, at INFO
+        int most_parts = 1, least_parts = 1 << 30;
+        bool any_rounds = false;
+        for (int hp = 0; hp < num_partition; hp++)
+            for (int tp = 0; tp < num_partition; tp++) {
+                if (hub_rows[hp] + hub_rows[tp] == 0) continue;
+                most_parts = std::max(most_parts, hub_parts_of(hp, tp)), least_parts = std::min(least_parts, hub_parts_of(hp, tp));
+                any_rounds = any_rounds || hub_rounds_of(hp, tp);
+            }
+        const int top = *std::max_element(hub_top_entries.begin(), hub_top_entries.end());
+        log_message(0, "hub rows by chains: up to %u rows per table (a batch is expected to hit them once or more), a batch as %d%s%d parts = launches "
+                    "(the largest hub row meets %d updates per batch: about %d per part%s%s), long chains %s%s",
+                    *std::max_element(hub_rows.begin(), hub_rows.end()), least_parts, least_parts == most_parts ? " = " : " .. ", most_parts, top,
+                    top / std::max(most_parts, 1), spread ? "; walk-ordered pools ask for augmentation_step^2 + 1 parts" : "",
+                    most_parts > 8 ? ": every launch costs its longest chain, 9-13 us, however few pairs it holds" : "",
+                    optimizer.type != GVK_SGD ? "as ONE sequential task each (a moment optimizer: a batch then takes as long as its largest hub row's updates one after the other)"
+                    : (any_rounds ? "in rounds of 4 entries per task (the largest vertex takes more than 2 % of the degree: about 28 % slower)" : "in one round"),
+                    fidelity == 0 ? "" : "; fidelity='throughput' trains every row pair by pair instead (2-3 x the rate, hub rows then keep a few of their updates per batch)");
+        rules_said = true;
+    }
     if (routed()) {
         if (pool_size % num_worker)
             return gvk_fail(GVK_EINVAL, "episode_size * batch_size (%zu) must be a multiple of #worker (%d) for the "
@@ -1052,6 +1072,18 @@ int gvx_solver::prepare_devices() {
         HIP_TRY(hipStreamCreateWithFlags(&w.compute, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&w.copy, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&w.exchange, hipStreamNonBlocking));
+        // GVX_CHAIN_CU_SHARE=N (measurement): the chain stream on every N-th compute unit only, the compute stream on the others
+        if (const char *share = getenv("GVX_CHAIN_CU_SHARE")) {
+            const int every = std::max(atoi(share), 2);
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDeviceProperties(&prop, w.device));
+            const int words = (prop.multiProcessorCount + 31) / 32;
+            std::vector<uint32_t> chain_mask(words, 0), pair_mask(words, 0);
+            for (int cu = 0; cu < prop.multiProcessorCount; cu++) ((cu / 8) % every == 0 ? chain_mask : pair_mask)[cu / 32] |= 1u << (cu % 32);
+            HIP_TRY(hipStreamDestroy(w.compute));
+            HIP_TRY(hipExtStreamCreateWithCUMask(&w.compute, (uint32_t)words, pair_mask.data()));
+            HIP_TRY(hipExtStreamCreateWithCUMask(&w.chains, (uint32_t)words, chain_mask.data()));
+        } else
         HIP_TRY(hipStreamCreateWithFlags(&w.chains, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&w.lists, hipStreamNonBlocking));
         for (int b = 0; b < 2; b++) {
@@ -1730,7 +1762,8 @@ int gvx_solver::hub_parts_of(int hp, int tp) const {
     // ... and, for the walk-ordered pools of DeepWalk / node2vec spread over the units (record i to unit i % units): one walk writes a
     // node's pairs — it heads `augmentation_step` consecutive records and is the tail of as many, spread over the
     // augmentation_step^2 + 1 records around them (graph.cuh:428-434) — so only with that many units no two of them share a unit
-    if (spread) want = std::max(want, config.augmentation_step * config.augmentation_step + 1);
+    static const bool walk_term = !(getenv("GVX_WALK_PARTS_TERM") && !strcmp(getenv("GVX_WALK_PARTS_TERM"), "0"));  // measurement: the rule without this term
+    if (spread && walk_term) want = std::max(want, config.augmentation_step * config.augmentation_step + 1);
     want = std::min(want, hub_max_parts);
     if (kv == part_rows && kc == part_rows) want = std::max(want, gvk_train_launches(B, part_rows));
     int parts = 1;

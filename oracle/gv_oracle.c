@@ -171,12 +171,22 @@ size_t gvo_hot_lists(const uint32_t *batch, const uint32_t *negatives, int batch
     return running;
 }
 
+/* Executor-simulator experiments (gvo_set_hub_snapshot): when set, a chain reads a partner that is a hub row — id below the count —
+ * from these copies instead of the tables: "what if the chains of several units read hub partners as the GROUP of units found
+ * them" (one launch for several units).  NULL (default): from the tables the caller passes. */
+static const float *gvo_snapshot_vertex = NULL, *gvo_snapshot_context = NULL;
+static uint32_t gvo_snapshot_kv = 0, gvo_snapshot_kc = 0;
+void gvo_set_hub_snapshot(const float *vertex_hub_rows, uint32_t kv, const float *context_hub_rows, uint32_t kc) {
+    gvo_snapshot_vertex = vertex_hub_rows, gvo_snapshot_kv = kv, gvo_snapshot_context = context_hub_rows, gvo_snapshot_kc = kc;
+}
+
 /* One chain task: entries [begin, end) applied one after the other to a copy of the own row; partner rows are only read. */
 static void gvo_chain(int dim, float *own, const float *partner, const uint32_t *entries, uint32_t begin, uint32_t end,
-                      float lr, float wd, float negative_weight) {
+                      float lr, float wd, float negative_weight, const float *hub_snapshot, uint32_t hub_count) {
     float dummy1 = 0, dummy2 = 0;
     for (uint32_t p = begin; p < end; p++) {
-        const float *c = partner + (size_t)(entries[p] & 0x7fffffffu) * dim;
+        const size_t id = entries[p] & 0x7fffffffu;
+        const float *c = hub_snapshot && id < hub_count ? hub_snapshot + id * dim : partner + id * dim;
         const int label = entries[p] >> 31;
         float logit = 0;
         for (int i = 0; i < dim; i++) logit += own[i] * c[i];
@@ -218,9 +228,11 @@ static int gvo_hot_chains(int dim, float *vertex, float *context, const float *p
     for (uint32_t chain = first_chain; chain < last_chain; chain++) {
         float *row = chain < kv ? vertex + (size_t)chain * dim : context + (size_t)(chain - kv) * dim;
         const float *partner = chain < kv ? partner_context : partner_vertex;
+        const float *snapshot = chain < kv ? gvo_snapshot_context : gvo_snapshot_vertex;  /* a head row's partners are context rows */
+        const uint32_t snapshot_count = chain < kv ? gvo_snapshot_kc : gvo_snapshot_kv;
         const uint32_t first = chain_start[chain], last = chain_start[chain + 1], n = last - first;
         if (n <= cap) {
-            gvo_chain(dim, row, partner, entries, first, last, lr, wd, negative_weight);
+            gvo_chain(dim, row, partner, entries, first, last, lr, wd, negative_weight, snapshot, snapshot_count);
             continue;
         }
         uint32_t per = gvo_long_task ? gvo_long_task : cap;
@@ -251,7 +263,7 @@ static int gvo_hot_chains(int dim, float *vertex, float *context, const float *p
                 const float before = (float)(pow(decay_positive, (double)positives_before) * pow(decay_negative, (double)(entries_before - positives_before)));
                 const float after = (float)(pow(decay_positive, (double)positives_after) * pow(decay_negative, (double)(entries_after - positives_after)));
                 for (int i = 0; i < dim; i++) own[i] = before * row[i];
-                gvo_chain(dim, own, partner, entries, from, to, lr, wd, negative_weight);
+                gvo_chain(dim, own, partner, entries, from, to, lr, wd, negative_weight, snapshot, snapshot_count);
                 for (int i = 0; i < dim; i++) sum[i] += (double)after * (double)own[i] - (double)total * (double)row[i];
                 positives_before += positives_inside, entries_before += to - from;
             }

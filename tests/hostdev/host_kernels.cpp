@@ -31,6 +31,7 @@ int gvo_hot_unit_chains(int dim, float *vertex, float *context, float lr, float 
 void gvo_set_pairs_concurrent(int on);
 void gvo_set_long_task(uint32_t entries);
 void gvo_set_round_steps(uint32_t steps);
+void gvo_set_hub_snapshot(const float *vertex_hub_rows, uint32_t kv, const float *context_hub_rows, uint32_t kc);
 int gvo_train_pairs_hot(int dim, float *vertex, float *context, const uint32_t *batch, const uint32_t *negatives, float *loss,
                         int batch_size, int k, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
                         const float *before_vertex, const float *before_context);
@@ -347,15 +348,27 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
             if (unit(u, true, true, nullptr, nullptr)) return gvk_fail(GVK_ENOMEM, "gvk_train_episode_hot: out of memory");
         return GVK_OK;
     }
+    // GVH_GROUP=g (experiment, round 6): the chains of g consecutive units read their hub PARTNERS as the group found them (their own
+    // rows go on from unit to unit) — what one launch for the chains of g units would compute
+    const int group = getenv("GVH_GROUP") ? std::max(atoi(getenv("GVH_GROUP")), 1) : 1;
+    std::vector<float> snap_v, snap_c;
+    auto group_start = [&](int u) {
+        if (group <= 1 || u % group) return;
+        snap_v.assign(tables->vertex, tables->vertex + hv), snap_c.assign(tables->context, tables->context + hc);
+        gvo_set_hub_snapshot(snap_v.data(), hot_vertex, snap_c.data(), hot_context);
+    };
+    struct ClearSnapshot { ~ClearSnapshot() { gvo_set_hub_snapshot(nullptr, 0, nullptr, 0); } } clear_snapshot;
     // the product form: launch u = the pairs of unit u + the chains of unit u + 1, which start before those pairs have written
     // anything and leave their rows in another mirror — the chains of unit u + 1 are computed from the tables as the pairs of
     // unit u - 1 left them, the pairs of unit u read the hub rows the chains of unit u left
     std::vector<float> before_v(hv), before_c(hc), now_v(hv), now_c(hc), next_v(hv), next_c(hc);
     memcpy(before_v.data(), tables->vertex, hv * 4), memcpy(before_c.data(), tables->context, hc * 4);
+    group_start(0);
     if (unit(0, true, false, nullptr, nullptr)) return gvk_fail(GVK_ENOMEM, "gvk_train_episode_hot: out of memory");
     for (int u = 0; u < units; u++) {
         memcpy(now_v.data(), tables->vertex, hv * 4), memcpy(now_c.data(), tables->context, hc * 4);
         if (u + 1 < units) {  // the chains of the next unit, from the tables as they are now; their rows land after this unit's pairs
+            group_start(u + 1);
             if (unit(u + 1, true, false, nullptr, nullptr)) return gvk_fail(GVK_ENOMEM, "gvk_train_episode_hot: out of memory");
             memcpy(next_v.data(), tables->vertex, hv * 4), memcpy(next_c.data(), tables->context, hc * 4);
             memcpy(tables->vertex, now_v.data(), hv * 4), memcpy(tables->context, now_c.data(), hc * 4);

@@ -63,6 +63,8 @@ def train(job, seed, optimizer=None, tweak=None, **solver_kw):
     fit = dict(augmentation_step=train_kw["augmentation_step"])
     if "walk_length" in train_kw:
         fit.update(random_walk_length=train_kw["walk_length"], random_walk_batch_size=train_kw["walk_batch"], shuffle_base=train_kw["shuffle_base"])
+    if "p" in train_kw:
+        fit.update(p=train_kw["p"], q=train_kw["q"])
     s.train(model=model, num_epoch=epochs, log_frequency=1 << 30, **fit)
     assert s.num_partition == partitions and s.batch_id == gbatches, (s.num_partition, s.batch_id, gbatches)
     auc = link_prediction_auc(s.vertex_embeddings, s.context_embeddings, H, T, Y)
@@ -103,6 +105,22 @@ def test_youtube_size_deepwalk_matches_the_reference_training_loop(partitions, s
         aucs.append(auc)
     print("youtube-size DeepWalk, %d partition(s), %s: %s" % (partitions, sampling, info))
     compare_auc("youtube-size DeepWalk P=%d %s" % (partitions, sampling), aucs, reference)
+
+
+@pytest.mark.parametrize("sampling", ["cpu", "device"])
+def test_youtube_size_node2vec_matches_the_reference_training_loop(sampling):
+    """BASELINE configs[3] as it is worded: node2vec p = q = 0.25 at Youtube's size (1 138 499 nodes / 4 945 382 edge lines) in the 4
+    partitions of its 4 GPUs, augmentation_step 5, walks of 40 — against the reference's own loop, whose sampler draws from per-edge
+    alias tables (graph.cuh:656-677: 2.3e9 entries = 18 GB on this graph, built once per golden seed; tests/golden/make_configs_golden.py
+    yt_p4_node2vec says why the graph is the exponent-2.5 one).  Here the tables would pass 2^30 entries: the CPU samplers draw the same
+    transition distribution by rejection (gvs.h GVS_MODE_BIASED_REJECT), the device sampler always does."""
+    aucs = []
+    for seed in SEEDS[:3]:
+        auc, reference, info = train("yt_p4_node2vec", seed, device_sampling=sampling == "device")
+        assert 0 < info["hub_rows"] < 1138499 // 4 and info["parts"] > 1 and info["pair_order"] == "spread", info
+        aucs.append(auc)
+    print("youtube-size node2vec 0.25 / 0.25, 4 partitions, %s samplers: %s" % (sampling, info))
+    compare_auc("youtube-size node2vec p=q=0.25 P=4 %s" % sampling, aucs, reference)
 
 
 @pytest.mark.parametrize("job", ["held_p1", "held_p8_e8"])
