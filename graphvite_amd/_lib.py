@@ -69,7 +69,7 @@ class WalkGraph(C.Structure):
 # ---- include/gvx.h ---------------------------------------------------------------------------------------------------
 GVX_AUTO = 0
 GVX_DEVICE_SAMPLING, GVX_PAIR_ORDER, GVX_SEED, GVX_NEGATIVE_TABLE, GVX_NODE2VEC_TABLE_LIMIT, GVX_HUB_ROWS, GVX_HUB_PARTS, GVX_FIDELITY = 1, 2, 3, 4, 5, 6, 7, 8
-GVX_HUB_LERP, GVX_HUB_CHAIN_CAP, GVX_HUB_ROUNDS, GVX_HUB_EXECUTOR, GVX_HUB_PAIR_LAUNCHES = 9, 10, 11, 12, 13
+GVX_HUB_LERP, GVX_HUB_CHAIN_CAP, GVX_HUB_ROUNDS, GVX_HUB_EXECUTOR, GVX_HUB_PAIR_LAUNCHES, GVX_HUB_GROUP = 9, 10, 11, 12, 13, 14
 GVX_UNIQUE_ID_BYTES = 256
 SCHEDULE_FUNCTION = C.CFUNCTYPE(C.c_float, C.c_int, C.c_int, C.c_void_p)
 TRANSPORT_ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -147,10 +147,10 @@ def lib():
     l.gvk_ahead_plan.restype = i32
     l.gvk_ahead_plan.argtypes = [i32, i32, i32, u32, u32, i32, i32, i32, P(C.c_size_t)]
     l.gvk_ahead_build.restype = i32
-    l.gvk_ahead_build.argtypes = [vp, i32, vp, C.c_size_t, vp, i32, i32, i32, P(NegativeSource), u32, u32, u32, u32, i32, i32]
+    l.gvk_ahead_build.argtypes = [vp, i32, vp, C.c_size_t, vp, i32, i32, i32, P(NegativeSource), u32, u32, u32, u32, i32, i32, i32]
     l.gvk_train_episode_ahead.restype = i32
     l.gvk_train_episode_ahead.argtypes = [vp, vp, i32, P(Optimizer), i32, P(Tables), vp, P(NegativeSource), u32, u32, u32, i32, vp,
-                                          i32, i32, f32, vp, C.c_size_t, u32, u32, i32, i32, i32, i32, i32]
+                                          i32, i32, f32, vp, C.c_size_t, u32, u32, i32, i32, i32, i32, i32, i32]
     l.gvk_predict.restype = i32
     l.gvk_predict.argtypes = [vp, i32, vp, vp, vp, vp, i32]
     l.gvk_probe_row_traffic.restype = i32

@@ -89,6 +89,13 @@ struct HotArgs {
     uint32_t slot_stride;         // rows between two slots of the ring (versioned: chains; mirrors: 0)
     uint32_t ring_slots;
     int versioned;
+    // grouped (gvk_train_episode_ahead with group > 1): one launch carries the chains of `group` consecutive units; a chain whose row
+    // had entries in an earlier unit of the same launch waits for that unit's chain to publish it (published[row] = that unit + 1)
+    uint32_t *published;
+    uint32_t unit;                // this unit's index in the call (a chain publishes unit + 1)
+    int grouped;
+    // train_group_kernel: the units of a launch lie `*_stride` words apart in the work lists
+    uint32_t units_in_launch, start_stride, entries_stride, long_stride, short_stride;
     uint32_t chains;              // hot_vertex + hot_context
     uint32_t long_capacity;
     uint32_t cap;                 // entries of one task (at most kShortEntries)
@@ -137,6 +144,59 @@ __device__ __forceinline__ const float *partner_of(const HotArgs &h, const uint3
     return id < partner_hot ? h.from + (size_t)(partner_base + id) * DIM : partner_table + (size_t)id * DIM;
 }
 
+// Grouped launches: the own row of a chain may have been stored by another workgroup of the SAME launch (the chain of an earlier unit
+// of the group), possibly on another XCD, whose L2 this one does not see: such a row is stored and loaded at agent scope (sc1: through
+// to memory), the hand-off is published[row] — measured in scripts/experiments/r6_micro/chain_micro.hip (ii): coherent loads and stores
+// with a relaxed flag pass a mirror between 256 workgroups without fences (a release / acquire fence pair per hand-off costs ten times more).
+template <int DIM, int G>
+__device__ __forceinline__ void load_row_coherent(const float *base, const int lane, float (&r)[DIM / G]) {
+    typedef Layout<DIM, G> L;
+#pragma unroll
+    for (int c = 0; c < L::NC; c++)
+#pragma unroll
+        for (int x = 0; x < L::CW; x++)
+            r[c * L::CW + x] = __hip_atomic_load(base + lane * L::CW + c * G * L::CW + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int DIM, int G>
+__device__ __forceinline__ void store_row_coherent(float *base, const int lane, const float (&r)[DIM / G]) {
+    typedef Layout<DIM, G> L;
+#pragma unroll
+    for (int c = 0; c < L::NC; c++)
+#pragma unroll
+        for (int x = 0; x < L::CW; x++)
+            __hip_atomic_store(base + lane * L::CW + c * G * L::CW + x, r[c * L::CW + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a record's fourth word: the slot the own row is read at (8 bits) | the unit + 1 whose chain stored it (16 bits) << 8 | 1 << 31 when
+// that unit belongs to this launch (hot_slots_kernel)
+constexpr uint32_t kRecordWaits = 0x80000000u;
+// the chain's row is there: published[chain] has reached the unit the record names (bounded: a bug must not hang the GPU — past the
+// bound the chain goes on with what it finds and the launch's result is wrong, which the parity tests see)
+__device__ __forceinline__ void await_row(const HotArgs &h, const uint32_t chain, const uint32_t word) {
+    if (!h.grouped || !(word & kRecordWaits)) return;
+    const uint32_t want = (word >> 8) & 0xffffu;
+    for (uint32_t spins = 0; __hip_atomic_load(h.published + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && spins < (1u << 20); spins++)
+        __builtin_amdgcn_s_sleep(2);
+}
+template <int DIM, int G>
+__device__ __forceinline__ void load_own_row(const HotArgs &h, const uint32_t chain, const uint32_t word, const int lane, float (&r)[DIM / G]) {
+    const float *at = hub_from<DIM>(h, chain, h.versioned ? word & 0xffu : 0u);
+    if (h.grouped && (word & kRecordWaits)) load_row_coherent<DIM, G>(at, lane, r);
+    else load_row_at<DIM, G>(at, lane, r);
+}
+// the chain's row to its next slot; grouped: at agent scope, then published (the stores of a wavefront are complete before its flag is set)
+template <int DIM, int G>
+__device__ __forceinline__ void store_own_row(const HotArgs &h, const uint32_t chain, const uint32_t word, const int lane, const bool writer,
+                                              const float (&r)[DIM / G]) {
+    float *at = hub_to<DIM>(h, chain, h.versioned ? word & 0xffu : 0u);
+    if (!h.grouped) {
+        if (writer) store_row_at<DIM, G>(at, lane, r);
+        return;
+    }
+    if (writer) store_row_coherent<DIM, G>(at, lane, r);
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): this wavefront's stores have been acknowledged
+    if (writer && lane == 0) __hip_atomic_store(h.published + chain, h.unit + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 #if !defined(GVK_CHAIN_STEPS_INLINE)
 #define GVK_CHAIN_STEPS_INLINE __forceinline__
 #endif
@@ -156,9 +216,14 @@ struct ChainShape {
 // group without work) — the loop runs as long as any group has entries left; a group past its end keeps requesting its own
 // mirror row and trains with weight 0.  Every step issues exactly one row request and consumes the one issued D steps
 // earlier, with no branch around either, so the wait before a step is "all but the D - 1 youngest" and not "all".
-template <int DIM, int G>
+struct NoPrepare {
+    __device__ __forceinline__ void operator()() const {}
+};
+// prepare(): called once, after the first partner rows have been requested and before the first step — where a grouped launch's chain
+// waits for its own row (await_row): what it waits for is another workgroup's work, and its own requests are on their way meanwhile
+template <int DIM, int G, class Prepare = NoPrepare>
 __device__ GVK_CHAIN_STEPS_INLINE void chain_steps(const TrainArgs &a, const HotArgs &h, const uint32_t chain, const uint32_t slot_from,
-                                            const uint32_t begin, const uint32_t end, const int lane, float (&own)[DIM / G]) {
+                                            const uint32_t begin, const uint32_t end, const int lane, float (&own)[DIM / G], Prepare prepare = Prepare()) {
     typedef ChainShape<DIM, G> S;
     constexpr int V = S::V, D = S::D;
     const bool is_vertex = chain < a.hot_vertex;
@@ -186,6 +251,7 @@ __device__ GVK_CHAIN_STEPS_INLINE void chain_steps(const TrainArgs &a, const Hot
         load_row_at<DIM, G>(row_of(begin + i, label), lane, ring[i]);
         labels |= label << i;
     }
+    prepare();
     for (uint32_t base = begin; __builtin_amdgcn_ballot_w64(base < end) != 0; base += D) {
         const uint32_t f = blk + 2 * G + lane;
         const uint32_t e_fut = h.entries[f < end ? f : (begin < end ? end - 1 : 0)];  // the window after e_nxt, asked for ahead of its use
@@ -228,10 +294,15 @@ constexpr int kShortEntries = 7;
 
 // The n <= kShortEntries entries entry_of(0 .. n - 1) of one chain applied one after the other to `own`: every partner row is
 // requested before the first step (where the registers hold them: dims up to 128), so the chain waits for memory once.
-template <int DIM, int G, class EntryOf>
+// GVK_TASK_ROWS (measurement knob, 16 in a build for fewer wavefronts per SIMD): a long chain's task of up to so many entries has all its
+// partner rows in flight at once (N below) instead of a ring of four
+#if !defined(GVK_TASK_ROWS)
+#define GVK_TASK_ROWS 7
+#endif
+template <int DIM, int G, class EntryOf, class Prepare = NoPrepare, int N = kShortEntries>
 __device__ __forceinline__ void short_steps(const TrainArgs &a, const HotArgs &h, const uint32_t chain, const uint32_t slot_from, const uint32_t n,
-                                            const int lane, float (&own)[DIM / G], EntryOf entry_of) {
-    constexpr int V = DIM / G, N = kShortEntries;
+                                            const int lane, float (&own)[DIM / G], EntryOf entry_of, Prepare prepare = Prepare()) {
+    constexpr int V = DIM / G;
     constexpr int D = V <= 8 ? N : (V <= 12 ? 3 : 2);  // partner rows in flight: all of them where the registers hold them
     const bool is_vertex = chain < a.hot_vertex;
     const float *partner_table = is_vertex ? a.context : a.vertex;
@@ -248,6 +319,7 @@ __device__ __forceinline__ void short_steps(const TrainArgs &a, const HotArgs &h
     };
 #pragma unroll
     for (int i = 0; i < D; i++) request(i);
+    prepare();
 #pragma unroll
     for (int i = 0; i < N; i++) {
         const bool positive = (labels >> i & 1u) != 0;
@@ -280,12 +352,15 @@ __device__ __forceinline__ void train_short_chains(const TrainArgs &a, const Hot
         return (uint32_t)(i < LW ? __shfl((int)word0, i, G) : __shfl((int)word1, i - LW, G));
     };
     const bool mine = at < count;
-    const uint32_t chain = mine ? word(0) : 0, n = mine ? word(1) : 0, slot_from = mine && h.versioned ? word(3) : 0;
+    const uint32_t chain = mine ? word(0) : 0, n = mine ? word(1) : 0, where = mine && h.versioned ? word(3) : 0, slot_from = where & 0xffu;
     float own[S::V];
-    load_row_at<DIM, G>(hub_from<DIM>(h, chain, slot_from), lane, own);
-    short_steps<DIM, G>(a, h, chain, slot_from, n, lane, own, [&](const int i) __attribute__((always_inline)) { return word(4 + i); });
+    short_steps<DIM, G>(a, h, chain, slot_from, n, lane, own, [&](const int i) __attribute__((always_inline)) { return word(4 + i); },
+                        [&]() __attribute__((always_inline)) {  // the partner rows are on their way: now the own row (a grouped launch: once it is there)
+                            await_row(h, chain, where);
+                            load_own_row<DIM, G>(h, chain, where, lane, own);
+                        });
     GVK_STAMP(h, 5);  // steps done
-    if (mine) store_row_at<DIM, G>(hub_to<DIM>(h, chain, slot_from), lane, own);
+    store_own_row<DIM, G>(h, chain, where, lane, mine, own);
 }
 
 // Hub rows the unit has no entry for pass from mirror to mirror unchanged — those that need it: the mirror `to` was last
@@ -343,7 +418,7 @@ __device__ __forceinline__ void train_long_chains_one_round(const TrainArgs &a, 
     const uint32_t count = h.long_list[0] < h.long_capacity ? h.long_list[0] : h.long_capacity;
     for (uint32_t j = block; j < count; j += (uint32_t)h.long_blocks) {
         if (j != block) record = *reinterpret_cast<const u32x4 *>(h.long_list + 4 + 4 * (size_t)j);
-        const uint32_t chain = record.x, first = record.y, n = record.z, last = first + n, slot_from = h.versioned ? record.w : 0u;
+        const uint32_t chain = record.x, first = record.y, n = record.z, last = first + n, where = h.versioned ? record.w : 0u, slot_from = where & 0xffu;
         if (j == block) {
             GVK_STAMP_VALUE(h, 0, 1);
             GVK_STAMP(h, 2);  // the record is here
@@ -357,7 +432,6 @@ __device__ __forceinline__ void train_long_chains_one_round(const TrainArgs &a, 
         const uint32_t begin = mine ? first + (uint32_t)group * per : last;
         const uint32_t end = last - begin > per ? begin + per : last;
         float own[V];
-        load_row_at<DIM, G>(hub_from<DIM>(h, chain, slot_from), lane, own);
         const uint32_t mine_entry = begin + lane < end ? h.entries[begin + lane] : 0;  // the task's first G entries, one per lane
         uint32_t inside = mine_entry >> 31;
         for (uint32_t p = begin + G + lane; p < end; p += G) inside += h.entries[p] >> 31;
@@ -374,13 +448,20 @@ __device__ __forceinline__ void train_long_chains_one_round(const TrainArgs &a, 
         const float before_ = exp2f(pb * h.log2_decay_positive + ((float)(begin - first) - pb) * h.log2_decay_negative);
         const float after_ = exp2f(pa * h.log2_decay_positive + ((float)(last - end) - pa) * h.log2_decay_negative);
         const float total = exp2f((pb + pi + pa) * h.log2_decay_positive + ((float)n - (pb + pi + pa)) * h.log2_decay_negative);
+        auto own_row = [&]() __attribute__((always_inline)) {  // after the task's first partner rows have been requested (a grouped launch waits here)
+            await_row(h, chain, where);
+            load_own_row<DIM, G>(h, chain, where, lane, own);
 #pragma unroll
-        for (int x = 0; x < V; x++) own[x] *= before_;
+            for (int x = 0; x < V; x++) own[x] *= before_;
+        };
+        auto entry_of = [&](const int i) __attribute__((always_inline)) { return (uint32_t)__shfl((int)mine_entry, i, G); };
         if (per <= (uint32_t)kShortEntries)  // the usual task: all its partner rows at once
-            short_steps<DIM, G>(a, h, chain, slot_from, end - begin, lane, own,
-                                [&](const int i) __attribute__((always_inline)) { return (uint32_t)__shfl((int)mine_entry, i, G); });
+            short_steps<DIM, G>(a, h, chain, slot_from, end - begin, lane, own, entry_of, own_row);
+        else if (GVK_TASK_ROWS > kShortEntries && V <= 8 && per <= (uint32_t)(GVK_TASK_ROWS < G ? GVK_TASK_ROWS : G))
+            short_steps<DIM, G, decltype(entry_of), decltype(own_row), (GVK_TASK_ROWS > kShortEntries ? (GVK_TASK_ROWS < G ? GVK_TASK_ROWS : G) : kShortEntries)>(
+                a, h, chain, slot_from, end - begin, lane, own, entry_of, own_row);
         else  // a chain of more than NG tasks of seven entries (the largest hubs): longer tasks, rows D at a time
-            chain_steps<DIM, G>(a, h, chain, slot_from, begin, end, lane, own);
+            chain_steps<DIM, G>(a, h, chain, slot_from, begin, end, lane, own, own_row);
         if (mine) {
 #pragma unroll
             for (int x = 0; x < V; x++) own[x] *= after_;
@@ -391,7 +472,7 @@ __device__ __forceinline__ void train_long_chains_one_round(const TrainArgs &a, 
         if (j == block) GVK_STAMP(h, 5);  // every task's steps are done
         if (group == 0) {
             float sum[V], row0[V];
-            load_row_at<DIM, G>(hub_from<DIM>(h, chain, slot_from), lane, row0);
+            load_own_row<DIM, G>(h, chain, where, lane, row0);
 #pragma unroll
             for (int x = 0; x < V; x++) sum[x] = (1.0f - (float)tasks) * total * row0[x];
             for (uint32_t t = 0; t < tasks; t++) {
@@ -400,7 +481,7 @@ __device__ __forceinline__ void train_long_chains_one_round(const TrainArgs &a, 
 #pragma unroll
                 for (int x = 0; x < V; x++) sum[x] += part[x];
             }
-            store_row_at<DIM, G>(hub_to<DIM>(h, chain, slot_from), lane, sum);
+            store_own_row<DIM, G>(h, chain, where, lane, true, sum);
         }
         __syncthreads();
         if (j == block) GVK_STAMP(h, 6);  // composed and stored
@@ -444,7 +525,7 @@ __device__ __forceinline__ void train_long_chains_in_rounds(const TrainArgs &a, 
     const uint32_t count = h.long_list[0] < h.long_capacity ? h.long_list[0] : h.long_capacity;
     for (uint32_t j = block; j < count; j += (uint32_t)h.long_blocks) {
         if (j != block) record = *reinterpret_cast<const u32x4 *>(h.long_list + 4 + 4 * (size_t)j);
-        const uint32_t chain = record.x, first = record.y, n = record.z, last = first + n, slot_from = h.versioned ? record.w : 0u;
+        const uint32_t chain = record.x, first = record.y, n = record.z, last = first + n, where = h.versioned ? record.w : 0u, slot_from = where & 0xffu;
         if (j == block) {
             GVK_STAMP_VALUE(h, 0, 1);
             GVK_STAMP(h, 2);  // the record is here
@@ -460,7 +541,8 @@ __device__ __forceinline__ void train_long_chains_in_rounds(const TrainArgs &a, 
         // entries a task applies per round (a round's segment fits one fetch of G entries)
         const uint32_t steps = h.round_steps && per > h.round_steps ? (h.round_steps < (uint32_t)G ? h.round_steps : (uint32_t)G) : per;
         float row[V], own[V];
-        load_row_at<DIM, G>(hub_from<DIM>(h, chain, slot_from), lane, row);
+        await_row(h, chain, where);
+        load_own_row<DIM, G>(h, chain, where, lane, row);
         const uint32_t mine_entry = begin + lane < end ? h.entries[begin + lane] : 0;  // the task's first G entries, one per lane
         // what the tasks of a round need from each other: {positives, entries} of every task's segment, through LDS
         auto share_counts = [&](const int buffer, const uint32_t positives, const uint32_t length) __attribute__((always_inline)) {
@@ -608,7 +690,7 @@ __device__ __forceinline__ void train_long_chains_in_rounds(const TrainArgs &a, 
             if (j == block) GVK_STAMP(h, 5);  // every task's steps are done
             compose(buffer);
         }
-        if (group == 0) store_row_at<DIM, G>(hub_to<DIM>(h, chain, slot_from), lane, row);
+        if (group == 0) store_own_row<DIM, G>(h, chain, where, lane, true, row);
         __syncthreads();
         if (j == block) GVK_STAMP(h, 6);  // composed and stored
     }
@@ -889,25 +971,58 @@ __global__ void __launch_bounds__(kBlock, 4) hot_pairs_kernel(const TrainArgs a)
     train_pair<DIM, G, GVK_SGD, KT, 1, 3>(a, blockIdx.x * kBlock + threadIdx.x);
 }
 
-// ver[u][c] = slot of chain c's row after unit u: the number of units up to u that have entries for it, modulo the ring
-__global__ void __launch_bounds__(kBlock) hot_version_kernel(const uint32_t *chain_start_all, uint8_t *ver_all, const uint32_t chains,
+// One launch for the chains of `units_in_launch` consecutive units AND the pairs of the units before them (gvk_train_episode_ahead with
+// group > 1): grid [chains of the first unit | pairs | chains of the second unit | ...].  A launch of
+// train_hot_kernel lasts as long as its unit's longest chain while its pairs are done in half the time; here the chains of the later
+// units start as soon as their own row is there — published by the chain of the unit before, a workgroup of the same launch (await_row)
+// — and their partners that are hub rows are read as the GROUP found them (hot_slots_kernel), so nothing else of the launch has to be
+// waited for.  Workgroups are dispatched in grid order: whatever a chain waits for was dispatched before it.
+template <int DIM, int G, int KT, int ROUNDS>
+__global__ void __launch_bounds__(kHotBlock, DIM / G > 12 ? 3 : GVK_HOT_WAVES) train_group_kernel(const TrainArgs a, const HotArgs h) {
+    const int per_unit = h.long_blocks + h.short_blocks;
+    int b = blockIdx.x, sub = 0;
+    if (b >= per_unit) {
+        if (b < per_unit + h.pair_blocks) {
+            train_pair<DIM, G, GVK_SGD, KT, 1, 3>(a, (b - per_unit) * kHotBlock + threadIdx.x);
+            return;
+        }
+        b -= per_unit + h.pair_blocks;
+        sub = 1 + b / per_unit, b %= per_unit;
+    }
+    if ((uint32_t)sub >= h.units_in_launch) return;
+    HotArgs u = h;  // the unit's own work lists
+    u.chain_start += (size_t)sub * h.start_stride, u.entries += (size_t)sub * h.entries_stride;
+    u.long_list += (size_t)sub * h.long_stride, u.short_list += (size_t)sub * h.short_stride;
+    u.unit = h.unit + (uint32_t)sub;
+    if (b < h.long_blocks) {
+        if constexpr (ROUNDS != 0) train_long_chains_in_rounds<DIM, G>(a, u, b);
+        else train_long_chains_one_round<DIM, G>(a, u, b);
+    } else {
+        train_short_chains<DIM, G>(a, u, b - h.long_blocks);
+    }
+}
+
+// ver[u][c] = slot of chain c's row after unit u: the number of units up to u that have entries for it, modulo the ring;
+// last[u][c] = 1 + the last unit up to u that has entries for it (0: none in this call) — what a grouped launch's chains wait for
+__global__ void __launch_bounds__(kBlock) hot_version_kernel(const uint32_t *chain_start_all, uint8_t *ver_all, uint16_t *last_all, const uint32_t chains,
                                                              const int units, const uint32_t ring_slots) {
     const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
     if (c >= chains) return;
-    uint32_t v = 0;
+    uint32_t v = 0, last = 0;
     for (int u = 0; u < units; u++) {
         const uint32_t *start = chain_start_all + (size_t)u * (chains + 1);
-        if (start[c + 1] != start[c]) v = v + 1 == ring_slots ? 0u : v + 1;
+        if (start[c + 1] != start[c]) v = v + 1 == ring_slots ? 0u : v + 1, last = (uint32_t)u + 1;
         ver_all[(size_t)u * chains + c] = (uint8_t)v;
+        last_all[(size_t)u * chains + c] = (uint16_t)last;
     }
 }
 
 // One workgroup per unit: the slots into the unit's work lists and the samples' slot words (see above)
 __global__ void __launch_bounds__(kListThreads) hot_slots_kernel(TrainArgs a, const uint32_t first_batch_id, const uint32_t stride,
                                                                  const uint32_t *chain_start_all, uint32_t *entries_all, uint32_t *long_all,
-                                                                 uint32_t *short_all, const uint8_t *ver_all, uint32_t *slots_all,
-                                                                 const uint32_t entry_capacity, const uint32_t long_capacity, const int parts,
-                                                                 const int slot_words) {
+                                                                 uint32_t *short_all, const uint8_t *ver_all, const uint16_t *last_all,
+                                                                 uint32_t *slots_all, const uint32_t entry_capacity, const uint32_t long_capacity,
+                                                                 const int parts, const int slot_words, const int group) {
     const uint32_t chains = a.hot_vertex + a.hot_context;
     const int B = a.batch_size, k = a.k, u = blockIdx.x;
     const int batch = u / parts, lo = (u % parts) * (B / parts), hi = lo + B / parts;
@@ -916,7 +1031,16 @@ __global__ void __launch_bounds__(kListThreads) hot_slots_kernel(TrainArgs a, co
     uint32_t *entries = entries_all + (size_t)u * entry_capacity;
     uint32_t *long_list = long_all + (size_t)u * 4 * (1 + (size_t)long_capacity);
     uint32_t *short_list = short_all + (size_t)u * 16 * (1 + (size_t)chains);
+    // group > 1: the chains of `group` consecutive units run in one launch and read their hub PARTNERS as the group found them — at the
+    // slots before the group's first unit —, their own row as the unit before left it (a chain of the same launch publishes it)
+    const int first_of_group = u - u % group;
     const uint8_t *now = ver_all + (size_t)u * chains, *before = u ? now - chains : nullptr;
+    const uint8_t *partners = first_of_group ? ver_all + (size_t)(first_of_group - 1) * chains : nullptr;
+    const uint16_t *stored_by = u ? last_all + (size_t)(u - 1) * chains : nullptr;
+    auto where_of = [&](const uint32_t chain) {  // a record's fourth word: slot | 1 + the unit that stored the row << 8 | it belongs to this launch << 31
+        const uint32_t unit = stored_by ? stored_by[chain] : 0u;
+        return (before ? (uint32_t)before[chain] : 0u) | unit << 8 | (unit > (uint32_t)first_of_group ? kRecordWaits : 0u);
+    };
     a.batch_id = first_batch_id + (uint32_t)batch * stride;
     // the samples: where the unit's pairs read their hub rows — as the unit's chains left them
     for (int s = lo + threadIdx.x; s < hi; s += kListThreads) {
@@ -938,7 +1062,7 @@ __global__ void __launch_bounds__(kListThreads) hot_slots_kernel(TrainArgs a, co
         const uint32_t x = entries[e], label = x & 0x80000000u, id = x & 0x7fffffffu;
         const bool of_head = e < head_entries;  // the chains are listed by row, head rows first: this entry's partner is a context row
         const uint32_t hot = of_head ? a.hot_context : a.hot_vertex, base = of_head ? a.hot_vertex : 0u;
-        entries[e] = id < hot ? (label | kEntryHub | (before ? (uint32_t)before[base + id] : 0u) << 16 | id) : x;
+        entries[e] = id < hot ? (label | kEntryHub | (partners ? (uint32_t)partners[base + id] : 0u) << 16 | id) : x;
     }
     __syncthreads();
     __threadfence_block();
@@ -946,12 +1070,12 @@ __global__ void __launch_bounds__(kListThreads) hot_slots_kernel(TrainArgs a, co
     const uint32_t long_count = long_list[0] < long_capacity ? long_list[0] : long_capacity, short_count = short_list[0];
     for (uint32_t j = threadIdx.x; j < long_count; j += kListThreads) {
         uint32_t *record = long_list + 4 + 4 * (size_t)j;
-        record[3] = before ? (uint32_t)before[record[0]] : 0u;
+        record[3] = where_of(record[0]);
     }
     for (uint32_t r = threadIdx.x / 8; r < short_count; r += kListThreads / 8) {
         uint32_t *record = short_list + 16 + 16 * (size_t)r;
         const uint32_t n = record[1], first = record[2], i = threadIdx.x % 8;
-        if (i == 7) record[3] = before ? (uint32_t)before[record[0]] : 0u;
+        if (i == 7) record[3] = where_of(record[0]);
         if (i < n) record[4 + i] = entries[first + i];
     }
 }
@@ -975,6 +1099,7 @@ __global__ void __launch_bounds__(kBlock) hub_versions_kernel(float *vertex, flo
 struct HotLayout {
     size_t chain_start = 0, entries = 0, long_list = 0, short_list = 0, mirrors = 0, mirror_bytes = 0, bytes = 0;  // offsets into the workspace
     size_t versions = 0, slots = 0;  // versioned (gvk_ahead_*): ver[units][chains] bytes, the samples' slot words; `mirrors` is the ring
+    size_t last = 0, published = 0;  // ... last[units][chains] (u16: 1 + the unit that stored a row last), published[chains]
     uint32_t chains = 0, entry_capacity = 0, long_capacity = 0, cap = 0, ring_slots = 0;
     int slot_words = 0;
 };
@@ -1017,7 +1142,9 @@ HotLayout hot_layout(int dim, int batch_size, int k, uint32_t hot_vertex, uint32
         l.mirror_bytes = (size_t)l.chains * dim * 4;
         l.versions = l.mirrors + align((size_t)l.ring_slots * l.mirror_bytes);
         l.slots = l.versions + align((size_t)num_batch * l.chains);
-        l.bytes = l.slots + align(samples * l.slot_words * 4);
+        l.last = l.slots + align(samples * l.slot_words * 4);
+        l.published = l.last + align((size_t)num_batch * l.chains * 2);
+        l.bytes = l.published + align((size_t)l.chains * 4);
     }
     return l;
 }
@@ -1295,8 +1422,10 @@ int gvk_ahead_plan(int dim, int batch_size, int num_negative, uint32_t hot_verte
 
 int gvk_ahead_build(void *stream, int dim, void *workspace, size_t workspace_bytes, const uint32_t *pool, int batch_size, int num_batch,
                     int num_negative, const gvk_negative_source *negative, uint32_t first_batch_id, uint32_t batch_id_stride,
-                    uint32_t hot_vertex, uint32_t hot_context, int parts, int chain_cap) {
+                    uint32_t hot_vertex, uint32_t hot_context, int parts, int chain_cap, int group) {
     if (parts > 127) return fail(GVK_EINVAL, "gvk_ahead_build: at most 127 parts");
+    if (group < 1 || parts % group) return fail(GVK_EINVAL, "gvk_ahead_build: group must divide parts");
+    if ((int64_t)num_batch * parts > 65534) return fail(GVK_EINVAL, "gvk_ahead_build: at most 65534 units per call (a unit's index is 16 bits of a record)");
     if (num_batch <= 0) return num_batch < 0 ? fail(GVK_EINVAL, "gvk_ahead_build: negative num_batch") : GVK_OK;
     if (hot_vertex > 0x7fffu || hot_context > 0x7fffu) return fail(GVK_EINVAL, "gvk_ahead_build: at most 32767 hub rows per table");
     const HotLayout l = hot_layout(dim, batch_size, num_negative, hot_vertex, hot_context, num_batch, parts, chain_cap, true);
@@ -1315,13 +1444,13 @@ int gvk_ahead_build(void *stream, int dim, void *workspace, size_t workspace_byt
     char *base = static_cast<char *>(workspace);
     const int units = num_batch * parts;
     hipLaunchKernelGGL(hot_version_kernel, dim3((l.chains + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream,
-                       reinterpret_cast<const uint32_t *>(base + l.chain_start), reinterpret_cast<uint8_t *>(base + l.versions), l.chains, units,
-                       l.ring_slots);
+                       reinterpret_cast<const uint32_t *>(base + l.chain_start), reinterpret_cast<uint8_t *>(base + l.versions),
+                       reinterpret_cast<uint16_t *>(base + l.last), l.chains, units, l.ring_slots);
     hipLaunchKernelGGL(hot_slots_kernel, dim3((unsigned)units), dim3(kListThreads), 0, (hipStream_t)stream, a, first_batch_id, batch_id_stride,
                        reinterpret_cast<const uint32_t *>(base + l.chain_start), reinterpret_cast<uint32_t *>(base + l.entries),
                        reinterpret_cast<uint32_t *>(base + l.long_list), reinterpret_cast<uint32_t *>(base + l.short_list),
-                       reinterpret_cast<const uint8_t *>(base + l.versions), reinterpret_cast<uint32_t *>(base + l.slots), l.entry_capacity,
-                       l.long_capacity, parts, l.slot_words);
+                       reinterpret_cast<const uint8_t *>(base + l.versions), reinterpret_cast<const uint16_t *>(base + l.last),
+                       reinterpret_cast<uint32_t *>(base + l.slots), l.entry_capacity, l.long_capacity, parts, l.slot_words, group);
     return check_launch("gvk_ahead_build");
 }
 
@@ -1334,6 +1463,16 @@ ChainKernel pick_chain(int dim, int rounds) {
 #define GVK_CHAIN(D, GG) case D: return rounds ? chain_kernel<D, GG, 1> : chain_kernel<D, GG, 0>;
     switch (dim) { GVK_CHAIN(32, 8) GVK_CHAIN(64, 16) GVK_CHAIN(96, 8) GVK_CHAIN(128, 16) GVK_CHAIN(256, 16) GVK_CHAIN(512, 32) }
 #undef GVK_CHAIN
+    return nullptr;
+}
+
+ChainKernel pick_group(int dim, int k, int rounds) {
+#define GVK_GROUP(D, GG)                                                                                   \
+    case D:                                                                                                \
+        return k == 1 ? (rounds ? train_group_kernel<D, GG, 1, 1> : train_group_kernel<D, GG, 1, 0>)       \
+                      : (rounds ? train_group_kernel<D, GG, 0, 1> : train_group_kernel<D, GG, 0, 0>);
+    switch (dim) { GVK_GROUP(32, 8) GVK_GROUP(64, 16) GVK_GROUP(96, 8) GVK_GROUP(128, 16) GVK_GROUP(256, 16) GVK_GROUP(512, 32) }
+#undef GVK_GROUP
     return nullptr;
 }
 
@@ -1382,8 +1521,9 @@ int gvk_train_episode_ahead(void *stream, void *chain_stream, int dim, const gvk
                             const gvk_tables *tables, const uint32_t *pairs, const gvk_negative_source *negative, uint32_t first_batch_id,
                             uint32_t batch_id_stride, uint32_t total_batches, int num_batches, float *loss, int batch_size,
                             int num_negative, float negative_weight, void *workspace, size_t workspace_bytes, uint32_t hot_vertex,
-                            uint32_t hot_context, int workspace_batches, int parts, int chain_cap, int pair_launches, int form) {
+                            uint32_t hot_context, int workspace_batches, int parts, int chain_cap, int pair_launches, int group, int form) {
     if (num_batches < 0 || num_batches > workspace_batches) return fail(GVK_EINVAL, "gvk_train_episode_ahead: more batches than the work lists cover");
+    if (group < 1 || parts % group) return fail(GVK_EINVAL, "gvk_train_episode_ahead: group must divide parts");
     int rc = validate_train(dim, optimizer, tables, pairs, negative, loss, batch_size, num_negative);
     if (rc <= 0) return rc;
     rc = validate_hot("gvk_train_episode_ahead", dim, batch_size, num_negative, hot_vertex, hot_context, workspace_batches, parts);
@@ -1399,14 +1539,15 @@ int gvk_train_episode_ahead(void *stream, void *chain_stream, int dim, const gvk
     if (pair_launches <= 0) pair_launches = parts;
     if (parts % pair_launches) return fail(GVK_EINVAL, "gvk_train_episode_ahead: pair_launches must divide parts");
     const bool serialized = (form & GVK_HOT_SERIALIZED) != 0 || g_hot_serialized != 0;
-    if (!serialized && (!chain_stream || chain_stream == stream))
+    const bool grouped = group > 1;  // one stream: a launch = the chains of `group` units + the pairs of the group before (train_group_kernel)
+    if (!serialized && !grouped && (!chain_stream || chain_stream == stream))
         return fail(GVK_EINVAL, "gvk_train_episode_ahead: the chains need a stream of their own (chain_stream)");
     const HotLayout l = hot_layout(dim, batch_size, num_negative, hot_vertex, hot_context, workspace_batches, parts, chain_cap, true);
     if (!workspace || workspace_bytes < l.bytes) return fail(GVK_EINVAL, "gvk_train_episode_ahead: workspace too small (gvk_ahead_plan)");
     const uint32_t round_steps = g_round_steps >= 0 ? (uint32_t)g_round_steps : ((form & GVK_HOT_ROUNDS) ? (uint32_t)GVK_HOT_ROUND_STEPS : 0u);
-    const ChainKernel chain = pick_chain(dim, round_steps != 0);
+    const ChainKernel chain = pick_chain(dim, round_steps != 0), fused = pick_group(dim, num_negative, round_steps != 0);
     const HotPairsKernel pair = pick_hot_pairs(dim, num_negative);
-    if (!chain || !pair) return fail(GVK_EDIM, "gvk_train_episode_ahead: no kernel for this dim");
+    if (!chain || !pair || !fused) return fail(GVK_EDIM, "gvk_train_episode_ahead: no kernel for this dim");
     if (num_batches == 0) return GVK_OK;
     const int lanes = default_lanes(dim);
     char *base = static_cast<char *>(workspace);
@@ -1428,6 +1569,8 @@ int gvk_train_episode_ahead(void *stream, void *chain_stream, int dim, const gvk
     h.round_steps = round_steps;
     h.from = ring, h.to = ring;
     h.slot_stride = l.chains, h.ring_slots = l.ring_slots, h.versioned = 1;
+    h.grouped = grouped, h.published = reinterpret_cast<uint32_t *>(base + l.published);
+    h.start_stride = l.chains + 1, h.entries_stride = l.entry_capacity, h.long_stride = 4 * (1 + l.long_capacity), h.short_stride = 16 * (1 + l.chains);
     const int groups = kHotBlock / lanes;
     h.short_blocks = (int)((l.chains + groups - 1) / groups);
     h.long_blocks = (int)std::min<uint32_t>(l.long_capacity, (uint32_t)kLongBlocks);
@@ -1442,7 +1585,7 @@ int gvk_train_episode_ahead(void *stream, void *chain_stream, int dim, const gvk
         }
         return optimizer->lr * scale;
     };
-    auto chains_of = [&](int u, hipStream_t on) {  // the chains of unit u
+    auto chains_at = [&](int u) {  // the work lists, learning rate and index of unit u
         h.chain_start = reinterpret_cast<const uint32_t *>(base + l.chain_start) + (size_t)u * (l.chains + 1);
         h.entries = reinterpret_cast<const uint32_t *>(base + l.entries) + (size_t)u * l.entry_capacity;
         h.long_list = reinterpret_cast<const uint32_t *>(base + l.long_list) + (size_t)u * 4 * (1 + (size_t)l.long_capacity);
@@ -1450,8 +1593,22 @@ int gvk_train_episode_ahead(void *stream, void *chain_stream, int dim, const gvk
         h.lr = lr_of(u / parts);
         h.log2_decay_positive = (float)std::log2(1.0 - (double)h.lr * a.wd);
         h.log2_decay_negative = (float)std::log2(1.0 - (double)h.lr * a.neg_weight * a.wd);
+        h.unit = (uint32_t)u;
+    };
+    auto chains_of = [&](int u, hipStream_t on) {  // the chains of unit u as a launch of their own
+        chains_at(u);
+        h.units_in_launch = 1;
         a.lr = h.lr;
         hipLaunchKernelGGL(chain, dim3((unsigned)(h.long_blocks + h.short_blocks)), dim3(kHotBlock), 0, on, a, h);
+    };
+    auto pairs_at = [&](int i, int first_part, int count) {  // the pairs of parts [first_part, first_part + count) of batch i: their arguments
+        a.lr = lr_of(i);
+        a.batch_id = first_batch_id + (uint32_t)i * batch_id_stride;
+        a.pairs = pairs + (size_t)i * batch_size * 2;
+        a.slots = reinterpret_cast<const uint32_t *>(base + l.slots) + (size_t)i * batch_size * l.slot_words;
+        a.first_sample = first_part * part_size;
+        a.batch_size = a.first_sample + count * part_size;
+        return (unsigned)(((int64_t)count * part_size * lanes + kBlock - 1) / kBlock);
     };
     auto pairs_of = [&](int i, int first_part, int count, hipStream_t on) {  // the pairs of parts [first_part, first_part + count) of batch i
         if (chains_only && i != num_batches - 1) return;
@@ -1468,7 +1625,25 @@ int gvk_train_episode_ahead(void *stream, void *chain_stream, int dim, const gvk
     const unsigned ring_blocks = (unsigned)(((size_t)l.chains * (size_t)(dim / 4) + kBlock - 1) / kBlock);
     // the hub rows enter the ring at slot 0
     hipLaunchKernelGGL(hub_versions_kernel, dim3(ring_blocks), dim3(kBlock), 0, main, a.vertex, a.context, ring, nullptr, hot_vertex, hot_context, dim, 1);
-    if (serialized) {  // tests: per unit the chains, then the pairs, on one stream — a pure function of the work lists
+    if (grouped && hipMemsetAsync(base + l.published, 0, (size_t)l.chains * 4, main) != hipSuccess) return fail(GVK_EHIP, "gvk_train_episode_ahead: memset failed");
+    auto launch_group = [&](int first_unit, bool with_chains, int pairs_first_unit) {  // the chains of units [first_unit, + group) and the pairs of the group before
+        h.pair_blocks = 0, h.units_in_launch = 0;
+        if (with_chains) chains_at(first_unit), h.units_in_launch = (uint32_t)group;
+        if (pairs_first_unit >= 0 && (!chains_only || pairs_first_unit / parts == num_batches - 1))
+            pairs_at(pairs_first_unit / parts, pairs_first_unit % parts, group), h.pair_blocks = (int)(((int64_t)group * part_size * lanes + kHotBlock - 1) / kHotBlock);
+        const unsigned per_unit = (unsigned)(h.long_blocks + h.short_blocks);
+        const unsigned grid = with_chains ? per_unit * (unsigned)group + (unsigned)h.pair_blocks : per_unit + (unsigned)h.pair_blocks;
+        hipLaunchKernelGGL(fused, dim3(grid), dim3(kHotBlock), 0, main, a, h);
+    };
+    if (serialized && grouped) {  // tests: per group the chains (one launch: the later units wait for the rows of the earlier ones), then its pairs
+        for (int u = 0; u < num_batches * parts; u += group) {
+            launch_group(u, true, -1);
+            launch_group(u, false, u);
+        }
+    } else if (grouped) {
+        launch_group(0, true, -1);
+        for (int u = 0; u < num_batches * parts; u += group) launch_group(u + group, u + group < num_batches * parts, u);
+    } else if (serialized) {  // tests: per unit the chains, then the pairs, on one stream — a pure function of the work lists
         for (int u = 0; u < num_batches * parts; u++) {
             chains_of(u, main);
             pairs_of(u / parts, u % parts, 1, main);

@@ -56,6 +56,7 @@ constexpr int kHubMaxEntriesPerPart = 1000;  // ... and past this many per part 
 constexpr int kHubMaxParts = 32;  // measured on the headline shape at P = 8 (a block's top hub holds 16 % of its samples: the rule asks for 64): 25 / 32 / 40 / 50
                                   // parts end -0.0013 / +0.0008 / +0.0013 / +0.0022 from the reference's loop — past 32 the parts only cost launches
 constexpr int kHubMaxPartsResident = 50;  // cache-resident tables (< 16 MiB): a small partition's chains are feasible up to this many parts (§7.8)
+constexpr int kHubGroup = 2;             // GVX_HUB_GROUP 0: under executor 2 the chains of so many consecutive parts share a launch
 constexpr int kHubLerp = 0;              // GVX_HUB_LERP -1: the pairs read hub rows as their part's chains left them
 constexpr int kHubExecutor = 0;          // GVX_HUB_EXECUTOR -1: one launch per unit carries its pairs and the next unit's chains (gvk_train_episode_hot); 1: the chains as a stream of their own, a batch ahead of the pairs (gvk_train_episode_ahead: measured slower)
 constexpr int kMinEpisodeSample = 20000000;
@@ -190,9 +191,18 @@ struct gvx_solver {
     int hub_lerp_request = -1;      // GVX_HUB_LERP: -1 the rule, 0 / 1: the pairs read hub rows as their unit's chains left them / along the chains' way
     int hub_executor_request = -1;  // GVX_HUB_EXECUTOR: -1 the rule (kHubExecutor; the fused launches where lerp is asked for), 0 / 1
     int hub_pair_launches_request = 0;  // GVX_HUB_PAIR_LAUNCHES: launches the pairs of a batch are trained as under the chain-stream executor (0: one per part)
-    bool hub_ahead() const {  // the chain-stream executor trains the hub rows (a schedule computed by a callback trains batch by batch: fused)
+    int hub_group_request = 0;      // GVX_HUB_GROUP: parts whose chains share a launch under executor 2 (0: kHubGroup)
+    int hub_executor() const {  // 0: a launch per part (gvk_train_episode_hot), 1: the chain stream, 2: the chains of a group of parts per launch (both gvk_train_episode_ahead)
         const int lerp = hub_lerp_request < 0 ? kHubLerp : hub_lerp_request;
-        return (hub_executor_request < 0 ? (lerp ? 0 : kHubExecutor) : hub_executor_request) == 1 && optimizer.schedule != 2 && optimizer.type == GVK_SGD;
+        const int wanted = hub_executor_request < 0 ? (lerp ? 0 : kHubExecutor) : hub_executor_request;
+        return optimizer.schedule != 2 && optimizer.type == GVK_SGD ? wanted : 0;  // a callback's schedule trains batch by batch, a moment optimizer's chains are one task each: fused
+    }
+    bool hub_ahead() const { return hub_executor() != 0; }  // the work lists carry versions and slots (gvk_ahead_build)
+    int hub_group_of(int parts) const {  // the largest divisor of the parts up to the group asked for
+        if (hub_executor() != 2) return 1;
+        int group = std::max(hub_group_request > 0 ? hub_group_request : kHubGroup, 1);
+        while (group > 1 && parts % group) group--;
+        return group;
     }
     int hub_chunk = kHubChunk;      // batches whose work lists are built at once (fewer where memory is short)
     int hub_max_parts = kHubMaxParts;  // most parts a batch is trained as (kHubMaxPartsResident for cache-resident tables)
@@ -608,7 +618,11 @@ extern "C" int gvx_solver_set(gvx_solver *s, int option, int64_t value) {
         s->hub_lerp_request = (int)value;
         return GVK_OK;
     }
-    if (option == GVX_HUB_EXECUTOR && value >= -1 && value <= 1) {
+    if (option == GVX_HUB_GROUP && value >= 0 && value <= 127) {
+        s->hub_group_request = (int)value;
+        return GVK_OK;
+    }
+    if (option == GVX_HUB_EXECUTOR && value >= -1 && value <= 2) {
         s->hub_executor_request = (int)value;
         return GVK_OK;
     }
@@ -1831,8 +1845,12 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int
             auto build = [&](int at) -> int {
                 const int slot = (int)(w.chunks_built & 1), m = std::min(chunk, n - at);
                 if (w.lists_trained_valid[slot]) HIP_TRY(hipStreamWaitEvent(w.lists, w.lists_trained[slot], 0));
-                GVK_TRY((ahead ? gvk_ahead_build : gvk_hot_build)(w.lists, dim, w.hub_workspaces[slot], w.hub_workspace_bytes, pool + (size_t)(done + at) * B * 2, B, m,
-                                                                  num_negative, &neg, (uint32_t)(first + (uint64_t)at * W), (uint32_t)W, kv, kc, parts, chain_cap));
+                if (ahead)
+                    GVK_TRY(gvk_ahead_build(w.lists, dim, w.hub_workspaces[slot], w.hub_workspace_bytes, pool + (size_t)(done + at) * B * 2, B, m, num_negative,
+                                            &neg, (uint32_t)(first + (uint64_t)at * W), (uint32_t)W, kv, kc, parts, chain_cap, hub_group_of(parts)));
+                else
+                    GVK_TRY(gvk_hot_build(w.lists, dim, w.hub_workspaces[slot], w.hub_workspace_bytes, pool + (size_t)(done + at) * B * 2, B, m, num_negative,
+                                          &neg, (uint32_t)(first + (uint64_t)at * W), (uint32_t)W, kv, kc, parts, chain_cap));
                 HIP_TRY(hipEventRecord(w.lists_built[slot], w.lists));
                 w.chunks_built++;
                 return GVK_OK;
@@ -1848,7 +1866,8 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int
                 if (ahead)
                     GVK_TRY(gvk_train_episode_ahead(w.compute, w.chains, dim, &ob, optimizer.schedule == 1, &t, batches, &neg, (uint32_t)id, (uint32_t)W,
                                                     (uint32_t)num_batch, m, w.loss, B, num_negative, config.negative_weight, w.hub_workspaces[slot],
-                                                    w.hub_workspace_bytes, kv, kc, m, parts, chain_cap, pair_launches, rounds ? GVK_HOT_ROUNDS : 0));
+                                                    w.hub_workspace_bytes, kv, kc, m, parts, chain_cap, pair_launches, hub_group_of(parts),
+                                                    rounds ? GVK_HOT_ROUNDS : 0));
                 else
                     GVK_TRY(gvk_train_episode_hot(w.compute, dim, &ob, optimizer.schedule == 1, &t, batches, &neg, (uint32_t)id, (uint32_t)W,
                                                   (uint32_t)num_batch, m, w.loss, B, num_negative, config.negative_weight,

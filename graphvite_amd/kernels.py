@@ -213,20 +213,20 @@ class HipKernels(object):
         return n.value
 
     def ahead_build(self, dim, workspace, pool, batch_size, num_batch, num_negative, table, seed, first_batch_id, hot_vertex,
-                    hot_context, batch_id_stride=1, parts=1, chain_cap=0):
+                    hot_context, batch_id_stride=1, parts=1, chain_cap=0, group=1):
         """gvk_ahead_build: the work lists of gvk_hot_build + the hub rows' versions and the slots that name them."""
         dev = pool.device
         _need(pool, torch.int32, "pool", dev)
         neg = self._negative(None, table, seed, dev)
         rc = self.lib.gvk_ahead_build(self._stream(pool), dim, _ptr(workspace), workspace.numel(), _ptr(pool), batch_size, num_batch,
                                       num_negative, C.byref(neg), first_batch_id, batch_id_stride, hot_vertex, hot_context, parts,
-                                      chain_cap)
+                                      chain_cap, group)
         _lib.check(rc, "gvk_ahead_build")
 
     def train_episode_ahead(self, vertex, context, pool, loss, optimizer, num_negative, negative_weight, table, seed,
                             first_batch_id, total_batches, num_batches, batch_size, workspace, hot_vertex, hot_context,
                             workspace_batches=None, batch_id_stride=1, serialized=False, parts=1, chain_cap=0, pair_launches=0,
-                            rounds=False, chain_stream=None):
+                            rounds=False, chain_stream=None, group=1):
         """gvk_train_episode_ahead: the chains on `chain_stream` (a torch.cuda.Stream; made once per device when not given), a batch
         ahead of the pairs on the current stream."""
         dev = vertex.device
@@ -236,7 +236,7 @@ class HipKernels(object):
         neg = self._negative(None, table, seed, dev)
         opt = optimizer.c_struct()
         side = 0
-        if not serialized:
+        if not serialized and group == 1:
             if chain_stream is None:
                 streams = self.__dict__.setdefault("_chain_streams", {})
                 chain_stream = streams.get(dev)
@@ -248,7 +248,7 @@ class HipKernels(object):
                                               first_batch_id, batch_id_stride, total_batches, num_batches, _ptr(loss), batch_size,
                                               num_negative, negative_weight, _ptr(workspace), workspace.numel(), hot_vertex,
                                               hot_context, num_batches if workspace_batches is None else workspace_batches,
-                                              parts, chain_cap, pair_launches,
+                                              parts, chain_cap, pair_launches, group,
                                               (self.HOT_SERIALIZED if serialized else 0) | (self.HOT_ROUNDS if rounds else 0))
         _lib.check(rc, "gvk_train_episode_ahead")
 

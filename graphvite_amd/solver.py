@@ -251,9 +251,11 @@ class GraphSolver(object):
         self.hub_rounds = None  # GVX_HUB_ROUNDS (gvx.h): None = the rule, False / True: long chains in one round / in rounds
         self.hub_chain_cap = 0  # GVX_HUB_CHAIN_CAP (gvx.h): 0 = the kernels' default
         # GVX_HUB_EXECUTOR (gvx.h): None = the rule (the chains as a stream of their own, a batch ahead of the pairs), "fused" = one
-        # launch per part of a batch carries its pairs and the next part's chains, "ahead" = the chain stream
+        # launch per part of a batch carries its pairs and the next part's chains, "ahead" = the chain stream, "grouped" = one launch for the
+        # chains of hub_group parts and the pairs of the parts before them
         self.hub_executor = os.environ.get("GVX_HUB_EXECUTOR") or None
         self.hub_pair_launches = int(os.environ.get("GVX_HUB_PAIR_LAUNCHES", "0"))  # GVX_HUB_PAIR_LAUNCHES: 0 = one launch per part
+        self.hub_group = int(os.environ.get("GVX_HUB_GROUP", "0"))  # GVX_HUB_GROUP: parts whose chains share a launch under "grouped" (0 = the rule's)
         if fidelity is not auto and fidelity not in ("auto", "throughput", "reference"):
             raise ValueError("fidelity must be auto, 'throughput' or 'reference', not %r" % (fidelity,))
         self.fidelity = "auto" if fidelity is auto else fidelity  # GVX_FIDELITY (gvx.h)
@@ -298,7 +300,8 @@ class GraphSolver(object):
                               (_lib.GVX_HUB_LERP, -1 if self.hub_lerp is None else int(bool(self.hub_lerp))),
                               (_lib.GVX_HUB_ROUNDS, -1 if self.hub_rounds is None else int(bool(self.hub_rounds))),
                               (_lib.GVX_HUB_CHAIN_CAP, int(self.hub_chain_cap)),
-                              (_lib.GVX_HUB_EXECUTOR, {None: -1, "fused": 0, "ahead": 1}[self.hub_executor]),
+                              (_lib.GVX_HUB_EXECUTOR, {None: -1, "fused": 0, "ahead": 1, "grouped": 2}[self.hub_executor]),
+                              (_lib.GVX_HUB_GROUP, int(self.hub_group)),
                               (_lib.GVX_HUB_PAIR_LAUNCHES, int(self.hub_pair_launches)),
                               (_lib.GVX_FIDELITY, {"auto": -1, "throughput": 0, "reference": 1}[self.fidelity])):
             self._check(self._lib.gvx_solver_set(self._handle, option, value), "GraphSolver")

@@ -229,18 +229,23 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
  *                    tables hold the hub rows again.  pair_launches (a divisor of parts; 0 = parts): launches the pairs of
  *                    a batch are trained as.  form: GVK_HOT_SERIALIZED (chain_stream unused: per unit the chains, then the
  *                    pairs, on `stream` — the function of the work lists the oracle restates), GVK_HOT_ROUNDS.
+ * group (a divisor of parts, the same in build and train; 1 = the chain stream above): group > 1 is a third executor on ONE stream —
+ * a launch carries the chains of `group` consecutive units and the pairs of the group before it (train_group_kernel): the chain of a
+ * later unit of the group starts as soon as its own row has been published by the chain of the unit before (a workgroup of the same
+ * launch; coherent loads and stores, a flag per row), and reads the partners that are hub rows as the GROUP found them — up to
+ * group - 1 units older than gvk_train_episode_hot reads them.  chain_stream is unused then.
  * parts <= 127 (a slot is one byte); at most 32767 hub rows per table and 2^30 rows per table (fields of a work-list entry). */
 int gvk_ahead_plan(int dim, int batch_size, int num_negative, uint32_t hot_vertex, uint32_t hot_context, int num_batch, int parts,
                    int chain_cap, size_t *bytes);
 int gvk_ahead_build(void *stream, int dim, void *workspace, size_t workspace_bytes, const uint32_t *pool, int batch_size,
                     int num_batch, int num_negative, const gvk_negative_source *negative, uint32_t first_batch_id,
-                    uint32_t batch_id_stride, uint32_t hot_vertex, uint32_t hot_context, int parts, int chain_cap);
+                    uint32_t batch_id_stride, uint32_t hot_vertex, uint32_t hot_context, int parts, int chain_cap, int group);
 int gvk_train_episode_ahead(void *stream, void *chain_stream, int dim, const gvk_optimizer *optimizer, int linear_schedule,
                             const gvk_tables *tables, const uint32_t *pairs, const gvk_negative_source *negative,
                             uint32_t first_batch_id, uint32_t batch_id_stride, uint32_t total_batches, int num_batches, float *loss,
                             int batch_size, int num_negative, float negative_weight, void *workspace, size_t workspace_bytes,
                             uint32_t hot_vertex, uint32_t hot_context, int workspace_batches, int parts, int chain_cap,
-                            int pair_launches, int form);
+                            int pair_launches, int group, int form);
 /* the events gvk_train_episode_ahead keeps for a chain stream: to be released before the stream is destroyed */
 void gvk_ahead_release(void *chain_stream);
 

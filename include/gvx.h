@@ -180,9 +180,12 @@ void gvx_solver_destroy(gvx_solver *s);
  * (gvk.h gvk_train_episode_ahead; the fused launches where GVX_HUB_LERP 1 is asked for or a callback computes the schedule);
  * 0: one launch per unit carries its pairs and the next unit's chains (gvk_train_episode_hot); 1: the chain stream.
  * GVX_HUB_PAIR_LAUNCHES 0 (default): under the chain stream the pairs of a batch are one launch per part; N (a divisor of the
- * parts, else ignored): N launches per batch. */
+ * parts, else ignored): N launches per batch.
+ * GVX_HUB_EXECUTOR 2: one stream, a launch = the chains of GVX_HUB_GROUP consecutive parts + the pairs of the parts before them
+ * (gvk.h `group`; GVX_HUB_GROUP: 0 = the rule's, N = a divisor of the parts, else the largest divisor below it). */
 #define GVX_HUB_EXECUTOR 12
 #define GVX_HUB_PAIR_LAUNCHES 13
+#define GVX_HUB_GROUP 14
 int gvx_solver_set(gvx_solver *s, int option, int64_t value);
 
 /* The graph is borrowed until the next build / destroy (solver.h:289).  num_partition / episode_size: GVX_AUTO. */

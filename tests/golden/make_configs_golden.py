@@ -57,6 +57,10 @@ JOBS = {
     # with exponent 2.5 (largest degree 19 115; the real graph's: 28 754) — the reference's per-edge tables (graph.cuh:656-677) hold
     # sum deg^2 = 2.3e9 entries = 18 GB here; on the exponent-2.3 graph of yt_deepwalk they would hold 8.3e9 = 66 GB, more than this host has
     "yt_p4_node2vec": ("youtube_n2v", 128, "node2vec", dict(augmentation_step=5, shuffle_base=1, p=0.25, q=0.25, **WALK), 4, 30, 100, None),
+    # two graphs between the headline shape (its largest vertex takes 1.0 % of the degree: long chains in one round) and the held-out one (6.8 %:
+    # rounds), either side of the 2 % at which configure() switches rounds on (gvx_engine.cpp kHubRoundShare): 1.8 % and 2.5 %
+    "mid18_p1": ("mid18", 128, "LINE", dict(augmentation_step=1), 1, 0, 42, None),
+    "mid25_p1": ("mid25", 128, "LINE", dict(augmentation_step=1), 1, 0, 42, None),
     "held_p1": ("held_out", 128, "LINE", dict(augmentation_step=1), 1, 0, 42, None),
     "held_p8_e8": ("held_out", 128, "LINE", dict(augmentation_step=1), 8, 8, 42, None),
 }
@@ -72,6 +76,10 @@ def graph_edges(name):
         return synthetic.hub_community_edges(num_vertex=1138499, num_edge=4945382, gamma=2.5, num_community=400, p_in=0.7, seed=1024)
     if name == "headline":
         return synthetic.power_law_edges(1000000, 10000000, seed=1024)
+    if name == "mid18":
+        return synthetic.power_law_edges(1200000, 11000000, gamma=2.2, seed=777)
+    if name == "mid25":
+        return synthetic.power_law_edges(1200000, 11000000, gamma=2.15, seed=778)
     if name == "held_out":
         return synthetic.power_law_edges(1500000, 12000000, gamma=2.0, seed=4711)
     raise KeyError(name)

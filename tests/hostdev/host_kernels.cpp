@@ -389,7 +389,7 @@ int gvk_ahead_plan(int dim, int batch_size, int num_negative, uint32_t hot_verte
 
 int gvk_ahead_build(void *stream, int dim, void *workspace, size_t workspace_bytes, const uint32_t *pool, int batch_size, int num_batch,
                     int num_negative, const gvk_negative_source *negative, uint32_t first_batch_id, uint32_t batch_id_stride,
-                    uint32_t hot_vertex, uint32_t hot_context, int parts, int chain_cap) {
+                    uint32_t hot_vertex, uint32_t hot_context, int parts, int chain_cap, int) {
     return gvk_hot_build(stream, dim, workspace, workspace_bytes, pool, batch_size, num_batch, num_negative, negative, first_batch_id,
                          batch_id_stride, hot_vertex, hot_context, parts, chain_cap);
 }
@@ -400,7 +400,7 @@ int gvk_train_episode_ahead(void *stream, void *, int dim, const gvk_optimizer *
                             const uint32_t *pairs, const gvk_negative_source *negative, uint32_t first_batch_id, uint32_t batch_id_stride,
                             uint32_t total_batches, int num_batches, float *loss, int batch_size, int num_negative, float negative_weight,
                             void *workspace, size_t workspace_bytes, uint32_t hot_vertex, uint32_t hot_context, int workspace_batches,
-                            int parts, int chain_cap, int, int form) {
+                            int parts, int chain_cap, int, int, int form) {
     return gvk_train_episode_hot(stream, dim, optimizer, linear_schedule, tables, pairs, negative, first_batch_id, batch_id_stride,
                                  total_batches, num_batches, loss, batch_size, num_negative, negative_weight, workspace, workspace_bytes,
                                  hot_vertex, hot_context, workspace_batches, parts, chain_cap, form);

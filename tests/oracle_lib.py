@@ -44,6 +44,13 @@ class Oracle(object):
                                                                          C.c_float, C.c_float, C.c_float, _f32p]
         lib.gvo_hot_lists.restype = C.c_size_t
         lib.gvo_hot_lists.argtypes = [_u32p, _u32p, C.c_int, C.c_int, C.c_uint32, C.c_uint32, _u32p, _u32p]
+        lib.gvo_hot_unit_chains.restype = C.c_int
+        lib.gvo_hot_unit_chains.argtypes = [C.c_int, _f32p, _f32p, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, _u32p, _u32p,
+                                            C.c_uint32, C.c_uint32, C.c_int]
+        lib.gvo_train_pairs_hot.restype = C.c_int
+        lib.gvo_train_pairs_hot.argtypes = [C.c_int, _f32p, _f32p, _u32p, _u32p, _f32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                            C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.gvo_set_hub_snapshot.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         lib.gvo_train_hot_moments.restype = C.c_int
         lib.gvo_train_hot_moments.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 6 + [_u32p, _u32p, _f32p, C.c_int, C.c_int, C.c_float,
                                                                                      C.c_float, C.c_float, _f32p, C.c_uint32, C.c_uint32,
@@ -151,6 +158,41 @@ class Oracle(object):
                                     hot_context, np.ascontiguousarray(chain_start, np.uint32), entries, cap, max_tasks, int(lerp))
         assert rc == 0
         return loss[:B]
+
+    def train_hot_group(self, vertex, context, batch, negatives, lr, wd, negative_weight, hot_vertex, hot_context, chain_starts, entries,
+                        cap, max_tasks=0, round_steps=0):
+        """One GROUP of units in the serialized form of the grouped executor (gvk_train_episode_ahead with group > 1): the chains of the
+        group's units one unit after the other — every chain from its own row as the unit before left it, its hub PARTNERS as the group
+        found them —, then the pairs of every unit with the hub rows as that unit's chains left them.  batch / negatives: the group's
+        samples, equal units; chain_starts / entries: per unit.  In place."""
+        self.lib.gvo_set_long_task(0)
+        self.lib.gvo_set_round_steps(int(round_steps))
+        units = len(chain_starts)
+        n = batch.shape[0] // units
+        k = negatives.size // batch.shape[0]
+        dim = vertex.shape[1]
+        snap_v, snap_c = vertex[:hot_vertex].copy(), context[:hot_context].copy()
+        self.lib.gvo_set_hub_snapshot(snap_v.ctypes.data, hot_vertex, snap_c.ctypes.data, hot_context)
+        after = []
+        try:
+            for u in range(units):
+                e = np.ascontiguousarray(entries[u], np.uint32)
+                rc = self.lib.gvo_hot_unit_chains(dim, vertex, context, lr, wd, negative_weight, hot_vertex, hot_context,
+                                                  np.ascontiguousarray(chain_starts[u], np.uint32), e if e.size else np.zeros(1, np.uint32), cap, max_tasks, k)
+                assert rc == 0
+                after.append((vertex[:hot_vertex].copy(), context[:hot_context].copy()))
+        finally:
+            self.lib.gvo_set_hub_snapshot(None, 0, None, 0)
+        loss = np.zeros(batch.shape[0], np.float32)
+        for u in range(units):  # the pairs of unit u read the hub rows as ITS chains left them
+            vertex[:hot_vertex], context[:hot_context] = after[u]
+            part, neg = np.ascontiguousarray(batch[u * n:(u + 1) * n].reshape(-1)), np.ascontiguousarray(negatives[u * n:(u + 1) * n].reshape(-1))
+            out = np.zeros(n, np.float32)
+            rc = self.lib.gvo_train_pairs_hot(dim, vertex, context, part, neg, out, n, k, lr, wd, negative_weight, hot_vertex, hot_context, None, None)
+            assert rc == 0
+            loss[u * n:(u + 1) * n] = out
+        vertex[:hot_vertex], context[:hot_context] = after[-1]
+        return loss
 
     def train_hot_moments(self, vertex, context, batch, negatives, lr, wd, negative_weight, optimizer, moments, hp, hot_vertex,
                           hot_context, chain_start, entries):

@@ -496,3 +496,74 @@ def test_moment_chains_match_the_oracle(hip, oracle, name, dim, k):
         ends.append((tv.cpu().numpy()[:kv], tc.cpu().numpy()[:kc]))
     for (a, b), start in zip(zip(*ends), (v[:kv], c[:kc])):
         assert np.isfinite(b).all() and np.linalg.norm(a - b) < 0.5 * np.linalg.norm(a - start)
+
+
+@pytest.mark.parametrize("dim,k,group,parts,rounds", [(128, 1, 2, 4, 0), (128, 1, 4, 4, 0), (128, 2, 2, 6, 0), (96, 1, 3, 3, 0), (32, 1, 2, 4, 0), (64, 1, 2, 2, 4),
+                                                      (256, 1, 2, 4, 0), (512, 1, 4, 4, 4), (128, 1, 2, 4, 4)])
+def test_grouped_chains_match_the_oracle(hip, oracle, dim, k, group, parts, rounds):
+    """gvk_train_episode_ahead with group > 1: ONE launch trains the chains of `group` consecutive units — the chain of a later unit
+    waits for its own row, published by the chain of the unit before (a workgroup of the same launch, maybe on another XCD: coherent
+    stores, a flag per row) and reads its hub partners as the group found them.  The serialized form (per group: that launch, then
+    its pairs) against the oracle's restatement of exactly that (Oracle.train_hot_group) on the device's own work lists: hub rows
+    elementwise — a stale or half-stored row would show here —, and the product form (chains of group G + 1 beside the pairs of group
+    G) stays with it over several batches, run after run the same bits for the chains."""
+    hip.set_tuning(12, rounds if rounds else -1)  # GVK_TUNE_ROUND_STEPS
+    try:
+        rng = np.random.default_rng(dim + 7 * group)
+        N, B, kv, kc = 1 << 16, 600 * parts, 24, 40
+        v = (rng.uniform(-0.5, 0.5, (N, dim)) * 0.05).astype(np.float32)
+        c = (rng.uniform(-0.5, 0.5, (N, dim)) * 0.05).astype(np.float32)
+        pool, w = hub_case(rng, N, B, 1, kv, kc)
+        table = negative_table(w, False)
+        opt = K.OptimizerSpec("SGD", 0.025, 0.005)
+        dpool = torch.from_numpy(pool.view(np.int32)).to(DEV)
+        ex = Executor(hip, "ahead")
+        ws = torch.zeros(hip.ahead_plan(dim, B, k, kv, kc, 1, parts), dtype=torch.uint8, device=DEV)
+        hip.ahead_build(dim, ws, dpool, B, 1, k, table, SEED, FIRST_ID, kv, kc, parts=parts, group=group)
+        torch.cuda.synchronize()
+        chains = kv + kc
+        cap_entries, entry_capacity, off = layout(B, k, chains, 1, 0, parts)
+        raw = ws.cpu().numpy()
+        starts = raw[:parts * (chains + 1) * 4].view(np.uint32).reshape(parts, chains + 1)
+        entries = ex.ids(raw[off:off + parts * entry_capacity * 4].view(np.uint32).reshape(parts, entry_capacity))
+        assert int(np.diff(starts.astype(np.int64), axis=1).max()) > cap_entries  # long chains: tasks side by side, composed
+        negs = torch.zeros(B * k, dtype=torch.int32, device=DEV)
+        hip.negative_draw(table, SEED, FIRST_ID, negs, B, k)
+        nb = negs.cpu().numpy().view(np.uint32).reshape(B, k)
+        lr = oracle.lr(0.025, True, FIRST_ID, TOTAL)
+        ov, oc = v.copy(), c.copy()
+        n = B // parts
+        for g0 in range(0, parts, group):
+            lo, hi = g0 * n, (g0 + group) * n
+            oracle.train_hot_group(ov, oc, pool[lo:hi], nb[lo:hi], lr, 0.005, 5.0, kv, kc, [starts[u] for u in range(g0, g0 + group)],
+                                   [entries[u, :starts[u, -1]] for u in range(g0, g0 + group)], cap_entries, max_tasks=HOT_BLOCK // LANES[dim], round_steps=rounds)
+        hubs = []
+        for repeat in range(3):  # the hand-off between the workgroups of a launch is a race when it is wrong: several runs, the same bits
+            tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
+            loss = torch.zeros(B, device=DEV)
+            hip.train_episode_ahead(tv, tc, dpool, loss, opt, k, 5.0, table, SEED, FIRST_ID, TOTAL, 1, B, ws, kv, kc, serialized=True, parts=parts, group=group)
+            torch.cuda.synchronize()
+            sv, sc = tv.cpu().numpy(), tc.cpu().numpy()
+            # hub rows: the oracle's; other rows are trained Hogwild inside a unit and are read by the chains of later groups (a chain that
+            # missed its row's hand-off would be off by a unit's updates: several per cent of the row)
+            np.testing.assert_allclose(sv[:kv], ov[:kv], rtol=5e-3, atol=5e-4)
+            np.testing.assert_allclose(sc[:kc], oc[:kc], rtol=5e-3, atol=5e-4)
+            assert np.linalg.norm(sv[:kv] - ov[:kv]) < 0.02 * np.linalg.norm(ov[:kv] - v[:kv])
+            hubs.append((sv[:kv].copy(), sc[:kc].copy()))
+        assert np.linalg.norm(hubs[0][0] - v[:kv]) > 0
+        # the product form over three batches: hub rows end near where the serialized form leaves them
+        pool3, _ = hub_case(rng, N, B, 3, kv, kc)
+        dpool3 = torch.from_numpy(pool3.view(np.int32)).to(DEV)
+        ws3 = torch.zeros(hip.ahead_plan(dim, B, k, kv, kc, 3, parts), dtype=torch.uint8, device=DEV)
+        hip.ahead_build(dim, ws3, dpool3, B, 3, k, table, SEED, FIRST_ID, kv, kc, parts=parts, group=group)
+        ends = []
+        for serialized in (True, False):
+            tv, tc = torch.from_numpy(v).to(DEV), torch.from_numpy(c).to(DEV)
+            hip.train_episode_ahead(tv, tc, dpool3, loss, opt, k, 5.0, table, SEED, FIRST_ID, TOTAL, 3, B, ws3, kv, kc, serialized=serialized, parts=parts,
+                                    group=group)
+            torch.cuda.synchronize()
+            ends.append((tv.cpu().numpy()[:kv], tc.cpu().numpy()[:kc]))
+        for (a, b), start in zip(zip(*ends), (v[:kv], c[:kc])):
+            assert np.isfinite(b).all() and np.linalg.norm(a - b) < 0.5 * np.linalg.norm(a - start)
+    finally:
+        hip.set_tuning(12, -1)
