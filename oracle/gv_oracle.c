@@ -305,6 +305,10 @@ int gvo_hot_unit_chains(int dim, float *vertex, float *context, float lr, float 
  * samples that write the same row the later one's row stays: what Hogwild inside a launch does to rows that are not hub rows. */
 static int gvo_pairs_concurrent = 0;
 void gvo_set_pairs_concurrent(int on) { gvo_pairs_concurrent = on != 0; }
+/* experiment: with before_vertex / before_context given, every sample reads hub rows at this fixed place of the chains' way (0 = as the unit
+ * found them) instead of at its own place in the unit; negative: off */
+static float gvo_pairs_at = -1;
+void gvo_set_pairs_at(float at) { gvo_pairs_at = at; }
 
 typedef struct {
     uint64_t *keys;   /* (table << 32 | row) + 1; 0 = empty */
@@ -351,7 +355,7 @@ int gvo_train_pairs_hot(int dim, float *vertex, float *context, const uint32_t *
         if (!seen.keys || !seen.slots || !seen.rows) return -1;
     }
     for (int s = 0; s < batch_size; s++) {
-        const float at = (s + 0.5f) / batch_size;
+        const float at = gvo_pairs_at >= 0 ? gvo_pairs_at : (s + 0.5f) / batch_size;
         const size_t head = batch[2 * s + 1];
         if (head < kv && before_vertex) {
             for (int i = 0; i < dim; i++) buf[i] = before_vertex[head * dim + i] + at * (vertex[head * dim + i] - before_vertex[head * dim + i]);
@@ -441,6 +445,11 @@ int gvo_train_hot(int dim, float *vertex, float *context, const uint32_t *batch,
  * this splits by row), the entries in list order, partner rows — hub rows included — as the unit found them.  Then the unit's
  * pairs: every sample in order as gvo_train, but a hub row and its moment rows are read (a sample's own steps move its copies)
  * and never written. */
+/* Executor-simulator experiment (round 6): 1 = the pairs of a unit read a hub row as the unit FOUND it (before its chains) instead of as
+ * its chains left it — a sample then computes its partner's update from the hub row without the hub's own step for that very sample. */
+static int gvo_pairs_read_before = 0;
+void gvo_set_pairs_read_before(int on) { gvo_pairs_read_before = on != 0; }
+
 int gvo_train_hot_moments(int dim, int type, float *vertex, float *context, float *vm1, float *cm1, float *vm2, float *cm2,
                           const uint32_t *batch, const uint32_t *negatives, float *loss, int batch_size, int k, float lr, float wd,
                           float negative_weight, const float *hp, uint32_t kv, uint32_t kc, const uint32_t *chain_start,
@@ -472,7 +481,7 @@ int gvo_train_hot_moments(int dim, int type, float *vertex, float *context, floa
     for (int s = 0; s < batch_size; s++) {
         const size_t head = batch[2 * s + 1];
         const int hub_head = head < kv;
-        memcpy(v, vertex + head * dim, sizeof(float) * dim);
+        memcpy(v, hub_head && gvo_pairs_read_before ? v0 + head * dim : vertex + head * dim, sizeof(float) * dim);
         float *pm1 = vm1 + head * dim, *pm2 = type == GVO_ADAM ? vm2 + head * dim : NULL;
         if (hub_head) {  /* the hub head's moment rows: copies */
             memcpy(tv1, pm1, sizeof(float) * dim), pm1 = tv1;
@@ -487,7 +496,7 @@ int gvo_train_hot_moments(int dim, int type, float *vertex, float *context, floa
             float *c = context + tail * dim, *q1 = cm1 + tail * dim, *q2 = type == GVO_ADAM ? cm2 + tail * dim : NULL;
             if (tail < kc) {  /* a hub target: copies, carried over when the next target is the same row */
                 if (!(have && tail == last)) {
-                    memcpy(hub, c, sizeof(float) * dim), memcpy(h1, q1, sizeof(float) * dim);
+                    memcpy(hub, gvo_pairs_read_before ? c0 + tail * dim : c, sizeof(float) * dim), memcpy(h1, q1, sizeof(float) * dim);
                     if (q2) memcpy(h2, q2, sizeof(float) * dim);
                 }
                 c = hub, q1 = h1, q2 = q2 ? h2 : NULL;

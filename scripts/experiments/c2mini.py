@@ -51,7 +51,8 @@ for config in extra.get("configs", "hub=0").split(";"):
                                   pair_order=kw.get("order", "sampled") if kw.get("order", "sampled") != "auto" else gv.auto)
         s.hub_parts, s.hub_chain_cap = int(kw.get("parts", 0)), int(kw.get("cap", 0))
         s.hub_lerp = None if "lerp" not in kw else bool(int(kw["lerp"]))
-        s.build(g, batch_size=B, episode_size=int(kw.get("episode", 20)), num_partition=int(kw.get("partitions", 0)))
+        optimizer = {"sgd": lambda: gv.auto, "adam": lambda: gv.optimizer.Adam(1e-3, 0.005), "momentum": lambda: gv.optimizer.Momentum(0.025, 0.005, 0.9)}[kw.get("opt", "sgd")]()
+        s.build(g, optimizer=optimizer, batch_size=B, episode_size=int(kw.get("episode", 20)), num_partition=int(kw.get("partitions", 0)))
         s.train(model="LINE", num_epoch=int(extra.get("epochs", 50)), augmentation_step=1, log_frequency=1 << 30)
         aucs.append(link_prediction_auc(s.vertex_embeddings, s.context_embeddings, name2id[H[keep]], name2id[T[keep]], Y[keep]))
         print("    seed %d: AUC %.6f (%d batches, %.0f s)" % (seed, aucs[-1], s.batch_id, time.time() - t0), flush=True)

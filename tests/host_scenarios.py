@@ -148,21 +148,17 @@ def hub_row_rules():
     s.build(g, batch_size=1000, episode_size=4, num_partition=2)
     s.train(model="DeepWalk", num_epoch=1, augmentation_step=2, log_frequency=1 << 30)
     assert 0 < s.hub_rows <= g.num_vertex // 2  # per partition (1000 rows each)
-    # moment optimizers have no chains: by default every row is trained pair by pair (and the log says so), asked for
-    # explicitly — hub_rows / fidelity="reference" — it is an error
+    # the moment optimizers have chains of their own (one sequential task per hub row: gvk_chains.hip train_moment_chains): hub rows by the
+    # same rule, asked for explicitly honoured, fidelity="throughput" turns them off
     s = gv.solver.GraphSolver(32, num_sampler_per_worker=2, seed=1)
     s.build(g, optimizer=gv.optimizer.Adam(1e-3), batch_size=1000, episode_size=4)
     s.train(model="DeepWalk", num_epoch=1, augmentation_step=2, log_frequency=1 << 30)
-    assert s.hub_rows == 0
-    for kw in (dict(hub_rows=50), dict(fidelity="reference")):
+    assert s.hub_rows > 0
+    for kw, rows in ((dict(hub_rows=50), 50), (dict(fidelity="reference"), None), (dict(fidelity="throughput"), 0)):
         s = gv.solver.GraphSolver(32, num_sampler_per_worker=2, seed=1, **kw)
         s.build(g, optimizer=gv.optimizer.Adam(1e-3), batch_size=1000, episode_size=4)
-        try:
-            s.train(model="LINE", num_epoch=1, log_frequency=1 << 30)
-        except ValueError as e:
-            assert "chains" in str(e)
-        else:
-            raise AssertionError("chains were promised for Adam")
+        s.train(model="LINE", num_epoch=1, log_frequency=1 << 30)
+        assert (s.hub_rows > 0) if rows is None else (s.hub_rows == rows), (kw, s.hub_rows)
     # a schedule computed by a callback: chains all the same (a call per batch, its learning rate from the host)
     tables = {}
     for name, schedule in (("linear", "linear"), ("callback", lambda batch_id, num_batch: max(1 - batch_id / num_batch, 1e-4))):

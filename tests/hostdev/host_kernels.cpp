@@ -32,6 +32,11 @@ void gvo_set_pairs_concurrent(int on);
 void gvo_set_long_task(uint32_t entries);
 void gvo_set_round_steps(uint32_t steps);
 void gvo_set_hub_snapshot(const float *vertex_hub_rows, uint32_t kv, const float *context_hub_rows, uint32_t kc);
+void gvo_set_pairs_read_before(int on);
+void gvo_set_pairs_at(float at);
+int gvo_train_hot_moments(int dim, int type, float *vertex, float *context, float *vm1, float *cm1, float *vm2, float *cm2, const uint32_t *batch,
+                          const uint32_t *negatives, float *loss, int batch_size, int k, float lr, float wd, float negative_weight, const float *hp,
+                          uint32_t kv, uint32_t kc, const uint32_t *chain_start, const uint32_t *entries);
 int gvo_train_pairs_hot(int dim, float *vertex, float *context, const uint32_t *batch, const uint32_t *negatives, float *loss,
                         int batch_size, int k, float lr, float wd, float negative_weight, uint32_t kv, uint32_t kc,
                         const float *before_vertex, const float *before_context);
@@ -247,6 +252,30 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     if (!executor || !*executor || !strcmp(executor, "sequential"))
         return gvk_train_episode(stream, dim, optimizer, linear_schedule, tables, pairs, negative, first_batch_id, batch_id_stride,
                                  total_batches, num_batches, loss, batch_size, num_negative, negative_weight);
+    gvo_set_pairs_read_before(getenv("GVH_PAIRS_READ") && !strcmp(getenv("GVH_PAIRS_READ"), "before"));  // experiment: hub rows as the unit found them
+    gvo_set_pairs_at(getenv("GVH_PAIRS_AT") ? (float)atof(getenv("GVH_PAIRS_AT")) : -1.0f);  // ... SGD: with lerp, at this fixed place of the chains' way
+    if (optimizer->type != GVK_SGD) {
+        // a moment optimizer (round 6): every unit in the serialized form of its chains (gvo_train_hot_moments: one sequential task per hub
+        // row from the unit's start state, then the unit's pairs in sample order) — what the unit scheme itself costs, without Hogwild
+        const int n = batch_size / parts, k = num_negative;
+        std::vector<uint32_t> start(hot_vertex + hot_context + 1), entries(2 * (size_t)(k + 1) * n + 1), negatives((size_t)batch_size * std::max(k, 1));
+        const float hp[3] = {optimizer->hp0, optimizer->hp1, optimizer->epsilon};
+        for (int i = 0; i < num_batches; i++) {
+            const uint32_t id = first_batch_id + (uint32_t)i * batch_id_stride;
+            if (negative->classes) gvk_negative_draw_classes(nullptr, negative->classes, negative->class_count, negative->seed, id, negatives.data(), batch_size, k);
+            else gvk_negative_draw(nullptr, negative->table, negative->count, negative->seed, id, negatives.data(), batch_size, k);
+            const float lr = gvo_lr(optimizer->lr, linear_schedule, (int)id, (int)total_batches);
+            for (int q = 0; q < parts; q++) {
+                const uint32_t *part = pairs + ((size_t)i * batch_size + (size_t)q * n) * 2, *neg = negatives.data() + (size_t)q * n * k;
+                gvo_hot_lists(part, neg, n, k, hot_vertex, hot_context, start.data(), entries.data());
+                if (gvo_train_hot_moments(dim, optimizer->type, tables->vertex, tables->context, tables->vertex_moment1, tables->context_moment1,
+                                          tables->vertex_moment2, tables->context_moment2, part, neg, loss + (size_t)q * n, n, k, lr, optimizer->weight_decay,
+                                          negative_weight, hp, hot_vertex, hot_context, start.data(), entries.data()))
+                    return gvk_fail(GVK_ENOMEM, "gvk_train_episode_hot: out of memory");
+            }
+        }
+        return GVK_OK;
+    }
     const int lerp = (form & GVK_HOT_LERP) || (getenv("GVH_LERP") && atoi(getenv("GVH_LERP")));
     // GVH_PAIRS=concurrent: the pairs of a unit as one launch runs them (reads as the unit found the rows, the later of two writers stays)
     gvo_set_pairs_concurrent(getenv("GVH_PAIRS") && !strcmp(getenv("GVH_PAIRS"), "concurrent"));

@@ -103,3 +103,10 @@ inline float __expf(float x) { return expf(x); }
 #define __builtin_amdgcn_ballot_w64 simt::ballot
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) simt::mfma_16x16x4(a, b, c)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+/* the grouped launches' coherent loads / stores and their flag (gvk_chains.hip await_row, load_row_coherent): plain accesses here — the
+ * stand-in runs one workgroup at a time, nothing is ever waited for */
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)

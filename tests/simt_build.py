@@ -103,7 +103,7 @@ def host_source():
         cut(common, "template <int DIM, int G>\nstruct Layout {", "// ---- arithmetic", include_end=False),
         cut(common, "__device__ __forceinline__ float sigmoidf(float x) {", "\n}\n"),
         # HotArgs, the chains of 1 .. 7 entries, the idle rows, train_long_chains: everything up to the kernel itself
-        cut(text, "// The logistic function of a chain step", "// HOT: 1 = the pairs read a hub row as the chains of their unit left it", include_end=False),
+        cut(text, "// The logistic function of a chain step", "// ---- moment optimizers (Momentum, AdaGrad, RMSprop, Adam", include_end=False),
     ]
     body = "\n".join(pieces)
     assert "asm volatile" not in body and "train_long_chains_in_rounds" in body
