@@ -56,6 +56,7 @@ constexpr int kHubMaxEntriesPerPart = 1000;  // ... and past this many per part 
 constexpr int kHubMaxParts = 32;  // measured on the headline shape at P = 8 (a block's top hub holds 16 % of its samples: the rule asks for 64): 25 / 32 / 40 / 50
                                   // parts end -0.0013 / +0.0008 / +0.0013 / +0.0022 from the reference's loop — past 32 the parts only cost launches
 constexpr int kHubMaxPartsResident = 50;  // cache-resident tables (< 16 MiB): a small partition's chains are feasible up to this many parts (§7.8)
+constexpr double kWalkHitsPerPart = 0.022;  // walk-ordered pools: parts so that the rows outside the chains meet no more than this (hit-weighted mean of expected hits) per part
 constexpr int kHubGroup = 2;             // GVX_HUB_GROUP 0: under executor 2 the chains of so many consecutive parts share a launch
 constexpr int kHubLerp = 0;              // GVX_HUB_LERP -1: the pairs read hub rows as their part's chains left them
 constexpr int kHubExecutor = 0;          // GVX_HUB_EXECUTOR -1: one launch per unit carries its pairs and the next unit's chains (gvk_train_episode_hot); 1: the chains as a stream of their own, a batch ahead of the pairs (gvk_train_episode_ahead: measured slower)
@@ -361,6 +362,7 @@ struct gvx_solver {
     int hub_workspace_for(Worker &w, size_t need);
     bool hub_rounds_of(int hp, int tp) const;
     double hub_graph_share = 0;  // the largest vertex's share of the graph's total degree
+    std::vector<double> hub_rest_hits;  // per partition: hit-weighted mean of the expected hits per batch of the rows that are not hub rows (as context rows)
     std::vector<double> hub_top_share, hub_next_hits;  // per partition: the largest row's share of the partition's degree; expected hits per batch of the first row that is not a hub row
     int stage(Worker &w, int step, int set, int b);
     int train_step(int step, int set, int first, int count, bool stage_next, int next_step, int next_set);
@@ -833,7 +835,7 @@ int gvx_solver::configure(const gvx_train_config &in) {
     // the partition) or as a negative (share of degree^exponent) — are trained by chains; their batches keep the sampler's order
     hub_rows.assign(num_partition, 0);
     hub_top_entries.assign(num_partition, 0);
-    hub_top_share.assign(num_partition, 0.0), hub_next_hits.assign(num_partition, 0.0);
+    hub_top_share.assign(num_partition, 0.0), hub_next_hits.assign(num_partition, 0.0), hub_rest_hits.assign(num_partition, 0.0);
     hubs = false;
     // the default rule (-2): every row of the walk-ordered pools of DeepWalk / node2vec on one partition of at most kMaxHubRows
     // rows; else the rows a part of a batch is expected to hit kHubHitsPerPart times — on tables that do not live in the caches
@@ -907,6 +909,18 @@ int gvx_solver::configure(const gvx_train_config &in) {
                 hub_top_entries[p] = (int)std::min(1e9, (double)batch_size * (num_negative + 1) * vertex_weights[ids[0]] / std::max(total, 1e-30));
                 hub_top_share[p] = vertex_weights[ids[0]] / std::max(total, 1e-30);
                 hub_next_hits[p] = 0;  // the caller chose the hub rows: the parts follow the largest of them
+            }
+            {   // what the rows the chains do NOT own meet per batch as context rows (tail or negative), weighted by the hits themselves:
+                // the expected hits per batch of the row a random such hit lands on — walk-ordered pools take their parts from it (hub_parts_of)
+                double total = 0, total_negative = 0, s1 = 0, s2 = 0;
+                for (uint32_t id : ids) total += vertex_weights[id], total_negative += std::pow((double)vertex_weights[id], (double)c.negative_sample_exponent);
+                for (size_t i = hub_rows[p]; i < ids.size(); i++) {
+                    const double w = vertex_weights[ids[i]];
+                    const double h = batch_size * w / std::max(total, 1e-30) +
+                                     (double)batch_size * num_negative * std::pow(w, (double)c.negative_sample_exponent) / std::max(total_negative, 1e-30);
+                    s1 += h, s2 += h * h;
+                }
+                hub_rest_hits[p] = s1 > 0 ? s2 / s1 : 0.0;
             }
             hubs = hubs || hub_rows[p] > 0;
         }
@@ -984,7 +998,7 @@ int gvx_solver::configure(const gvx_train_config &in) {
         log_message(0, "hub rows by chains: up to %u rows per table (a batch is expected to hit them once or more), a batch as %d%s%d parts = launches "
                     "(the largest hub row meets %d updates per batch: about %d per part%s%s), long chains %s%s",
                     *std::max_element(hub_rows.begin(), hub_rows.end()), least_parts, least_parts == most_parts ? " = " : " .. ", most_parts, top,
-                    top / std::max(most_parts, 1), spread ? "; walk-ordered pools ask for augmentation_step^2 + 1 parts" : "",
+                    top / std::max(most_parts, 1), spread ? "; walk-ordered pools: parts also by the hits of the rows outside the chains" : "",
                     most_parts > 8 ? ": every launch costs its longest chain, 9-13 us, however few pairs it holds" : "",
                     optimizer.type != GVK_SGD ? "as ONE sequential task each (a moment optimizer: a batch then takes as long as its largest hub row's updates one after the other)"
                     : (any_rounds ? "in rounds of 4 entries per task (the largest vertex takes more than 2 % of the degree: about 28 % slower)" : "in one round"),
@@ -1773,11 +1787,13 @@ int gvx_solver::hub_parts_of(int hp, int tp) const {
     int want = std::max((std::max(hub_top_entries[hp], hub_top_entries[tp]) + kHubEntriesPerPart / 2) / kHubEntriesPerPart, 1);
     // ... and so many that no row the chains do not own is expected to be hit more than kHubHitsPerPart times per part
     want = std::max(want, (int)std::ceil(std::min(1e6, std::max(hub_next_hits[hp], hub_next_hits[tp]) / kHubHitsPerPart)));
-    // ... and, for the walk-ordered pools of DeepWalk / node2vec spread over the units (record i to unit i % units): one walk writes a
-    // node's pairs — it heads `augmentation_step` consecutive records and is the tail of as many, spread over the
-    // augmentation_step^2 + 1 records around them (graph.cuh:428-434) — so only with that many units no two of them share a unit
+    // ... and, for the walk-ordered pools of DeepWalk / node2vec (spread over the units: record i to unit i % units, so the pairs of one walk
+    // never share a launch), so many that the rows the chains do not own collide as rarely inside a launch as they do on the headline
+    // shape: the hit-weighted mean of their expected hits per batch / kWalkHitsPerPart.  Measured at Youtube size (DESIGN.md section 7.11 e): one
+    // partition (0.33 hits) 8 / 16 / 32 parts -0.0014 / -0.0008 / -0.0001; four partitions (0.72 hits) 16 / 32 parts -0.0025 / -0.0009.
+    // (Until round 6 this term was augmentation_step^2 + 1 = 26 -> 32 parts for every walk pool.)
     static const bool walk_term = !(getenv("GVX_WALK_PARTS_TERM") && !strcmp(getenv("GVX_WALK_PARTS_TERM"), "0"));  // measurement: the rule without this term
-    if (spread && walk_term) want = std::max(want, config.augmentation_step * config.augmentation_step + 1);
+    if (spread && walk_term) want = std::max(want, (int)std::ceil(std::min(1e6, std::max(hub_rest_hits[hp], hub_rest_hits[tp]) / kWalkHitsPerPart)));
     want = std::min(want, hub_max_parts);
     if (kv == part_rows && kc == part_rows) want = std::max(want, gvk_train_launches(B, part_rows));
     int parts = 1;
