@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(kBlock) sample_walks_kernel(const gvk_walk_gra
 // per block would take every atomic of the launch on P * P addresses (measured: 0.36 G pairs/s at 16 blocks), striped
 // they spread over a few hundred times as many.  counters[b][stripe] keeps counting past the stripe's capacity, so the
 // caller sees each block's share and which stripes are full.
-// The pseudo shuffle (graph.cuh:713-728) keeps the pairs of a walk that share a row — pair i and pairs i + 1 .. i + 2 aug
+// The pseudo shuffle (graph.cuh:362-364,439-441) keeps the pairs of a walk that share a row — pair i and pairs i + 1 .. i + 2 aug
 // - 1 — out of one another's batch: pair i goes to part i % sb of the pool.  A wavefront's 64 walks append in lock step, so
 // here the part is chosen by the pair's INDEX IN ITS WALK, not by the slot it is handed: pair i of wavefront w goes to
 // stripe (w + (i % sb) * (stripes / sb)) % stripes — capacity / sb records away from pair i + 1.  (Choosing the part by

@@ -132,6 +132,7 @@ struct Worker {
     std::vector<gvk_class_entry *> negative_classes; // ... the sampler draws by weight class (gvk.h): an alias table over
     std::vector<uint32_t> negative_class_counts;     // the classes of equal-degree rows, a few thousand entries
     float *loss = nullptr;
+    int32_t *agreement = nullptr;  // [#worker] staging of allocate_pools' episode-size agreement: made with the streams, before anything can fail
     uint32_t *pool[2] = {nullptr, nullptr}, *landing = nullptr;
     void *group_workspace = nullptr;
     size_t group_workspace_bytes = 0;
@@ -283,7 +284,7 @@ struct gvx_solver {
         for (Worker &w : workers) {
             hipSetDevice(w.device);
             hipFree(w.head), hipFree(w.context), hipFree(w.loss), hipFree(w.pool[0]), hipFree(w.pool[1]);
-            hipFree(w.landing), hipFree(w.group_workspace), hipFree(w.hub_workspaces[0]), hipFree(w.hub_workspaces[1]);
+            hipFree(w.landing), hipFree(w.group_workspace), hipFree(w.hub_workspaces[0]), hipFree(w.hub_workspaces[1]), hipFree(w.agreement);
             for (int b = 0; b < 2; b++) {
                 if (w.lists_built[b]) hipEventDestroy(w.lists_built[b]);
                 if (w.lists_trained[b]) hipEventDestroy(w.lists_trained[b]);
@@ -1124,6 +1125,7 @@ int gvx_solver::prepare_devices() {
         HIP_TRY(hipMemsetAsync(w.head, 0, head_slots * slot_floats() * 4, w.compute));
         HIP_TRY(hipMemsetAsync(w.context, 0, context_slots * slot_floats() * 4, w.compute));
         HIP_TRY(hipMalloc(&w.loss, (size_t)batch_size * 4));
+        HIP_TRY(hipMalloc(&w.agreement, (size_t)std::max(num_worker, 1) * 4));
         HIP_TRY(hipMemsetAsync(w.loss, 0, (size_t)batch_size * 4, w.compute));
         for (int b = 0; b < 2; b++) {
             HIP_TRY(hipEventCreateWithFlags(&w.uploaded[b], hipEventDisableTiming));
@@ -1214,21 +1216,22 @@ int gvx_solver::allocate_pools() {
         }
         return ok;
     };
-    auto smallest_of = [&](int32_t mine, int32_t *smallest) {  // collective; nothing of it outlives the call
+    auto smallest_of = [&](int32_t mine, int32_t *smallest) {  // collective: every rank enters it whatever happened to it locally; its staging buffer exists since prepare_devices
         Worker &w = workers[0];
-        int32_t *sizes = nullptr;
+        int32_t *sizes = w.agreement;
         std::vector<int32_t> host(W, 0);
         host[w.rank] = mine;
-        int rc = hipSetDevice(w.device) == hipSuccess && hipMalloc(&sizes, (size_t)W * 4) == hipSuccess ? GVK_OK : GVK_EHIP;
-        // a rank whose staging buffer failed still enters the gather (from a null buffer the carrier reports the error on every rank)
-        if (rc == GVK_OK && hipMemcpyAsync(sizes, host.data(), (size_t)W * 4, hipMemcpyHostToDevice, w.exchange) != hipSuccess) rc = GVK_EHIP;
-        const int gathered = comm->all_gather({{w.rank, w.device, w.exchange}}, {sizes}, 4);
+        int rc = hipSetDevice(w.device) == hipSuccess &&
+                 hipMemcpyAsync(sizes, host.data(), (size_t)W * 4, hipMemcpyHostToDevice, w.exchange) == hipSuccess ? GVK_OK : GVK_EHIP;
+        const int gathered = comm->all_gather({{w.rank, w.device, w.exchange}}, {sizes}, 4);  // (a transport whose all_gather fails must fail on every rank: gvx.h)
         if (rc == GVK_OK) rc = gathered;
         if (rc == GVK_OK && (hipMemcpyAsync(host.data(), sizes, (size_t)W * 4, hipMemcpyDeviceToHost, w.exchange) != hipSuccess ||
                              hipStreamSynchronize(w.exchange) != hipSuccess))
             rc = GVK_EHIP;
-        hipFree(sizes);
-        if (rc != GVK_OK) return gvk_fail(rc, "GraphSolver: the workers could not agree on an episode size (%s)", gvk_last_error());
+        if (rc != GVK_OK) {
+            release_pools();  // nothing stays allocated on a rank that could not agree
+            return gvk_fail(rc, "GraphSolver: the workers could not agree on an episode size (%s)", gvk_last_error());
+        }
         *smallest = *std::min_element(host.begin(), host.end());
         return GVK_OK;
     };

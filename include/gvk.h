@@ -320,7 +320,7 @@ int gvk_sample_walks(void *stream, const gvk_walk_graph *graph, uint64_t seed, u
  * pools + 2 * offsets[b] (offsets in pairs; ~0 = this call does not collect b), capacity pairs long, cut into num_stripe
  * stripes (any divisor of capacity; a few hundred keeps the atomics off each other) of capacity / num_stripe slots with
  * one counter each — counters[b * num_stripe + stripe].  Pair i of a walk of wavefront w (= thread / 64) is appended to
- * stripe (w + (i % sb) * max(num_stripe / sb, 1)) % num_stripe: the pseudo shuffle of include/instance/graph.cuh:713-728 —
+ * stripe (w + (i % sb) * max(num_stripe / sb, 1)) % num_stripe: the pseudo shuffle of include/instance/graph.cuh:362-364,439-441 —
  * the pairs of a walk that share a row, capacity / sb records apart — with the part chosen by the pair's index in its
  * walk (a wavefront's 64 walks append in lock step: the slot says nothing about the walk).  Slot s of stripe k is record
  * k * (capacity / num_stripe) + s.  Pairs beyond a stripe's capacity are dropped (solver.h:1045-1052) but still counted, so the counters tell the

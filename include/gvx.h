@@ -105,7 +105,8 @@ gvx_solver *gvx_solver_create(int dim, const int *device_ids, int num_device, in
  *   all_gather  in place: `slab` holds world_size parts of `bytes` bytes, this rank's part already at slab + rank * bytes;
  *   all_to_all  part q of `send` arrives as part `rank` of rank q's `recv` (world_size parts of `bytes` bytes each).
  * Besides the exchanges of train(), build() calls all_gather twice with 4 bytes per rank (the ranks agree on the episode size every
- * one of them can allocate: gvx_engine.cpp allocate_pools) — on every rank, whatever happened to the rank locally. */
+ * one of them can allocate: gvx_engine.cpp allocate_pools) — on every rank, whatever happened to the rank locally.  A call that fails
+ * must fail on EVERY rank (a collective that some ranks leave and others wait in cannot be recovered from here). */
 typedef struct {
     int (*all_gather)(void *user, void *slab, size_t bytes, void *stream);
     int (*all_to_all)(void *user, const void *send, void *recv, size_t bytes, void *stream);

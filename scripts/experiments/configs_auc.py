@@ -35,7 +35,7 @@ for variant in extra.get("variants", "default").split(";"):
         from graphvite_amd.kernels import HipKernels
         HipKernels().set_tuning(int(kw["tune"].split(":")[0]), int(kw["tune"].split(":")[1]))
     base = T.JOBS[job][3].get("shuffle_base")
-    if "sb" in kw:  # the pseudo shuffle's base (graph.cuh:713-728) — a large one mixes the CPU samplers' walk-ordered pools
+    if "sb" in kw:  # the pseudo shuffle's base (graph.cuh:362-364,439-441) — a large one mixes the CPU samplers' walk-ordered pools
         T.JOBS[job][3]["shuffle_base"] = int(kw["sb"])
     aucs = []
     for seed in seeds:

@@ -538,7 +538,7 @@ def test_sample_walks_blocks_matches_the_oracle_per_block(hip, oracle, biased):
     block = part[want[:, 1]].astype(np.int64) * P + part[want[:, 0]]
     stripes, sb = 7, 3
     # pair i of a walk of wavefront w (64 walks) goes to stripe (w + (i % sb) * (stripes // sb)) % stripes: the pseudo shuffle's
-    # parts (graph.cuh:713-728) chosen by the pair's index in its walk
+    # parts (graph.cuh:362-364,439-441) chosen by the pair's index in its walk
     index = np.arange(len(want))
     stripe_of = (index // per_walk // 64 + index % per_walk % sb * (stripes // sb)) % stripes
     per_stripe = max(np.bincount(block[stripe_of == k], minlength=P * P).max() for k in range(stripes))
