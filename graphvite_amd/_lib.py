@@ -99,7 +99,8 @@ class SolverMembers(C.Structure):  # gvx_solver_members
                 ("optimizer", SolverOptimizer), ("batch_id", C.c_uint64), ("num_batch", C.c_uint64),
                 ("train_seconds", C.c_double), ("rank", C.c_int), ("num_local_worker", C.c_int), ("pair_order", C.c_int),
                 ("sampler_mode", C.c_int), ("device_sampling", C.c_int), ("partition_rows", C.c_uint32),
-                ("transport", C.c_char_p), ("hub_rows", C.c_uint32), ("hub_parts", C.c_int32), ("hub_lerp", C.c_int32), ("hub_rounds", C.c_int32)]
+                ("transport", C.c_char_p), ("hub_rows", C.c_uint32), ("hub_parts", C.c_int32), ("hub_lerp", C.c_int32), ("hub_rounds", C.c_int32),
+                ("lists_prefetched", C.c_uint32)]
 
 
 class Transport(C.Structure):  # gvx_transport
@@ -171,6 +172,8 @@ def lib():
     l.gvk_sample_walks.argtypes = [vp, P(WalkGraph), u64, u64, vp, C.c_size_t, i32, i32, i32]
     l.gvk_sample_walks_blocks.restype = i32
     l.gvk_sample_walks_blocks.argtypes = [vp, P(WalkGraph), vp, i32, u64, u64, u64, vp, vp, vp, u32, i32, i32, i32, i32]
+    l.gvk_sample_walks_blocks_thinned.restype = i32
+    l.gvk_sample_walks_blocks_thinned.argtypes = [vp, P(WalkGraph), vp, i32, u64, u64, u64, vp, vp, vp, u32, i32, i32, i32, i32, vp]
     l.gvk_spread_pairs.restype = i32
     l.gvk_spread_pairs.argtypes = [vp, vp, vp, C.c_size_t, i32]
     l.gvk_group_pairs.restype = i32

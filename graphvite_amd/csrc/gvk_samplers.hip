@@ -177,9 +177,17 @@ struct BlockPools {
     const uint64_t *offsets;  // [P * P] first pair of the block's pool, or ~0: not collected
     uint32_t *counters;       // [P * P][stripes]
     const int32_t *part;      // [num_vertex]
+    const float *accept;      // [P * P] or null: a pair of block b is kept with this probability (gvk_sample_walks_blocks_thinned)
     uint32_t capacity, stripes, stripe_capacity, sb;
     int P;
 };
+
+// uniform in [0, 1) from (walk, pair index in the walk, seed): which pairs of a walk a thinned block keeps (include/gvk.h)
+__device__ __forceinline__ float thinning_uniform(uint64_t walk, uint64_t i, uint64_t seed) {
+    uint32_t h = (uint32_t)walk ^ (uint32_t)(walk >> 32) * 0x85ebca6bu ^ (uint32_t)i * 0x9e3779b9u ^ (uint32_t)seed * 0xc2b2ae35u;
+    h ^= h >> 16, h *= 0x85ebca6bu, h ^= h >> 13, h *= 0xc2b2ae35u, h ^= h >> 16;
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
 
 __global__ void __launch_bounds__(kBlock) sample_walks_blocks_kernel(const gvk_walk_graph g, const BlockPools b, uint64_t seed,
                                                                      uint64_t first_walk, int L, int aug, uint64_t pairs_per_walk,
@@ -191,6 +199,7 @@ __global__ void __launch_bounds__(kBlock) sample_walks_blocks_kernel(const gvk_w
         const int block = b.part[head] * b.P + b.part[tail];
         const uint64_t first = b.offsets[block];
         if (first == ~(uint64_t)0) return;
+        if (b.accept && thinning_uniform(first_walk + t, i, seed) >= b.accept[block]) return;
         const uint32_t stripe = (wave + (uint32_t)(i % b.sb) * apart) % b.stripes;
         const uint32_t slot = atomicAdd(b.counters + (size_t)block * b.stripes + stripe, 1u);
         if (slot >= b.stripe_capacity) return;
@@ -290,6 +299,14 @@ int gvk_sample_walks_blocks(void *stream, const gvk_walk_graph *graph, const int
                             uint64_t first_walk, uint64_t num_walks, uint32_t *pools, const uint64_t *offsets,
                             uint32_t *counters, uint32_t capacity, int num_stripe, int walk_length, int augmentation_step,
                             int shuffle_base) {
+    return gvk_sample_walks_blocks_thinned(stream, graph, part, num_partition, seed, first_walk, num_walks, pools, offsets, counters, capacity,
+                                           num_stripe, walk_length, augmentation_step, shuffle_base, nullptr);
+}
+
+int gvk_sample_walks_blocks_thinned(void *stream, const gvk_walk_graph *graph, const int32_t *part, int num_partition, uint64_t seed,
+                                    uint64_t first_walk, uint64_t num_walks, uint32_t *pools, const uint64_t *offsets,
+                                    uint32_t *counters, uint32_t capacity, int num_stripe, int walk_length, int augmentation_step,
+                                    int shuffle_base, const float *accept) {
     if (num_walks == 0) return GVK_OK;
     if (!graph || !part || !pools || !offsets || !counters) return fail(GVK_EINVAL, "gvk_sample_walks_blocks: null pointer");
     if (!graph->flat_offsets || !graph->edges_uv || !graph->edge_table || !graph->neighbor_table || !graph->local ||
@@ -311,7 +328,7 @@ int gvk_sample_walks_blocks(void *stream, const gvk_walk_graph *graph, const int
     const uint64_t blocks = (num_walks + kBlock - 1) / kBlock;
     if (blocks > 0x7fffffffu) return fail(GVK_EINVAL, "gvk_sample_walks_blocks: too many walks for one call");
     BlockPools b;
-    b.pools = reinterpret_cast<u32x2 *>(pools), b.offsets = offsets, b.counters = counters, b.part = part;
+    b.pools = reinterpret_cast<u32x2 *>(pools), b.offsets = offsets, b.counters = counters, b.part = part, b.accept = accept;
     b.capacity = capacity, b.stripes = (uint32_t)num_stripe, b.stripe_capacity = capacity / (uint32_t)num_stripe, b.sb = (uint32_t)shuffle_base, b.P = num_partition;
     hipLaunchKernelGGL(sample_walks_blocks_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, *graph, b, seed,
                        first_walk, walk_length, augmentation_step, per_walk, num_walks);

@@ -144,6 +144,20 @@ struct Worker {
     hipEvent_t lists_built[2] = {nullptr, nullptr}, lists_trained[2] = {nullptr, nullptr};
     bool lists_trained_valid[2] = {false, false};
     uint64_t chunks_built = 0, chunks_trained = 0;
+    // The first chunk of the NEXT visit's lists is built while this visit's last chunk trains (prefetch_lists): `staged` is the visit stage()
+    // announced last, `prefetched` says what was built from it — train_block takes it when every field is what it would build itself.
+    struct Staged {
+        bool valid = false;
+        int hp = 0, tp = 0, set = 0, b = 0;
+    } staged;
+    struct Prefetched {
+        bool valid = false;
+        const uint32_t *pool = nullptr;
+        const void *workspace = nullptr;
+        uint64_t first = 0;
+        int m = 0, parts = 0, cap = 0, set = 0, b = 0;
+        uint32_t kv = 0, kc = 0;
+    } prefetched;
     hipEvent_t uploaded[2] = {nullptr, nullptr}, released[2] = {nullptr, nullptr}, trained = nullptr;
     bool released_valid[2] = {false, false};
     std::vector<hipEvent_t> copied;     // H2D copies of the current pool set still reading pinned memory
@@ -166,6 +180,8 @@ struct Worker {
     int32_t *walk_part = nullptr;
     uint64_t *walk_offsets = nullptr;
     uint32_t *walk_counters = nullptr;
+    float *walk_accept = nullptr;          // [P * P] the blocks' thinning rates of the next launch (device_fill)
+    std::vector<char> walk_collects;       // [P * P] this worker collects the block's pairs (walk_offsets != ~0)
     uint64_t sample_seed = 0, sample_index = 0;
 };
 
@@ -237,6 +253,7 @@ struct gvx_solver {
     gvx_train_config config{};
     int mode = 0;
     uint64_t batch_id = 0, num_batch = 0;
+    uint64_t lists_prefetched = 0;  // visits whose first chunk of work lists was built ahead and trained as built (prefetch_lists)
     double train_seconds = 0;
     gvs_sampler *sampler = nullptr;
     int sampler_mode = -1;
@@ -298,7 +315,7 @@ struct gvx_solver {
             for (auto &b : w.edge_blocks) hipFree(b.table);
             hipFree((void *)w.walk.flat_offsets), hipFree((void *)w.walk.edges_uv), hipFree((void *)w.walk.edge_table);
             hipFree((void *)w.walk.neighbor_table), hipFree((void *)w.walk.sorted_neighbors), hipFree((void *)w.walk.local);
-            hipFree(w.walk_part), hipFree(w.walk_offsets), hipFree(w.walk_counters);
+            hipFree(w.walk_part), hipFree(w.walk_offsets), hipFree(w.walk_counters), hipFree(w.walk_accept);
             for (hipEvent_t e : w.filled)
                 if (e) hipEventDestroy(e);
             if (w.episode_end) hipEventDestroy(w.episode_end);
@@ -361,6 +378,10 @@ struct gvx_solver {
     int route_slices(int set);
     int hub_parts_of(int hp, int tp) const;
     int hub_workspace_for(Worker &w, size_t need);
+    gvk_negative_source negative_source(Worker &w, int tp);
+    int build_lists(Worker &w, int hp, int tp, const uint32_t *batches, uint64_t first_id, int m, int parts);
+    int prefetch_lists(Worker &w, uint64_t next_batch_id);
+    void discard_prefetched(Worker &w);
     bool hub_rounds_of(int hp, int tp) const;
     double hub_graph_share = 0;  // the largest vertex's share of the graph's total degree
     std::vector<double> hub_rest_hits;  // per partition: hit-weighted mean of the expected hits per batch of the rows that are not hub rows (as context rows)
@@ -1404,6 +1425,8 @@ int gvx_solver::prepare_device_sampling() {
             }
         GVK_TRY(to_device(&w.walk_offsets, offsets.data(), offsets.size()));
         HIP_TRY(hipMalloc(&w.walk_counters, (size_t)P * P * largest_divisor(n_slice, 256) * 4));
+        HIP_TRY(hipMalloc(&w.walk_accept, (size_t)P * P * 4));
+        w.walk_collects.assign((size_t)P * P, 1);  // every worker collects its slice of every block
     }
     return GVK_OK;
 }
@@ -1471,9 +1494,16 @@ int gvx_solver::device_fill(int set) {
     const int stripes = largest_divisor(n_slice, 256);
     const uint64_t stripe_capacity = n_slice / stripes, every = 64ull * stripes;  // the same number of wavefronts per stripe
     const size_t num_counter = (size_t)P * P * stripes;
-    std::vector<uint64_t> walks(L, ((n_slice * P * P + per_walk - 1) / per_walk / every + 1) * every), used(L, 0);
+    // Blocks receive unequal shares of the walks' pairs, and a pool that is full drops what arrives later in the launch — with node2vec's
+    // rejection sampling the late walks are those that rejected most, a selection the AUC sees (DESIGN.md section 7.11 f).  So: a first small
+    // launch shows every block's share; from then on every block is THINNED (gvk_sample_walks_blocks_thinned: by a hash of walk and pair, not by
+    // arrival) to the rate at which its pool fills together with the slowest one's, and only the last per cent of a pool is first come, first served.
+    const uint64_t all_walks = ((n_slice * P * P + per_walk - 1) / per_walk / every + 1) * every;
+    std::vector<uint64_t> walks(L, std::max<uint64_t>(all_walks / 8 / every, 1) * every), used(L, 0);
     std::vector<char> full(L, 0);
     std::vector<uint32_t> counters(num_counter);
+    std::vector<std::vector<double>> share(L);
+    std::vector<std::vector<float>> accept(L, std::vector<float>((size_t)P * P, 1.0f));
     for (Worker &w : workers) {
         HIP_TRY(hipSetDevice(w.device));
         HIP_TRY(hipMemsetAsync(w.walk_counters, 0, num_counter * 4, w.sample));
@@ -1484,9 +1514,10 @@ int gvx_solver::device_fill(int set) {
             Worker &w = workers[l];
             if (full[l]) continue;
             HIP_TRY(hipSetDevice(w.device));
-            GVK_TRY(gvk_sample_walks_blocks(w.sample, &w.walk, w.walk_part, P, w.sample_seed, w.sample_index + used[l], walks[l],
-                                            W == 1 ? w.block_pools[set] : w.route_send, w.walk_offsets, w.walk_counters,
-                                            (uint32_t)n_slice, stripes, length, aug, config.shuffle_base));
+            if (round > 0) HIP_TRY(hipMemcpyAsync(w.walk_accept, accept[l].data(), (size_t)P * P * 4, hipMemcpyHostToDevice, w.sample));
+            GVK_TRY(gvk_sample_walks_blocks_thinned(w.sample, &w.walk, w.walk_part, P, w.sample_seed, w.sample_index + used[l], walks[l],
+                                                    W == 1 ? w.block_pools[set] : w.route_send, w.walk_offsets, w.walk_counters,
+                                                    (uint32_t)n_slice, stripes, length, aug, config.shuffle_base, round > 0 ? w.walk_accept : nullptr));
             used[l] += walks[l];
         }
         bool all_full = true;
@@ -1496,18 +1527,34 @@ int gvx_solver::device_fill(int set) {
             HIP_TRY(hipSetDevice(w.device));
             HIP_TRY(hipMemcpyAsync(counters.data(), w.walk_counters, num_counter * 4, hipMemcpyDeviceToHost, w.sample));
             HIP_TRY(hipStreamSynchronize(w.sample));
-            // next round from the share of all pairs each stripe still short has received so far
-            double need = 0;
-            for (size_t i = 0; i < num_counter; i++) {
-                if (counters[i] >= stripe_capacity) continue;
-                const double share = std::max((double)counters[i] / ((double)used[l] * per_walk), 1.0 / (64.0 * num_counter));
-                if (counters[i] == 0 && used[l] * per_walk > 64ull * n_slice * P * P)
-                    return gvk_fail(GVK_EINVAL, "block (%zu, %zu) of the partition grid receives no random-walk pairs; use "
-                                    "fewer partitions", i / stripes / P, i / stripes % P);
-                need = std::max(need, (double)(stripe_capacity - counters[i]) / share / per_walk);
+            if (round == 0) {  // unthinned: the counters are the blocks' shares of everything the walks emit
+                share[l].assign((size_t)P * P, 0.0);
+                for (size_t i = 0; i < num_counter; i++) share[l][i / stripes] += (double)counters[i] / ((double)used[l] * per_walk);
             }
-            full[l] = need == 0;
-            walks[l] = ((uint64_t)(need * 1.1) / every + 1) * every;
+            // how many emitted pairs each block still needs at its share: the slowest sets the next launch, the others are thinned to its pace
+            double longest = 0;
+            std::vector<double> time_to_fill((size_t)P * P, 0.0);
+            for (size_t blk = 0; blk < (size_t)P * P; blk++) {
+                double missing = 0;
+                bool collected = false;
+                for (int k = 0; k < stripes; k++) {
+                    const uint32_t have = counters[blk * stripes + k];
+                    collected = collected || have > 0;
+                    if (have < stripe_capacity) missing += (double)(stripe_capacity - have);
+                }
+                if (missing == 0) continue;
+                if (!collected && share[l][blk] == 0) {  // a block this worker does not collect — or one that receives nothing at all
+                    if (w.walk_collects[blk] && used[l] * per_walk > 64ull * n_slice * P * P)
+                        return gvk_fail(GVK_EINVAL, "block (%zu, %zu) of the partition grid receives no random-walk pairs; use "
+                                        "fewer partitions", blk / P, blk % P);
+                    if (!w.walk_collects[blk]) continue;
+                }
+                time_to_fill[blk] = missing / std::max(share[l][blk], 1.0 / (64.0 * P * P * stripes));
+                longest = std::max(longest, time_to_fill[blk]);
+            }
+            full[l] = longest == 0;
+            for (size_t blk = 0; blk < (size_t)P * P; blk++) accept[l][blk] = longest > 0 ? (float)std::min(1.0, std::max(time_to_fill[blk] / longest, 0.0)) : 1.0f;
+            walks[l] = ((uint64_t)(longest * 1.02 / per_walk) / every + 1) * every;
             all_full = all_full && full[l];
         }
         if (all_full) break;
@@ -1807,6 +1854,75 @@ int gvx_solver::hub_parts_of(int hp, int tp) const {
     return parts;
 }
 
+gvk_negative_source gvx_solver::negative_source(Worker &w, int tp) {
+    const int ti = (int)tail_index(w, tp);
+    gvk_negative_source neg{};
+    neg.table = w.negative_tables[ti], neg.count = (uint32_t)part_ids[tp].size();
+    neg.classes = w.negative_classes[ti], neg.class_count = w.negative_class_counts[ti];
+    neg.seed = seed * 0x100000001B3ull + 0x100000001B3ull + (uint64_t)w.rank;
+    return neg;
+}
+
+// The work lists of m batches of block (hp, tp) — the batches at `batches`, ids first_id, first_id + W, ... — on the lists stream into the
+// workspace whose turn it is (two in rotation; it waits until the chunk that trained out of that workspace last has trained).
+int gvx_solver::build_lists(Worker &w, int hp, int tp, const uint32_t *batches, uint64_t first_id, int m, int parts) {
+    const int slot = (int)(w.chunks_built & 1);
+    const uint32_t kv = hub_rows[hp], kc = hub_rows[tp];
+    gvk_negative_source neg = negative_source(w, tp);
+    if (w.lists_trained_valid[slot]) HIP_TRY(hipStreamWaitEvent(w.lists, w.lists_trained[slot], 0));
+    if (hub_ahead())
+        GVK_TRY(gvk_ahead_build(w.lists, dim, w.hub_workspaces[slot], w.hub_workspace_bytes, batches, batch_size, m, num_negative, &neg, (uint32_t)first_id,
+                                (uint32_t)num_worker, kv, kc, parts, hub_chain_cap_request, hub_group_of(parts)));
+    else
+        GVK_TRY(gvk_hot_build(w.lists, dim, w.hub_workspaces[slot], w.hub_workspace_bytes, batches, batch_size, m, num_negative, &neg, (uint32_t)first_id,
+                              (uint32_t)num_worker, kv, kc, parts, hub_chain_cap_request));
+    HIP_TRY(hipEventRecord(w.lists_built[slot], w.lists));
+    w.chunks_built++;
+    return GVK_OK;
+}
+
+// Lists that were built ahead and will not be trained (the next call trained something else): their workspace is the next to be built into again.
+void gvx_solver::discard_prefetched(Worker &w) {
+    if (w.prefetched.valid && w.chunks_built > w.chunks_trained) w.chunks_built--;
+    w.prefetched.valid = false;
+}
+
+// The lists of a visit's FIRST chunk depend on its pool and the ids of its batches, never on the embeddings, and a work list kernel is one
+// workgroup's latency (about 100 us) however few batches it covers: built when the visit begins, it is time in which the GPU trains nothing
+// (4 % of a 20-batch visit on the headline shape, 3 % of an 8-batch visit at the shard size of an 8-GPU run).  So once a visit's last
+// launches are enqueued, the first chunk of the visit stage() announced last is built on the lists stream — beside those launches — under the
+// assumption that the next call trains that visit from its first batch with the ids that follow this call's; train_block checks the assumption
+// field by field and builds as before where it fails.  GVX_LISTS_PREFETCH=0: never (measurement).
+int gvx_solver::prefetch_lists(Worker &w, uint64_t next_batch_id) {
+    const char *knob = getenv("GVX_LISTS_PREFETCH");
+    const bool enabled = !(knob && !strcmp(knob, "0"));
+    if (!w.staged.valid) return GVK_OK;
+    const Worker::Staged s = w.staged;
+    w.staged.valid = false;
+    if (!enabled || !hubs || w.prefetched.valid || next_batch_id >= num_batch) return GVK_OK;
+    const uint32_t kv = hub_rows[s.hp], kc = hub_rows[s.tp];
+    if (kv + kc == 0 || w.chunks_built != w.chunks_trained) return GVK_OK;
+    const int W = num_worker, parts = hub_parts_of(s.hp, s.tp);
+    size_t need = 0;
+    GVK_TRY((hub_ahead() ? gvk_ahead_plan : gvk_hot_plan)(dim, batch_size, num_negative, kv, kc, hub_chunk, parts, hub_chain_cap_request, &need));
+    if (need > w.hub_workspace_bytes) return GVK_OK;  // a larger block than any before it: its visit makes room (hub_workspace_for)
+    const uint64_t first = next_batch_id + (uint64_t)w.rank;
+    int n = 1;  // as train_block: up to, not including, the worker's next logging batch
+    while (n < episode_size && (first + (uint64_t)n * W) % config.log_frequency) n++;
+    const int m = std::min(optimizer.schedule == 2 ? 1 : hub_chunk, n);
+    const uint32_t *pool = trained_pool(w, s.set, s.b, s.hp, s.tp);
+    HIP_TRY(hipSetDevice(w.device));
+    HIP_TRY(hipStreamWaitEvent(w.lists, w.uploaded[s.b], 0));
+    if (w.block_pools[0]) HIP_TRY(hipStreamWaitEvent(w.lists, w.filled[s.set], 0));
+    const void *workspace = w.hub_workspaces[w.chunks_built & 1];
+    GVK_TRY(build_lists(w, s.hp, s.tp, pool, first, m, parts));
+    w.prefetched.valid = true;
+    w.prefetched.pool = pool, w.prefetched.workspace = workspace, w.prefetched.first = first;
+    w.prefetched.m = m, w.prefetched.parts = parts, w.prefetched.cap = hub_chain_cap_request, w.prefetched.set = s.set, w.prefetched.b = s.b;
+    w.prefetched.kv = kv, w.prefetched.kc = kc;
+    return GVK_OK;
+}
+
 int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int first_batch, int count) {
     Range range("Train Batch");  // solver.h:1526 (one range per block: its batches are back-to-back launches)
     const int W = num_worker, r = w.rank, B = batch_size, nm = num_moment;
@@ -1817,10 +1933,7 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int
     if (nm >= 2) t.vertex_moment2 = head_table(w, hp, 2), t.context_moment2 = context_table(w, ti, 2);
     t.n_vertex = t.n_context = part_rows;
     t.flags = walk_ordered() ? GVK_PAIRS_OF_WALKS : 0;
-    gvk_negative_source neg{};
-    neg.table = w.negative_tables[ti], neg.count = (uint32_t)part_ids[tp].size();
-    neg.classes = w.negative_classes[ti], neg.class_count = w.negative_class_counts[ti];
-    neg.seed = seed * 0x100000001B3ull + 0x100000001B3ull + (uint64_t)r;
+    gvk_negative_source neg = negative_source(w, tp);
     gvk_optimizer o{};
     o.type = optimizer.type, o.lr = optimizer.lr, o.weight_decay = optimizer.weight_decay;
     o.hp0 = optimizer.hp0, o.hp1 = optimizer.hp1, o.epsilon = optimizer.epsilon;
@@ -1862,19 +1975,20 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int
             // the pool: train_step) — nothing but training launches on the compute stream.
             const int pair_launches = hub_pair_launches_request > 0 && parts % hub_pair_launches_request == 0 ? hub_pair_launches_request : 0;
             auto build = [&](int at) -> int {
-                const int slot = (int)(w.chunks_built & 1), m = std::min(chunk, n - at);
-                if (w.lists_trained_valid[slot]) HIP_TRY(hipStreamWaitEvent(w.lists, w.lists_trained[slot], 0));
-                if (ahead)
-                    GVK_TRY(gvk_ahead_build(w.lists, dim, w.hub_workspaces[slot], w.hub_workspace_bytes, pool + (size_t)(done + at) * B * 2, B, m, num_negative,
-                                            &neg, (uint32_t)(first + (uint64_t)at * W), (uint32_t)W, kv, kc, parts, chain_cap, hub_group_of(parts)));
-                else
-                    GVK_TRY(gvk_hot_build(w.lists, dim, w.hub_workspaces[slot], w.hub_workspace_bytes, pool + (size_t)(done + at) * B * 2, B, m, num_negative,
-                                          &neg, (uint32_t)(first + (uint64_t)at * W), (uint32_t)W, kv, kc, parts, chain_cap));
-                HIP_TRY(hipEventRecord(w.lists_built[slot], w.lists));
-                w.chunks_built++;
-                return GVK_OK;
+                return build_lists(w, hp, tp, pool + (size_t)(done + at) * B * 2, first + (uint64_t)at * W, std::min(chunk, n - at), parts);
             };
-            GVK_TRY(build(0));
+            // the first chunk may be there already: built while the visit before this one trained its last chunk (prefetch_lists)
+            bool built = false;
+            if (w.prefetched.valid) {
+                const Worker::Prefetched &p = w.prefetched;
+                built = p.pool == pool + (size_t)done * B * 2 && p.first == first && p.m == std::min(chunk, n) && p.parts == parts && p.cap == chain_cap &&
+                        p.kv == kv && p.kc == kc && p.workspace == w.hub_workspaces[w.chunks_trained & 1] && w.chunks_built == w.chunks_trained + 1;
+                if (built)
+                    w.prefetched.valid = false, lists_prefetched++;
+                else
+                    discard_prefetched(w);
+            }
+            if (!built) GVK_TRY(build(0));
             for (int at = 0; at < n; at += chunk) {
                 const int slot = (int)(w.chunks_trained & 1), m = std::min(chunk, n - at);
                 const uint64_t id = first + (uint64_t)at * W;
@@ -1952,6 +2066,8 @@ int gvx_solver::stage(Worker &w, int step, int set, int b) {
         GVK_TRY(gvk_spread_pairs(w.copy, source, w.pool[b], (size_t)episode_size * batch_size, episode_size * hub_parts_of(hp, tp)));
     }
     HIP_TRY(hipEventRecord(w.uploaded[b], w.copy));
+    if (w.prefetched.valid && w.prefetched.b == b) discard_prefetched(w);  // lists of what this buffer held
+    w.staged.valid = true, w.staged.hp = hp, w.staged.tp = tp, w.staged.set = set, w.staged.b = b;
     return GVK_OK;
 }
 
@@ -2045,6 +2161,9 @@ int gvx_solver::train_step(int step, int set, int first, int count, bool stage_n
         }
         if (streamed) GVK_TRY(load_block(w, hp, tp));
         GVK_TRY(train_block(w, hp, tp, trained_pool(w, set, b, hp, tp), first, count));
+        // the visit announced by stage() — unless it is this one — gets the lists of its first chunk now, beside this visit's last launches
+        if (w.staged.valid && w.staged.b == b && w.staged.hp == hp && w.staged.tp == tp && w.staged.set == set) w.staged.valid = false;
+        GVK_TRY(prefetch_lists(w, batch_id + (uint64_t)count * W));
         HIP_TRY(hipEventRecord(w.released[b], w.compute));
         w.released_valid[b] = true;
         HIP_TRY(hipEventRecord(w.trained, w.compute));
@@ -2173,7 +2292,13 @@ extern "C" int gvx_session_block(gvx_solver *s, int step, int worker, int *head_
 extern "C" int gvx_session_fill(gvx_solver *s, int set) {
     SESSION(s, "gvx_session_fill");
     if (set != 0 && set != 1) return gvk_fail(GVK_EINVAL, "gvx_session_fill: set must be 0 or 1");
-    return guarded("gvx_session_fill", [&]() { return s->fill(set); });
+    return guarded("gvx_session_fill", [&]() {
+        for (Worker &w : s->workers) {  // lists built ahead from the pools this call overwrites
+            if (w.prefetched.valid && w.prefetched.set == set) s->discard_prefetched(w);
+            if (w.staged.set == set) w.staged.valid = false;
+        }
+        return s->fill(set);
+    });
 }
 
 extern "C" int gvx_session_stage(gvx_solver *s, int step, int set, int buffer) {
@@ -2385,6 +2510,7 @@ extern "C" int gvx_solver_get(gvx_solver *s, gvx_solver_members *out) {
                 out->hub_rounds = out->hub_rounds || s->hub_rounds_of(hp, tp);
             }
     out->hub_lerp = out->hub_rows ? (s->hub_lerp_request < 0 ? kHubLerp : s->hub_lerp_request) : 0;
+    out->lists_prefetched = (uint32_t)s->lists_prefetched;
     return GVK_OK;
 }
 

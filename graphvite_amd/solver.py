@@ -328,6 +328,7 @@ class GraphSolver(object):
         self.partition_rows = m.partition_rows
         self.hub_rows = m.hub_rows
         self.hub_parts_used, self.hub_lerp_used, self.hub_rounds_used = m.hub_parts, bool(m.hub_lerp), bool(m.hub_rounds)
+        self.lists_prefetched = m.lists_prefetched
         self.transport = (m.transport or b"").decode()
         self.train_seconds = m.train_seconds
         self._mode = _MODES.get(m.sampler_mode, "edge")

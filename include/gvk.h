@@ -331,6 +331,17 @@ int gvk_sample_walks_blocks(void *stream, const gvk_walk_graph *graph, const int
                             uint64_t first_walk, uint64_t num_walks, uint32_t *pools, const uint64_t *offsets,
                             uint32_t *counters, uint32_t capacity, int num_stripe, int walk_length, int augmentation_step,
                             int shuffle_base);
+/* The same with THINNING: accept (device memory, num_partition^2 floats, or NULL = gvk_sample_walks_blocks) gives every block the
+ * probability with which a pair that belongs to it is kept — decided by a hash of (walk, the pair's index in its walk, seed), not by
+ * when the pair arrives: u = fmix32(lo(walk) ^ hi(walk) * 0x85ebca6b ^ i * 0x9e3779b9 ^ lo(seed) * 0xc2b2ae35) >> 8 / 2^24 < accept[b].
+ * Why: blocks receive unequal shares of the walks' pairs, a pool that is full drops what arrives LATER in the launch, and with
+ * node2vec's rejection sampling the walks that arrive late are those that rejected most — a selection the AUC sees (+0.003 at
+ * Youtube size in 4 partitions).  A caller that thins every block to the rate at which its pool fills together
+ * with the others' (the engine: from the shares a first small launch shows) loses nothing to arrival order but the last per cent. */
+int gvk_sample_walks_blocks_thinned(void *stream, const gvk_walk_graph *graph, const int32_t *part, int num_partition, uint64_t seed,
+                                    uint64_t first_walk, uint64_t num_walks, uint32_t *pools, const uint64_t *offsets,
+                                    uint32_t *counters, uint32_t capacity, int num_stripe, int walk_length, int augmentation_step,
+                                    int shuffle_base, const float *accept);
 
 /* Optional pool pre-pass: inside each of the num_batch batches (batch_size {tail, head} records each) of pool_in, make
  * the records that share a head row adjacent, writing the regrouped pool to pool_out (distinct from pool_in).  Each

@@ -92,6 +92,7 @@ typedef struct {
     int32_t hub_parts;           /* ... the parts it trained a batch as (the largest block value; 0 = no hub rows) */
     int32_t hub_lerp;            /* ... 1 = its pairs read hub rows along the chains' way (gvk.h GVK_HOT_LERP) */
     int32_t hub_rounds;          /* ... 1 = some block's long chains worked in rounds (gvk.h GVK_HOT_ROUNDS) */
+    uint32_t lists_prefetched;   /* visits whose first chunk of work lists was built while the visit before trained, and trained as built (this solver, so far) */
 } gvx_solver_members;
 
 /* device_ids: num_device GPU ids (an id may repeat: its workers then share that GPU), or num_device == 0 for all

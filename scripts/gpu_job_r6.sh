@@ -12,7 +12,7 @@ mkdir -p $O
 # the suite into pytest_gpu_refresh.log / parity_auc_refresh.log, then the bench command, its trace and its PMC passes as below
 LOG=pytest_gpu_full.log; PARITY=parity_auc.log; WHAT="tests -m gpu"
 if [ "$REFRESH" = "1" ]; then LOG=pytest_gpu_refresh.log; PARITY=parity_auc_refresh.log; WHAT="tests/test_configs_gpu.py tests/test_hub_chains_gpu.py tests/test_kernel_gpu.py -m gpu"; fi
-timeout 2800 python -m pytest $WHAT -q -rP > $O/$LOG 2>&1
+timeout 2800 python -m pytest $WHAT -q -rPx > $O/$LOG 2>&1
 grep -E "passed|failed" $O/$LOG | tail -2; grep -E "^FAILED" $O/$LOG
 grep -hE "^(headline|tube|hub100k|blog|module|friendster|youtube|held|hub rows after|a head row|DeepWalk over)|AUC here|hub rows after" $O/$LOG | grep -v "print(" > $O/$PARITY
 timeout 1200 python bench.py --steps 20 --warmup 5 > $O/bench_n1_steps20.json 2> $O/bench_n1_steps20.err

@@ -349,6 +349,64 @@ def session_equals_train():
         assert (a.vertex_embeddings == b.vertex_embeddings).all() and (a.context_embeddings == b.context_embeddings).all()
 
 
+def lists_prefetch():
+    """The work lists of a visit's first chunk are built while the visit before it trains (gvx_engine.cpp prefetch_lists) under the assumption
+    that the next call trains the visit stage() announced from its first batch: the tables must be those of a run that never builds ahead
+    (GVX_LISTS_PREFETCH=0), the assumption must hold in the episode loop and in a session that walks the schedule as bench.py does, and a
+    session that breaks it (a visit left early, a visit in pieces, logging batches that cut a chunk) must train what train() trains."""
+    g = make_graph(n=2000, e=30000)
+    kw = dict(model="LINE", num_epoch=3, augmentation_step=1)
+    tables = {}
+    for workers, partitions, log in ((1, 2, 1 << 30), (2, 4, 1 << 30), (1, 3, 7)):
+        for knob in ("0", "1"):
+            os.environ["GVX_LISTS_PREFETCH"] = knob
+            s = gv.solver.GraphSolver(32, device_ids=[0] * workers, num_sampler_per_worker=1, seed=4, hub_rows=60)
+            s.build(g, batch_size=1000, episode_size=3, num_partition=partitions)
+            s.train(log_frequency=log, **kw)
+            s._refresh()
+            # every visit but an episode's first is announced while the visit before it trains; logging batches cut some first chunks short
+            visits = s.num_batch // (3 * workers)
+            episodes = -(-visits // (partitions * partitions // workers))
+            assert s.lists_prefetched == (0 if knob == "0" else (visits - episodes) * workers), (workers, partitions, knob, s.lists_prefetched, visits, episodes)
+            key = (workers, partitions, log)
+            tables.setdefault(key, (s.vertex_embeddings.copy(), s.context_embeddings.copy()))
+            assert (tables[key][0] == s.vertex_embeddings).all() and (tables[key][1] == s.context_embeddings).all(), (key, knob)
+    del os.environ["GVX_LISTS_PREFETCH"]
+    # a session that walks the schedule the way bench.py does: the next visit staged before this one trains; pools resident and reused
+    reference = gv.solver.GraphSolver(32, num_sampler_per_worker=1, seed=4, hub_rows=60)
+    reference.build(g, batch_size=1000, episode_size=4, num_partition=2)
+    for walk in ("whole visits", "pieces and visits left early"):
+        for knob in ("0", "1"):
+            os.environ["GVX_LISTS_PREFETCH"] = knob
+            b = gv.solver.GraphSolver(32, num_sampler_per_worker=1, seed=4, hub_rows=60)
+            b.build(g, batch_size=1000, episode_size=4, num_partition=2)
+            session = b.session(resident_pools=True, log_frequency=1 << 30, **kw)
+            session.fill(0)
+            session.stage(0, 0, 0)
+            for visit in range(12):
+                session.stage((visit + 1) % session.steps, 0, (visit + 1) & 1)
+                step = visit % session.steps
+                if walk == "whole visits":
+                    session.train(step, 0, visit & 1, 0, 4)
+                elif visit % 4 == 0:
+                    session.train(step, 0, visit & 1, 0, 2)   # left after two batches: the next visit's lists were built for other ids
+                elif visit % 4 == 1:
+                    session.train(step, 0, visit & 1, 0, 1)   # in pieces: the second call continues the visit, the lists built ahead are dropped
+                    session.train(step, 0, visit & 1, 1, 3)
+                else:
+                    session.train(step, 0, visit & 1, 0, 4)
+                session.exchange(step)
+            session.close()
+            b._refresh()
+            if walk == "whole visits":
+                assert b.lists_prefetched == (11 if knob == "1" else 0), b.lists_prefetched
+            else:
+                assert b.lists_prefetched == (3 if knob == "1" else 0), b.lists_prefetched  # the whole visits that follow a whole visit
+            tables.setdefault(walk, (b.vertex_embeddings.copy(), b.context_embeddings.copy()))
+            assert (tables[walk][0] == b.vertex_embeddings).all() and (tables[walk][1] == b.context_embeddings).all(), (walk, knob)
+    del os.environ["GVX_LISTS_PREFETCH"]
+
+
 def custom_schedule_and_optimizers():
     g = make_graph(150, 900, seed=4)
     log = Launches()

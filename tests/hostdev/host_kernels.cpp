@@ -477,9 +477,22 @@ int gvk_sample_walks(void *, const gvk_walk_graph *g, uint64_t seed, uint64_t fi
 
 // gvk_sample_walks_blocks restated: the walks of gvk_sample_walks (vertex ids instead of rows), every pair binned into the
 // pool of its (head partition, tail partition) block; pair i of a walk to stripe ((walk / 64) + (i % sb) * (stripes / sb)) % stripes, in walk order.
-int gvk_sample_walks_blocks(void *, const gvk_walk_graph *g, const int32_t *part, int P, uint64_t seed, uint64_t first_walk,
+static float thinning_uniform(uint64_t walk, uint64_t i, uint64_t seed) {  // gvk.h gvk_sample_walks_blocks_thinned
+    uint32_t h = (uint32_t)walk ^ (uint32_t)(walk >> 32) * 0x85ebca6bu ^ (uint32_t)i * 0x9e3779b9u ^ (uint32_t)seed * 0xc2b2ae35u;
+    h ^= h >> 16, h *= 0x85ebca6bu, h ^= h >> 13, h *= 0xc2b2ae35u, h ^= h >> 16;
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+int gvk_sample_walks_blocks(void *stream, const gvk_walk_graph *g, const int32_t *part, int P, uint64_t seed, uint64_t first_walk,
                             uint64_t num_walks, uint32_t *pools, const uint64_t *offsets, uint32_t *counters, uint32_t capacity,
                             int num_stripe, int walk_length, int aug, int shuffle_base) {
+    return gvk_sample_walks_blocks_thinned(stream, g, part, P, seed, first_walk, num_walks, pools, offsets, counters, capacity, num_stripe, walk_length, aug,
+                                           shuffle_base, nullptr);
+}
+
+int gvk_sample_walks_blocks_thinned(void *, const gvk_walk_graph *g, const int32_t *part, int P, uint64_t seed, uint64_t first_walk,
+                                    uint64_t num_walks, uint32_t *pools, const uint64_t *offsets, uint32_t *counters, uint32_t capacity,
+                                    int num_stripe, int walk_length, int aug, int shuffle_base, const float *accept) {
     if (capacity % (uint32_t)num_stripe || capacity % (uint32_t)shuffle_base)
         return gvk_fail(GVK_EINVAL, "gvk_sample_walks_blocks: stripes / shuffle base must divide the pool size");
     std::vector<float> ep, np;
@@ -503,6 +516,7 @@ int gvk_sample_walks_blocks(void *, const gvk_walk_graph *g, const int32_t *part
             const int block = part[head] * P + part[tail];
             const uint64_t first = offsets[block];
             if (first == ~(uint64_t)0) continue;
+            if (accept && thinning_uniform(first_walk + t, i, seed) >= accept[block]) continue;
             const uint32_t slot = counters[(size_t)block * num_stripe + stripe]++;
             if (slot >= stripe_capacity) continue;
             uint32_t *record = pools + 2 * (first + ((size_t)stripe * stripe_capacity + slot));

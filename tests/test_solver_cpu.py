@@ -55,6 +55,10 @@ def test_hub_row_rules(host_build):
     scenario(host_build, "hub_row_rules")
 
 
+def test_work_lists_built_ahead_train_the_same_tables(host_build):
+    scenario(host_build, "lists_prefetch")
+
+
 def test_executor_simulator_forms(host_build):
     scenario(host_build, "executor_simulator")
 
