@@ -36,7 +36,7 @@ from graphvite_amd import synthetic  # noqa: E402  (graph generators only; nothi
 from oracle_lib import Oracle, ReferenceSolver, link_prediction_auc, reference_train  # noqa: E402
 
 PATH = os.path.join(HERE, "reference_configs.npz")
-SEEDS = (17, 18, 19, 20)[:int(os.environ.get("SEEDS", "3"))]
+SEEDS = (17, 18, 19, 20, 21, 22, 23, 24)[:int(os.environ.get("SEEDS", "3"))]
 BATCH = 100000
 WALK = dict(walk_length=40, walk_batch=100)
 
