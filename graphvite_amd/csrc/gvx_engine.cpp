@@ -1844,6 +1844,11 @@ int gvx_solver::hub_parts_of(int hp, int tp) const {
     // (Until round 6 this term was augmentation_step^2 + 1 = 26 -> 32 parts for every walk pool.)
     static const bool walk_term = !(getenv("GVX_WALK_PARTS_TERM") && !strcmp(getenv("GVX_WALK_PARTS_TERM"), "0"));  // measurement: the rule without this term
     if (spread && walk_term) want = std::max(want, (int)std::ceil(std::min(1e6, std::max(hub_rest_hits[hp], hub_rest_hits[tp]) / kWalkHitsPerPart)));
+    // ... and, under a moment optimizer, as many as a batch may have: a hub row's chain is one sequential task whatever the parts (they cost its
+    // launches 8 % at 32 against 8), and what the parts buy is fewer concurrent updates of the rows outside the chains — to which Adam, whose
+    // every step has the same length, is more sensitive than SGD.  Measured on the headline shape, eight seeds (DESIGN.md section 7.11 b): Adam
+    // 8 / 16 / 32 / 100 parts -0.0043 / -0.0034 / -0.0028 / -0.0024 from the reference's loop.
+    if (optimizer.type != GVK_SGD) want = std::max(want, hub_max_parts);
     want = std::min(want, hub_max_parts);
     if (kv == part_rows && kc == part_rows) want = std::max(want, gvk_train_launches(B, part_rows));
     int parts = 1;

@@ -448,7 +448,7 @@ int gvo_train_hot(int dim, float *vertex, float *context, const uint32_t *batch,
 /* Executor-simulator experiment (round 6): 1 = the pairs of a unit read a hub row as the unit FOUND it (before its chains) instead of as
  * its chains left it — a sample then computes its partner's update from the hub row without the hub's own step for that very sample. */
 static int gvo_pairs_read_before = 0;
-void gvo_set_pairs_read_before(int on) { gvo_pairs_read_before = on != 0; }
+void gvo_set_pairs_read_before(int on) { gvo_pairs_read_before = on; }  /* 2 (experiment): on the straight line from before to after, at the sample's place in the unit */
 
 int gvo_train_hot_moments(int dim, int type, float *vertex, float *context, float *vm1, float *cm1, float *vm2, float *cm2,
                           const uint32_t *batch, const uint32_t *negatives, float *loss, int batch_size, int k, float lr, float wd,
@@ -482,6 +482,8 @@ int gvo_train_hot_moments(int dim, int type, float *vertex, float *context, floa
         const size_t head = batch[2 * s + 1];
         const int hub_head = head < kv;
         memcpy(v, hub_head && gvo_pairs_read_before ? v0 + head * dim : vertex + head * dim, sizeof(float) * dim);
+        if (hub_head && gvo_pairs_read_before == 2)
+            for (int i = 0; i < dim; i++) v[i] += (s + 0.5f) / batch_size * (vertex[head * dim + i] - v[i]);
         float *pm1 = vm1 + head * dim, *pm2 = type == GVO_ADAM ? vm2 + head * dim : NULL;
         if (hub_head) {  /* the hub head's moment rows: copies */
             memcpy(tv1, pm1, sizeof(float) * dim), pm1 = tv1;
@@ -497,6 +499,8 @@ int gvo_train_hot_moments(int dim, int type, float *vertex, float *context, floa
             if (tail < kc) {  /* a hub target: copies, carried over when the next target is the same row */
                 if (!(have && tail == last)) {
                     memcpy(hub, gvo_pairs_read_before ? c0 + tail * dim : c, sizeof(float) * dim), memcpy(h1, q1, sizeof(float) * dim);
+                    if (gvo_pairs_read_before == 2)
+                        for (int i = 0; i < dim; i++) hub[i] += (s + 0.5f) / batch_size * (c[i] - hub[i]);
                     if (q2) memcpy(h2, q2, sizeof(float) * dim);
                 }
                 c = hub, q1 = h1, q2 = q2 ? h2 : NULL;

@@ -252,7 +252,7 @@ int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer,
     if (!executor || !*executor || !strcmp(executor, "sequential"))
         return gvk_train_episode(stream, dim, optimizer, linear_schedule, tables, pairs, negative, first_batch_id, batch_id_stride,
                                  total_batches, num_batches, loss, batch_size, num_negative, negative_weight);
-    gvo_set_pairs_read_before(getenv("GVH_PAIRS_READ") && !strcmp(getenv("GVH_PAIRS_READ"), "before"));  // experiment: hub rows as the unit found them
+    gvo_set_pairs_read_before(getenv("GVH_PAIRS_READ") ? (!strcmp(getenv("GVH_PAIRS_READ"), "before") ? 1 : (!strcmp(getenv("GVH_PAIRS_READ"), "lerp") ? 2 : 0)) : 0);  // experiment: hub rows as the unit found them
     gvo_set_pairs_at(getenv("GVH_PAIRS_AT") ? (float)atof(getenv("GVH_PAIRS_AT")) : -1.0f);  // ... SGD: with lerp, at this fixed place of the chains' way
     if (optimizer->type != GVK_SGD) {
         // a moment optimizer (round 6): every unit in the serialized form of its chains (gvo_train_hot_moments: one sequential task per hub
