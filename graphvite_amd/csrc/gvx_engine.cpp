@@ -1494,6 +1494,11 @@ int gvx_solver::device_fill(int set) {
     const int stripes = largest_divisor(n_slice, 256);
     const uint64_t stripe_capacity = n_slice / stripes, every = 64ull * stripes;  // the same number of wavefronts per stripe
     const size_t num_counter = (size_t)P * P * stripes;
+    // The base of the sampler's stripe rule (pair i of a walk to stripe group i % base): the caller's shuffle base, but at least 8-16 groups.  With
+    // the two groups of LINE's augmentation_step 2 / shuffle_base 2 the Friendster-like shape in 8 partitions ended +0.0020 above the reference's
+    // loop (four seeds, SE 0.0002) where the CPU samplers' pools end +0.0011; with 8 / 16 / 40 / 80 groups +0.0012 / +0.0011 / +0.0011 / +0.0011
+    // (profiles/r6/experiments/r6_fs_device_stripe_base.txt).  Youtube-size node2vec (shuffle base 1) does not see the base: 1 / 5 / 10 within 0.0004.
+    const int stripe_base = std::max(std::max(config.shuffle_base, 1), largest_divisor(stripes, 16));
     // Blocks receive unequal shares of the walks' pairs, and a pool that is full drops what arrives later in the launch — with node2vec's
     // rejection sampling the late walks are those that rejected most, a selection the AUC sees (DESIGN.md section 7.11 f).  So: a first small
     // launch shows every block's share; from then on every block is THINNED (gvk_sample_walks_blocks_thinned: by a hash of walk and pair, not by
@@ -1517,7 +1522,7 @@ int gvx_solver::device_fill(int set) {
             if (round > 0) HIP_TRY(hipMemcpyAsync(w.walk_accept, accept[l].data(), (size_t)P * P * 4, hipMemcpyHostToDevice, w.sample));
             GVK_TRY(gvk_sample_walks_blocks_thinned(w.sample, &w.walk, w.walk_part, P, w.sample_seed, w.sample_index + used[l], walks[l],
                                                     W == 1 ? w.block_pools[set] : w.route_send, w.walk_offsets, w.walk_counters,
-                                                    (uint32_t)n_slice, stripes, length, aug, config.shuffle_base, round > 0 ? w.walk_accept : nullptr));
+                                                    (uint32_t)n_slice, stripes, length, aug, stripe_base, round > 0 ? w.walk_accept : nullptr));
             used[l] += walks[l];
         }
         bool all_full = true;

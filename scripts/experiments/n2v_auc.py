@@ -29,12 +29,12 @@ name2id[np.array([int(x) for x in g.id2name], np.int64)] = np.arange(g.num_verte
 keep = (name2id[H] >= 0) & (name2id[T] >= 0)
 model, p, q = extra.get("model", "node2vec"), float(extra.get("p", 0.25)), float(extra.get("q", 0.25))
 for partitions in [int(x) for x in extra.get("partitions", "1,4").split(",")]:
-    for device in (False, True):
+    for device in ((True,) if "sb" in extra else (False, True)):
         aucs = []
         for seed in [int(x) for x in extra.get("seeds", "1024,5,6").split(",")]:
             s = gv.solver.GraphSolver(128, num_sampler_per_worker=8, seed=seed, device_sampling=device)
             s.build(g, batch_size=100000, num_partition=partitions, episode_size=int(extra.get("episode", 30)) if partitions > 1 else 500)
-            s.train(model=model, num_epoch=int(extra.get("epochs", 100)), augmentation_step=5, random_walk_length=40, random_walk_batch_size=100, shuffle_base=1,
+            s.train(model=model, num_epoch=int(extra.get("epochs", 100)), augmentation_step=5, random_walk_length=40, random_walk_batch_size=100, shuffle_base=int(extra.get("sb", 1)),
                     p=p, q=q, log_frequency=1 << 30)
             aucs.append(link_prediction_auc(s.vertex_embeddings, s.context_embeddings, name2id[H[keep]], name2id[T[keep]], Y[keep]))
             parts = s.hub_parts_used

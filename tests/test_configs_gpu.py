@@ -156,7 +156,9 @@ def test_moment_optimizers_on_the_headline_shape(job, optimizer):
     spec = JOBS[job][7]
     make = dict(Momentum=lambda: gv.optimizer.Momentum(spec[1], spec[2], *spec[3:]), Adam=lambda: gv.optimizer.Adam(spec[1], spec[2]))[optimizer]
     aucs = []
-    for seed in SEEDS[:3]:
+    # Adam 1e-3 is far from converged after 50 epochs and both loops spread widely over seeds (the reference's own eight: 0.6240 ... 0.6336, sd 0.0030;
+    # here sd 0.002-0.0035): eight seeds on either side, and even then the difference of the means carries an SE of 0.0015
+    for seed in (SEEDS + (8, 9, 10, 11) if optimizer == "Adam" else SEEDS[:3]):
         auc, reference, info = train(job, seed, optimizer=make())
         assert info["hub_rows"] > 0 and info["parts"] > 1, info
         aucs.append(auc)
@@ -166,7 +168,8 @@ def test_moment_optimizers_on_the_headline_shape(job, optimizer):
     except AssertionError as outside:
         if optimizer != "Adam":
             raise
-        # Measured on the MI355X (round 6, profiles/r6/parity_auc.log): Adam 1e-3 with chains ends 0.0032 (SE 0.0011; the reference's own
-        # three seeds spread over 0.0033) below the reference's loop — pair by pair it was 0.0145 below.  north_star's +-0.002 is NOT met
-        # for this optimizer: an expected failure that says so, not a wider bound.
+        # Measured on the MI355X (round 6, profiles/r6/experiments/r6_adam_seeds8.txt), eight seeds here against the reference's eight (0.62945):
+        # a batch as 8 / 16 / 32 / 100 parts -0.0021 / -0.0012 / -0.0006 / -0.0003 (SE 0.0015); the moment optimizers train a batch as 32 parts since.
+        # Against the golden's first four seeds alone (0.63164) the same runs read -0.0043 ... -0.0024, which is what earlier sessions reported.  With
+        # this spread a run can still land outside +-0.002: reported as an expected failure with its line, not hidden behind a wider bound.
         pytest.xfail("Adam on the headline shape: %s (tolerance 0.002; pair by pair: -0.0145)" % (outside.args[0],))
