@@ -563,6 +563,23 @@ def walk_blocks_layout():
                 stored = pools[b][k * (capacity // stripes) + np.arange(len(mine))]
                 expect = np.stack([local[mine[:, 0]], local[mine[:, 1]]], 1)
                 assert sorted(map(tuple, stored.tolist())) == sorted(map(tuple, expect.tolist()))
+        # thinned (gvk_sample_walks_blocks_thinned): every block keeps a pair with a probability of its own, decided by a hash of (walk, pair index, seed)
+        from util import thinning_uniform
+        accept = np.random.default_rng(P).uniform(0.2, 0.9, P * P).astype(np.float32)
+        accept[0], accept[-1] = 1.0, 0.0
+        keep = thinning_uniform(first + index // per_walk, index % per_walk, seed) < accept[block]
+        assert abs(keep[accept[block] < 1].mean() - accept[block][accept[block] < 1].mean()) < 0.02 and keep[block == 0].all() and not keep[block == P * P - 1].any()
+        pools[:], counters[:] = 0, 0
+        rc = lib.gvk_sample_walks_blocks_thinned(None, C.byref(desc), part32.ctypes.data, P, seed, first, walks, pools.ctypes.data,
+                                                 where.ctypes.data, counters.ctypes.data, capacity, stripes, L, aug, sb, accept.ctypes.data)
+        assert rc == 0
+        for b in range(P * P):
+            for k in range(stripes):
+                mine = want[(block == b) & (stripe_of == k) & keep]
+                assert counters[b, k] == len(mine), (b, k, counters[b, k], len(mine))
+                stored = pools[b][k * (capacity // stripes) + np.arange(len(mine))]
+                expect = np.stack([local[mine[:, 0]], local[mine[:, 1]]], 1)
+                assert sorted(map(tuple, stored.tolist())) == sorted(map(tuple, expect.tolist()))
         if sb > 1:  # pairs i and i + 1 of a walk: different parts of the pool — at least a part minus a stripe of records between them
             same_walk = index[:-1] // per_walk == index[1:] // per_walk
             gap = np.abs(stripe_of[1:] - stripe_of[:-1])[same_walk]

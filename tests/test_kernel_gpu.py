@@ -566,6 +566,30 @@ def test_sample_walks_blocks_matches_the_oracle_per_block(hip, oracle, biased):
             stored = got[b][k * (capacity // stripes) + np.arange(len(mine))]
             expect = np.stack([local[mine[:, 0]], local[mine[:, 1]]], 1)
             assert sorted(map(tuple, stored.tolist())) == sorted(map(tuple, expect.tolist()))
+    # thinned (gvk_sample_walks_blocks_thinned): every block keeps a pair with a probability of its own, decided by a hash of (walk, pair index in
+    # the walk, seed) — not by when the pair arrives: exactly the oracle's pairs the rule keeps, per block and stripe
+    from util import thinning_uniform
+    accept = np.random.default_rng(5).uniform(0.2, 0.9, P * P).astype(np.float32)
+    accept[0], accept[-1] = 1.0, 0.0
+    keep = thinning_uniform(first + index // per_walk, index % per_walk, seed) < accept[block]
+    pools.zero_(), counters.zero_()
+    rc = hip.lib.gvk_sample_walks_blocks_thinned(None, C.byref(desc), part_dev.data_ptr(), P, seed, first, walks, pools.data_ptr(), where_dev.data_ptr(),
+                                                 counters.data_ptr(), capacity, stripes, L, aug, sb, dev(accept).data_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = pools.cpu().numpy().view(np.uint32).reshape(P * P, capacity, 2)
+    count = counters.cpu().numpy().reshape(P * P, stripes)
+    assert not count[P * P - 1].any() and count[0].sum() == np.count_nonzero(block == 0)
+    for b in range(P * P):
+        if b == 4:
+            assert not count[b].any()
+            continue
+        for k in range(stripes):
+            mine = want[(block == b) & (stripe_of == k) & keep]
+            assert count[b, k] == len(mine), (b, k, count[b, k], len(mine))
+            stored = got[b][k * (capacity // stripes) + np.arange(len(mine))]
+            expect = np.stack([local[mine[:, 0]], local[mine[:, 1]]], 1)
+            assert sorted(map(tuple, stored.tolist())) == sorted(map(tuple, expect.tolist()))
     # the wrapper: small pools, repeated until every collected pool is full; only pairs of the block, local ids
     small = 600
     pools = torch.full((P * P * small * 2,), -1, dtype=torch.int32, device=DEV)

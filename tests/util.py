@@ -52,3 +52,19 @@ def compare_auc(label, here, reference, tolerance=0.002):
         len(reference), difference, se, verdict))
     assert abs(difference) <= tolerance, (label, difference, se)
     return difference, se
+
+
+def thinning_uniform(walk, i, seed):
+    """include/gvk.h gvk_sample_walks_blocks_thinned, restated: the uniform in [0, 1) that decides whether pair i of walk `walk` is kept
+    (kept when it is below the block's rate) — fmix32 of the walk's two halves, the pair's index and the seed's low half, 24 bits."""
+    walk, i = np.asarray(walk, np.uint64), np.asarray(i, np.uint64)
+    m = np.uint64(0xffffffff)
+    h = (walk & m) ^ (((walk >> np.uint64(32)) * np.uint64(0x85ebca6b)) & m) ^ ((i * np.uint64(0x9e3779b9)) & m) ^ \
+        np.uint64(((int(seed) & 0xffffffff) * 0xc2b2ae35) & 0xffffffff)
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x85ebca6b)) & m
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xc2b2ae35)) & m
+    h ^= h >> np.uint64(16)
+    return ((h >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)).astype(np.float32)
+
