@@ -588,6 +588,10 @@ def main(argv=None):
                       "compare with the one-GPU rate at the same shard size (bench.py --partitions), not with the 512 MB "
                       "tables of the one-partition run" if 2 * shard_bytes <= INFINITY_CACHE_BYTES else
                       "tables larger than the caches: HBM-bound")
+    solver._refresh()
+    prefetched = int(getattr(solver, "lists_prefetched", 0))
+    work_lists_note = ("%d visit(s) of this process trained lists built while the visit before them trained; a timed visit builds the next visit's "
+                       "inside the timed region" % prefetched) if prefetched else "built when a visit begins"
     result = {
         "metric": "million edge-samples/sec at dim=%d" % dim,
         "value": world * args.steps * B / wall / 1e6,
@@ -604,6 +608,9 @@ def main(argv=None):
                                   % (world, partitions, args.block_batches, solver.transport or "one worker: none"),
                    "engine": "native solver engine (include/gvx.h) stepped through its session API",
                    "block_batches": args.block_batches, "block_visits_timed": visits,
+                   # the work lists of a visit's first chunk are built while the visit before it trains (gvx_engine.cpp prefetch_lists): every timed visit
+                   # builds the lists of the visit after it inside the timed region, as the steady state of the episode loop does
+                   "work_lists": work_lists_note,
                    "shard": {"rows": rows, "table_bytes": shard_bytes, "residency": residency_note},
                    "negative_table": solver.negative_table,
                    "pair_order": solver.pair_order + (" (gvk_group_pairs once per block visit on the copy stream)"
