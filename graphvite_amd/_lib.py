@@ -142,6 +142,8 @@ def lib():
     l.gvk_hot_plan.argtypes = [i32, i32, i32, u32, u32, i32, i32, i32, P(C.c_size_t)]
     l.gvk_hot_build.restype = i32
     l.gvk_hot_build.argtypes = [vp, i32, vp, C.c_size_t, vp, i32, i32, i32, P(NegativeSource), u32, u32, u32, u32, i32, i32]
+    l.gvk_hot_build_sliced.restype = i32
+    l.gvk_hot_build_sliced.argtypes = [vp, i32, vp, C.c_size_t, vp, i32, i32, i32, P(NegativeSource), u32, u32, u32, u32, i32, i32, i32]
     l.gvk_train_episode_hot.restype = i32
     l.gvk_train_episode_hot.argtypes = [vp, i32, P(Optimizer), i32, P(Tables), vp, P(NegativeSource), u32, u32, u32, i32, vp,
                                         i32, i32, f32, vp, C.c_size_t, u32, u32, i32, i32, i32, i32]

@@ -848,19 +848,20 @@ constexpr int kListThreads = 1024;
 __global__ void __launch_bounds__(kListThreads) hot_list_kernel(TrainArgs a, const uint32_t first_batch_id, const uint32_t stride,
                                                                 uint32_t *chain_start_all, uint32_t *entries_all, uint32_t *long_all,
                                                                 uint32_t *short_all, const uint32_t entry_capacity, const uint32_t long_capacity,
-                                                                const uint32_t cap, const int parts) {
+                                                                const uint32_t cap, const int parts, const uint32_t first_unit) {
     extern __shared__ uint32_t bins[];  // [chains]
     __shared__ uint32_t wave_total[kListThreads / 64];
     __shared__ uint32_t long_count, short_count;
     const uint32_t chains = a.hot_vertex + a.hot_context;
-    // list blockIdx.x = part (blockIdx.x % parts) of batch (blockIdx.x / parts): samples [lo, hi) of the batch
+    // list `unit` = part (unit % parts) of batch (unit / parts): samples [lo, hi) of the batch; a launch covers the units from first_unit on
     const int B = a.batch_size, k = a.k;
-    const int batch = blockIdx.x / parts, lo = (int)(blockIdx.x % parts) * (B / parts), hi = lo + B / parts;
+    const uint32_t unit = first_unit + blockIdx.x;
+    const int batch = (int)(unit / (uint32_t)parts), lo = (int)(unit % (uint32_t)parts) * (B / parts), hi = lo + B / parts;
     const u32x2 *records = reinterpret_cast<const u32x2 *>(a.pairs) + (size_t)batch * B;
-    uint32_t *chain_start = chain_start_all + (size_t)blockIdx.x * (chains + 1);
-    uint32_t *entries = entries_all + (size_t)blockIdx.x * entry_capacity;
-    uint32_t *long_list = long_all + (size_t)blockIdx.x * 4 * (1 + (size_t)long_capacity);
-    uint32_t *short_list = short_all + (size_t)blockIdx.x * 16 * (1 + (size_t)chains);
+    uint32_t *chain_start = chain_start_all + (size_t)unit * (chains + 1);
+    uint32_t *entries = entries_all + (size_t)unit * entry_capacity;
+    uint32_t *long_list = long_all + (size_t)unit * 4 * (1 + (size_t)long_capacity);
+    uint32_t *short_list = short_all + (size_t)unit * 16 * (1 + (size_t)chains);
     a.batch_id = first_batch_id + (uint32_t)batch * stride;
 
     for (uint32_t i = threadIdx.x; i < chains; i += kListThreads) bins[i] = 0;
@@ -1215,6 +1216,14 @@ int gvk_hot_plan(int dim, int batch_size, int num_negative, uint32_t hot_vertex,
 int gvk_hot_build(void *stream, int dim, void *workspace, size_t workspace_bytes, const uint32_t *pool, int batch_size, int num_batch,
                   int num_negative, const gvk_negative_source *negative, uint32_t first_batch_id, uint32_t batch_id_stride,
                   uint32_t hot_vertex, uint32_t hot_context, int parts, int chain_cap) {
+    return gvk_hot_build_sliced(stream, dim, workspace, workspace_bytes, pool, batch_size, num_batch, num_negative, negative, first_batch_id, batch_id_stride,
+                                hot_vertex, hot_context, parts, chain_cap, 0);
+}
+
+int gvk_hot_build_sliced(void *stream, int dim, void *workspace, size_t workspace_bytes, const uint32_t *pool, int batch_size, int num_batch,
+                         int num_negative, const gvk_negative_source *negative, uint32_t first_batch_id, uint32_t batch_id_stride,
+                         uint32_t hot_vertex, uint32_t hot_context, int parts, int chain_cap, int units_per_launch) {
+    if (units_per_launch < 0) return fail(GVK_EINVAL, "gvk_hot_build_sliced: negative units_per_launch");
     int rc = validate_hot("gvk_hot_build", dim, batch_size, num_negative, hot_vertex, hot_context, num_batch, parts);
     if (rc != GVK_OK) return rc;
     if (num_batch == 0) return GVK_OK;
@@ -1238,10 +1247,12 @@ int gvk_hot_build(void *stream, int dim, void *workspace, size_t workspace_bytes
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kMaxChains * 4));
         if (e != hipSuccess) return gvk_fail(GVK_EHIP, "gvk_hot_build: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(hot_list_kernel, dim3((unsigned)(num_batch * parts)), dim3(kListThreads), lds, (hipStream_t)stream, a,
-                       first_batch_id, batch_id_stride, reinterpret_cast<uint32_t *>(base + l.chain_start),
-                       reinterpret_cast<uint32_t *>(base + l.entries), reinterpret_cast<uint32_t *>(base + l.long_list),
-                       reinterpret_cast<uint32_t *>(base + l.short_list), l.entry_capacity, l.long_capacity, l.cap, parts);
+    const int units = num_batch * parts, slice = units_per_launch > 0 && units_per_launch < units ? units_per_launch : units;
+    for (int first = 0; first < units; first += slice)
+        hipLaunchKernelGGL(hot_list_kernel, dim3((unsigned)std::min(slice, units - first)), dim3(kListThreads), lds, (hipStream_t)stream, a,
+                           first_batch_id, batch_id_stride, reinterpret_cast<uint32_t *>(base + l.chain_start),
+                           reinterpret_cast<uint32_t *>(base + l.entries), reinterpret_cast<uint32_t *>(base + l.long_list),
+                           reinterpret_cast<uint32_t *>(base + l.short_list), l.entry_capacity, l.long_capacity, l.cap, parts, (uint32_t)first);
     return check_launch("gvk_hot_build");
 }
 

@@ -48,6 +48,7 @@ constexpr int kMinBatchSize = 10000;
 constexpr int kSamplePerVertex = 175;
 constexpr double kHubHits = 1.0;           // GVX_HUB_ROWS -1: a row a BATCH is expected to hit this often is a hub row (§7.10)
 constexpr double kHubHitsPerPart = 0.125;  // ... and no row outside the chains is to be hit more often than this per PART of a batch: the parts follow (hub_parts_of)
+constexpr int kHubListSlice = 32;           // GVX_LIST_SLICE: units of work lists per launch when the lists are built ahead (build_lists)
 constexpr double kHubRoundShare = 0.02;    // GVX_HUB_ROUNDS -1: long chains work in rounds where the graph's largest vertex takes more than this share of its total degree (§7.11)
 constexpr uint64_t kMaxHubRows = 16384;  // per table (gvk_hot_build counts the chains of both tables in LDS)
 constexpr int kHubChunk = 128;          // batches whose work lists are built at once
@@ -379,7 +380,7 @@ struct gvx_solver {
     int hub_parts_of(int hp, int tp) const;
     int hub_workspace_for(Worker &w, size_t need);
     gvk_negative_source negative_source(Worker &w, int tp);
-    int build_lists(Worker &w, int hp, int tp, const uint32_t *batches, uint64_t first_id, int m, int parts);
+    int build_lists(Worker &w, int hp, int tp, const uint32_t *batches, uint64_t first_id, int m, int parts, bool ahead);
     int prefetch_lists(Worker &w, uint64_t next_batch_id);
     void discard_prefetched(Worker &w);
     bool hub_rounds_of(int hp, int tp) const;
@@ -1875,7 +1876,7 @@ gvk_negative_source gvx_solver::negative_source(Worker &w, int tp) {
 
 // The work lists of m batches of block (hp, tp) — the batches at `batches`, ids first_id, first_id + W, ... — on the lists stream into the
 // workspace whose turn it is (two in rotation; it waits until the chunk that trained out of that workspace last has trained).
-int gvx_solver::build_lists(Worker &w, int hp, int tp, const uint32_t *batches, uint64_t first_id, int m, int parts) {
+int gvx_solver::build_lists(Worker &w, int hp, int tp, const uint32_t *batches, uint64_t first_id, int m, int parts, bool ahead) {
     const int slot = (int)(w.chunks_built & 1);
     const uint32_t kv = hub_rows[hp], kc = hub_rows[tp];
     gvk_negative_source neg = negative_source(w, tp);
@@ -1883,9 +1884,16 @@ int gvx_solver::build_lists(Worker &w, int hp, int tp, const uint32_t *batches, 
     if (hub_ahead())
         GVK_TRY(gvk_ahead_build(w.lists, dim, w.hub_workspaces[slot], w.hub_workspace_bytes, batches, batch_size, m, num_negative, &neg, (uint32_t)first_id,
                                 (uint32_t)num_worker, kv, kc, parts, hub_chain_cap_request, hub_group_of(parts)));
-    else
-        GVK_TRY(gvk_hot_build(w.lists, dim, w.hub_workspaces[slot], w.hub_workspace_bytes, batches, batch_size, m, num_negative, &neg, (uint32_t)first_id,
-                              (uint32_t)num_worker, kv, kc, parts, hub_chain_cap_request));
+    else {
+        // Lists built AHEAD run beside the launches that train the chunk before them: a few list workgroups at a time (each holds a compute unit's
+        // wave slots and half its registers for 0.1 ms; a whole visit's at once slowed seven training launches of the headline shape to 20-41 us
+        // from 14.5 — kernel trace of profiles/r6 —, a few at a time cost nothing: a training launch ends with its longest chain, its pairs have slack).
+        // Lists the training waits for are built in one launch.  GVX_LIST_SLICE: units per launch (0: never slice).
+        const char *knob = getenv("GVX_LIST_SLICE");
+        const int slice = ahead ? (knob ? std::max(atoi(knob), 0) : kHubListSlice) : 0;
+        GVK_TRY(gvk_hot_build_sliced(w.lists, dim, w.hub_workspaces[slot], w.hub_workspace_bytes, batches, batch_size, m, num_negative, &neg, (uint32_t)first_id,
+                                     (uint32_t)num_worker, kv, kc, parts, hub_chain_cap_request, slice));
+    }
     HIP_TRY(hipEventRecord(w.lists_built[slot], w.lists));
     w.chunks_built++;
     return GVK_OK;
@@ -1925,7 +1933,7 @@ int gvx_solver::prefetch_lists(Worker &w, uint64_t next_batch_id) {
     HIP_TRY(hipStreamWaitEvent(w.lists, w.uploaded[s.b], 0));
     if (w.block_pools[0]) HIP_TRY(hipStreamWaitEvent(w.lists, w.filled[s.set], 0));
     const void *workspace = w.hub_workspaces[w.chunks_built & 1];
-    GVK_TRY(build_lists(w, s.hp, s.tp, pool, first, m, parts));
+    GVK_TRY(build_lists(w, s.hp, s.tp, pool, first, m, parts, true));
     w.prefetched.valid = true;
     w.prefetched.pool = pool, w.prefetched.workspace = workspace, w.prefetched.first = first;
     w.prefetched.m = m, w.prefetched.parts = parts, w.prefetched.cap = hub_chain_cap_request, w.prefetched.set = s.set, w.prefetched.b = s.b;
@@ -1985,7 +1993,7 @@ int gvx_solver::train_block(Worker &w, int hp, int tp, const uint32_t *pool, int
             // the pool: train_step) — nothing but training launches on the compute stream.
             const int pair_launches = hub_pair_launches_request > 0 && parts % hub_pair_launches_request == 0 ? hub_pair_launches_request : 0;
             auto build = [&](int at) -> int {
-                return build_lists(w, hp, tp, pool + (size_t)(done + at) * B * 2, first + (uint64_t)at * W, std::min(chunk, n - at), parts);
+                return build_lists(w, hp, tp, pool + (size_t)(done + at) * B * 2, first + (uint64_t)at * W, std::min(chunk, n - at), parts, at > 0);
             };
             // the first chunk may be there already: built while the visit before this one trained its last chunk (prefetch_lists)
             bool built = false;

@@ -233,6 +233,11 @@ int gvk_hot_build(void *, int, void *workspace, size_t, const uint32_t *pool, in
     return workspace && pool && negative ? GVK_OK : gvk_fail(GVK_EINVAL, "gvk_hot_build: null argument");
 }
 
+int gvk_hot_build_sliced(void *, int, void *workspace, size_t, const uint32_t *pool, int, int, int, const gvk_negative_source *negative, uint32_t,
+                         uint32_t, uint32_t, uint32_t, int, int, int units_per_launch) {
+    return workspace && pool && negative && units_per_launch >= 0 ? GVK_OK : gvk_fail(GVK_EINVAL, "gvk_hot_build_sliced: bad argument");
+}
+
 int gvk_train_episode_hot(void *stream, int dim, const gvk_optimizer *optimizer, int linear_schedule, const gvk_tables *tables,
                           const uint32_t *pairs, const gvk_negative_source *negative, uint32_t first_batch_id,
                           uint32_t batch_id_stride, uint32_t total_batches, int num_batches, float *loss, int batch_size,

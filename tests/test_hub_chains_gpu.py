@@ -307,6 +307,41 @@ def test_a_batch_trained_as_parts(hip, oracle, executor):
 
 
 # shape: (nodes, edges, exponent, generator seed, partitions, parts, rounds) — parts / rounds as gvx_engine.cpp configure gives them for the shape
+def test_lists_built_in_slices_are_the_lists(hip):
+    """gvk_hot_build_sliced: the list kernel as launches of a few units each (what the engine does for lists it builds ahead, beside the
+    launches that train the chunk before) writes the lists gvk_hot_build writes — offsets identical, every chain's entries the same multiset."""
+    import ctypes as C
+    rng = np.random.default_rng(21)
+    N, B, kv, kc, dim, k, parts, batches = 1 << 14, 1200, 24, 40, 128, 1, 3, 3
+    pool, w = hub_case(rng, N, B, batches, kv, kc)
+    table = negative_table(w, False)
+    dpool = torch.from_numpy(pool.view(np.int32)).to(DEV)
+    chains, units = kv + kc, batches * parts
+    _, entry_capacity, off = layout(B, k, chains, batches, 0, parts)
+    bytes_needed = hip.hot_plan(dim, B, k, kv, kc, batches, parts)
+    got = {}
+    for slice_units in (0, 1, 4, 100):
+        ws = torch.zeros(bytes_needed, dtype=torch.uint8, device=DEV)
+        neg = hip._negative(None, table, SEED, torch.device(DEV))
+        rc = hip.lib.gvk_hot_build_sliced(None, dim, ws.data_ptr(), ws.numel(), dpool.data_ptr(), B, batches, k, C.byref(neg), FIRST_ID, 1, kv, kc, parts, 0,
+                                          slice_units)
+        assert rc == 0
+        torch.cuda.synchronize()
+        raw = ws.cpu().numpy()
+        starts = raw[:units * (chains + 1) * 4].view(np.uint32).reshape(units, chains + 1).copy()
+        entries = raw[off:off + units * entry_capacity * 4].view(np.uint32).reshape(units, entry_capacity)
+        per_chain = [[np.sort(entries[u, starts[u, ch]:starts[u, ch + 1]]) for ch in range(chains)] for u in range(units)]
+        got[slice_units] = (starts, per_chain)
+    assert got[0][0][:, -1].min() > 0
+    for slice_units in (1, 4, 100):
+        assert (got[slice_units][0] == got[0][0]).all()
+        for u in range(units):
+            for ch in range(chains):
+                assert (got[slice_units][1][u][ch] == got[0][1][u][ch]).all(), (slice_units, u, ch)
+    rc = hip.lib.gvk_hot_build_sliced(None, dim, ws.data_ptr(), ws.numel(), dpool.data_ptr(), B, batches, k, C.byref(neg), FIRST_ID, 1, kv, kc, parts, 0, -1)
+    assert rc != 0
+
+
 HUB_SHAPES = {
     "headline": (1000000, 10000000, 2.3, 1024, 1, 8, False),        # configs[1], one partition
     "headline_p8": (1000000, 10000000, 2.3, 1024, 8, 32, False),    # ... block (0, 0) of its 8 partitions: the shard an 8-GPU run trains
