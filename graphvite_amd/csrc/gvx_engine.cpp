@@ -48,7 +48,7 @@ constexpr int kMinBatchSize = 10000;
 constexpr int kSamplePerVertex = 175;
 constexpr double kHubHits = 1.0;           // GVX_HUB_ROWS -1: a row a BATCH is expected to hit this often is a hub row (§7.10)
 constexpr double kHubHitsPerPart = 0.125;  // ... and no row outside the chains is to be hit more often than this per PART of a batch: the parts follow (hub_parts_of)
-constexpr int kHubListSlice = 32;           // GVX_LIST_SLICE: units of work lists per launch when the lists are built ahead (build_lists)
+constexpr int kHubListSlice = 0;            // GVX_LIST_SLICE: units of work lists per launch when the lists are built ahead (build_lists); 0: one launch (measured: slices are slower)
 constexpr double kHubRoundShare = 0.02;    // GVX_HUB_ROUNDS -1: long chains work in rounds where the graph's largest vertex takes more than this share of its total degree (§7.11)
 constexpr uint64_t kMaxHubRows = 16384;  // per table (gvk_hot_build counts the chains of both tables in LDS)
 constexpr int kHubChunk = 128;          // batches whose work lists are built at once
@@ -1885,10 +1885,11 @@ int gvx_solver::build_lists(Worker &w, int hp, int tp, const uint32_t *batches, 
         GVK_TRY(gvk_ahead_build(w.lists, dim, w.hub_workspaces[slot], w.hub_workspace_bytes, batches, batch_size, m, num_negative, &neg, (uint32_t)first_id,
                                 (uint32_t)num_worker, kv, kc, parts, hub_chain_cap_request, hub_group_of(parts)));
     else {
-        // Lists built AHEAD run beside the launches that train the chunk before them: a few list workgroups at a time (each holds a compute unit's
-        // wave slots and half its registers for 0.1 ms; a whole visit's at once slowed seven training launches of the headline shape to 20-41 us
-        // from 14.5 — kernel trace of profiles/r6 —, a few at a time cost nothing: a training launch ends with its longest chain, its pairs have slack).
-        // Lists the training waits for are built in one launch.  GVX_LIST_SLICE: units per launch (0: never slice).
+        // Lists built AHEAD run beside the launches that train the chunk before them, and a visit's list workgroups at once slow seven of those
+        // launches (headline shape: 20-41 us from 14.5, kernel trace of profiles/r6).  Building them a few units per launch (gvk_hot_build_sliced) was
+        // measured and is SLOWER — 16 / 32 / 64 units per launch 723 / 775-782 / 779 against 789-813 M/s in one launch, 221 against 231 at the shard
+        // size of an 8-GPU run (profiles/r6/experiments/r6_list_slice_ab.txt): the disturbance lasts as many launches longer as it is thinner.  One
+        // launch stays; GVX_LIST_SLICE = units per launch is the measurement knob.
         const char *knob = getenv("GVX_LIST_SLICE");
         const int slice = ahead ? (knob ? std::max(atoi(knob), 0) : kHubListSlice) : 0;
         GVK_TRY(gvk_hot_build_sliced(w.lists, dim, w.hub_workspaces[slot], w.hub_workspace_bytes, batches, batch_size, m, num_negative, &neg, (uint32_t)first_id,

@@ -206,10 +206,8 @@ int gvk_hot_build(void *stream, int dim, void *workspace, size_t workspace_bytes
                   int num_batch, int num_negative, const gvk_negative_source *negative, uint32_t first_batch_id,
                   uint32_t batch_id_stride, uint32_t hot_vertex, uint32_t hot_context, int parts, int chain_cap);
 /* gvk_hot_build as launches of at most units_per_launch units each (a unit = a part of a batch = one workgroup of the list kernel; 0 = all
- * in one launch = gvk_hot_build): for lists built AHEAD, beside the launches that train the chunk before.  A list workgroup holds a
- * compute unit's wave slots and half its registers for 0.1 ms; a whole chunk's at once halve the training kernel's throughput on most of the
- * chip for that long, a few at a time cost it nothing — a training launch ends with its longest chain, its pairs have slack (DESIGN.md
- * section 3.1.2).  Same lists, same bits. */
+ * in one launch = gvk_hot_build).  Same lists.  A measurement form: lists built ahead run beside the launches that train the chunk before
+ * and slow some of them; thinner launches were measured slower still (profiles/r6/experiments/r6_list_slice_ab.txt), callers use gvk_hot_build. */
 int gvk_hot_build_sliced(void *stream, int dim, void *workspace, size_t workspace_bytes, const uint32_t *pool, int batch_size,
                          int num_batch, int num_negative, const gvk_negative_source *negative, uint32_t first_batch_id,
                          uint32_t batch_id_stride, uint32_t hot_vertex, uint32_t hot_context, int parts, int chain_cap, int units_per_launch);
