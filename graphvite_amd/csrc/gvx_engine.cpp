@@ -1136,7 +1136,16 @@ int gvx_solver::prepare_devices() {
             HIP_TRY(hipExtStreamCreateWithCUMask(&w.chains, (uint32_t)words, chain_mask.data()));
         } else
         HIP_TRY(hipStreamCreateWithFlags(&w.chains, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&w.lists, hipStreamNonBlocking));
+        {  // GVX_LISTS_PRIORITY=low / high (measurement): the lists stream at the device's least / greatest priority — measured: 337-366 / 299 against 808 M/s
+           // (profiles/r6/experiments/r6_lists_priority_ab.txt): an ordinary stream stays
+            const char *knob = getenv("GVX_LISTS_PRIORITY");
+            int least = 0, greatest = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            if (knob && (!strcmp(knob, "low") || !strcmp(knob, "high")))
+                HIP_TRY(hipStreamCreateWithPriority(&w.lists, hipStreamNonBlocking, !strcmp(knob, "low") ? least : greatest));
+            else
+                HIP_TRY(hipStreamCreateWithFlags(&w.lists, hipStreamNonBlocking));
+        }
         for (int b = 0; b < 2; b++) {
             HIP_TRY(hipEventCreateWithFlags(&w.lists_built[b], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&w.lists_trained[b], hipEventDisableTiming));

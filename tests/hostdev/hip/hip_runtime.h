@@ -49,6 +49,8 @@ inline hipError_t hipMemcpy2DAsync(void *to, size_t to_pitch, const void *from, 
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)malloc(1); return hipSuccess; }
 struct hipDeviceProp_t { int multiProcessorCount = 256; };
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *, int) { return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned flags, int) { return hipStreamCreateWithFlags(s, flags); }
+inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 0, *greatest = 0; return hipSuccess; }
 inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t *s, uint32_t, const uint32_t *) { return hipStreamCreateWithFlags(s, 0); }
 inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
