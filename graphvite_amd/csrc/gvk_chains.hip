@@ -844,7 +844,6 @@ __global__ void __launch_bounds__(kBlock) hub_rows_kernel(float *vertex, float *
 // those of 1 .. cap entries in short_list (train_short_chains: records of 16 words from word 16 on — {chain, entries, first
 // entry, -} and, from word 4, the entries themselves).
 constexpr int kListThreads = 1024;
-constexpr int kListTile = 7;  // samples a thread of the list kernel has in flight (a part of 12 500 samples: two tiles)
 
 __global__ void __launch_bounds__(kListThreads) hot_list_kernel(TrainArgs a, const uint32_t first_batch_id, const uint32_t stride,
                                                                 uint32_t *chain_start_all, uint32_t *entries_all, uint32_t *long_all,
@@ -868,34 +867,15 @@ __global__ void __launch_bounds__(kListThreads) hot_list_kernel(TrainArgs a, con
     for (uint32_t i = threadIdx.x; i < chains; i += kListThreads) bins[i] = 0;
     if (threadIdx.x == 0) long_count = 0, short_count = 0;
     __syncthreads();
-    // A: how many entries every chain gets.  kListTile samples per thread at a time: their records are requested together, then their draws'
-    // alias entries together — one sample after the other the loop was two dependent round trips per sample, thirteen samples per thread
-    for (int base = lo; base < hi; base += kListThreads * kListTile) {
-        u32x2 pr[kListTile];
-#pragma unroll
-        for (int t = 0; t < kListTile; t++) {
-            const int s = base + t * kListThreads + (int)threadIdx.x;
-            pr[t] = s < hi ? records[s] : u32x2{0xffffffffu, 0xffffffffu};
-        }
-#pragma unroll
-        for (int t = 0; t < kListTile; t++) {
-            if (pr[t].y < a.hot_vertex) atomicAdd(&bins[pr[t].y], (uint32_t)(k + 1));
-            if (pr[t].x < a.hot_context) atomicAdd(&bins[a.hot_vertex + pr[t].x], 1u);
-        }
+    // A: how many entries every chain gets
+    for (int s = lo + threadIdx.x; s < hi; s += kListThreads) {
+        const u32x2 pr = records[s];
+        if (pr.y < a.hot_vertex) atomicAdd(&bins[pr.y], (uint32_t)(k + 1));
+        if (pr.x < a.hot_context) atomicAdd(&bins[a.hot_vertex + pr.x], 1u);
         for (int j = 0; j < k; j++) {
-            Draw d[kListTile];
-            NegEntry e[kListTile];
-#pragma unroll
-            for (int t = 0; t < kListTile; t++) {
-                const int s = base + t * kListThreads + (int)threadIdx.x;
-                d[t] = negative_slot(a, (uint32_t)(s < hi ? s : lo), (uint32_t)j);
-                e[t] = load_entry(a, d[t]);
-            }
-#pragma unroll
-            for (int t = 0; t < kListTile; t++) {
-                const uint32_t n = resolve(a, d[t], e[t]);
-                if (base + t * kListThreads + (int)threadIdx.x < hi && n < a.hot_context) atomicAdd(&bins[a.hot_vertex + n], 1u);
-            }
+            const Draw d = negative_slot(a, (uint32_t)s, (uint32_t)j);
+            const uint32_t n = resolve(a, d, load_entry(a, d));
+            if (n < a.hot_context) atomicAdd(&bins[a.hot_vertex + n], 1u);
         }
     }
     __syncthreads();
@@ -933,39 +913,19 @@ __global__ void __launch_bounds__(kListThreads) hot_list_kernel(TrainArgs a, con
     }
     __syncthreads();
     if (threadIdx.x == 0) long_list[0] = long_count, short_list[0] = short_count;
-    // B: scatter (tiles as in A)
-    for (int base = lo; base < hi; base += kListThreads * kListTile) {
-        u32x2 pr[kListTile];
-        uint32_t at[kListTile];
-#pragma unroll
-        for (int t = 0; t < kListTile; t++) {
-            const int s = base + t * kListThreads + (int)threadIdx.x;
-            pr[t] = s < hi ? records[s] : u32x2{0xffffffffu, 0xffffffffu};
-        }
-#pragma unroll
-        for (int t = 0; t < kListTile; t++) at[t] = pr[t].y < a.hot_vertex ? atomicAdd(&bins[pr[t].y], (uint32_t)(k + 1)) : 0;
+    // B: scatter
+    for (int s = lo + threadIdx.x; s < hi; s += kListThreads) {
+        const u32x2 pr = records[s];
+        const bool hot_head = pr.y < a.hot_vertex;
+        uint32_t at = hot_head ? atomicAdd(&bins[pr.y], (uint32_t)(k + 1)) : 0;
         for (int j = 0; j < k; j++) {
-            Draw d[kListTile];
-            NegEntry e[kListTile];
-#pragma unroll
-            for (int t = 0; t < kListTile; t++) {
-                const int s = base + t * kListThreads + (int)threadIdx.x;
-                d[t] = negative_slot(a, (uint32_t)(s < hi ? s : lo), (uint32_t)j);
-                e[t] = load_entry(a, d[t]);
-            }
-#pragma unroll
-            for (int t = 0; t < kListTile; t++) {
-                if (base + t * kListThreads + (int)threadIdx.x >= hi) continue;
-                const uint32_t n = resolve(a, d[t], e[t]);
-                if (pr[t].y < a.hot_vertex) entries[at[t] + j] = n;
-                if (n < a.hot_context) entries[atomicAdd(&bins[a.hot_vertex + n], 1u)] = pr[t].y;
-            }
+            const Draw d = negative_slot(a, (uint32_t)s, (uint32_t)j);
+            const uint32_t n = resolve(a, d, load_entry(a, d));
+            if (hot_head) entries[at + j] = n;
+            if (n < a.hot_context) entries[atomicAdd(&bins[a.hot_vertex + n], 1u)] = pr.y;
         }
-#pragma unroll
-        for (int t = 0; t < kListTile; t++) {
-            if (pr[t].y < a.hot_vertex) entries[at[t] + k] = pr[t].x | 0x80000000u;
-            if (pr[t].x < a.hot_context) entries[atomicAdd(&bins[a.hot_vertex + pr[t].x], 1u)] = pr[t].y | 0x80000000u;
-        }
+        if (hot_head) entries[at + k] = pr.x | 0x80000000u;
+        if (pr.x < a.hot_context) entries[atomicAdd(&bins[a.hot_vertex + pr.x], 1u)] = pr.y | 0x80000000u;
     }
     __syncthreads();
     // C: the short chains' entries into their records (written by this workgroup above: its own stores are visible to it
