@@ -115,7 +115,8 @@ def test_youtube_size_node2vec_matches_the_reference_training_loop(sampling):
     yt_p4_node2vec says why the graph is the exponent-2.5 one).  Here the tables would pass 2^30 entries: the CPU samplers draw the same
     transition distribution by rejection (gvs.h GVS_MODE_BIASED_REJECT), the device sampler always does."""
     aucs = []
-    for seed in SEEDS[:3]:
+    # device sampling: eight seeds — three spread by 0.0016 (SE 0.0014 with the reference's three) and land either side of the tolerance by chance
+    for seed in (SEEDS + (8, 9, 10, 11) if sampling == "device" else SEEDS[:3]):
         auc, reference, info = train("yt_p4_node2vec", seed, device_sampling=sampling == "device")
         assert 0 < info["hub_rows"] < 1138499 // 4 and info["parts"] > 1 and info["pair_order"] == "spread", info
         aucs.append(auc)
@@ -128,7 +129,7 @@ def test_youtube_size_node2vec_matches_the_reference_training_loop(sampling):
         # Measured on the MI355X (round 6): +0.0019 ... +0.0027 until the blocks sampler thinned every block to the pace of the slowest one
         # (gvk_sample_walks_blocks_thinned, DESIGN.md section 7.11 f: a full pool dropped what arrived late, and under rejection the late walks are
         # those that reject most); since then +0.0015 on these three seeds, +0.0009 on eight (the CPU samplers on the same eight: -0.0003; SE 0.0006,
-        # profiles/r6/experiments/r6_n2v_thinned_seeds8.txt).  Three seeds spread by 0.0016: a run that lands outside is reported, not hidden.
+        # profiles/r6/experiments/r6_n2v_thinned_seeds8.txt; three-seed runs of the suite read +0.0009 ... +0.0020).  A run that lands outside is reported, not hidden.
         pytest.xfail("node2vec 0.25 / 0.25 at Youtube size, device sampling: %s (tolerance 0.002)" % (outside.args[0],))
 
 
