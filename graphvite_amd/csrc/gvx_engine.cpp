@@ -810,6 +810,10 @@ int gvx_solver::configure(const gvx_train_config &in) {
     model = m;
     config = c;
     config.model = model.c_str();
+    for (Worker &w : workers) {  // lists built ahead for a visit of the training before this one (a session closed early): its pools are refilled
+        discard_prefetched(w);
+        w.staged.valid = false;
+    }
     make_info();
     if (first_rank == 0)
         log_message(1, "\n<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<<\n%s\n>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>>", info_text.c_str());

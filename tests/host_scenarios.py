@@ -404,6 +404,21 @@ def lists_prefetch():
                 assert b.lists_prefetched == (3 if knob == "1" else 0), b.lists_prefetched  # the whole visits that follow a whole visit
             tables.setdefault(walk, (b.vertex_embeddings.copy(), b.context_embeddings.copy()))
             assert (tables[walk][0] == b.vertex_embeddings).all() and (tables[walk][1] == b.context_embeddings).all(), (walk, knob)
+    # a session closed while lists built ahead are outstanding, then train(resume): the next training refills the pools those lists were built from
+    for knob in ("0", "1"):
+        os.environ["GVX_LISTS_PREFETCH"] = knob
+        b = gv.solver.GraphSolver(32, num_sampler_per_worker=1, seed=4, hub_rows=60)
+        b.build(g, batch_size=1000, episode_size=4, num_partition=2)
+        session = b.session(resident_pools=True, log_frequency=1 << 30, **kw)
+        session.fill(0)
+        session.stage(0, 0, 0)
+        session.stage(1, 0, 1)
+        session.train(0, 0, 0, 0, 4)
+        session.exchange(0)
+        session.close()
+        b.train(resume=True, log_frequency=1 << 30, **kw)
+        tables.setdefault("resumed", (b.vertex_embeddings.copy(), b.context_embeddings.copy()))
+        assert (tables["resumed"][0] == b.vertex_embeddings).all() and (tables["resumed"][1] == b.context_embeddings).all(), knob
     del os.environ["GVX_LISTS_PREFETCH"]
 
 
